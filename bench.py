@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py — point-cloud pairs/sec of DV-Matcher's correspondence hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): synthetic random pairs, N = M = 2048 points, d = 128,
+"correspondence + deform forward only": for every pair and both directions
+  graph(verts) -> soft correspondence (top-10) -> Pi@verts -> xyz kNN -> Deformer -> ED warp +
+  ARAP -> 2x Chamfer (+ map term),
+i.e. GraphDeformLoss_Neural.deform() x2 without the dumps (reference models/loss.py:1401-1411).
+A "step" is one pass over a resident batch of `--pairs` pairs per GPU; inputs are in HBM before
+the timed region.  One process per GPU; pairs shard across ranks with no data-path collective
+(weak scaling: per-GPU work is fixed).
+
+  python bench.py [--gpus N --steps K --warmup W --pairs P]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fp32-MFMA soft
+correspondence kernel), its launch time measured with HIP events on the launch stream inside
+the timed region; `cpu_baseline` is the C oracle ("port") timed on the host cores over a
+bounded sample of the same workload.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "dv-matcher_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+N_PTS, M_PTS, DIM, ALPHA = 2048, 2048, 128, 100.0
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def make_batch(P, seed, device):
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    f1 = torch.randn(P, N_PTS, DIM, generator=g)
+    f2 = torch.randn(P, M_PTS, DIM, generator=g)
+    v1 = torch.rand(P, N_PTS, 3, generator=g)
+    v2 = torch.rand(P, M_PTS, 3, generator=g)
+    s1 = torch.zeros(P, dtype=torch.int32)  # FPS start index 0 (explicit; the reference draws it at random)
+    s2 = torch.zeros(P, dtype=torch.int32)
+    return [t.to(device) for t in (f1, f2, v1, v2, s1, s2)]
+
+
+def load_weights():
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", "deformer_scape_r_weights.npz")
+    return dict(np.load(path))  # the reference's shipped Deformer checkpoint (ckpt/dvmatcher_scape_r), as data
+
+
+def cpu_baseline(sample_pairs):
+    """The oracle (a C port of the reference's algorithm, OpenMP) on `sample_pairs` pairs, both directions."""
+    import numpy as np
+    import torch
+    from oracle import oracle as O
+    O.lib()
+    w = load_weights()
+    f1, f2, v1, v2, s1, s2 = [t.numpy() for t in make_batch(sample_pairs, 4242, "cpu")]
+    O.pair_direction(w, f1[0][:256], f2[0][:256], v1[0][:256], v2[0][:256], ALPHA, 0)  # warm the thread pool
+    t0 = time.perf_counter()
+    for p in range(sample_pairs):
+        O.pair_direction(w, f1[p], f2[p], v1[p], v2[p], ALPHA, int(s1[p]))
+        O.pair_direction(w, f2[p], f1[p], v2[p], v1[p], ALPHA, int(s2[p]))
+    dt = time.perf_counter() - t0
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    omp = int(os.environ.get("OMP_NUM_THREADS", cores))
+    return {"value": sample_pairs / dt, "unit": "pairs/s", "cores": min(cores, omp), "kind": "port",
+            "sample": "%d pairs, N=M=%d, d=%d, both directions, C oracle with OpenMP (%.1f s)" % (sample_pairs, N_PTS, DIM, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=64, help="pairs per GPU per step (resident batch)")
+    ap.add_argument("--cpu-sample", type=int, default=3, help="pairs timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--traffic-bytes", type=float, default=None, help="per-launch HBM bytes from the PMC passes (profiles/)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from dvm import _lib, ops
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    lib = _lib.load()
+
+    P = args.pairs
+    wl = ops.deformer_weight_list(load_weights(), dev)
+    f1, f2, v1, v2, s1, s2 = make_batch(P, 1000 + rank, dev)  # every rank has its own shard of pairs
+    out12 = out21 = None
+
+    def step():
+        nonlocal out12, out21
+        out12 = ops.pair_direction(wl, f1, f2, v1, v2, ALPHA, s1, with_map=True, out=out12)
+        out21 = ops.pair_direction(wl, f2, f1, v2, v1, ALPHA, s2, with_map=True, out=out21)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.check(lib.dvm_profile_enable(2 * args.steps + 4), "dvm_profile_enable")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms, nl = ctypes.c_double(), ctypes.c_int()
+    ops.check(lib.dvm_profile_read(ctypes.byref(ms), ctypes.byref(nl)), "dvm_profile_read")
+    lib.dvm_profile_disable()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # sanity: finite outputs (a bench number over garbage is worthless)
+    assert torch.isfinite(out12["losses"]).all() and torch.isfinite(out21["warped"]).all()
+
+    if rank == 0:
+        pairs_total = P * args.steps * world
+        value = pairs_total / dt
+        # roofline of the dominant kernel: algorithmic flops of one launch = P pairs x (2*N*M*d)/2
+        # (SURVEY §8d counts 2*N*M*d per PAIR with the distance tile shared by both directions; one
+        # launch covers one direction of P pairs)
+        k1_ms = ms.value / max(nl.value, 1)
+        flops_launch = P * (2.0 * N_PTS * M_PTS * DIM) / 2.0
+        achieved = flops_launch / (k1_ms * 1e-3) / 1e12 if k1_ms > 0 else 0.0
+        res = {
+            "metric": "point-cloud pairs/sec (N=2048, d=128)", "value": value, "unit": "pairs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: synthetic random pairs N=M=2048 d=128, correspondence+deform "
+                                   "forward, both directions", "pairs_per_gpu_per_step": P, "alpha": ALPHA,
+                       "deformer_weights": "reference ckpt/dvmatcher_scape_r (fixture)", "fps_start": 0,
+                       "parallelism": "pairs sharded over %d GPU(s), no collective" % world},
+            "roofline": {"bound": "mfma", "kernel": "softcorr_mfma_kernel<10>", "achieved": achieved,
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                         "traffic": args.traffic_bytes, "launch_ms": k1_ms, "launches_timed": nl.value,
+                         "flops_per_launch": flops_launch,
+                         "share_of_step": (ms.value * 1e-3) / dt if dt > 0 else None},
+        }
+        if world == 1 and args.cpu_sample > 0:
+            res["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

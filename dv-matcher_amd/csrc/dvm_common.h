@@ -1,0 +1,226 @@
+// dvm_common.h — shared host/device helpers for libdvm_hip.so (gfx950 only).
+// Built with -ffp-contract=off: every fused multiply-add in this library is an explicit
+// fmaf()/MFMA, every separate mul/add stays separate, because integer outputs (arg-min maps,
+// top-k columns, kNN / FPS indices) are required to be bit-exact with the oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/dvm.h"
+
+#define DVM_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace dvm {
+
+void set_error(const char *fmt, ...);
+void prof_begin(hipStream_t s);  // dvm_api.cpp: optional event bracket around K1 launches
+void prof_end(hipStream_t s);
+
+#define DVM_REQUIRE(cond, ...)            \
+    do {                                  \
+        if (!(cond)) {                    \
+            dvm::set_error(__VA_ARGS__);  \
+            return DVM_EINVAL;            \
+        }                                 \
+    } while (0)
+
+#define DVM_CHECK_LAUNCH(name)                                                          \
+    do {                                                                                \
+        hipError_t e_ = hipGetLastError();                                              \
+        if (e_ != hipSuccess) {                                                         \
+            dvm::set_error("%s: launch failed: %s", name, hipGetErrorString(e_));       \
+            return DVM_ELAUNCH;                                                         \
+        }                                                                               \
+    } while (0)
+
+static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// bump allocator over a caller-provided workspace
+struct Arena {
+    char *base;
+    size_t cap, off;
+    Arena(void *p, size_t n) : base((char *)p), cap(n), off(0) {}
+    template <typename T>
+    T *take(size_t count) {
+        size_t bytes = align_up(count * sizeof(T));
+        char *p = base ? base + off : nullptr;
+        off += bytes;
+        return (T *)p;
+    }
+    bool ok() const { return base != nullptr && off <= cap; }
+};
+
+constexpr int WAVE = 64;
+
+// ---------------------------------------------------------------- device helpers
+// Sorted "k best" list in registers: keys ascending, ties keep the earlier (lower-index)
+// entry first provided candidates arrive in ascending index order.
+template <int K, typename KeyT>
+struct KBest {
+    KeyT key[K];
+    int idx[K];
+    __device__ __forceinline__ void init(KeyT inf) {
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+            key[t] = inf;
+            idx[t] = 0x7fffffff;
+        }
+    }
+    __device__ __forceinline__ KeyT worst() const { return key[K - 1]; }
+    // insert (v, j) assuming v < key[K-1] was already tested by the caller (or test here)
+    __device__ __forceinline__ void insert(KeyT v, int j) {
+        if (!(v < key[K - 1])) return;
+        key[K - 1] = v;
+        idx[K - 1] = j;
+#pragma unroll
+        for (int p = K - 1; p > 0; --p) {
+            bool sw = key[p] < key[p - 1];
+            KeyT a = key[p - 1], b = key[p];
+            int ia = idx[p - 1], ib = idx[p];
+            key[p - 1] = sw ? b : a;
+            key[p] = sw ? a : b;
+            idx[p - 1] = sw ? ib : ia;
+            idx[p] = sw ? ia : ib;
+        }
+    }
+    // insert honouring (key, idx) lexicographic order for candidates arriving in any order
+    __device__ __forceinline__ void insert_lex(KeyT v, int j) {
+        bool better = (v < key[K - 1]) || (v == key[K - 1] && j < idx[K - 1]);
+        if (!better) return;
+        key[K - 1] = v;
+        idx[K - 1] = j;
+#pragma unroll
+        for (int p = K - 1; p > 0; --p) {
+            bool sw = (key[p] < key[p - 1]) || (key[p] == key[p - 1] && idx[p] < idx[p - 1]);
+            KeyT a = key[p - 1], b = key[p];
+            int ia = idx[p - 1], ib = idx[p];
+            key[p - 1] = sw ? b : a;
+            key[p] = sw ? a : b;
+            idx[p - 1] = sw ? ib : ia;
+            idx[p] = sw ? ia : ib;
+        }
+    }
+};
+
+// ATen cascade sum of squares of one contiguous row (see oracle/dvm_oracle.c dvo_aten_sum):
+// 8-lane vectors, 4-way ILP, cascade levels of 16 vectors, lanes added last.
+__device__ inline float aten_sumsq_row(const float *__restrict__ x, int K) {
+    if (K < 8) {
+        // scalar path: row viewed as (-1,4)
+        float p[4] = {0.f, 0.f, 0.f, 0.f};
+        int si = K / 4;
+        for (int i = 0; i < si; ++i)
+            for (int k = 0; k < 4; ++k) {
+                float v = x[i * 4 + k];
+                p[k] = p[k] + v * v;
+            }
+        for (int i = si * 4; i < K; ++i) {
+            float v = x[i];
+            p[0] = p[0] + v * v;
+        }
+        for (int k = 1; k < 4; ++k) p[0] = p[0] + p[k];
+        return p[0];
+    }
+    const int V = 8;
+    int vec_size = K / V, size_ilp = vec_size / 4;
+    int cl = 0;
+    while ((1 << cl) < size_ilp) cl++;
+    int level_power = cl / 4;
+    if (level_power < 4) level_power = 4;
+    int level_step = 1 << level_power, level_mask = level_step - 1;
+    float fin_lane[8];
+#pragma unroll
+    for (int l = 0; l < 8; ++l) fin_lane[l] = 0.f;
+    // process lane by lane to keep register use small: each lane's sum is independent
+    for (int l = 0; l < V; ++l) {
+        float acc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+        int i = 0;
+        for (; i + level_step <= size_ilp;) {
+            for (int j = 0; j < level_step; ++j, ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float v = x[(i * 4 + k) * V + l];
+                    acc[0][k] = acc[0][k] + v * v;
+                }
+#pragma unroll
+            for (int j = 1; j < 4; ++j) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    acc[j][k] = acc[j][k] + acc[j - 1][k];
+                    acc[j - 1][k] = 0.f;
+                }
+                int mask = level_mask << (j * level_power);
+                if ((i & mask) != 0) break;
+            }
+        }
+        for (; i < size_ilp; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float v = x[(i * 4 + k) * V + l];
+                acc[0][k] = acc[0][k] + v * v;
+            }
+#pragma unroll
+        for (int j = 1; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[0][k] = acc[0][k] + acc[j][k];
+        for (int ii = size_ilp * 4; ii < vec_size; ++ii) {
+            float v = x[ii * V + l];
+            acc[0][0] = acc[0][0] + v * v;
+        }
+#pragma unroll
+        for (int k = 1; k < 4; ++k) acc[0][0] = acc[0][0] + acc[0][k];
+        fin_lane[l] = acc[0][0];
+    }
+    float fin = 0.f;
+    for (int k = vec_size * V; k < K; ++k) {
+        float v = x[k];
+        fin = fin + v * v;
+    }
+#pragma unroll
+    for (int l = 0; l < V; ++l) fin = fin + fin_lane[l];
+    return fin;
+}
+
+// |x|^2 of a 3-vector in ATen order: ((0 + x0^2) + x1^2) + x2^2
+__device__ __forceinline__ float sumsq3(float x, float y, float z) {
+    float a = x * x, b = y * y, c = z * z;
+    return (a + b) + c;
+}
+
+// squared distance of 3-vectors, matmul form (torch.cdist default for >25 rows):
+// fma chain over [-2a,|a|^2,1].[b,1,|b|^2], clamp at 0.  `a` is the ROW operand.
+__device__ __forceinline__ float d2_mm3(float ax, float ay, float az, float na, float bx, float by, float bz,
+                                        float nb) {
+    float acc = fmaf(-2.f * ax, bx, 0.f);
+    acc = fmaf(-2.f * ay, by, acc);
+    acc = fmaf(-2.f * az, bz, acc);
+    acc = acc + na;
+    acc = acc + nb;
+    return acc > 0.f ? acc : 0.f;
+}
+
+// squared distance of 3-vectors, difference form, no contraction: (dx^2 + dy^2) + dz^2
+__device__ __forceinline__ float d2_diff3(float ax, float ay, float az, float bx, float by, float bz) {
+    float dx = ax - bx, dy = ay - by, dz = az - bz;
+    float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    return (xx + yy) + zz;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace dvm

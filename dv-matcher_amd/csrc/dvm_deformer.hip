@@ -1,0 +1,339 @@
+// dvm_deformer.hip — Deformer.forward on the GPU without the (B,N,k,128) gathers and without the
+// dense Pi.   Reference: models/model.py:464-478 (Deformer), 433-452 (MLP); the caller-side
+// gathers it replaces are models/loss.py:1254-1257.
+//
+//   pool   g[i,:]  = sum_s conv_w[s] * feat[idx[i,s],:] + conv_b        (Conv2d k->1, 1x1)
+//   xfer   g2'[v,:] = sum_t P[v,t] * g2[pidx[v,t],:]                    (Pi~ @ g2, sparse)
+//   z[n]   = [verts1_v, g1_v, verts12_v, g2'_v],  v = fps1[n]           (262 floats)
+//   MLP    262 -> 512 -> 256 -> 128 -> 9, ELU between layers.
+//
+// The MLP is 0.6 GFLOP per direction at N = 2048 — the second largest contraction of the path —
+// and runs on the fp32 matrix cores: 32 nodes per workgroup, activations resident in LDS
+// (k-deinterleaved so an MFMA A-fragment is one ds_read_b128 per 4 k-steps), weights pre-packed
+// into the MFMA B-fragment order so each k-step is one coalesced 256-B load per wave.  The
+// accumulation is the same k-ordered fma chain as the oracle's (and torch's CPU addmm).
+#include "dvm_common.h"
+
+namespace dvm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int DF_C = 128;
+
+// pooled[r,:] = sum_s w[s]*feat[idx[row(r),s],:] + bias ; row(r) = rowmap ? rowmap[r] : r
+__global__ __launch_bounds__(256) void pool_kernel(const float *__restrict__ feat, const int32_t *__restrict__ idx,
+                                                   const int32_t *__restrict__ rowmap, int P, int nrows, int k,
+                                                   const float *__restrict__ cw, const float *__restrict__ cb,
+                                                   float *__restrict__ out, int out_stride, int out_off) {
+    const int b = blockIdx.y;
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (long)nrows * (DF_C / 4)) return;
+    const int r = (int)(g / (DF_C / 4)), c4 = (int)(g % (DF_C / 4));
+    const int v = rowmap ? rowmap[(size_t)b * nrows + r] : r;
+    const float *fb = feat + (size_t)b * P * DF_C;
+    const int32_t *ix = idx + ((size_t)b * P + v) * k;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < k; ++s) {
+        f32x4 f = *(const f32x4 *)(fb + (size_t)ix[s] * DF_C + 4 * c4);
+        float w = cw[s];
+        acc.x = fmaf(w, f.x, acc.x);
+        acc.y = fmaf(w, f.y, acc.y);
+        acc.z = fmaf(w, f.z, acc.z);
+        acc.w = fmaf(w, f.w, acc.w);
+    }
+    const float bias = cb[0];
+    float *o = out + ((size_t)b * nrows + r) * out_stride + out_off + 4 * c4;
+    o[0] = acc.x + bias, o[1] = acc.y + bias, o[2] = acc.z + bias, o[3] = acc.w + bias;
+}
+
+// z[n, 0:3] = verts1[v]; z[n,131:134] = verts12[v]; z[n,134:262] = sum_t P[v,t] g2[pidx[v,t],:]
+// (ascending column order); z[n,262:ZS] = 0.
+constexpr int DF_IN = 262;
+constexpr int DF_ZS = 264;  // z row stride (padded to a multiple of 4)
+
+template <int TOPK>
+__global__ __launch_bounds__(256) void assemble_kernel(const float *__restrict__ verts1, const float *__restrict__ verts12,
+                                                       const float *__restrict__ g2, const float *__restrict__ pi_val,
+                                                       const int32_t *__restrict__ pi_idx, const int32_t *__restrict__ fps1,
+                                                       int N, int M, int Nn, int topk, float *__restrict__ z) {
+    const int b = blockIdx.y;
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (long)Nn * (DF_C / 4)) return;
+    const int n = (int)(g / (DF_C / 4)), c4 = (int)(g % (DF_C / 4));
+    const int v = fps1[(size_t)b * Nn + n];
+    const size_t row = (size_t)b * N + v;
+    float pv[TOPK];
+    int pc[TOPK];
+#pragma unroll
+    for (int t = 0; t < TOPK; ++t) {
+        bool live = t < topk;
+        pv[t] = live ? pi_val[row * topk + t] : 0.f;
+        pc[t] = live ? pi_idx[row * topk + t] : 0x7fffffff;
+    }
+    // insertion sort by column
+#pragma unroll
+    for (int a = 1; a < TOPK; ++a) {
+#pragma unroll
+        for (int p = a; p > 0; --p) {
+            bool sw = pc[p] < pc[p - 1];
+            int c0 = pc[p - 1], c1 = pc[p];
+            float v0 = pv[p - 1], v1 = pv[p];
+            pc[p - 1] = sw ? c1 : c0;
+            pc[p] = sw ? c0 : c1;
+            pv[p - 1] = sw ? v1 : v0;
+            pv[p] = sw ? v0 : v1;
+        }
+    }
+    const float *g2b = g2 + (size_t)b * M * DF_C;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < TOPK; ++t) {
+        if (t < topk) {
+            f32x4 f = *(const f32x4 *)(g2b + (size_t)pc[t] * DF_C + 4 * c4);
+            acc.x = fmaf(pv[t], f.x, acc.x);
+            acc.y = fmaf(pv[t], f.y, acc.y);
+            acc.z = fmaf(pv[t], f.z, acc.z);
+            acc.w = fmaf(pv[t], f.w, acc.w);
+        }
+    }
+    float *zr = z + ((size_t)b * Nn + n) * DF_ZS;
+    zr[134 + 4 * c4] = acc.x, zr[135 + 4 * c4] = acc.y, zr[136 + 4 * c4] = acc.z, zr[137 + 4 * c4] = acc.w;
+    if (c4 == 0) {
+        for (int c = 0; c < 3; ++c) {
+            zr[c] = verts1[row * 3 + c];
+            zr[131 + c] = verts12[row * 3 + c];
+        }
+        zr[262] = 0.f, zr[263] = 0.f;
+    }
+}
+
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+
+// ---------------------------------------------------------------- scalar MLP layer (check variant)
+__global__ void mlp_layer_scalar_kernel(const float *__restrict__ in, int in_stride, const float *__restrict__ W,
+                                        const float *__restrict__ bias, int rows, int I, int O, int act,
+                                        float *__restrict__ out, int out_stride) {
+    long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (long)rows * O) return;
+    int r = (int)(g / O), o = (int)(g % O);
+    const float *x = in + (size_t)r * in_stride, *w = W + (size_t)o * I;
+    float acc = 0.f;
+    for (int c = 0; c < I; ++c) acc = fmaf(x[c], w[c], acc);
+    acc = acc + bias[o];
+    out[(size_t)r * out_stride + o] = act ? elu1(acc) : acc;
+}
+
+// ---------------------------------------------------------------- MFMA MLP
+// Packed weights: Wp[otile][step][lane] = W[otile*32 + (lane&31)][2*step + (lane>>5)] (0 outside).
+__global__ void pack_weights_kernel(const float *__restrict__ W, int O, int I, int otiles, int steps, float *__restrict__ Wp) {
+    long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)otiles * steps * 64;
+    if (g >= total) return;
+    int lane = (int)(g % 64);
+    int step = (int)((g / 64) % steps);
+    int ot = (int)(g / (64L * steps));
+    int o = ot * 32 + (lane & 31), c = 2 * step + (lane >> 5);
+    Wp[g] = (o < O && c < I) ? W[(size_t)o * I + c] : 0.f;
+}
+
+constexpr int ML_NODES = 32;
+constexpr int ML_WAVES = 8;
+constexpr int ML_THREADS = 64 * ML_WAVES;
+// activation buffers, k-deinterleaved: element (node, c) at node*stride + (c&1)*half + (c>>1)
+constexpr int ML_SA = 268;  // holds z (264 -> halves of 132) and h1 (256 -> halves of 128)
+constexpr int ML_SB = 516;  // holds h0 (512 -> halves of 256) and h2 (128 -> halves of 64)
+constexpr size_t ML_LDS_BYTES = (size_t)ML_NODES * (ML_SA + ML_SB) * sizeof(float);
+
+// one 32x32 output tile: acc[node][out] = sum_k act[node][k] * W[out][k], K = 2*steps (steps % 4 == 0)
+__device__ __forceinline__ f32x16 mlp_tile(const float *__restrict__ act_row /* lane's node row + h*half */,
+                                           const float *__restrict__ wp /* + lane */, int steps) {
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < steps; s += 4) {
+        f32x4 a = *(const f32x4 *)(act_row + s);
+        float b0 = wp[(size_t)(s + 0) * 64], b1 = wp[(size_t)(s + 1) * 64], b2 = wp[(size_t)(s + 2) * 64],
+              b3 = wp[(size_t)(s + 3) * 64];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b3, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// write a finished tile (bias + optional ELU) into the next activation buffer
+__device__ __forceinline__ void mlp_store(const f32x16 &acc, const float *__restrict__ bias, int o, int O, bool act,
+                                          float *__restrict__ dst, int stride, int half, int h) {
+    const float bv = o < O ? bias[o] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int node = (r & 3) + 8 * (r >> 2) + 4 * h;
+        float v = acc[r] + bv;
+        v = act ? elu1(v) : v;
+        if (o < O) dst[node * stride + (o & 1) * half + (o >> 1)] = v;
+    }
+}
+
+__global__ __launch_bounds__(ML_THREADS) void mlp_mfma_kernel(const float *__restrict__ z, int rows,
+                                                              const float *__restrict__ Wp0, const float *__restrict__ b0,
+                                                              const float *__restrict__ Wp1, const float *__restrict__ b1,
+                                                              const float *__restrict__ Wp2, const float *__restrict__ b2,
+                                                              const float *__restrict__ Wp3, const float *__restrict__ b3,
+                                                              float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *bufA = smem;                      // [32][ML_SA]
+    float *bufB = smem + ML_NODES * ML_SA;   // [32][ML_SB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r32 = lane & 31, h = lane >> 5;
+    const int row0 = blockIdx.x * ML_NODES;
+
+    // stage z (de-interleave k): 32 rows x 264 floats
+    for (int e = tid; e < ML_NODES * (DF_ZS / 4); e += ML_THREADS) {
+        int r = e / (DF_ZS / 4), c = e % (DF_ZS / 4);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row0 + r < rows) v = *(const f32x4 *)(z + (size_t)(row0 + r) * DF_ZS + 4 * c);
+        float2 ev = {v.x, v.z}, od = {v.y, v.w};
+        *(float2 *)(bufA + r * ML_SA + 2 * c) = ev;
+        *(float2 *)(bufA + r * ML_SA + 132 + 2 * c) = od;
+    }
+    __syncthreads();
+    // layer 0: 264(262) -> 512 : 16 output tiles, 2 per wave; steps = 132
+    for (int q = 0; q < 2; ++q) {
+        int ot = wave * 2 + q;
+        f32x16 acc = mlp_tile(bufA + r32 * ML_SA + h * 132, Wp0 + (size_t)ot * 132 * 64 + lane, 132);
+        mlp_store(acc, b0, ot * 32 + r32, 512, true, bufB, ML_SB, 256, h);
+    }
+    __syncthreads();
+    // layer 1: 512 -> 256 : 8 tiles, 1 per wave; steps = 256
+    {
+        int ot = wave;
+        f32x16 acc = mlp_tile(bufB + r32 * ML_SB + h * 256, Wp1 + (size_t)ot * 256 * 64 + lane, 256);
+        mlp_store(acc, b1, ot * 32 + r32, 256, true, bufA, ML_SA, 128, h);
+    }
+    __syncthreads();
+    // layer 2: 256 -> 128 : 4 tiles; steps = 128
+    if (wave < 4) {
+        int ot = wave;
+        f32x16 acc = mlp_tile(bufA + r32 * ML_SA + h * 128, Wp2 + (size_t)ot * 128 * 64 + lane, 128);
+        mlp_store(acc, b2, ot * 32 + r32, 128, true, bufB, ML_SB, 64, h);
+    }
+    __syncthreads();
+    // layer 3: 128 -> 9 : one tile; steps = 64; straight to HBM
+    if (wave == 0) {
+        f32x16 acc = mlp_tile(bufB + r32 * ML_SB + h * 64, Wp3 + lane, 64);
+        const int o = r32;
+        const float bv = o < 9 ? b3[o] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int node = (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (o < 9 && row0 + node < rows) out[(size_t)(row0 + node) * 9 + o] = acc[r] + bv;
+        }
+    }
+}
+
+struct DeformerWs {
+    float *g2, *z, *Wp0, *Wp1, *Wp2, *Wp3, *h0, *h1, *h2;
+};
+
+static size_t carve(Arena &ar, int B, int M, int Nn, DeformerWs &w) {
+    w.g2 = ar.take<float>((size_t)B * M * DF_C);
+    w.z = ar.take<float>((size_t)B * Nn * DF_ZS);
+    w.Wp0 = ar.take<float>((size_t)16 * 132 * 64);
+    w.Wp1 = ar.take<float>((size_t)8 * 256 * 64);
+    w.Wp2 = ar.take<float>((size_t)4 * 128 * 64);
+    w.Wp3 = ar.take<float>((size_t)1 * 64 * 64);
+    w.h0 = ar.take<float>((size_t)B * Nn * 512);
+    w.h1 = ar.take<float>((size_t)B * Nn * 256);
+    w.h2 = ar.take<float>((size_t)B * Nn * 128);
+    return ar.off;
+}
+
+int launch_deformer(const float *feat1, const float *feat2, const float *verts1, const float *verts12, const int32_t *idx11,
+                    const int32_t *idx22, const float *pi_val, const int32_t *pi_idx, const int32_t *fps1, int B, int N,
+                    int M, int Nn, int k, int topk, const float *conv_w, const float *conv_b, const float *W0,
+                    const float *b0, const float *W1, const float *b1, const float *W2, const float *b2, const float *W3,
+                    const float *b3, float *out, int variant, void *ws, size_t ws_bytes, hipStream_t s) {
+    Arena ar(ws, ws_bytes);
+    DeformerWs w;
+    carve(ar, B, M, Nn, w);
+    if (!ar.ok()) {
+        set_error("dvm_deformer_fwd_f32: workspace too small (%zu < %zu)", ws_bytes, ar.off);
+        return DVM_ENOSPACE;
+    }
+    const int rows = B * Nn;
+    // g2 for every target point; g1 only at the graph nodes (written straight into z[:,3:131])
+    hipLaunchKernelGGL(pool_kernel, dim3((unsigned)(((long)M * 32 + 255) / 256), B), dim3(256), 0, s, feat2, idx22,
+                       (const int32_t *)nullptr, M, M, k, conv_w, conv_b, w.g2, DF_C, 0);
+    hipLaunchKernelGGL(pool_kernel, dim3((unsigned)(((long)Nn * 32 + 255) / 256), B), dim3(256), 0, s, feat1, idx11, fps1, N,
+                       Nn, k, conv_w, conv_b, w.z, DF_ZS, 3);
+    if (topk <= 10)
+        hipLaunchKernelGGL(assemble_kernel<10>, dim3((unsigned)(((long)Nn * 32 + 255) / 256), B), dim3(256), 0, s, verts1,
+                           verts12, w.g2, pi_val, pi_idx, fps1, N, M, Nn, topk, w.z);
+    else
+        hipLaunchKernelGGL(assemble_kernel<16>, dim3((unsigned)(((long)Nn * 32 + 255) / 256), B), dim3(256), 0, s, verts1,
+                           verts12, w.g2, pi_val, pi_idx, fps1, N, M, Nn, topk, w.z);
+    if (variant == 1) {
+        auto layer = [&](const float *in, int is, const float *W, const float *bb, int I, int O, int act, float *o, int os) {
+            long th = (long)rows * O;
+            hipLaunchKernelGGL(mlp_layer_scalar_kernel, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, in, is, W, bb, rows,
+                               I, O, act, o, os);
+        };
+        layer(w.z, DF_ZS, W0, b0, DF_IN, 512, 1, w.h0, 512);
+        layer(w.h0, 512, W1, b1, 512, 256, 1, w.h1, 256);
+        layer(w.h1, 256, W2, b2, 256, 128, 1, w.h2, 128);
+        layer(w.h2, 128, W3, b3, 128, 9, 0, out, 9);
+    } else {
+        auto pack = [&](const float *W, int O, int I, int otiles, int steps, float *Wp) {
+            long th = (long)otiles * steps * 64;
+            hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, W, O, I, otiles, steps,
+                               Wp);
+        };
+        pack(W0, 512, DF_IN, 16, 132, w.Wp0);
+        pack(W1, 256, 512, 8, 256, w.Wp1);
+        pack(W2, 128, 256, 4, 128, w.Wp2);
+        pack(W3, 9, 128, 1, 64, w.Wp3);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void *)mlp_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)ML_LDS_BYTES);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(mlp_mfma_kernel, dim3((rows + ML_NODES - 1) / ML_NODES), dim3(ML_THREADS), ML_LDS_BYTES, s, w.z,
+                           rows, w.Wp0, b0, w.Wp1, b1, w.Wp2, b2, w.Wp3, b3, out);
+    }
+    return DVM_OK;
+}
+
+size_t deformer_ws_bytes(int B, int M, int Nn) {
+    Arena ar(nullptr, 0);
+    DeformerWs w;
+    return carve(ar, B, M, Nn, w);
+}
+
+}  // namespace dvm
+
+using namespace dvm;
+
+DVM_EXPORT size_t dvm_deformer_workspace_bytes(int B, int N, int M, int Nn) {
+    (void)N;
+    return deformer_ws_bytes(B, M, Nn);
+}
+
+DVM_EXPORT int dvm_deformer_fwd_f32(const float *feat1, const float *feat2, const float *verts1, const float *verts12,
+                                    const int32_t *idx11, const int32_t *idx22, const float *pi_val, const int32_t *pi_idx,
+                                    const int32_t *fps1, int B, int N, int M, int Nn, int k, int topk, const float *conv_w,
+                                    const float *conv_b, const float *W0, const float *b0, const float *W1, const float *b1,
+                                    const float *W2, const float *b2, const float *W3, const float *b3, float *out,
+                                    int variant, void *ws, size_t ws_bytes, void *stream) {
+    DVM_REQUIRE(feat1 && feat2 && verts1 && verts12 && idx11 && idx22 && pi_val && pi_idx && fps1 && out,
+                "dvm_deformer_fwd_f32: null tensor pointer");
+    DVM_REQUIRE(conv_w && conv_b && W0 && b0 && W1 && b1 && W2 && b2 && W3 && b3, "dvm_deformer_fwd_f32: null weight pointer");
+    DVM_REQUIRE(B >= 1 && N >= 1 && M >= 1 && Nn >= 1, "dvm_deformer_fwd_f32: empty input");
+    DVM_REQUIRE(k >= 1 && k <= 64 && topk >= 1 && topk <= 16, "dvm_deformer_fwd_f32: k=%d topk=%d out of range", k, topk);
+    DVM_REQUIRE(variant >= 0 && variant <= 2, "dvm_deformer_fwd_f32: bad variant %d", variant);
+    int rc = launch_deformer(feat1, feat2, verts1, verts12, idx11, idx22, pi_val, pi_idx, fps1, B, N, M, Nn, k, topk, conv_w,
+                             conv_b, W0, b0, W1, b1, W2, b2, W3, b3, out, variant, ws, ws_bytes, (hipStream_t)stream);
+    if (rc != DVM_OK) return rc;
+    DVM_CHECK_LAUNCH("deformer");
+    return DVM_OK;
+}

@@ -1,0 +1,471 @@
+// dvm_geom.hip — small geometric kernels of the correspondence path:
+//   arg-min map in the exact-difference form (knnsearch_t), xyz kNN (knn_grad), sparse Pi~ @ V,
+//   Chamfer nearest neighbours, the map-loss numerator, and fixed-order reductions.
+// All are HBM-light brute-force sweeps with the "other" cloud staged through LDS; every
+// floating-point expression is written in the rounding order of the reference's CPU path
+// (see oracle/dvm_oracle.c) so that the integer outputs are bit-exact.
+#include "dvm_common.h"
+
+namespace dvm {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------- argmin (exact form)
+// knnsearch_t: reference models/loss.py:91-95, test.py:19-23.  agg = agg + (a-b)*(a-b) summed
+// sequentially over the feature index with separately rounded mul and add (d % 4 == 0).
+constexpr int AM_KT = 32, AM_DC = 32;
+
+__global__ __launch_bounds__(128) void argmin_exact_kernel(const float *__restrict__ f1, const float *__restrict__ f2,
+                                                           int N, int M, int d, int32_t *__restrict__ T,
+                                                           float *__restrict__ dmin) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [AM_KT][d]
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ic = i < N ? i : N - 1;
+    const float *q = f1 + ((size_t)b * N + ic) * d;
+    const float *kbase = f2 + (size_t)b * M * d;
+    float best = INFINITY;
+    int bj = 0;
+    for (int j0 = 0; j0 < M; j0 += AM_KT) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < AM_KT * d / 4; e += blockDim.x) {
+            int r = e / (d / 4), c = e % (d / 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (j0 + r < M) v = *(const f32x4 *)(kbase + (size_t)(j0 + r) * d + 4 * c);
+            *(f32x4 *)(smem + r * d + 4 * c) = v;
+        }
+        __syncthreads();
+        float acc[AM_KT];
+#pragma unroll
+        for (int j = 0; j < AM_KT; ++j) acc[j] = 0.f;
+        for (int c0 = 0; c0 < d; c0 += AM_DC) {
+            float qr[AM_DC];
+            int cw = d - c0 < AM_DC ? d - c0 : AM_DC;
+#pragma unroll
+            for (int c = 0; c < AM_DC; c += 4) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (c < cw) v = *(const f32x4 *)(q + c0 + c);
+                qr[c] = v.x, qr[c + 1] = v.y, qr[c + 2] = v.z, qr[c + 3] = v.w;
+            }
+#pragma unroll
+            for (int j = 0; j < AM_KT; ++j) {
+#pragma unroll
+                for (int c = 0; c < AM_DC; c += 4) {
+                    if (c < cw) {
+                        f32x4 kv = *(const f32x4 *)(smem + j * d + c0 + c);
+                        float e0 = qr[c] - kv.x, e1 = qr[c + 1] - kv.y, e2 = qr[c + 2] - kv.z, e3 = qr[c + 3] - kv.w;
+                        float p0 = e0 * e0, p1 = e1 * e1, p2 = e2 * e2, p3 = e3 * e3;
+                        acc[j] = acc[j] + p0;
+                        acc[j] = acc[j] + p1;
+                        acc[j] = acc[j] + p2;
+                        acc[j] = acc[j] + p3;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < AM_KT; ++j) {
+            float dv = __fsqrt_rn(acc[j]);
+            if (j0 + j < M && dv < best) {
+                best = dv;
+                bj = j0 + j;
+            }
+        }
+    }
+    if (i < N) {
+        T[(size_t)b * N + i] = bj;
+        if (dmin) dmin[(size_t)b * N + i] = best;
+    }
+}
+
+// ---------------------------------------------------------------- xyz kNN (knn_grad)
+// k smallest of torch.cdist (matmul form) per row, ascending (distance, index).  C <= 16.
+constexpr int KN_PT = 256;  // points per LDS tile
+
+template <int K>
+__global__ __launch_bounds__(128) void knn_cdist_kernel(const float *__restrict__ x, const float *__restrict__ y, int N,
+                                                        int M, int C, int k, int32_t *__restrict__ idx) {
+    __shared__ float pts[KN_PT * 16];
+    __shared__ float pn[KN_PT];
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ic = i < N ? i : N - 1;
+    float q[16];
+    const float *qp = x + ((size_t)b * N + ic) * C;
+    for (int c = 0; c < 16; ++c) q[c] = c < C ? qp[c] : 0.f;
+    const float nq = aten_sumsq_row(qp, C);
+    for (int c = 0; c < 16; ++c) q[c] = -2.f * q[c];
+    KBest<K, float> kb;
+    kb.init(INFINITY);
+    const float *yb = y + (size_t)b * M * C;
+    for (int j0 = 0; j0 < M; j0 += KN_PT) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < KN_PT; e += blockDim.x) {
+            if (j0 + e < M) {
+                for (int c = 0; c < C; ++c) pts[e * C + c] = yb[(size_t)(j0 + e) * C + c];
+                pn[e] = aten_sumsq_row(yb + (size_t)(j0 + e) * C, C);
+            } else {
+                for (int c = 0; c < C; ++c) pts[e * C + c] = 0.f;
+                pn[e] = INFINITY;
+            }
+        }
+        __syncthreads();
+        int lim = M - j0 < KN_PT ? M - j0 : KN_PT;
+        for (int j = 0; j < lim; ++j) {
+            float acc = 0.f;
+            for (int c = 0; c < C; ++c) acc = fmaf(q[c], pts[j * C + c], acc);
+            acc = acc + nq;
+            acc = acc + pn[j];
+            acc = acc > 0.f ? acc : 0.f;
+            kb.insert(__fsqrt_rn(acc), j0 + j);
+        }
+    }
+    if (i < N)
+        for (int t = 0; t < K; ++t)
+            if (t < k) idx[((size_t)b * N + i) * k + t] = t < M ? kb.idx[t] : 0;
+}
+
+// specialisation for C == 3 (the only shape on the hot path): coordinates in registers
+template <int K>
+__global__ __launch_bounds__(128) void knn_cdist3_kernel(const float *__restrict__ x, const float *__restrict__ y, int N,
+                                                         int M, int k, int32_t *__restrict__ idx) {
+    __shared__ float4 pts[KN_PT];  // x,y,z,|p|^2
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ic = i < N ? i : N - 1;
+    const float *qp = x + ((size_t)b * N + ic) * 3;
+    const float qx = qp[0], qy = qp[1], qz = qp[2];
+    const float nq = sumsq3(qx, qy, qz);
+    KBest<K, float> kb;
+    kb.init(INFINITY);
+    const float *yb = y + (size_t)b * M * 3;
+    for (int j0 = 0; j0 < M; j0 += KN_PT) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < KN_PT; e += blockDim.x) {
+            float4 p = {0.f, 0.f, 0.f, INFINITY};
+            if (j0 + e < M) {
+                const float *pp = yb + (size_t)(j0 + e) * 3;
+                p.x = pp[0], p.y = pp[1], p.z = pp[2];
+                p.w = sumsq3(p.x, p.y, p.z);
+            }
+            pts[e] = p;
+        }
+        __syncthreads();
+        int lim = M - j0 < KN_PT ? M - j0 : KN_PT;
+#pragma unroll 4
+        for (int j = 0; j < lim; ++j) {
+            float4 p = pts[j];
+            float d2 = d2_mm3(qx, qy, qz, nq, p.x, p.y, p.z, p.w);
+            kb.insert(__fsqrt_rn(d2), j0 + j);
+        }
+    }
+    if (i < N)
+        for (int t = 0; t < K; ++t)
+            if (t < k) idx[((size_t)b * N + i) * k + t] = t < M ? kb.idx[t] : 0;
+}
+
+// ---------------------------------------------------------------- sparse Pi~ @ V
+// One thread per (row, 4-channel group); the row's entries are visited in ascending column order
+// (the order in which a dense k-ordered GEMM meets the non-zeros).
+template <int TOPK>
+__device__ __forceinline__ void sort_by_col(float (&v)[TOPK], int (&c)[TOPK]) {
+#pragma unroll
+    for (int a = 1; a < TOPK; ++a) {
+#pragma unroll
+        for (int p = a; p > 0; --p) {
+            bool sw = c[p] < c[p - 1];
+            int c0 = c[p - 1], c1 = c[p];
+            float v0 = v[p - 1], v1 = v[p];
+            c[p - 1] = sw ? c1 : c0;
+            c[p] = sw ? c0 : c1;
+            v[p - 1] = sw ? v1 : v0;
+            v[p] = sw ? v0 : v1;
+        }
+    }
+}
+
+template <int TOPK>
+__global__ __launch_bounds__(256) void apply_kernel(const float *__restrict__ pi_val, const int32_t *__restrict__ pi_idx,
+                                                    const float *__restrict__ V, int N, int M, int topk, int C,
+                                                    float *__restrict__ out) {
+    const int groups = (C + 3) / 4;
+    const int b = blockIdx.y;
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (long)N * groups) return;
+    const int i = (int)(g / groups), cg = (int)(g % groups);
+    const size_t row = (size_t)b * N + i;
+    float v[TOPK];
+    int c[TOPK];
+#pragma unroll
+    for (int t = 0; t < TOPK; ++t) {
+        bool live = t < topk;
+        v[t] = live ? pi_val[row * topk + t] : 0.f;
+        c[t] = live ? pi_idx[row * topk + t] : 0x7fffffff;  // padding sorts last, contributes 0*V[0]
+    }
+    sort_by_col<TOPK>(v, c);
+    const float *Vb = V + (size_t)b * M * C;
+    const int c0 = cg * 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < TOPK; ++t) {
+        if (t < topk) {
+            const float *vr = Vb + (size_t)c[t] * C + c0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c0 + e < C) acc[e] = fmaf(v[t], vr[e], acc[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (c0 + e < C) out[row * C + c0 + e] = acc[e];
+}
+
+// ---------------------------------------------------------------- Chamfer NN
+// d1[i] = min_j |a_i - b_j|^2 ((dx^2+dy^2)+dz^2, no contraction), first minimum wins.
+__global__ __launch_bounds__(128) void chamfer_kernel(const float *__restrict__ a, const float *__restrict__ bpts, int N,
+                                                      int M, float *__restrict__ dout, int32_t *__restrict__ iout) {
+    __shared__ float4 pts[KN_PT];
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ic = i < N ? i : N - 1;
+    const float *qp = a + ((size_t)b * N + ic) * 3;
+    const float qx = qp[0], qy = qp[1], qz = qp[2];
+    float best = INFINITY;
+    int bj = 0;
+    const float *yb = bpts + (size_t)b * M * 3;
+    for (int j0 = 0; j0 < M; j0 += KN_PT) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < KN_PT; e += blockDim.x) {
+            float4 p = {0.f, 0.f, 0.f, 0.f};
+            if (j0 + e < M) {
+                const float *pp = yb + (size_t)(j0 + e) * 3;
+                p.x = pp[0], p.y = pp[1], p.z = pp[2];
+            }
+            pts[e] = p;
+        }
+        __syncthreads();
+        int lim = M - j0 < KN_PT ? M - j0 : KN_PT;
+#pragma unroll 4
+        for (int j = 0; j < lim; ++j) {
+            float4 p = pts[j];
+            float dv = d2_diff3(qx, qy, qz, p.x, p.y, p.z);
+            if (dv < best) {
+                best = dv;
+                bj = j0 + j;
+            }
+        }
+    }
+    if (i < N) {
+        dout[(size_t)b * N + i] = best;
+        if (iout) iout[(size_t)b * N + i] = bj;
+    }
+}
+
+// ---------------------------------------------------------------- map-loss numerator
+// thread per (i, s): e_c = verts12[idx11[i,s],c] - sum_t P[i,t] verts2[idx22[pidx[i,t],s],c]
+template <int TOPK>
+__global__ __launch_bounds__(256) void map_term_kernel(const float *__restrict__ verts12, const float *__restrict__ verts2,
+                                                       const int32_t *__restrict__ idx11, const int32_t *__restrict__ idx22,
+                                                       const float *__restrict__ pi_val, const int32_t *__restrict__ pi_idx,
+                                                       int N, int M, int k, int topk, double *__restrict__ partial) {
+    const int b = blockIdx.y;
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    float e2 = 0.f;
+    if (g < (long)N * k) {
+        const int i = (int)(g / k), s = (int)(g % k);
+        const size_t row = (size_t)b * N + i;
+        float v[TOPK];
+        int c[TOPK];
+#pragma unroll
+        for (int t = 0; t < TOPK; ++t) {
+            bool live = t < topk;
+            v[t] = live ? pi_val[row * topk + t] : 0.f;
+            c[t] = live ? pi_idx[row * topk + t] : 0x7fffffff;
+        }
+        sort_by_col<TOPK>(v, c);
+        const float *v2 = verts2 + (size_t)b * M * 3;
+        const int32_t *i22 = idx22 + (size_t)b * M * k;
+        float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < TOPK; ++t) {
+            if (t < topk) {
+                const float *p = v2 + 3 * (size_t)i22[(size_t)c[t] * k + s];
+                acc[0] = fmaf(v[t], p[0], acc[0]);
+                acc[1] = fmaf(v[t], p[1], acc[1]);
+                acc[2] = fmaf(v[t], p[2], acc[2]);
+            }
+        }
+        const float *p12 = verts12 + ((size_t)b * N + idx11[row * k + s]) * 3;
+        float e0 = p12[0] - acc[0], e1 = p12[1] - acc[1], e2c = p12[2] - acc[2];
+        e2 = (e0 * e0 + e1 * e1) + e2c * e2c;
+    }
+    // block reduction in double, fixed order
+    __shared__ double red[256 / 64];
+    double w = wave_sum((double)e2);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int q = 0; q < (int)(blockDim.x >> 6); ++q) s += red[q];
+        partial[(size_t)b * gridDim.x + blockIdx.x] = s;
+    }
+}
+
+// out[b] = scale * sum_q partial[b,q]   (one block per b, fixed order)
+__global__ void reduce_partials_kernel(const double *__restrict__ partial, int nparts, float scale, float *__restrict__ out,
+                                       int out_stride, int out_off) {
+    const int b = blockIdx.x;
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int q = threadIdx.x; q < nparts; q += blockDim.x) s += partial[(size_t)b * nparts + q];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[(size_t)b * out_stride + out_off] = (float)(red[0] * (double)scale);
+}
+
+// out[b*stride+off] (+)= scale * mean(in[b, 0..n))  — fixed-order double accumulation
+__global__ void mean_kernel(const float *__restrict__ in, int n, float scale, float *__restrict__ out, int out_stride,
+                            int out_off, int accumulate) {
+    const int b = blockIdx.x;
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int q = threadIdx.x; q < n; q += blockDim.x) s += (double)in[(size_t)b * n + q];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float v = (float)(red[0] / (double)n * (double)scale);
+        float *o = out + (size_t)b * out_stride + out_off;
+        *o = accumulate ? *o + v : v;
+    }
+}
+
+}  // namespace dvm
+
+using namespace dvm;
+
+DVM_EXPORT int dvm_argmin_exact_f32(const float *f1, const float *f2, int B, int N, int M, int d, int32_t *T, float *dmin,
+                                    void *stream) {
+    DVM_REQUIRE(f1 && f2 && T, "dvm_argmin_exact_f32: null pointer");
+    DVM_REQUIRE(B >= 1 && N >= 1 && M >= 1, "dvm_argmin_exact_f32: empty input (B=%d N=%d M=%d)", B, N, M);
+    DVM_REQUIRE(d >= 4 && d % 4 == 0 && d <= 512, "dvm_argmin_exact_f32: d=%d unsupported (need d%%4==0, 4<=d<=512)", d);
+    size_t lds = (size_t)AM_KT * d * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)argmin_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(argmin_exact_kernel, dim3((N + 127) / 128, B), dim3(128), lds, (hipStream_t)stream, f1, f2, N, M, d, T,
+                       dmin);
+    DVM_CHECK_LAUNCH("argmin_exact");
+    return DVM_OK;
+}
+
+DVM_EXPORT int dvm_knn_cdist_f32(const float *x, const float *y, int B, int N, int M, int C, int k, int32_t *idx,
+                                 void *stream) {
+    DVM_REQUIRE(x && y && idx, "dvm_knn_cdist_f32: null pointer");
+    DVM_REQUIRE(B >= 1 && N >= 1 && M >= 1, "dvm_knn_cdist_f32: empty input (B=%d N=%d M=%d)", B, N, M);
+    DVM_REQUIRE(C >= 1 && C <= 16, "dvm_knn_cdist_f32: C=%d unsupported (1..16)", C);
+    DVM_REQUIRE(k >= 1 && k <= 16, "dvm_knn_cdist_f32: k=%d unsupported (1..16)", k);
+    dim3 grid((N + 127) / 128, B), block(128);
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 3) {
+        if (k <= 3)
+            hipLaunchKernelGGL(knn_cdist3_kernel<3>, grid, block, 0, s, x, y, N, M, k, idx);
+        else if (k <= 10)
+            hipLaunchKernelGGL(knn_cdist3_kernel<10>, grid, block, 0, s, x, y, N, M, k, idx);
+        else
+            hipLaunchKernelGGL(knn_cdist3_kernel<16>, grid, block, 0, s, x, y, N, M, k, idx);
+    } else {
+        if (k <= 10)
+            hipLaunchKernelGGL(knn_cdist_kernel<10>, grid, block, 0, s, x, y, N, M, C, k, idx);
+        else
+            hipLaunchKernelGGL(knn_cdist_kernel<16>, grid, block, 0, s, x, y, N, M, C, k, idx);
+    }
+    DVM_CHECK_LAUNCH("knn_cdist");
+    return DVM_OK;
+}
+
+DVM_EXPORT int dvm_softcorr_apply_f32(const float *pi_val, const int32_t *pi_idx, const float *V, int B, int N, int M,
+                                      int topk, int C, float *out, void *stream) {
+    DVM_REQUIRE(pi_val && pi_idx && V && out, "dvm_softcorr_apply_f32: null pointer");
+    DVM_REQUIRE(B >= 1 && N >= 1 && M >= 1 && C >= 1, "dvm_softcorr_apply_f32: empty input");
+    DVM_REQUIRE(topk >= 1 && topk <= 16, "dvm_softcorr_apply_f32: topk=%d unsupported (1..16)", topk);
+    long threads = (long)N * ((C + 3) / 4);
+    dim3 grid((unsigned)((threads + 255) / 256), B), block(256);
+    if (topk <= 10)
+        hipLaunchKernelGGL(apply_kernel<10>, grid, block, 0, (hipStream_t)stream, pi_val, pi_idx, V, N, M, topk, C, out);
+    else
+        hipLaunchKernelGGL(apply_kernel<16>, grid, block, 0, (hipStream_t)stream, pi_val, pi_idx, V, N, M, topk, C, out);
+    DVM_CHECK_LAUNCH("softcorr_apply");
+    return DVM_OK;
+}
+
+DVM_EXPORT int dvm_chamfer_fwd_f32(const float *a, const float *b, int B, int N, int M, float *d1, float *d2, int32_t *i1,
+                                   int32_t *i2, void *stream) {
+    DVM_REQUIRE(a && b && (d1 || d2), "dvm_chamfer_fwd_f32: null pointer");
+    DVM_REQUIRE(B >= 1 && N >= 1 && M >= 1, "dvm_chamfer_fwd_f32: empty input (B=%d N=%d M=%d)", B, N, M);
+    hipStream_t s = (hipStream_t)stream;
+    if (d1) hipLaunchKernelGGL(chamfer_kernel, dim3((N + 127) / 128, B), dim3(128), 0, s, a, b, N, M, d1, i1);
+    if (d2) hipLaunchKernelGGL(chamfer_kernel, dim3((M + 127) / 128, B), dim3(128), 0, s, b, a, M, N, d2, i2);
+    DVM_CHECK_LAUNCH("chamfer");
+    return DVM_OK;
+}
+
+DVM_EXPORT size_t dvm_map_term_workspace_bytes(int B, int N) {
+    return align_up((size_t)B * (((size_t)N * 16 + 255) / 256) * sizeof(double));
+}
+
+DVM_EXPORT int dvm_map_term_f32(const float *verts12, const float *verts2, const int32_t *idx11, const int32_t *idx22,
+                                const float *pi_val, const int32_t *pi_idx, int B, int N, int M, int k, int topk, float *out,
+                                void *ws, size_t ws_bytes, void *stream) {
+    DVM_REQUIRE(verts12 && verts2 && idx11 && idx22 && pi_val && pi_idx && out, "dvm_map_term_f32: null pointer");
+    DVM_REQUIRE(B >= 1 && N >= 1 && M >= 1, "dvm_map_term_f32: empty input");
+    DVM_REQUIRE(k >= 1 && k <= 16 && topk >= 1 && topk <= 16, "dvm_map_term_f32: k/topk out of range");
+    int nblk = (int)(((long)N * k + 255) / 256);
+    Arena ar(ws, ws_bytes);
+    double *partial = ar.take<double>((size_t)B * nblk);
+    if (!ar.ok()) {
+        set_error("dvm_map_term_f32: workspace too small (%zu < %zu)", ws_bytes, ar.off);
+        return DVM_ENOSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (topk <= 10)
+        hipLaunchKernelGGL(map_term_kernel<10>, dim3(nblk, B), dim3(256), 0, s, verts12, verts2, idx11, idx22, pi_val, pi_idx,
+                           N, M, k, topk, partial);
+    else
+        hipLaunchKernelGGL(map_term_kernel<16>, dim3(nblk, B), dim3(256), 0, s, verts12, verts2, idx11, idx22, pi_val, pi_idx,
+                           N, M, k, topk, partial);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(B), dim3(256), 0, s, partial, nblk, 1.0f, out, 1, 0);
+    DVM_CHECK_LAUNCH("map_term");
+    return DVM_OK;
+}
+
+// internal helpers used by dvm_pair.hip
+namespace dvm {
+int launch_mean(const float *in, int B, int n, float scale, float *out, int stride, int off, int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(mean_kernel, dim3(B), dim3(256), 0, s, in, n, scale, out, stride, off, accumulate);
+    return DVM_OK;
+}
+int launch_reduce_partials(const double *partial, int B, int nparts, float scale, float *out, int stride, int off,
+                           hipStream_t s) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(B), dim3(256), 0, s, partial, nparts, scale, out, stride, off);
+    return DVM_OK;
+}
+int map_term_blocks(int N, int k) { return (int)(((long)N * k + 255) / 256); }
+int launch_map_term(const float *verts12, const float *verts2, const int32_t *idx11, const int32_t *idx22,
+                    const float *pi_val, const int32_t *pi_idx, int B, int N, int M, int k, int topk, double *partial,
+                    hipStream_t s) {
+    int nblk = map_term_blocks(N, k);
+    hipLaunchKernelGGL(map_term_kernel<10>, dim3(nblk, B), dim3(256), 0, s, verts12, verts2, idx11, idx22, pi_val, pi_idx, N,
+                       M, k, topk, partial);
+    return DVM_OK;
+}
+}  // namespace dvm

@@ -1,0 +1,417 @@
+// dvm_graph.hip — K7/K8: embedded-deformation graph on a point cloud, entirely on the GPU.
+//
+// Replaces DeformationGraph_geod.construct_graph_euclidean / .forward and their driver
+// deformation_graph_node (reference lib/deformation_graph_point.py:18-33,177-201,233-261;
+// models/loss.py:1325-1337, 39-45): the reference copies an N x N distance matrix to the host
+// and runs a Python FPS loop + scipy KDTree per shape per step; here FPS runs as one workgroup
+// per shape with the cloud and the running distances resident in registers/LDS, the KDTree
+// queries become brute-force fp64 sweeps (exactly scipy's arithmetic), and nothing leaves HBM.
+#include "dvm_common.h"
+
+namespace dvm {
+
+// ---------------------------------------------------------------- farthest point sampling
+// One workgroup per shape; thread t owns points t, t+T, t+2T, ... (PPT of them) with their
+// running min-distance in registers; the cloud is also kept in LDS for the centroid broadcast.
+constexpr int FPS_T = 256;
+
+struct ArgMax {
+    float v;
+    int i;
+};
+__device__ __forceinline__ ArgMax better(ArgMax a, ArgMax b) {  // larger value, then lower index
+    bool tb = (b.v > a.v) || (b.v == a.v && b.i < a.i);
+    return tb ? b : a;
+}
+
+template <int PPT>
+__global__ __launch_bounds__(FPS_T) void fps_kernel(const float *__restrict__ xyz, int N, int npoint,
+                                                    const int32_t *__restrict__ start, int32_t *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [N*3] cloud + [2][4] partial argmax
+    float *cloud = smem;
+    ArgMax *part = (ArgMax *)(smem + ((N * 3 + 3) & ~3));
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float *p = xyz + (size_t)b * N * 3;
+    for (int e = tid; e < N * 3; e += FPS_T) cloud[e] = p[e];
+    float px[PPT], py[PPT], pz[PPT], dist[PPT];
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        int j = tid + q * FPS_T;
+        bool ok = j < N;
+        px[q] = ok ? p[3 * j] : 0.f;
+        py[q] = ok ? p[3 * j + 1] : 0.f;
+        pz[q] = ok ? p[3 * j + 2] : 0.f;
+        dist[q] = ok ? 1e10f : -INFINITY;  // padding can never be the arg-max
+    }
+    __syncthreads();
+    int far = start[b];
+    int32_t *o = out + (size_t)b * npoint;
+    for (int it = 0; it < npoint; ++it) {
+        if (tid == 0) o[it] = far;
+        const float cx = cloud[3 * far], cy = cloud[3 * far + 1], cz = cloud[3 * far + 2];
+        ArgMax best = {-INFINITY, 0x7fffffff};
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            float dv = d2_diff3(px[q], py[q], pz[q], cx, cy, cz);
+            dist[q] = (dv < dist[q]) ? dv : dist[q];
+            ArgMax c = {dist[q], tid + q * FPS_T};
+            best = (c.v > best.v) ? c : best;  // ascending index within the thread: strict keeps the first
+        }
+#pragma unroll
+        for (int ofs = 32; ofs > 0; ofs >>= 1) {
+            ArgMax o2 = {__shfl_xor(best.v, ofs, 64), __shfl_xor(best.i, ofs, 64)};
+            best = better(best, o2);
+        }
+        ArgMax *slot = part + (it & 1) * (FPS_T / 64);
+        if ((tid & 63) == 0) slot[tid >> 6] = best;
+        __syncthreads();
+        ArgMax r = slot[0];
+#pragma unroll
+        for (int w = 1; w < FPS_T / 64; ++w) r = better(r, slot[w]);
+        far = r.i;
+    }
+}
+
+// ---------------------------------------------------------------- node ring: 9-NN among nodes
+// scipy.spatial.KDTree(nodes).query(nodes, 9): fp64 squared distances of the fp32 coordinates,
+// ascending, self first.  Thread per node, nodes staged through LDS.
+constexpr int DG_TILE = 256;
+
+__device__ __forceinline__ double d2_f64(float ax, float ay, float az, float bx, float by, float bz) {
+    double dx = (double)ax - (double)bx, dy = (double)ay - (double)by, dz = (double)az - (double)bz;
+    double s = 0.0;
+    s = s + dx * dx;
+    s = s + dy * dy;
+    s = s + dz * dz;
+    return s;
+}
+
+__global__ __launch_bounds__(128) void dg_ring_kernel(const float *__restrict__ xyz, const int32_t *__restrict__ nodes_idx,
+                                                      int N, int Nn, int32_t *__restrict__ ring) {
+    __shared__ float tx[DG_TILE], ty[DG_TILE], tz[DG_TILE];
+    const int b = blockIdx.y;
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    const float *p = xyz + (size_t)b * N * 3;
+    const int32_t *nid = nodes_idx + (size_t)b * Nn;
+    const int ac = a < Nn ? a : Nn - 1;
+    const int va = nid[ac];
+    const float ax = p[3 * va], ay = p[3 * va + 1], az = p[3 * va + 2];
+    KBest<9, double> kb;
+    kb.init((double)INFINITY);
+    for (int j0 = 0; j0 < Nn; j0 += DG_TILE) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < DG_TILE; e += blockDim.x) {
+            int v = (j0 + e < Nn) ? nid[j0 + e] : 0;
+            tx[e] = p[3 * v], ty[e] = p[3 * v + 1], tz[e] = p[3 * v + 2];
+        }
+        __syncthreads();
+        int lim = Nn - j0 < DG_TILE ? Nn - j0 : DG_TILE;
+        for (int j = 0; j < lim; ++j) kb.insert(d2_f64(ax, ay, az, tx[j], ty[j], tz[j]), j0 + j);
+    }
+    if (a < Nn)
+        for (int t = 0; t < 9; ++t) ring[((size_t)b * Nn + a) * 9 + t] = t < Nn ? kb.idx[t] : a;
+}
+
+// ---------------------------------------------------------------- influence nodes + 1-NN distance
+// (dists, infl) = 3 smallest of cdist(verts,verts)[nodes_idx] (matmul form, node = row operand);
+// nnd[i] = distance to the nearest other vertex in fp64 (KDTree(vertices).query(vertices,2)[:,1]).
+__global__ __launch_bounds__(128) void dg_infl_kernel(const float *__restrict__ xyz, const int32_t *__restrict__ nodes_idx,
+                                                      int N, int Nn, int32_t *__restrict__ infl, float *__restrict__ dists,
+                                                      double *__restrict__ nnd) {
+    __shared__ float4 tp[DG_TILE];
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float *p = xyz + (size_t)b * N * 3;
+    const int32_t *nid = nodes_idx + (size_t)b * Nn;
+    const int ic = i < N ? i : N - 1;
+    const float vx = p[3 * ic], vy = p[3 * ic + 1], vz = p[3 * ic + 2];
+    const float nv = sumsq3(vx, vy, vz);
+    KBest<3, float> kb;
+    kb.init(INFINITY);
+    for (int j0 = 0; j0 < Nn; j0 += DG_TILE) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < DG_TILE; e += blockDim.x) {
+            int v = (j0 + e < Nn) ? nid[j0 + e] : 0;
+            float4 q = {p[3 * v], p[3 * v + 1], p[3 * v + 2], 0.f};
+            q.w = sumsq3(q.x, q.y, q.z);
+            tp[e] = q;
+        }
+        __syncthreads();
+        int lim = Nn - j0 < DG_TILE ? Nn - j0 : DG_TILE;
+#pragma unroll 4
+        for (int j = 0; j < lim; ++j) {
+            float4 q = tp[j];
+            kb.insert(__fsqrt_rn(d2_mm3(q.x, q.y, q.z, q.w, vx, vy, vz, nv)), j0 + j);
+        }
+    }
+    double m1 = (double)INFINITY, m2 = (double)INFINITY;
+    for (int j0 = 0; j0 < N; j0 += DG_TILE) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < DG_TILE; e += blockDim.x) {
+            int v = (j0 + e < N) ? j0 + e : 0;
+            float4 q = {p[3 * v], p[3 * v + 1], p[3 * v + 2], 0.f};
+            tp[e] = q;
+        }
+        __syncthreads();
+        int lim = N - j0 < DG_TILE ? N - j0 : DG_TILE;
+#pragma unroll 4
+        for (int j = 0; j < lim; ++j) {
+            float4 q = tp[j];
+            double v = d2_f64(vx, vy, vz, q.x, q.y, q.z);
+            bool lt1 = v < m1, lt2 = v < m2;
+            m2 = lt1 ? m1 : (lt2 ? v : m2);
+            m1 = lt1 ? v : m1;
+        }
+    }
+    if (i < N) {
+        size_t row = (size_t)b * N + i;
+        for (int t = 0; t < 3; ++t) {
+            infl[row * 3 + t] = t < Nn ? kb.idx[t] : 0;
+            dists[row * 3 + t] = kb.key[t];
+        }
+        nnd[row] = sqrt(m2);
+    }
+}
+
+// sigma = 20 * mean(nnd) (fp64, fixed order); weights = exp(-d^2 / float(2 sigma^2)) row-normalised
+__global__ __launch_bounds__(256) void dg_weights_kernel(const double *__restrict__ nnd, const float *__restrict__ dists,
+                                                         int N, float *__restrict__ weights, double *__restrict__ sigma) {
+    __shared__ double red[256];
+    const int b = blockIdx.x;
+    double s = 0.0;
+    for (int q = threadIdx.x; q < N; q += blockDim.x) s += nnd[(size_t)b * N + q];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    const double sg = 20.0 * (red[0] / (double)N);
+    if (threadIdx.x == 0 && sigma) sigma[b] = sg;
+    const float den = (float)(2.0 * sg * sg);
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        size_t row = (size_t)b * N + i;
+        float w[3], tot = 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            float dv = dists[row * 3 + t];
+            w[t] = expf(-((dv * dv) / den));
+            tot = tot + w[t];
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) weights[row * 3 + t] = w[t] / tot;
+    }
+}
+
+// ---------------------------------------------------------------- rot6d, warp, ARAP
+// def9 = [t(3), r6(6)]: r6 += [1,0,0,0,1,0]; Gram-Schmidt; rows (b1,b2,b1 x b2)
+__device__ __forceinline__ void rot6d(const float *__restrict__ d, float (&r)[9], float (&t)[3]) {
+    float a1x = d[3] + 1.f, a1y = d[4] + 0.f, a1z = d[5] + 0.f;
+    float a2x = d[6] + 0.f, a2y = d[7] + 1.f, a2z = d[8] + 0.f;
+    float n1 = __fsqrt_rn((a1x * a1x + a1y * a1y) + a1z * a1z);
+    n1 = n1 > 1e-12f ? n1 : 1e-12f;
+    float b1x = a1x / n1, b1y = a1y / n1, b1z = a1z / n1;
+    float dot = (b1x * a2x + b1y * a2y) + b1z * a2z;
+    float b2x = a2x - dot * b1x, b2y = a2y - dot * b1y, b2z = a2z - dot * b1z;
+    float n2 = __fsqrt_rn((b2x * b2x + b2y * b2y) + b2z * b2z);
+    n2 = n2 > 1e-12f ? n2 : 1e-12f;
+    b2x = b2x / n2, b2y = b2y / n2, b2z = b2z / n2;
+    r[0] = b1x, r[1] = b1y, r[2] = b1z;
+    r[3] = b2x, r[4] = b2y, r[5] = b2z;
+    r[6] = b1y * b2z - b1z * b2y, r[7] = b1z * b2x - b1x * b2z, r[8] = b1x * b2y - b1y * b2x;
+    t[0] = d[0], t[1] = d[1], t[2] = d[2];
+}
+
+__global__ void rot6d_kernel(const float *__restrict__ def9, int total, float *__restrict__ R, float *__restrict__ T) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= total) return;
+    float r[9], t[3];
+    rot6d(def9 + (size_t)n * 9, r, t);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) R[(size_t)n * 9 + c] = r[c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) T[(size_t)n * 3 + c] = t[c];
+}
+
+// v' = sum_s w_s (R_s (v - g_s) + g_s + t_s)
+__global__ __launch_bounds__(256) void dg_warp_kernel(const float *__restrict__ xyz, int N, int Nn,
+                                                      const int32_t *__restrict__ nodes_idx, const int32_t *__restrict__ infl,
+                                                      const float *__restrict__ weights, const float *__restrict__ R,
+                                                      const float *__restrict__ T, float *__restrict__ warped) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float *p = xyz + (size_t)b * N * 3;
+    const size_t row = (size_t)b * N + i;
+    const float vx = p[3 * i], vy = p[3 * i + 1], vz = p[3 * i + 2];
+    float o[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        int nb = infl[row * 3 + s];
+        int gv = nodes_idx[(size_t)b * Nn + nb];
+        const float *r = R + ((size_t)b * Nn + nb) * 9, *t = T + ((size_t)b * Nn + nb) * 3;
+        float gx = p[3 * gv], gy = p[3 * gv + 1], gz = p[3 * gv + 2];
+        float dx = vx - gx, dy = vy - gy, dz = vz - gz;
+        float w = weights[row * 3 + s];
+        float g[3] = {gx, gy, gz};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float rv = (r[3 * c] * dx + r[3 * c + 1] * dy) + r[3 * c + 2] * dz;
+            o[c] = o[c] + ((rv + g[c]) + t[c]) * w;
+        }
+    }
+    warped[row * 3] = o[0], warped[row * 3 + 1] = o[1], warped[row * 3 + 2] = o[2];
+}
+
+// arap = sum_{a, b in ring(a)} |(g_a+t_a) - (g_b+t_b) - R_a (g_a-g_b)|^2 / Nn ; sr = mean (R_a-R_b)^2
+__global__ __launch_bounds__(256) void dg_arap_kernel(const float *__restrict__ xyz, int N, int Nn,
+                                                      const int32_t *__restrict__ nodes_idx, const int32_t *__restrict__ ring,
+                                                      const float *__restrict__ R, const float *__restrict__ T,
+                                                      float *__restrict__ arap, int arap_stride, float *__restrict__ sr) {
+    __shared__ double red[2][256];
+    const int b = blockIdx.x;
+    const float *p = xyz + (size_t)b * N * 3;
+    double sa = 0.0, ss = 0.0;
+    for (int a = threadIdx.x; a < Nn; a += blockDim.x) {
+        size_t na = (size_t)b * Nn + a;
+        int va = nodes_idx[na];
+        const float *ra = R + na * 9, *ta = T + na * 3;
+        float gax = p[3 * va], gay = p[3 * va + 1], gaz = p[3 * va + 2];
+        float ga[3] = {gax, gay, gaz};
+        for (int q = 0; q < 9; ++q) {
+            int nb = ring[na * 9 + q];
+            size_t nbg = (size_t)b * Nn + nb;
+            int vb = nodes_idx[nbg];
+            const float *rb = R + nbg * 9, *tb = T + nbg * 3;
+            float gb[3] = {p[3 * vb], p[3 * vb + 1], p[3 * vb + 2]};
+            float dx = ga[0] - gb[0], dy = ga[1] - gb[1], dz = ga[2] - gb[2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float rv = (ra[3 * c] * dx + ra[3 * c + 1] * dy) + ra[3 * c + 2] * dz;
+                float e = ((ga[c] + ta[c]) - (gb[c] + tb[c])) - rv;
+                sa += (double)(e * e);
+            }
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                float e = ra[c] - rb[c];
+                ss += (double)(e * e);
+            }
+        }
+    }
+    red[0][threadIdx.x] = sa;
+    red[1][threadIdx.x] = ss;
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + o];
+            red[1][threadIdx.x] += red[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        arap[(size_t)b * arap_stride] = (float)(red[0][0] / (double)Nn);
+        if (sr) sr[b] = (float)(red[1][0] / ((double)Nn * 81.0));
+    }
+}
+
+int launch_fps(const float *xyz, int B, int N, int npoint, const int32_t *start, int32_t *out, hipStream_t s) {
+    size_t lds = (size_t)((N * 3 + 3) & ~3) * sizeof(float) + 2 * (FPS_T / 64) * sizeof(ArgMax);
+    int ppt = (N + FPS_T - 1) / FPS_T;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)fps_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)fps_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)fps_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)fps_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    if (ppt <= 8)
+        hipLaunchKernelGGL(fps_kernel<8>, dim3(B), dim3(FPS_T), lds, s, xyz, N, npoint, start, out);
+    else if (ppt <= 16)
+        hipLaunchKernelGGL(fps_kernel<16>, dim3(B), dim3(FPS_T), lds, s, xyz, N, npoint, start, out);
+    else if (ppt <= 32)
+        hipLaunchKernelGGL(fps_kernel<32>, dim3(B), dim3(FPS_T), lds, s, xyz, N, npoint, start, out);
+    else
+        hipLaunchKernelGGL(fps_kernel<48>, dim3(B), dim3(FPS_T), lds, s, xyz, N, npoint, start, out);
+    return DVM_OK;
+}
+
+int launch_dg_build(const float *xyz, int B, int N, const int32_t *start, int32_t *nodes_idx, int32_t *ring,
+                    int32_t *infl_idx, float *dists, float *weights, double *sigma, double *nnd, hipStream_t s) {
+    const int Nn = N / 2;
+    launch_fps(xyz, B, N, Nn, start, nodes_idx, s);
+    hipLaunchKernelGGL(dg_ring_kernel, dim3((Nn + 127) / 128, B), dim3(128), 0, s, xyz, nodes_idx, N, Nn, ring);
+    hipLaunchKernelGGL(dg_infl_kernel, dim3((N + 127) / 128, B), dim3(128), 0, s, xyz, nodes_idx, N, Nn, infl_idx, dists, nnd);
+    hipLaunchKernelGGL(dg_weights_kernel, dim3(B), dim3(256), 0, s, nnd, dists, N, weights, sigma);
+    return DVM_OK;
+}
+
+int launch_dg_warp(const float *xyz, int B, int N, const int32_t *nodes_idx, const int32_t *ring, const int32_t *infl_idx,
+                   const float *weights, const float *def9, float *R, float *T, float *warped, float *arap, int arap_stride,
+                   float *sr, hipStream_t s) {
+    const int Nn = N / 2;
+    hipLaunchKernelGGL(rot6d_kernel, dim3((B * Nn + 255) / 256), dim3(256), 0, s, def9, B * Nn, R, T);
+    hipLaunchKernelGGL(dg_warp_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, xyz, N, Nn, nodes_idx, infl_idx, weights, R, T,
+                       warped);
+    hipLaunchKernelGGL(dg_arap_kernel, dim3(B), dim3(256), 0, s, xyz, N, Nn, nodes_idx, ring, R, T, arap, arap_stride, sr);
+    return DVM_OK;
+}
+
+}  // namespace dvm
+
+using namespace dvm;
+
+constexpr int DVM_MAX_POINTS = 48 * 256;  // fps_kernel<48>; LDS: 12288*12 B = 144 KiB
+
+DVM_EXPORT int dvm_fps_f32(const float *xyz, int B, int N, int npoint, const int32_t *start, int32_t *out, void *stream) {
+    DVM_REQUIRE(xyz && start && out, "dvm_fps_f32: null pointer");
+    DVM_REQUIRE(B >= 1 && N >= 1 && npoint >= 1 && npoint <= N, "dvm_fps_f32: bad sizes (B=%d N=%d npoint=%d)", B, N, npoint);
+    DVM_REQUIRE(N <= DVM_MAX_POINTS, "dvm_fps_f32: N=%d exceeds %d", N, DVM_MAX_POINTS);
+    launch_fps(xyz, B, N, npoint, start, out, (hipStream_t)stream);
+    DVM_CHECK_LAUNCH("fps");
+    return DVM_OK;
+}
+
+DVM_EXPORT size_t dvm_dg_build_workspace_bytes(int B, int N) { return align_up((size_t)B * N * sizeof(double)); }
+
+DVM_EXPORT int dvm_dg_build_f32(const float *xyz, int B, int N, const int32_t *start, int32_t *nodes_idx, int32_t *ring,
+                                int32_t *infl_idx, float *dists, float *weights, double *sigma, void *ws, size_t ws_bytes,
+                                void *stream) {
+    DVM_REQUIRE(xyz && start && nodes_idx && ring && infl_idx && dists && weights, "dvm_dg_build_f32: null pointer");
+    DVM_REQUIRE(B >= 1 && N >= 2, "dvm_dg_build_f32: bad sizes (B=%d N=%d)", B, N);
+    DVM_REQUIRE(N <= DVM_MAX_POINTS, "dvm_dg_build_f32: N=%d exceeds %d", N, DVM_MAX_POINTS);
+    Arena ar(ws, ws_bytes);
+    double *nnd = ar.take<double>((size_t)B * N);
+    if (!ar.ok()) {
+        set_error("dvm_dg_build_f32: workspace too small (%zu < %zu)", ws_bytes, ar.off);
+        return DVM_ENOSPACE;
+    }
+    launch_dg_build(xyz, B, N, start, nodes_idx, ring, infl_idx, dists, weights, sigma, nnd, (hipStream_t)stream);
+    DVM_CHECK_LAUNCH("dg_build");
+    return DVM_OK;
+}
+
+DVM_EXPORT size_t dvm_dg_warp_workspace_bytes(int B, int N) {
+    size_t Nn = (size_t)N / 2;
+    return align_up(B * Nn * 9 * sizeof(float)) + align_up(B * Nn * 3 * sizeof(float));
+}
+
+DVM_EXPORT int dvm_dg_warp_arap_fwd_f32(const float *xyz, int B, int N, const int32_t *nodes_idx, const int32_t *ring,
+                                        const int32_t *infl_idx, const float *weights, const float *def9, float *R_out,
+                                        float *warped, float *arap, float *sr, void *ws, size_t ws_bytes, void *stream) {
+    DVM_REQUIRE(xyz && nodes_idx && ring && infl_idx && weights && def9 && warped && arap,
+                "dvm_dg_warp_arap_fwd_f32: null pointer");
+    DVM_REQUIRE(B >= 1 && N >= 2, "dvm_dg_warp_arap_fwd_f32: bad sizes (B=%d N=%d)", B, N);
+    const int Nn = N / 2;
+    Arena ar(ws, ws_bytes);
+    float *R = ar.take<float>((size_t)B * Nn * 9);
+    float *T = ar.take<float>((size_t)B * Nn * 3);
+    if (!ar.ok()) {
+        set_error("dvm_dg_warp_arap_fwd_f32: workspace too small (%zu < %zu)", ws_bytes, ar.off);
+        return DVM_ENOSPACE;
+    }
+    if (R_out) R = R_out;
+    launch_dg_warp(xyz, B, N, nodes_idx, ring, infl_idx, weights, def9, R, T, warped, arap, 1, sr, (hipStream_t)stream);
+    DVM_CHECK_LAUNCH("dg_warp_arap");
+    return DVM_OK;
+}

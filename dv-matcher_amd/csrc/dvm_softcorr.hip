@@ -1,0 +1,409 @@
+// dvm_softcorr.hip — K1: fused feature-distance + row-softmax + top-k soft correspondence.
+//
+// Replaces knnsearch_t_grad + topk_pi (reference models/loss.py:110-114, 1339-1347, 1404-1407):
+// the N x M distance / softmax matrices are never written to HBM.  Squared distances are the
+// matmul form of torch.cdist, [-2a,|a|^2,1].[b,1,|b|^2], evaluated as a k-ordered fp32 fma
+// chain — on the matrix cores v_mfma_f32_32x32x2_f32 computes exactly that chain, so the
+// distances equal the reference's CPU (MKL sgemm) values bit for bit and the top-k columns /
+// arg-max map are bit-exact integers.
+//
+// Data layout: features row-major [B][N][d] fp32 in HBM; one workgroup owns 128 query rows
+// (4 waves x 32) and sweeps all M keys through a double-buffered, k-deinterleaved LDS tile;
+// the accumulator tile is [key][query] so that a query's candidates sit in one lane's
+// registers (top-k insertion and online softmax need no cross-lane traffic until the end).
+#include "dvm_common.h"
+
+namespace dvm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+// ------------------------------------------------------------------ row norms
+__global__ void rownorm2_kernel(const float *__restrict__ x, int rows, int K, float *__restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    out[i] = aten_sumsq_row(x + (size_t)i * K, K);
+}
+
+// ------------------------------------------------------- per-row running state
+template <int TOPK>
+struct RowState {
+    KBest<TOPK, float> kb;  // keyed on the post-sqrt distance, as torch.topk sees it
+    float smax;             // running max of s = d * neg_alpha   (-inf initially)
+    float l;                // sum exp(s - smax)
+    __device__ __forceinline__ void init() {
+        kb.init(INFINITY);
+        smax = -INFINITY;
+        l = 0.f;
+    }
+    __device__ __forceinline__ void rescale(float new_smax) {
+        if (new_smax > smax) {
+            l = l * exp2f((smax - new_smax) * LOG2E);  // smax=-inf, l=0 -> 0*0
+            smax = new_smax;
+        }
+    }
+    __device__ __forceinline__ void merge(const RowState &o) {
+        float m = fmaxf(smax, o.smax);
+        float a = (smax == -INFINITY) ? 0.f : l * exp2f((smax - m) * LOG2E);
+        float b = (o.smax == -INFINITY) ? 0.f : o.l * exp2f((o.smax - m) * LOG2E);
+        l = a + b;
+        smax = m;
+#pragma unroll
+        for (int t = 0; t < TOPK; ++t) kb.insert_lex(o.kb.key[t], o.kb.idx[t]);
+    }
+};
+
+template <int TOPK>
+__device__ __forceinline__ void store_row(const RowState<TOPK> &st, int topk, int M, float neg_alpha, float *val,
+                                          int32_t *idx, float *row_smax, float *row_sum) {
+    float inv = 1.0f / st.l;
+#pragma unroll
+    for (int t = 0; t < TOPK; ++t) {
+        if (t < topk) {
+            bool live = t < M;
+            float s = st.kb.key[t] * neg_alpha;
+            val[t] = live ? exp2f((s - st.smax) * LOG2E) * inv : 0.f;
+            idx[t] = live ? st.kb.idx[t] : 0;
+        }
+    }
+    if (row_smax) *row_smax = st.smax;
+    if (row_sum) *row_sum = st.l;
+}
+
+// ------------------------------------------------------------ scalar variant
+// One thread per query row; keys staged through LDS in tiles of 32; the dot product is an
+// explicit k-ordered fmaf chain.  Any d % 4 == 0.  Reference kernel for the MFMA variant and
+// the fallback for d != 128.
+constexpr int SC_KT = 32;   // keys per tile
+constexpr int SC_DC = 32;   // feature chunk held in registers
+
+template <int TOPK>
+__global__ __launch_bounds__(128) void softcorr_scalar_kernel(const float *__restrict__ f1, const float *__restrict__ f2,
+                                                              const float *__restrict__ n1, const float *__restrict__ n2,
+                                                              int N, int M, int d, float neg_alpha, int topk,
+                                                              float *__restrict__ pi_val, int32_t *__restrict__ pi_idx,
+                                                              float *__restrict__ row_smax, float *__restrict__ row_sum) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [SC_KT][d] keys + [SC_KT] norms
+    float *kt = smem;
+    float *kn = smem + SC_KT * d;
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ic = i < N ? i : N - 1;
+    const float *q = f1 + ((size_t)b * N + ic) * d;
+    const float na = n1[(size_t)b * N + ic];
+    const float *kbase = f2 + (size_t)b * M * d;
+    RowState<TOPK> st;
+    st.init();
+    for (int j0 = 0; j0 < M; j0 += SC_KT) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < SC_KT * d / 4; e += blockDim.x) {
+            int r = e / (d / 4), c = e % (d / 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (j0 + r < M) v = *(const f32x4 *)(kbase + (size_t)(j0 + r) * d + 4 * c);
+            *(f32x4 *)(kt + r * d + 4 * c) = v;
+        }
+        if (threadIdx.x < SC_KT) kn[threadIdx.x] = (j0 + threadIdx.x < M) ? n2[(size_t)b * M + j0 + threadIdx.x] : INFINITY;
+        __syncthreads();
+        float acc[SC_KT];
+#pragma unroll
+        for (int j = 0; j < SC_KT; ++j) acc[j] = 0.f;
+        for (int c0 = 0; c0 < d; c0 += SC_DC) {
+            float qr[SC_DC];
+            int cw = d - c0 < SC_DC ? d - c0 : SC_DC;
+#pragma unroll
+            for (int c = 0; c < SC_DC; c += 4) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (c < cw) v = *(const f32x4 *)(q + c0 + c);
+                qr[c] = -2.f * v.x, qr[c + 1] = -2.f * v.y, qr[c + 2] = -2.f * v.z, qr[c + 3] = -2.f * v.w;
+            }
+#pragma unroll
+            for (int j = 0; j < SC_KT; ++j) {
+#pragma unroll
+                for (int c = 0; c < SC_DC; c += 4) {
+                    if (c < cw) {
+                        f32x4 kv = *(const f32x4 *)(kt + j * d + c0 + c);
+                        acc[j] = fmaf(qr[c], kv.x, acc[j]);
+                        acc[j] = fmaf(qr[c + 1], kv.y, acc[j]);
+                        acc[j] = fmaf(qr[c + 2], kv.z, acc[j]);
+                        acc[j] = fmaf(qr[c + 3], kv.w, acc[j]);
+                    }
+                }
+            }
+        }
+        // epilogue: distances, online softmax, top-k
+        float dd[SC_KT];
+        float tmin = INFINITY;
+#pragma unroll
+        for (int j = 0; j < SC_KT; ++j) {
+            float d2 = (acc[j] + na) + kn[j];
+            d2 = d2 > 0.f ? d2 : 0.f;
+            dd[j] = __fsqrt_rn(d2);
+            tmin = fminf(tmin, dd[j]);
+        }
+        st.rescale(tmin * neg_alpha);
+#pragma unroll
+        for (int j = 0; j < SC_KT; ++j) {
+            float s = dd[j] * neg_alpha;
+            st.l += exp2f((s - st.smax) * LOG2E);
+            st.kb.insert(dd[j], j0 + j);
+        }
+    }
+    if (i < N) {
+        size_t row = (size_t)b * N + i;
+        store_row<TOPK>(st, topk, M, neg_alpha, pi_val + row * topk, pi_idx + row * topk, row_smax ? row_smax + row : nullptr,
+                        row_sum ? row_sum + row : nullptr);
+    }
+}
+
+// -------------------------------------------------------------- MFMA variant
+constexpr int MF_D = 128;
+constexpr int MF_KT = 64;              // keys per LDS tile (two 32-key MFMA sub-tiles)
+constexpr int MF_LDK = MF_D + 4;       // padded row (floats): 528 B, keeps ds_read_b128 conflict-free
+constexpr int MF_QW = 32;              // queries per wave
+constexpr int MF_WAVES = 4;
+constexpr int MF_QB = MF_QW * MF_WAVES;  // 128 queries per workgroup
+constexpr int MF_THREADS = 64 * MF_WAVES;
+constexpr int MF_LD_PER_THREAD = MF_KT * MF_D / 4 / MF_THREADS;  // float4 loads per thread per tile = 8
+constexpr size_t MF_LDS_BYTES = (size_t)2 * (MF_KT * MF_LDK + MF_KT) * sizeof(float);
+
+__device__ __forceinline__ float select16(const float (&v)[16], int b) {
+    float a0 = (b & 1) ? v[1] : v[0], a1 = (b & 1) ? v[3] : v[2], a2 = (b & 1) ? v[5] : v[4], a3 = (b & 1) ? v[7] : v[6];
+    float a4 = (b & 1) ? v[9] : v[8], a5 = (b & 1) ? v[11] : v[10], a6 = (b & 1) ? v[13] : v[12],
+          a7 = (b & 1) ? v[15] : v[14];
+    float b0 = (b & 2) ? a1 : a0, b1 = (b & 2) ? a3 : a2, b2 = (b & 2) ? a5 : a4, b3 = (b & 2) ? a7 : a6;
+    float c0 = (b & 4) ? b1 : b0, c1 = (b & 4) ? b3 : b2;
+    return (b & 8) ? c1 : c0;
+}
+
+// XCD-aware block remap (bijective for any grid): blocks that share `orig % 8` share an L2;
+// give each XCD a contiguous range of logical ids so the row tiles of one pair reuse its keys
+// from that L2.
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+    int q = nwg / 8, r = nwg % 8, xcd = orig % 8;
+    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + orig / 8;
+}
+
+template <int TOPK>
+__global__ __launch_bounds__(MF_THREADS, 2) void softcorr_mfma_kernel(
+    const float *__restrict__ f1, const float *__restrict__ f2, const float *__restrict__ n1,
+    const float *__restrict__ n2, int N, int M, float neg_alpha, int topk, int tiles_per_batch,
+    float *__restrict__ pi_val, int32_t *__restrict__ pi_idx, float *__restrict__ row_smax,
+    float *__restrict__ row_sum) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *const ktile0 = smem;                       // [2][MF_KT][MF_LDK]
+    float *const knorm0 = smem + 2 * MF_KT * MF_LDK;  // [2][MF_KT]
+
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = lid / tiles_per_batch;
+    const int qt = lid % tiles_per_batch;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r32 = lane & 31, h = lane >> 5;
+
+    const float *kbase = f2 + (size_t)b * M * MF_D;
+    const float *knb = n2 + (size_t)b * M;
+
+    // this lane's query row and its B-operand fragment: q[s] = -2 * f1[row][2s + h]
+    const int qrow = qt * MF_QB + wave * MF_QW + r32;
+    const int qrc = qrow < N ? qrow : N - 1;
+    const float *qp = f1 + ((size_t)b * N + qrc) * MF_D;
+    float q[MF_D / 2];
+#pragma unroll
+    for (int c = 0; c < MF_D / 4; ++c) {
+        f32x4 v = *(const f32x4 *)(qp + 4 * c);
+        q[2 * c] = -2.f * (h ? v.y : v.x);
+        q[2 * c + 1] = -2.f * (h ? v.w : v.z);
+    }
+    const float na = n1[(size_t)b * N + qrc];
+
+    RowState<TOPK> st;
+    st.init();
+
+    const int ntiles = (M + MF_KT - 1) / MF_KT;
+    f32x4 pre[MF_LD_PER_THREAD];
+    float pren = 0.f;
+
+    auto issue_loads = [&](int t) {
+        int j0 = t * MF_KT;
+#pragma unroll
+        for (int e = 0; e < MF_LD_PER_THREAD; ++e) {
+            int id = tid + e * MF_THREADS;
+            int r = id >> 5, c = id & 31;  // 32 float4 per 128-float row
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (j0 + r < M) v = *(const f32x4 *)(kbase + (size_t)(j0 + r) * MF_D + 4 * c);
+            pre[e] = v;
+        }
+        if (tid < MF_KT) pren = (j0 + tid < M) ? knb[j0 + tid] : INFINITY;
+    };
+    auto commit_loads = [&](int buf) {
+        float *kt = ktile0 + buf * (MF_KT * MF_LDK);
+#pragma unroll
+        for (int e = 0; e < MF_LD_PER_THREAD; ++e) {
+            int id = tid + e * MF_THREADS;
+            int r = id >> 5, c = id & 31;
+            // k = 4c+{0,1,2,3} -> (h,s) = (0,2c) (1,2c) (0,2c+1) (1,2c+1)
+            float2 ev = {pre[e].x, pre[e].z}, od = {pre[e].y, pre[e].w};
+            *(float2 *)(kt + r * MF_LDK + 2 * c) = ev;
+            *(float2 *)(kt + r * MF_LDK + 64 + 2 * c) = od;
+        }
+        if (tid < MF_KT) knorm0[buf * MF_KT + tid] = pren;
+    };
+
+    issue_loads(0);
+    commit_loads(0);
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) issue_loads(t + 1);
+        const float *kt = ktile0 + buf * (MF_KT * MF_LDK);
+#pragma unroll
+        for (int sub = 0; sub < MF_KT / 32; ++sub) {
+            const float *arow = kt + (sub * 32 + r32) * MF_LDK + h * 64;
+            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                f32x4 a = *(const f32x4 *)(arow + 4 * c);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, q[4 * c], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, q[4 * c + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, q[4 * c + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, q[4 * c + 3], acc, 0, 0, 0);
+            }
+            // epilogue for this lane's 16 keys: local key = (r&3) + 8*(r>>2) + 4*h
+            const float *kn = knorm0 + buf * MF_KT + sub * 32 + 4 * h;
+            float dd[16];
+            float tmin = INFINITY;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 nb = *(const f32x4 *)(kn + 8 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float d2 = (acc[4 * g + e] + na) + nb[e];
+                    d2 = d2 > 0.f ? d2 : 0.f;
+                    float dv = __fsqrt_rn(d2);
+                    dd[4 * g + e] = dv;
+                    tmin = fminf(tmin, dv);
+                }
+            }
+            st.rescale(tmin * neg_alpha);
+            float lsum = 0.f;
+            unsigned mask = 0;
+            const float thr = st.kb.worst();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float s = dd[r] * neg_alpha;
+                lsum += exp2f((s - st.smax) * LOG2E);
+                mask |= (dd[r] < thr) ? (1u << r) : 0u;
+            }
+            st.l += lsum;
+            const int jbase = t * MF_KT + sub * 32 + 4 * h;
+            while (__any(mask != 0)) {
+                if (mask != 0) {
+                    int bpos = __ffs(mask) - 1;
+                    mask &= mask - 1;
+                    float v = select16(dd, bpos);
+                    st.kb.insert(v, jbase + (bpos & 3) + 8 * (bpos >> 2));
+                }
+            }
+        }
+        if (t + 1 < ntiles) commit_loads(buf ^ 1);
+        __syncthreads();
+    }
+
+    // merge the two half-lanes that share a query (lane, lane^32)
+    RowState<TOPK> other;
+    other.smax = __shfl_xor(st.smax, 32, 64);
+    other.l = __shfl_xor(st.l, 32, 64);
+#pragma unroll
+    for (int t = 0; t < TOPK; ++t) {
+        other.kb.key[t] = __shfl_xor(st.kb.key[t], 32, 64);
+        other.kb.idx[t] = __shfl_xor(st.kb.idx[t], 32, 64);
+    }
+    st.merge(other);
+    if (h == 0 && qrow < N) {
+        size_t row = (size_t)b * N + qrow;
+        store_row<TOPK>(st, topk, M, neg_alpha, pi_val + row * topk, pi_idx + row * topk, row_smax ? row_smax + row : nullptr,
+                        row_sum ? row_sum + row : nullptr);
+    }
+}
+
+}  // namespace dvm
+
+using namespace dvm;
+
+DVM_EXPORT int dvm_rownorm2_f32(const float *x, int rows, int K, float *out, void *stream) {
+    DVM_REQUIRE(x && out && rows >= 0 && K >= 1, "dvm_rownorm2_f32: bad arguments");
+    if (rows == 0) return DVM_OK;
+    hipLaunchKernelGGL(rownorm2_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, rows, K, out);
+    DVM_CHECK_LAUNCH("rownorm2");
+    return DVM_OK;
+}
+
+DVM_EXPORT size_t dvm_softcorr_workspace_bytes(int B, int N, int M, int d) {
+    (void)d;
+    return align_up((size_t)B * N * sizeof(float)) + align_up((size_t)B * M * sizeof(float));
+}
+
+DVM_EXPORT int dvm_softcorr_fwd_f32(const float *f1, const float *f2, int B, int N, int M, int d, float neg_alpha,
+                                    int topk, float *pi_val, int32_t *pi_idx, float *row_smax, float *row_sum,
+                                    int variant, void *ws, size_t ws_bytes, void *stream) {
+    DVM_REQUIRE(f1 && f2 && pi_val && pi_idx, "dvm_softcorr_fwd_f32: null pointer");
+    DVM_REQUIRE(B >= 1 && N >= 1 && M >= 1, "dvm_softcorr_fwd_f32: empty input (B=%d N=%d M=%d)", B, N, M);
+    DVM_REQUIRE(d >= 4 && d % 4 == 0 && d <= 512, "dvm_softcorr_fwd_f32: d=%d unsupported (need d%%4==0, 4<=d<=512)", d);
+    DVM_REQUIRE(topk >= 1 && topk <= 16, "dvm_softcorr_fwd_f32: topk=%d unsupported (1..16)", topk);
+    DVM_REQUIRE(neg_alpha < 0.f, "dvm_softcorr_fwd_f32: neg_alpha must be negative (got %g)", (double)neg_alpha);
+    DVM_REQUIRE(variant >= 0 && variant <= 2, "dvm_softcorr_fwd_f32: bad variant %d", variant);
+    DVM_REQUIRE(variant != 2 || d == MF_D, "dvm_softcorr_fwd_f32: MFMA variant needs d == 128");
+    Arena ar(ws, ws_bytes);
+    float *n1 = ar.take<float>((size_t)B * N);
+    float *n2 = ar.take<float>((size_t)B * M);
+    if (!ar.ok()) {
+        set_error("dvm_softcorr_fwd_f32: workspace too small (%zu < %zu)", ws_bytes, ar.off);
+        return DVM_ENOSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(rownorm2_kernel, dim3((B * N + 255) / 256), dim3(256), 0, s, f1, B * N, d, n1);
+    hipLaunchKernelGGL(rownorm2_kernel, dim3((B * M + 255) / 256), dim3(256), 0, s, f2, B * M, d, n2);
+    bool mfma = (variant == 2) || (variant == 0 && d == MF_D);
+    prof_begin(s);
+    if (mfma) {
+        int tiles = (N + MF_QB - 1) / MF_QB;
+        dim3 grid(tiles * B);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void *)softcorr_mfma_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)MF_LDS_BYTES);
+            (void)hipFuncSetAttribute((const void *)softcorr_mfma_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)MF_LDS_BYTES);
+            attr_set = true;
+        }
+        if (topk <= 10)
+            hipLaunchKernelGGL(softcorr_mfma_kernel<10>, grid, dim3(MF_THREADS), MF_LDS_BYTES, s, f1, f2, n1, n2, N, M,
+                               neg_alpha, topk, tiles, pi_val, pi_idx, row_smax, row_sum);
+        else
+            hipLaunchKernelGGL(softcorr_mfma_kernel<16>, grid, dim3(MF_THREADS), MF_LDS_BYTES, s, f1, f2, n1, n2, N, M,
+                               neg_alpha, topk, tiles, pi_val, pi_idx, row_smax, row_sum);
+    } else {
+        dim3 grid((N + 127) / 128, B);
+        size_t lds = (size_t)(SC_KT * d + SC_KT) * sizeof(float);
+        static bool sattr_set = false;
+        if (!sattr_set) {
+            (void)hipFuncSetAttribute((const void *)softcorr_scalar_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      66 * 1024);
+            (void)hipFuncSetAttribute((const void *)softcorr_scalar_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      66 * 1024);
+            sattr_set = true;
+        }
+        if (topk <= 10)
+            hipLaunchKernelGGL(softcorr_scalar_kernel<10>, grid, dim3(128), lds, s, f1, f2, n1, n2, N, M, d, neg_alpha, topk,
+                               pi_val, pi_idx, row_smax, row_sum);
+        else
+            hipLaunchKernelGGL(softcorr_scalar_kernel<16>, grid, dim3(128), lds, s, f1, f2, n1, n2, N, M, d, neg_alpha, topk,
+                               pi_val, pi_idx, row_smax, row_sum);
+    }
+    prof_end(s);
+    DVM_CHECK_LAUNCH("softcorr");
+    return DVM_OK;
+}

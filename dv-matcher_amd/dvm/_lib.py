@@ -1,0 +1,76 @@
+"""ctypes loader for libdvm_hip.so (C ABI: include/dvm.h).
+
+There is deliberately no CPU fallback: if the shared library is missing, or a
+tensor is not on a HIP device, every op raises.  Build with
+`python -c "import __graft_entry__ as g; g.build()"` or `make -C dv-matcher_amd/csrc`.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
+SO_PATH = os.path.join(CSRC, "libdvm_hip.so")
+
+_lib = None
+
+c_int, c_float, c_size_t, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
+
+# name -> (restype, [argtypes])  — mirrors include/dvm.h one to one
+_P = c_void_p
+SIGNATURES = {
+    "dvm_abi_version": (c_int, []),
+    "dvm_last_error": (ctypes.c_char_p, []),
+    "dvm_device_count": (c_int, []),
+    "dvm_profile_enable": (c_int, [c_int]),
+    "dvm_profile_read": (c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),
+    "dvm_profile_disable": (c_int, []),
+    "dvm_rownorm2_f32": (c_int, [_P, c_int, c_int, _P, _P]),
+    "dvm_softcorr_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "dvm_softcorr_fwd_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P, _P, _P, _P, c_int, _P,
+                                     c_size_t, _P]),
+    "dvm_argmin_exact_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "dvm_knn_cdist_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "dvm_softcorr_apply_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "dvm_fps_f32": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
+    "dvm_dg_build_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "dvm_dg_build_f32": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "dvm_dg_warp_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "dvm_dg_warp_arap_fwd_f32": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "dvm_chamfer_fwd_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    "dvm_deformer_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "dvm_deformer_fwd_f32": (c_int, [_P] * 9 + [c_int] * 6 + [_P] * 10 + [_P, c_int, _P, c_size_t, _P]),
+    "dvm_map_term_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "dvm_map_term_f32": (c_int, [_P] * 6 + [c_int] * 5 + [_P, _P, c_size_t, _P]),
+    "dvm_pair_direction_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dvm_pair_direction_fwd_f32": (c_int, [_P] * 4 + [c_int] * 3 + [c_float, _P] + [_P] * 10 + [c_int] + [_P] * 4 +
+                                   [_P, c_size_t, _P]),
+}
+
+
+class DvmError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once). Raises DvmError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise DvmError("libdvm_hip.so not found at %s — build it first (make -C %s); there is no CPU fallback"
+                       % (SO_PATH, CSRC))
+    lib = ctypes.CDLL(SO_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here == ABI mismatch, let it propagate
+        fn.restype = res
+        fn.argtypes = args
+    if lib.dvm_abi_version() != 1:
+        raise DvmError("libdvm_hip.so ABI version %d != 1" % lib.dvm_abi_version())
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().dvm_last_error()
+        raise DvmError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))

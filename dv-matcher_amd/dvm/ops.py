@@ -1,0 +1,246 @@
+"""Tensor-level wrappers over the C ABI (include/dvm.h).
+
+torch is used for device memory and streams only: every function takes
+contiguous fp32 / int32 tensors that live on a HIP device, allocates the outputs
+and the scratch there, and enqueues the kernels on torch's current stream.
+"""
+import torch
+
+from . import _lib
+from ._lib import DvmError, check
+
+_ws_cache = {}
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not isinstance(t, torch.Tensor) or not t.is_cuda:
+            raise DvmError("dvm ops need tensors on a HIP device (got %s); there is no CPU fallback"
+                           % (t.device if isinstance(t, torch.Tensor) else type(t)))
+
+
+def _f(t):
+    return t.detach().contiguous().float()
+
+
+def _i(t):
+    return t.detach().contiguous().to(torch.int32)
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def workspace(nbytes, device, tag="ws"):
+    """Grow-only scratch buffer per (device, tag); reused across calls on the same stream."""
+    key = (device, tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def neg_alpha_f32(alpha):
+    """`-alpha * distance`: ATen casts the python/numpy scalar to fp32 (models/loss.py:112)."""
+    return float(torch.tensor(-float(alpha), dtype=torch.float32).item())
+
+
+def rownorm2(x):
+    _need_gpu(x)
+    x = _f(x)
+    rows, K = x.numel() // x.shape[-1], x.shape[-1]
+    out = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
+    check(_lib.load().dvm_rownorm2_f32(_p(x), rows, K, _p(out), _stream()), "dvm_rownorm2_f32")
+    return out
+
+
+def softcorr(f1, f2, alpha, topk=10, variant=0, stats=True):
+    """f1 (B,N,d), f2 (B,M,d) -> pi_val (B,N,topk), pi_idx (B,N,topk) int32, row_smax (B,N), row_sum (B,N)."""
+    _need_gpu(f1, f2)
+    f1, f2 = _f(f1), _f(f2)
+    B, N, d = f1.shape
+    M = f2.shape[1]
+    lib = _lib.load()
+    val = torch.empty(B, N, topk, dtype=torch.float32, device=f1.device)
+    idx = torch.empty(B, N, topk, dtype=torch.int32, device=f1.device)
+    smax = torch.empty(B, N, dtype=torch.float32, device=f1.device) if stats else None
+    ssum = torch.empty(B, N, dtype=torch.float32, device=f1.device) if stats else None
+    nb = lib.dvm_softcorr_workspace_bytes(B, N, M, d)
+    ws = workspace(nb, f1.device, "softcorr")
+    check(lib.dvm_softcorr_fwd_f32(_p(f1), _p(f2), B, N, M, d, neg_alpha_f32(alpha), topk, _p(val), _p(idx), _p(smax),
+                                   _p(ssum), variant, _p(ws), nb, _stream()), "dvm_softcorr_fwd_f32")
+    return val, idx, smax, ssum
+
+
+def argmin_exact(f1, f2, want_dist=False):
+    _need_gpu(f1, f2)
+    f1, f2 = _f(f1), _f(f2)
+    B, N, d = f1.shape
+    M = f2.shape[1]
+    T = torch.empty(B, N, dtype=torch.int32, device=f1.device)
+    dm = torch.empty(B, N, dtype=torch.float32, device=f1.device) if want_dist else None
+    check(_lib.load().dvm_argmin_exact_f32(_p(f1), _p(f2), B, N, M, d, _p(T), _p(dm), _stream()), "dvm_argmin_exact_f32")
+    return (T, dm) if want_dist else T
+
+
+def knn_cdist(x, y, k):
+    _need_gpu(x, y)
+    x, y = _f(x), _f(y)
+    B, N, C = x.shape
+    M = y.shape[1]
+    idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
+    check(_lib.load().dvm_knn_cdist_f32(_p(x), _p(y), B, N, M, C, k, _p(idx), _stream()), "dvm_knn_cdist_f32")
+    return idx
+
+
+def apply(pi_val, pi_idx, V):
+    _need_gpu(pi_val, pi_idx, V)
+    pi_val, pi_idx, V = _f(pi_val), _i(pi_idx), _f(V)
+    B, N, topk = pi_val.shape
+    M, C = V.shape[1], V.shape[2]
+    out = torch.empty(B, N, C, dtype=torch.float32, device=V.device)
+    check(_lib.load().dvm_softcorr_apply_f32(_p(pi_val), _p(pi_idx), _p(V), B, N, M, topk, C, _p(out), _stream()),
+          "dvm_softcorr_apply_f32")
+    return out
+
+
+def fps(xyz, npoint, start):
+    _need_gpu(xyz, start)
+    xyz, start = _f(xyz), _i(start)
+    B, N, _ = xyz.shape
+    out = torch.empty(B, npoint, dtype=torch.int32, device=xyz.device)
+    check(_lib.load().dvm_fps_f32(_p(xyz), B, N, npoint, _p(start), _p(out), _stream()), "dvm_fps_f32")
+    return out
+
+
+def dg_build(xyz, start):
+    """xyz (B,N,3), start (B,) -> dict(nodes_idx, one_ring, infl_idx, dists, weights, sigma)."""
+    _need_gpu(xyz, start)
+    xyz, start = _f(xyz), _i(start)
+    B, N, _ = xyz.shape
+    Nn = N // 2
+    dev = xyz.device
+    lib = _lib.load()
+    out = dict(nodes_idx=torch.empty(B, Nn, dtype=torch.int32, device=dev),
+               one_ring=torch.empty(B, Nn, 9, dtype=torch.int32, device=dev),
+               infl_idx=torch.empty(B, N, 3, dtype=torch.int32, device=dev),
+               dists=torch.empty(B, N, 3, dtype=torch.float32, device=dev),
+               weights=torch.empty(B, N, 3, dtype=torch.float32, device=dev),
+               sigma=torch.empty(B, dtype=torch.float64, device=dev))
+    nb = lib.dvm_dg_build_workspace_bytes(B, N)
+    ws = workspace(nb, dev, "dg_build")
+    check(lib.dvm_dg_build_f32(_p(xyz), B, N, _p(start), _p(out["nodes_idx"]), _p(out["one_ring"]), _p(out["infl_idx"]),
+                               _p(out["dists"]), _p(out["weights"]), _p(out["sigma"]), _p(ws), nb, _stream()),
+          "dvm_dg_build_f32")
+    return out
+
+
+def dg_warp_arap(xyz, g, def9, want_R=False):
+    """xyz (B,N,3), graph dict, def9 (B,Nn,9) -> warped (B,N,3), arap (B,), sr (B,) [, R (B,Nn,3,3)]."""
+    _need_gpu(xyz, def9)
+    xyz, def9 = _f(xyz), _f(def9)
+    B, N, _ = xyz.shape
+    Nn = N // 2
+    dev = xyz.device
+    lib = _lib.load()
+    warped = torch.empty(B, N, 3, dtype=torch.float32, device=dev)
+    arap = torch.empty(B, dtype=torch.float32, device=dev)
+    sr = torch.empty(B, dtype=torch.float32, device=dev)
+    R = torch.empty(B, Nn, 3, 3, dtype=torch.float32, device=dev) if want_R else None
+    nb = lib.dvm_dg_warp_workspace_bytes(B, N)
+    ws = workspace(nb, dev, "dg_warp")
+    check(lib.dvm_dg_warp_arap_fwd_f32(_p(xyz), B, N, _p(_i(g["nodes_idx"])), _p(_i(g["one_ring"])), _p(_i(g["infl_idx"])),
+                                       _p(_f(g["weights"])), _p(def9), _p(R), _p(warped), _p(arap), _p(sr), _p(ws), nb,
+                                       _stream()), "dvm_dg_warp_arap_fwd_f32")
+    return (warped, arap, sr, R) if want_R else (warped, arap, sr)
+
+
+def chamfer(a, b, want_idx=True):
+    _need_gpu(a, b)
+    a, b = _f(a), _f(b)
+    B, N, _ = a.shape
+    M = b.shape[1]
+    dev = a.device
+    d1 = torch.empty(B, N, dtype=torch.float32, device=dev)
+    d2 = torch.empty(B, M, dtype=torch.float32, device=dev)
+    i1 = torch.empty(B, N, dtype=torch.int32, device=dev) if want_idx else None
+    i2 = torch.empty(B, M, dtype=torch.int32, device=dev) if want_idx else None
+    check(_lib.load().dvm_chamfer_fwd_f32(_p(a), _p(b), B, N, M, _p(d1), _p(d2), _p(i1), _p(i2), _stream()),
+          "dvm_chamfer_fwd_f32")
+    return d1, d2, i1, i2
+
+
+DEFORMER_KEYS = ["conv_layer.weight", "conv_layer.bias"] + [
+    "deformation_decoder_layer.linear.%d.%s" % (li, wb) for li in (0, 2, 4, 6) for wb in ("weight", "bias")]
+
+
+def deformer_weight_list(weights, device):
+    """state_dict (reference key names; '.' may be '__') -> the 10 contiguous fp32 device tensors of the ABI."""
+    out = []
+    for k in DEFORMER_KEYS:
+        v = weights[k] if k in weights else weights[k.replace(".", "__")]
+        v = torch.as_tensor(v)
+        out.append(v.detach().to(device=device, dtype=torch.float32).contiguous().reshape(-1) if "conv_layer" in k
+                   else v.detach().to(device=device, dtype=torch.float32).contiguous())
+    return out
+
+
+def deformer(wl, feat1, feat2, verts1, verts12, idx11, idx22, pi_val, pi_idx, fps1, variant=0):
+    _need_gpu(feat1, feat2, verts1, verts12, idx11, idx22, pi_val, pi_idx, fps1, *wl)
+    feat1, feat2, verts1, verts12, pi_val = _f(feat1), _f(feat2), _f(verts1), _f(verts12), _f(pi_val)
+    idx11, idx22, pi_idx, fps1 = _i(idx11), _i(idx22), _i(pi_idx), _i(fps1)
+    B, N, _ = feat1.shape
+    M = feat2.shape[1]
+    Nn, k, topk = fps1.shape[1], idx11.shape[2], pi_val.shape[2]
+    lib = _lib.load()
+    out = torch.empty(B, Nn, 9, dtype=torch.float32, device=feat1.device)
+    nb = lib.dvm_deformer_workspace_bytes(B, N, M, Nn)
+    ws = workspace(nb, feat1.device, "deformer")
+    check(lib.dvm_deformer_fwd_f32(_p(feat1), _p(feat2), _p(verts1), _p(verts12), _p(idx11), _p(idx22), _p(pi_val),
+                                   _p(pi_idx), _p(fps1), B, N, M, Nn, k, topk, *[_p(w) for w in wl], _p(out), variant,
+                                   _p(ws), nb, _stream()), "dvm_deformer_fwd_f32")
+    return out
+
+
+def map_term(verts12, verts2, idx11, idx22, pi_val, pi_idx):
+    _need_gpu(verts12, verts2, idx11, idx22, pi_val, pi_idx)
+    verts12, verts2, pi_val = _f(verts12), _f(verts2), _f(pi_val)
+    idx11, idx22, pi_idx = _i(idx11), _i(idx22), _i(pi_idx)
+    B, N, _ = verts12.shape
+    M, k, topk = verts2.shape[1], idx11.shape[2], pi_val.shape[2]
+    lib = _lib.load()
+    out = torch.empty(B, dtype=torch.float32, device=verts12.device)
+    nb = lib.dvm_map_term_workspace_bytes(B, N)
+    ws = workspace(nb, verts12.device, "map")
+    check(lib.dvm_map_term_f32(_p(verts12), _p(verts2), _p(idx11), _p(idx22), _p(pi_val), _p(pi_idx), B, N, M, k, topk,
+                               _p(out), _p(ws), nb, _stream()), "dvm_map_term_f32")
+    return out
+
+
+def pair_direction(wl, feat1, feat2, verts1, verts2, alpha, fps_start, with_map=True, out=None):
+    """Config-2 path for B pairs, one direction. Returns dict(warped, verts12, T12, losses[B,4])."""
+    _need_gpu(feat1, feat2, verts1, verts2, fps_start, *wl)
+    feat1, feat2, verts1, verts2, fps_start = _f(feat1), _f(feat2), _f(verts1), _f(verts2), _i(fps_start)
+    B, N, _ = feat1.shape
+    M = feat2.shape[1]
+    dev = feat1.device
+    lib = _lib.load()
+    if out is None:
+        out = dict(warped=torch.empty(B, N, 3, dtype=torch.float32, device=dev),
+                   verts12=torch.empty(B, N, 3, dtype=torch.float32, device=dev),
+                   T12=torch.empty(B, N, dtype=torch.int32, device=dev),
+                   losses=torch.empty(B, 4, dtype=torch.float32, device=dev))
+    nb = lib.dvm_pair_direction_workspace_bytes(B, N, M)
+    ws = workspace(nb, dev, "pair")
+    check(lib.dvm_pair_direction_fwd_f32(_p(feat1), _p(feat2), _p(verts1), _p(verts2), B, N, M, neg_alpha_f32(alpha),
+                                         _p(fps_start), *[_p(w) for w in wl], int(with_map), _p(out["warped"]),
+                                         _p(out["verts12"]), _p(out["T12"]), _p(out["losses"]), _p(ws), nb, _stream()),
+          "dvm_pair_direction_fwd_f32")
+    return out

@@ -1,0 +1,155 @@
+/*
+ * dvm.h — C ABI of libdvm_hip.so: the MI355X (gfx950) implementation of
+ * DV-Matcher's correspondence hot path.
+ *
+ * The reference has no FFI layer (it is pure Python/PyTorch); its boundary
+ * for this path is the Python module API.  Each entry point
+ * below names the reference function(s) it replaces (paths relative to the
+ * reference checkout).  The Python mirror of the reference's modules in
+ * dv-matcher_amd/{models,lib}/ binds these through ctypes; INTEGRATION.md
+ * shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative DVM_E* code;
+ *    dvm_last_error() returns a thread-local message for the last failure;
+ *  - all tensor pointers are caller-owned DEVICE pointers, contiguous,
+ *    row-major, fp32 / int32 (double where stated), 16-byte aligned;
+ *  - `stream` is a hipStream_t (NULL = default stream); calls are
+ *    asynchronous on it, never synchronise, never allocate (graph-capturable);
+ *    scratch comes from the caller: query the size with *_workspace_bytes;
+ *  - B is the batch (pairs or shapes); per-batch tensors are stacked on dim 0;
+ *  - indices are 0-based int32.
+ */
+#ifndef DVM_H
+#define DVM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVM_ABI_VERSION 1
+
+#define DVM_OK 0
+#define DVM_EINVAL (-1)    /* bad argument (shape, null pointer, unsupported size) */
+#define DVM_ELAUNCH (-2)   /* HIP launch / runtime error */
+#define DVM_ENOSPACE (-3)  /* workspace too small */
+
+int dvm_abi_version(void);
+const char *dvm_last_error(void);
+/* number of visible HIP devices (<=0: none) — lets callers fail loudly. */
+int dvm_device_count(void);
+
+/* Launch timing of the soft-correspondence kernel (K1) with HIP events recorded on the
+ * launch stream: enable (pre-creates 2*max_launches events), run, then read the summed
+ * kernel time and launch count (read synchronises on the recorded events and resets). */
+int dvm_profile_enable(int max_launches);
+int dvm_profile_read(double *total_ms, int *launches);
+int dvm_profile_disable(void);
+
+/* x.pow(2).sum(-1) in ATen's summation order (the |a|^2 terms of torch.cdist's
+ * matmul form and of knn_new/knn: models/model.py:274-275, models/loss.py:458-459).
+ * x [rows,K] -> out [rows]. */
+int dvm_rownorm2_f32(const float *x, int rows, int K, float *out, void *stream);
+
+/* knnsearch_t_grad + topk_pi (+ the argmax map)  —  models/loss.py:110-114,
+ * 1339-1347, 1404-1407.   D = cdist(f1,f2) (matmul form, bit-identical squared
+ * distances); P = softmax(D*neg_alpha) over M; keep the `topk` largest of each
+ * row, no renormalisation.  Sparse result, rows ordered by descending P
+ * (ascending distance, ties -> lowest column):
+ *   pi_val [B,N,topk], pi_idx [B,N,topk];
+ *   row_smax [B,N] = max_j s_ij, row_sum [B,N] = sum_j exp(s_ij - smax)  (s = D*neg_alpha)
+ * f1 [B,N,d], f2 [B,M,d]; neg_alpha = (float)(-alpha) < 0; 1 <= topk <= 16; d % 4 == 0, d <= 512.
+ * variant: 0 = auto, 1 = scalar-FMA kernel, 2 = fp32-MFMA kernel (d == 128). */
+size_t dvm_softcorr_workspace_bytes(int B, int N, int M, int d);
+int dvm_softcorr_fwd_f32(const float *f1, const float *f2, int B, int N, int M, int d, float neg_alpha, int topk,
+                         float *pi_val, int32_t *pi_idx, float *row_smax, float *row_sum, int variant, void *ws,
+                         size_t ws_bytes, void *stream);
+
+/* knnsearch_t / search_t — models/loss.py:91-95,121-124; test.py:19-28.
+ * T[b,i] = argmin_j cdist(f1,f2, 'donot_use_mm_for_euclid_dist') (0-based; the
+ * test scripts add 1), ties -> lowest j; dmin [B,N] optional (may be NULL). */
+int dvm_argmin_exact_f32(const float *f1, const float *f2, int B, int N, int M, int d, int32_t *T, float *dmin,
+                         void *stream);
+
+/* knn_grad — models/loss.py:97-101: the k smallest of cdist(x,y) (matmul form)
+ * per row, ascending.  x [B,N,C], y [B,M,C] -> idx [B,N,k]; C <= 16, k <= 16. */
+int dvm_knn_cdist_f32(const float *x, const float *y, int B, int N, int M, int C, int k, int32_t *idx, void *stream);
+
+/* Pi~ @ V for the sparse Pi~ — models/loss.py:1408-1409 (verts), models/model.py:471
+ * (pooled features).  out[b,i,:] = sum_t val[b,i,t] * V[b, idx[b,i,t], :], summed in
+ * ascending column order.  V [B,M,C] -> out [B,N,C]. */
+int dvm_softcorr_apply_f32(const float *pi_val, const int32_t *pi_idx, const float *V, int B, int N, int M, int topk,
+                           int C, float *out, void *stream);
+
+/* farthest_point_sample — lib/deformation_graph_point.py:18-33 with the random
+ * start index made an input.  xyz [B,N,3], start [B] -> out [B,npoint]. */
+int dvm_fps_f32(const float *xyz, int B, int N, int npoint, const int32_t *start, int32_t *out, void *stream);
+
+/* DeformationGraph_geod.construct_graph_euclidean via deformation_graph_node —
+ * lib/deformation_graph_point.py:177-201, models/loss.py:1325-1337.
+ * xyz [B,N,3], start [B] -> nodes_idx [B,Nn] (Nn = N/2), ring [B,Nn,9] (node-local),
+ * infl_idx [B,N,3] (node-local), dists [B,N,3], weights [B,N,3], sigma [B] (double). */
+size_t dvm_dg_build_workspace_bytes(int B, int N);
+int dvm_dg_build_f32(const float *xyz, int B, int N, const int32_t *start, int32_t *nodes_idx, int32_t *ring,
+                     int32_t *infl_idx, float *dists, float *weights, double *sigma, void *ws, size_t ws_bytes,
+                     void *stream);
+
+/* rotation_6d_to_matrix(+identity) and DeformationGraph_geod.forward —
+ * models/loss.py:39-45,1258-1264; lib/deformation_graph_point.py:233-261.
+ * def9 [B,Nn,9] = [t(3), r6(6)] (raw Deformer output) -> R [B,Nn,9] (optional), warped [B,N,3],
+ * arap [B], sr [B] (optional). */
+size_t dvm_dg_warp_workspace_bytes(int B, int N);
+int dvm_dg_warp_arap_fwd_f32(const float *xyz, int B, int N, const int32_t *nodes_idx, const int32_t *ring,
+                             const int32_t *infl_idx, const float *weights, const float *def9, float *R_out,
+                             float *warped, float *arap, float *sr, void *ws, size_t ws_bytes, void *stream);
+
+/* chamfer_3DDist — third-party ChamferDistancePytorch (un-vendored); call sites
+ * models/loss.py:1120,1223,874.  a [B,N,3], b [B,M,3] -> d1 [B,N], d2 [B,M] squared NN
+ * distances, i1 [B,N], i2 [B,M] (optional). */
+int dvm_chamfer_fwd_f32(const float *a, const float *b, int B, int N, int M, float *d1, float *d2, int32_t *i1,
+                        int32_t *i2, void *stream);
+
+/* Deformer.forward — models/model.py:464-478 (+ MLP 433-452), fed the raw features and
+ * kNN indices instead of the (B,N,k,128) gathers of models/loss.py:1254-1255.
+ * feat1 [B,N,128], feat2 [B,M,128], verts1 [B,N,3], verts12 [B,N,3], idx11 [B,N,k],
+ * idx22 [B,M,k], pi_val/pi_idx [B,N,topk], fps1 [B,Nn]; weights: conv_w [k], conv_b [1],
+ * W0 [512,262] b0, W1 [256,512] b1, W2 [128,256] b2, W3 [9,128] b3 -> out [B,Nn,9].
+ * variant: 0/2 = fp32-MFMA MLP, 1 = scalar-FMA MLP (cross-check). */
+size_t dvm_deformer_workspace_bytes(int B, int N, int M, int Nn);
+int dvm_deformer_fwd_f32(const float *feat1, const float *feat2, const float *verts1, const float *verts12,
+                         const int32_t *idx11, const int32_t *idx22, const float *pi_val, const int32_t *pi_idx,
+                         const int32_t *fps1, int B, int N, int M, int Nn, int k, int topk, const float *conv_w,
+                         const float *conv_b, const float *W0, const float *b0, const float *W1, const float *b1,
+                         const float *W2, const float *b2, const float *W3, const float *b3, float *out, int variant,
+                         void *ws, size_t ws_bytes, void *stream);
+
+/* map-loss numerator — models/loss.py:1232-1238 + FrobeniusLoss 476-482:
+ * out[b] = sum_{i,s,c} (verts12[idx11[i,s],c] - sum_t P[i,t] verts2[idx22[pidx[i,t],s],c])^2. */
+size_t dvm_map_term_workspace_bytes(int B, int N);
+int dvm_map_term_f32(const float *verts12, const float *verts2, const int32_t *idx11, const int32_t *idx22,
+                     const float *pi_val, const int32_t *pi_idx, int B, int N, int M, int k, int topk, float *out,
+                     void *ws, size_t ws_bytes, void *stream);
+
+/* One direction of GraphDeformLoss_Neural.deform() for B pairs, forward only, with no
+ * host round trip — models/loss.py:1228-1296, 1401-1410; deform.py:232-257:
+ *   graph(verts1) -> Pi_12 -> verts12 -> kNN(verts1), kNN(verts2) -> Deformer -> rot6d ->
+ *   ED warp + ARAP -> chamfer(warped,verts2), chamfer(verts12,verts2) (+ map term).
+ * Inputs: feat1 [B,N,128], feat2 [B,M,128], verts1 [B,N,3], verts2 [B,M,3], fps_start [B],
+ * Deformer weights as in dvm_deformer_fwd_f32 (k = topk = 10).
+ * Outputs: warped [B,N,3], verts12 [B,N,3], T12 [B,N] (argmax of Pi),
+ *          losses [B,4] = {chamfer(warped,verts2), arap, chamfer(verts12,verts2), map_sum}. */
+size_t dvm_pair_direction_workspace_bytes(int B, int N, int M);
+int dvm_pair_direction_fwd_f32(const float *feat1, const float *feat2, const float *verts1, const float *verts2,
+                               int B, int N, int M, float neg_alpha, const int32_t *fps_start, const float *conv_w,
+                               const float *conv_b, const float *W0, const float *b0, const float *W1,
+                               const float *b1, const float *W2, const float *b2, const float *W3, const float *b3,
+                               int with_map, float *warped, float *verts12, int32_t *T12, float *losses, void *ws,
+                               size_t ws_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVM_H */

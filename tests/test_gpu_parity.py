@@ -1,0 +1,259 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle and the golden vectors.
+
+Bars: integer outputs bit-exact (arg-min / arg-max maps, top-k columns, kNN, FPS, graph
+indices); floats within 1e-4 (absolute, the tolerance BASELINE.json's north_star states),
+most of them far tighter.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def names(prefix):
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, prefix + "*.npz")))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from dvm import ops as _ops
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return _ops
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t if dtype is None else t.to(dtype)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def check_softcorr(ops, f1, f2, alpha, variant, topk=10):
+    val, idx, smax, ssum = ops.softcorr(dev(f1)[None], dev(f2)[None], alpha, topk=topk, variant=variant)
+    oval, oidx, osmax, osum = O.softcorr(f1, f2, alpha, topk=topk)
+    assert np.array_equal(host(idx)[0], oidx), "top-k columns differ from the oracle"
+    np.testing.assert_array_equal(host(smax)[0], osmax)
+    np.testing.assert_allclose(host(ssum)[0], osum, rtol=2e-5)
+    np.testing.assert_allclose(host(val)[0], oval, rtol=5e-5, atol=1e-30)
+    return host(val)[0], host(idx)[0]
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("name", names("softcorr_"))
+def test_softcorr_vs_oracle_and_golden(ops, golden, name, variant):
+    g = golden(name)
+    f1, f2 = g["feat1"][0], g["feat2"][0]
+    val, idx = check_softcorr(ops, f1, f2, float(g["alpha"]), variant)
+    # against the reference itself
+    rv, ri = g["topk_val"][0], g["topk_idx"][0]
+    pad = np.pad(rv, ((0, 0), (1, 1)), constant_values=-1.0)
+    uniq = (rv != pad[:, :-2]) & (rv != pad[:, 2:]) & (rv > 0)
+    assert np.array_equal(idx[uniq], ri[uniq])
+    assert np.array_equal(idx[:, 0], ri[:, 0])  # the arg-max correspondence
+    np.testing.assert_allclose(val, rv, rtol=0, atol=1e-4)
+    v12 = ops.apply(dev(val)[None], dev(idx)[None], dev(g["verts2"]))
+    np.testing.assert_allclose(host(v12)[0], g["verts12"][0], rtol=0, atol=1e-5)
+    np.testing.assert_array_equal(host(v12)[0], O.apply(val, idx, g["verts2"][0]))
+
+
+@pytest.mark.parametrize("shape", [(1, 5, 3, 128), (1, 130, 77, 128), (2, 64, 2049, 128), (1, 257, 64, 64), (1, 100, 100, 36)])
+def test_softcorr_ragged_shapes(ops, shape):
+    """ragged / tiny / non-128 feature sizes, both kernels where applicable."""
+    B, N, M, d = shape
+    g = torch.Generator().manual_seed(N * 1000 + M)
+    f1 = torch.randn(B, N, d, generator=g).numpy()
+    f2 = torch.randn(B, M, d, generator=g).numpy()
+    for b in range(B):
+        for variant in ([1, 2] if d == 128 else [1]):
+            check_softcorr(ops, f1[b], f2[b], 25.0, variant)
+
+
+def test_softcorr_duplicate_rows(ops):
+    """exact ties (duplicated target features): lowest column first, like the oracle."""
+    g = torch.Generator().manual_seed(5)
+    f1 = torch.randn(96, 128, generator=g).numpy()
+    f2 = torch.randn(70, 128, generator=g).numpy()
+    f2 = np.concatenate([f2, f2[:40]], 0)
+    for variant in (1, 2):
+        check_softcorr(ops, f1, f2, 40.0, variant)
+
+
+def test_softcorr_large_alpha_and_topk16(ops):
+    g = torch.Generator().manual_seed(6)
+    f1 = torch.randn(200, 128, generator=g).numpy()
+    f2 = torch.randn(300, 128, generator=g).numpy()
+    for variant in (1, 2):
+        check_softcorr(ops, f1, f2, 101.0, variant)
+        check_softcorr(ops, f1, f2, 10.0, variant, topk=16)
+        check_softcorr(ops, f1, f2, 10.0, variant, topk=1)
+
+
+@pytest.mark.parametrize("name", names("softcorr_"))
+def test_argmin_exact(ops, golden, name):
+    g = golden(name)
+    f1, f2 = g["feat1"][0], g["feat2"][0]
+    T, dm = ops.argmin_exact(dev(f1)[None], dev(f2)[None], want_dist=True)
+    oT, odm = O.argmin_exact(f1, f2)
+    assert np.array_equal(host(T)[0], oT)
+    assert np.array_equal(host(dm)[0], odm)
+    assert np.array_equal(host(T)[0], g["T12"][0, :, 0])  # the reference's knnsearch_t
+
+
+@pytest.mark.parametrize("name", names("knn_"))
+def test_knn_cdist(ops, golden, name):
+    g = golden(name)
+    v = g["verts"][0]
+    idx = host(ops.knn_cdist(dev(v)[None], dev(v)[None], 10))[0]
+    assert np.array_equal(idx, O.knn_cdist(v, v, 10))
+    ref = g["knn_grad_idx"][0]
+    assert (idx != ref).any(1).mean() < 0.01  # exact fp32 ties only (see test_oracle_vs_golden)
+
+
+def test_knn_cdist_general_C(ops):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 150, 7, generator=g).numpy()
+    y = torch.randn(2, 90, 7, generator=g).numpy()
+    idx = host(ops.knn_cdist(dev(x), dev(y), 5))
+    for b in range(2):
+        assert np.array_equal(idx[b], O.knn_cdist(x[b], y[b], 5))
+
+
+@pytest.mark.parametrize("name", names("dg_"))
+def test_graph_build_and_warp(ops, golden, name):
+    g = golden(name)
+    v = g["verts"]
+    N = v.shape[0]
+    start = np.array([int(g["fps_start"])], np.int32)
+    nodes = host(ops.fps(dev(v)[None], N // 2, dev(start)))[0]
+    assert np.array_equal(nodes, g["nodes_idx"])
+    b = ops.dg_build(dev(v)[None], dev(start))
+    ob = O.dg_build(v, int(start[0]))
+    for key in ("nodes_idx", "one_ring", "infl_idx"):
+        assert np.array_equal(host(b[key])[0], ob[key]), key
+        assert np.array_equal(host(b[key])[0], g[key]), key  # and the reference itself
+    assert np.array_equal(host(b["dists"])[0], ob["dists"])
+    np.testing.assert_allclose(host(b["sigma"])[0], ob["sigma"], rtol=1e-13)
+    np.testing.assert_allclose(host(b["weights"])[0], ob["weights"], rtol=0, atol=2e-7)
+    np.testing.assert_allclose(host(b["weights"])[0], g["weights"], rtol=0, atol=3e-7)
+    def9 = np.concatenate([g["T"][0], g["d6"][0]], -1)
+    warped, arap, sr, R = ops.dg_warp_arap(dev(v)[None], b, dev(def9)[None], want_R=True)
+    np.testing.assert_allclose(host(R)[0], g["R"][0], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(host(warped)[0], g["warped"][0], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(float(arap[0]), float(g["arap"]), rtol=1e-5)
+    np.testing.assert_allclose(float(sr[0]), float(g["sr"]), rtol=1e-5)
+
+
+def test_fps_batched_and_large(ops):
+    g = torch.Generator().manual_seed(9)
+    for N in (300, 2048, 4995):
+        v = torch.rand(3, N, 3, generator=g).numpy()
+        start = np.array([0, N // 2, N - 1], np.int32)
+        out = host(ops.fps(dev(v), N // 2, dev(start)))
+        for b in range(3):
+            assert np.array_equal(out[b], O.fps(v[b], N // 2, int(start[b])))
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("name", ["deformer_256x256", "deformer_300x200"])
+def test_deformer_and_chamfer(ops, golden, name, variant):
+    g = golden(name)
+    w = golden("deformer_scape_r_weights")
+    wl = ops.deformer_weight_list(w, "cuda")
+    f1, f2, v1, v2 = dev(g["feat1"]), dev(g["feat2"]), dev(g["verts1"]), dev(g["verts2"])
+    val, idx, _, _ = ops.softcorr(f1, f2, float(g["alpha"]))
+    v12 = ops.apply(val, idx, v2)
+    np.testing.assert_allclose(host(v12), g["verts12"], rtol=0, atol=1e-5)
+    idx11, idx22 = ops.knn_cdist(v1, v1, 10), ops.knn_cdist(v2, v2, 10)
+    out = host(ops.deformer(wl, f1, f2, v1, v12, idx11, idx22, val, idx, dev(g["fps1"]), variant=variant))
+    np.testing.assert_allclose(out, g["deformations"], rtol=0, atol=1e-4)
+    for b in range(out.shape[0]):
+        o = O.deformer(w, g["feat1"][b], g["feat2"][b], g["verts1"][b], host(v12)[b], host(idx11)[b], host(idx22)[b],
+                       host(val)[b], host(idx)[b], g["fps1"][b])
+        np.testing.assert_allclose(out[b], o, rtol=0, atol=2e-6)
+    d1, d2, i1, i2 = ops.chamfer(dev(g["verts12"]), v2)
+    for b in range(out.shape[0]):
+        od1, od2, oi1, oi2 = O.chamfer(g["verts12"][b], g["verts2"][b])
+        assert np.array_equal(host(d1)[b], od1) and np.array_equal(host(d2)[b], od2)
+        assert np.array_equal(host(i1)[b], oi1) and np.array_equal(host(i2)[b], oi2)
+
+
+def _pair_inputs(B, N, M, seed):
+    g = torch.Generator().manual_seed(seed)
+    f1 = 0.3 * torch.relu(torch.randn(B, N, 128, generator=g))
+    f2 = 0.3 * torch.relu(torch.randn(B, M, 128, generator=g))
+    v1 = torch.rand(B, N, 3, generator=g)
+    v2 = torch.rand(B, M, 3, generator=g)
+    start = torch.randint(0, N, (B,), generator=g).int()
+    return f1, f2, v1, v2, start
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 256), (2, 300, 170), (1, 1024, 1024)])
+def test_pair_direction_vs_oracle(ops, golden, shape):
+    B, N, M = shape
+    w = golden("deformer_scape_r_weights")
+    wl = ops.deformer_weight_list(w, "cuda")
+    f1, f2, v1, v2, start = _pair_inputs(B, N, M, 77 + N)
+    out = ops.pair_direction(wl, f1.cuda(), f2.cuda(), v1.cuda(), v2.cuda(), 40.0, start.cuda())
+    torch.cuda.synchronize()
+    for b in range(B):
+        o = O.pair_direction(w, f1[b].numpy(), f2[b].numpy(), v1[b].numpy(), v2[b].numpy(), 40.0, int(start[b]))
+        assert np.array_equal(host(out["T12"])[b], o["T12"])
+        np.testing.assert_allclose(host(out["verts12"])[b], o["verts12"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(host(out["warped"])[b], o["warped"], rtol=0, atol=1e-4)
+        L = host(out["losses"])[b]
+        np.testing.assert_allclose(L[0], o["chamfer_warp"], rtol=1e-4)
+        np.testing.assert_allclose(L[1], o["arap"], rtol=1e-3, atol=1e-7)
+        np.testing.assert_allclose(L[2], o["chamfer_self"], rtol=1e-4)
+        np.testing.assert_allclose(L[3], o["map_sum"], rtol=1e-4)
+
+
+def test_pair_direction_full_size_properties(ops, golden):
+    """BASELINE config 2 size (N = M = 2048): properties that do not need the oracle at full size,
+    plus the oracle on one pair."""
+    B, N, M = 4, 2048, 2048
+    w = golden("deformer_scape_r_weights")
+    wl = ops.deformer_weight_list(w, "cuda")
+    f1, f2, v1, v2, start = _pair_inputs(B, N, M, 1234)
+    d = [t.cuda() for t in (f1, f2, v1, v2)]
+    out = ops.pair_direction(wl, *d, 100.0, start.cuda())
+    # (1) determinism: same launch twice -> identical bits
+    out2 = ops.pair_direction(wl, *d, 100.0, start.cuda(), out=None)
+    for k in out:
+        assert torch.equal(out[k], out2[k]), k
+    # (2) batch independence: pair b alone gives the same bits as inside the batch
+    solo = ops.pair_direction(wl, *[t[2:3] for t in d], 100.0, start[2:3].cuda())
+    for k in out:
+        assert torch.equal(out[k][2:3], solo[k]), k
+    # (3) verts12 is a convex-ish combination of target points: inside their bounding box (Pi rows sum <= 1)
+    assert float(out["verts12"].max()) <= float(d[3].max()) + 1e-6 and float(out["verts12"].min()) >= -1e-6
+    # (4) the arg-max map agrees with brute-force torch on the device up to fp32 ties
+    T = torch.cdist(d[0], d[1]).argmin(-1)
+    assert (T.int() != out["T12"]).float().mean() < 1e-3
+    # (5) one pair against the oracle
+    o = O.pair_direction(w, f1[0].numpy(), f2[0].numpy(), v1[0].numpy(), v2[0].numpy(), 100.0, int(start[0]))
+    assert np.array_equal(host(out["T12"])[0], o["T12"])
+    np.testing.assert_allclose(host(out["warped"])[0], o["warped"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(host(out["losses"])[0], [o["chamfer_warp"], o["arap"], o["chamfer_self"], o["map_sum"]],
+                               rtol=1e-3)
+
+
+def test_errors_are_loud(ops):
+    from dvm._lib import DvmError
+    f = torch.randn(1, 8, 128)
+    with pytest.raises(DvmError):
+        ops.softcorr(f, f, 10.0)  # CPU tensors: no fallback
+    with pytest.raises(DvmError):
+        ops.softcorr(f.cuda(), f.cuda(), 10.0, topk=17)
+    with pytest.raises(DvmError):
+        ops.softcorr(torch.randn(1, 8, 130).cuda(), torch.randn(1, 8, 130).cuda(), 10.0)
+    with pytest.raises(DvmError):
+        ops.softcorr(f.cuda(), f.cuda(), -10.0)
