@@ -187,6 +187,25 @@ __device__ inline float aten_sumsq_row(const float *__restrict__ x, int K) {
     return fin;
 }
 
+// Correctly rounded fp32 sqrt for x >= 0 (+0, subnormal, normal, +inf), written out explicitly:
+// hipcc lowers some (SLP-vectorised) sqrtf calls to the bare 1-ulp v_sqrt_f32 even with
+// -fhip-fp32-correctly-rounded-divide-sqrt, and a 1-ulp distance changes rankings.  Same
+// sequence as LLVM's IEEE expansion: v_sqrt_f32, then pick among {s-1ulp, s, s+1ulp} by the sign
+// of the fused residuals.
+__device__ __forceinline__ float sqrt_rn(float x) {
+    const bool tiny = x < 0x1p-96f;
+    const float xs = tiny ? x * 0x1p+32f : x;
+    float s = __builtin_amdgcn_sqrtf(xs);
+    const int si = __float_as_int(s);
+    const float s_dn = __int_as_float(si - 1), s_up = __int_as_float(si + 1);
+    const float r_dn = fmaf(-s_dn, s, xs);
+    const float r_up = fmaf(-s_up, s, xs);
+    s = (r_dn <= 0.f) ? s_dn : s;
+    s = (r_up > 0.f) ? s_up : s;
+    s = tiny ? s * 0x1p-16f : s;
+    return (xs == 0.f || xs == INFINITY) ? xs : s;
+}
+
 // |x|^2 of a 3-vector in ATen order: ((0 + x0^2) + x1^2) + x2^2
 __device__ __forceinline__ float sumsq3(float x, float y, float z) {
     float a = x * x, b = y * y, c = z * z;

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(128) void argmin_exact_kernel(const float *__restri
         }
 #pragma unroll
         for (int j = 0; j < AM_KT; ++j) {
-            float dv = __fsqrt_rn(acc[j]);
+            float dv = sqrt_rn(acc[j]);
             if (j0 + j < M && dv < best) {
                 best = dv;
                 bj = j0 + j;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(128) void knn_cdist_kernel(const float *__restrict_
             acc = acc + nq;
             acc = acc + pn[j];
             acc = acc > 0.f ? acc : 0.f;
-            kb.insert(__fsqrt_rn(acc), j0 + j);
+            kb.insert(sqrt_rn(acc), j0 + j);
         }
     }
     if (i < N)
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(128) void knn_cdist3_kernel(const float *__restrict
         for (int j = 0; j < lim; ++j) {
             float4 p = pts[j];
             float d2 = d2_mm3(qx, qy, qz, nq, p.x, p.y, p.z, p.w);
-            kb.insert(__fsqrt_rn(d2), j0 + j);
+            kb.insert(sqrt_rn(d2), j0 + j);
         }
     }
     if (i < N)

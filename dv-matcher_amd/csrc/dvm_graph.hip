@@ -141,7 +141,7 @@ __global__ __launch_bounds__(128) void dg_infl_kernel(const float *__restrict__ 
 #pragma unroll 4
         for (int j = 0; j < lim; ++j) {
             float4 q = tp[j];
-            kb.insert(__fsqrt_rn(d2_mm3(q.x, q.y, q.z, q.w, vx, vy, vz, nv)), j0 + j);
+            kb.insert(sqrt_rn(d2_mm3(q.x, q.y, q.z, q.w, vx, vy, vz, nv)), j0 + j);
         }
     }
     double m1 = (double)INFINITY, m2 = (double)INFINITY;
@@ -208,12 +208,12 @@ __global__ __launch_bounds__(256) void dg_weights_kernel(const double *__restric
 __device__ __forceinline__ void rot6d(const float *__restrict__ d, float (&r)[9], float (&t)[3]) {
     float a1x = d[3] + 1.f, a1y = d[4] + 0.f, a1z = d[5] + 0.f;
     float a2x = d[6] + 0.f, a2y = d[7] + 1.f, a2z = d[8] + 0.f;
-    float n1 = __fsqrt_rn((a1x * a1x + a1y * a1y) + a1z * a1z);
+    float n1 = sqrt_rn((a1x * a1x + a1y * a1y) + a1z * a1z);
     n1 = n1 > 1e-12f ? n1 : 1e-12f;
     float b1x = a1x / n1, b1y = a1y / n1, b1z = a1z / n1;
     float dot = (b1x * a2x + b1y * a2y) + b1z * a2z;
     float b2x = a2x - dot * b1x, b2y = a2y - dot * b1y, b2z = a2z - dot * b1z;
-    float n2 = __fsqrt_rn((b2x * b2x + b2y * b2y) + b2z * b2z);
+    float n2 = sqrt_rn((b2x * b2x + b2y * b2y) + b2z * b2z);
     n2 = n2 > 1e-12f ? n2 : 1e-12f;
     b2x = b2x / n2, b2y = b2y / n2, b2z = b2z / n2;
     r[0] = b1x, r[1] = b1y, r[2] = b1z;

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(128) void softcorr_scalar_kernel(const float *__res
         for (int j = 0; j < SC_KT; ++j) {
             float d2 = (acc[j] + na) + kn[j];
             d2 = d2 > 0.f ? d2 : 0.f;
-            dd[j] = __fsqrt_rn(d2);
+            dd[j] = sqrt_rn(d2);
             tmin = fminf(tmin, dd[j]);
         }
         st.rescale(tmin * neg_alpha);
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void softcorr_mfma_kernel(
                 for (int e = 0; e < 4; ++e) {
                     float d2 = (acc[4 * g + e] + na) + nb[e];
                     d2 = d2 > 0.f ? d2 : 0.f;
-                    float dv = __fsqrt_rn(d2);
+                    float dv = sqrt_rn(d2);
                     dd[4 * g + e] = dv;
                     tmin = fminf(tmin, dv);
                 }

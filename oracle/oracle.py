@@ -211,3 +211,10 @@ def densify(val, idx, M):
     out = np.zeros((N, M), np.float32)
     np.put_along_axis(out, idx.astype(np.int64), val, axis=1)
     return out
+
+
+def dot_chain(a, b):
+    a, b = _f(a), _f(b)
+    out = np.empty((a.shape[0], b.shape[0]), np.float32)
+    lib().dvo_dot_chain(_p(a), _p(b), a.shape[0], b.shape[0], a.shape[1], _p(out))
+    return out
