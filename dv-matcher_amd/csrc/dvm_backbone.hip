@@ -1,0 +1,674 @@
+// dvm_backbone.hip — LG-Net (Uni3FC) hot operators on gfx950:
+//   K3  feature-space kNN (knn_new / knn): fp32-MFMA score tiles + per-row radix select
+//   K4  neighbour-to-point attention (N2PAttention[_DIM]) on gathered projections
+//   K5  offset self-attention of SA_Layer: symmetric energy, row softmax, column re-normalisation
+//   positional sin/cos encoding, and the dist-loss term (K10).
+// Reference: models/model.py:267-278 (knn_new), 325-395 (N2PAttention), 97-123 (SA_Layer),
+// 544-561 (pos_encoding_sin_wave); models/loss.py:451-462 (knn), 1351-1396 (dist loss).
+// Layout: all activations are point-major [B][N][C] fp32 in HBM (the host transposes the
+// reference's (B,C,N) once per block), so neighbour rows are contiguous 256/512-B gathers.
+#include "dvm_common.h"
+
+namespace dvm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ============================================================== K3: scores + radix select
+// s_ij = (-|a_i|^2 - (-2 * a_i.b_j)) - |b_j|^2, the dot product a k-ordered fma chain.
+// MFMA orientation: A = queries, B = keys, so a lane owns one key column and a register one
+// query row: rows of S are written as contiguous 128-B segments.
+constexpr int KS_KT = 64, KS_WAVES = 4, KS_QB = 128, KS_THREADS = 256;
+
+template <int D>
+__global__ __launch_bounds__(KS_THREADS, 2) void knn_scores_mfma_kernel(const float *__restrict__ a, const float *__restrict__ bq,
+                                                                       const float *__restrict__ na, const float *__restrict__ nb,
+                                                                       int N, int M, float *__restrict__ S) {
+    constexpr int LDK = D + 4, H = D / 2;
+    __shared__ __attribute__((aligned(16))) float kt[KS_KT * LDK];
+    __shared__ float kn[KS_KT];
+    const int b = blockIdx.y, qt = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r32 = lane & 31, h = lane >> 5;
+    const int qrow = qt * KS_QB + wave * 32 + r32;
+    const int qrc = qrow < N ? qrow : N - 1;
+    const float *qp = a + ((size_t)b * N + qrc) * D;
+    float q[H];
+#pragma unroll
+    for (int c = 0; c < D / 4; ++c) {
+        f32x4 v = *(const f32x4 *)(qp + 4 * c);
+        q[2 * c] = h ? v.y : v.x;
+        q[2 * c + 1] = h ? v.w : v.z;
+    }
+    // norms of the 16 query rows this lane's accumulator registers cover
+    float nq[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int row = qt * KS_QB + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        nq[r] = na[(size_t)b * N + (row < N ? row : N - 1)];
+    }
+    const float *kb = bq + (size_t)b * M * D;
+    for (int j0 = 0; j0 < M; j0 += KS_KT) {
+        __syncthreads();
+        for (int e = tid; e < KS_KT * D / 4; e += KS_THREADS) {
+            int r = e / (D / 4), c = e % (D / 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (j0 + r < M) v = *(const f32x4 *)(kb + (size_t)(j0 + r) * D + 4 * c);
+            float2 ev = {v.x, v.z}, od = {v.y, v.w};
+            *(float2 *)(kt + r * LDK + 2 * c) = ev;
+            *(float2 *)(kt + r * LDK + H + 2 * c) = od;
+        }
+        if (tid < KS_KT) kn[tid] = (j0 + tid < M) ? nb[(size_t)b * M + j0 + tid] : 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const float *krow = kt + (sub * 32 + r32) * LDK + h * H;
+            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < H / 4; ++c) {
+                f32x4 kv = *(const f32x4 *)(krow + 4 * c);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q[4 * c], kv.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q[4 * c + 1], kv.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q[4 * c + 2], kv.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q[4 * c + 3], kv.w, acc, 0, 0, 0);
+            }
+            const int j = j0 + sub * 32 + r32;
+            const float nbj = kn[sub * 32 + r32];
+            if (j < M) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int row = qt * KS_QB + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    float inner = -2.f * acc[r];
+                    float s = (-nq[r] - inner) - nbj;
+                    if (row < N) S[((size_t)b * N + row) * M + j] = s;
+                }
+            }
+        }
+    }
+}
+
+// generic-C scalar scores (any C): thread per (query, key tile)
+__global__ __launch_bounds__(128) void knn_scores_scalar_kernel(const float *__restrict__ a, const float *__restrict__ bq,
+                                                                const float *__restrict__ na, const float *__restrict__ nb, int N,
+                                                                int M, int C, float *__restrict__ S) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float *qp = a + ((size_t)b * N + i) * C;
+    const float nqi = na[(size_t)b * N + i];
+    for (int j = 0; j < M; ++j) {
+        const float *kp = bq + ((size_t)b * M + j) * C;
+        float dot = 0.f;
+        for (int c = 0; c < C; ++c) dot = fmaf(qp[c], kp[c], dot);
+        float inner = -2.f * dot;
+        S[((size_t)b * N + i) * M + j] = (-nqi - inner) - nb[(size_t)b * M + j];
+    }
+}
+
+// order-preserving map float -> uint (ascending), then inverted: smaller key == larger score
+__device__ __forceinline__ unsigned desc_key(float f) {
+    unsigned u = __float_as_uint(f);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ~u;
+}
+
+__device__ __forceinline__ int block_exclusive_scan(int v, int *smem /* [8] */, int &total) {
+    // 256 threads; returns exclusive prefix of v in thread order
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    __syncthreads();
+    if (lane == 63) smem[wave] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += smem[w];
+    total = smem[0] + smem[1] + smem[2] + smem[3];
+    return base + inc - v;
+}
+
+// One workgroup per row: exact k-th key by 4 radix passes, compaction in index order (ties ->
+// lowest index), bitonic sort of the k winners by (key, index).
+template <int EPT>
+__global__ __launch_bounds__(256) void topk_select_kernel(const float *__restrict__ S, int M, int k, int32_t *__restrict__ idx) {
+    __shared__ int hist[256];
+    __shared__ int sc[8];
+    __shared__ int bc[4];
+    __shared__ unsigned long long sel[512];
+    const size_t row = blockIdx.x;
+    const float *s = S + row * M;
+    const int tid = threadIdx.x;
+    unsigned key[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        int j = tid * EPT + e;
+        key[e] = j < M ? desc_key(s[j]) : 0xffffffffu;  // padding sorts last (NaN-free inputs assumed)
+    }
+    unsigned prefix = 0, mask = 0;
+    int remaining = k;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        hist[tid] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            int j = tid * EPT + e;
+            if (j < M && (key[e] & mask) == prefix) atomicAdd(&hist[(key[e] >> shift) & 255], 1);
+        }
+        __syncthreads();
+        int total;
+        int mine = hist[tid];
+        int excl = block_exclusive_scan(mine, sc, total);
+        if (excl < remaining && excl + mine >= remaining) {  // exactly one bin
+            bc[0] = tid;
+            bc[1] = excl;
+        }
+        __syncthreads();
+        prefix |= (unsigned)bc[0] << shift;
+        mask |= 255u << shift;
+        remaining -= bc[1];
+        __syncthreads();
+    }
+    // prefix == k-th smallest key; take all keys < prefix and the first `remaining` keys == prefix
+    int nlt = 0, neq = 0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        int j = tid * EPT + e;
+        if (j < M) {
+            nlt += key[e] < prefix;
+            neq += key[e] == prefix;
+        }
+    }
+    int tot_lt, tot_eq;
+    int plt = block_exclusive_scan(nlt, sc, tot_lt);
+    int peq = block_exclusive_scan(neq, sc, tot_eq);
+    int kp2 = 1;
+    while (kp2 < k) kp2 <<= 1;
+    for (int e = tid; e < kp2; e += 256) sel[e] = ~0ull;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        int j = tid * EPT + e;
+        if (j < M) {
+            if (key[e] < prefix) {
+                sel[plt++] = ((unsigned long long)key[e] << 32) | (unsigned)j;
+            } else if (key[e] == prefix) {
+                if (peq < remaining) sel[tot_lt + peq] = ((unsigned long long)key[e] << 32) | (unsigned)j;
+                peq++;
+            }
+        }
+    }
+    __syncthreads();
+    for (int size = 2; size <= kp2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < kp2 / 2; t += 256) {
+                int lo = (t / stride) * stride * 2 + (t % stride), hi = lo + stride;
+                bool up = ((lo & size) == 0);
+                unsigned long long x = sel[lo], y = sel[hi];
+                if ((x > y) == up) {
+                    sel[lo] = y;
+                    sel[hi] = x;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int t = tid; t < k; t += 256) idx[row * k + t] = (int32_t)(sel[t] & 0xffffffffu);
+}
+
+// ============================================================== positional encoding
+__global__ void minmax_partial_kernel(const float *__restrict__ x, long n, float *__restrict__ part) {
+    __shared__ float smn[256], smx[256];
+    float mn = INFINITY, mx = -INFINITY;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float v = x[i];
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+    }
+    smn[threadIdx.x] = mn;
+    smx[threadIdx.x] = mx;
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            smn[threadIdx.x] = fminf(smn[threadIdx.x], smn[threadIdx.x + o]);
+            smx[threadIdx.x] = fmaxf(smx[threadIdx.x], smx[threadIdx.x + o]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = smn[0];
+        part[2 * blockIdx.x + 1] = smx[0];
+    }
+}
+
+// out[b, c*128 + j, n] = sin(nc * f_j), out[b, c*128 + 64 + j, n] = cos(nc * f_j);
+// nc = 2*((x - mn)/(mx - mn)) - 1, f_j = fl32(pi) * 2^j.   x, out are (B,3,N) / (B,384,N).
+__global__ void posenc_kernel(const float *__restrict__ x, const float *__restrict__ part, int nparts, int B, int N,
+                              float *__restrict__ out) {
+    float mn = INFINITY, mx = -INFINITY;
+    for (int q = 0; q < nparts; ++q) {
+        mn = fminf(mn, part[2 * q]);
+        mx = fmaxf(mx, part[2 * q + 1]);
+    }
+    const long total = (long)B * 3 * 64 * N;
+    const float range = mx - mn;
+    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long)gridDim.x * blockDim.x) {
+        int n = (int)(g % N);
+        int j = (int)((g / N) % 64);
+        int c = (int)((g / ((long)N * 64)) % 3);
+        int b = (int)(g / ((long)N * 64 * 3));
+        float v = x[((size_t)b * 3 + c) * N + n];
+        float t = __fdiv_rn(v - mn, range);
+        float nc = 2.f * t - 1.f;
+        float f = __uint_as_float(0x40490fdbu) * __uint_as_float((unsigned)(127 + j) << 23);  // fl32(pi) * 2^j, exact
+        float kk = nc * f;
+        size_t o = ((size_t)b * 384 + c * 128 + j) * N + n;
+        out[o] = sinf(kk);
+        out[o + (size_t)64 * N] = cosf(kk);
+    }
+}
+
+// ============================================================== K5: SA_Layer attention
+// p [B][N][16] = Wqk x, v [B][N][64] = Wv x + bv (host GEMMs).  E_ij = p_i . p_j is symmetric.
+//   pass 1: row statistics (m_i, l_i) of softmax_j(E_ij)
+//   pass 2: for every column j:  x_r[j,:] = sum_i v_i w_ij / (1e-9 + sum_i w_ij),  w_ij = exp(E_ij - m_i)/l_i
+constexpr int SA_P = 16, SA_C = 64, SA_LDP = 20;
+
+__global__ __launch_bounds__(256) void sa_rowstats_kernel(const float *__restrict__ p, int N, float *__restrict__ stats) {
+    __shared__ __attribute__((aligned(16))) float pt[64 * SA_LDP];
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r32 = lane & 31, h = lane >> 5;
+    const int irow = blockIdx.x * 128 + wave * 32 + r32;
+    const int irc = irow < N ? irow : N - 1;
+    const float *pb = p + (size_t)b * N * SA_P;
+    float pi[8];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        f32x4 v = *(const f32x4 *)(pb + (size_t)irc * SA_P + 4 * c);
+        pi[2 * c] = h ? v.y : v.x;
+        pi[2 * c + 1] = h ? v.w : v.z;
+    }
+    float m = -INFINITY, l = 0.f;
+    for (int j0 = 0; j0 < N; j0 += 64) {
+        __syncthreads();
+        {
+            int r = tid >> 2, c = tid & 3;  // 64 rows x 4 float4
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (j0 + r < N) v = *(const f32x4 *)(pb + (size_t)(j0 + r) * SA_P + 4 * c);
+            float2 ev = {v.x, v.z}, od = {v.y, v.w};
+            *(float2 *)(pt + r * SA_LDP + 2 * c) = ev;
+            *(float2 *)(pt + r * SA_LDP + 8 + 2 * c) = od;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const float *jr = pt + (sub * 32 + r32) * SA_LDP + h * 8;
+            f32x4 a0 = *(const f32x4 *)(jr), a1 = *(const f32x4 *)(jr + 4);
+            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, pi[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, pi[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, pi[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, pi[3], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, pi[4], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, pi[5], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, pi[6], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, pi[7], acc, 0, 0, 0);
+            // this lane: row i = irow, 16 columns j = j0 + sub*32 + (r&3) + 8*(r>>2) + 4*h
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int j = j0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float e = j < N ? acc[r] : -INFINITY;
+                acc[r] = e;
+                tmax = fmaxf(tmax, e);
+            }
+            if (tmax > m) {
+                l = l * __expf(m - tmax);  // m = -inf, l = 0 -> 0 * 0
+                m = tmax;
+            }
+            if (tmax != -INFINITY) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) l += __expf(acc[r] - m);
+            }
+        }
+    }
+    float mo = __shfl_xor(m, 32, 64), lo = __shfl_xor(l, 32, 64);
+    float mm = fmaxf(m, mo);
+    float ll = (m == -INFINITY ? 0.f : l * __expf(m - mm)) + (mo == -INFINITY ? 0.f : lo * __expf(mo - mm));
+    if (h == 0 && irow < N) {
+        stats[((size_t)b * N + irow) * 2] = mm;
+        stats[((size_t)b * N + irow) * 2 + 1] = 1.0f / ll;
+    }
+}
+
+__global__ __launch_bounds__(256) void sa_apply_kernel(const float *__restrict__ p, const float *__restrict__ v,
+                                                       const float *__restrict__ stats, int N, float *__restrict__ xr) {
+    __shared__ __attribute__((aligned(16))) float pt[32 * SA_LDP];
+    __shared__ __attribute__((aligned(16))) float vt[32 * SA_C];
+    __shared__ float st[32 * 2];
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r32 = lane & 31, h = lane >> 5;
+    const int jcol = blockIdx.x * 128 + wave * 32 + r32;
+    const int jc = jcol < N ? jcol : N - 1;
+    const float *pb = p + (size_t)b * N * SA_P;
+    const float *vb = v + (size_t)b * N * SA_C;
+    float pj[8];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        f32x4 q = *(const f32x4 *)(pb + (size_t)jc * SA_P + 4 * c);
+        pj[2 * c] = h ? q.y : q.x;
+        pj[2 * c + 1] = h ? q.w : q.z;
+    }
+    f32x16 o0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, o1 = o0;
+    float colsum = 0.f;
+    for (int i0 = 0; i0 < N; i0 += 32) {
+        __syncthreads();
+        if (tid < 128) {
+            int r = tid >> 2, c = tid & 3;
+            f32x4 q = {0.f, 0.f, 0.f, 0.f};
+            if (i0 + r < N) q = *(const f32x4 *)(pb + (size_t)(i0 + r) * SA_P + 4 * c);
+            float2 ev = {q.x, q.z}, od = {q.y, q.w};
+            *(float2 *)(pt + r * SA_LDP + 2 * c) = ev;
+            *(float2 *)(pt + r * SA_LDP + 8 + 2 * c) = od;
+        } else if (tid < 192) {
+            int r = (tid - 128) >> 1, c = (tid - 128) & 1;
+            st[r * 2 + c] = (i0 + r < N) ? stats[((size_t)b * N + i0 + r) * 2 + c] : 0.f;  // invl = 0 kills padding
+        }
+        for (int e = tid; e < 32 * SA_C / 4; e += 256) {
+            int r = e >> 4, c = e & 15;
+            f32x4 q = {0.f, 0.f, 0.f, 0.f};
+            if (i0 + r < N) q = *(const f32x4 *)(vb + (size_t)(i0 + r) * SA_C + 4 * c);
+            *(f32x4 *)(vt + r * SA_C + 4 * c) = q;
+        }
+        __syncthreads();
+        // E tile: rows = keys i (A operand from LDS), cols = this lane's column j
+        const float *ir = pt + r32 * SA_LDP + h * 8;
+        f32x4 a0 = *(const f32x4 *)(ir), a1 = *(const f32x4 *)(ir + 4);
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, pj[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, pj[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, pj[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, pj[3], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, pj[4], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, pj[5], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, pj[6], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, pj[7], acc, 0, 0, 0);
+        // w_r = exp(E - m_i) / l_i for the 16 key rows of this lane; then x_r += V^T w on the matrix cores:
+        // MFMA step r pairs key rho_r (lanes h=0) with key rho_r+4 (lanes h=1) in both operands.
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int key = (r & 3) + 8 * (r >> 2) + 4 * h;
+            float w = __expf(acc[r] - st[key * 2]) * st[key * 2 + 1];
+            colsum += w;
+            float va = vt[key * SA_C + r32], vb2 = vt[key * SA_C + 32 + r32];
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va, w, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vb2, w, o1, 0, 0, 0);
+        }
+    }
+    colsum += __shfl_xor(colsum, 32, 64);
+    const float inv = 1.0f / (1e-9f + colsum);
+    if (jcol < N) {
+        float *o = xr + ((size_t)b * N + jcol) * SA_C;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int ch = (r & 3) + 8 * (r >> 2) + 4 * h;
+            o[ch] = o0[r] * inv;
+            o[32 + ch] = o1[r] * inv;
+        }
+    }
+}
+
+// ============================================================== K4: N2P attention
+// q, kp, vp [B][N][C] (= Wq x, Wk x, Wv x), idx [B][N][K].  One wave per point:
+//   e_hj = q_h . (kp_j - kp_i)_h / sqrt(D),  a = softmax_j,  out_h = sum_j a_hj (vp_j - vp_i)_h
+template <int C>
+__global__ __launch_bounds__(256) void n2p_attention_kernel(const float *__restrict__ q, const float *__restrict__ kp,
+                                                            const float *__restrict__ vp, const int32_t *__restrict__ idx,
+                                                            int N, int K, int heads, float *__restrict__ out) {
+    constexpr int CPL = C / 64;  // channels per lane
+    const int lane = threadIdx.x & 63;
+    const long pt = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    if (pt >= N) return;
+    const size_t base = (size_t)b * N;
+    const int D = C / heads;                 // 16 or 32
+    const int lanes_per_head = D / CPL;      // 16
+    const float scale = sqrtf((float)D);
+    float qv[CPL], ki[CPL], vi[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        qv[c] = q[(base + pt) * C + lane * CPL + c];
+        ki[c] = kp[(base + pt) * C + lane * CPL + c];
+        vi[c] = vp[(base + pt) * C + lane * CPL + c];
+    }
+    const int32_t *nb = idx + (base + pt) * K;
+    float m = -INFINITY, l = 0.f, acc[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
+    for (int j = 0; j < K; ++j) {
+        const size_t nrow = (base + nb[j]) * C + lane * CPL;
+        float part = 0.f;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) part = fmaf(qv[c], kp[nrow + c] - ki[c], part);
+        for (int o = 1; o < lanes_per_head; o <<= 1) part += __shfl_xor(part, o, 64);
+        const float e = part / scale;
+        const float mn = fmaxf(m, e);
+        const float sc = __expf(m - mn);  // first neighbour: exp(-inf) = 0
+        const float w = __expf(e - mn);
+        l = l * sc + w;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) acc[c] = fmaf(w, vp[nrow + c] - vi[c], acc[c] * sc);
+        m = mn;
+    }
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) out[(base + pt) * C + lane * CPL + c] = acc[c] * inv;
+}
+
+// ============================================================== K10: dist loss term
+// per (b, anchor n): x_j = |feat[idx_j] - feat[a_n]|_2, y_j = dist[b, idx_j, a_n], j < k;
+// term = 1 - |cos(x, y)|;  out[b] = sum_n term.   One wave per (b, n).
+__global__ __launch_bounds__(256) void dist_loss_kernel(const float *__restrict__ feat, const float *__restrict__ dist,
+                                                        const int32_t *__restrict__ anchors, const int32_t *__restrict__ idx,
+                                                        int N, int C, int nA, int k, double *__restrict__ partial) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * (blockDim.x >> 6) + wave;
+    const int b = blockIdx.y;
+    __shared__ double red[4];
+    double term = 0.0;
+    if (n < nA) {
+        const int a = anchors[n];
+        const float *fa = feat + ((size_t)b * N + a) * C;
+        const int32_t *ix = idx + ((size_t)b * nA + n) * k;
+        float sxy = 0.f, sxx = 0.f, syy = 0.f;
+        for (int j = lane; j < k; j += 64) {
+            const int v = ix[j];
+            const float *fv = feat + ((size_t)b * N + v) * C;
+            float s2 = 0.f;
+            for (int c = 0; c < C; c += 4) {
+                f32x4 p = *(const f32x4 *)(fv + c), q = *(const f32x4 *)(fa + c);
+                float d0 = p.x - q.x, d1 = p.y - q.y, d2 = p.z - q.z, d3 = p.w - q.w;
+                s2 = fmaf(d0, d0, s2);
+                s2 = fmaf(d1, d1, s2);
+                s2 = fmaf(d2, d2, s2);
+                s2 = fmaf(d3, d3, s2);
+            }
+            float x = sqrt_rn(s2);
+            float y = dist[((size_t)b * N + v) * N + a];
+            sxy = fmaf(x, y, sxy);
+            sxx = fmaf(x, x, sxx);
+            syy = fmaf(y, y, syy);
+        }
+        sxy = wave_sum(sxy);
+        sxx = wave_sum(sxx);
+        syy = wave_sum(syy);
+        float nx = fmaxf(sqrt_rn(sxx), 1e-8f), ny = fmaxf(sqrt_rn(syy), 1e-8f);
+        float cosv = sxy / (nx * ny);
+        term = 1.0 - (double)fabsf(cosv);
+    }
+    if (lane == 0) red[wave] = term;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(size_t)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void gather_rows_kernel(const float *__restrict__ src, const int32_t *__restrict__ rows, int N, int C, int nR,
+                                   float *__restrict__ dst) {
+    const int b = blockIdx.y;
+    long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (long)nR * C) return;
+    int r = (int)(g / C), c = (int)(g % C);
+    dst[((size_t)b * nR + r) * C + c] = src[((size_t)b * N + rows[r]) * C + c];
+}
+
+__global__ void rownorm2_kernel2(const float *__restrict__ x, int rows, int K, float *__restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    out[i] = aten_sumsq_row(x + (size_t)i * K, K);
+}
+
+int launch_reduce_partials(const double *partial, int B, int nparts, float scale, float *out, int stride, int off, hipStream_t s);
+
+int launch_knn_neg(const float *a, const float *bq, int B, int N, int M, int C, int k, int32_t *idx, float *na, float *nb,
+                   float *S, hipStream_t s) {
+    hipLaunchKernelGGL(rownorm2_kernel2, dim3((B * N + 255) / 256), dim3(256), 0, s, a, B * N, C, na);
+    hipLaunchKernelGGL(rownorm2_kernel2, dim3((B * M + 255) / 256), dim3(256), 0, s, bq, B * M, C, nb);
+    if (C == 128)
+        hipLaunchKernelGGL(knn_scores_mfma_kernel<128>, dim3((N + KS_QB - 1) / KS_QB, B), dim3(KS_THREADS), 0, s, a, bq, na, nb, N,
+                           M, S);
+    else if (C == 64)
+        hipLaunchKernelGGL(knn_scores_mfma_kernel<64>, dim3((N + KS_QB - 1) / KS_QB, B), dim3(KS_THREADS), 0, s, a, bq, na, nb, N,
+                           M, S);
+    else
+        hipLaunchKernelGGL(knn_scores_scalar_kernel, dim3((N + 127) / 128, B), dim3(128), 0, s, a, bq, na, nb, N, M, C, S);
+    int ept = (M + 255) / 256;
+    dim3 grid((unsigned)((size_t)B * N));
+    if (ept <= 8)
+        hipLaunchKernelGGL(topk_select_kernel<8>, grid, dim3(256), 0, s, S, M, k, idx);
+    else if (ept <= 16)
+        hipLaunchKernelGGL(topk_select_kernel<16>, grid, dim3(256), 0, s, S, M, k, idx);
+    else
+        hipLaunchKernelGGL(topk_select_kernel<32>, grid, dim3(256), 0, s, S, M, k, idx);
+    return DVM_OK;
+}
+
+}  // namespace dvm
+
+using namespace dvm;
+
+DVM_EXPORT size_t dvm_knn_neg_workspace_bytes(int B, int N, int M, int C, int k) {
+    (void)C;
+    (void)k;
+    return align_up((size_t)B * N * sizeof(float)) + align_up((size_t)B * M * sizeof(float)) +
+           align_up((size_t)B * N * M * sizeof(float));
+}
+
+DVM_EXPORT int dvm_knn_neg_f32(const float *a, const float *b, int B, int N, int M, int C, int k, int32_t *idx, void *ws,
+                               size_t ws_bytes, void *stream) {
+    DVM_REQUIRE(a && b && idx, "dvm_knn_neg_f32: null pointer");
+    DVM_REQUIRE(B >= 1 && N >= 1 && M >= 1 && C >= 1, "dvm_knn_neg_f32: empty input (B=%d N=%d M=%d C=%d)", B, N, M, C);
+    DVM_REQUIRE(k >= 1 && k <= 512 && k <= M, "dvm_knn_neg_f32: k=%d unsupported (1..min(512,M=%d))", k, M);
+    DVM_REQUIRE(M <= 8192, "dvm_knn_neg_f32: M=%d exceeds 8192", M);
+    DVM_REQUIRE((C != 64 && C != 128) || true, "unreachable");
+    Arena ar(ws, ws_bytes);
+    float *na = ar.take<float>((size_t)B * N);
+    float *nb = ar.take<float>((size_t)B * M);
+    float *S = ar.take<float>((size_t)B * N * M);
+    if (!ar.ok()) {
+        set_error("dvm_knn_neg_f32: workspace too small (%zu < %zu)", ws_bytes, ar.off);
+        return DVM_ENOSPACE;
+    }
+    launch_knn_neg(a, b, B, N, M, C, k, idx, na, nb, S, (hipStream_t)stream);
+    DVM_CHECK_LAUNCH("knn_neg");
+    return DVM_OK;
+}
+
+DVM_EXPORT size_t dvm_pos_encoding_workspace_bytes(void) { return align_up(2 * 256 * sizeof(float)); }
+
+DVM_EXPORT int dvm_pos_encoding_f32(const float *x, int B, int N, float *out, void *ws, size_t ws_bytes, void *stream) {
+    DVM_REQUIRE(x && out && B >= 1 && N >= 1, "dvm_pos_encoding_f32: bad arguments");
+    Arena ar(ws, ws_bytes);
+    float *part = ar.take<float>(2 * 256);
+    if (!ar.ok()) {
+        set_error("dvm_pos_encoding_f32: workspace too small");
+        return DVM_ENOSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    long n = (long)B * 3 * N;
+    int nparts = (int)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256);
+    hipLaunchKernelGGL(minmax_partial_kernel, dim3(nparts), dim3(256), 0, s, x, n, part);
+    long total = (long)B * 3 * 64 * N;
+    int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(posenc_kernel, dim3(blocks), dim3(256), 0, s, x, part, nparts, B, N, out);
+    DVM_CHECK_LAUNCH("pos_encoding");
+    return DVM_OK;
+}
+
+DVM_EXPORT size_t dvm_sa_attention_workspace_bytes(int B, int N) { return align_up((size_t)B * N * 2 * sizeof(float)); }
+
+DVM_EXPORT int dvm_sa_attention_fwd_f32(const float *p, const float *v, int B, int N, float *xr, void *ws, size_t ws_bytes,
+                                        void *stream) {
+    DVM_REQUIRE(p && v && xr && B >= 1 && N >= 1, "dvm_sa_attention_fwd_f32: bad arguments");
+    Arena ar(ws, ws_bytes);
+    float *stats = ar.take<float>((size_t)B * N * 2);
+    if (!ar.ok()) {
+        set_error("dvm_sa_attention_fwd_f32: workspace too small");
+        return DVM_ENOSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((N + 127) / 128, B);
+    hipLaunchKernelGGL(sa_rowstats_kernel, grid, dim3(256), 0, s, p, N, stats);
+    hipLaunchKernelGGL(sa_apply_kernel, grid, dim3(256), 0, s, p, v, stats, N, xr);
+    DVM_CHECK_LAUNCH("sa_attention");
+    return DVM_OK;
+}
+
+DVM_EXPORT int dvm_n2p_attention_fwd_f32(const float *q, const float *kp, const float *vp, const int32_t *idx, int B, int N,
+                                         int C, int K, int heads, float *out, void *stream) {
+    DVM_REQUIRE(q && kp && vp && idx && out, "dvm_n2p_attention_fwd_f32: null pointer");
+    DVM_REQUIRE(B >= 1 && N >= 1, "dvm_n2p_attention_fwd_f32: empty input");
+    DVM_REQUIRE((C == 64 || C == 128) && heads == 4, "dvm_n2p_attention_fwd_f32: C=%d heads=%d unsupported", C, heads);
+    DVM_REQUIRE(K >= 1 && K <= 64, "dvm_n2p_attention_fwd_f32: K=%d unsupported (1..64)", K);
+    dim3 grid((N + 3) / 4, B);
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 64)
+        hipLaunchKernelGGL(n2p_attention_kernel<64>, grid, dim3(256), 0, s, q, kp, vp, idx, N, K, heads, out);
+    else
+        hipLaunchKernelGGL(n2p_attention_kernel<128>, grid, dim3(256), 0, s, q, kp, vp, idx, N, K, heads, out);
+    DVM_CHECK_LAUNCH("n2p_attention");
+    return DVM_OK;
+}
+
+DVM_EXPORT size_t dvm_dist_loss_workspace_bytes(int B, int N, int C, int nA, int k) {
+    return align_up((size_t)B * nA * C * sizeof(float)) + align_up((size_t)B * nA * k * sizeof(int32_t)) +
+           align_up((size_t)B * ((nA + 3) / 4) * sizeof(double)) + dvm_knn_neg_workspace_bytes(B, nA, N, C, k);
+}
+
+DVM_EXPORT int dvm_dist_loss_fwd_f32(const float *feat, const float *dist, const int32_t *anchors, int B, int N, int C, int nA,
+                                     int k, float *out, int32_t *idx_out, void *ws, size_t ws_bytes, void *stream) {
+    DVM_REQUIRE(feat && dist && anchors && out, "dvm_dist_loss_fwd_f32: null pointer");
+    DVM_REQUIRE(B >= 1 && N >= 1 && nA >= 1 && C % 4 == 0, "dvm_dist_loss_fwd_f32: bad sizes");
+    DVM_REQUIRE(k >= 1 && k <= 512 && k <= N, "dvm_dist_loss_fwd_f32: k=%d unsupported", k);
+    Arena ar(ws, ws_bytes);
+    float *fa = ar.take<float>((size_t)B * nA * C);
+    int32_t *idx = ar.take<int32_t>((size_t)B * nA * k);
+    int nblk = (nA + 3) / 4;
+    double *partial = ar.take<double>((size_t)B * nblk);
+    float *na = ar.take<float>((size_t)B * nA);
+    float *nb = ar.take<float>((size_t)B * N);
+    float *S = ar.take<float>((size_t)B * nA * N);
+    if (!ar.ok()) {
+        set_error("dvm_dist_loss_fwd_f32: workspace too small (%zu < %zu)", ws_bytes, ar.off);
+        return DVM_ENOSPACE;
+    }
+    if (idx_out) idx = idx_out;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)(((long)nA * C + 255) / 256), B), dim3(256), 0, s, feat, anchors, N, C, nA,
+                       fa);
+    launch_knn_neg(fa, feat, B, nA, N, C, k, idx, na, nb, S, s);
+    hipLaunchKernelGGL(dist_loss_kernel, dim3(nblk, B), dim3(256), 0, s, feat, dist, anchors, idx, N, C, nA, k, partial);
+    launch_reduce_partials(partial, B, nblk, 1.f, out, 1, 0, s);
+    DVM_CHECK_LAUNCH("dist_loss");
+    return DVM_OK;
+}

@@ -304,6 +304,13 @@ int launch_deformer(const float *feat1, const float *feat2, const float *verts1,
     return DVM_OK;
 }
 
+__global__ void pad_rows_kernel(const float *__restrict__ in, int rows, int I, int stride, float *__restrict__ out) {
+    long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (long)rows * stride) return;
+    int r = (int)(g / stride), c = (int)(g % stride);
+    out[g] = c < I ? in[(size_t)r * I + c] : 0.f;
+}
+
 size_t deformer_ws_bytes(int B, int M, int Nn) {
     Arena ar(nullptr, 0);
     DeformerWs w;
@@ -335,5 +342,39 @@ DVM_EXPORT int dvm_deformer_fwd_f32(const float *feat1, const float *feat2, cons
                              conv_b, W0, b0, W1, b1, W2, b2, W3, b3, out, variant, ws, ws_bytes, (hipStream_t)stream);
     if (rc != DVM_OK) return rc;
     DVM_CHECK_LAUNCH("deformer");
+    return DVM_OK;
+}
+
+/* Deformer's decoder alone (reference MLP, models/model.py:433-452, as used at 476-477):
+ * z [rows,262] -> out [rows,9]. */
+DVM_EXPORT size_t dvm_deformer_mlp_workspace_bytes(int rows) { return deformer_ws_bytes(1, 1, rows); }
+
+DVM_EXPORT int dvm_deformer_mlp_fwd_f32(const float *z, int rows, const float *W0, const float *b0, const float *W1,
+                                        const float *b1, const float *W2, const float *b2, const float *W3, const float *b3,
+                                        float *out, void *ws, size_t ws_bytes, void *stream) {
+    DVM_REQUIRE(z && out && rows >= 1, "dvm_deformer_mlp_fwd_f32: bad arguments");
+    DVM_REQUIRE(W0 && b0 && W1 && b1 && W2 && b2 && W3 && b3, "dvm_deformer_mlp_fwd_f32: null weight pointer");
+    Arena ar(ws, ws_bytes);
+    DeformerWs w;
+    carve(ar, 1, 1, rows, w);
+    if (!ar.ok()) {
+        set_error("dvm_deformer_mlp_fwd_f32: workspace too small (%zu < %zu)", ws_bytes, ar.off);
+        return DVM_ENOSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    long th = (long)rows * DF_ZS;
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, z, rows, DF_IN, DF_ZS, w.z);
+    auto pack = [&](const float *W, int O, int I, int otiles, int steps, float *Wp) {
+        long t2 = (long)otiles * steps * 64;
+        hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, s, W, O, I, otiles, steps, Wp);
+    };
+    pack(W0, 512, DF_IN, 16, 132, w.Wp0);
+    pack(W1, 256, 512, 8, 256, w.Wp1);
+    pack(W2, 128, 256, 4, 128, w.Wp2);
+    pack(W3, 9, 128, 1, 64, w.Wp3);
+    (void)hipFuncSetAttribute((const void *)mlp_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_LDS_BYTES);
+    hipLaunchKernelGGL(mlp_mfma_kernel, dim3((rows + ML_NODES - 1) / ML_NODES), dim3(ML_THREADS), ML_LDS_BYTES, s, w.z, rows,
+                       w.Wp0, b0, w.Wp1, b1, w.Wp2, b2, w.Wp3, b3, out);
+    DVM_CHECK_LAUNCH("deformer_mlp");
     return DVM_OK;
 }

@@ -222,6 +222,28 @@ __device__ __forceinline__ void rot6d(const float *__restrict__ d, float (&r)[9]
     t[0] = d[0], t[1] = d[1], t[2] = d[2];
 }
 
+// rotation_6d_to_matrix proper (models/loss.py:39-45): d6 [rows,6] -> R [rows,9], no identity offset
+__global__ void rot6d_plain_kernel(const float *__restrict__ d6, int total, float *__restrict__ R) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= total) return;
+    float r[9];
+    float a1x = d6[(size_t)n * 6 + 0], a1y = d6[(size_t)n * 6 + 1], a1z = d6[(size_t)n * 6 + 2];
+    float a2x = d6[(size_t)n * 6 + 3], a2y = d6[(size_t)n * 6 + 4], a2z = d6[(size_t)n * 6 + 5];
+    float n1 = sqrt_rn((a1x * a1x + a1y * a1y) + a1z * a1z);
+    n1 = n1 > 1e-12f ? n1 : 1e-12f;
+    float b1x = a1x / n1, b1y = a1y / n1, b1z = a1z / n1;
+    float dot = (b1x * a2x + b1y * a2y) + b1z * a2z;
+    float b2x = a2x - dot * b1x, b2y = a2y - dot * b1y, b2z = a2z - dot * b1z;
+    float n2 = sqrt_rn((b2x * b2x + b2y * b2y) + b2z * b2z);
+    n2 = n2 > 1e-12f ? n2 : 1e-12f;
+    b2x = b2x / n2, b2y = b2y / n2, b2z = b2z / n2;
+    r[0] = b1x, r[1] = b1y, r[2] = b1z;
+    r[3] = b2x, r[4] = b2y, r[5] = b2z;
+    r[6] = b1y * b2z - b1z * b2y, r[7] = b1z * b2x - b1x * b2z, r[8] = b1x * b2y - b1y * b2x;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) R[(size_t)n * 9 + c] = r[c];
+}
+
 __global__ void rot6d_kernel(const float *__restrict__ def9, int total, float *__restrict__ R, float *__restrict__ T) {
     int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= total) return;
@@ -346,6 +368,16 @@ int launch_dg_build(const float *xyz, int B, int N, const int32_t *start, int32_
     return DVM_OK;
 }
 
+int launch_dg_warp_rt(const float *xyz, int B, int N, const int32_t *nodes_idx, const int32_t *ring,
+                      const int32_t *infl_idx, const float *weights, const float *R, const float *T, float *warped,
+                      float *arap, int arap_stride, float *sr, hipStream_t s) {
+    const int Nn = N / 2;
+    hipLaunchKernelGGL(dg_warp_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, xyz, N, Nn, nodes_idx, infl_idx, weights, R, T,
+                       warped);
+    hipLaunchKernelGGL(dg_arap_kernel, dim3(B), dim3(256), 0, s, xyz, N, Nn, nodes_idx, ring, R, T, arap, arap_stride, sr);
+    return DVM_OK;
+}
+
 int launch_dg_warp(const float *xyz, int B, int N, const int32_t *nodes_idx, const int32_t *ring, const int32_t *infl_idx,
                    const float *weights, const float *def9, float *R, float *T, float *warped, float *arap, int arap_stride,
                    float *sr, hipStream_t s) {
@@ -391,27 +423,20 @@ DVM_EXPORT int dvm_dg_build_f32(const float *xyz, int B, int N, const int32_t *s
     return DVM_OK;
 }
 
-DVM_EXPORT size_t dvm_dg_warp_workspace_bytes(int B, int N) {
-    size_t Nn = (size_t)N / 2;
-    return align_up(B * Nn * 9 * sizeof(float)) + align_up(B * Nn * 3 * sizeof(float));
+DVM_EXPORT int dvm_rot6d_f32(const float *d6, int rows, float *R, void *stream) {
+    DVM_REQUIRE(d6 && R && rows >= 1, "dvm_rot6d_f32: bad arguments");
+    hipLaunchKernelGGL(rot6d_plain_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, d6, rows, R);
+    DVM_CHECK_LAUNCH("rot6d");
+    return DVM_OK;
 }
 
 DVM_EXPORT int dvm_dg_warp_arap_fwd_f32(const float *xyz, int B, int N, const int32_t *nodes_idx, const int32_t *ring,
-                                        const int32_t *infl_idx, const float *weights, const float *def9, float *R_out,
-                                        float *warped, float *arap, float *sr, void *ws, size_t ws_bytes, void *stream) {
-    DVM_REQUIRE(xyz && nodes_idx && ring && infl_idx && weights && def9 && warped && arap,
+                                        const int32_t *infl_idx, const float *weights, const float *R, const float *T,
+                                        float *warped, float *arap, float *sr, void *stream) {
+    DVM_REQUIRE(xyz && nodes_idx && ring && infl_idx && weights && R && T && warped && arap,
                 "dvm_dg_warp_arap_fwd_f32: null pointer");
     DVM_REQUIRE(B >= 1 && N >= 2, "dvm_dg_warp_arap_fwd_f32: bad sizes (B=%d N=%d)", B, N);
-    const int Nn = N / 2;
-    Arena ar(ws, ws_bytes);
-    float *R = ar.take<float>((size_t)B * Nn * 9);
-    float *T = ar.take<float>((size_t)B * Nn * 3);
-    if (!ar.ok()) {
-        set_error("dvm_dg_warp_arap_fwd_f32: workspace too small (%zu < %zu)", ws_bytes, ar.off);
-        return DVM_ENOSPACE;
-    }
-    if (R_out) R = R_out;
-    launch_dg_warp(xyz, B, N, nodes_idx, ring, infl_idx, weights, def9, R, T, warped, arap, 1, sr, (hipStream_t)stream);
+    launch_dg_warp_rt(xyz, B, N, nodes_idx, ring, infl_idx, weights, R, T, warped, arap, 1, sr, (hipStream_t)stream);
     DVM_CHECK_LAUNCH("dg_warp_arap");
     return DVM_OK;
 }

@@ -115,22 +115,22 @@ DVM_EXPORT int dvm_pair_direction_fwd_f32(const float *feat1, const float *feat2
                          conv_b, W0, b0, W1, b1, W2, b2, W3, b3, w.def9, 0, w.df_ws, w.df_bytes, s);
     if (rc != DVM_OK) return rc;
     // embedded-deformation warp + ARAP (losses[:,1])
-    launch_dg_warp(verts1, B, N, w.nodes, w.ring, w.infl, w.weights, w.def9, w.R, w.T, warped, losses + 1, 4, nullptr, s);
-    // chamfer(warped, verts2) -> losses[:,0]; chamfer(verts12, verts2) -> losses[:,2]
+    launch_dg_warp(verts1, B, N, w.nodes, w.ring, w.infl, w.weights, w.def9, w.R, w.T, warped, losses + 2, 6, nullptr, s);
+    // chamfer(warped, verts2) -> losses[:,0:2]; chamfer(verts12, verts2) -> losses[:,3:5]
     rc = dvm_chamfer_fwd_f32(warped, verts2, B, N, M, w.d1, w.d2, nullptr, nullptr, s);
     if (rc != DVM_OK) return rc;
-    launch_mean(w.d1, B, N, 1.f, losses, 4, 0, 0, s);
-    launch_mean(w.d2, B, M, 1.f, losses, 4, 0, 1, s);
+    launch_mean(w.d1, B, N, 1.f, losses, 6, 0, 0, s);
+    launch_mean(w.d2, B, M, 1.f, losses, 6, 1, 0, s);
     rc = dvm_chamfer_fwd_f32(verts12, verts2, B, N, M, w.d1, w.d2, nullptr, nullptr, s);
     if (rc != DVM_OK) return rc;
-    launch_mean(w.d1, B, N, 1.f, losses, 4, 2, 0, s);
-    launch_mean(w.d2, B, M, 1.f, losses, 4, 2, 1, s);
+    launch_mean(w.d1, B, N, 1.f, losses, 6, 3, 0, s);
+    launch_mean(w.d2, B, M, 1.f, losses, 6, 4, 0, s);
     if (with_map) {
         launch_map_term(verts12, verts2, w.idx11, w.idx22, w.pval, w.pidx, B, N, M, k, topk, w.partial, s);
-        launch_reduce_partials(w.partial, B, map_term_blocks(N, k), 1.f, losses, 4, 3, s);
+        launch_reduce_partials(w.partial, B, map_term_blocks(N, k), 1.f, losses, 6, 5, s);
     } else {
-        // losses[:,3] = 0 — written by a strided fill through the mean kernel's overwrite path
-        launch_mean(w.d1, B, 1, 0.f, losses, 4, 3, 0, s);
+        // losses[:,5] = 0 — a strided fill through the mean kernel's overwrite path
+        launch_mean(w.d1, B, 1, 0.f, losses, 6, 5, 0, s);
     }
     DVM_CHECK_LAUNCH("pair_direction");
     return DVM_OK;

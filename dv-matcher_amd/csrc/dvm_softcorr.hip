@@ -157,6 +157,53 @@ __global__ __launch_bounds__(128) void softcorr_scalar_kernel(const float *__res
     }
 }
 
+// ------------------------------------------------------------ dense Pi (API compatibility)
+// knnsearch_t_grad as a dense (N x M) matrix for callers that really want it (reference
+// models/loss.py:110-114, deform.py:241).  Recomputes the distances tile by tile and normalises
+// with the row statistics of the fused kernel.
+template <int DUMMY>
+__global__ __launch_bounds__(128) void softcorr_dense_kernel(const float *__restrict__ f1, const float *__restrict__ f2,
+                                                             const float *__restrict__ n1, const float *__restrict__ n2,
+                                                             const float *__restrict__ row_smax, const float *__restrict__ row_sum,
+                                                             int N, int M, int d, float neg_alpha, float *__restrict__ P) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *kt = smem;
+    float *kn = smem + SC_KT * d;
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ic = i < N ? i : N - 1;
+    const float *q = f1 + ((size_t)b * N + ic) * d;
+    const float na = n1[(size_t)b * N + ic];
+    const float smax = row_smax[(size_t)b * N + ic];
+    const float inv = 1.0f / row_sum[(size_t)b * N + ic];
+    const float *kbase = f2 + (size_t)b * M * d;
+    for (int j0 = 0; j0 < M; j0 += SC_KT) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < SC_KT * d / 4; e += blockDim.x) {
+            int r = e / (d / 4), c = e % (d / 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (j0 + r < M) v = *(const f32x4 *)(kbase + (size_t)(j0 + r) * d + 4 * c);
+            *(f32x4 *)(kt + r * d + 4 * c) = v;
+        }
+        if (threadIdx.x < SC_KT) kn[threadIdx.x] = (j0 + threadIdx.x < M) ? n2[(size_t)b * M + j0 + threadIdx.x] : INFINITY;
+        __syncthreads();
+        for (int j = 0; j < SC_KT && j0 + j < M; ++j) {
+            float acc = 0.f;
+            for (int c = 0; c < d; c += 4) {
+                f32x4 qv = *(const f32x4 *)(q + c), kv = *(const f32x4 *)(kt + j * d + c);
+                acc = fmaf(-2.f * qv.x, kv.x, acc);
+                acc = fmaf(-2.f * qv.y, kv.y, acc);
+                acc = fmaf(-2.f * qv.z, kv.z, acc);
+                acc = fmaf(-2.f * qv.w, kv.w, acc);
+            }
+            float d2 = (acc + na) + kn[j];
+            d2 = d2 > 0.f ? d2 : 0.f;
+            float s = sqrt_rn(d2) * neg_alpha;
+            if (i < N) P[((size_t)b * N + i) * M + j0 + j] = exp2f((s - smax) * LOG2E) * inv;
+        }
+    }
+}
+
 // -------------------------------------------------------------- MFMA variant
 constexpr int MF_D = 128;
 constexpr int MF_KT = 64;              // keys per LDS tile (two 32-key MFMA sub-tiles)
@@ -405,5 +452,40 @@ DVM_EXPORT int dvm_softcorr_fwd_f32(const float *f1, const float *f2, int B, int
     }
     prof_end(s);
     DVM_CHECK_LAUNCH("softcorr");
+    return DVM_OK;
+}
+
+DVM_EXPORT size_t dvm_softcorr_dense_workspace_bytes(int B, int N, int M, int d) {
+    return dvm_softcorr_workspace_bytes(B, N, M, d) + 2 * align_up((size_t)B * N * sizeof(float)) +
+           align_up((size_t)B * N * sizeof(float)) + align_up((size_t)B * N * sizeof(int32_t));
+}
+
+DVM_EXPORT int dvm_softcorr_dense_f32(const float *f1, const float *f2, int B, int N, int M, int d, float neg_alpha, float *P,
+                                      void *ws, size_t ws_bytes, void *stream) {
+    DVM_REQUIRE(f1 && f2 && P, "dvm_softcorr_dense_f32: null pointer");
+    DVM_REQUIRE(B >= 1 && N >= 1 && M >= 1, "dvm_softcorr_dense_f32: empty input");
+    DVM_REQUIRE(d >= 4 && d % 4 == 0 && d <= 512, "dvm_softcorr_dense_f32: d=%d unsupported", d);
+    DVM_REQUIRE(neg_alpha < 0.f, "dvm_softcorr_dense_f32: neg_alpha must be negative");
+    Arena ar(ws, ws_bytes);
+    size_t scb = dvm_softcorr_workspace_bytes(B, N, M, d);
+    char *scws = ar.take<char>(scb);
+    float *smax = ar.take<float>((size_t)B * N), *ssum = ar.take<float>((size_t)B * N);
+    float *v1 = ar.take<float>((size_t)B * N);
+    int32_t *i1 = ar.take<int32_t>((size_t)B * N);
+    if (!ar.ok()) {
+        set_error("dvm_softcorr_dense_f32: workspace too small (%zu < %zu)", ws_bytes, ar.off);
+        return DVM_ENOSPACE;
+    }
+    int rc = dvm_softcorr_fwd_f32(f1, f2, B, N, M, d, neg_alpha, 1, v1, i1, smax, ssum, 0, scws, scb, stream);
+    if (rc != DVM_OK) return rc;
+    // the norms are the first two carve-outs of the soft-correspondence workspace
+    Arena a2(scws, scb);
+    float *n1 = a2.take<float>((size_t)B * N);
+    float *n2 = a2.take<float>((size_t)B * M);
+    size_t lds = (size_t)(SC_KT * d + SC_KT) * sizeof(float);
+    (void)hipFuncSetAttribute((const void *)softcorr_dense_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 66 * 1024);
+    hipLaunchKernelGGL(softcorr_dense_kernel<0>, dim3((N + 127) / 128, B), dim3(128), lds, (hipStream_t)stream, f1, f2, n1, n2, smax,
+                       ssum, N, M, d, neg_alpha, P);
+    DVM_CHECK_LAUNCH("softcorr_dense");
     return DVM_OK;
 }

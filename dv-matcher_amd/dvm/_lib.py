@@ -30,12 +30,25 @@ SIGNATURES = {
                                      c_size_t, _P]),
     "dvm_argmin_exact_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "dvm_knn_cdist_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "dvm_knn_neg_workspace_bytes": (c_size_t, [c_int] * 5),
+    "dvm_knn_neg_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_size_t, _P]),
+    "dvm_softcorr_dense_workspace_bytes": (c_size_t, [c_int] * 4),
+    "dvm_softcorr_dense_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, c_size_t, _P]),
+    "dvm_deformer_mlp_workspace_bytes": (c_size_t, [c_int]),
+    "dvm_deformer_mlp_fwd_f32": (c_int, [_P, c_int] + [_P] * 8 + [_P, _P, c_size_t, _P]),
+    "dvm_pos_encoding_workspace_bytes": (c_size_t, []),
+    "dvm_pos_encoding_f32": (c_int, [_P, c_int, c_int, _P, _P, c_size_t, _P]),
+    "dvm_sa_attention_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "dvm_sa_attention_fwd_f32": (c_int, [_P, _P, c_int, c_int, _P, _P, c_size_t, _P]),
+    "dvm_n2p_attention_fwd_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "dvm_dist_loss_workspace_bytes": (c_size_t, [c_int] * 5),
+    "dvm_dist_loss_fwd_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
     "dvm_softcorr_apply_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "dvm_fps_f32": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
     "dvm_dg_build_workspace_bytes": (c_size_t, [c_int, c_int]),
     "dvm_dg_build_f32": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
-    "dvm_dg_warp_workspace_bytes": (c_size_t, [c_int, c_int]),
-    "dvm_dg_warp_arap_fwd_f32": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "dvm_rot6d_f32": (c_int, [_P, c_int, _P, _P]),
+    "dvm_dg_warp_arap_fwd_f32": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dvm_chamfer_fwd_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "dvm_deformer_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dvm_deformer_fwd_f32": (c_int, [_P] * 9 + [c_int] * 6 + [_P] * 10 + [_P, c_int, _P, c_size_t, _P]),

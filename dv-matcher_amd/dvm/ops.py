@@ -142,24 +142,29 @@ def dg_build(xyz, start):
     return out
 
 
-def dg_warp_arap(xyz, g, def9, want_R=False):
-    """xyz (B,N,3), graph dict, def9 (B,Nn,9) -> warped (B,N,3), arap (B,), sr (B,) [, R (B,Nn,3,3)]."""
-    _need_gpu(xyz, def9)
-    xyz, def9 = _f(xyz), _f(def9)
+def rot6d(d6):
+    """rotation_6d_to_matrix: d6 (...,6) -> (...,3,3)."""
+    _need_gpu(d6)
+    d6 = _f(d6)
+    rows = d6.numel() // 6
+    R = torch.empty(*d6.shape[:-1], 3, 3, dtype=torch.float32, device=d6.device)
+    check(_lib.load().dvm_rot6d_f32(_p(d6), rows, _p(R), _stream()), "dvm_rot6d_f32")
+    return R
+
+
+def dg_warp_arap(xyz, g, R, T):
+    """xyz (B,N,3), graph dict, R (B,Nn,3,3), T (B,Nn,3) -> warped (B,N,3), arap (B,), sr (B,)."""
+    _need_gpu(xyz, R, T)
+    xyz, R, T = _f(xyz), _f(R), _f(T)
     B, N, _ = xyz.shape
-    Nn = N // 2
     dev = xyz.device
-    lib = _lib.load()
     warped = torch.empty(B, N, 3, dtype=torch.float32, device=dev)
     arap = torch.empty(B, dtype=torch.float32, device=dev)
     sr = torch.empty(B, dtype=torch.float32, device=dev)
-    R = torch.empty(B, Nn, 3, 3, dtype=torch.float32, device=dev) if want_R else None
-    nb = lib.dvm_dg_warp_workspace_bytes(B, N)
-    ws = workspace(nb, dev, "dg_warp")
-    check(lib.dvm_dg_warp_arap_fwd_f32(_p(xyz), B, N, _p(_i(g["nodes_idx"])), _p(_i(g["one_ring"])), _p(_i(g["infl_idx"])),
-                                       _p(_f(g["weights"])), _p(def9), _p(R), _p(warped), _p(arap), _p(sr), _p(ws), nb,
-                                       _stream()), "dvm_dg_warp_arap_fwd_f32")
-    return (warped, arap, sr, R) if want_R else (warped, arap, sr)
+    check(_lib.load().dvm_dg_warp_arap_fwd_f32(_p(xyz), B, N, _p(_i(g["nodes_idx"])), _p(_i(g["one_ring"])),
+                                               _p(_i(g["infl_idx"])), _p(_f(g["weights"])), _p(R), _p(T), _p(warped),
+                                               _p(arap), _p(sr), _stream()), "dvm_dg_warp_arap_fwd_f32")
+    return warped, arap, sr
 
 
 def chamfer(a, b, want_idx=True):
@@ -225,7 +230,7 @@ def map_term(verts12, verts2, idx11, idx22, pi_val, pi_idx):
 
 
 def pair_direction(wl, feat1, feat2, verts1, verts2, alpha, fps_start, with_map=True, out=None):
-    """Config-2 path for B pairs, one direction. Returns dict(warped, verts12, T12, losses[B,4])."""
+    """Config-2 path for B pairs, one direction. Returns dict(warped, verts12, T12, losses[B,6])."""
     _need_gpu(feat1, feat2, verts1, verts2, fps_start, *wl)
     feat1, feat2, verts1, verts2, fps_start = _f(feat1), _f(feat2), _f(verts1), _f(verts2), _i(fps_start)
     B, N, _ = feat1.shape
@@ -236,7 +241,7 @@ def pair_direction(wl, feat1, feat2, verts1, verts2, alpha, fps_start, with_map=
         out = dict(warped=torch.empty(B, N, 3, dtype=torch.float32, device=dev),
                    verts12=torch.empty(B, N, 3, dtype=torch.float32, device=dev),
                    T12=torch.empty(B, N, dtype=torch.int32, device=dev),
-                   losses=torch.empty(B, 4, dtype=torch.float32, device=dev))
+                   losses=torch.empty(B, 6, dtype=torch.float32, device=dev))
     nb = lib.dvm_pair_direction_workspace_bytes(B, N, M)
     ws = workspace(nb, dev, "pair")
     check(lib.dvm_pair_direction_fwd_f32(_p(feat1), _p(feat2), _p(verts1), _p(verts2), B, N, M, neg_alpha_f32(alpha),
@@ -244,3 +249,117 @@ def pair_direction(wl, feat1, feat2, verts1, verts2, alpha, fps_start, with_map=
                                          _p(out["verts12"]), _p(out["T12"]), _p(out["losses"]), _p(ws), nb, _stream()),
           "dvm_pair_direction_fwd_f32")
     return out
+
+
+def knn_neg(a, b, k):
+    """knn_new / knn: a (B,N,C), b (B,M,C) -> idx (B,N,k) int32, nearest (largest score) first."""
+    _need_gpu(a, b)
+    a, b = _f(a), _f(b)
+    B, N, C = a.shape
+    M = b.shape[1]
+    lib = _lib.load()
+    idx = torch.empty(B, N, k, dtype=torch.int32, device=a.device)
+    nb = lib.dvm_knn_neg_workspace_bytes(B, N, M, C, k)
+    ws = workspace(nb, a.device, "knn_neg")
+    check(lib.dvm_knn_neg_f32(_p(a), _p(b), B, N, M, C, k, _p(idx), _p(ws), nb, _stream()), "dvm_knn_neg_f32")
+    return idx
+
+
+def softcorr_dense(f1, f2, alpha):
+    _need_gpu(f1, f2)
+    f1, f2 = _f(f1), _f(f2)
+    B, N, d = f1.shape
+    M = f2.shape[1]
+    lib = _lib.load()
+    P = torch.empty(B, N, M, dtype=torch.float32, device=f1.device)
+    nb = lib.dvm_softcorr_dense_workspace_bytes(B, N, M, d)
+    ws = workspace(nb, f1.device, "softcorr_dense")
+    check(lib.dvm_softcorr_dense_f32(_p(f1), _p(f2), B, N, M, d, neg_alpha_f32(alpha), _p(P), _p(ws), nb, _stream()),
+          "dvm_softcorr_dense_f32")
+    return P
+
+
+def deformer_mlp(wl, z):
+    """z (..., 262) -> (..., 9) with the Deformer's decoder weights wl (deformer_weight_list)."""
+    _need_gpu(z, *wl)
+    z = _f(z)
+    rows = z.numel() // 262
+    lib = _lib.load()
+    out = torch.empty(*z.shape[:-1], 9, dtype=torch.float32, device=z.device)
+    nb = lib.dvm_deformer_mlp_workspace_bytes(rows)
+    ws = workspace(nb, z.device, "mlp")
+    check(lib.dvm_deformer_mlp_fwd_f32(_p(z), rows, *[_p(w) for w in wl[2:]], _p(out), _p(ws), nb, _stream()),
+          "dvm_deformer_mlp_fwd_f32")
+    return out
+
+
+def pos_encoding(x):
+    """x (B,3,N) -> (B,384,N)."""
+    _need_gpu(x)
+    x = _f(x)
+    B, _, N = x.shape
+    lib = _lib.load()
+    out = torch.empty(B, 384, N, dtype=torch.float32, device=x.device)
+    nb = lib.dvm_pos_encoding_workspace_bytes()
+    ws = workspace(nb, x.device, "posenc")
+    check(lib.dvm_pos_encoding_f32(_p(x), B, N, _p(out), _p(ws), nb, _stream()), "dvm_pos_encoding_f32")
+    return out
+
+
+def sa_attention_pm(p, v):
+    """point-major p (B,N,16), v (B,N,64) -> x_r (B,N,64)."""
+    _need_gpu(p, v)
+    p, v = _f(p), _f(v)
+    B, N, _ = p.shape
+    lib = _lib.load()
+    xr = torch.empty(B, N, 64, dtype=torch.float32, device=p.device)
+    nb = lib.dvm_sa_attention_workspace_bytes(B, N)
+    ws = workspace(nb, p.device, "sa")
+    check(lib.dvm_sa_attention_fwd_f32(_p(p), _p(v), B, N, _p(xr), _p(ws), nb, _stream()), "dvm_sa_attention_fwd_f32")
+    return xr
+
+
+def sa_attention(x, w_qk, w_v, b_v):
+    """x (B,64,N) channel-major like the reference; returns x_r (B,64,N)."""
+    xt = x.transpose(1, 2).contiguous()
+    p = torch.nn.functional.linear(xt, w_qk.reshape(w_qk.shape[0], -1))
+    v = torch.nn.functional.linear(xt, w_v.reshape(w_v.shape[0], -1), b_v)
+    return sa_attention_pm(p, v).transpose(1, 2)
+
+
+def n2p_attention_pm(q, kp, vp, idx, heads=4):
+    _need_gpu(q, kp, vp, idx)
+    q, kp, vp, idx = _f(q), _f(kp), _f(vp), _i(idx)
+    B, N, C = q.shape
+    K = idx.shape[2]
+    out = torch.empty(B, N, C, dtype=torch.float32, device=q.device)
+    check(_lib.load().dvm_n2p_attention_fwd_f32(_p(q), _p(kp), _p(vp), _p(idx), B, N, C, K, heads, _p(out), _stream()),
+          "dvm_n2p_attention_fwd_f32")
+    return out
+
+
+def n2p_attention(x, K, wq, wk, wv, heads=4):
+    """x (B,C,N) channel-major like the reference; returns the attention output (B,C,N)."""
+    C = x.shape[1]
+    xt = x.transpose(1, 2).contiguous()
+    idx = knn_neg(xt, xt, K)
+    w = torch.cat([wq.reshape(C, C), wk.reshape(C, C), wv.reshape(C, C)], 0)
+    qkv = torch.nn.functional.linear(xt, w)
+    out = n2p_attention_pm(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], idx, heads)
+    return out.transpose(1, 2)
+
+
+def dist_loss(feat, dist, anchors, k, want_idx=False):
+    """feat (B,N,C), dist (B,N,N), anchors (nA,) -> (B,) sum over anchors of 1-|cos|."""
+    _need_gpu(feat, dist, anchors)
+    feat, dist, anchors = _f(feat), _f(dist), _i(anchors)
+    B, N, C = feat.shape
+    nA = anchors.shape[0]
+    lib = _lib.load()
+    out = torch.empty(B, dtype=torch.float32, device=feat.device)
+    idx = torch.empty(B, nA, k, dtype=torch.int32, device=feat.device) if want_idx else None
+    nb = lib.dvm_dist_loss_workspace_bytes(B, N, C, nA, k)
+    ws = workspace(nb, feat.device, "dist")
+    check(lib.dvm_dist_loss_fwd_f32(_p(feat), _p(dist), _p(anchors), B, N, C, nA, k, _p(out), _p(idx), _p(ws), nb,
+                                    _stream()), "dvm_dist_loss_fwd_f32")
+    return (out, idx) if want_idx else out

@@ -1,1 +1,221 @@
-"""placeholder"""
+"""LG-Net (`Uni3FC`) and `Deformer` — MI355X path behind the reference's module API.
+
+Mirrors the public names, constructor arguments, forward signatures and state_dict keys of the
+reference's `models/model.py` (Uni3FC 480-761, N2PAttention 325-395, SA_Layer 97-123, Deformer
+454-478, MLP 433-452, knn_new 267-278, index_points 255-264) so that the reference's train.py /
+test.py / deform.py call sequence runs unchanged and its checkpoints load with
+`load_state_dict`.  Hot operators go through the C ABI (include/dvm.h, dvm.ops); the dense
+1x1 convolutions / BatchNorm stay on PyTorch-ROCm as BASELINE.json's north_star prescribes.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from dvm import ops
+from dvm import nn_ops
+
+
+# ------------------------------------------------------------------ index helpers
+def index_points(points, idx):
+    """points (B,N,C), idx (B,N,K) -> (B,N,K,C)."""
+    B, N, K = idx.shape
+    flat = idx.reshape(B, N * K, 1).expand(-1, -1, points.shape[-1]).long()
+    return torch.gather(points, 1, flat).view(B, N, K, -1)
+
+
+def index_points_idx(points, idx):
+    """points (B,N,C), idx (B,S) -> (B,S,C)."""
+    return torch.gather(points, 1, idx.long().unsqueeze(-1).expand(-1, -1, points.shape[-1]))
+
+
+def knn_new(a, b, k):
+    """Feature-space kNN: the k largest of -|a|^2 + 2ab - |b|^2, nearest first (int64, like torch.topk)."""
+    return ops.knn_neg(a, b, k).long()
+
+
+def farthest_point_sample(xyz, npoint):
+    from lib.deformation_graph_point import farthest_point_sample as _fps
+    return _fps(xyz.unsqueeze(0), npoint)
+
+
+# ------------------------------------------------------------------ attention blocks
+class SA_Layer(nn.Module):
+    """Offset self-attention with shared q/k weights and column re-normalisation."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.bn1 = nn.BatchNorm1d(64)  # unused in forward (kept: the reference registers it)
+        self.conv1 = nn.Sequential(nn.Conv1d(128, 64, kernel_size=1, bias=False), self.bn1,
+                                   nn.LeakyReLU(negative_slope=0.2))
+        self.q_conv = nn.Conv1d(channels, channels // 4, 1, bias=False)
+        self.k_conv = nn.Conv1d(channels, channels // 4, 1, bias=False)
+        self.q_conv.weight = self.k_conv.weight  # tied
+        self.v_conv = nn.Conv1d(channels, channels, 1)
+        self.trans_conv = nn.Conv1d(channels, channels, 1)
+        self.after_norm = nn.BatchNorm1d(channels)
+        self.act = nn.ReLU()
+        self.softmax = nn.Softmax(dim=-1)
+
+    def forward(self, x):
+        x_r = nn_ops.sa_attention(x, self.k_conv.weight, self.v_conv.weight, self.v_conv.bias)
+        return x + self.act(self.after_norm(self.trans_conv(x - x_r)))
+
+
+class _N2P(nn.Module):
+    """Neighbour-to-point attention over the K feature-space nearest neighbours (4 heads)."""
+
+    def __init__(self, k, C):
+        super().__init__()
+        self.heads = 4
+        self.K = k
+        self.group_type = 'diff'
+        self.q_conv = nn.Conv2d(C, C, 1, bias=False)
+        self.k_conv = nn.Conv2d(C, C, 1, bias=False)
+        self.v_conv = nn.Conv2d(C, C, 1, bias=False)
+        self.softmax = nn.Softmax(dim=-1)
+        self.ff = nn.Sequential(nn.Conv1d(C, 4 * C, 1, bias=False), nn.LeakyReLU(0.2), nn.Conv1d(4 * C, C, 1, bias=False))
+        self.bn1 = nn.BatchNorm1d(C)
+        self.bn2 = nn.BatchNorm1d(C)
+
+    def forward(self, x):
+        att = nn_ops.n2p_attention(x, self.K, self.q_conv.weight, self.k_conv.weight, self.v_conv.weight, self.heads)
+        x = self.bn1(x + att)
+        return self.bn2(x + self.ff(x))
+
+    @staticmethod
+    def split_heads(x, heads):
+        B, C, N, K = x.shape
+        return x.view(B, heads, C // heads, N, K).permute(0, 1, 3, 4, 2).contiguous()
+
+
+class N2PAttention(_N2P):
+    def __init__(self, k):
+        super().__init__(k, 64)
+
+
+class N2PAttention_DIM(_N2P):
+    def __init__(self, k):
+        super().__init__(k, 128)
+
+
+# ------------------------------------------------------------------ Deformer
+class MLP(nn.Module):
+    def __init__(self, input_dim, output_dim, hidden_dims=[], bias=True, act=nn.ELU()):
+        super().__init__()
+        self.input_dim, self.output_dim, self.hidden_dims, self.act = input_dim, output_dim, hidden_dims, act
+        dims = [input_dim] + list(hidden_dims)
+        fc = []
+        for a, b in zip(dims[:-1], dims[1:]):
+            fc += [nn.Linear(a, b, bias=bias), act]
+        fc.append(nn.Linear(dims[-1], output_dim, bias=bias))
+        if not hidden_dims:
+            fc.append(act)
+        self.linear = nn.Sequential(*fc)
+
+    def forward(self, x):
+        return self.linear(x)
+
+
+class Deformer(nn.Module):
+    """Per-node [translation(3), rotation-6D(6)] from pooled local features (reference 454-478)."""
+
+    def __init__(self, k):
+        super().__init__()
+        self.k = k
+        self.conv_layer = nn.Conv2d(in_channels=k, out_channels=1, kernel_size=(1, 1))
+        self.deformation_decoder_layer = MLP(input_dim=128 * 2 + 3 * 2, output_dim=3 + 6, hidden_dims=[512, 256, 128],
+                                             bias=True, act=nn.ELU())
+
+    def weight_list(self, device=None):
+        sd = {k: v for k, v in self.state_dict().items()}
+        return ops.deformer_weight_list(sd, device if device is not None else next(self.parameters()).device)
+
+    def forward_sparse(self, feat1, feat2, verts1, verts12, idx11, idx22, pi_val, pi_idx, fps1):
+        """Fused path used by the criterion: raw features + kNN indices + sparse Pi (no (B,N,k,128)
+        gathers, no dense Pi).  Shapes as in include/dvm.h::dvm_deformer_fwd_f32."""
+        return nn_ops.deformer_sparse(self, feat1, feat2, verts1, verts12, idx11, idx22, pi_val, pi_idx, fps1)
+
+    def forward(self, feat1_conv, feat2_conv, verts1, verts12, Pi_12, fps1):
+        """Reference signature: feat*_conv (B,N,k,128) gathered features, dense Pi_12 (B,N,M), fps1 (B,Nn)."""
+        w = self.conv_layer.weight.view(1, 1, -1, 1)
+        g1 = (feat1_conv * w).sum(2) + self.conv_layer.bias
+        g2 = (feat2_conv * w).sum(2) + self.conv_layer.bias
+        g2 = torch.matmul(Pi_12, g2)
+        z = torch.cat([index_points_idx(verts1, fps1), index_points_idx(g1, fps1), index_points_idx(verts12, fps1),
+                       index_points_idx(g2, fps1)], dim=-1)
+        return nn_ops.mlp(self, z)
+
+
+# ------------------------------------------------------------------ LG-Net
+class Uni3FC(nn.Module):
+    def __init__(self, k=40):
+        super().__init__()
+        self.device = 'cuda:0'
+        self.k = k
+        self.emb_dims = 512
+        self.out = 128
+        self.bn = nn.BatchNorm1d(384)
+        self.bn0 = nn.BatchNorm1d(64)
+        self.bn1 = nn.BatchNorm1d(self.emb_dims)
+        self.bn2 = nn.BatchNorm1d(self.emb_dims)
+        self.bn3 = nn.BatchNorm1d(128)
+        self.bn4 = nn.BatchNorm1d(128)
+        self.bn5 = nn.BatchNorm1d(128)
+        self.bn6 = nn.BatchNorm1d(128)
+
+        def block(cin, cout, bn):
+            return nn.Sequential(nn.Conv1d(cin, cout, kernel_size=1, bias=False), bn, nn.LeakyReLU(negative_slope=0.2))
+
+        self.conv = block(1152, 384, self.bn)
+        self.conv0 = block(384, 64, self.bn0)
+        self.conv1 = block(256, self.emb_dims, self.bn1)
+        self.conv2 = block(256, self.emb_dims, self.bn2)
+        self.conv3 = block(256 + self.emb_dims, 128, self.bn3)
+        self.conv4 = block(256 + self.emb_dims, 128, self.bn4)
+        self.conv5 = block(256, 128, self.bn5)
+        self.conv6 = block(512, 128, self.bn6)
+        self.n2p_attention1 = N2PAttention(self.k)
+        self.n2p_attention2 = N2PAttention(self.k)
+        self.n2p_attention3 = N2PAttention(self.k)
+        self.n2p_attention4 = N2PAttention(self.k)
+        self.n2p_attention5 = N2PAttention_DIM(self.k)
+        self.n2p_attention6 = N2PAttention_DIM(self.k)
+        self.n2p_attention7 = N2PAttention_DIM(self.k)
+        self.sa1 = SA_Layer(64)
+        self.sa2 = SA_Layer(64)
+        self.sa3 = SA_Layer(64)
+        self.sa4 = SA_Layer(64)
+
+    def pos_encoding_sin_wave(self, coor):
+        """64-octave sin/cos encoding of the batch-normalised coordinates: (B,3,N) -> (B,384,N)."""
+        return nn_ops.pos_encoding(coor)
+
+    def forward(self, x, dino_feat, upsampler=None):
+        """x (B,3,N), dino_feat (B,N,1152) -> (feat (B,N,128), cfeats (B,N,64))."""
+        if dino_feat is None:
+            raise NotImplementedError("the point->image->DINOv2 projection branch is outside this path "
+                                      "(SURVEY §8f-1); pass per-point visual features as dino_feat")
+        B, _, N = x.shape
+        f = self.conv(dino_feat.permute(0, 2, 1))
+        tmp = self.conv0(f + self.pos_encoding_sin_wave(x))
+        x1 = self.n2p_attention1(tmp)
+        x1g = self.sa1(tmp)
+        x2 = self.n2p_attention2(x1)
+        x2g = self.sa2(x1g)
+        x3 = self.n2p_attention3(x2)
+        x3g = self.sa3(x2g)
+        x4 = self.n2p_attention4(x3)
+        x4g = self.sa4(x3g)
+        loc = torch.cat((x1, x2, x3, x4), dim=1)
+        glo = torch.cat((x1g, x2g, x3g, x4g), dim=1)
+        lmax = self.conv1(loc).max(dim=-1, keepdim=True)[0].expand(-1, -1, N)
+        gmax = self.conv2(glo).max(dim=-1, keepdim=True)[0].expand(-1, -1, N)
+        y = torch.cat((self.conv3(torch.cat((lmax, loc), dim=1)), self.conv4(torch.cat((gmax, glo), dim=1))), dim=1)
+        y1 = self.conv5(y)
+        y2 = self.n2p_attention5(y1)
+        y3 = self.n2p_attention6(y2)
+        y4 = self.n2p_attention7(y3)
+        out = self.conv6(torch.cat((y1, y2, y3, y4), dim=1))
+        return out.transpose(2, 1).contiguous().view(B, N, self.out), tmp.permute(0, 2, 1)

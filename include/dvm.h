@@ -78,6 +78,20 @@ int dvm_argmin_exact_f32(const float *f1, const float *f2, int B, int N, int M, 
  * per row, ascending.  x [B,N,C], y [B,M,C] -> idx [B,N,k]; C <= 16, k <= 16. */
 int dvm_knn_cdist_f32(const float *x, const float *y, int B, int N, int M, int C, int k, int32_t *idx, void *stream);
 
+/* knn_new / knn — models/model.py:267-278, models/loss.py:451-462: the k largest of
+ * (-|a|^2 - (-2 a.b)) - |b|^2 per row, descending (ties -> lowest column).
+ * a [B,N,C], b [B,M,C] -> idx [B,N,k]; k <= min(512, M), M <= 8192.  C in {64,128} uses the
+ * fp32 matrix cores; any other C a scalar kernel. */
+size_t dvm_knn_neg_workspace_bytes(int B, int N, int M, int C, int k);
+int dvm_knn_neg_f32(const float *a, const float *b, int B, int N, int M, int C, int k, int32_t *idx, void *ws,
+                    size_t ws_bytes, void *stream);
+
+/* knnsearch_t_grad as a dense matrix — models/loss.py:110-114 (compatibility entry; the
+ * criterion uses dvm_softcorr_fwd_f32).  P [B,N,M] = softmax(cdist(f1,f2) * neg_alpha). */
+size_t dvm_softcorr_dense_workspace_bytes(int B, int N, int M, int d);
+int dvm_softcorr_dense_f32(const float *f1, const float *f2, int B, int N, int M, int d, float neg_alpha, float *P,
+                           void *ws, size_t ws_bytes, void *stream);
+
 /* Pi~ @ V for the sparse Pi~ — models/loss.py:1408-1409 (verts), models/model.py:471
  * (pooled features).  out[b,i,:] = sum_t val[b,i,t] * V[b, idx[b,i,t], :], summed in
  * ascending column order.  V [B,M,C] -> out [B,N,C]. */
@@ -97,14 +111,14 @@ int dvm_dg_build_f32(const float *xyz, int B, int N, const int32_t *start, int32
                      int32_t *infl_idx, float *dists, float *weights, double *sigma, void *ws, size_t ws_bytes,
                      void *stream);
 
-/* rotation_6d_to_matrix(+identity) and DeformationGraph_geod.forward —
- * models/loss.py:39-45,1258-1264; lib/deformation_graph_point.py:233-261.
- * def9 [B,Nn,9] = [t(3), r6(6)] (raw Deformer output) -> R [B,Nn,9] (optional), warped [B,N,3],
- * arap [B], sr [B] (optional). */
-size_t dvm_dg_warp_workspace_bytes(int B, int N);
+/* rotation_6d_to_matrix — models/loss.py:39-45.  d6 [rows,6] -> R [rows,9] (rows b1,b2,b1xb2). */
+int dvm_rot6d_f32(const float *d6, int rows, float *R, void *stream);
+
+/* DeformationGraph_geod.forward — lib/deformation_graph_point.py:233-261.
+ * R [B,Nn,9], T [B,Nn,3] -> warped [B,N,3], arap [B], sr [B] (optional). */
 int dvm_dg_warp_arap_fwd_f32(const float *xyz, int B, int N, const int32_t *nodes_idx, const int32_t *ring,
-                             const int32_t *infl_idx, const float *weights, const float *def9, float *R_out,
-                             float *warped, float *arap, float *sr, void *ws, size_t ws_bytes, void *stream);
+                             const int32_t *infl_idx, const float *weights, const float *R, const float *T,
+                             float *warped, float *arap, float *sr, void *stream);
 
 /* chamfer_3DDist — third-party ChamferDistancePytorch (un-vendored); call sites
  * models/loss.py:1120,1223,874.  a [B,N,3], b [B,M,3] -> d1 [B,N], d2 [B,M] squared NN
@@ -126,6 +140,39 @@ int dvm_deformer_fwd_f32(const float *feat1, const float *feat2, const float *ve
                          const float *W2, const float *b2, const float *W3, const float *b3, float *out, int variant,
                          void *ws, size_t ws_bytes, void *stream);
 
+/* The Deformer's decoder MLP alone — models/model.py:433-452, 476-477.
+ * z [rows,262] -> out [rows,9] (262 -> 512 -> 256 -> 128 -> 9, ELU). */
+size_t dvm_deformer_mlp_workspace_bytes(int rows);
+int dvm_deformer_mlp_fwd_f32(const float *z, int rows, const float *W0, const float *b0, const float *W1,
+                             const float *b1, const float *W2, const float *b2, const float *W3, const float *b3,
+                             float *out, void *ws, size_t ws_bytes, void *stream);
+
+/* Uni3FC.pos_encoding_sin_wave — models/model.py:544-561.  x [B,3,N] -> out [B,384,N]:
+ * nc = 2*((x-min)/(max-min))-1 with the min/max of the WHOLE tensor, 64 octaves pi*2^j. */
+size_t dvm_pos_encoding_workspace_bytes(void);
+int dvm_pos_encoding_f32(const float *x, int B, int N, float *out, void *ws, size_t ws_bytes, void *stream);
+
+/* SA_Layer attention core — models/model.py:113-121.  p [B,N,16] = Wqk x (q and k share the
+ * weight), v [B,N,64] = Wv x + bv, point-major.  energy = p p^T, row softmax, every column
+ * divided by (1e-9 + its sum over rows), x_r = attention^T-weighted sum of v -> xr [B,N,64]. */
+size_t dvm_sa_attention_workspace_bytes(int B, int N);
+int dvm_sa_attention_fwd_f32(const float *p, const float *v, int B, int N, float *xr, void *ws, size_t ws_bytes,
+                             void *stream);
+
+/* N2PAttention[_DIM] attention core — models/model.py:339-350, 375-386.  q/kp/vp [B,N,C] =
+ * Wq x, Wk x, Wv x (point-major; k(x_j - x_i) = kp_j - kp_i by linearity), idx [B,N,K] the
+ * feature-space neighbours -> out [B,N,C] = sum_j softmax_j(q.(kp_j-kp_i)/sqrt(D)) (vp_j - vp_i)
+ * per head.  C in {64,128}, heads = 4, K <= 64. */
+int dvm_n2p_attention_fwd_f32(const float *q, const float *kp, const float *vp, const int32_t *idx, int B, int N,
+                              int C, int K, int heads, float *out, void *stream);
+
+/* dist-loss term — models/loss.py:1351-1396 for one shape batch: anchors [nA] (shared by the
+ * batch), idx = knn(feat[:,anchors], feat, k); x = |feat[idx] - feat[anchor]|, y = dist[b, idx, anchor];
+ * out[b] = sum_n (1 - |cos(x_n, y_n)|).  feat [B,N,C], dist [B,N,N]; idx_out [B,nA,k] optional. */
+size_t dvm_dist_loss_workspace_bytes(int B, int N, int C, int nA, int k);
+int dvm_dist_loss_fwd_f32(const float *feat, const float *dist, const int32_t *anchors, int B, int N, int C, int nA,
+                          int k, float *out, int32_t *idx_out, void *ws, size_t ws_bytes, void *stream);
+
 /* map-loss numerator — models/loss.py:1232-1238 + FrobeniusLoss 476-482:
  * out[b] = sum_{i,s,c} (verts12[idx11[i,s],c] - sum_t P[i,t] verts2[idx22[pidx[i,t],s],c])^2. */
 size_t dvm_map_term_workspace_bytes(int B, int N);
@@ -140,7 +187,9 @@ int dvm_map_term_f32(const float *verts12, const float *verts2, const int32_t *i
  * Inputs: feat1 [B,N,128], feat2 [B,M,128], verts1 [B,N,3], verts2 [B,M,3], fps_start [B],
  * Deformer weights as in dvm_deformer_fwd_f32 (k = topk = 10).
  * Outputs: warped [B,N,3], verts12 [B,N,3], T12 [B,N] (argmax of Pi),
- *          losses [B,4] = {chamfer(warped,verts2), arap, chamfer(verts12,verts2), map_sum}. */
+ *          losses [B,6] = {mean d(warped->verts2), mean d(verts2->warped), arap,
+ *                          mean d(verts12->verts2), mean d(verts2->verts12), map_sum}
+ *          (squared NN distances; chamfer_loss = [0]+[1], the partial variant keeps one side). */
 size_t dvm_pair_direction_workspace_bytes(int B, int N, int M);
 int dvm_pair_direction_fwd_f32(const float *feat1, const float *feat2, const float *verts1, const float *verts2,
                                int B, int N, int M, float neg_alpha, const int32_t *fps_start, const float *conv_w,

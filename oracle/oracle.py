@@ -197,12 +197,12 @@ def pair_direction(weights, feat1, feat2, verts1, verts2, alpha, fps_start, with
     warped = np.empty((N, 3), np.float32)
     verts12 = np.empty((N, 3), np.float32)
     T12 = np.empty(N, np.int32)
-    losses = np.empty(4, np.float32)
+    losses = np.empty(6, np.float32)
     lib().dvo_pair_direction(_p(feat1), _p(feat2), _p(verts1), _p(verts2), N, M, ctypes.c_float(neg_alpha_f32(alpha)),
                              int(fps_start), _p(cw), ctypes.c_float(cb), *[_p(m) for m in mats], int(with_map),
                              _p(warped), _p(verts12), _p(T12), _p(losses))
-    return dict(warped=warped, verts12=verts12, T12=T12, chamfer_warp=float(losses[0]), arap=float(losses[1]),
-                chamfer_self=float(losses[2]), map_sum=float(losses[3]))
+    return dict(warped=warped, verts12=verts12, T12=T12, losses=losses, chamfer_warp=float(losses[0] + losses[1]),
+                arap=float(losses[2]), chamfer_self=float(losses[3] + losses[4]), map_sum=float(losses[5]))
 
 
 def densify(val, idx, M):

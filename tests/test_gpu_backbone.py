@@ -1,0 +1,200 @@
+"""-m gpu: LG-Net operators, the reference-named modules and the whole criterion on the MI355X,
+against golden vectors from the reference and the torch / C oracles."""
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+from weights_init import reinit  # noqa: E402
+
+from oracle import oracle as O  # noqa: E402
+from oracle import torch_ref as TR  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from dvm import ops as _ops
+    assert torch.cuda.is_available()
+    return _ops
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def rank_equal_up_to_ties(idx, ref, scores):
+    bad = np.unique(np.argwhere(idx != ref)[:, 0])
+    assert len(bad) <= max(1, idx.shape[0] // 50), len(bad)
+    for r in bad:
+        k = scores[r][ref[r]]
+        for c in np.argwhere(idx[r] != ref[r])[:, 0]:
+            run = np.argwhere(k == k[c])[:, 0]
+            assert len(run) > 1 and sorted(idx[r][run]) == sorted(ref[r][run]), (r, c)
+
+
+@pytest.mark.parametrize("name", ["knn_rand_256", "knn_scape_1024", "knn_rand_2048"])
+def test_knn_neg(ops, golden, name):
+    g = golden(name)
+    f = g["feat64"]
+    idx = host(ops.knn_neg(dev(f), dev(f), 40))[0]
+    assert np.array_equal(idx, O.knn_neg(f[0], f[0], 40))          # oracle: bit-exact incl. tie order
+    s = TR.knn_scores(torch.from_numpy(f), torch.from_numpy(f))[0].numpy()
+    rank_equal_up_to_ties(idx, g["knn_new_idx"][0], s)               # reference: up to exact fp32 ties
+    f = g["feat128"]
+    a = f[:, g["anchors"]]
+    k = g["knn_idx"].shape[-1]
+    idx = host(ops.knn_neg(dev(a), dev(f), k))[0]
+    assert np.array_equal(idx, O.knn_neg(a[0], f[0], k))
+    rank_equal_up_to_ties(idx, g["knn_idx"][0], TR.knn_scores(torch.from_numpy(a), torch.from_numpy(f))[0].numpy())
+
+
+def test_knn_neg_shapes(ops):
+    g = torch.Generator().manual_seed(11)
+    for (B, N, M, C, k) in [(2, 70, 300, 36, 17), (1, 129, 65, 64, 64), (1, 10, 600, 128, 500), (1, 300, 3000, 64, 40)]:
+        a, b = torch.randn(B, N, C, generator=g), torch.randn(B, M, C, generator=g)
+        b[:, 5] = b[:, 3]  # an exact tie
+        idx = host(ops.knn_neg(a.cuda(), b.cuda(), k))
+        for bb in range(B):
+            assert np.array_equal(idx[bb], O.knn_neg(a[bb].numpy(), b[bb].numpy(), k)), (N, M, C, k)
+
+
+def test_pos_encoding(ops, golden):
+    g = golden("bb_posenc")
+    out = host(ops.pos_encoding(dev(g["x"])))
+    # low octaves tight; the top octaves evaluate sin/cos at |arg| up to 3e19 where the device libm's
+    # range reduction decides everything: compare all of it anyway
+    np.testing.assert_allclose(out, g["pos"], rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_sa_layer(ops, golden, mode):
+    import models.model as mm
+    g = golden("bb_sa_" + mode)
+    sa = reinit(mm.SA_Layer(64), salt=2).cuda()
+    getattr(sa, mode)()
+    with torch.no_grad():
+        out = sa(dev(g["x"]))
+    np.testing.assert_allclose(host(out), g["out"], rtol=0, atol=1e-4)
+    x = dev(g["x"])
+    xr = ops.sa_attention(x, sa.k_conv.weight, sa.v_conv.weight, sa.v_conv.bias)
+    ref = TR.sa_attention(x, sa.k_conv.weight, sa.v_conv.weight, sa.v_conv.bias)
+    np.testing.assert_allclose(host(xr), host(ref), rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("name,C", [("n2p64", 64), ("n2p128", 128)])
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_n2p_block(ops, golden, name, C, mode):
+    import models.model as mm
+    g = golden("bb_%s_%s" % (name, mode))
+    blk = reinit((mm.N2PAttention if C == 64 else mm.N2PAttention_DIM)(40), salt=3).cuda()
+    getattr(blk, mode)()
+    x = dev(g["x"])
+    xt = x.transpose(1, 2).contiguous()
+    idx = host(ops.knn_neg(xt, xt, 40))
+    assert (idx != g["knn_idx"]).any(-1).mean() < 0.02
+    with torch.no_grad():
+        out = blk(x)
+    np.testing.assert_allclose(host(out), g["out"], rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_uni3fc(ops, golden, mode):
+    import models.model as mm
+    g = golden("bb_uni3fc_" + mode)
+    net = reinit(mm.Uni3FC(k=40), salt=4).cuda()
+    getattr(net, mode)()
+    with torch.no_grad():
+        feat, cf = net(dev(g["xyz"]), dev(g["dino"]).float(), None)
+    assert feat.shape == g["feat"].shape and cf.shape == g["cfeats"].shape
+    np.testing.assert_allclose(host(cf), g["cfeats"], rtol=0, atol=1e-4)
+    err = np.abs(host(feat) - g["feat"])
+    # kNN neighbourhoods are discrete: an fp32-level tie flip changes a point's feature visibly, so
+    # bound the bulk tightly and the tail loosely
+    assert np.median(err) < 1e-5 and np.quantile(err, 0.999) < 1e-3, (np.median(err), err.max())
+
+
+def test_deformer_reference_signature(ops, golden):
+    """Deformer.forward with the reference's own (B,N,k,128) / dense-Pi arguments."""
+    import models.loss as ml
+    import models.model as mm
+    g = golden("deformer_256x256")
+    w = golden("deformer_scape_r_weights")
+    d = mm.Deformer(10)
+    d.load_state_dict({k.replace("__", "."): torch.from_numpy(v) for k, v in w.items()})
+    d = d.cuda().eval()
+    f1, f2, v1, v2 = dev(g["feat1"]), dev(g["feat2"]), dev(g["verts1"]), dev(g["verts2"])
+    Pi = ml.knnsearch_t_grad(f1, f2, alpha=float(g["alpha"]))
+    crit = ml.GraphDeformLoss_Neural(save_name="t")
+    Pk = crit.topk_pi(Pi)
+    v12 = torch.matmul(Pk, v2)
+    np.testing.assert_allclose(host(v12), g["verts12"], rtol=0, atol=1e-5)
+    idx11, idx22 = ml.knn_grad(v1, v1, 10), ml.knn_grad(v2, v2, 10)
+    with torch.no_grad():
+        out = d(ml.index_points(f1, idx11), ml.index_points(f2, idx22), v1, v12, Pk, dev(g["fps1"]).long())
+    np.testing.assert_allclose(host(out), g["deformations"], rtol=0, atol=1e-4)
+
+
+def _criterion_case(golden, name, cls_name, kw):
+    import models.loss as ml
+    import models.model as mm
+    g = golden(name)
+    w = golden("deformer_scape_r_weights")
+    d = mm.Deformer(10)
+    d.load_state_dict({k.replace("__", "."): torch.from_numpy(v) for k, v in w.items()})
+    d = d.cuda().train()
+    crit = getattr(ml, cls_name)(save_name="t", **kw)
+    f1, f2, v1, v2 = dev(g["feat1"]), dev(g["feat2"]), dev(g["verts1"]), dev(g["verts2"])
+    dist1, dist2 = torch.cdist(v1, v1), torch.cdist(v2, v2)
+    random.seed(int(g["py_seed"]))
+    torch.manual_seed(int(g["torch_seed"]))
+    with torch.no_grad():
+        out = crit(f1, f2, dist1, dist2, v1, v2, np.float64(g["alpha"]), d)
+    return g, [float(o) for o in out]
+
+
+def test_criterion_full(golden):
+    kw = dict(k_deform=10, w_dist=0.02, w_map=0.005, k_dist=50, N_dist=100, partial=False, w_deform=0.5, w_img=0,
+              w_rank=0, w_self_rec=0.5, w_cd=0.1, w_arap=0.01)
+    for name in ("loss_full_256", "loss_full_scape_384"):
+        g, out = _criterion_case(golden, name, "GraphDeformLoss_Neural", kw)
+        ref = [float(g[k]) for k in ("loss", "dist_loss", "deform_loss", "map_loss", "self_rec_loss")]
+        np.testing.assert_allclose(out, ref, rtol=2e-4, err_msg=name)
+
+
+def test_criterion_partial(golden):
+    kw = dict(k_deform=10, w_dist=0.02, w_map=0.005, k_dist=30, N_dist=60, partial=True, w_deform=1000, w_img=0,
+              w_rank=0, w_self_rec=1000, w_cd=0.1, w_arap=0.01)
+    g, out = _criterion_case(golden, "loss_partial_256x120", "GraphDeformLoss_Neural_Partial", kw)
+    ref = [float(g[k]) for k in ("loss", "dist_loss", "deform_loss", "map_loss", "self_rec_loss")]
+    np.testing.assert_allclose(out, ref, rtol=2e-4)
+
+
+def test_dist_loss_vs_torch(ops):
+    g = torch.Generator().manual_seed(21)
+    B, N, C, nA, k = 2, 300, 128, 40, 25
+    feat = torch.randn(B, N, C, generator=g).cuda()
+    v = torch.rand(B, N, 3, generator=g).cuda()
+    dist = torch.cdist(v, v)
+    anchors = torch.randperm(N, generator=g)[:nA].cuda()
+    out = ops.dist_loss(feat, dist, anchors, k)
+    ref = TR.dist_loss_term(feat, dist, anchors, k)
+    np.testing.assert_allclose(host(out), host(ref), rtol=1e-5)
+
+
+def test_softcorr_dense_rows_sum_to_one(ops):
+    g = torch.Generator().manual_seed(22)
+    f1, f2 = torch.randn(2, 150, 128, generator=g).cuda(), torch.randn(2, 90, 128, generator=g).cuda()
+    P = ops.softcorr_dense(f1, f2, 12.5)
+    np.testing.assert_allclose(host(P.sum(-1)), 1.0, rtol=1e-5)
+    ref = torch.softmax(torch.cdist(f1, f2) * ops.neg_alpha_f32(12.5), -1)
+    np.testing.assert_allclose(host(P), host(ref), rtol=0, atol=1e-5)

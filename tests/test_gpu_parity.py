@@ -145,8 +145,10 @@ def test_graph_build_and_warp(ops, golden, name):
     np.testing.assert_allclose(host(b["weights"])[0], ob["weights"], rtol=0, atol=2e-7)
     np.testing.assert_allclose(host(b["weights"])[0], g["weights"], rtol=0, atol=3e-7)
     def9 = np.concatenate([g["T"][0], g["d6"][0]], -1)
-    warped, arap, sr, R = ops.dg_warp_arap(dev(v)[None], b, dev(def9)[None], want_R=True)
+    iden = np.array([1, 0, 0, 0, 1, 0], np.float32)
+    R = ops.rot6d(dev(g["d6"] + iden))
     np.testing.assert_allclose(host(R)[0], g["R"][0], rtol=0, atol=1e-6)
+    warped, arap, sr = ops.dg_warp_arap(dev(v)[None], b, R, dev(g["T"]))
     np.testing.assert_allclose(host(warped)[0], g["warped"][0], rtol=0, atol=1e-5)
     np.testing.assert_allclose(float(arap[0]), float(g["arap"]), rtol=1e-5)
     np.testing.assert_allclose(float(sr[0]), float(g["sr"]), rtol=1e-5)
@@ -210,10 +212,8 @@ def test_pair_direction_vs_oracle(ops, golden, shape):
         np.testing.assert_allclose(host(out["verts12"])[b], o["verts12"], rtol=0, atol=1e-6)
         np.testing.assert_allclose(host(out["warped"])[b], o["warped"], rtol=0, atol=1e-4)
         L = host(out["losses"])[b]
-        np.testing.assert_allclose(L[0], o["chamfer_warp"], rtol=1e-4)
-        np.testing.assert_allclose(L[1], o["arap"], rtol=1e-3, atol=1e-7)
-        np.testing.assert_allclose(L[2], o["chamfer_self"], rtol=1e-4)
-        np.testing.assert_allclose(L[3], o["map_sum"], rtol=1e-4)
+        np.testing.assert_allclose(L, o["losses"], rtol=1e-3, atol=1e-7)
+        np.testing.assert_allclose(L[[3, 4, 5]], o["losses"][[3, 4, 5]], rtol=1e-4)
 
 
 def test_pair_direction_full_size_properties(ops, golden):
@@ -242,8 +242,7 @@ def test_pair_direction_full_size_properties(ops, golden):
     o = O.pair_direction(w, f1[0].numpy(), f2[0].numpy(), v1[0].numpy(), v2[0].numpy(), 100.0, int(start[0]))
     assert np.array_equal(host(out["T12"])[0], o["T12"])
     np.testing.assert_allclose(host(out["warped"])[0], o["warped"], rtol=0, atol=1e-4)
-    np.testing.assert_allclose(host(out["losses"])[0], [o["chamfer_warp"], o["arap"], o["chamfer_self"], o["map_sum"]],
-                               rtol=1e-3)
+    np.testing.assert_allclose(host(out["losses"])[0], o["losses"], rtol=1e-3)
 
 
 def test_errors_are_loud(ops):
