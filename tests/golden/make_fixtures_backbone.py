@@ -39,7 +39,7 @@ def run(rm, save):
         net = reinit(rm.Uni3FC(k=40), salt=4)
         getattr(net, mode)()
         xyz = torch.rand(B, 3, N, generator=g)
-        dino = torch.randn(B, N, 1152, generator=g)
+        dino = torch.randn(B, N, 1152, generator=g).half().float()  # exactly representable in fp16 (stored as such)
         with torch.no_grad():
             feat, cf = net(xyz, dino, None)
         save("bb_uni3fc_" + mode, xyz=xyz, dino=dino.half(), feat=feat, cfeats=cf)
