@@ -1,0 +1,65 @@
+"""N > 1 path on CPU: two gloo processes exercise the pair sharding, the single-bucket gradient
+all-reduce and the batch-global min/max (what the RCCL path does on GPUs)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, os.path.join(ROOT, "dv-matcher_amd"))
+    from dvm.dist import FlatGradBucket, global_minmax, shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ELU(), torch.nn.Linear(5, 3))
+        unused = torch.nn.Parameter(torch.zeros(4))  # a parameter that never gets a gradient
+        data = torch.arange(7 * 6, dtype=torch.float32).view(7, 6) / 10.0  # 7 "pairs"
+        lo, hi = shard_range(7, rank, world)
+        loss = net(data[lo:hi]).pow(2).sum() / 7.0 * world  # DDP convention: mean over ranks of local losses
+        loss.backward()
+        bucket = FlatGradBucket(list(net.parameters()) + [unused])
+        bucket.all_reduce_mean()
+        mn, mx = global_minmax(data[lo:hi])
+        ret[rank] = ([p.grad.clone() for p in net.parameters()], unused.grad.clone(), (lo, hi), float(mn), float(mx),
+                     bucket.numel)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_process_gloo():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    # single-process reference
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ELU(), torch.nn.Linear(5, 3))
+    data = torch.arange(7 * 6, dtype=torch.float32).view(7, 6) / 10.0
+    (net(data).pow(2).sum() / 7.0).backward()
+    assert ret[0][2] == (0, 4) and ret[1][2] == (4, 7)
+    for r in range(world):
+        grads, ug, _, mn, mx, numel = ret[r]
+        for g, p in zip(grads, net.parameters()):
+            torch.testing.assert_close(g, p.grad, rtol=1e-5, atol=1e-6)
+        assert torch.equal(ug, torch.zeros(4)) and numel == 6 * 5 + 5 + 5 * 3 + 3 + 4
+        assert mn == float(data.min()) and mx == float(data.max())
+
+
+def test_shard_range_covers_everything():
+    sys.path.insert(0, os.path.join(ROOT, "dv-matcher_amd"))
+    from dvm.dist import shard_range
+    for n in (0, 1, 7, 64, 255):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
