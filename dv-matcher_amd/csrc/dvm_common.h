@@ -85,6 +85,23 @@ struct KBest {
             idx[p] = sw ? ia : ib;
         }
     }
+    // branch-free form of insert(): a candidate that does not beat the current worst leaves the list
+    // unchanged (used inside wave-uniform loops where a divergent early-out costs register copies)
+    __device__ __forceinline__ void insert_nb(KeyT v, int j) {
+        const bool better = v < key[K - 1];
+        key[K - 1] = better ? v : key[K - 1];
+        idx[K - 1] = better ? j : idx[K - 1];
+#pragma unroll
+        for (int p = K - 1; p > 0; --p) {
+            bool sw = key[p] < key[p - 1];
+            KeyT a = key[p - 1], b = key[p];
+            int ia = idx[p - 1], ib = idx[p];
+            key[p - 1] = sw ? b : a;
+            key[p] = sw ? a : b;
+            idx[p - 1] = sw ? ib : ia;
+            idx[p] = sw ? ia : ib;
+        }
+    }
     // insert honouring (key, idx) lexicographic order for candidates arriving in any order
     __device__ __forceinline__ void insert_lex(KeyT v, int j) {
         bool better = (v < key[K - 1]) || (v == key[K - 1] && j < idx[K - 1]);

@@ -20,6 +20,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr float LOG2E = 1.4426950408889634f;
 
+
 // ------------------------------------------------------------------ row norms
 __global__ void rownorm2_kernel(const float *__restrict__ x, int rows, int K, float *__restrict__ out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -209,8 +210,8 @@ constexpr int MF_D = 128;
 constexpr int MF_KT = 64;              // keys per LDS tile (two 32-key MFMA sub-tiles)
 constexpr int MF_LDK = MF_D + 4;       // padded row (floats): 528 B, keeps ds_read_b128 conflict-free
 constexpr int MF_QW = 32;              // queries per wave
-constexpr int MF_WAVES = 4;
-constexpr int MF_QB = MF_QW * MF_WAVES;  // 128 queries per workgroup
+constexpr int MF_WAVES = 8;             // waves 0-3 and 4-7 pair up on the 4 SIMDs (two per SIMD)
+constexpr int MF_QB = MF_QW * MF_WAVES;  // 256 queries per workgroup
 constexpr int MF_THREADS = 64 * MF_WAVES;
 constexpr int MF_LD_PER_THREAD = MF_KT * MF_D / 4 / MF_THREADS;  // float4 loads per thread per tile = 8
 constexpr size_t MF_LDS_BYTES = (size_t)2 * (MF_KT * MF_LDK + MF_KT) * sizeof(float);
@@ -233,29 +234,52 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
     return base + orig / 8;
 }
 
+// One launch covers up to two "groups" (the two directions of a pair batch: (f1 -> f2) and
+// (f2 -> f1)), each with its own query/key tensors and outputs.
+struct SCGroup {
+    const float *q, *k, *nq, *nk;  // queries [B][N][128], keys [B][M][128], their |.|^2
+    int N, M, tiles;               // tiles = ceil(N / MF_QB)
+    float *val;
+    int32_t *idx;
+    float *smax, *sum;
+};
+struct SCArgs {
+    SCGroup g[2];
+    int blocks0;  // B * g[0].tiles : logical block ids below this belong to group 0
+    float neg_alpha;
+    int topk;
+};
+
+// Epilogue design: per candidate the fast path is {2 add, max, v_sqrt_f32, fma, v_exp_f32, add,
+// 2 cmp} — the 1-ulp hardware sqrt feeds only softmax terms whose weight is < 3e-4.  Candidates
+// that may enter the top-k (d2 <= threshold^2) or carry a significant weight are re-evaluated
+// with the correctly rounded sqrt and the reference's rounding sequence (s = d*neg_alpha, s - c)
+// inside a compacted, wave-uniform loop, so the ranking and the dominant terms stay exact.
 template <int TOPK>
-__global__ __launch_bounds__(MF_THREADS, 2) void softcorr_mfma_kernel(
-    const float *__restrict__ f1, const float *__restrict__ f2, const float *__restrict__ n1,
-    const float *__restrict__ n2, int N, int M, float neg_alpha, int topk, int tiles_per_batch,
-    float *__restrict__ pi_val, int32_t *__restrict__ pi_idx, float *__restrict__ row_smax,
-    float *__restrict__ row_sum) {
+__global__ __launch_bounds__(MF_THREADS, 2) void softcorr_mfma_kernel(const SCArgs args) {
+    // __launch_bounds__(512, 2): two waves per SIMD, i.e. ONE 512-thread workgroup per CU
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *const ktile0 = smem;                       // [2][MF_KT][MF_LDK]
     float *const knorm0 = smem + 2 * MF_KT * MF_LDK;  // [2][MF_KT]
 
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int b = lid / tiles_per_batch;
-    const int qt = lid % tiles_per_batch;
+    int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int grp = lid >= args.blocks0 ? 1 : 0;
+    lid -= grp ? args.blocks0 : 0;
+    const SCGroup &G = args.g[grp];
+    const int N = G.N, M = G.M;
+    const int b = lid / G.tiles;
+    const int qt = lid % G.tiles;
+    const float neg_alpha = args.neg_alpha;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r32 = lane & 31, h = lane >> 5;
 
-    const float *kbase = f2 + (size_t)b * M * MF_D;
-    const float *knb = n2 + (size_t)b * M;
+    const float *kbase = G.k + (size_t)b * M * MF_D;
+    const float *knb = G.nk + (size_t)b * M;
 
     // this lane's query row and its B-operand fragment: q[s] = -2 * f1[row][2s + h]
     const int qrow = qt * MF_QB + wave * MF_QW + r32;
     const int qrc = qrow < N ? qrow : N - 1;
-    const float *qp = f1 + ((size_t)b * N + qrc) * MF_D;
+    const float *qp = G.q + ((size_t)b * N + qrc) * MF_D;
     float q[MF_D / 2];
 #pragma unroll
     for (int c = 0; c < MF_D / 4; ++c) {
@@ -263,10 +287,14 @@ __global__ __launch_bounds__(MF_THREADS, 2) void softcorr_mfma_kernel(
         q[2 * c] = -2.f * (h ? v.y : v.x);
         q[2 * c + 1] = -2.f * (h ? v.w : v.z);
     }
-    const float na = n1[(size_t)b * N + qrc];
+    const float na = G.nq[(size_t)b * N + qrc];
 
-    RowState<TOPK> st;
-    st.init();
+    KBest<TOPK, float> kb;  // keyed on the correctly rounded distance
+    kb.init(INFINITY);
+    float cref = -INFINITY;  // running reference shift (~ max of s = d*neg_alpha), softmax is shift-invariant
+    float l = 0.f;           // sum exp(s - cref)
+    float thr2 = INFINITY;   // conservative squared-distance bound for "may enter the top-k"
+    const float a2 = neg_alpha * LOG2E;
 
     const int ntiles = (M + MF_KT - 1) / MF_KT;
     f32x4 pre[MF_LD_PER_THREAD];
@@ -302,78 +330,167 @@ __global__ __launch_bounds__(MF_THREADS, 2) void softcorr_mfma_kernel(
     commit_loads(0);
     __syncthreads();
 
+    // Phase structure.  Every wave alternates an MFMA phase M (64 dependent MFMAs, 4096 matrix-pipe
+    // cycles) with a VALU phase V (the epilogue) of about the same length.  The two waves that
+    // share a SIMD (w and w+4) would run them in lockstep — matrix pipe contended, then idle — so
+    // waves 4-7 (role 1) defer the epilogue of each tile's second sub-tile across the barrier:
+    //     role 0:   M0 V0 M1 V1 | barrier        role 1:   V1' M0 V0 M1 | barrier
+    // After every barrier one wave of the SIMD starts in M and its partner in V.
+    const int role = __builtin_amdgcn_readfirstlane(wave >> 2);
+
+    auto mfma_chain = [&](const float *kt, int sub, f32x16 &acc, float (&nbv)[16], int buf) {
+        const float *arow = kt + (sub * 32 + r32) * MF_LDK + h * 64;
+        acc = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            f32x4 a = *(const f32x4 *)(arow + 4 * c);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, q[4 * c], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, q[4 * c + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, q[4 * c + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, q[4 * c + 3], acc, 0, 0, 0);
+        }
+        // |key|^2 of this lane's 16 keys: local key = (r&3) + 8*(r>>2) + 4*h
+        const float *kn = knorm0 + buf * MF_KT + sub * 32 + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 nb = *(const f32x4 *)(kn + 8 * g);
+            nbv[4 * g] = nb.x, nbv[4 * g + 1] = nb.y, nbv[4 * g + 2] = nb.z, nbv[4 * g + 3] = nb.w;
+        }
+    };
+
+    auto epilogue = [&](const f32x16 &acc, const float (&nbv)[16], int jbase) {
+        float d2[16], df[16];
+        float tminf = INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = (acc[r] + na) + nbv[r];
+            v = v > 0.f ? v : 0.f;
+            d2[r] = v;
+            float f = __builtin_amdgcn_sqrtf(v);
+            df[r] = f;
+            tminf = fminf(tminf, f);
+        }
+        const float cnew = tminf * neg_alpha;
+        if (cnew > cref) {
+            l = l * exp2f((cref - cnew) * LOG2E);  // cref = -inf, l = 0 -> 0 * 0
+            cref = cnew;
+        }
+        const float c2 = cref * LOG2E;
+        float lsum = 0.f;
+        unsigned mask = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float arg = fmaf(df[r], a2, -c2);
+            lsum += __builtin_amdgcn_exp2f(arg);
+            bool flag = (d2[r] <= thr2) || (arg > -11.5f);
+            mask |= flag ? (1u << r) : 0u;
+        }
+        l += lsum;
+        // Branch-free body (inactive lanes insert +inf, a no-op): keeps the top-k registers in place
+        // instead of copying them around a divergent region every iteration.
+        while (__any(mask != 0)) {
+            const bool act = mask != 0;
+            const int bpos = act ? (__ffs(mask) - 1) : 0;
+            mask &= mask - 1;
+            const float v2 = act ? select16(d2, bpos) : INFINITY;
+            const float dfast = __builtin_amdgcn_sqrtf(v2);
+            const float de = sqrt_rn(v2);
+            const float s = de * neg_alpha;
+            // replace this term's fast value by the reference-rounded one (both 0 for +inf)
+            l += __builtin_amdgcn_exp2f((s - cref) * LOG2E) - __builtin_amdgcn_exp2f(fmaf(dfast, a2, -c2));
+            kb.insert_nb(de, jbase + (bpos & 3) + 8 * (bpos >> 2));
+        }
+        // the half-lane partner (same query, other keys) bounds the union's k-th best too
+        float w = kb.worst();
+        w = fminf(w, __shfl_xor(w, 32, 64));
+        thr2 = (w * w) * 1.0000004f;
+    };
+
+    f32x16 acc;
+    float nbv[16];
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
         if (t + 1 < ntiles) issue_loads(t + 1);
         const float *kt = ktile0 + buf * (MF_KT * MF_LDK);
-#pragma unroll
-        for (int sub = 0; sub < MF_KT / 32; ++sub) {
-            const float *arow = kt + (sub * 32 + r32) * MF_LDK + h * 64;
-            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                f32x4 a = *(const f32x4 *)(arow + 4 * c);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, q[4 * c], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, q[4 * c + 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, q[4 * c + 2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, q[4 * c + 3], acc, 0, 0, 0);
-            }
-            // epilogue for this lane's 16 keys: local key = (r&3) + 8*(r>>2) + 4*h
-            const float *kn = knorm0 + buf * MF_KT + sub * 32 + 4 * h;
-            float dd[16];
-            float tmin = INFINITY;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 nb = *(const f32x4 *)(kn + 8 * g);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float d2 = (acc[4 * g + e] + na) + nb[e];
-                    d2 = d2 > 0.f ? d2 : 0.f;
-                    float dv = sqrt_rn(d2);
-                    dd[4 * g + e] = dv;
-                    tmin = fminf(tmin, dv);
-                }
-            }
-            st.rescale(tmin * neg_alpha);
-            float lsum = 0.f;
-            unsigned mask = 0;
-            const float thr = st.kb.worst();
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float s = dd[r] * neg_alpha;
-                lsum += exp2f((s - st.smax) * LOG2E);
-                mask |= (dd[r] < thr) ? (1u << r) : 0u;
-            }
-            st.l += lsum;
-            const int jbase = t * MF_KT + sub * 32 + 4 * h;
-            while (__any(mask != 0)) {
-                if (mask != 0) {
-                    int bpos = __ffs(mask) - 1;
-                    mask &= mask - 1;
-                    float v = select16(dd, bpos);
-                    st.kb.insert(v, jbase + (bpos & 3) + 8 * (bpos >> 2));
-                }
-            }
-        }
+        if (role == 1 && t > 0) epilogue(acc, nbv, (t - 1) * MF_KT + 32 + 4 * h);  // V1' of the previous tile
+        mfma_chain(kt, 0, acc, nbv, buf);
+        epilogue(acc, nbv, t * MF_KT + 4 * h);
+        mfma_chain(kt, 1, acc, nbv, buf);
+        if (role == 0) epilogue(acc, nbv, t * MF_KT + 32 + 4 * h);
         if (t + 1 < ntiles) commit_loads(buf ^ 1);
         __syncthreads();
     }
+    if (role == 1) epilogue(acc, nbv, (ntiles - 1) * MF_KT + 32 + 4 * h);
 
     // merge the two half-lanes that share a query (lane, lane^32)
-    RowState<TOPK> other;
-    other.smax = __shfl_xor(st.smax, 32, 64);
-    other.l = __shfl_xor(st.l, 32, 64);
+    {
+        float co = __shfl_xor(cref, 32, 64), lo = __shfl_xor(l, 32, 64);
+        float cm = fmaxf(cref, co);
+        float a = (cref == -INFINITY) ? 0.f : l * exp2f((cref - cm) * LOG2E);
+        float bb = (co == -INFINITY) ? 0.f : lo * exp2f((co - cm) * LOG2E);
+        l = a + bb;
+        cref = cm;
+        float ok[TOPK];
+        int oi[TOPK];
 #pragma unroll
-    for (int t = 0; t < TOPK; ++t) {
-        other.kb.key[t] = __shfl_xor(st.kb.key[t], 32, 64);
-        other.kb.idx[t] = __shfl_xor(st.kb.idx[t], 32, 64);
+        for (int t = 0; t < TOPK; ++t) {
+            ok[t] = __shfl_xor(kb.key[t], 32, 64);
+            oi[t] = __shfl_xor(kb.idx[t], 32, 64);
+        }
+#pragma unroll
+        for (int t = 0; t < TOPK; ++t) kb.insert_lex(ok[t], oi[t]);
     }
-    st.merge(other);
     if (h == 0 && qrow < N) {
-        size_t row = (size_t)b * N + qrow;
-        store_row<TOPK>(st, topk, M, neg_alpha, pi_val + row * topk, pi_idx + row * topk, row_smax ? row_smax + row : nullptr,
-                        row_sum ? row_sum + row : nullptr);
+        const size_t row = (size_t)b * N + qrow;
+        const int topk = args.topk;
+        const float smax = kb.key[0] * neg_alpha;                  // exact max of s
+        const float lsm = l * exp2f((cref - smax) * LOG2E);        // sum exp(s - smax)
+        const float inv = 1.0f / lsm;
+        float *val = G.val + row * topk;
+        int32_t *idx = G.idx + row * topk;
+#pragma unroll
+        for (int t = 0; t < TOPK; ++t) {
+            if (t < topk) {
+                bool live = t < M;
+                float s = kb.key[t] * neg_alpha;
+                val[t] = live ? exp2f((s - smax) * LOG2E) * inv : 0.f;
+                idx[t] = live ? kb.idx[t] : 0;
+            }
+        }
+        if (G.smax) G.smax[row] = smax;
+        if (G.sum) G.sum[row] = lsm;
     }
+}
+
+static void softcorr_set_attr() {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)softcorr_mfma_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)MF_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)softcorr_mfma_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)MF_LDS_BYTES);
+        attr_set = true;
+    }
+}
+
+// both directions of B pairs in one launch; n1/n2 are the row norms of f1/f2 (computed once)
+int launch_softcorr_both(const float *f1, const float *f2, const float *n1, const float *n2, int B, int N, int M,
+                         float neg_alpha, float *val12, int32_t *idx12, float *val21, int32_t *idx21, hipStream_t s) {
+    SCArgs a;
+    a.g[0] = SCGroup{f1, f2, n1, n2, N, M, (N + MF_QB - 1) / MF_QB, val12, idx12, nullptr, nullptr};
+    a.g[1] = SCGroup{f2, f1, n2, n1, M, N, (M + MF_QB - 1) / MF_QB, val21, idx21, nullptr, nullptr};
+    a.blocks0 = B * a.g[0].tiles;
+    a.neg_alpha = neg_alpha;
+    a.topk = 10;
+    softcorr_set_attr();
+    prof_begin(s);
+    hipLaunchKernelGGL(softcorr_mfma_kernel<10>, dim3(a.blocks0 + B * a.g[1].tiles), dim3(MF_THREADS), MF_LDS_BYTES, s, a);
+    prof_end(s);
+    return DVM_OK;
+}
+
+void launch_rownorm2(const float *x, int rows, int K, float *out, hipStream_t s) {
+    hipLaunchKernelGGL(rownorm2_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, x, rows, K, out);
 }
 
 }  // namespace dvm
@@ -416,22 +533,17 @@ DVM_EXPORT int dvm_softcorr_fwd_f32(const float *f1, const float *f2, int B, int
     bool mfma = (variant == 2) || (variant == 0 && d == MF_D);
     prof_begin(s);
     if (mfma) {
-        int tiles = (N + MF_QB - 1) / MF_QB;
-        dim3 grid(tiles * B);
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void *)softcorr_mfma_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)MF_LDS_BYTES);
-            (void)hipFuncSetAttribute((const void *)softcorr_mfma_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)MF_LDS_BYTES);
-            attr_set = true;
-        }
+        SCArgs a;
+        a.g[0] = SCGroup{f1, f2, n1, n2, N, M, (N + MF_QB - 1) / MF_QB, pi_val, pi_idx, row_smax, row_sum};
+        a.g[1] = a.g[0];
+        a.blocks0 = B * a.g[0].tiles;
+        a.neg_alpha = neg_alpha;
+        a.topk = topk;
+        softcorr_set_attr();
         if (topk <= 10)
-            hipLaunchKernelGGL(softcorr_mfma_kernel<10>, grid, dim3(MF_THREADS), MF_LDS_BYTES, s, f1, f2, n1, n2, N, M,
-                               neg_alpha, topk, tiles, pi_val, pi_idx, row_smax, row_sum);
+            hipLaunchKernelGGL(softcorr_mfma_kernel<10>, dim3(a.blocks0), dim3(MF_THREADS), MF_LDS_BYTES, s, a);
         else
-            hipLaunchKernelGGL(softcorr_mfma_kernel<16>, grid, dim3(MF_THREADS), MF_LDS_BYTES, s, f1, f2, n1, n2, N, M,
-                               neg_alpha, topk, tiles, pi_val, pi_idx, row_smax, row_sum);
+            hipLaunchKernelGGL(softcorr_mfma_kernel<16>, dim3(a.blocks0), dim3(MF_THREADS), MF_LDS_BYTES, s, a);
     } else {
         dim3 grid((N + 127) / 128, B);
         size_t lds = (size_t)(SC_KT * d + SC_KT) * sizeof(float);
