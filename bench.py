@@ -77,8 +77,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=64, help="pairs per GPU per step (resident batch)")
-    ap.add_argument("--cpu-sample", type=int, default=3, help="pairs timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--pairs", type=int, default=256, help="pairs per GPU per step (resident batch)")
+    ap.add_argument("--cpu-sample", type=int, default=48, help="pairs timed for cpu_baseline (0 = skip)")
     ap.add_argument("--traffic-bytes", type=float, default=None, help="per-launch HBM bytes from the PMC passes (profiles/)")
     args = ap.parse_args()
 
@@ -102,11 +102,12 @@ def main():
     wl = ops.deformer_weight_list(load_weights(), dev)
     f1, f2, v1, v2, s1, s2 = make_batch(P, 1000 + rank, dev)  # every rank has its own shard of pairs
     out12 = out21 = None
+    outs = None
 
     def step():
-        nonlocal out12, out21
-        out12 = ops.pair_direction(wl, f1, f2, v1, v2, ALPHA, s1, with_map=True, out=out12)
-        out21 = ops.pair_direction(wl, f2, f1, v2, v1, ALPHA, s2, with_map=True, out=out21)
+        nonlocal out12, out21, outs
+        outs = ops.pair_forward(wl, f1, f2, v1, v2, ALPHA, s1, s2, with_map=True, out=outs)
+        out12, out21 = outs
 
     for _ in range(args.warmup):
         step()
@@ -114,7 +115,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ops.check(lib.dvm_profile_enable(2 * args.steps + 4), "dvm_profile_enable")
+    ops.check(lib.dvm_profile_enable(args.steps + 4), "dvm_profile_enable")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -137,11 +138,11 @@ def main():
     if rank == 0:
         pairs_total = P * args.steps * world
         value = pairs_total / dt
-        # roofline of the dominant kernel: algorithmic flops of one launch = P pairs x (2*N*M*d)/2
-        # (SURVEY §8d counts 2*N*M*d per PAIR with the distance tile shared by both directions; one
-        # launch covers one direction of P pairs)
+        # roofline of the dominant kernel: one launch covers BOTH directions of P pairs; its algorithmic
+        # flops are P x 2*N*M*d (SURVEY §8d counts the distance tile once per pair; the kernel evaluates it
+        # once per direction, i.e. performs twice that)
         k1_ms = ms.value / max(nl.value, 1)
-        flops_launch = P * (2.0 * N_PTS * M_PTS * DIM) / 2.0
+        flops_launch = P * (2.0 * N_PTS * M_PTS * DIM)
         achieved = flops_launch / (k1_ms * 1e-3) / 1e12 if k1_ms > 0 else 0.0
         res = {
             "metric": "point-cloud pairs/sec (N=2048, d=128)", "value": value, "unit": "pairs/s", "n_gpus": world,

@@ -108,6 +108,66 @@ __global__ __launch_bounds__(256) void assemble_kernel(const float *__restrict__
     }
 }
 
+// z row from POOLED features of both clouds (used by the two-direction path, where g(feat, idx) is
+// computed once per cloud):  z[n] = [vsrc_v, gsrc[v,:], vcorr_v, sum_t P[v,t] gtgt[pidx[v,t],:]], v = fps[n]
+template <int TOPK>
+__global__ __launch_bounds__(256) void assemble_pooled_kernel(const float *__restrict__ vsrc, const float *__restrict__ vcorr,
+                                                              const float *__restrict__ gsrc, const float *__restrict__ gtgt,
+                                                              const float *__restrict__ pi_val, const int32_t *__restrict__ pi_idx,
+                                                              const int32_t *__restrict__ fps, int N, int M, int Nn, int topk,
+                                                              float *__restrict__ z) {
+    const int b = blockIdx.y;
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (long)Nn * (DF_C / 4)) return;
+    const int n = (int)(g / (DF_C / 4)), c4 = (int)(g % (DF_C / 4));
+    const int v = fps[(size_t)b * Nn + n];
+    const size_t row = (size_t)b * N + v;
+    float pv[TOPK];
+    int pc[TOPK];
+#pragma unroll
+    for (int t = 0; t < TOPK; ++t) {
+        bool live = t < topk;
+        pv[t] = live ? pi_val[row * topk + t] : 0.f;
+        pc[t] = live ? pi_idx[row * topk + t] : 0x7fffffff;
+    }
+#pragma unroll
+    for (int a = 1; a < TOPK; ++a) {
+#pragma unroll
+        for (int p = a; p > 0; --p) {
+            bool sw = pc[p] < pc[p - 1];
+            int c0 = pc[p - 1], c1 = pc[p];
+            float v0 = pv[p - 1], v1 = pv[p];
+            pc[p - 1] = sw ? c1 : c0;
+            pc[p] = sw ? c0 : c1;
+            pv[p - 1] = sw ? v1 : v0;
+            pv[p] = sw ? v0 : v1;
+        }
+    }
+    const float *gt = gtgt + (size_t)b * M * DF_C;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < TOPK; ++t) {
+        if (t < topk) {
+            f32x4 f = *(const f32x4 *)(gt + (size_t)pc[t] * DF_C + 4 * c4);
+            acc.x = fmaf(pv[t], f.x, acc.x);
+            acc.y = fmaf(pv[t], f.y, acc.y);
+            acc.z = fmaf(pv[t], f.z, acc.z);
+            acc.w = fmaf(pv[t], f.w, acc.w);
+        }
+    }
+    float *zr = z + ((size_t)b * Nn + n) * DF_ZS;
+    f32x4 gs = *(const f32x4 *)(gsrc + row * DF_C + 4 * c4);
+    zr[3 + 4 * c4] = gs.x, zr[4 + 4 * c4] = gs.y, zr[5 + 4 * c4] = gs.z, zr[6 + 4 * c4] = gs.w;
+    zr[134 + 4 * c4] = acc.x, zr[135 + 4 * c4] = acc.y, zr[136 + 4 * c4] = acc.z, zr[137 + 4 * c4] = acc.w;
+    if (c4 == 0) {
+        for (int c = 0; c < 3; ++c) {
+            zr[c] = vsrc[row * 3 + c];
+            zr[131 + c] = vcorr[row * 3 + c];
+        }
+        zr[262] = 0.f, zr[263] = 0.f;
+    }
+}
+
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
 
 // ---------------------------------------------------------------- scalar MLP layer (check variant)
@@ -309,6 +369,38 @@ __global__ void pad_rows_kernel(const float *__restrict__ in, int rows, int I, i
     if (g >= (long)rows * stride) return;
     int r = (int)(g / stride), c = (int)(g % stride);
     out[g] = c < I ? in[(size_t)r * I + c] : 0.f;
+}
+
+void launch_pool_all(const float *feat, const int32_t *idx, int B, int P, int k, const float *cw, const float *cb, float *out,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(pool_kernel, dim3((unsigned)(((long)P * 32 + 255) / 256), B), dim3(256), 0, s, feat, idx,
+                       (const int32_t *)nullptr, P, P, k, cw, cb, out, DF_C, 0);
+}
+void launch_assemble_pooled(const float *vsrc, const float *vcorr, const float *gsrc, const float *gtgt, const float *pi_val,
+                            const int32_t *pi_idx, const int32_t *fps, int B, int N, int M, int Nn, float *z, hipStream_t s) {
+    hipLaunchKernelGGL(assemble_pooled_kernel<10>, dim3((unsigned)(((long)Nn * 32 + 255) / 256), B), dim3(256), 0, s, vsrc, vcorr,
+                       gsrc, gtgt, pi_val, pi_idx, fps, N, M, Nn, 10, z);
+}
+size_t mlp_pack_floats() { return (size_t)16 * 132 * 64 + (size_t)8 * 256 * 64 + (size_t)4 * 128 * 64 + (size_t)64 * 64; }
+// z [rows][264] -> out [rows][9]; wp = scratch of mlp_pack_floats() floats
+void launch_mlp_rows(const float *z, int rows, const float *W0, const float *b0, const float *W1, const float *b1, const float *W2,
+                     const float *b2, const float *W3, const float *b3, float *wp, float *out, hipStream_t s) {
+    float *Wp0 = wp, *Wp1 = Wp0 + (size_t)16 * 132 * 64, *Wp2 = Wp1 + (size_t)8 * 256 * 64, *Wp3 = Wp2 + (size_t)4 * 128 * 64;
+    auto pack = [&](const float *W, int O, int I, int otiles, int steps, float *Wp) {
+        long th = (long)otiles * steps * 64;
+        hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, W, O, I, otiles, steps, Wp);
+    };
+    pack(W0, 512, DF_IN, 16, 132, Wp0);
+    pack(W1, 256, 512, 8, 256, Wp1);
+    pack(W2, 128, 256, 4, 128, Wp2);
+    pack(W3, 9, 128, 1, 64, Wp3);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)mlp_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(mlp_mfma_kernel, dim3((rows + ML_NODES - 1) / ML_NODES), dim3(ML_THREADS), ML_LDS_BYTES, s, z, rows, Wp0, b0,
+                       Wp1, b1, Wp2, b2, Wp3, b3, out);
 }
 
 size_t deformer_ws_bytes(int B, int M, int Nn) {

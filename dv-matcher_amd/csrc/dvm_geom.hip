@@ -261,6 +261,49 @@ __global__ __launch_bounds__(128) void chamfer_kernel(const float *__restrict__ 
     }
 }
 
+// grouped form: up to 8 independent (a -> b) nearest-neighbour problems in one launch
+struct ChGroup {
+    const float *a, *b;
+    int Na, Nb;
+    float *dout;
+};
+struct ChArgs {
+    ChGroup g[8];
+};
+__global__ __launch_bounds__(128) void chamfer_grouped_kernel(const ChArgs args) {
+    __shared__ float4 pts[KN_PT];
+    const ChGroup &G = args.g[blockIdx.z];
+    const int N = G.Na, M = G.Nb;
+    if ((int)(blockIdx.x * blockDim.x) >= N) return;  // uniform per block
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ic = i < N ? i : N - 1;
+    const float *qp = G.a + ((size_t)b * N + ic) * 3;
+    const float qx = qp[0], qy = qp[1], qz = qp[2];
+    float best = INFINITY;
+    const float *yb = G.b + (size_t)b * M * 3;
+    for (int j0 = 0; j0 < M; j0 += KN_PT) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < KN_PT; e += blockDim.x) {
+            float4 p = {0.f, 0.f, 0.f, 0.f};
+            if (j0 + e < M) {
+                const float *pp = yb + (size_t)(j0 + e) * 3;
+                p.x = pp[0], p.y = pp[1], p.z = pp[2];
+            }
+            pts[e] = p;
+        }
+        __syncthreads();
+        int lim = M - j0 < KN_PT ? M - j0 : KN_PT;
+#pragma unroll 4
+        for (int j = 0; j < lim; ++j) {
+            float4 p = pts[j];
+            float dv = d2_diff3(qx, qy, qz, p.x, p.y, p.z);
+            best = dv < best ? dv : best;
+        }
+    }
+    if (i < N) G.dout[(size_t)b * N + i] = best;
+}
+
 // ---------------------------------------------------------------- map-loss numerator
 // thread per (i, s): e_c = verts12[idx11[i,s],c] - sum_t P[i,t] verts2[idx22[pidx[i,t],s],c]
 template <int TOPK>
@@ -457,6 +500,18 @@ int launch_mean(const float *in, int B, int n, float scale, float *out, int stri
 int launch_reduce_partials(const double *partial, int B, int nparts, float scale, float *out, int stride, int off,
                            hipStream_t s) {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(B), dim3(256), 0, s, partial, nparts, scale, out, stride, off);
+    return DVM_OK;
+}
+int launch_chamfer_grouped(const float *const *a, const float *const *b, const int *Na, const int *Nb, float *const *dout,
+                           int ngroups, int B, hipStream_t s) {
+    ChArgs args;
+    int maxN = 1;
+    for (int g = 0; g < 8; ++g) {
+        int q = g < ngroups ? g : 0;
+        args.g[g] = ChGroup{a[q], b[q], Na[q], Nb[q], dout[q]};
+        if (g < ngroups && Na[q] > maxN) maxN = Na[q];
+    }
+    hipLaunchKernelGGL(chamfer_grouped_kernel, dim3((maxN + 127) / 128, B, ngroups), dim3(128), 0, s, args);
     return DVM_OK;
 }
 int map_term_blocks(int N, int k) { return (int)(((long)N * k + 255) / 256); }

@@ -135,3 +135,165 @@ DVM_EXPORT int dvm_pair_direction_fwd_f32(const float *feat1, const float *feat2
     DVM_CHECK_LAUNCH("pair_direction");
     return DVM_OK;
 }
+
+// ================================================================ both directions at once
+// GraphDeformLoss_Neural.forward's deformation part for B pairs (reference models/loss.py:1401-1411):
+// graphs of both clouds, Pi_12 and Pi_21 (one launch), xyz kNN and pooled features once per cloud,
+// one Deformer-MLP launch over all nodes of both directions, warps, 4 Chamfer terms in one grouped
+// launch, map terms.  When N == M the per-cloud stages run as single launches over 2B shapes.
+namespace dvm {
+int launch_softcorr_both(const float *f1, const float *f2, const float *n1, const float *n2, int B, int N, int M,
+                         float neg_alpha, float *val12, int32_t *idx12, float *val21, int32_t *idx21, hipStream_t s);
+void launch_rownorm2(const float *x, int rows, int K, float *out, hipStream_t s);
+void launch_pool_all(const float *feat, const int32_t *idx, int B, int P, int k, const float *cw, const float *cb, float *out,
+                     hipStream_t s);
+void launch_assemble_pooled(const float *vsrc, const float *vcorr, const float *gsrc, const float *gtgt, const float *pi_val,
+                            const int32_t *pi_idx, const int32_t *fps, int B, int N, int M, int Nn, float *z, hipStream_t s);
+size_t mlp_pack_floats();
+void launch_mlp_rows(const float *z, int rows, const float *W0, const float *b0, const float *W1, const float *b1, const float *W2,
+                     const float *b2, const float *W3, const float *b3, float *wp, float *out, hipStream_t s);
+int launch_chamfer_grouped(const float *const *a, const float *const *b, const int *Na, const int *Nb, float *const *dout,
+                           int ngroups, int B, hipStream_t s);
+
+struct Pair2Ws {
+    float *vcat;                                  // [2B][N][3] when N == M
+    int32_t *startcat;                            // [2B]
+    int32_t *nodes[2], *ring[2], *infl[2], *idxk[2], *pidx[2];
+    float *dists[2], *weights[2], *pval[2], *nrm[2], *gall[2];
+    double *nnd[2], *partial[2];
+    float *z, *def9, *R, *T, *wp;
+    float *cd[8];
+};
+
+static size_t carve_pair2(Arena &ar, int B, int N, int M, Pair2Ws &w) {
+    const int P[2] = {N, M};
+    w.vcat = ar.take<float>((size_t)2 * B * (N > M ? N : M) * 3);
+    w.startcat = ar.take<int32_t>((size_t)2 * B);
+    // per-cloud arrays are carved back to back so that for N == M side 1 follows side 0 contiguously
+    for (int sd = 0; sd < 2; ++sd) w.nodes[sd] = ar.take<int32_t>((size_t)B * (P[sd] / 2));
+    for (int sd = 0; sd < 2; ++sd) w.ring[sd] = ar.take<int32_t>((size_t)B * (P[sd] / 2) * 9);
+    for (int sd = 0; sd < 2; ++sd) w.infl[sd] = ar.take<int32_t>((size_t)B * P[sd] * 3);
+    for (int sd = 0; sd < 2; ++sd) w.dists[sd] = ar.take<float>((size_t)B * P[sd] * 3);
+    for (int sd = 0; sd < 2; ++sd) w.weights[sd] = ar.take<float>((size_t)B * P[sd] * 3);
+    for (int sd = 0; sd < 2; ++sd) w.nnd[sd] = ar.take<double>((size_t)B * P[sd]);
+    for (int sd = 0; sd < 2; ++sd) w.idxk[sd] = ar.take<int32_t>((size_t)B * P[sd] * 10);
+    for (int sd = 0; sd < 2; ++sd) w.pval[sd] = ar.take<float>((size_t)B * P[sd] * 10);
+    for (int sd = 0; sd < 2; ++sd) w.pidx[sd] = ar.take<int32_t>((size_t)B * P[sd] * 10);
+    for (int sd = 0; sd < 2; ++sd) w.nrm[sd] = ar.take<float>((size_t)B * P[sd]);
+    for (int sd = 0; sd < 2; ++sd) w.gall[sd] = ar.take<float>((size_t)B * P[sd] * 128);
+    for (int sd = 0; sd < 2; ++sd) w.partial[sd] = ar.take<double>((size_t)B * map_term_blocks(P[sd], 10));
+    const size_t rows = (size_t)B * (N / 2) + (size_t)B * (M / 2);
+    w.z = ar.take<float>(rows * 264);
+    w.def9 = ar.take<float>(rows * 9);
+    w.R = ar.take<float>(rows * 9);
+    w.T = ar.take<float>(rows * 3);
+    w.wp = ar.take<float>(mlp_pack_floats());
+    const int cdn[8] = {N, M, N, M, M, N, M, N};
+    for (int q = 0; q < 8; ++q) w.cd[q] = ar.take<float>((size_t)B * cdn[q]);
+    return ar.off;
+}
+
+// arrays carved back to back are contiguous only if every per-side size is a multiple of the arena
+// alignment (256 B); otherwise the N == M fast path is not used.
+static bool contiguous_sides(int B, int N) {
+    return ((size_t)B * (N / 2) * sizeof(int32_t)) % 256 == 0 && ((size_t)B * N * sizeof(float)) % 256 == 0;
+}
+}  // namespace dvm
+
+DVM_EXPORT size_t dvm_pair_workspace_bytes(int B, int N, int M) {
+    Arena ar(nullptr, 0);
+    Pair2Ws w;
+    return carve_pair2(ar, B, N, M, w);
+}
+
+DVM_EXPORT int dvm_pair_fwd_f32(const float *feat1, const float *feat2, const float *verts1, const float *verts2, int B, int N,
+                                int M, float neg_alpha, const int32_t *start1, const int32_t *start2, const float *conv_w,
+                                const float *conv_b, const float *W0, const float *b0, const float *W1, const float *b1,
+                                const float *W2, const float *b2, const float *W3, const float *b3, int with_map, float *warped12,
+                                float *verts12, int32_t *T12, float *losses12, float *warped21, float *verts21, int32_t *T21,
+                                float *losses21, void *ws, size_t ws_bytes, void *stream) {
+    DVM_REQUIRE(feat1 && feat2 && verts1 && verts2 && start1 && start2, "dvm_pair_fwd_f32: null input pointer");
+    DVM_REQUIRE(warped12 && verts12 && T12 && losses12 && warped21 && verts21 && T21 && losses21,
+                "dvm_pair_fwd_f32: null output pointer");
+    DVM_REQUIRE(conv_w && conv_b && W0 && b0 && W1 && b1 && W2 && b2 && W3 && b3, "dvm_pair_fwd_f32: null weight pointer");
+    DVM_REQUIRE(B >= 1 && N >= 20 && M >= 20, "dvm_pair_fwd_f32: bad sizes (B=%d N=%d M=%d)", B, N, M);
+    DVM_REQUIRE(neg_alpha < 0.f, "dvm_pair_fwd_f32: neg_alpha must be negative");
+    Arena ar(ws, ws_bytes);
+    Pair2Ws w;
+    carve_pair2(ar, B, N, M, w);
+    if (!ar.ok()) {
+        set_error("dvm_pair_fwd_f32: workspace too small (%zu < %zu)", ws_bytes, ar.off);
+        return DVM_ENOSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int P[2] = {N, M};
+    const float *verts[2] = {verts1, verts2}, *feat[2] = {feat1, feat2};
+    const int32_t *start[2] = {start1, start2};
+    int rc;
+    const bool both = (N == M) && contiguous_sides(B, N);
+    // ---- per-cloud geometry: graph + xyz kNN
+    if (both) {
+        (void)hipMemcpyAsync(w.vcat, verts1, (size_t)B * N * 3 * sizeof(float), hipMemcpyDeviceToDevice, s);
+        (void)hipMemcpyAsync(w.vcat + (size_t)B * N * 3, verts2, (size_t)B * N * 3 * sizeof(float), hipMemcpyDeviceToDevice, s);
+        (void)hipMemcpyAsync(w.startcat, start1, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
+        (void)hipMemcpyAsync(w.startcat + B, start2, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
+        launch_dg_build(w.vcat, 2 * B, N, w.startcat, w.nodes[0], w.ring[0], w.infl[0], w.dists[0], w.weights[0], nullptr,
+                        w.nnd[0], s);
+        rc = dvm_knn_cdist_f32(w.vcat, w.vcat, 2 * B, N, N, 3, 10, w.idxk[0], s);
+        if (rc != DVM_OK) return rc;
+    } else {
+        for (int sd = 0; sd < 2; ++sd) {
+            launch_dg_build(verts[sd], B, P[sd], start[sd], w.nodes[sd], w.ring[sd], w.infl[sd], w.dists[sd], w.weights[sd],
+                            nullptr, w.nnd[sd], s);
+            rc = dvm_knn_cdist_f32(verts[sd], verts[sd], B, P[sd], P[sd], 3, 10, w.idxk[sd], s);
+            if (rc != DVM_OK) return rc;
+        }
+    }
+    // ---- soft correspondence, both directions in one launch
+    launch_rownorm2(feat1, B * N, 128, w.nrm[0], s);
+    launch_rownorm2(feat2, B * M, 128, w.nrm[1], s);
+    launch_softcorr_both(feat1, feat2, w.nrm[0], w.nrm[1], B, N, M, neg_alpha, w.pval[0], w.pidx[0], w.pval[1], w.pidx[1], s);
+    hipLaunchKernelGGL(take_col0_kernel, dim3((B * N + 255) / 256), dim3(256), 0, s, w.pidx[0], B * N, 10, T12);
+    hipLaunchKernelGGL(take_col0_kernel, dim3((B * M + 255) / 256), dim3(256), 0, s, w.pidx[1], B * M, 10, T21);
+    rc = dvm_softcorr_apply_f32(w.pval[0], w.pidx[0], verts2, B, N, M, 10, 3, verts12, s);
+    if (rc != DVM_OK) return rc;
+    rc = dvm_softcorr_apply_f32(w.pval[1], w.pidx[1], verts1, B, M, N, 10, 3, verts21, s);
+    if (rc != DVM_OK) return rc;
+    // ---- Deformer: pooled features once per cloud, z for both directions, one MLP launch
+    launch_pool_all(feat1, w.idxk[0], B, N, 10, conv_w, conv_b, w.gall[0], s);
+    launch_pool_all(feat2, w.idxk[1], B, M, 10, conv_w, conv_b, w.gall[1], s);
+    const int Nn1 = N / 2, Nn2 = M / 2;
+    float *z21 = w.z + (size_t)B * Nn1 * 264;
+    launch_assemble_pooled(verts1, verts12, w.gall[0], w.gall[1], w.pval[0], w.pidx[0], w.nodes[0], B, N, M, Nn1, w.z, s);
+    launch_assemble_pooled(verts2, verts21, w.gall[1], w.gall[0], w.pval[1], w.pidx[1], w.nodes[1], B, M, N, Nn2, z21, s);
+    const int rows = B * (Nn1 + Nn2);
+    launch_mlp_rows(w.z, rows, W0, b0, W1, b1, W2, b2, W3, b3, w.wp, w.def9, s);
+    // ---- ED warp + ARAP (losses[:,2])
+    float *def21 = w.def9 + (size_t)B * Nn1 * 9, *R21 = w.R + (size_t)B * Nn1 * 9, *T21v = w.T + (size_t)B * Nn1 * 3;
+    launch_dg_warp(verts1, B, N, w.nodes[0], w.ring[0], w.infl[0], w.weights[0], w.def9, w.R, w.T, warped12, losses12 + 2, 6,
+                   nullptr, s);
+    launch_dg_warp(verts2, B, M, w.nodes[1], w.ring[1], w.infl[1], w.weights[1], def21, R21, T21v, warped21, losses21 + 2, 6,
+                   nullptr, s);
+    // ---- the four Chamfer terms, both sides each, in one grouped launch
+    {
+        const float *a[8] = {warped12, verts2, verts12, verts2, warped21, verts1, verts21, verts1};
+        const float *bq[8] = {verts2, warped12, verts2, verts12, verts1, warped21, verts1, verts21};
+        const int Na[8] = {N, M, N, M, M, N, M, N}, Nb[8] = {M, N, M, N, N, M, N, M};
+        launch_chamfer_grouped(a, bq, Na, Nb, w.cd, 8, B, s);
+        float *L[2] = {losses12, losses21};
+        const int off[4] = {0, 1, 3, 4};
+        for (int q = 0; q < 8; ++q) launch_mean(w.cd[q], B, Na[q], 1.f, L[q / 4], 6, off[q % 4], 0, s);
+    }
+    // ---- map terms (losses[:,5])
+    if (with_map) {
+        launch_map_term(verts12, verts2, w.idxk[0], w.idxk[1], w.pval[0], w.pidx[0], B, N, M, 10, 10, w.partial[0], s);
+        launch_reduce_partials(w.partial[0], B, map_term_blocks(N, 10), 1.f, losses12, 6, 5, s);
+        launch_map_term(verts21, verts1, w.idxk[1], w.idxk[0], w.pval[1], w.pidx[1], B, M, N, 10, 10, w.partial[1], s);
+        launch_reduce_partials(w.partial[1], B, map_term_blocks(M, 10), 1.f, losses21, 6, 5, s);
+    } else {
+        launch_mean(w.cd[0], B, 1, 0.f, losses12, 6, 5, 0, s);
+        launch_mean(w.cd[0], B, 1, 0.f, losses21, 6, 5, 0, s);
+    }
+    DVM_CHECK_LAUNCH("pair_fwd");
+    return DVM_OK;
+}

@@ -363,3 +363,29 @@ def dist_loss(feat, dist, anchors, k, want_idx=False):
     check(lib.dvm_dist_loss_fwd_f32(_p(feat), _p(dist), _p(anchors), B, N, C, nA, k, _p(out), _p(idx), _p(ws), nb,
                                     _stream()), "dvm_dist_loss_fwd_f32")
     return (out, idx) if want_idx else out
+
+
+def pair_forward(wl, feat1, feat2, verts1, verts2, alpha, start1, start2, with_map=True, out=None):
+    """Config-2 path for B pairs, BOTH directions in one call.
+    Returns (out12, out21), each dict(warped, verts12, T12, losses[B,6])."""
+    _need_gpu(feat1, feat2, verts1, verts2, start1, start2, *wl)
+    feat1, feat2, verts1, verts2 = _f(feat1), _f(feat2), _f(verts1), _f(verts2)
+    start1, start2 = _i(start1), _i(start2)
+    B, N, _ = feat1.shape
+    M = feat2.shape[1]
+    dev = feat1.device
+    lib = _lib.load()
+
+    def alloc(n):
+        return dict(warped=torch.empty(B, n, 3, dtype=torch.float32, device=dev),
+                    verts12=torch.empty(B, n, 3, dtype=torch.float32, device=dev),
+                    T12=torch.empty(B, n, dtype=torch.int32, device=dev),
+                    losses=torch.empty(B, 6, dtype=torch.float32, device=dev))
+    o12, o21 = out if out is not None else (alloc(N), alloc(M))
+    nb = lib.dvm_pair_workspace_bytes(B, N, M)
+    ws = workspace(nb, dev, "pair2")
+    check(lib.dvm_pair_fwd_f32(_p(feat1), _p(feat2), _p(verts1), _p(verts2), B, N, M, neg_alpha_f32(alpha), _p(start1),
+                               _p(start2), *[_p(w) for w in wl], int(with_map), _p(o12["warped"]), _p(o12["verts12"]),
+                               _p(o12["T12"]), _p(o12["losses"]), _p(o21["warped"]), _p(o21["verts12"]), _p(o21["T12"]),
+                               _p(o21["losses"]), _p(ws), nb, _stream()), "dvm_pair_fwd_f32")
+    return o12, o21

@@ -198,6 +198,19 @@ int dvm_pair_direction_fwd_f32(const float *feat1, const float *feat2, const flo
                                int with_map, float *warped, float *verts12, int32_t *T12, float *losses, void *ws,
                                size_t ws_bytes, void *stream);
 
+/* Both directions of the deformation part of GraphDeformLoss_Neural.forward for B pairs —
+ * models/loss.py:1401-1411 (graphs of both clouds, Pi_12 and Pi_21, deform() twice) with the work
+ * shared between the directions (xyz kNN, pooled features, one soft-correspondence launch, one MLP
+ * launch, one grouped Chamfer launch).  Outputs as in dvm_pair_direction_fwd_f32, once per direction
+ * (`12`: cloud 1 deformed towards cloud 2; `21`: the reverse). */
+size_t dvm_pair_workspace_bytes(int B, int N, int M);
+int dvm_pair_fwd_f32(const float *feat1, const float *feat2, const float *verts1, const float *verts2, int B, int N,
+                     int M, float neg_alpha, const int32_t *start1, const int32_t *start2, const float *conv_w,
+                     const float *conv_b, const float *W0, const float *b0, const float *W1, const float *b1,
+                     const float *W2, const float *b2, const float *W3, const float *b3, int with_map, float *warped12,
+                     float *verts12, int32_t *T12, float *losses12, float *warped21, float *verts21, int32_t *T21,
+                     float *losses21, void *ws, size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -245,6 +245,24 @@ def test_pair_direction_full_size_properties(ops, golden):
     np.testing.assert_allclose(host(out["losses"])[0], o["losses"], rtol=1e-3)
 
 
+@pytest.mark.parametrize("shape", [(3, 512, 512), (2, 300, 170), (2, 330, 330)])
+def test_pair_forward_equals_two_directions(ops, golden, shape):
+    """The fused two-direction entry shares work between the directions; every output must be
+    bit-identical to running the one-direction entry twice."""
+    B, N, M = shape
+    w = golden("deformer_scape_r_weights")
+    wl = ops.deformer_weight_list(w, "cuda")
+    f1, f2, v1, v2, s1 = _pair_inputs(B, N, M, 5 + N)
+    s2 = torch.arange(B, dtype=torch.int32) % M
+    d = [t.cuda() for t in (f1, f2, v1, v2)]
+    o12, o21 = ops.pair_forward(wl, *d, 33.0, s1.cuda(), s2.cuda())
+    r12 = ops.pair_direction(wl, d[0], d[1], d[2], d[3], 33.0, s1.cuda())
+    r21 = ops.pair_direction(wl, d[1], d[0], d[3], d[2], 33.0, s2.cuda())
+    for k in r12:
+        assert torch.equal(o12[k], r12[k]), ("12", k)
+        assert torch.equal(o21[k], r21[k]), ("21", k)
+
+
 def test_errors_are_loud(ops):
     from dvm._lib import DvmError
     f = torch.randn(1, 8, 128)
