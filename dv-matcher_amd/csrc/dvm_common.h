@@ -54,6 +54,34 @@ struct Arena {
 
 constexpr int WAVE = 64;
 
+// uniform-grid neighbour search (dvm_grid.hip)
+struct GridBuf {
+    float4 *pts;
+    int32_t *ids;
+    int32_t *start;
+    float *params;
+    int P, G;
+};
+size_t grid_bytes(int B, int P);
+// view of shapes [b0, ...) of a batched grid
+static inline GridBuf grid_slice(const GridBuf &g, int b0) {
+    GridBuf r = g;
+    const int G3 = g.G * g.G * g.G;
+    r.pts = g.pts + (size_t)b0 * g.P;
+    r.ids = g.ids + (size_t)b0 * g.P;
+    r.start = g.start + (size_t)b0 * (G3 + 1);
+    r.params = g.params + (size_t)b0 * 8;
+    return r;
+}
+GridBuf grid_carve(Arena &ar, int B, int P);
+void launch_grid_build(const float *xyz, int B, int Nsrc, const int32_t *sel, const GridBuf &gb, hipStream_t s);
+void launch_grid_knn_self(const GridBuf &gb, int B, int k, int32_t *idx, hipStream_t s);
+void launch_grid_ring(const GridBuf &gnodes, int B, int32_t *ring, hipStream_t s);
+void launch_grid_infl(const float *xyz, int B, int N, const GridBuf &gnodes, const GridBuf &gverts, int32_t *infl, float *dists,
+                      double *nnd, hipStream_t s);
+void launch_grid_chamfer(const GridBuf *gq, const GridBuf *gb, float *const *dout, int32_t *const *iout, int ngroups, int B,
+                         hipStream_t s);
+
 // ---------------------------------------------------------------- device helpers
 // Sorted "k best" list in registers: keys ascending, ties keep the earlier (lower-index)
 // entry first provided candidates arrive in ascending index order.

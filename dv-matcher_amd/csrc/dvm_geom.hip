@@ -411,14 +411,32 @@ DVM_EXPORT int dvm_argmin_exact_f32(const float *f1, const float *f2, int B, int
     return DVM_OK;
 }
 
-DVM_EXPORT int dvm_knn_cdist_f32(const float *x, const float *y, int B, int N, int M, int C, int k, int32_t *idx,
-                                 void *stream) {
+DVM_EXPORT size_t dvm_knn_cdist_workspace_bytes(int B, int N, int M, int C) {
+    (void)M;
+    return C == 3 ? grid_bytes(B, N) : 256;
+}
+
+DVM_EXPORT int dvm_knn_cdist_f32(const float *x, const float *y, int B, int N, int M, int C, int k, int32_t *idx, void *ws,
+                                 size_t ws_bytes, void *stream) {
     DVM_REQUIRE(x && y && idx, "dvm_knn_cdist_f32: null pointer");
     DVM_REQUIRE(B >= 1 && N >= 1 && M >= 1, "dvm_knn_cdist_f32: empty input (B=%d N=%d M=%d)", B, N, M);
     DVM_REQUIRE(C >= 1 && C <= 16, "dvm_knn_cdist_f32: C=%d unsupported (1..16)", C);
     DVM_REQUIRE(k >= 1 && k <= 16, "dvm_knn_cdist_f32: k=%d unsupported (1..16)", k);
     dim3 grid((N + 127) / 128, B), block(128);
     hipStream_t s = (hipStream_t)stream;
+    if (C == 3 && x == y && N == M && N >= 64 && ws != nullptr) {
+        // a cloud against itself (the hot-path case): exact search on a uniform grid
+        Arena ar(ws, ws_bytes);
+        GridBuf gb = grid_carve(ar, B, N);
+        if (!ar.ok()) {
+            set_error("dvm_knn_cdist_f32: workspace too small (%zu < %zu)", ws_bytes, ar.off);
+            return DVM_ENOSPACE;
+        }
+        launch_grid_build(x, B, N, nullptr, gb, s);
+        launch_grid_knn_self(gb, B, k, idx, s);
+        DVM_CHECK_LAUNCH("knn_cdist(grid)");
+        return DVM_OK;
+    }
     if (C == 3) {
         if (k <= 3)
             hipLaunchKernelGGL(knn_cdist3_kernel<3>, grid, block, 0, s, x, y, N, M, k, idx);
@@ -451,11 +469,35 @@ DVM_EXPORT int dvm_softcorr_apply_f32(const float *pi_val, const int32_t *pi_idx
     return DVM_OK;
 }
 
+DVM_EXPORT size_t dvm_chamfer_workspace_bytes(int B, int N, int M) { return grid_bytes(B, N) + grid_bytes(B, M); }
+
 DVM_EXPORT int dvm_chamfer_fwd_f32(const float *a, const float *b, int B, int N, int M, float *d1, float *d2, int32_t *i1,
-                                   int32_t *i2, void *stream) {
+                                   int32_t *i2, void *ws, size_t ws_bytes, void *stream) {
     DVM_REQUIRE(a && b && (d1 || d2), "dvm_chamfer_fwd_f32: null pointer");
     DVM_REQUIRE(B >= 1 && N >= 1 && M >= 1, "dvm_chamfer_fwd_f32: empty input (B=%d N=%d M=%d)", B, N, M);
     hipStream_t s = (hipStream_t)stream;
+    if (ws != nullptr && N >= 64 && M >= 64) {
+        Arena ar(ws, ws_bytes);
+        GridBuf ga = grid_carve(ar, B, N), gb = grid_carve(ar, B, M);
+        if (!ar.ok()) {
+            set_error("dvm_chamfer_fwd_f32: workspace too small (%zu < %zu)", ws_bytes, ar.off);
+            return DVM_ENOSPACE;
+        }
+        GridBuf qg[2] = {ga, gb}, tg[2] = {gb, ga};
+        float *dout[2] = {d1, d2};
+        int32_t *iout[2] = {i1, i2};
+        launch_grid_build(b, B, M, nullptr, gb, s);
+        launch_grid_build(a, B, N, nullptr, ga, s);
+        if (d1 && d2) {
+            launch_grid_chamfer(qg, tg, dout, iout, 2, B, s);
+        } else if (d1) {
+            launch_grid_chamfer(qg, tg, dout, iout, 1, B, s);
+        } else {
+            launch_grid_chamfer(qg + 1, tg + 1, dout + 1, iout + 1, 1, B, s);
+        }
+        DVM_CHECK_LAUNCH("chamfer(grid)");
+        return DVM_OK;
+    }
     if (d1) hipLaunchKernelGGL(chamfer_kernel, dim3((N + 127) / 128, B), dim3(128), 0, s, a, b, N, M, d1, i1);
     if (d2) hipLaunchKernelGGL(chamfer_kernel, dim3((M + 127) / 128, B), dim3(128), 0, s, b, a, M, N, d2, i2);
     DVM_CHECK_LAUNCH("chamfer");

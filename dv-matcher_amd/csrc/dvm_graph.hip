@@ -358,12 +358,17 @@ int launch_fps(const float *xyz, int B, int N, int npoint, const int32_t *start,
     return DVM_OK;
 }
 
+// graph build on uniform grids (dvm_grid.hip): gverts = grid over all vertices (built here, reusable by
+// the caller), gnodes = grid over the FPS nodes
 int launch_dg_build(const float *xyz, int B, int N, const int32_t *start, int32_t *nodes_idx, int32_t *ring,
-                    int32_t *infl_idx, float *dists, float *weights, double *sigma, double *nnd, hipStream_t s) {
+                    int32_t *infl_idx, float *dists, float *weights, double *sigma, double *nnd, const GridBuf &gverts,
+                    const GridBuf &gnodes, bool build_gverts, hipStream_t s) {
     const int Nn = N / 2;
     launch_fps(xyz, B, N, Nn, start, nodes_idx, s);
-    hipLaunchKernelGGL(dg_ring_kernel, dim3((Nn + 127) / 128, B), dim3(128), 0, s, xyz, nodes_idx, N, Nn, ring);
-    hipLaunchKernelGGL(dg_infl_kernel, dim3((N + 127) / 128, B), dim3(128), 0, s, xyz, nodes_idx, N, Nn, infl_idx, dists, nnd);
+    if (build_gverts) launch_grid_build(xyz, B, N, nullptr, gverts, s);
+    launch_grid_build(xyz, B, N, nodes_idx, gnodes, s);
+    launch_grid_ring(gnodes, B, ring, s);
+    launch_grid_infl(xyz, B, N, gnodes, gverts, infl_idx, dists, nnd, s);
     hipLaunchKernelGGL(dg_weights_kernel, dim3(B), dim3(256), 0, s, nnd, dists, N, weights, sigma);
     return DVM_OK;
 }
@@ -404,7 +409,9 @@ DVM_EXPORT int dvm_fps_f32(const float *xyz, int B, int N, int npoint, const int
     return DVM_OK;
 }
 
-DVM_EXPORT size_t dvm_dg_build_workspace_bytes(int B, int N) { return align_up((size_t)B * N * sizeof(double)); }
+DVM_EXPORT size_t dvm_dg_build_workspace_bytes(int B, int N) {
+    return align_up((size_t)B * N * sizeof(double)) + grid_bytes(B, N) + grid_bytes(B, N / 2);
+}
 
 DVM_EXPORT int dvm_dg_build_f32(const float *xyz, int B, int N, const int32_t *start, int32_t *nodes_idx, int32_t *ring,
                                 int32_t *infl_idx, float *dists, float *weights, double *sigma, void *ws, size_t ws_bytes,
@@ -414,11 +421,12 @@ DVM_EXPORT int dvm_dg_build_f32(const float *xyz, int B, int N, const int32_t *s
     DVM_REQUIRE(N <= DVM_MAX_POINTS, "dvm_dg_build_f32: N=%d exceeds %d", N, DVM_MAX_POINTS);
     Arena ar(ws, ws_bytes);
     double *nnd = ar.take<double>((size_t)B * N);
+    GridBuf gv = grid_carve(ar, B, N), gn = grid_carve(ar, B, N / 2);
     if (!ar.ok()) {
         set_error("dvm_dg_build_f32: workspace too small (%zu < %zu)", ws_bytes, ar.off);
         return DVM_ENOSPACE;
     }
-    launch_dg_build(xyz, B, N, start, nodes_idx, ring, infl_idx, dists, weights, sigma, nnd, (hipStream_t)stream);
+    launch_dg_build(xyz, B, N, start, nodes_idx, ring, infl_idx, dists, weights, sigma, nnd, gv, gn, true, (hipStream_t)stream);
     DVM_CHECK_LAUNCH("dg_build");
     return DVM_OK;
 }

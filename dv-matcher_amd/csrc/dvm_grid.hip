@@ -1,0 +1,404 @@
+// dvm_grid.hip — exact 3-D nearest-neighbour queries on a uniform grid.
+//
+// The reference solves four small 3-D neighbour problems per shape and step by brute force /
+// KDTree: xyz kNN (knn_grad, models/loss.py:97-101), the node ring and the 1-NN distance
+// (scipy KDTree, lib/deformation_graph_point.py:181-191), the 3 nearest graph nodes of every vertex
+// (:186-187) and Chamfer's nearest neighbours (models/loss.py:1216-1226).  Here each cloud is
+// binned once into a G^3 grid (counting sort in LDS, one workgroup per shape) and every query walks
+// cubes of growing radius until its k-th best distance is certified against the distance to the
+// cube's faces.  Distances are evaluated in the reference's own rounding (matmul-form fp32, exact
+// fp64, or difference-form fp32) and ranked by (distance, index), so results equal the brute-force
+// kernels bit for bit whatever order the cells are visited in.
+#include "dvm_common.h"
+
+namespace dvm {
+
+constexpr int GRID_T = 256;
+
+struct GridView {          // one shape's grid (device pointers already offset to the shape)
+    const float4 *pts;     // sorted points: x, y, z, |p|^2 (ATen order)
+    const int32_t *ids;    // original (candidate-local) index of each sorted point
+    const int32_t *start;  // [G^3 + 1]
+    float ox, oy, oz, h, scale2;
+    int G;
+};
+
+// GridBuf (dvm_common.h): batched storage — pts [B][P], ids [B][P], start [B][G^3+1], params [B][8]
+
+__host__ __device__ inline int grid_dim_for(int P) { return P <= 4096 ? 8 : 16; }
+
+// One workgroup per shape.  src points are xyz[sel[j]] (sel == nullptr: identity), j < P.
+__global__ __launch_bounds__(GRID_T) void grid_build_kernel(const float *__restrict__ xyz, int Nsrc,
+                                                            const int32_t *__restrict__ sel, GridBuf gb) {
+    extern __shared__ int lds[];  // [G^3 + 1] counts/starts, then cursors [G^3]
+    __shared__ float red[6][GRID_T / 64];
+    __shared__ float par[8];
+    __shared__ int wsum[GRID_T / 64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = gb.P, G = gb.G, G3 = G * G * G;
+    const float *p = xyz + (size_t)b * Nsrc * 3;
+    const int32_t *sl = sel ? sel + (size_t)b * P : nullptr;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int j = tid; j < P; j += GRID_T) {
+        int v = sl ? sl[j] : j;
+        for (int a = 0; a < 3; ++a) {
+            float c = p[3 * v + a];
+            mn[a] = fminf(mn[a], c);
+            mx[a] = fmaxf(mx[a], c);
+        }
+    }
+    for (int a = 0; a < 3; ++a) {
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, 64));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, 64));
+        }
+        if (lane == 0) {
+            red[a][wave] = mn[a];
+            red[3 + a][wave] = mx[a];
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float lo[3], hi[3];
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = fminf(fminf(red[a][0], red[a][1]), fminf(red[a][2], red[a][3]));
+            hi[a] = fmaxf(fmaxf(red[3 + a][0], red[3 + a][1]), fmaxf(red[3 + a][2], red[3 + a][3]));
+        }
+        float ext = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
+        float h = ext > 0.f ? (ext / (float)G) * 1.000001f : 1.f;
+        float m = 0.f;
+        for (int a = 0; a < 3; ++a) m = fmaxf(m, fmaxf(fabsf(lo[a]), fabsf(hi[a])));
+        par[0] = lo[0], par[1] = lo[1], par[2] = lo[2], par[3] = h, par[4] = 3.f * m * m + 1e-30f;
+        for (int q = 0; q < 5; ++q) gb.params[(size_t)b * 8 + q] = par[q];
+    }
+    for (int c = tid; c <= G3; c += GRID_T) lds[c] = 0;
+    __syncthreads();
+    const float ox = par[0], oy = par[1], oz = par[2], inv = 1.0f / par[3];
+    auto cell_of = [&](float x, float y, float z) {
+        int cx = (int)((x - ox) * inv), cy = (int)((y - oy) * inv), cz = (int)((z - oz) * inv);
+        cx = cx < 0 ? 0 : (cx > G - 1 ? G - 1 : cx);
+        cy = cy < 0 ? 0 : (cy > G - 1 ? G - 1 : cy);
+        cz = cz < 0 ? 0 : (cz > G - 1 ? G - 1 : cz);
+        return (cz * G + cy) * G + cx;
+    };
+    for (int j = tid; j < P; j += GRID_T) {
+        int v = sl ? sl[j] : j;
+        atomicAdd(&lds[cell_of(p[3 * v], p[3 * v + 1], p[3 * v + 2])], 1);
+    }
+    __syncthreads();
+    // exclusive scan of G3 counts (each thread owns a contiguous chunk)
+    const int chunk = (G3 + GRID_T - 1) / GRID_T;
+    int local = 0;
+    for (int c = tid * chunk; c < (tid + 1) * chunk && c < G3; ++c) local += lds[c];
+    int inc = local;
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int base = inc - local;
+    for (int w2 = 0; w2 < wave; ++w2) base += wsum[w2];
+    __syncthreads();
+    int *cursor = lds + G3 + 1;
+    int run = base;
+    for (int c = tid * chunk; c < (tid + 1) * chunk && c < G3; ++c) {
+        int cnt = lds[c];
+        lds[c] = run;
+        cursor[c] = run;
+        run += cnt;
+    }
+    if (tid == 0) lds[G3] = P;
+    __syncthreads();
+    int32_t *st = gb.start + (size_t)b * (G3 + 1);
+    for (int c = tid; c <= G3; c += GRID_T) st[c] = lds[c];
+    float4 *op = gb.pts + (size_t)b * P;
+    int32_t *oi = gb.ids + (size_t)b * P;
+    for (int j = tid; j < P; j += GRID_T) {
+        int v = sl ? sl[j] : j;
+        float x = p[3 * v], y = p[3 * v + 1], z = p[3 * v + 2];
+        int pos = atomicAdd(&cursor[cell_of(x, y, z)], 1);
+        op[pos] = make_float4(x, y, z, sumsq3(x, y, z));
+        oi[pos] = j;
+    }
+}
+
+__device__ __forceinline__ GridView grid_view(const GridBuf &gb, int b) {
+    GridView g;
+    const int G3 = gb.G * gb.G * gb.G;
+    g.pts = gb.pts + (size_t)b * gb.P;
+    g.ids = gb.ids + (size_t)b * gb.P;
+    g.start = gb.start + (size_t)b * (G3 + 1);
+    const float *pr = gb.params + (size_t)b * 8;
+    g.ox = pr[0], g.oy = pr[1], g.oz = pr[2], g.h = pr[3], g.scale2 = pr[4];
+    g.G = gb.G;
+    return g;
+}
+
+// distance functors: return the RANKING key of candidate c (x,y,z,|c|^2) for query q
+struct MetricMMQueryRow {  // torch.cdist matmul form, query is the row operand (knn_grad)
+    typedef float key_t;
+    float qx, qy, qz, nq;
+    __device__ __forceinline__ void set(float x, float y, float z) { qx = x, qy = y, qz = z, nq = sumsq3(x, y, z); }
+    __device__ __forceinline__ float operator()(const float4 &c) const {
+        return sqrt_rn(d2_mm3(qx, qy, qz, nq, c.x, c.y, c.z, c.w));
+    }
+    __device__ __forceinline__ static float to_d2(float k) { return k * k; }
+};
+struct MetricMMCandRow {  // matmul form with the CANDIDATE as row operand (geod[nodes_idx] transposed)
+    typedef float key_t;
+    float qx, qy, qz, nq;
+    __device__ __forceinline__ void set(float x, float y, float z) { qx = x, qy = y, qz = z, nq = sumsq3(x, y, z); }
+    __device__ __forceinline__ float operator()(const float4 &c) const {
+        return sqrt_rn(d2_mm3(c.x, c.y, c.z, c.w, qx, qy, qz, nq));
+    }
+    __device__ __forceinline__ static float to_d2(float k) { return k * k; }
+};
+struct MetricF64 {  // scipy KDTree: exact fp64 squared distance of the fp32 coordinates
+    typedef double key_t;
+    float qx, qy, qz;
+    __device__ __forceinline__ void set(float x, float y, float z) { qx = x, qy = y, qz = z; }
+    __device__ __forceinline__ double operator()(const float4 &c) const {
+        double dx = (double)qx - (double)c.x, dy = (double)qy - (double)c.y, dz = (double)qz - (double)c.z;
+        double s = 0.0;
+        s = s + dx * dx;
+        s = s + dy * dy;
+        s = s + dz * dz;
+        return s;
+    }
+    __device__ __forceinline__ static float to_d2(double k) { return (float)k; }
+};
+struct MetricDiff {  // chamfer: (dx^2 + dy^2) + dz^2 in fp32, no contraction
+    typedef float key_t;
+    float qx, qy, qz;
+    __device__ __forceinline__ void set(float x, float y, float z) { qx = x, qy = y, qz = z; }
+    __device__ __forceinline__ float operator()(const float4 &c) const { return d2_diff3(qx, qy, qz, c.x, c.y, c.z); }
+    __device__ __forceinline__ static float to_d2(float k) { return k; }
+};
+
+// Walk cubes of radius R = 1, 2, ... around the query's cell until the K-th best key is certified:
+// every unvisited point is at least `face` away (true distance), the reference-rounded squared
+// distance of such a point is >= face^2 - margin, so once kth_d2 < face^2*(1-1e-4) - margin nothing
+// outside can rank before the current K-th.
+template <int K, class Metric>
+__device__ __forceinline__ void grid_search(const GridView &g, float qx, float qy, float qz, Metric &met,
+                                            KBest<K, typename Metric::key_t> &kb) {
+    const int G = g.G;
+    const float inv = 1.0f / g.h;
+    int cx = (int)((qx - g.ox) * inv), cy = (int)((qy - g.oy) * inv), cz = (int)((qz - g.oz) * inv);
+    cx = cx < 0 ? 0 : (cx > G - 1 ? G - 1 : cx);
+    cy = cy < 0 ? 0 : (cy > G - 1 ? G - 1 : cy);
+    cz = cz < 0 ? 0 : (cz > G - 1 ? G - 1 : cz);
+    const float q2 = sumsq3(qx, qy, qz);
+    const float margin = 64.f * 1.1920929e-7f * (g.scale2 + q2) + 1e-30f;
+    int Rprev = -1;
+    for (int R = 1; R <= G; ++R) {
+        const int x0 = cx - R < 0 ? 0 : cx - R, x1 = cx + R > G - 1 ? G - 1 : cx + R;
+        const int y0 = cy - R < 0 ? 0 : cy - R, y1 = cy + R > G - 1 ? G - 1 : cy + R;
+        const int z0 = cz - R < 0 ? 0 : cz - R, z1 = cz + R > G - 1 ? G - 1 : cz + R;
+        // cells that are adjacent in x are adjacent in memory: each (z, y) row of the cube is one
+        // contiguous candidate range (two when the row crosses the already visited inner cube)
+        for (int z = z0; z <= z1; ++z)
+            for (int y = y0; y <= y1; ++y) {
+                const int rowbase = (z * G + y) * G;
+                const bool inner_zy = (abs(z - cz) <= Rprev) && (abs(y - cy) <= Rprev);
+                int sa0, sa1, sb0 = 0, sb1 = 0;
+                if (inner_zy) {
+                    const int ix0 = cx - Rprev < 0 ? 0 : cx - Rprev;  // visited run, clipped like the cube
+                    const int ix1 = cx + Rprev > G - 1 ? G - 1 : cx + Rprev;
+                    sa0 = g.start[rowbase + x0];
+                    sa1 = g.start[rowbase + ix0];
+                    sb0 = g.start[rowbase + ix1 + 1];
+                    sb1 = g.start[rowbase + x1 + 1];
+                } else {
+                    sa0 = g.start[rowbase + x0];
+                    sa1 = g.start[rowbase + x1 + 1];
+                }
+                for (int s = sa0; s < sa1; ++s) kb.insert_lex(met(g.pts[s]), g.ids[s]);
+                for (int s = sb0; s < sb1; ++s) kb.insert_lex(met(g.pts[s]), g.ids[s]);
+            }
+        // certification.  An unvisited point lies inside the grid's box but beyond one of the cube's
+        // (unclipped) faces, say along axis a:  |p - q|^2 >= f_a^2 + sum_{b != a} e_b^2, with f_a the
+        // distance from q to that face and e_b the distance from q to the box along axis b (0 inside).
+        const float ext = (float)G * g.h;
+        const float ex = fmaxf(0.f, fmaxf(g.ox - qx, qx - (g.ox + ext)));
+        const float ey = fmaxf(0.f, fmaxf(g.oy - qy, qy - (g.oy + ext)));
+        const float ez = fmaxf(0.f, fmaxf(g.oz - qz, qz - (g.oz + ext)));
+        const float exx = ex * ex, eyy = ey * ey, ezz = ez * ez;
+        float bound2 = INFINITY;
+        auto face_x = [&](float f) { f = fmaxf(f, 0.f); bound2 = fminf(bound2, f * f + eyy + ezz); };
+        auto face_y = [&](float f) { f = fmaxf(f, 0.f); bound2 = fminf(bound2, f * f + exx + ezz); };
+        auto face_z = [&](float f) { f = fmaxf(f, 0.f); bound2 = fminf(bound2, f * f + exx + eyy); };
+        if (cx - R >= 1) face_x(qx - (g.ox + (float)(cx - R) * g.h));
+        if (cx + R < G - 1) face_x((g.ox + (float)(cx + R + 1) * g.h) - qx);
+        if (cy - R >= 1) face_y(qy - (g.oy + (float)(cy - R) * g.h));
+        if (cy + R < G - 1) face_y((g.oy + (float)(cy + R + 1) * g.h) - qy);
+        if (cz - R >= 1) face_z(qz - (g.oz + (float)(cz - R) * g.h));
+        if (cz + R < G - 1) face_z((g.oz + (float)(cz + R + 1) * g.h) - qz);
+        if (bound2 == INFINITY) break;  // the cube covers the whole grid
+        const float kth = Metric::to_d2(kb.key[K - 1]);
+        if (kth < bound2 * 0.9999f - margin) break;
+        Rprev = R;
+    }
+}
+
+// ---------------------------------------------------------------- kernels on top of grid_search
+// xyz kNN of a cloud against itself (knn_grad): thread t handles the t-th point in cell order.
+template <int K>
+__global__ __launch_bounds__(128) void grid_knn_self_kernel(GridBuf gb, int k, int32_t *__restrict__ idx) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int P = gb.P;
+    if (t >= P) return;
+    GridView g = grid_view(gb, b);
+    const float4 qp = g.pts[t];
+    MetricMMQueryRow met;
+    met.set(qp.x, qp.y, qp.z);
+    KBest<K, float> kb;
+    kb.init(INFINITY);
+    grid_search<K, MetricMMQueryRow>(g, qp.x, qp.y, qp.z, met, kb);
+    int32_t *o = idx + ((size_t)b * P + g.ids[t]) * k;
+    for (int q = 0; q < K; ++q)
+        if (q < k) o[q] = q < P ? kb.idx[q] : 0;
+}
+
+// node ring: 9-NN among nodes in fp64 (grid over the nodes, queries = nodes in cell order)
+__global__ __launch_bounds__(128) void grid_ring_kernel(GridBuf gb, int32_t *__restrict__ ring) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int P = gb.P;
+    if (t >= P) return;
+    GridView g = grid_view(gb, b);
+    const float4 qp = g.pts[t];
+    MetricF64 met;
+    met.set(qp.x, qp.y, qp.z);
+    KBest<9, double> kb;
+    kb.init((double)INFINITY);
+    grid_search<9, MetricF64>(g, qp.x, qp.y, qp.z, met, kb);
+    const int a = g.ids[t];
+    int32_t *o = ring + ((size_t)b * P + a) * 9;
+    for (int q = 0; q < 9; ++q) o[q] = q < P ? kb.idx[q] : a;
+}
+
+// influence nodes (3 nearest nodes, matmul form with the node as row operand) on the node grid, and
+// the fp64 distance to the nearest other vertex on the vertex grid
+__global__ __launch_bounds__(128) void grid_infl_kernel(const float *__restrict__ xyz, int N, GridBuf gnodes, GridBuf gverts,
+                                                        int32_t *__restrict__ infl, float *__restrict__ dists,
+                                                        double *__restrict__ nnd) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N) return;
+    GridView gv = grid_view(gverts, b);
+    const float4 qp = gv.pts[t];  // vertices in cell order (coherent waves)
+    const int i = gv.ids[t];
+    {
+        GridView gn = grid_view(gnodes, b);
+        MetricMMCandRow met;
+        met.set(qp.x, qp.y, qp.z);
+        KBest<3, float> kb;
+        kb.init(INFINITY);
+        grid_search<3, MetricMMCandRow>(gn, qp.x, qp.y, qp.z, met, kb);
+        const size_t row = (size_t)b * N + i;
+        for (int q = 0; q < 3; ++q) {
+            infl[row * 3 + q] = q < gnodes.P ? kb.idx[q] : 0;
+            dists[row * 3 + q] = kb.key[q];
+        }
+    }
+    {
+        MetricF64 met;
+        met.set(qp.x, qp.y, qp.z);
+        KBest<2, double> kb;
+        kb.init((double)INFINITY);
+        grid_search<2, MetricF64>(gv, qp.x, qp.y, qp.z, met, kb);
+        nnd[(size_t)b * N + i] = sqrt(kb.key[1]);
+    }
+    (void)xyz;
+}
+
+// Chamfer: nearest neighbour of every a-point in cloud b (difference form), grouped launches
+struct ChGridGroup {
+    GridBuf gq;  // grid of the QUERY cloud: queries are taken in its cell order so that the lanes of a
+                 // wave walk the same target cells (coalesced / broadcast loads)
+    GridBuf gb;  // grid of the target cloud
+    float *dout;
+    int32_t *iout;
+};
+struct ChGridArgs {
+    ChGridGroup g[8];
+};
+__global__ __launch_bounds__(128) void grid_chamfer_kernel(const ChGridArgs args) {
+    const ChGridGroup &G = args.g[blockIdx.z];
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int Na = G.gq.P;
+    if (t >= Na) return;
+    GridView g = grid_view(G.gb, b);
+    GridView q = grid_view(G.gq, b);
+    const float4 qp = q.pts[t];
+    const int i = q.ids[t];
+    MetricDiff met;
+    met.set(qp.x, qp.y, qp.z);
+    KBest<1, float> kb;
+    kb.init(INFINITY);
+    grid_search<1, MetricDiff>(g, qp.x, qp.y, qp.z, met, kb);
+    G.dout[(size_t)b * Na + i] = kb.key[0];
+    if (G.iout) G.iout[(size_t)b * Na + i] = kb.idx[0];
+}
+
+// ---------------------------------------------------------------- host side
+size_t grid_bytes(int B, int P) {
+    const int G = grid_dim_for(P), G3 = G * G * G;
+    return align_up((size_t)B * P * sizeof(float4)) + align_up((size_t)B * P * sizeof(int32_t)) +
+           align_up((size_t)B * (G3 + 1) * sizeof(int32_t)) + align_up((size_t)B * 8 * sizeof(float));
+}
+
+GridBuf grid_carve(Arena &ar, int B, int P) {
+    GridBuf gb;
+    gb.P = P;
+    gb.G = grid_dim_for(P);
+    const int G3 = gb.G * gb.G * gb.G;
+    gb.pts = ar.take<float4>((size_t)B * P);
+    gb.ids = ar.take<int32_t>((size_t)B * P);
+    gb.start = ar.take<int32_t>((size_t)B * (G3 + 1));
+    gb.params = ar.take<float>((size_t)B * 8);
+    return gb;
+}
+
+void launch_grid_build(const float *xyz, int B, int Nsrc, const int32_t *sel, const GridBuf &gb, hipStream_t s) {
+    const int G3 = gb.G * gb.G * gb.G;
+    size_t lds = (size_t)(2 * G3 + 1) * sizeof(int);
+    hipLaunchKernelGGL(grid_build_kernel, dim3(B), dim3(GRID_T), lds, s, xyz, Nsrc, sel, gb);
+}
+
+void launch_grid_knn_self(const GridBuf &gb, int B, int k, int32_t *idx, hipStream_t s) {
+    dim3 grid((gb.P + 127) / 128, B);
+    if (k <= 3)
+        hipLaunchKernelGGL(grid_knn_self_kernel<3>, grid, dim3(128), 0, s, gb, k, idx);
+    else if (k <= 10)
+        hipLaunchKernelGGL(grid_knn_self_kernel<10>, grid, dim3(128), 0, s, gb, k, idx);
+    else
+        hipLaunchKernelGGL(grid_knn_self_kernel<16>, grid, dim3(128), 0, s, gb, k, idx);
+}
+
+void launch_grid_ring(const GridBuf &gnodes, int B, int32_t *ring, hipStream_t s) {
+    hipLaunchKernelGGL(grid_ring_kernel, dim3((gnodes.P + 127) / 128, B), dim3(128), 0, s, gnodes, ring);
+}
+
+void launch_grid_infl(const float *xyz, int B, int N, const GridBuf &gnodes, const GridBuf &gverts, int32_t *infl, float *dists,
+                      double *nnd, hipStream_t s) {
+    hipLaunchKernelGGL(grid_infl_kernel, dim3((N + 127) / 128, B), dim3(128), 0, s, xyz, N, gnodes, gverts, infl, dists, nnd);
+}
+
+void launch_grid_chamfer(const GridBuf *gq, const GridBuf *gb, float *const *dout, int32_t *const *iout, int ngroups, int B,
+                         hipStream_t s) {
+    ChGridArgs args;
+    int maxN = 1;
+    for (int q = 0; q < 8; ++q) {
+        int r = q < ngroups ? q : 0;
+        args.g[q] = ChGridGroup{gq[r], gb[r], dout[r], iout ? iout[r] : nullptr};
+        if (q < ngroups && gq[r].P > maxN) maxN = gq[r].P;
+    }
+    hipLaunchKernelGGL(grid_chamfer_kernel, dim3((maxN + 127) / 128, B, ngroups), dim3(128), 0, s, args);
+}
+
+}  // namespace dvm

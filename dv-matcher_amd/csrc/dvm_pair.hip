@@ -11,7 +11,8 @@ int map_term_blocks(int N, int k);
 int launch_map_term(const float *verts12, const float *verts2, const int32_t *idx11, const int32_t *idx22, const float *pi_val,
                     const int32_t *pi_idx, int B, int N, int M, int k, int topk, double *partial, hipStream_t s);
 int launch_dg_build(const float *xyz, int B, int N, const int32_t *start, int32_t *nodes_idx, int32_t *ring, int32_t *infl_idx,
-                    float *dists, float *weights, double *sigma, double *nnd, hipStream_t s);
+                    float *dists, float *weights, double *sigma, double *nnd, const GridBuf &gverts, const GridBuf &gnodes,
+                    bool build_gverts, hipStream_t s);
 int launch_dg_warp(const float *xyz, int B, int N, const int32_t *nodes_idx, const int32_t *ring, const int32_t *infl_idx,
                    const float *weights, const float *def9, float *R, float *T, float *warped, float *arap, int arap_stride,
                    float *sr, hipStream_t s);
@@ -37,6 +38,7 @@ struct PairWs {
     double *nnd, *partial;
     void *sc_ws, *df_ws;
     size_t sc_bytes, df_bytes;
+    GridBuf gv1, gn1, gv2, gw, g12;
 };
 
 static size_t carve_pair(Arena &ar, int B, int N, int M, PairWs &w) {
@@ -61,6 +63,11 @@ static size_t carve_pair(Arena &ar, int B, int N, int M, PairWs &w) {
     w.sc_ws = ar.take<char>(w.sc_bytes);
     w.df_bytes = deformer_ws_bytes(B, M, Nn);
     w.df_ws = ar.take<char>(w.df_bytes);
+    w.gv1 = grid_carve(ar, B, N);
+    w.gn1 = grid_carve(ar, B, Nn);
+    w.gv2 = grid_carve(ar, B, M);
+    w.gw = grid_carve(ar, B, N);
+    w.g12 = grid_carve(ar, B, N);
     return ar.off;
 }
 }  // namespace dvm
@@ -96,7 +103,7 @@ DVM_EXPORT int dvm_pair_direction_fwd_f32(const float *feat1, const float *feat2
     const int Nn = N / 2, k = 10, topk = 10;
     int rc;
     // graph of the source cloud (nodes, ring, skinning weights)
-    launch_dg_build(verts1, B, N, fps_start, w.nodes, w.ring, w.infl, w.dists, w.weights, nullptr, w.nnd, s);
+    launch_dg_build(verts1, B, N, fps_start, w.nodes, w.ring, w.infl, w.dists, w.weights, nullptr, w.nnd, w.gv1, w.gn1, true, s);
     // soft correspondence Pi_12 (top-10) and the arg-max map
     rc = dvm_softcorr_fwd_f32(feat1, feat2, B, N, M, 128, neg_alpha, topk, w.pval, w.pidx, nullptr, nullptr, 0, w.sc_ws,
                               w.sc_bytes, s);
@@ -105,11 +112,10 @@ DVM_EXPORT int dvm_pair_direction_fwd_f32(const float *feat1, const float *feat2
     // verts12 = Pi_12 @ verts2
     rc = dvm_softcorr_apply_f32(w.pval, w.pidx, verts2, B, N, M, topk, 3, verts12, s);
     if (rc != DVM_OK) return rc;
-    // xyz neighbourhoods
-    rc = dvm_knn_cdist_f32(verts1, verts1, B, N, N, 3, k, w.idx11, s);
-    if (rc != DVM_OK) return rc;
-    rc = dvm_knn_cdist_f32(verts2, verts2, B, M, M, 3, k, w.idx22, s);
-    if (rc != DVM_OK) return rc;
+    // xyz neighbourhoods (grids: verts1's was built with the graph)
+    launch_grid_knn_self(w.gv1, B, k, w.idx11, s);
+    launch_grid_build(verts2, B, M, nullptr, w.gv2, s);
+    launch_grid_knn_self(w.gv2, B, k, w.idx22, s);
     // Deformer -> per-node [t, r6]
     rc = launch_deformer(feat1, feat2, verts1, verts12, w.idx11, w.idx22, w.pval, w.pidx, w.nodes, B, N, M, Nn, k, topk, conv_w,
                          conv_b, W0, b0, W1, b1, W2, b2, W3, b3, w.def9, 0, w.df_ws, w.df_bytes, s);
@@ -117,14 +123,19 @@ DVM_EXPORT int dvm_pair_direction_fwd_f32(const float *feat1, const float *feat2
     // embedded-deformation warp + ARAP (losses[:,1])
     launch_dg_warp(verts1, B, N, w.nodes, w.ring, w.infl, w.weights, w.def9, w.R, w.T, warped, losses + 2, 6, nullptr, s);
     // chamfer(warped, verts2) -> losses[:,0:2]; chamfer(verts12, verts2) -> losses[:,3:5]
-    rc = dvm_chamfer_fwd_f32(warped, verts2, B, N, M, w.d1, w.d2, nullptr, nullptr, s);
-    if (rc != DVM_OK) return rc;
-    launch_mean(w.d1, B, N, 1.f, losses, 6, 0, 0, s);
-    launch_mean(w.d2, B, M, 1.f, losses, 6, 1, 0, s);
-    rc = dvm_chamfer_fwd_f32(verts12, verts2, B, N, M, w.d1, w.d2, nullptr, nullptr, s);
-    if (rc != DVM_OK) return rc;
-    launch_mean(w.d1, B, N, 1.f, losses, 6, 3, 0, s);
-    launch_mean(w.d2, B, M, 1.f, losses, 6, 4, 0, s);
+    launch_grid_build(warped, B, N, nullptr, w.gw, s);
+    launch_grid_build(verts12, B, N, nullptr, w.g12, s);
+    {
+        GridBuf qg[2] = {w.gw, w.gv2}, tg[2] = {w.gv2, w.gw};
+        float *dout[2] = {w.d1, w.d2};
+        launch_grid_chamfer(qg, tg, dout, nullptr, 2, B, s);
+        launch_mean(w.d1, B, N, 1.f, losses, 6, 0, 0, s);
+        launch_mean(w.d2, B, M, 1.f, losses, 6, 1, 0, s);
+        GridBuf qg2[2] = {w.g12, w.gv2}, tg2[2] = {w.gv2, w.g12};
+        launch_grid_chamfer(qg2, tg2, dout, nullptr, 2, B, s);
+        launch_mean(w.d1, B, N, 1.f, losses, 6, 3, 0, s);
+        launch_mean(w.d2, B, M, 1.f, losses, 6, 4, 0, s);
+    }
     if (with_map) {
         launch_map_term(verts12, verts2, w.idx11, w.idx22, w.pval, w.pidx, B, N, M, k, topk, w.partial, s);
         launch_reduce_partials(w.partial, B, map_term_blocks(N, k), 1.f, losses, 6, 5, s);
@@ -163,6 +174,8 @@ struct Pair2Ws {
     double *nnd[2], *partial[2];
     float *z, *def9, *R, *T, *wp;
     float *cd[8];
+    GridBuf gv[2], gn[2], gw[2], gc[2];  // vertices, nodes, warped clouds, Pi-mapped clouds
+    GridBuf gvcat, gncat;                // 2B-shape grids when N == M
 };
 
 static size_t carve_pair2(Arena &ar, int B, int N, int M, Pair2Ws &w) {
@@ -190,6 +203,23 @@ static size_t carve_pair2(Arena &ar, int B, int N, int M, Pair2Ws &w) {
     w.wp = ar.take<float>(mlp_pack_floats());
     const int cdn[8] = {N, M, N, M, M, N, M, N};
     for (int q = 0; q < 8; ++q) w.cd[q] = ar.take<float>((size_t)B * cdn[q]);
+    if (N == M) {
+        w.gvcat = grid_carve(ar, 2 * B, N);
+        w.gncat = grid_carve(ar, 2 * B, N / 2);
+        for (int sd = 0; sd < 2; ++sd) {
+            w.gv[sd] = grid_slice(w.gvcat, sd * B);
+            w.gn[sd] = grid_slice(w.gncat, sd * B);
+        }
+    } else {
+        for (int sd = 0; sd < 2; ++sd) {
+            w.gv[sd] = grid_carve(ar, B, P[sd]);
+            w.gn[sd] = grid_carve(ar, B, P[sd] / 2);
+        }
+    }
+    for (int sd = 0; sd < 2; ++sd) {
+        w.gw[sd] = grid_carve(ar, B, P[sd]);
+        w.gc[sd] = grid_carve(ar, B, P[sd]);
+    }
     return ar.off;
 }
 
@@ -238,15 +268,13 @@ DVM_EXPORT int dvm_pair_fwd_f32(const float *feat1, const float *feat2, const fl
         (void)hipMemcpyAsync(w.startcat, start1, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
         (void)hipMemcpyAsync(w.startcat + B, start2, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
         launch_dg_build(w.vcat, 2 * B, N, w.startcat, w.nodes[0], w.ring[0], w.infl[0], w.dists[0], w.weights[0], nullptr,
-                        w.nnd[0], s);
-        rc = dvm_knn_cdist_f32(w.vcat, w.vcat, 2 * B, N, N, 3, 10, w.idxk[0], s);
-        if (rc != DVM_OK) return rc;
+                        w.nnd[0], w.gvcat, w.gncat, true, s);
+        launch_grid_knn_self(w.gvcat, 2 * B, 10, w.idxk[0], s);
     } else {
         for (int sd = 0; sd < 2; ++sd) {
             launch_dg_build(verts[sd], B, P[sd], start[sd], w.nodes[sd], w.ring[sd], w.infl[sd], w.dists[sd], w.weights[sd],
-                            nullptr, w.nnd[sd], s);
-            rc = dvm_knn_cdist_f32(verts[sd], verts[sd], B, P[sd], P[sd], 3, 10, w.idxk[sd], s);
-            if (rc != DVM_OK) return rc;
+                            nullptr, w.nnd[sd], w.gv[sd], w.gn[sd], true, s);
+            launch_grid_knn_self(w.gv[sd], B, 10, w.idxk[sd], s);
         }
     }
     // ---- soft correspondence, both directions in one launch
@@ -276,10 +304,14 @@ DVM_EXPORT int dvm_pair_fwd_f32(const float *feat1, const float *feat2, const fl
                    nullptr, s);
     // ---- the four Chamfer terms, both sides each, in one grouped launch
     {
-        const float *a[8] = {warped12, verts2, verts12, verts2, warped21, verts1, verts21, verts1};
-        const float *bq[8] = {verts2, warped12, verts2, verts12, verts1, warped21, verts1, verts21};
-        const int Na[8] = {N, M, N, M, M, N, M, N}, Nb[8] = {M, N, M, N, N, M, N, M};
-        launch_chamfer_grouped(a, bq, Na, Nb, w.cd, 8, B, s);
+        launch_grid_build(warped12, B, N, nullptr, w.gw[0], s);
+        launch_grid_build(verts12, B, N, nullptr, w.gc[0], s);
+        launch_grid_build(warped21, B, M, nullptr, w.gw[1], s);
+        launch_grid_build(verts21, B, M, nullptr, w.gc[1], s);
+        const GridBuf qg[8] = {w.gw[0], w.gv[1], w.gc[0], w.gv[1], w.gw[1], w.gv[0], w.gc[1], w.gv[0]};
+        const GridBuf tg[8] = {w.gv[1], w.gw[0], w.gv[1], w.gc[0], w.gv[0], w.gw[1], w.gv[0], w.gc[1]};
+        const int Na[8] = {N, M, N, M, M, N, M, N};
+        launch_grid_chamfer(qg, tg, w.cd, nullptr, 8, B, s);
         float *L[2] = {losses12, losses21};
         const int off[4] = {0, 1, 3, 4};
         for (int q = 0; q < 8; ++q) launch_mean(w.cd[q], B, Na[q], 1.f, L[q / 4], 6, off[q % 4], 0, s);

@@ -29,7 +29,8 @@ SIGNATURES = {
     "dvm_softcorr_fwd_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P, _P, _P, _P, c_int, _P,
                                      c_size_t, _P]),
     "dvm_argmin_exact_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
-    "dvm_knn_cdist_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "dvm_knn_cdist_workspace_bytes": (c_size_t, [c_int] * 4),
+    "dvm_knn_cdist_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_size_t, _P]),
     "dvm_knn_neg_workspace_bytes": (c_size_t, [c_int] * 5),
     "dvm_knn_neg_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_size_t, _P]),
     "dvm_softcorr_dense_workspace_bytes": (c_size_t, [c_int] * 4),
@@ -49,7 +50,8 @@ SIGNATURES = {
     "dvm_dg_build_f32": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "dvm_rot6d_f32": (c_int, [_P, c_int, _P, _P]),
     "dvm_dg_warp_arap_fwd_f32": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "dvm_chamfer_fwd_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    "dvm_chamfer_workspace_bytes": (c_size_t, [c_int] * 3),
+    "dvm_chamfer_fwd_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
     "dvm_deformer_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dvm_deformer_fwd_f32": (c_int, [_P] * 9 + [c_int] * 6 + [_P] * 10 + [_P, c_int, _P, c_size_t, _P]),
     "dvm_map_term_workspace_bytes": (c_size_t, [c_int, c_int]),

@@ -96,7 +96,10 @@ def knn_cdist(x, y, k):
     B, N, C = x.shape
     M = y.shape[1]
     idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
-    check(_lib.load().dvm_knn_cdist_f32(_p(x), _p(y), B, N, M, C, k, _p(idx), _stream()), "dvm_knn_cdist_f32")
+    lib = _lib.load()
+    nb = lib.dvm_knn_cdist_workspace_bytes(B, N, M, C)
+    ws = workspace(nb, x.device, "knn_cdist")
+    check(lib.dvm_knn_cdist_f32(_p(x), _p(y), B, N, M, C, k, _p(idx), _p(ws), nb, _stream()), "dvm_knn_cdist_f32")
     return idx
 
 
@@ -177,7 +180,10 @@ def chamfer(a, b, want_idx=True):
     d2 = torch.empty(B, M, dtype=torch.float32, device=dev)
     i1 = torch.empty(B, N, dtype=torch.int32, device=dev) if want_idx else None
     i2 = torch.empty(B, M, dtype=torch.int32, device=dev) if want_idx else None
-    check(_lib.load().dvm_chamfer_fwd_f32(_p(a), _p(b), B, N, M, _p(d1), _p(d2), _p(i1), _p(i2), _stream()),
+    lib = _lib.load()
+    nb = lib.dvm_chamfer_workspace_bytes(B, N, M)
+    ws = workspace(nb, dev, "chamfer")
+    check(lib.dvm_chamfer_fwd_f32(_p(a), _p(b), B, N, M, _p(d1), _p(d2), _p(i1), _p(i2), _p(ws), nb, _stream()),
           "dvm_chamfer_fwd_f32")
     return d1, d2, i1, i2
 

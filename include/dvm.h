@@ -75,8 +75,11 @@ int dvm_argmin_exact_f32(const float *f1, const float *f2, int B, int N, int M, 
                          void *stream);
 
 /* knn_grad — models/loss.py:97-101: the k smallest of cdist(x,y) (matmul form)
- * per row, ascending.  x [B,N,C], y [B,M,C] -> idx [B,N,k]; C <= 16, k <= 16. */
-int dvm_knn_cdist_f32(const float *x, const float *y, int B, int N, int M, int C, int k, int32_t *idx, void *stream);
+ * per row, ascending.  x [B,N,C], y [B,M,C] -> idx [B,N,k]; C <= 16, k <= 16.  A 3-D cloud against
+ * itself (x == y) is searched exactly on a uniform grid; otherwise brute force (ws may be NULL). */
+size_t dvm_knn_cdist_workspace_bytes(int B, int N, int M, int C);
+int dvm_knn_cdist_f32(const float *x, const float *y, int B, int N, int M, int C, int k, int32_t *idx, void *ws,
+                      size_t ws_bytes, void *stream);
 
 /* knn_new / knn — models/model.py:267-278, models/loss.py:451-462: the k largest of
  * (-|a|^2 - (-2 a.b)) - |b|^2 per row, descending (ties -> lowest column).
@@ -123,8 +126,9 @@ int dvm_dg_warp_arap_fwd_f32(const float *xyz, int B, int N, const int32_t *node
 /* chamfer_3DDist — third-party ChamferDistancePytorch (un-vendored); call sites
  * models/loss.py:1120,1223,874.  a [B,N,3], b [B,M,3] -> d1 [B,N], d2 [B,M] squared NN
  * distances, i1 [B,N], i2 [B,M] (optional). */
+size_t dvm_chamfer_workspace_bytes(int B, int N, int M);
 int dvm_chamfer_fwd_f32(const float *a, const float *b, int B, int N, int M, float *d1, float *d2, int32_t *i1,
-                        int32_t *i2, void *stream);
+                        int32_t *i2, void *ws, size_t ws_bytes, void *stream);
 
 /* Deformer.forward — models/model.py:464-478 (+ MLP 433-452), fed the raw features and
  * kNN indices instead of the (B,N,k,128) gathers of models/loss.py:1254-1255.

@@ -63,5 +63,5 @@ def test_argument_validation_without_gpu():
     assert rc == -1 and b"d=130" in lib.dvm_last_error()
     rc = lib.dvm_softcorr_fwd_f32(one, one, 1, 8, 8, 128, -1.0, 10, one, one, None, None, 0, None, 0, None)
     assert rc == -3 and b"workspace" in lib.dvm_last_error()
-    rc = lib.dvm_knn_cdist_f32(one, one, 1, 8, 8, 3, 17, one, None)
+    rc = lib.dvm_knn_cdist_f32(one, one, 1, 8, 8, 3, 17, one, None, 0, None)
     assert rc == -1
