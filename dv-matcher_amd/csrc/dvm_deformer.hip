@@ -168,7 +168,9 @@ __global__ __launch_bounds__(256) void assemble_pooled_kernel(const float *__res
     }
 }
 
-__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+// ELU as torch evaluates it on fp32: exp(x) - 1 (not expm1); v_exp_f32 keeps the epilogue off the
+// fp32 ALU that the matrix instructions of this kernel also run on
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : __builtin_amdgcn_exp2f(x * 1.4426950408889634f) - 1.f; }
 
 // ---------------------------------------------------------------- scalar MLP layer (check variant)
 __global__ void mlp_layer_scalar_kernel(const float *__restrict__ in, int in_stride, const float *__restrict__ W,
@@ -209,14 +211,40 @@ constexpr size_t ML_LDS_BYTES = (size_t)ML_NODES * (ML_SA + ML_SB) * sizeof(floa
 __device__ __forceinline__ f32x16 mlp_tile(const float *__restrict__ act_row /* lane's node row + h*half */,
                                            const float *__restrict__ wp /* + lane */, int steps) {
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < steps; s += 4) {
-        f32x4 a = *(const f32x4 *)(act_row + s);
-        float b0 = wp[(size_t)(s + 0) * 64], b1 = wp[(size_t)(s + 1) * 64], b2 = wp[(size_t)(s + 2) * 64],
-              b3 = wp[(size_t)(s + 3) * 64];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b2, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b3, acc, 0, 0, 0);
+    // The chain is dependent (one MFMA per 64 cycles), so the operands of the NEXT 8 k-steps are
+    // fetched (weights: 8 coalesced 256-B loads from L2; activations: 2 ds_read_b128) while the
+    // current 8 MFMAs run.  steps % 4 == 0; a trailing group of 4 is handled after the loop.
+    float b[8], bn[8];
+    f32x4 a0, a1, an0, an1;
+    const int full = steps & ~7;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) b[u] = (u < steps) ? wp[(size_t)u * 64] : 0.f;
+    a0 = *(const f32x4 *)(act_row);
+    a1 = (steps > 4) ? *(const f32x4 *)(act_row + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < full; s += 8) {
+        const int sn = s + 8;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) bn[u] = (sn + u < steps) ? wp[(size_t)(sn + u) * 64] : 0.f;
+        an0 = (sn < steps) ? *(const f32x4 *)(act_row + sn) : f32x4{0.f, 0.f, 0.f, 0.f};
+        an1 = (sn + 4 < steps) ? *(const f32x4 *)(act_row + sn + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b[3], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b[4], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b[5], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b[6], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b[7], acc, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) b[u] = bn[u];
+        a0 = an0;
+        a1 = an1;
+    }
+    if (steps & 4) {  // trailing 4 steps (operands already loaded)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b[3], acc, 0, 0, 0);
     }
     return acc;
 }

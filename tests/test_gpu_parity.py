@@ -180,7 +180,7 @@ def test_deformer_and_chamfer(ops, golden, name, variant):
     for b in range(out.shape[0]):
         o = O.deformer(w, g["feat1"][b], g["feat2"][b], g["verts1"][b], host(v12)[b], host(idx11)[b], host(idx22)[b],
                        host(val)[b], host(idx)[b], g["fps1"][b])
-        np.testing.assert_allclose(out[b], o, rtol=0, atol=2e-6)
+        np.testing.assert_allclose(out[b], o, rtol=0, atol=5e-6)
     d1, d2, i1, i2 = ops.chamfer(dev(g["verts12"]), v2)
     for b in range(out.shape[0]):
         od1, od2, oi1, oi2 = O.chamfer(g["verts12"][b], g["verts2"][b])
