@@ -79,7 +79,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=256, help="pairs per GPU per step (resident batch)")
     ap.add_argument("--cpu-sample", type=int, default=48, help="pairs timed for cpu_baseline (0 = skip)")
-    ap.add_argument("--traffic-bytes", type=float, default=None, help="per-launch HBM bytes from the PMC passes (profiles/)")
+    ap.add_argument("--traffic-bytes", type=float, default=None,
+                    help="per-launch HBM bytes of the dominant kernel from the PMC passes (default: profiles/k1_traffic.json)")
     args = ap.parse_args()
 
     import torch
@@ -141,6 +142,10 @@ def main():
         # roofline of the dominant kernel: one launch covers BOTH directions of P pairs; its algorithmic
         # flops are P x 2*N*M*d (SURVEY §8d counts the distance tile once per pair; the kernel evaluates it
         # once per direction, i.e. performs twice that)
+        traffic = args.traffic_bytes
+        tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
+        if traffic is None and P == 256 and os.path.exists(tpath):  # measured for this exact launch shape
+            traffic = json.load(open(tpath)).get("bytes_per_launch")
         k1_ms = ms.value / max(nl.value, 1)
         flops_launch = P * (2.0 * N_PTS * M_PTS * DIM)
         achieved = flops_launch / (k1_ms * 1e-3) / 1e12 if k1_ms > 0 else 0.0
@@ -154,7 +159,7 @@ def main():
                        "parallelism": "pairs sharded over %d GPU(s), no collective" % world},
             "roofline": {"bound": "mfma", "kernel": "softcorr_mfma_kernel<10>", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": args.traffic_bytes, "launch_ms": k1_ms, "launches_timed": nl.value,
+                         "traffic": traffic, "launch_ms": k1_ms, "launches_timed": nl.value,
                          "flops_per_launch": flops_launch,
                          "share_of_step": (ms.value * 1e-3) / dt if dt > 0 else None},
         }
