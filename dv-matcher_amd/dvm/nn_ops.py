@@ -25,9 +25,152 @@ def pos_encoding(coor):
     return ops.pos_encoding(coor)
 
 
+def _needs_grad(*ts):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+
+
 def sa_attention(x, w_qk, w_v, b_v):
-    return ops.sa_attention(x, w_qk, w_v, b_v)
+    """SA_Layer's x_r.  Inference: fused HIP kernels (no N x N in HBM).  Training: the same math with
+    torch ops so autograd supplies the backward (interim, see the header comment further down)."""
+    if not _needs_grad(x, w_qk, w_v, b_v):
+        return ops.sa_attention(x, w_qk, w_v, b_v)
+    p = torch.nn.functional.conv1d(x, w_qk)
+    v = torch.nn.functional.conv1d(x, w_v, b_v)
+    att = torch.softmax(torch.bmm(p.transpose(1, 2), p), dim=-1)
+    att = att / (1e-9 + att.sum(dim=1, keepdim=True))
+    return torch.bmm(v, att)
 
 
 def n2p_attention(x, K, wq, wk, wv, heads):
-    return ops.n2p_attention(x, K, wq, wk, wv, heads)
+    """N2PAttention's attention output.  The kNN indices always come from the HIP kernel; training
+    evaluates the attention with torch ops (projection by linearity, gathered rows) for autograd."""
+    if not _needs_grad(x, wq, wk, wv):
+        return ops.n2p_attention(x, K, wq, wk, wv, heads)
+    B, C, N = x.shape
+    xt = x.transpose(1, 2).contiguous()
+    idx = ops.knn_neg(xt, xt, K)
+    w = torch.cat([wq.reshape(C, C), wk.reshape(C, C), wv.reshape(C, C)], 0)
+    qkv = torch.nn.functional.linear(xt, w)
+    q, kp, vp = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    D = C // heads
+    kd = (gather_rows(kp, idx) - kp.unsqueeze(2)).view(B, N, K, heads, D)
+    vd = (gather_rows(vp, idx) - vp.unsqueeze(2)).view(B, N, K, heads, D)
+    e = (q.view(B, N, 1, heads, D) * kd).sum(-1) / (D ** 0.5)                 # (B,N,K,H)
+    a = torch.softmax(e, dim=2)
+    out = (a.unsqueeze(-1) * vd).sum(2).reshape(B, N, C)
+    return out.transpose(1, 2)
+
+
+# ------------------------------------------------------------------------------------------
+# Differentiable pieces of the criterion (training path).
+# Index searches and the fused soft correspondence run on the HIP kernels; the light, differentiable
+# algebra around them (gathers, weighted sums, the Deformer's GEMMs, the warp) is expressed with
+# torch ops on the device so that autograd provides its backward.  The soft correspondence's
+# backward recomputes the dense row softmax with torch ops (interim: a fused HIP backward kernel —
+# recompute tiles from row_smax/row_sum — is the next step, DESIGN.md §7).
+# ------------------------------------------------------------------------------------------
+class _SoftCorrTopK(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, f1, f2, alpha, topk):
+        val, idx, smax, ssum = ops.softcorr(f1, f2, alpha, topk=topk)
+        ctx.save_for_backward(f1.detach(), f2.detach(), val, idx, smax, ssum)
+        ctx.neg_alpha = ops.neg_alpha_f32(alpha)
+        ctx.mark_non_differentiable(idx)
+        return val, idx
+
+    @staticmethod
+    def backward(ctx, gval, _gidx):
+        f1, f2, val, idx, smax, ssum = ctx.saved_tensors
+        na = ctx.neg_alpha
+        idx64 = idx.long()
+        df1 = torch.empty_like(f1)
+        df2 = torch.zeros_like(f2)
+        B, N, _ = f1.shape
+        step = max(1, min(N, (1 << 22) // max(1, f2.shape[1])))  # bound the dense temporary to ~16 MB rows-chunk
+        for b in range(B):
+            for r0 in range(0, N, step):
+                a = f1[b, r0:r0 + step]
+                D = torch.cdist(a[None], f2[b][None])[0]                      # (n, M)
+                P = torch.exp(D * na - smax[b, r0:r0 + step, None]) / ssum[b, r0:r0 + step, None]
+                gp = gval[b, r0:r0 + step] * val[b, r0:r0 + step]             # g_t P_t at the kept entries
+                dS = -P * gp.sum(-1, keepdim=True)
+                dS.scatter_add_(-1, idx64[b, r0:r0 + step], gp)
+                W = torch.where(D > 0, dS * na / D.clamp_min(1e-30), torch.zeros_like(D))
+                df1[b, r0:r0 + step] = W.sum(-1, keepdim=True) * a - W @ f2[b]
+                df2[b] += W.sum(0)[:, None] * f2[b] - W.t() @ a
+        return df1, df2, None, None
+
+
+def softcorr_topk(f1, f2, alpha, topk=10):
+    """Differentiable (w.r.t. f1, f2) top-k soft correspondence: (val (B,N,k), idx (B,N,k) int32)."""
+    return _SoftCorrTopK.apply(f1, f2, alpha, topk)
+
+
+def sparse_apply(val, idx, V):
+    """Pi~ @ V with autograd: val (B,N,k), idx (B,N,k), V (B,M,C) -> (B,N,C)."""
+    B, N, k = val.shape
+    C = V.shape[-1]
+    g = torch.gather(V, 1, idx.long().reshape(B, N * k, 1).expand(-1, -1, C)).view(B, N, k, C)
+    return (val.unsqueeze(-1) * g).sum(2)
+
+
+def gather_rows(x, idx):
+    """x (B,P,C), idx (B,N,k) -> (B,N,k,C)."""
+    B, N, k = idx.shape
+    return torch.gather(x, 1, idx.long().reshape(B, N * k, 1).expand(-1, -1, x.shape[-1])).view(B, N, k, -1)
+
+
+class _ChamferNN(torch.autograd.Function):
+    """Squared nearest-neighbour distances both ways; gradients flow to both clouds through the
+    (constant) arg-min indices, like the ChamferDistancePytorch extension's backward."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        d1, d2, i1, i2 = ops.chamfer(a, b)
+        ctx.save_for_backward(a.detach(), b.detach(), i1, i2)
+        return d1, d2
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        a, b, i1, i2 = ctx.saved_tensors
+        nb = torch.gather(b, 1, i1.long().unsqueeze(-1).expand(-1, -1, 3))
+        na = torch.gather(a, 1, i2.long().unsqueeze(-1).expand(-1, -1, 3))
+        t1 = 2 * g1.unsqueeze(-1) * (a - nb)       # d d1_i / d a_i ; minus that for b[i1]
+        t2 = 2 * g2.unsqueeze(-1) * (b - na)
+        ga = t1.clone()
+        gb = t2.clone()
+        ga.scatter_add_(1, i2.long().unsqueeze(-1).expand(-1, -1, 3), -t2)
+        gb.scatter_add_(1, i1.long().unsqueeze(-1).expand(-1, -1, 3), -t1)
+        return ga, gb
+
+
+def chamfer_nn(a, b):
+    return _ChamferNN.apply(a, b)
+
+
+def rot6d_torch(d6):
+    a1, a2 = d6[..., :3], d6[..., 3:]
+    b1 = torch.nn.functional.normalize(a1, dim=-1)
+    b2 = torch.nn.functional.normalize(a2 - (b1 * a2).sum(-1, keepdim=True) * b1, dim=-1)
+    return torch.stack((b1, b2, torch.cross(b1, b2, dim=-1)), dim=-2)
+
+
+def dg_warp_arap_torch(verts, g, R, T):
+    """Differentiable (w.r.t. R, T) embedded-deformation warp + ARAP for a batch.
+    verts (B,N,3), g: batched graph dict (int32 tensors), R (B,Nn,3,3), T (B,Nn,3) -> warped (B,N,3), arap (B,)."""
+    B, N, _ = verts.shape
+    Nn = R.shape[1]
+    nodes = torch.gather(verts, 1, g["nodes_idx"].long().unsqueeze(-1).expand(-1, -1, 3))      # (B,Nn,3)
+    infl = g["infl_idx"].long()                                                                # (B,N,3)
+    flat = infl.reshape(B, N * 3)
+    gn = torch.gather(nodes, 1, flat.unsqueeze(-1).expand(-1, -1, 3)).view(B, N, 3, 3)         # influencing node coords
+    Rn = torch.gather(R.reshape(B, Nn, 9), 1, flat.unsqueeze(-1).expand(-1, -1, 9)).view(B, N, 3, 3, 3)
+    Tn = torch.gather(T, 1, flat.unsqueeze(-1).expand(-1, -1, 3)).view(B, N, 3, 3)
+    diff = verts.unsqueeze(2) - gn
+    warped = ((torch.einsum('bnsij,bnsj->bnsi', Rn, diff) + gn + Tn) * g["weights"].unsqueeze(-1)).sum(2)
+    ring = g["one_ring"].long().reshape(B, Nn * 9)
+    nb = torch.gather(nodes, 1, ring.unsqueeze(-1).expand(-1, -1, 3)).view(B, Nn, 9, 3)
+    tb = torch.gather(T, 1, ring.unsqueeze(-1).expand(-1, -1, 3)).view(B, Nn, 9, 3)
+    e = (nodes + T).unsqueeze(2) - (nb + tb) - torch.einsum('bnij,bnqj->bnqi', R, nodes.unsqueeze(2) - nb)
+    arap = (e ** 2).sum(dim=(1, 2, 3)) / Nn
+    return warped, arap

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from dvm import ops
+from dvm import nn_ops, ops
 from lib.deformation_graph_point import DeformationGraph_geod
 from models.model import Deformer, index_points  # noqa: F401  (re-exported like the reference)
 
@@ -129,6 +129,50 @@ class GraphDeformLoss_Neural(nn.Module):
         map_sum = ops.map_term(verts12, verts2, idx11, idx22, pval, pidx) if (self.w_map > 0 and not self.partial_variant) else None
         return map_sum, cd_warp, arap.sum(), cd_self, dict(warped=warped, verts12=verts12, pval=pval, pidx=pidx)
 
+    def _chamfer_train(self, a, b):
+        d1, d2 = nn_ops.chamfer_nn(a, b)
+        if self.partial_variant:
+            return torch.mean(d1 if d1.shape[1] <= d2.shape[1] else d2)
+        return torch.mean(d1) + torch.mean(d2)
+
+    def _dist_term_train(self, feat, dist, anchors):
+        """dist-loss term with autograd: kNN indices from the HIP kernel, the rest in torch ops."""
+        B, N, C = feat.shape
+        f1 = feat[:, anchors]
+        idx = ops.knn_neg(f1, feat, self.k_dist).long()                       # (B,nA,k)
+        nA, k = idx.shape[1], idx.shape[2]
+        f2 = nn_ops.gather_rows(feat, idx)
+        x = torch.norm(f2 - f1[:, :, None, :], dim=-1)
+        y = torch.gather(dist, 1, idx.reshape(B, nA * k, 1).expand(-1, -1, N))  # rows dist[b, idx, :]
+        y = torch.gather(y, 2, anchors.view(1, nA, 1).expand(B, -1, k).reshape(B, nA * k, 1)).view(B, nA, k)
+        return torch.sum(1 - torch.abs(torch.nn.functional.cosine_similarity(x, y, dim=2)))
+
+    def _direction_train(self, feat1, feat2, verts1, verts2, alpha, g1, deformer, idx11, idx22):
+        """deform() with autograd (models/loss.py:1228-1296)."""
+        B, N, _ = verts1.shape
+        pval, pidx = nn_ops.softcorr_topk(feat1, feat2, alpha, 10)
+        verts12 = nn_ops.sparse_apply(pval, pidx, verts2)
+        w = deformer.conv_layer.weight.view(1, 1, -1, 1)
+        g1p = (nn_ops.gather_rows(feat1, idx11) * w).sum(2) + deformer.conv_layer.bias
+        g2p = (nn_ops.gather_rows(feat2, idx22) * w).sum(2) + deformer.conv_layer.bias
+        g2t = nn_ops.sparse_apply(pval, pidx, g2p)
+        fps = g1["nodes_idx"].long().unsqueeze(-1)
+        pick = lambda t: torch.gather(t, 1, fps.expand(-1, -1, t.shape[-1]))  # noqa: E731
+        z = torch.cat([pick(verts1), pick(g1p), pick(verts12), pick(g2t)], dim=-1)
+        def9 = deformer.deformation_decoder_layer(z)
+        iden = torch.tensor([1, 0, 0, 0, 1, 0], dtype=torch.float32, device=def9.device)
+        R = nn_ops.rot6d_torch(def9[..., 3:] + iden)
+        warped, arap = nn_ops.dg_warp_arap_torch(verts1, g1, R, def9[..., :3])
+        cd_warp = self._chamfer_train(warped, verts2)
+        cd_self = self._chamfer_train(verts12, verts2)
+        map_sum = None
+        if self.w_map > 0 and not self.partial_variant:
+            lhs = nn_ops.gather_rows(verts12, idx11)                                   # (B,N,k,3)
+            v2n = nn_ops.gather_rows(verts2, idx22).reshape(B, verts2.shape[1], -1)    # (B,M,k*3)
+            rhs = nn_ops.sparse_apply(pval, pidx, v2n).view(B, N, -1, 3)
+            map_sum = ((lhs - rhs) ** 2).sum(dim=(1, 2, 3))
+        return map_sum, cd_warp, arap.sum(), cd_self, dict(warped=warped, verts12=verts12, pval=pval, pidx=pidx)
+
     def _dump(self, ex, verts1, verts2, n, cd, arap):
         print("Rand:%s, Deform_Result: cd_loss:%s, arap_loss:%s" % (n, cd, arap))
         path = 'visual_result/' + str(self.save_name)
@@ -144,12 +188,16 @@ class GraphDeformLoss_Neural(nn.Module):
         loss = 0
         B, N, _ = verts1.shape
         M = verts2.shape[1]
+        train = torch.is_grad_enabled() and (feat1.requires_grad or feat2.requires_grad or
+                                             any(p.requires_grad for p in deformer.parameters()))
+        dist_term = self._dist_term_train if train else self._dist_term
+        direction = self._direction_train if train else self._direction
         if self.w_dist > 0:
             if anchors is None:
                 anchors = (random.sample(range(dist1.shape[1]), self.N_dist), random.sample(range(dist2.shape[1]), self.N_dist))
             a1 = torch.as_tensor(np.asarray(anchors[0]), device=feat1.device)
             a2 = torch.as_tensor(np.asarray(anchors[1]), device=feat2.device)
-            self.dist_loss = (self._dist_term(feat1, dist1, a1) + self._dist_term(feat2, dist2, a2)) * self.w_dist
+            self.dist_loss = (dist_term(feat1, dist1, a1) + dist_term(feat2, dist2, a2)) * self.w_dist
             loss = loss + self.dist_loss
         if self.w_deform > 0 or not self.partial_variant:
             s1, s2 = fps_starts if fps_starts is not None else (None, None)
@@ -157,9 +205,9 @@ class GraphDeformLoss_Neural(nn.Module):
             _, _, g2 = self.deformation_graph_node(verts2, s2)
             k = self.k_deform
             idx11, idx22 = ops.knn_cdist(verts1, verts1, k), ops.knn_cdist(verts2, verts2, k)
-            m12, c12, a12, s12, ex12 = self._direction(feat1, feat2, verts1, verts2, alpha_i, g1, deformer, idx11, idx22)
+            m12, c12, a12, s12, ex12 = direction(feat1, feat2, verts1, verts2, alpha_i, g1, deformer, idx11, idx22)
             n12 = str(random.randint(0, 10))
-            m21, c21, a21, s21, ex21 = self._direction(feat2, feat1, verts2, verts1, alpha_i, g2, deformer, idx22, idx11)
+            m21, c21, a21, s21, ex21 = direction(feat2, feat1, verts2, verts1, alpha_i, g2, deformer, idx22, idx11)
             n21 = str(random.randint(0, 10))
             cross12 = c12 * self.w_cd + a12 * self.w_arap
             cross21 = c21 * self.w_cd + a21 * self.w_arap

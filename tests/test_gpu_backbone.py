@@ -179,6 +179,82 @@ def test_criterion_partial(golden):
     np.testing.assert_allclose(out, ref, rtol=2e-4)
 
 
+@pytest.mark.parametrize("name,cls,kw", [
+    ("loss_full_256", "GraphDeformLoss_Neural", dict(k_dist=50, N_dist=100, partial=False, w_deform=0.5, w_self_rec=0.5)),
+    ("loss_partial_256x120", "GraphDeformLoss_Neural_Partial", dict(k_dist=30, N_dist=60, partial=True, w_deform=1000,
+                                                                 w_self_rec=1000)),
+])
+def test_criterion_backward_matches_reference(golden, name, cls, kw):
+    """Training step parity: loss and gradients w.r.t. feat1, feat2 and every Deformer parameter against the
+    reference's autograd (fixture)."""
+    import models.loss as ml
+    import models.model as mm
+    g = golden(name)
+    w = golden("deformer_scape_r_weights")
+    d = mm.Deformer(10)
+    d.load_state_dict({k.replace("__", "."): torch.from_numpy(v) for k, v in w.items()})
+    d = d.cuda().train()
+    crit = getattr(ml, cls)(save_name="t", k_deform=10, w_dist=0.02, w_map=0.005, w_img=0, w_rank=0, w_cd=0.1, w_arap=0.01, **kw)
+    f1, f2 = dev(g["feat1"]).requires_grad_(True), dev(g["feat2"]).requires_grad_(True)
+    v1, v2 = dev(g["verts1"]), dev(g["verts2"])
+    random.seed(int(g["py_seed"]))
+    torch.manual_seed(int(g["torch_seed"]))
+    out = crit(f1, f2, torch.cdist(v1, v1), torch.cdist(v2, v2), v1, v2, np.float64(g["alpha"]), d)
+    ref = [float(g[k]) for k in ("loss", "dist_loss", "deform_loss", "map_loss", "self_rec_loss")]
+    np.testing.assert_allclose([float(o) for o in out], ref, rtol=2e-4)
+    out[0].backward()
+
+    def close(a, b, what):
+        a, b = host(a), np.asarray(b)
+        scale = np.abs(b).max() + 1e-30
+        assert np.abs(a - b).max() <= 2e-3 * scale, (what, np.abs(a - b).max(), scale)
+
+    close(f1.grad, g["g_feat1"], "feat1")
+    close(f2.grad, g["g_feat2"], "feat2")
+    for k, p in d.named_parameters():
+        close(p.grad, g["g_" + k.replace(".", "__")], k)
+
+
+def test_full_training_step_matches_reference(golden):
+    """Uni3FC x2 -> criterion -> backward, BN in train mode, against the reference's own
+    step (losses, features, gradients of backbone and Deformer parameters)."""
+    import models.loss as ml
+    import models.model as mm
+    g = golden("bb_trainstep")
+    w = golden("deformer_scape_r_weights")
+    net = reinit(mm.Uni3FC(k=40), salt=5).cuda().train()
+    d = mm.Deformer(10)
+    d.load_state_dict({k.replace("__", "."): torch.from_numpy(v) for k, v in w.items()})
+    d = d.cuda().train()
+    crit = ml.GraphDeformLoss_Neural(k_deform=10, w_dist=0.02, w_map=0.005, k_dist=40, N_dist=64, partial=False, w_deform=0.5,
+                                     w_img=0, w_rank=0, w_self_rec=0.5, w_cd=0.1, w_arap=0.01, save_name="t")
+    v1, v2 = dev(g["verts1"]), dev(g["verts2"])
+    random.seed(9001)
+    torch.manual_seed(9002)
+    f1, _ = net(v1.permute(0, 2, 1), dev(g["dino1"]).float(), None)
+    f2, _ = net(v2.permute(0, 2, 1), dev(g["dino2"]).float(), None)
+    e1 = np.abs(host(f1) - g["feat1"])
+    assert np.median(e1) < 5e-5 and np.quantile(e1, 0.999) < 5e-3, (np.median(e1), e1.max())
+    out = crit(f1, f2, torch.cdist(v1, v1), torch.cdist(v2, v2), v1, v2, np.float64(g["alpha"]), d)
+    np.testing.assert_allclose([float(o.detach()) for o in out], g["losses"], rtol=2e-3)
+    out[0].backward()
+    named = dict(net.named_parameters())
+    no_grad = sum(1 for p in net.parameters() if p.grad is None)
+    assert no_grad == int(g["n_params_without_grad"])  # the 12 parameters the reference never trains
+    gn = torch.sqrt(sum((p.grad ** 2).sum() for p in net.parameters() if p.grad is not None))
+    np.testing.assert_allclose(float(gn), float(g["gnorm_backbone"]), rtol=2e-2)
+    for key in g:
+        if key.startswith("g_"):
+            p = named[key[2:].replace("__", ".")]
+            ref = g[key]
+            rel = np.linalg.norm(host(p.grad) - ref) / (np.linalg.norm(ref) + 1e-30)
+            assert rel < 5e-2, (key, rel)
+    for k, p in d.named_parameters():
+        ref = g["gd_" + k.replace(".", "__")]
+        rel = np.linalg.norm(host(p.grad) - ref) / (np.linalg.norm(ref) + 1e-30)
+        assert rel < 5e-2, (k, rel)
+
+
 def test_dist_loss_vs_torch(ops):
     g = torch.Generator().manual_seed(21)
     B, N, C, nA, k = 2, 300, 128, 40, 25
