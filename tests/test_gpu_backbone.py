@@ -247,6 +247,9 @@ def test_full_training_step_matches_reference(golden):
         if key.startswith("g_"):
             p = named[key[2:].replace("__", ".")]
             ref = g[key]
+            if np.linalg.norm(ref) < 1e-4:  # e.g. a conv bias in front of train-mode BN: exactly 0 in exact arithmetic
+                assert float(p.grad.norm()) < 1e-3, key
+                continue
             rel = np.linalg.norm(host(p.grad) - ref) / (np.linalg.norm(ref) + 1e-30)
             assert rel < 5e-2, (key, rel)
     for k, p in d.named_parameters():
