@@ -34,6 +34,7 @@ def sa_attention(x, w_qk, w_v, b_v):
     torch ops so autograd supplies the backward (interim, see the header comment further down)."""
     if not _needs_grad(x, w_qk, w_v, b_v):
         return ops.sa_attention(x, w_qk, w_v, b_v)
+    ops._need_gpu(x, w_qk, w_v)  # the training path is a device path too: never a CPU fallback
     p = torch.nn.functional.conv1d(x, w_qk)
     v = torch.nn.functional.conv1d(x, w_v, b_v)
     att = torch.softmax(torch.bmm(p.transpose(1, 2), p), dim=-1)
