@@ -214,7 +214,8 @@ constexpr int MF_WAVES = 8;             // waves 0-3 and 4-7 pair up on the 4 SI
 constexpr int MF_QB = MF_QW * MF_WAVES;  // 256 queries per workgroup
 constexpr int MF_THREADS = 64 * MF_WAVES;
 constexpr int MF_LD_PER_THREAD = MF_KT * MF_D / 4 / MF_THREADS;  // float4 loads per thread per tile = 8
-constexpr size_t MF_LDS_BYTES = (size_t)2 * (MF_KT * MF_LDK + MF_KT) * sizeof(float);
+constexpr int MF_STAGE = 16 * 64;  // floats per wave: this sub-tile's 16 squared distances of each lane, [r][lane]
+constexpr size_t MF_LDS_BYTES = ((size_t)2 * (MF_KT * MF_LDK + MF_KT) + (size_t)MF_WAVES * MF_STAGE) * sizeof(float);
 
 __device__ __forceinline__ float select16(const float (&v)[16], int b) {
     float a0 = (b & 1) ? v[1] : v[0], a1 = (b & 1) ? v[3] : v[2], a2 = (b & 1) ? v[5] : v[4], a3 = (b & 1) ? v[7] : v[6];
@@ -234,6 +235,10 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
     return base + orig / 8;
 }
 
+#ifdef DVM_COUNT_ITERS
+__device__ unsigned long long g_dbg_counters[4];
+#endif
+
 // One launch covers up to two "groups" (the two directions of a pair batch: (f1 -> f2) and
 // (f2 -> f1)), each with its own query/key tensors and outputs.
 struct SCGroup {
@@ -247,6 +252,7 @@ struct SCArgs {
     SCGroup g[2];
     int blocks0;  // B * g[0].tiles : logical block ids below this belong to group 0
     float neg_alpha;
+    float cutw;  // 20 / alpha: distance window above the row minimum whose softmax terms are kept (LEAN)
     int topk;
 };
 
@@ -255,12 +261,13 @@ struct SCArgs {
 // that may enter the top-k (d2 <= threshold^2) or carry a significant weight are re-evaluated
 // with the correctly rounded sqrt and the reference's rounding sequence (s = d*neg_alpha, s - c)
 // inside a compacted, wave-uniform loop, so the ranking and the dominant terms stay exact.
-template <int TOPK>
+template <int TOPK, bool LEAN>
 __global__ __launch_bounds__(MF_THREADS, 2) void softcorr_mfma_kernel(const SCArgs args) {
     // __launch_bounds__(512, 2): two waves per SIMD, i.e. ONE 512-thread workgroup per CU
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *const ktile0 = smem;                       // [2][MF_KT][MF_LDK]
     float *const knorm0 = smem + 2 * MF_KT * MF_LDK;  // [2][MF_KT]
+    float *const stage = knorm0 + 2 * MF_KT + (threadIdx.x >> 6) * MF_STAGE + (threadIdx.x & 63);  // this lane's column
 
     int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int grp = lid >= args.blocks0 ? 1 : 0;
@@ -341,6 +348,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void softcorr_mfma_kernel(const SCAr
     auto mfma_chain = [&](const float *kt, int sub, f32x16 &acc, float (&nbv)[16], int buf) {
         const float *arow = kt + (sub * 32 + r32) * MF_LDK + h * 64;
         acc = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#ifdef DVM_ABL_NOMFMA
+        for (int c = 0; c < 16; ++c) acc[c] = arow[4 * c] * q[c] + 100.f + (float)c;
+#else
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             f32x4 a = *(const f32x4 *)(arow + 4 * c);
@@ -349,6 +359,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void softcorr_mfma_kernel(const SCAr
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, q[4 * c + 2], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, q[4 * c + 3], acc, 0, 0, 0);
         }
+#endif
         // |key|^2 of this lane's 16 keys: local key = (r&3) + 8*(r>>2) + 4*h
         const float *kn = knorm0 + buf * MF_KT + sub * 32 + 4 * h;
 #pragma unroll
@@ -358,52 +369,101 @@ __global__ __launch_bounds__(MF_THREADS, 2) void softcorr_mfma_kernel(const SCAr
         }
     };
 
+    // Epilogue.  fp32 MFMA executes on the same ALUs as VALU code (tools/probe_interleave.hip: every
+    // VALU instruction adds its full issue time to the chain), so the epilogue is kept lean:
+    //   LEAN (alpha >= 32): per candidate only {2 adds, 1 compare}: it is looked at again iff its squared
+    //     distance is below lim2 = max(top-k bound, significance bound); everything else contributes
+    //     < e^-20 to the softmax sum and is dropped.  Flagged candidates go through the exact path.
+    //   !LEAN (flat softmax): every candidate adds a fast exp term; flagged ones are replaced exactly.
+    // The 16 squared distances are parked in LDS ([r][lane], conflict-free) for the dynamic pick.
+    float lim2 = INFINITY;
+    const float cutw = args.cutw;
     auto epilogue = [&](const f32x16 &acc, const float (&nbv)[16], int jbase) {
-        float d2[16], df[16];
-        float tminf = INFINITY;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float v = (acc[r] + na) + nbv[r];
-            v = v > 0.f ? v : 0.f;
-            d2[r] = v;
-            float f = __builtin_amdgcn_sqrtf(v);
-            df[r] = f;
-            tminf = fminf(tminf, f);
-        }
-        const float cnew = tminf * neg_alpha;
-        if (cnew > cref) {
-            l = l * exp2f((cref - cnew) * LOG2E);  // cref = -inf, l = 0 -> 0 * 0
-            cref = cnew;
-        }
-        const float c2 = cref * LOG2E;
-        float lsum = 0.f;
+#ifdef DVM_ABL_NOEPI
+        for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[r]), "v"(nbv[r]));
+        return;
+#endif
         unsigned mask = 0;
+        float c2 = 0.f;
+        if (LEAN) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float arg = fmaf(df[r], a2, -c2);
-            lsum += __builtin_amdgcn_exp2f(arg);
-            bool flag = (d2[r] <= thr2) || (arg > -11.5f);
-            mask |= flag ? (1u << r) : 0u;
+            for (int r = 0; r < 16; ++r) {
+                float v = (acc[r] + na) + nbv[r];
+                stage[r * 64] = v;
+                mask |= (v <= lim2) ? (1u << r) : 0u;
+            }
+        } else {
+            float df[16];
+            float tminf = INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = (acc[r] + na) + nbv[r];
+                stage[r * 64] = v;
+                mask |= (v <= lim2) ? (1u << r) : 0u;
+                float f = __builtin_amdgcn_sqrtf(fabsf(v));
+                df[r] = f;
+                tminf = fminf(tminf, f);
+            }
+            const float cnew = tminf * neg_alpha;
+            if (cnew > cref) {
+                l = l * exp2f((cref - cnew) * LOG2E);  // cref = -inf, l = 0 -> 0 * 0
+                cref = cnew;
+            }
+            c2 = cref * LOG2E;
+            float lsum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float arg = fmaf(df[r], a2, -c2);
+                lsum += __builtin_amdgcn_exp2f(arg);
+                mask |= (arg > -11.5f) ? (1u << r) : 0u;
+            }
+            l += lsum;
         }
-        l += lsum;
-        // Branch-free body (inactive lanes insert +inf, a no-op): keeps the top-k registers in place
+        // Branch-free body (inactive lanes process +inf, a no-op): keeps the top-k registers in place
         // instead of copying them around a divergent region every iteration.
+#ifdef DVM_COUNT_ITERS
+        if (lane == 0) atomicAdd(&g_dbg_counters[1], 1ull);
+        atomicAdd(&g_dbg_counters[2], (unsigned long long)__popc(mask));
+#endif
         while (__any(mask != 0)) {
+#ifdef DVM_COUNT_ITERS
+            if (lane == 0) atomicAdd(&g_dbg_counters[0], 1ull);
+#endif
             const bool act = mask != 0;
             const int bpos = act ? (__ffs(mask) - 1) : 0;
             mask &= mask - 1;
-            const float v2 = act ? select16(d2, bpos) : INFINITY;
-            const float dfast = __builtin_amdgcn_sqrtf(v2);
+            float v2 = stage[bpos * 64];
+            v2 = act ? (v2 > 0.f ? v2 : 0.f) : INFINITY;
             const float de = sqrt_rn(v2);
-            const float s = de * neg_alpha;
-            // replace this term's fast value by the reference-rounded one (both 0 for +inf)
-            l += __builtin_amdgcn_exp2f((s - cref) * LOG2E) - __builtin_amdgcn_exp2f(fmaf(dfast, a2, -c2));
+            const float s = de * neg_alpha;  // -inf for inactive lanes
+            if (LEAN) {
+                const float cnew = fmaxf(cref, s);
+                const float sc = (cnew == cref) ? 1.f : __builtin_amdgcn_exp2f((cref - cnew) * LOG2E);
+                const float term = act ? __builtin_amdgcn_exp2f((s - cnew) * LOG2E) : 0.f;
+                l = l * sc + term;
+                cref = cnew;
+            } else {
+                const float dfast = __builtin_amdgcn_sqrtf(v2);
+                // replace this term's fast value by the reference-rounded one (both 0 for +inf)
+                l += __builtin_amdgcn_exp2f((s - cref) * LOG2E) - __builtin_amdgcn_exp2f(fmaf(dfast, a2, -c2));
+            }
             kb.insert_nb(de, jbase + (bpos & 3) + 8 * (bpos >> 2));
         }
-        // the half-lane partner (same query, other keys) bounds the union's k-th best too
-        float w = kb.worst();
-        w = fminf(w, __shfl_xor(w, 32, 64));
-        thr2 = (w * w) * 1.0000004f;
+        // bounds for the next sub-tile.  Top-k: the row's k-th best is at most min(a_k, b_k, max(a_m, b_m))
+        // with a, b the sorted lists of the two half-lanes and m = k/2 (2m elements lie below that max).
+        {
+            const float wk = kb.key[TOPK - 1], wm = kb.key[TOPK / 2 - 1], w0 = kb.key[0];
+            const float pk = __shfl_xor(wk, 32, 64), pm = __shfl_xor(wm, 32, 64);
+            const float w = fminf(fminf(wk, pk), fmaxf(wm, pm));
+            thr2 = (w * w) * 1.0000004f;
+            if (LEAN) {
+                const float dmin = fminf(w0, __shfl_xor(w0, 32, 64));
+                const float cut = dmin + cutw;  // beyond this the softmax term is < e^-20 of the largest
+                lim2 = fmaxf(thr2, (cut * cut) * 1.000001f);
+            } else {
+                lim2 = thr2;
+            }
+        }
     };
 
     f32x16 acc;
@@ -462,15 +522,24 @@ __global__ __launch_bounds__(MF_THREADS, 2) void softcorr_mfma_kernel(const SCAr
     }
 }
 
-static void softcorr_set_attr() {
+constexpr float LEAN_MIN_ALPHA = 32.f;
+
+template <int TOPK>
+static void launch_softcorr_mfma(SCArgs &a, int blocks, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)softcorr_mfma_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void *)softcorr_mfma_kernel<TOPK, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)MF_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void *)softcorr_mfma_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void *)softcorr_mfma_kernel<TOPK, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)MF_LDS_BYTES);
         attr_set = true;
     }
+    const float alpha = -a.neg_alpha;
+    a.cutw = 20.f / alpha;
+    if (alpha >= LEAN_MIN_ALPHA)
+        hipLaunchKernelGGL((softcorr_mfma_kernel<TOPK, true>), dim3(blocks), dim3(MF_THREADS), MF_LDS_BYTES, s, a);
+    else
+        hipLaunchKernelGGL((softcorr_mfma_kernel<TOPK, false>), dim3(blocks), dim3(MF_THREADS), MF_LDS_BYTES, s, a);
 }
 
 // both directions of B pairs in one launch; n1/n2 are the row norms of f1/f2 (computed once)
@@ -482,9 +551,8 @@ int launch_softcorr_both(const float *f1, const float *f2, const float *n1, cons
     a.blocks0 = B * a.g[0].tiles;
     a.neg_alpha = neg_alpha;
     a.topk = 10;
-    softcorr_set_attr();
     prof_begin(s);
-    hipLaunchKernelGGL(softcorr_mfma_kernel<10>, dim3(a.blocks0 + B * a.g[1].tiles), dim3(MF_THREADS), MF_LDS_BYTES, s, a);
+    launch_softcorr_mfma<10>(a, a.blocks0 + B * a.g[1].tiles, s);
     prof_end(s);
     return DVM_OK;
 }
@@ -539,11 +607,10 @@ DVM_EXPORT int dvm_softcorr_fwd_f32(const float *f1, const float *f2, int B, int
         a.blocks0 = B * a.g[0].tiles;
         a.neg_alpha = neg_alpha;
         a.topk = topk;
-        softcorr_set_attr();
         if (topk <= 10)
-            hipLaunchKernelGGL(softcorr_mfma_kernel<10>, dim3(a.blocks0), dim3(MF_THREADS), MF_LDS_BYTES, s, a);
+            launch_softcorr_mfma<10>(a, a.blocks0, s);
         else
-            hipLaunchKernelGGL(softcorr_mfma_kernel<16>, dim3(a.blocks0), dim3(MF_THREADS), MF_LDS_BYTES, s, a);
+            launch_softcorr_mfma<16>(a, a.blocks0, s);
     } else {
         dim3 grid((N + 127) / 128, B);
         size_t lds = (size_t)(SC_KT * d + SC_KT) * sizeof(float);
@@ -601,3 +668,13 @@ DVM_EXPORT int dvm_softcorr_dense_f32(const float *f1, const float *f2, int B, i
     DVM_CHECK_LAUNCH("softcorr_dense");
     return DVM_OK;
 }
+
+#ifdef DVM_COUNT_ITERS
+DVM_EXPORT int dvm_debug_counters(unsigned long long *out4) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out4, HIP_SYMBOL(dvm::g_dbg_counters), 32);
+    unsigned long long z[4] = {0, 0, 0, 0};
+    hipMemcpyToSymbol(HIP_SYMBOL(dvm::g_dbg_counters), z, 32);
+    return 0;
+}
+#endif
