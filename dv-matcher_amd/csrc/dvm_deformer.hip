@@ -323,13 +323,17 @@ struct DeformerWs {
     float *g2, *z, *Wp0, *Wp1, *Wp2, *Wp3, *h0, *h1, *h2;
 };
 
+size_t mlp_pack_floats();
+void launch_mlp_rows(const float *z, int rows, const float *W0, const float *b0, const float *W1, const float *b1, const float *W2,
+                     const float *b2, const float *W3, const float *b3, float *wp, float *out, hipStream_t s, int variant);
+
 static size_t carve(Arena &ar, int B, int M, int Nn, DeformerWs &w) {
     w.g2 = ar.take<float>((size_t)B * M * DF_C);
     w.z = ar.take<float>((size_t)B * Nn * DF_ZS);
-    w.Wp0 = ar.take<float>((size_t)16 * 132 * 64);
-    w.Wp1 = ar.take<float>((size_t)8 * 256 * 64);
-    w.Wp2 = ar.take<float>((size_t)4 * 128 * 64);
-    w.Wp3 = ar.take<float>((size_t)1 * 64 * 64);
+    w.Wp0 = ar.take<float>(mlp_pack_floats());  // packed weights of all layers (either kernel's format)
+    w.Wp1 = w.Wp0 + (size_t)16 * 132 * 64;
+    w.Wp2 = w.Wp1 + (size_t)8 * 256 * 64;
+    w.Wp3 = w.Wp2 + (size_t)4 * 128 * 64;
     w.h0 = ar.take<float>((size_t)B * Nn * 512);
     w.h1 = ar.take<float>((size_t)B * Nn * 256);
     w.h2 = ar.take<float>((size_t)B * Nn * 128);
@@ -371,23 +375,7 @@ int launch_deformer(const float *feat1, const float *feat2, const float *verts1,
         layer(w.h1, 256, W2, b2, 256, 128, 1, w.h2, 128);
         layer(w.h2, 128, W3, b3, 128, 9, 0, out, 9);
     } else {
-        auto pack = [&](const float *W, int O, int I, int otiles, int steps, float *Wp) {
-            long th = (long)otiles * steps * 64;
-            hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, W, O, I, otiles, steps,
-                               Wp);
-        };
-        pack(W0, 512, DF_IN, 16, 132, w.Wp0);
-        pack(W1, 256, 512, 8, 256, w.Wp1);
-        pack(W2, 128, 256, 4, 128, w.Wp2);
-        pack(W3, 9, 128, 1, 64, w.Wp3);
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void *)mlp_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)ML_LDS_BYTES);
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(mlp_mfma_kernel, dim3((rows + ML_NODES - 1) / ML_NODES), dim3(ML_THREADS), ML_LDS_BYTES, s, w.z,
-                           rows, w.Wp0, b0, w.Wp1, b1, w.Wp2, b2, w.Wp3, b3, out);
+        launch_mlp_rows(w.z, rows, W0, b0, W1, b1, W2, b2, W3, b3, w.Wp0, out, s, variant);
     }
     return DVM_OK;
 }
@@ -409,10 +397,23 @@ void launch_assemble_pooled(const float *vsrc, const float *vcorr, const float *
     hipLaunchKernelGGL(assemble_pooled_kernel<10>, dim3((unsigned)(((long)Nn * 32 + 255) / 256), B), dim3(256), 0, s, vsrc, vcorr,
                        gsrc, gtgt, pi_val, pi_idx, fps, N, M, Nn, 10, z);
 }
-size_t mlp_pack_floats() { return (size_t)16 * 132 * 64 + (size_t)8 * 256 * 64 + (size_t)4 * 128 * 64 + (size_t)64 * 64; }
-// z [rows][264] -> out [rows][9]; wp = scratch of mlp_pack_floats() floats
+size_t mlp_bf16_pack_bytes();
+void launch_mlp_rows_bf16(const float *z, int rows, const float *W0, const float *b0, const float *W1, const float *b1,
+                          const float *W2, const float *b2, const float *W3, const float *b3, void *scratch, float *out,
+                          hipStream_t s);
+size_t mlp_pack_floats() {
+    size_t f32 = (size_t)16 * 132 * 64 + (size_t)8 * 256 * 64 + (size_t)4 * 128 * 64 + (size_t)64 * 64;
+    size_t b16 = (mlp_bf16_pack_bytes() + 3) / 4;
+    return f32 > b16 ? f32 : b16;
+}
+// z [rows][264] -> out [rows][9]; wp = scratch of mlp_pack_floats() floats.
+// variant 0: bf16x3-split matrix-core kernel (dvm_mlp_bf16.hip); 2: fp32-MFMA kernel (k-ordered fma chain)
 void launch_mlp_rows(const float *z, int rows, const float *W0, const float *b0, const float *W1, const float *b1, const float *W2,
-                     const float *b2, const float *W3, const float *b3, float *wp, float *out, hipStream_t s) {
+                     const float *b2, const float *W3, const float *b3, float *wp, float *out, hipStream_t s, int variant) {
+    if (variant == 0) {
+        launch_mlp_rows_bf16(z, rows, W0, b0, W1, b1, W2, b2, W3, b3, wp, out, s);
+        return;
+    }
     float *Wp0 = wp, *Wp1 = Wp0 + (size_t)16 * 132 * 64, *Wp2 = Wp1 + (size_t)8 * 256 * 64, *Wp3 = Wp2 + (size_t)4 * 128 * 64;
     auto pack = [&](const float *W, int O, int I, int otiles, int steps, float *Wp) {
         long th = (long)otiles * steps * 64;
@@ -484,17 +485,7 @@ DVM_EXPORT int dvm_deformer_mlp_fwd_f32(const float *z, int rows, const float *W
     hipStream_t s = (hipStream_t)stream;
     long th = (long)rows * DF_ZS;
     hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, z, rows, DF_IN, DF_ZS, w.z);
-    auto pack = [&](const float *W, int O, int I, int otiles, int steps, float *Wp) {
-        long t2 = (long)otiles * steps * 64;
-        hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, s, W, O, I, otiles, steps, Wp);
-    };
-    pack(W0, 512, DF_IN, 16, 132, w.Wp0);
-    pack(W1, 256, 512, 8, 256, w.Wp1);
-    pack(W2, 128, 256, 4, 128, w.Wp2);
-    pack(W3, 9, 128, 1, 64, w.Wp3);
-    (void)hipFuncSetAttribute((const void *)mlp_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_LDS_BYTES);
-    hipLaunchKernelGGL(mlp_mfma_kernel, dim3((rows + ML_NODES - 1) / ML_NODES), dim3(ML_THREADS), ML_LDS_BYTES, s, w.z, rows,
-                       w.Wp0, b0, w.Wp1, b1, w.Wp2, b2, w.Wp3, b3, out);
+    launch_mlp_rows(w.z, rows, W0, b0, W1, b1, W2, b2, W3, b3, w.Wp0, out, s, 0);
     DVM_CHECK_LAUNCH("deformer_mlp");
     return DVM_OK;
 }

@@ -162,7 +162,7 @@ void launch_assemble_pooled(const float *vsrc, const float *vcorr, const float *
                             const int32_t *pi_idx, const int32_t *fps, int B, int N, int M, int Nn, float *z, hipStream_t s);
 size_t mlp_pack_floats();
 void launch_mlp_rows(const float *z, int rows, const float *W0, const float *b0, const float *W1, const float *b1, const float *W2,
-                     const float *b2, const float *W3, const float *b3, float *wp, float *out, hipStream_t s);
+                     const float *b2, const float *W3, const float *b3, float *wp, float *out, hipStream_t s, int variant);
 int launch_chamfer_grouped(const float *const *a, const float *const *b, const int *Na, const int *Nb, float *const *dout,
                            int ngroups, int B, hipStream_t s);
 
@@ -295,7 +295,7 @@ DVM_EXPORT int dvm_pair_fwd_f32(const float *feat1, const float *feat2, const fl
     launch_assemble_pooled(verts1, verts12, w.gall[0], w.gall[1], w.pval[0], w.pidx[0], w.nodes[0], B, N, M, Nn1, w.z, s);
     launch_assemble_pooled(verts2, verts21, w.gall[1], w.gall[0], w.pval[1], w.pidx[1], w.nodes[1], B, M, N, Nn2, z21, s);
     const int rows = B * (Nn1 + Nn2);
-    launch_mlp_rows(w.z, rows, W0, b0, W1, b1, W2, b2, W3, b3, w.wp, w.def9, s);
+    launch_mlp_rows(w.z, rows, W0, b0, W1, b1, W2, b2, W3, b3, w.wp, w.def9, s, 0);
     // ---- ED warp + ARAP (losses[:,2])
     float *def21 = w.def9 + (size_t)B * Nn1 * 9, *R21 = w.R + (size_t)B * Nn1 * 9, *T21v = w.T + (size_t)B * Nn1 * 3;
     launch_dg_warp(verts1, B, N, w.nodes[0], w.ring[0], w.infl[0], w.weights[0], w.def9, w.R, w.T, warped12, losses12 + 2, 6,

@@ -164,7 +164,7 @@ def test_fps_batched_and_large(ops):
             assert np.array_equal(out[b], O.fps(v[b], N // 2, int(start[b])))
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("name", ["deformer_256x256", "deformer_300x200"])
 def test_deformer_and_chamfer(ops, golden, name, variant):
     g = golden(name)
@@ -209,7 +209,7 @@ def test_pair_direction_vs_oracle(ops, golden, shape):
     for b in range(B):
         o = O.pair_direction(w, f1[b].numpy(), f2[b].numpy(), v1[b].numpy(), v2[b].numpy(), 40.0, int(start[b]))
         assert np.array_equal(host(out["T12"])[b], o["T12"])
-        np.testing.assert_allclose(host(out["verts12"])[b], o["verts12"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(host(out["verts12"])[b], o["verts12"], rtol=0, atol=5e-6)
         np.testing.assert_allclose(host(out["warped"])[b], o["warped"], rtol=0, atol=1e-4)
         L = host(out["losses"])[b]
         np.testing.assert_allclose(L, o["losses"], rtol=1e-3, atol=1e-7)
