@@ -40,6 +40,21 @@ def farthest_point_sample(xyz, npoint):
     return _fps(xyz.unsqueeze(0), npoint)
 
 
+class PointwiseConv1d(nn.Conv1d):
+    """nn.Conv1d(kernel_size=1) with the reference's parameter names/shapes (weight (Cout,Cin,1)), evaluated
+    as the GEMM it is: W @ x over (B,Cin,N).  Going through the convolution library costs ~10x here (MIOpen
+    has no tuned fp32 1x1-conv1d path on gfx950 and falls back to its naive kernels, fwd and bwd)."""
+
+    accumulate = "f32"   # "f64": accumulate in double (what MIOpen's naive kernels do) — for wiring tests only
+
+    def forward(self, x):
+        if PointwiseConv1d.accumulate == "f64":
+            y = torch.matmul(self.weight[:, :, 0].double(), x.double()).to(x.dtype)
+        else:
+            y = torch.matmul(self.weight[:, :, 0], x)
+        return y if self.bias is None else y + self.bias[:, None]
+
+
 # ------------------------------------------------------------------ attention blocks
 class SA_Layer(nn.Module):
     """Offset self-attention with shared q/k weights and column re-normalisation."""
@@ -52,8 +67,8 @@ class SA_Layer(nn.Module):
         self.q_conv = nn.Conv1d(channels, channels // 4, 1, bias=False)
         self.k_conv = nn.Conv1d(channels, channels // 4, 1, bias=False)
         self.q_conv.weight = self.k_conv.weight  # tied
-        self.v_conv = nn.Conv1d(channels, channels, 1)
-        self.trans_conv = nn.Conv1d(channels, channels, 1)
+        self.v_conv = PointwiseConv1d(channels, channels, 1)
+        self.trans_conv = PointwiseConv1d(channels, channels, 1)
         self.after_norm = nn.BatchNorm1d(channels)
         self.act = nn.ReLU()
         self.softmax = nn.Softmax(dim=-1)
@@ -75,7 +90,8 @@ class _N2P(nn.Module):
         self.k_conv = nn.Conv2d(C, C, 1, bias=False)
         self.v_conv = nn.Conv2d(C, C, 1, bias=False)
         self.softmax = nn.Softmax(dim=-1)
-        self.ff = nn.Sequential(nn.Conv1d(C, 4 * C, 1, bias=False), nn.LeakyReLU(0.2), nn.Conv1d(4 * C, C, 1, bias=False))
+        self.ff = nn.Sequential(PointwiseConv1d(C, 4 * C, 1, bias=False), nn.LeakyReLU(0.2),
+                                PointwiseConv1d(4 * C, C, 1, bias=False))
         self.bn1 = nn.BatchNorm1d(C)
         self.bn2 = nn.BatchNorm1d(C)
 
@@ -166,7 +182,7 @@ class Uni3FC(nn.Module):
         self.bn6 = nn.BatchNorm1d(128)
 
         def block(cin, cout, bn):
-            return nn.Sequential(nn.Conv1d(cin, cout, kernel_size=1, bias=False), bn, nn.LeakyReLU(negative_slope=0.2))
+            return nn.Sequential(PointwiseConv1d(cin, cout, kernel_size=1, bias=False), bn, nn.LeakyReLU(negative_slope=0.2))
 
         self.conv = block(1152, 384, self.bn)
         self.conv0 = block(384, 64, self.bn0)
