@@ -28,6 +28,9 @@ SIGNATURES = {
     "dvm_softcorr_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dvm_softcorr_fwd_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P, _P, _P, _P, c_int, _P,
                                      c_size_t, _P]),
+    "dvm_softcorr_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "dvm_softcorr_bwd_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P, _P, _P, _P, _P, _P, _P, c_int,
+                                     _P, c_size_t, _P]),
     "dvm_argmin_exact_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "dvm_knn_cdist_workspace_bytes": (c_size_t, [c_int] * 4),
     "dvm_knn_cdist_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_size_t, _P]),

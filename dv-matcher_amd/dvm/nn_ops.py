@@ -66,39 +66,25 @@ def n2p_attention(x, K, wq, wk, wv, heads):
 # Differentiable pieces of the criterion (training path).
 # Index searches and the fused soft correspondence run on the HIP kernels; the light, differentiable
 # algebra around them (gathers, weighted sums, the Deformer's GEMMs, the warp) is expressed with
-# torch ops on the device so that autograd provides its backward.  The soft correspondence's
-# backward recomputes the dense row softmax with torch ops (interim: a fused HIP backward kernel —
-# recompute tiles from row_smax/row_sum — is the next step).
+# torch ops on the device so that autograd provides its backward.  The soft correspondence has its own
+# fused HIP backward (dvm_softcorr_bwd_f32).
 # ------------------------------------------------------------------------------------------
 class _SoftCorrTopK(torch.autograd.Function):
+    """Top-k soft correspondence with its fused HIP backward (dvm_softcorr_bwd_f32: the dense N x M softmax
+    term is recomputed tile by tile from row_smax / row_sum, never stored)."""
+
     @staticmethod
     def forward(ctx, f1, f2, alpha, topk):
         val, idx, smax, ssum = ops.softcorr(f1, f2, alpha, topk=topk)
         ctx.save_for_backward(f1.detach(), f2.detach(), val, idx, smax, ssum)
-        ctx.neg_alpha = ops.neg_alpha_f32(alpha)
+        ctx.alpha = alpha
         ctx.mark_non_differentiable(idx)
         return val, idx
 
     @staticmethod
     def backward(ctx, gval, _gidx):
         f1, f2, val, idx, smax, ssum = ctx.saved_tensors
-        na = ctx.neg_alpha
-        idx64 = idx.long()
-        df1 = torch.empty_like(f1)
-        df2 = torch.zeros_like(f2)
-        B, N, _ = f1.shape
-        step = max(1, min(N, (1 << 22) // max(1, f2.shape[1])))  # bound the dense temporary to ~16 MB rows-chunk
-        for b in range(B):
-            for r0 in range(0, N, step):
-                a = f1[b, r0:r0 + step]
-                D = torch.cdist(a[None], f2[b][None])[0]                      # (n, M)
-                P = torch.exp(D * na - smax[b, r0:r0 + step, None]) / ssum[b, r0:r0 + step, None]
-                gp = gval[b, r0:r0 + step] * val[b, r0:r0 + step]             # g_t P_t at the kept entries
-                dS = -P * gp.sum(-1, keepdim=True)
-                dS.scatter_add_(-1, idx64[b, r0:r0 + step], gp)
-                W = torch.where(D > 0, dS * na / D.clamp_min(1e-30), torch.zeros_like(D))
-                df1[b, r0:r0 + step] = W.sum(-1, keepdim=True) * a - W @ f2[b]
-                df2[b] += W.sum(0)[:, None] * f2[b] - W.t() @ a
+        df1, df2 = ops.softcorr_bwd(f1, f2, ctx.alpha, val, idx, smax, ssum, gval.contiguous())
         return df1, df2, None, None
 
 

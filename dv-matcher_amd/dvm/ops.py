@@ -79,6 +79,23 @@ def softcorr(f1, f2, alpha, topk=10, variant=0, stats=True):
     return val, idx, smax, ssum
 
 
+def softcorr_bwd(f1, f2, alpha, val, idx, smax, ssum, gval, variant=0):
+    """Backward of softcorr: gval (B,N,topk) -> (d_f1 (B,N,d), d_f2 (B,M,d))."""
+    _need_gpu(f1, f2, gval)
+    f1, f2, gval, val = _f(f1), _f(f2), _f(gval), _f(val)
+    B, N, d = f1.shape
+    M = f2.shape[1]
+    topk = val.shape[-1]
+    lib = _lib.load()
+    df1, df2 = torch.empty_like(f1), torch.empty_like(f2)
+    nb = lib.dvm_softcorr_bwd_workspace_bytes(B, N, M, d)
+    ws = workspace(nb, f1.device, "softcorr_bwd")
+    check(lib.dvm_softcorr_bwd_f32(_p(f1), _p(f2), B, N, M, d, neg_alpha_f32(alpha), topk, _p(val), _p(idx.contiguous()),
+                                   _p(smax), _p(ssum), _p(gval), _p(df1), _p(df2), variant, _p(ws), nb, _stream()),
+          "dvm_softcorr_bwd_f32")
+    return df1, df2
+
+
 def argmin_exact(f1, f2, want_dist=False):
     _need_gpu(f1, f2)
     f1, f2 = _f(f1), _f(f2)

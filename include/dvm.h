@@ -68,6 +68,17 @@ int dvm_softcorr_fwd_f32(const float *f1, const float *f2, int B, int N, int M, 
                          float *pi_val, int32_t *pi_idx, float *row_smax, float *row_sum, int variant, void *ws,
                          size_t ws_bytes, void *stream);
 
+/* Backward of dvm_softcorr_fwd_f32 (autograd through models/loss.py:110-114 + the top-k keep of
+ * 1339-1347): given g_val [B,N,topk] = dL/d pi_val and the forward's outputs (pi_val, pi_idx, row_smax,
+ * row_sum), writes d_f1 [B,N,d] and d_f2 [B,M,d] (overwritten, not accumulated).  The dense N x M term is
+ * recomputed tile by tile (never stored); rows with distance exactly 0 contribute 0, like cdist's backward.
+ * Sums over rows/columns use fp32 atomics (order not fixed).  variant as in the forward. */
+size_t dvm_softcorr_bwd_workspace_bytes(int B, int N, int M, int d);
+int dvm_softcorr_bwd_f32(const float *f1, const float *f2, int B, int N, int M, int d, float neg_alpha, int topk,
+                         const float *pi_val, const int32_t *pi_idx, const float *row_smax, const float *row_sum,
+                         const float *g_val, float *d_f1, float *d_f2, int variant, void *ws, size_t ws_bytes,
+                         void *stream);
+
 /* knnsearch_t / search_t — models/loss.py:91-95,121-124; test.py:19-28.
  * T[b,i] = argmin_j cdist(f1,f2, 'donot_use_mm_for_euclid_dist') (0-based; the
  * test scripts add 1), ties -> lowest j; dmin [B,N] optional (may be NULL). */

@@ -64,3 +64,17 @@ def dist_loss_term(feat, dist, anchors, k):
     x = torch.norm(f2 - f1[:, :, None, :], dim=-1)
     y = torch.stack([dist[b][idx[b].reshape(-1), anchors.repeat_interleave(k)].view(nA, k) for b in range(B)])
     return (1 - torch.abs(F.cosine_similarity(x, y, dim=2))).sum(1)
+
+
+def softcorr_bwd(f1, f2, neg_alpha, idx, gval):
+    """fp64 autograd through softmax(neg_alpha * cdist(f1, f2)) gathered at idx (reference
+    models/loss.py:110-114 + 1339-1347): returns (val, d_f1, d_f2) for L = sum(val * gval).
+    f1 (B,N,d), f2 (B,M,d) float32 tensors; idx (B,N,k) int; gval (B,N,k)."""
+    a = f1.detach().double().requires_grad_(True)
+    b = f2.detach().double().requires_grad_(True)
+    diff = a[:, :, None, :] - b[:, None, :, :]
+    D = torch.sqrt((diff * diff).sum(-1).clamp_min(1e-300))
+    P = torch.softmax(D * float(neg_alpha), dim=-1)
+    val = torch.gather(P, 2, idx.long())
+    (val * gval.double()).sum().backward()
+    return val.detach(), a.grad, b.grad

@@ -1,0 +1,69 @@
+"""-m gpu: the HIP backward kernels (C ABI `*_bwd_f32`) against fp64 autograd of the reference formulas
+(oracle/torch_ref.py).  Gradients are floating point: the bar is a relative L2 error <= 1e-4 per tensor
+(north_star's tolerance) unless a test states why it is looser."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_ref as TR
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from dvm import ops as _ops
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return _ops
+
+
+def rel(a, ref):
+    a, ref = a.detach().double().cpu(), ref.detach().double().cpu()
+    return float((a - ref).norm() / (ref.norm() + 1e-300))
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("shape,alpha", [((2, 200, 150, 128), 10.0), ((1, 130, 333, 128), 100.0), ((2, 64, 64, 128), 37.5),
+                                         ((1, 257, 129, 128), 10.0)])
+def test_softcorr_bwd_vs_fp64_autograd(ops, shape, alpha, variant):
+    B, N, M, d = shape
+    g = torch.Generator().manual_seed(N * 1000 + M)
+    scale = 0.25 if alpha >= 30 else 1.0  # keep the softmax from being one-hot so every term carries gradient
+    f1 = (torch.randn(B, N, d, generator=g) * scale).cuda()
+    f2 = (torch.randn(B, M, d, generator=g) * scale).cuda()
+    gval = torch.randn(B, N, 10, generator=g).cuda()
+    val, idx, smax, ssum = ops.softcorr(f1, f2, alpha)
+    df1, df2 = ops.softcorr_bwd(f1, f2, alpha, val, idx, smax, ssum, gval, variant=variant)
+    rval, rf1, rf2 = TR.softcorr_bwd(f1.cpu(), f2.cpu(), ops.neg_alpha_f32(alpha), idx.cpu(), gval.cpu())
+    assert rel(val, rval) < 1e-4
+    # s = -alpha*D is evaluated in fp32 (|s| ~ alpha*D, one ulp of D moves a weight by ~alpha*D*6e-8), so the
+    # gradient's error scales with alpha: 1e-4 holds at alpha = 10; at alpha = 100 the fp32 reference itself
+    # sits at a few 1e-4 of this fp64 ground truth
+    tol = 1e-4 if alpha <= 40 else 1e-3
+    assert rel(df1, rf1) < tol and rel(df2, rf2) < tol, (rel(df1, rf1), rel(df2, rf2))
+
+
+def test_softcorr_bwd_other_dims_and_duplicates(ops):
+    g = torch.Generator().manual_seed(5)
+    f1 = torch.randn(1, 70, 36, generator=g)
+    f2 = torch.randn(1, 90, 36, generator=g)
+    f2[0, 3] = f1[0, 5]  # an exact zero distance: contributes no gradient (cdist's backward convention)
+    f1, f2 = f1.cuda(), f2.cuda()
+    gval = torch.randn(1, 70, 10, generator=g).cuda()
+    val, idx, smax, ssum = ops.softcorr(f1, f2, 2.0)
+    df1, df2 = ops.softcorr_bwd(f1, f2, 2.0, val, idx, smax, ssum, gval)
+    _, rf1, rf2 = TR.softcorr_bwd(f1.cpu(), f2.cpu(), ops.neg_alpha_f32(2.0), idx.cpu(), gval.cpu())
+    assert torch.isfinite(df1).all() and torch.isfinite(df2).all()
+    assert rel(df1, rf1) < 1e-4 and rel(df2, rf2) < 1e-4
+
+
+def test_softcorr_bwd_split_and_full_size(ops):
+    """B=1 at N=M=2048 takes the split-inner path (atomics); compare the two kernels with each other."""
+    g = torch.Generator().manual_seed(6)
+    f1 = (torch.randn(1, 2048, 128, generator=g) * 0.3).cuda()
+    f2 = (torch.randn(1, 2048, 128, generator=g) * 0.3).cuda()
+    gval = torch.randn(1, 2048, 10, generator=g).cuda()
+    val, idx, smax, ssum = ops.softcorr(f1, f2, 10.0)
+    a1, a2 = ops.softcorr_bwd(f1, f2, 10.0, val, idx, smax, ssum, gval, variant=2)
+    b1, b2 = ops.softcorr_bwd(f1, f2, 10.0, val, idx, smax, ssum, gval, variant=1)
+    assert rel(a1, b1) < 2e-5 and rel(a2, b2) < 2e-5, (rel(a1, b1), rel(a2, b2))
