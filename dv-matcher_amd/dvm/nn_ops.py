@@ -42,24 +42,35 @@ def sa_attention(x, w_qk, w_v, b_v):
     return torch.bmm(v, att)
 
 
+class _N2PCore(torch.autograd.Function):
+    """Attention of every point over its K gathered neighbours, forward and backward on the HIP kernels
+    (dvm_n2p_core_{fwd,bwd}_f32); only the (B,N,K,heads) attention weights are kept for the backward."""
+
+    @staticmethod
+    def forward(ctx, qkv, idx, heads):
+        out, attn = ops.n2p_core_fwd(qkv, idx, heads)
+        ctx.save_for_backward(qkv.detach(), idx, attn)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        qkv, idx, attn = ctx.saved_tensors
+        return ops.n2p_core_bwd(qkv, idx, attn, gout.contiguous(), ctx.heads), None, None
+
+
 def n2p_attention(x, K, wq, wk, wv, heads):
-    """N2PAttention's attention output.  The kNN indices always come from the HIP kernel; training
-    evaluates the attention with torch ops (projection by linearity, gathered rows) for autograd."""
+    """N2PAttention's attention output.  The kNN indices come from the HIP kernel (no gradient, as in the
+    reference); training projects q/k/v with one GEMM (k(x_j - x_i) = kp_j - kp_i by linearity) under
+    autograd and runs the gather-attention core and its backward on the HIP kernels."""
     if not _needs_grad(x, wq, wk, wv):
         return ops.n2p_attention(x, K, wq, wk, wv, heads)
     B, C, N = x.shape
     xt = x.transpose(1, 2).contiguous()
     idx = ops.knn_neg(xt, xt, K)
     w = torch.cat([wq.reshape(C, C), wk.reshape(C, C), wv.reshape(C, C)], 0)
-    qkv = torch.nn.functional.linear(xt, w)
-    q, kp, vp = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
-    D = C // heads
-    kd = (gather_rows(kp, idx) - kp.unsqueeze(2)).view(B, N, K, heads, D)
-    vd = (gather_rows(vp, idx) - vp.unsqueeze(2)).view(B, N, K, heads, D)
-    e = (q.view(B, N, 1, heads, D) * kd).sum(-1) / (D ** 0.5)                 # (B,N,K,H)
-    a = torch.softmax(e, dim=2)
-    out = (a.unsqueeze(-1) * vd).sum(2).reshape(B, N, C)
-    return out.transpose(1, 2)
+    qkv = torch.nn.functional.linear(xt, w)                                  # (B,N,3C)
+    return _N2PCore.apply(qkv, idx, heads).transpose(1, 2)
 
 
 # ------------------------------------------------------------------------------------------

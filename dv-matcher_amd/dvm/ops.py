@@ -96,6 +96,31 @@ def softcorr_bwd(f1, f2, alpha, val, idx, smax, ssum, gval, variant=0):
     return df1, df2
 
 
+def n2p_core_fwd(qkv, idx, heads=4):
+    """qkv (B,N,3C), idx (B,N,K) int32 -> out (B,N,C), attn (B,N,K,heads)."""
+    _need_gpu(qkv, idx)
+    qkv = _f(qkv)
+    B, N, C3 = qkv.shape
+    C, K = C3 // 3, idx.shape[-1]
+    out = torch.empty(B, N, C, dtype=torch.float32, device=qkv.device)
+    attn = torch.empty(B, N, K, heads, dtype=torch.float32, device=qkv.device)
+    check(_lib.load().dvm_n2p_core_fwd_f32(_p(qkv), _p(idx.contiguous()), B, N, C, K, heads, _p(out), _p(attn), _stream()),
+          "dvm_n2p_core_fwd_f32")
+    return out, attn
+
+
+def n2p_core_bwd(qkv, idx, attn, gout, heads=4):
+    """-> d_qkv (B,N,3C)."""
+    _need_gpu(qkv, idx, attn, gout)
+    qkv, gout = _f(qkv), _f(gout)
+    B, N, C3 = qkv.shape
+    C, K = C3 // 3, idx.shape[-1]
+    dqkv = torch.empty_like(qkv)
+    check(_lib.load().dvm_n2p_core_bwd_f32(_p(qkv), _p(idx.contiguous()), _p(attn), _p(gout), B, N, C, K, heads, _p(dqkv),
+                                           _stream()), "dvm_n2p_core_bwd_f32")
+    return dqkv
+
+
 def argmin_exact(f1, f2, want_dist=False):
     _need_gpu(f1, f2)
     f1, f2 = _f(f1), _f(f2)

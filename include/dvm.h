@@ -182,6 +182,15 @@ int dvm_sa_attention_fwd_f32(const float *p, const float *v, int B, int N, float
 int dvm_n2p_attention_fwd_f32(const float *q, const float *kp, const float *vp, const int32_t *idx, int B, int N,
                               int C, int K, int heads, float *out, void *stream);
 
+/* Training twins of the N2P attention core.  qkv [B,N,3C] = [Wq x | Wk x | Wv x] per point (one GEMM's
+ * output, used in place), idx [B,N,K].  fwd: out [B,N,C] as dvm_n2p_attention_fwd_f32, plus the attention
+ * weights attn [B,N,K,heads] kept for the backward.  bwd: g_out [B,N,C] -> d_qkv [B,N,3C] (overwritten;
+ * neighbour rows are accumulated with fp32 atomics, order not fixed).  C in {64,128}, heads = 4, K <= 64. */
+int dvm_n2p_core_fwd_f32(const float *qkv, const int32_t *idx, int B, int N, int C, int K, int heads, float *out,
+                         float *attn, void *stream);
+int dvm_n2p_core_bwd_f32(const float *qkv, const int32_t *idx, const float *attn, const float *g_out, int B, int N,
+                         int C, int K, int heads, float *d_qkv, void *stream);
+
 /* dist-loss term — models/loss.py:1351-1396 for one shape batch: anchors [nA] (shared by the
  * batch), idx = knn(feat[:,anchors], feat, k); x = |feat[idx] - feat[anchor]|, y = dist[b, idx, anchor];
  * out[b] = sum_n (1 - |cos(x_n, y_n)|).  feat [B,N,C], dist [B,N,N]; idx_out [B,nA,k] optional. */

@@ -67,3 +67,26 @@ def test_softcorr_bwd_split_and_full_size(ops):
     a1, a2 = ops.softcorr_bwd(f1, f2, 10.0, val, idx, smax, ssum, gval, variant=2)
     b1, b2 = ops.softcorr_bwd(f1, f2, 10.0, val, idx, smax, ssum, gval, variant=1)
     assert rel(a1, b1) < 2e-5 and rel(a2, b2) < 2e-5, (rel(a1, b1), rel(a2, b2))
+
+
+@pytest.mark.parametrize("C,K,N", [(64, 40, 300), (128, 40, 257), (128, 7, 50), (64, 64, 130)])
+def test_n2p_core_fwd_bwd_vs_fp64_autograd(ops, C, K, N):
+    B, H = 2, 4
+    g = torch.Generator().manual_seed(C + K)
+    qkv = torch.randn(B, N, 3 * C, generator=g)
+    idx = torch.randint(0, N, (B, N, K), generator=g, dtype=torch.int32)
+    gout = torch.randn(B, N, C, generator=g)
+    out, attn = ops.n2p_core_fwd(qkv.cuda(), idx.cuda(), H)
+    dqkv = ops.n2p_core_bwd(qkv.cuda(), idx.cuda(), attn, gout.cuda(), H)
+    # fp64 reference: the reference's formulation (models/model.py:339-350) on projected rows
+    x = qkv.double().requires_grad_(True)
+    q, kp, vp = x[..., :C], x[..., C:2 * C], x[..., 2 * C:]
+    gi = idx.long().reshape(B, N * K, 1).expand(-1, -1, C)
+    kd = (torch.gather(kp, 1, gi).view(B, N, K, C) - kp[:, :, None]).view(B, N, K, H, C // H)
+    vd = (torch.gather(vp, 1, gi).view(B, N, K, C) - vp[:, :, None]).view(B, N, K, H, C // H)
+    e = (q.view(B, N, 1, H, C // H) * kd).sum(-1) / (C // H) ** 0.5
+    a = torch.softmax(e, dim=2)
+    ref = (a.unsqueeze(-1) * vd).sum(2).reshape(B, N, C)
+    (ref * gout.double()).sum().backward()
+    assert rel(out, ref) < 1e-5 and rel(attn, a) < 1e-5
+    assert rel(dqkv, x.grad) < 1e-5, rel(dqkv, x.grad)
