@@ -513,6 +513,65 @@ __global__ __launch_bounds__(256) void dist_loss_kernel(const float *__restrict_
     if (threadIdx.x == 0) partial[(size_t)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// Backward of the dist-loss term, first half: the (anchor, point) weights
+//     W[b, n, idx_j] = g[b] * d term_n / d x_j / x_j          (0 where x_j = 0; idx rows are distinct points)
+// with d term / d x_j = -sgn(cos) (y_j / (|x||y|) - cos x_j / |x|^2).  The caller finishes with plain GEMMs:
+//     d feat      = diag(colsum W) feat - W^T feat[anchors]
+//     d feat[a_n] += rowsum(W)_n feat[a_n] - (W feat)_n
+// (k = 500 neighbours x 128 channels per anchor as atomics would be 0.5 G atomics per shape batch).
+// W [B][nA][N] must be zero-filled by the caller.  One wave per (b, n), k <= 512.
+__global__ __launch_bounds__(256) void dist_loss_bwd_weights_kernel(const float *__restrict__ feat, const float *__restrict__ dist,
+                                                                    const int32_t *__restrict__ anchors,
+                                                                    const int32_t *__restrict__ idx, const float *__restrict__ gterm,
+                                                                    int N, int C, int nA, int k, float *__restrict__ W) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * (blockDim.x >> 6) + wave;
+    const int b = blockIdx.y;
+    if (n >= nA) return;
+    const int a = anchors[n];
+    const float *fa = feat + ((size_t)b * N + a) * C;
+    const int32_t *ix = idx + ((size_t)b * nA + n) * k;
+    float xs[8], ys[8];
+    float sxy = 0.f, sxx = 0.f, syy = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int j = lane + 64 * u;
+        xs[u] = ys[u] = 0.f;
+        if (j < k) {
+            const int v = ix[j];
+            const float *fv = feat + ((size_t)b * N + v) * C;
+            float s2 = 0.f;
+            for (int c = 0; c < C; c += 4) {
+                f32x4 p = *(const f32x4 *)(fv + c), q = *(const f32x4 *)(fa + c);
+                float d0 = p.x - q.x, d1 = p.y - q.y, d2 = p.z - q.z, d3 = p.w - q.w;
+                s2 = fmaf(d0, d0, s2);
+                s2 = fmaf(d1, d1, s2);
+                s2 = fmaf(d2, d2, s2);
+                s2 = fmaf(d3, d3, s2);
+            }
+            xs[u] = sqrt_rn(s2);
+            ys[u] = dist[((size_t)b * N + v) * N + a];
+            sxy = fmaf(xs[u], ys[u], sxy);
+            sxx = fmaf(xs[u], xs[u], sxx);
+            syy = fmaf(ys[u], ys[u], syy);
+        }
+    }
+    sxy = wave_sum(sxy);
+    sxx = wave_sum(sxx);
+    syy = wave_sum(syy);
+    const float nx = fmaxf(sqrt_rn(sxx), 1e-8f), ny = fmaxf(sqrt_rn(syy), 1e-8f);
+    const float cosv = sxy / (nx * ny);
+    const float sg = cosv > 0.f ? -1.f : (cosv < 0.f ? 1.f : 0.f);  // d(1 - |cos|)/d cos
+    const float g = gterm[b] * sg;
+    const float inv = 1.f / (nx * ny), cx = cosv / (nx * nx);
+    float *Wr = W + ((size_t)b * nA + n) * N;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int j = lane + 64 * u;
+        if (j < k && xs[u] > 0.f) Wr[ix[j]] = g * (ys[u] * inv - cx * xs[u]) / xs[u];
+    }
+}
+
 __global__ void gather_rows_kernel(const float *__restrict__ src, const int32_t *__restrict__ rows, int N, int C, int nR,
                                    float *__restrict__ dst) {
     const int b = blockIdx.y;
@@ -637,6 +696,19 @@ DVM_EXPORT int dvm_n2p_attention_fwd_f32(const float *q, const float *kp, const 
     else
         hipLaunchKernelGGL(n2p_attention_kernel<128>, grid, dim3(256), 0, s, q, kp, vp, idx, N, K, heads, out);
     DVM_CHECK_LAUNCH("n2p_attention");
+    return DVM_OK;
+}
+
+DVM_EXPORT int dvm_dist_loss_bwd_weights_f32(const float *feat, const float *dist, const int32_t *anchors, const int32_t *idx,
+                                             const float *g_out, int B, int N, int C, int nA, int k, float *W, void *stream) {
+    DVM_REQUIRE(feat && dist && anchors && idx && g_out && W, "dvm_dist_loss_bwd_weights_f32: null pointer");
+    DVM_REQUIRE(B >= 1 && N >= 1 && nA >= 1 && C % 4 == 0, "dvm_dist_loss_bwd_weights_f32: bad sizes");
+    DVM_REQUIRE(k >= 1 && k <= 512 && k <= N, "dvm_dist_loss_bwd_weights_f32: k=%d unsupported", k);
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipMemsetAsync(W, 0, (size_t)B * nA * N * sizeof(float), s);
+    hipLaunchKernelGGL(dist_loss_bwd_weights_kernel, dim3((nA + 3) / 4, B), dim3(256), 0, s, feat, dist, anchors, idx, g_out, N, C, nA,
+                       k, W);
+    DVM_CHECK_LAUNCH("dist_loss_bwd_weights");
     return DVM_OK;
 }
 

@@ -220,6 +220,42 @@ __global__ __launch_bounds__(256) void apply_kernel(const float *__restrict__ pi
         if (c0 + e < C) out[row * C + c0 + e] = acc[e];
 }
 
+// Backward of apply_kernel: out[i] = sum_t val[i,t] V[idx[i,t]]  =>  d_val[i,t] = g[i] . V[idx[i,t]],
+// d_V[idx[i,t]] += val[i,t] g[i] (fp32 atomics).  A row's ceil(C/4) channel groups sit in GP2 (power of two
+// >= groups, <= 64) consecutive lanes so the dot products reduce with shuffles.
+__global__ __launch_bounds__(256) void apply_bwd_kernel(const float *__restrict__ pi_val, const int32_t *__restrict__ pi_idx,
+                                                        const float *__restrict__ V, const float *__restrict__ gout, int N, int M,
+                                                        int topk, int C, int gp2, float *__restrict__ dval,
+                                                        float *__restrict__ dV) {
+    const int groups = (C + 3) / 4;
+    const int b = blockIdx.y;
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long i0 = g / gp2;
+    const int cg = (int)(g % gp2);
+    const bool live = i0 < N && cg < groups;
+    const int i = i0 < N ? (int)i0 : N - 1;
+    const size_t row = (size_t)b * N + i;
+    const int c0 = cg * 4;
+    float gv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) gv[e] = (live && c0 + e < C) ? gout[row * C + c0 + e] : 0.f;
+    for (int t = 0; t < topk; ++t) {
+        const int j = pi_idx[row * topk + t];
+        const bool ok = live && j >= 0 && j < M;
+        const float w = pi_val[row * topk + t];
+        const size_t vr = ((size_t)b * M + (ok ? j : 0)) * C + c0;
+        float part = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (ok && c0 + e < C) {
+                part = fmaf(gv[e], V[vr + e], part);
+                unsafeAtomicAdd(dV + vr + e, w * gv[e]);
+            }
+        for (int o = 1; o < gp2; o <<= 1) part += __shfl_xor(part, o, 64);
+        if (cg == 0 && i0 < N) dval[row * topk + t] = part;
+    }
+}
+
 // ---------------------------------------------------------------- Chamfer NN
 // d1[i] = min_j |a_i - b_j|^2 ((dx^2+dy^2)+dz^2, no contraction), first minimum wins.
 __global__ __launch_bounds__(128) void chamfer_kernel(const float *__restrict__ a, const float *__restrict__ bpts, int N,
@@ -466,6 +502,23 @@ DVM_EXPORT int dvm_softcorr_apply_f32(const float *pi_val, const int32_t *pi_idx
     else
         hipLaunchKernelGGL(apply_kernel<16>, grid, block, 0, (hipStream_t)stream, pi_val, pi_idx, V, N, M, topk, C, out);
     DVM_CHECK_LAUNCH("softcorr_apply");
+    return DVM_OK;
+}
+
+DVM_EXPORT int dvm_softcorr_apply_bwd_f32(const float *pi_val, const int32_t *pi_idx, const float *V, const float *g_out, int B,
+                                          int N, int M, int topk, int C, float *d_val, float *d_V, void *stream) {
+    DVM_REQUIRE(pi_val && pi_idx && V && g_out && d_val && d_V, "dvm_softcorr_apply_bwd_f32: null pointer");
+    DVM_REQUIRE(B >= 1 && N >= 1 && M >= 1 && C >= 1, "dvm_softcorr_apply_bwd_f32: empty input");
+    DVM_REQUIRE(C <= 256, "dvm_softcorr_apply_bwd_f32: C=%d unsupported (<= 256)", C);
+    DVM_REQUIRE(topk >= 1 && topk <= 64, "dvm_softcorr_apply_bwd_f32: topk=%d unsupported (1..64)", topk);
+    int gp2 = 1;
+    while (gp2 < (C + 3) / 4) gp2 <<= 1;
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipMemsetAsync(d_V, 0, (size_t)B * M * C * sizeof(float), s);
+    long threads = (long)N * gp2;
+    dim3 grid((unsigned)((threads + 255) / 256), B), block(256);
+    hipLaunchKernelGGL(apply_bwd_kernel, grid, block, 0, s, pi_val, pi_idx, V, g_out, N, M, topk, C, gp2, d_val, d_V);
+    DVM_CHECK_LAUNCH("softcorr_apply_bwd");
     return DVM_OK;
 }
 

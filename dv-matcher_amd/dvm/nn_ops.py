@@ -104,12 +104,58 @@ def softcorr_topk(f1, f2, alpha, topk=10):
     return _SoftCorrTopK.apply(f1, f2, alpha, topk)
 
 
+class _SparseApply(torch.autograd.Function):
+    """out[i] = sum_t val[i,t] V[idx[i,t]] on the HIP kernels, both ways (no (B,N,k,C) gather in HBM)."""
+
+    @staticmethod
+    def forward(ctx, val, idx, V):
+        ctx.save_for_backward(val.detach(), idx, V.detach())
+        return ops.apply(val, idx, V)
+
+    @staticmethod
+    def backward(ctx, gout):
+        val, idx, V = ctx.saved_tensors
+        dval, dV = ops.apply_bwd(val, idx, V, gout)
+        return dval, None, dV
+
+
+class _DistLoss(torch.autograd.Function):
+    """dist-loss term (models/loss.py:1351-1396) per batch element: fused HIP forward; the backward builds the
+    sparse (anchor, point) weights with a HIP kernel and finishes with two library GEMMs per batch."""
+
+    @staticmethod
+    def forward(ctx, feat, dist, anchors, k):
+        out, idx = ops.dist_loss(feat, dist, anchors, k, want_idx=True)
+        ctx.save_for_backward(feat.detach(), dist, anchors, idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        feat, dist, anchors, idx = ctx.saved_tensors
+        W = ops.dist_loss_bwd_weights(feat, dist, anchors, idx, gout.contiguous())   # (B,nA,N)
+        a = anchors.long()
+        fa = feat[:, a]
+        dfeat = W.sum(1).unsqueeze(-1) * feat - torch.bmm(W.transpose(1, 2), fa)
+        dfa = W.sum(2).unsqueeze(-1) * fa - torch.bmm(W, feat)
+        dfeat.index_add_(1, a, dfa)
+        return dfeat, None, None, None
+
+
+def dist_loss(feat, dist, anchors, k):
+    """(B,) sum over anchors of 1 - |cos(x, y)| with autograd w.r.t. feat."""
+    return _DistLoss.apply(feat, dist, anchors, k)
+
+
 def sparse_apply(val, idx, V):
     """Pi~ @ V with autograd: val (B,N,k), idx (B,N,k), V (B,M,C) -> (B,N,C)."""
-    B, N, k = val.shape
-    C = V.shape[-1]
-    g = torch.gather(V, 1, idx.long().reshape(B, N * k, 1).expand(-1, -1, C)).view(B, N, k, C)
-    return (val.unsqueeze(-1) * g).sum(2)
+    return _SparseApply.apply(val, idx, V)
+
+
+def pool_rows(x, idx, w, bias):
+    """Deformer's k -> 1 pooling conv: out[i] = sum_s w[s] x[idx[i,s]] + bias (models/model.py:466-470) — the
+    same weighted gather-sum with row-independent weights (autograd sums the expanded weights' gradient)."""
+    B, N, k = idx.shape
+    return _SparseApply.apply(w.reshape(1, 1, k).expand(B, N, k), idx, x) + bias
 
 
 def gather_rows(x, idx):

@@ -156,6 +156,19 @@ def apply(pi_val, pi_idx, V):
     return out
 
 
+def apply_bwd(pi_val, pi_idx, V, gout):
+    """Backward of apply: -> (d_val (B,N,topk), d_V (B,M,C))."""
+    _need_gpu(pi_val, pi_idx, V, gout)
+    pi_val, pi_idx, V, gout = _f(pi_val), _i(pi_idx), _f(V), _f(gout)
+    B, N, topk = pi_val.shape
+    M, C = V.shape[1], V.shape[2]
+    dval = torch.empty_like(pi_val)
+    dV = torch.empty_like(V)
+    check(_lib.load().dvm_softcorr_apply_bwd_f32(_p(pi_val), _p(pi_idx), _p(V), _p(gout), B, N, M, topk, C, _p(dval), _p(dV),
+                                                 _stream()), "dvm_softcorr_apply_bwd_f32")
+    return dval, dV
+
+
 def fps(xyz, npoint, start):
     _need_gpu(xyz, start)
     xyz, start = _f(xyz), _i(start)
@@ -411,6 +424,18 @@ def dist_loss(feat, dist, anchors, k, want_idx=False):
     check(lib.dvm_dist_loss_fwd_f32(_p(feat), _p(dist), _p(anchors), B, N, C, nA, k, _p(out), _p(idx), _p(ws), nb,
                                     _stream()), "dvm_dist_loss_fwd_f32")
     return (out, idx) if want_idx else out
+
+
+def dist_loss_bwd_weights(feat, dist, anchors, idx, gout):
+    """-> W (B,nA,N), see include/dvm.h."""
+    _need_gpu(feat, dist, anchors, idx, gout)
+    feat, dist, anchors, idx, gout = _f(feat), _f(dist), _i(anchors), _i(idx), _f(gout)
+    B, N, C = feat.shape
+    nA, k = idx.shape[1], idx.shape[2]
+    W = torch.empty(B, nA, N, dtype=torch.float32, device=feat.device)
+    check(_lib.load().dvm_dist_loss_bwd_weights_f32(_p(feat), _p(dist), _p(anchors), _p(idx), _p(gout), B, N, C, nA, k, _p(W),
+                                                    _stream()), "dvm_dist_loss_bwd_weights_f32")
+    return W
 
 
 def pair_forward(wl, feat1, feat2, verts1, verts2, alpha, start1, start2, with_map=True, out=None):

@@ -136,25 +136,16 @@ class GraphDeformLoss_Neural(nn.Module):
         return torch.mean(d1) + torch.mean(d2)
 
     def _dist_term_train(self, feat, dist, anchors):
-        """dist-loss term with autograd: kNN indices from the HIP kernel, the rest in torch ops."""
-        B, N, C = feat.shape
-        f1 = feat[:, anchors]
-        idx = ops.knn_neg(f1, feat, self.k_dist).long()                       # (B,nA,k)
-        nA, k = idx.shape[1], idx.shape[2]
-        f2 = nn_ops.gather_rows(feat, idx)
-        x = torch.norm(f2 - f1[:, :, None, :], dim=-1)
-        y = torch.gather(dist, 1, idx.reshape(B, nA * k, 1).expand(-1, -1, N))  # rows dist[b, idx, :]
-        y = torch.gather(y, 2, anchors.view(1, nA, 1).expand(B, -1, k).reshape(B, nA * k, 1)).view(B, nA, k)
-        return torch.sum(1 - torch.abs(torch.nn.functional.cosine_similarity(x, y, dim=2)))
+        """dist-loss term with autograd (HIP forward, HIP weights + GEMM backward)."""
+        return nn_ops.dist_loss(feat, dist, anchors, self.k_dist).sum()
 
     def _direction_train(self, feat1, feat2, verts1, verts2, alpha, g1, deformer, idx11, idx22):
         """deform() with autograd (models/loss.py:1228-1296)."""
         B, N, _ = verts1.shape
         pval, pidx = nn_ops.softcorr_topk(feat1, feat2, alpha, 10)
         verts12 = nn_ops.sparse_apply(pval, pidx, verts2)
-        w = deformer.conv_layer.weight.view(1, 1, -1, 1)
-        g1p = (nn_ops.gather_rows(feat1, idx11) * w).sum(2) + deformer.conv_layer.bias
-        g2p = (nn_ops.gather_rows(feat2, idx22) * w).sum(2) + deformer.conv_layer.bias
+        g1p = nn_ops.pool_rows(feat1, idx11, deformer.conv_layer.weight, deformer.conv_layer.bias)
+        g2p = nn_ops.pool_rows(feat2, idx22, deformer.conv_layer.weight, deformer.conv_layer.bias)
         g2t = nn_ops.sparse_apply(pval, pidx, g2p)
         fps = g1["nodes_idx"].long().unsqueeze(-1)
         pick = lambda t: torch.gather(t, 1, fps.expand(-1, -1, t.shape[-1]))  # noqa: E731

@@ -112,6 +112,11 @@ int dvm_softcorr_dense_f32(const float *f1, const float *f2, int B, int N, int M
 int dvm_softcorr_apply_f32(const float *pi_val, const int32_t *pi_idx, const float *V, int B, int N, int M, int topk,
                            int C, float *out, void *stream);
 
+/* Backward of dvm_softcorr_apply_f32: g_out [B,N,C] -> d_val [B,N,topk] = g_out[i] . V[idx[i,t]] and
+ * d_V [B,M,C] (overwritten; scatter-accumulated with fp32 atomics).  C <= 256, topk <= 64. */
+int dvm_softcorr_apply_bwd_f32(const float *pi_val, const int32_t *pi_idx, const float *V, const float *g_out, int B,
+                               int N, int M, int topk, int C, float *d_val, float *d_V, void *stream);
+
 /* farthest_point_sample — lib/deformation_graph_point.py:18-33 with the random
  * start index made an input.  xyz [B,N,3], start [B] -> out [B,npoint]. */
 int dvm_fps_f32(const float *xyz, int B, int N, int npoint, const int32_t *start, int32_t *out, void *stream);
@@ -197,6 +202,14 @@ int dvm_n2p_core_bwd_f32(const float *qkv, const int32_t *idx, const float *attn
 size_t dvm_dist_loss_workspace_bytes(int B, int N, int C, int nA, int k);
 int dvm_dist_loss_fwd_f32(const float *feat, const float *dist, const int32_t *anchors, int B, int N, int C, int nA,
                           int k, float *out, int32_t *idx_out, void *ws, size_t ws_bytes, void *stream);
+
+/* Backward of dvm_dist_loss_fwd_f32, first half: with idx [B,nA,k] from the forward (idx_out) and
+ * g_out [B] = dL/d out, writes the dense weights W [B,nA,N] (overwritten; zero outside idx):
+ *   W[b,n,v] = g_out[b] * d term_n/d x_v / x_v   (x_v = |feat[v] - feat[a_n]|, 0 where x_v = 0).
+ * The feature gradient follows with library GEMMs:
+ *   d feat = diag(colsum W) feat - W^T feat[anchors];  d feat[a_n] += rowsum(W)_n feat[a_n] - (W feat)_n. */
+int dvm_dist_loss_bwd_weights_f32(const float *feat, const float *dist, const int32_t *anchors, const int32_t *idx,
+                                  const float *g_out, int B, int N, int C, int nA, int k, float *W, void *stream);
 
 /* map-loss numerator — models/loss.py:1232-1238 + FrobeniusLoss 476-482:
  * out[b] = sum_{i,s,c} (verts12[idx11[i,s],c] - sum_t P[i,t] verts2[idx22[pidx[i,t],s],c])^2. */

@@ -90,3 +90,43 @@ def test_n2p_core_fwd_bwd_vs_fp64_autograd(ops, C, K, N):
     (ref * gout.double()).sum().backward()
     assert rel(out, ref) < 1e-5 and rel(attn, a) < 1e-5
     assert rel(dqkv, x.grad) < 1e-5, rel(dqkv, x.grad)
+
+
+@pytest.mark.parametrize("C", [3, 30, 128, 64, 200])
+def test_sparse_apply_bwd_vs_fp64_autograd(ops, C):
+    B, N, M, k = 2, 190, 75, 10
+    g = torch.Generator().manual_seed(C)
+    val = torch.rand(B, N, k, generator=g)
+    idx = torch.randint(0, M, (B, N, k), generator=g, dtype=torch.int32)
+    V = torch.randn(B, M, C, generator=g)
+    gout = torch.randn(B, N, C, generator=g)
+    dval, dV = ops.apply_bwd(val.cuda(), idx.cuda(), V.cuda(), gout.cuda())
+    v64, V64 = val.double().requires_grad_(True), V.double().requires_grad_(True)
+    rows = torch.gather(V64, 1, idx.long().reshape(B, N * k, 1).expand(-1, -1, C)).view(B, N, k, C)
+    ((v64.unsqueeze(-1) * rows).sum(2) * gout.double()).sum().backward()
+    assert rel(dval, v64.grad) < 1e-5 and rel(dV, V64.grad) < 1e-5
+
+
+def test_dist_loss_bwd_vs_fp64_autograd(ops):
+    from dvm import nn_ops
+    B, N, C, nA, k = 2, 300, 128, 40, 25
+    g = torch.Generator().manual_seed(31)
+    feat = torch.randn(B, N, C, generator=g)
+    v = torch.rand(B, N, 3, generator=g)
+    dist = torch.cdist(v, v)
+    anchors = torch.randperm(N, generator=g)[:nA]
+    gout = torch.randn(B, generator=g)
+    f = feat.cuda().requires_grad_(True)
+    out = nn_ops.dist_loss(f, dist.cuda(), anchors.cuda(), k)
+    (out * gout.cuda()).sum().backward()
+    idx = ops.dist_loss(feat.cuda(), dist.cuda(), anchors.cuda(), k, want_idx=True)[1].cpu().long()
+    f64 = feat.double().requires_grad_(True)   # the reference's formulation, models/loss.py:1351-1396
+    f1 = f64[:, anchors]
+    f2 = torch.gather(f64, 1, idx.reshape(B, nA * k, 1).expand(-1, -1, C)).view(B, nA, k, C)
+    d2 = ((f2 - f1[:, :, None, :]) ** 2).sum(-1)
+    x = torch.where(d2 > 0, torch.sqrt(d2.clamp_min(1e-300)), torch.zeros_like(d2))
+    y = torch.stack([dist[b].double()[idx[b], anchors[:, None]] for b in range(B)])
+    ref = (1 - torch.abs(torch.nn.functional.cosine_similarity(x, y, dim=2))).sum(1)
+    (ref * gout.double()).sum().backward()
+    assert rel(out, ref) < 1e-5
+    assert rel(f.grad, f64.grad) < 1e-4, rel(f.grad, f64.grad)
