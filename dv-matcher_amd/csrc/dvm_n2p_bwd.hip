@@ -10,7 +10,7 @@
 //     dq_h  = sum_j de_hj kp_j / sqrt(D)                      (sum_j de_hj = 0 removes kp_i)
 //     dkp_j += de_hj q_h / sqrt(D) ,  dvp_j += a_hj g_h ,  dvp_i -= g_h
 // One wave per point, a head = 16 consecutive lanes (C/64 channels per lane); neighbour rows are gathered
-// with coalesced 256/512 B reads and scattered with hardware fp32 atomics.
+// with coalesced 256/512 B reads; the backward's scatter is a second gather over the reversed neighbour lists.
 #include "dvm_common.h"
 
 namespace dvm {
@@ -68,10 +68,14 @@ __global__ __launch_bounds__(256) void n2p_core_fwd_kernel(const float *__restri
         for (int t = lane; t < K * NP_H; t += 64) attn[(base + pt) * K * NP_H + t] = __expf(se[wave][t] - mh) * ih;
 }
 
+// ---- backward.  Point pass: de (scaled by 1/sqrt(D)) for every (point, neighbour, head) and dq by gathering
+// kp rows.  The scatter side (dkp_j += de q_i, dvp_j += a g_i) is turned into a gather as well: a counting
+// sort of idx gives every target row its list of (point, slot) references (CSR), and one wave per target row
+// sums its in-edges in registers — 40 int atomics per point instead of 80 x C float atomics.
 template <int C>
-__global__ __launch_bounds__(256) void n2p_core_bwd_kernel(const float *__restrict__ qkv, const int32_t *__restrict__ idx,
-                                                           const float *__restrict__ attn, const float *__restrict__ gout, int N,
-                                                           int K, float *__restrict__ dqkv) {
+__global__ __launch_bounds__(256) void n2p_bwd_point_kernel(const float *__restrict__ qkv, const int32_t *__restrict__ idx,
+                                                            const float *__restrict__ attn, const float *__restrict__ gout, int N,
+                                                            int K, float *__restrict__ de_out, float *__restrict__ dqkv) {
     constexpr int CPL = C / 64, D = C / NP_H, LD = 3 * C;
     __shared__ float sa[4][NP_KMAX * NP_H], sd[4][NP_KMAX * NP_H];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -81,11 +85,9 @@ __global__ __launch_bounds__(256) void n2p_core_bwd_kernel(const float *__restri
     const size_t base = (size_t)blockIdx.y * N;
     const int hd = lane >> 4;
     const float inv_scale = 1.0f / sqrtf((float)D);
-    const float *self = qkv + (base + pt) * LD + lane * CPL;
-    float qv[CPL], gv[CPL], dq[CPL];
+    float gv[CPL], dq[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
-        qv[c] = self[c];
         gv[c] = valid ? gout[(base + pt) * C + lane * CPL + c] : 0.f;
         dq[c] = 0.f;
     }
@@ -108,24 +110,116 @@ __global__ __launch_bounds__(256) void n2p_core_bwd_kernel(const float *__restri
     }
 #pragma unroll
     for (int o = 4; o < 64; o <<= 1) dot += __shfl_xor(dot, o, 64);
-    for (int t = lane; t < K * NP_H; t += 64) sd[wave][t] = sa[wave][t] * (sd[wave][t] - dot) * inv_scale;  // de / sqrt(D)
+    for (int t = lane; t < K * NP_H; t += 64) {
+        const float de = sa[wave][t] * (sd[wave][t] - dot) * inv_scale;
+        sd[wave][t] = de;
+        if (valid) de_out[(base + pt) * K * NP_H + t] = de;
+    }
     __syncthreads();
     if (!valid) return;
     for (int j = 0; j < K; ++j) {
-        const size_t r = (base + nb[j]) * LD + lane * CPL;
-        const float de = sd[wave][j * NP_H + hd], a = sa[wave][j * NP_H + hd];
+        const float *nrow = qkv + (base + nb[j]) * LD + C + lane * CPL;
+        const float de = sd[wave][j * NP_H + hd];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) dq[c] = fmaf(de, nrow[c], dq[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) dqkv[(base + pt) * LD + lane * CPL + c] = dq[c];
+}
+
+__global__ void csr_count_kernel(const int32_t *__restrict__ idx, int N, int K, int32_t *__restrict__ cnt) {
+    const int b = blockIdx.y;
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)N * K) return;
+    atomicAdd(cnt + (size_t)b * (N + 1) + idx[(size_t)b * N * K + e], 1);
+}
+
+// exclusive scan of cnt[b][0..N) in place -> offs (cnt[b][N] = total); cursor = copy of the offsets
+__global__ __launch_bounds__(1024) void csr_scan_kernel(int32_t *__restrict__ cnt, int N, int32_t *__restrict__ cursor) {
+    __shared__ int part[1024];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int32_t *c = cnt + (size_t)b * (N + 1);
+    const int per = (N + 1023) / 1024;
+    const int lo = min(N, tid * per), hi = min(N, lo + per);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += c[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        int v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - s;  // exclusive prefix of this thread's chunk
+    for (int i = lo; i < hi; ++i) {
+        const int v = c[i];
+        c[i] = run;
+        cursor[(size_t)b * N + i] = run;
+        run += v;
+    }
+    if (tid == 1023) c[N] = part[1023];
+}
+
+__global__ void csr_fill_kernel(const int32_t *__restrict__ idx, int N, int K, int32_t *__restrict__ cursor,
+                                int32_t *__restrict__ edges) {
+    const int b = blockIdx.y;
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)N * K) return;
+    const int pos = atomicAdd(cursor + (size_t)b * N + idx[(size_t)b * N * K + e], 1);
+    edges[(size_t)b * N * K + pos] = (int32_t)e;  // e = point * K + slot
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void n2p_bwd_gather_kernel(const float *__restrict__ qkv, const float *__restrict__ attn,
+                                                             const float *__restrict__ de_buf, const float *__restrict__ gout,
+                                                             const int32_t *__restrict__ offs, const int32_t *__restrict__ edges,
+                                                             int N, int K, float *__restrict__ dqkv) {
+    constexpr int CPL = C / 64, LD = 3 * C;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long r = (long)blockIdx.x * 4 + wave;
+    if (r >= N) return;
+    const int b = blockIdx.y;
+    const size_t base = (size_t)b * N;
+    const int hd = lane >> 4;
+    const int beg = offs[(size_t)b * (N + 1) + r], end = offs[(size_t)b * (N + 1) + r + 1];
+    const int32_t *ed = edges + base * K;
+    const float *ab = attn + base * K * NP_H, *db = de_buf + base * K * NP_H;
+    float ak[CPL], av[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) ak[c] = 0.f, av[c] = 0.f;
+    int e = beg;
+    for (; e + 1 < end; e += 2) {  // two in-edges in flight
+        const int e0 = ed[e], e1 = ed[e + 1];
+        const int n0 = e0 / K, n1 = e1 / K;
+        const float d0 = db[(size_t)e0 * NP_H + hd], a0 = ab[(size_t)e0 * NP_H + hd];
+        const float d1 = db[(size_t)e1 * NP_H + hd], a1 = ab[(size_t)e1 * NP_H + hd];
+        const float *q0 = qkv + (base + n0) * LD + lane * CPL, *g0 = gout + (base + n0) * C + lane * CPL;
+        const float *q1 = qkv + (base + n1) * LD + lane * CPL, *g1 = gout + (base + n1) * C + lane * CPL;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
-            dq[c] = fmaf(de, qkv[r + C + c], dq[c]);
-            unsafeAtomicAdd(dqkv + r + C + c, de * qv[c]);
-            unsafeAtomicAdd(dqkv + r + 2 * C + c, a * gv[c]);
+            ak[c] = fmaf(d0, q0[c], ak[c]);
+            av[c] = fmaf(a0, g0[c], av[c]);
+            ak[c] = fmaf(d1, q1[c], ak[c]);
+            av[c] = fmaf(a1, g1[c], av[c]);
         }
     }
-    float *dself = dqkv + (base + pt) * LD + lane * CPL;
+    if (e < end) {
+        const int e0 = ed[e];
+        const int n0 = e0 / K;
+        const float d0 = db[(size_t)e0 * NP_H + hd], a0 = ab[(size_t)e0 * NP_H + hd];
+        const float *q0 = qkv + (base + n0) * LD + lane * CPL, *g0 = gout + (base + n0) * C + lane * CPL;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            ak[c] = fmaf(d0, q0[c], ak[c]);
+            av[c] = fmaf(a0, g0[c], av[c]);
+        }
+    }
+    float *dst = dqkv + (base + r) * LD + lane * CPL;
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
-        dself[c] = dq[c];  // nobody else writes the q part
-        unsafeAtomicAdd(dself + 2 * C + c, -gv[c]);
+        dst[C + c] = ak[c];
+        dst[2 * C + c] = av[c] - gout[(base + r) * C + lane * CPL + c];
     }
 }
 
@@ -151,20 +245,40 @@ DVM_EXPORT int dvm_n2p_core_fwd_f32(const float *qkv, const int32_t *idx, int B,
     return DVM_OK;
 }
 
+DVM_EXPORT size_t dvm_n2p_core_bwd_workspace_bytes(int B, int N, int K) {
+    return align_up((size_t)B * N * K * NP_H * sizeof(float)) + align_up((size_t)B * (N + 1) * sizeof(int32_t)) +
+           align_up((size_t)B * N * sizeof(int32_t)) + align_up((size_t)B * N * K * sizeof(int32_t));
+}
+
 DVM_EXPORT int dvm_n2p_core_bwd_f32(const float *qkv, const int32_t *idx, const float *attn, const float *g_out, int B, int N, int C,
-                                    int K, int heads, float *d_qkv, void *stream) {
+                                    int K, int heads, float *d_qkv, void *ws, size_t ws_bytes, void *stream) {
     DVM_REQUIRE(qkv && idx && attn && g_out && d_qkv, "dvm_n2p_core_bwd_f32: null pointer");
     DVM_REQUIRE(B >= 1 && N >= 1, "dvm_n2p_core_bwd_f32: empty input");
     DVM_REQUIRE((C == 64 || C == 128) && heads == NP_H, "dvm_n2p_core_bwd_f32: need C in {64,128}, heads == 4 (C=%d heads=%d)", C,
                 heads);
     DVM_REQUIRE(K >= 1 && K <= NP_KMAX, "dvm_n2p_core_bwd_f32: K=%d unsupported (1..64)", K);
-    dim3 grid((N + 3) / 4, B);
+    Arena ar(ws, ws_bytes);
+    float *de = ar.take<float>((size_t)B * N * K * NP_H);
+    int32_t *offs = ar.take<int32_t>((size_t)B * (N + 1));
+    int32_t *cursor = ar.take<int32_t>((size_t)B * N);
+    int32_t *edges = ar.take<int32_t>((size_t)B * N * K);
+    if (!ar.ok()) {
+        set_error("dvm_n2p_core_bwd_f32: workspace too small (%zu < %zu)", ws_bytes, ar.off);
+        return DVM_ENOSPACE;
+    }
     hipStream_t s = (hipStream_t)stream;
-    (void)hipMemsetAsync(d_qkv, 0, (size_t)B * N * 3 * C * sizeof(float), s);
-    if (C == 64)
-        hipLaunchKernelGGL(n2p_core_bwd_kernel<64>, grid, dim3(256), 0, s, qkv, idx, attn, g_out, N, K, d_qkv);
-    else
-        hipLaunchKernelGGL(n2p_core_bwd_kernel<128>, grid, dim3(256), 0, s, qkv, idx, attn, g_out, N, K, d_qkv);
+    dim3 grid((N + 3) / 4, B), egrid((unsigned)(((long)N * K + 255) / 256), B);
+    (void)hipMemsetAsync(offs, 0, (size_t)B * (N + 1) * sizeof(int32_t), s);
+    hipLaunchKernelGGL(csr_count_kernel, egrid, dim3(256), 0, s, idx, N, K, offs);
+    hipLaunchKernelGGL(csr_scan_kernel, dim3(B), dim3(1024), 0, s, offs, N, cursor);
+    hipLaunchKernelGGL(csr_fill_kernel, egrid, dim3(256), 0, s, idx, N, K, cursor, edges);
+    if (C == 64) {
+        hipLaunchKernelGGL(n2p_bwd_point_kernel<64>, grid, dim3(256), 0, s, qkv, idx, attn, g_out, N, K, de, d_qkv);
+        hipLaunchKernelGGL(n2p_bwd_gather_kernel<64>, grid, dim3(256), 0, s, qkv, attn, de, g_out, offs, edges, N, K, d_qkv);
+    } else {
+        hipLaunchKernelGGL(n2p_bwd_point_kernel<128>, grid, dim3(256), 0, s, qkv, idx, attn, g_out, N, K, de, d_qkv);
+        hipLaunchKernelGGL(n2p_bwd_gather_kernel<128>, grid, dim3(256), 0, s, qkv, attn, de, g_out, offs, edges, N, K, d_qkv);
+    }
     DVM_CHECK_LAUNCH("n2p_core_bwd");
     return DVM_OK;
 }

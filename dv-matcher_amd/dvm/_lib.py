@@ -32,7 +32,8 @@ SIGNATURES = {
     "dvm_softcorr_bwd_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P, _P, _P, _P, _P, _P, _P, c_int,
                                      _P, c_size_t, _P]),
     "dvm_n2p_core_fwd_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
-    "dvm_n2p_core_bwd_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "dvm_n2p_core_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dvm_n2p_core_bwd_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_size_t, _P]),
     "dvm_softcorr_apply_bwd_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "dvm_dist_loss_bwd_weights_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "dvm_argmin_exact_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),

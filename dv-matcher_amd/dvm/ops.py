@@ -116,8 +116,11 @@ def n2p_core_bwd(qkv, idx, attn, gout, heads=4):
     B, N, C3 = qkv.shape
     C, K = C3 // 3, idx.shape[-1]
     dqkv = torch.empty_like(qkv)
-    check(_lib.load().dvm_n2p_core_bwd_f32(_p(qkv), _p(idx.contiguous()), _p(attn), _p(gout), B, N, C, K, heads, _p(dqkv),
-                                           _stream()), "dvm_n2p_core_bwd_f32")
+    lib = _lib.load()
+    nb = lib.dvm_n2p_core_bwd_workspace_bytes(B, N, K)
+    ws = workspace(nb, qkv.device, "n2p_bwd")
+    check(lib.dvm_n2p_core_bwd_f32(_p(qkv), _p(idx.contiguous()), _p(attn), _p(gout), B, N, C, K, heads, _p(dqkv), _p(ws), nb,
+                                   _stream()), "dvm_n2p_core_bwd_f32")
     return dqkv
 
 

@@ -189,12 +189,14 @@ int dvm_n2p_attention_fwd_f32(const float *q, const float *kp, const float *vp, 
 
 /* Training twins of the N2P attention core.  qkv [B,N,3C] = [Wq x | Wk x | Wv x] per point (one GEMM's
  * output, used in place), idx [B,N,K].  fwd: out [B,N,C] as dvm_n2p_attention_fwd_f32, plus the attention
- * weights attn [B,N,K,heads] kept for the backward.  bwd: g_out [B,N,C] -> d_qkv [B,N,3C] (overwritten;
- * neighbour rows are accumulated with fp32 atomics, order not fixed).  C in {64,128}, heads = 4, K <= 64. */
+ * weights attn [B,N,K,heads] kept for the backward.  bwd: g_out [B,N,C] -> d_qkv [B,N,3C] (overwritten; the
+ * scatter onto neighbour rows runs as a gather over the reversed neighbour lists — a counting sort of idx
+ * in the workspace — so no float atomics; idx entries must lie in [0,N)).  C in {64,128}, heads = 4, K <= 64. */
 int dvm_n2p_core_fwd_f32(const float *qkv, const int32_t *idx, int B, int N, int C, int K, int heads, float *out,
                          float *attn, void *stream);
+size_t dvm_n2p_core_bwd_workspace_bytes(int B, int N, int K);
 int dvm_n2p_core_bwd_f32(const float *qkv, const int32_t *idx, const float *attn, const float *g_out, int B, int N,
-                         int C, int K, int heads, float *d_qkv, void *stream);
+                         int C, int K, int heads, float *d_qkv, void *ws, size_t ws_bytes, void *stream);
 
 /* dist-loss term — models/loss.py:1351-1396 for one shape batch: anchors [nA] (shared by the
  * batch), idx = knn(feat[:,anchors], feat, k); x = |feat[idx] - feat[anchor]|, y = dist[b, idx, anchor];
