@@ -177,19 +177,52 @@ class _ChamferNN(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g1, g2):
         a, b, i1, i2 = ctx.saved_tensors
-        nb = torch.gather(b, 1, i1.long().unsqueeze(-1).expand(-1, -1, 3))
-        na = torch.gather(a, 1, i2.long().unsqueeze(-1).expand(-1, -1, 3))
-        t1 = 2 * g1.unsqueeze(-1) * (a - nb)       # d d1_i / d a_i ; minus that for b[i1]
-        t2 = 2 * g2.unsqueeze(-1) * (b - na)
-        ga = t1.clone()
-        gb = t2.clone()
-        ga.scatter_add_(1, i2.long().unsqueeze(-1).expand(-1, -1, 3), -t2)
-        gb.scatter_add_(1, i1.long().unsqueeze(-1).expand(-1, -1, 3), -t1)
-        return ga, gb
+        return ops.chamfer_bwd(a, b, i1, i2, g1.contiguous(), g2.contiguous())
 
 
 def chamfer_nn(a, b):
     return _ChamferNN.apply(a, b)
+
+
+class _Rot6D(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, d6):
+        ctx.save_for_backward(d6.detach())
+        return ops.rot6d(d6)
+
+    @staticmethod
+    def backward(ctx, gR):
+        (d6,) = ctx.saved_tensors
+        return ops.rot6d_bwd(d6, gR.contiguous())
+
+
+def rot6d(d6):
+    """rotation_6d_to_matrix with autograd, both ways on the HIP kernels: (...,6) -> (...,3,3)."""
+    return _Rot6D.apply(d6)
+
+
+class _WarpArap(torch.autograd.Function):
+    """Embedded-deformation warp + ARAP (lib/deformation_graph_point.py:233-261), differentiable w.r.t. the
+    node rotations / translations; forward and backward on the HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, verts, R, T, nodes_idx, one_ring, infl_idx, weights):
+        g = dict(nodes_idx=nodes_idx, one_ring=one_ring, infl_idx=infl_idx, weights=weights)
+        warped, arap, _ = ops.dg_warp_arap(verts, g, R, T)
+        ctx.save_for_backward(verts, R.detach(), T.detach(), nodes_idx, one_ring, infl_idx, weights)
+        return warped, arap
+
+    @staticmethod
+    def backward(ctx, gw, ga):
+        verts, R, T, nodes_idx, one_ring, infl_idx, weights = ctx.saved_tensors
+        g = dict(nodes_idx=nodes_idx, one_ring=one_ring, infl_idx=infl_idx, weights=weights)
+        dR, dT = ops.dg_warp_arap_bwd(verts, g, R, T, gw.contiguous(), ga.contiguous())
+        return None, dR, dT, None, None, None, None
+
+
+def dg_warp_arap(verts, g, R, T):
+    """verts (B,N,3), batched graph dict, R (B,Nn,3,3), T (B,Nn,3) -> warped (B,N,3), arap (B,), with autograd."""
+    return _WarpArap.apply(verts, R, T.contiguous(), g["nodes_idx"], g["one_ring"], g["infl_idx"], g["weights"])
 
 
 def rot6d_torch(d6):

@@ -213,6 +213,37 @@ def rot6d(d6):
     return R
 
 
+def rot6d_bwd(d6, gR):
+    _need_gpu(d6, gR)
+    d6, gR = _f(d6), _f(gR)
+    out = torch.empty_like(d6)
+    check(_lib.load().dvm_rot6d_bwd_f32(_p(d6), _p(gR), d6.numel() // 6, _p(out), _stream()), "dvm_rot6d_bwd_f32")
+    return out
+
+
+def dg_warp_arap_bwd(xyz, g, R, T, gw, ga):
+    """-> (d_R (B,Nn,3,3), d_T (B,Nn,3))."""
+    _need_gpu(xyz, R, T, gw, ga)
+    xyz, R, T, gw, ga = _f(xyz), _f(R), _f(T), _f(gw), _f(ga)
+    B, N, _ = xyz.shape
+    dR, dT = torch.empty_like(R), torch.empty_like(T)
+    check(_lib.load().dvm_dg_warp_arap_bwd_f32(_p(xyz), B, N, _p(_i(g["nodes_idx"])), _p(_i(g["one_ring"])),
+                                               _p(_i(g["infl_idx"])), _p(_f(g["weights"])), _p(R), _p(T), _p(gw), _p(ga),
+                                               _p(dR), _p(dT), _stream()), "dvm_dg_warp_arap_bwd_f32")
+    return dR, dT
+
+
+def chamfer_bwd(a, b, i1, i2, g1, g2):
+    _need_gpu(a, b, g1, g2)
+    a, b, g1, g2 = _f(a), _f(b), _f(g1), _f(g2)
+    B, N, _ = a.shape
+    M = b.shape[1]
+    da, db = torch.empty_like(a), torch.empty_like(b)
+    check(_lib.load().dvm_chamfer_bwd_f32(_p(a), _p(b), _p(_i(i1)), _p(_i(i2)), _p(g1), _p(g2), B, N, M, _p(da), _p(db),
+                                          _stream()), "dvm_chamfer_bwd_f32")
+    return da, db
+
+
 def dg_warp_arap(xyz, g, R, T):
     """xyz (B,N,3), graph dict, R (B,Nn,3,3), T (B,Nn,3) -> warped (B,N,3), arap (B,), sr (B,)."""
     _need_gpu(xyz, R, T)

@@ -152,8 +152,8 @@ class GraphDeformLoss_Neural(nn.Module):
         z = torch.cat([pick(verts1), pick(g1p), pick(verts12), pick(g2t)], dim=-1)
         def9 = deformer.deformation_decoder_layer(z)
         iden = torch.tensor([1, 0, 0, 0, 1, 0], dtype=torch.float32, device=def9.device)
-        R = nn_ops.rot6d_torch(def9[..., 3:] + iden)
-        warped, arap = nn_ops.dg_warp_arap_torch(verts1, g1, R, def9[..., :3])
+        R = nn_ops.rot6d(def9[..., 3:] + iden)
+        warped, arap = nn_ops.dg_warp_arap(verts1, g1, R, def9[..., :3])
         cd_warp = self._chamfer_train(warped, verts2)
         cd_self = self._chamfer_train(verts12, verts2)
         map_sum = None

@@ -132,12 +132,19 @@ int dvm_dg_build_f32(const float *xyz, int B, int N, const int32_t *start, int32
 
 /* rotation_6d_to_matrix — models/loss.py:39-45.  d6 [rows,6] -> R [rows,9] (rows b1,b2,b1xb2). */
 int dvm_rot6d_f32(const float *d6, int rows, float *R, void *stream);
+/* Backward of dvm_rot6d_f32: g_R [rows,9] -> g_d6 [rows,6] (Gram-Schmidt differentiated). */
+int dvm_rot6d_bwd_f32(const float *d6, const float *g_R, int rows, float *g_d6, void *stream);
 
 /* DeformationGraph_geod.forward — lib/deformation_graph_point.py:233-261.
  * R [B,Nn,9], T [B,Nn,3] -> warped [B,N,3], arap [B], sr [B] (optional). */
 int dvm_dg_warp_arap_fwd_f32(const float *xyz, int B, int N, const int32_t *nodes_idx, const int32_t *ring,
                              const int32_t *infl_idx, const float *weights, const float *R, const float *T,
                              float *warped, float *arap, float *sr, void *stream);
+/* Backward of dvm_dg_warp_arap_fwd_f32 w.r.t. the node transforms: g_warped [B,N,3], g_arap [B] ->
+ * d_R [B,Nn,9], d_T [B,Nn,3] (overwritten; fp32 atomics).  The vertices carry no gradient (inputs). */
+int dvm_dg_warp_arap_bwd_f32(const float *xyz, int B, int N, const int32_t *nodes_idx, const int32_t *ring,
+                             const int32_t *infl_idx, const float *weights, const float *R, const float *T,
+                             const float *g_warped, const float *g_arap, float *d_R, float *d_T, void *stream);
 
 /* chamfer_3DDist — third-party ChamferDistancePytorch (un-vendored); call sites
  * models/loss.py:1120,1223,874.  a [B,N,3], b [B,M,3] -> d1 [B,N], d2 [B,M] squared NN
@@ -145,6 +152,10 @@ int dvm_dg_warp_arap_fwd_f32(const float *xyz, int B, int N, const int32_t *node
 size_t dvm_chamfer_workspace_bytes(int B, int N, int M);
 int dvm_chamfer_fwd_f32(const float *a, const float *b, int B, int N, int M, float *d1, float *d2, int32_t *i1,
                         int32_t *i2, void *ws, size_t ws_bytes, void *stream);
+/* Backward of dvm_chamfer_fwd_f32 through the arg-min indices held fixed (as the upstream CUDA extension
+ * does): g_d1 [B,N], g_d2 [B,M] -> d_a [B,N,3], d_b [B,M,3] (overwritten; fp32 atomics). */
+int dvm_chamfer_bwd_f32(const float *a, const float *b, const int32_t *idx1, const int32_t *idx2, const float *g_d1,
+                        const float *g_d2, int B, int N, int M, float *d_a, float *d_b, void *stream);
 
 /* Deformer.forward — models/model.py:464-478 (+ MLP 433-452), fed the raw features and
  * kNN indices instead of the (B,N,k,128) gathers of models/loss.py:1254-1255.

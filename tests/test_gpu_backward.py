@@ -130,3 +130,40 @@ def test_dist_loss_bwd_vs_fp64_autograd(ops):
     (ref * gout.double()).sum().backward()
     assert rel(out, ref) < 1e-5
     assert rel(f.grad, f64.grad) < 1e-4, rel(f.grad, f64.grad)
+
+
+def test_rot6d_warp_arap_bwd_vs_fp64_autograd(ops):
+    from dvm import nn_ops
+    B, N = 2, 400
+    g = torch.Generator().manual_seed(77)
+    verts = torch.rand(B, N, 3, generator=g).cuda()
+    graph = ops.dg_build(verts, torch.tensor([3, 11], dtype=torch.int32).cuda())
+    Nn = N // 2
+    d6 = (torch.randn(B, Nn, 6, generator=g) * 0.3 + torch.tensor([1., 0, 0, 0, 1, 0])).cuda().requires_grad_(True)
+    T = (torch.randn(B, Nn, 3, generator=g) * 0.05).cuda().requires_grad_(True)
+    gw = torch.randn(B, N, 3, generator=g).cuda()
+    ga = torch.randn(B, generator=g).cuda()
+    warped, arap = nn_ops.dg_warp_arap(verts, graph, nn_ops.rot6d(d6), T)
+    ((warped * gw).sum() + (arap * ga).sum()).backward()
+    # fp64 reference: the torch formulation of the same math (nn_ops.*_torch) under autograd
+    d64 = d6.detach().double().requires_grad_(True)
+    t64 = T.detach().double().requires_grad_(True)
+    g64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in graph.items() if torch.is_tensor(v)}
+    w_ref, a_ref = nn_ops.dg_warp_arap_torch(verts.double(), g64, nn_ops.rot6d_torch(d64), t64)
+    ((w_ref * gw.double()).sum() + (a_ref * ga.double()).sum()).backward()
+    assert rel(warped, w_ref) < 1e-5 and rel(arap, a_ref) < 1e-5
+    assert rel(d6.grad, d64.grad) < 1e-4 and rel(T.grad, t64.grad) < 1e-4, (rel(d6.grad, d64.grad), rel(T.grad, t64.grad))
+
+
+def test_chamfer_bwd_vs_autograd(ops):
+    from dvm import nn_ops
+    g = torch.Generator().manual_seed(78)
+    a = torch.rand(2, 300, 3, generator=g).cuda().requires_grad_(True)
+    b = torch.rand(2, 170, 3, generator=g).cuda().requires_grad_(True)
+    g1, g2 = torch.randn(2, 300, generator=g).cuda(), torch.randn(2, 170, generator=g).cuda()
+    d1, d2 = nn_ops.chamfer_nn(a, b)
+    ((d1 * g1).sum() + (d2 * g2).sum()).backward()
+    a64, b64 = a.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    D = ((a64[:, :, None] - b64[:, None]) ** 2).sum(-1)
+    ((D.min(2)[0] * g1.double()).sum() + (D.min(1)[0] * g2.double()).sum()).backward()
+    assert rel(a.grad, a64.grad) < 1e-5 and rel(b.grad, b64.grad) < 1e-5
