@@ -344,7 +344,8 @@ __global__ __launch_bounds__(256) void sa_rowstats_kernel(const float *__restric
 }
 
 __global__ __launch_bounds__(256) void sa_apply_kernel(const float *__restrict__ p, const float *__restrict__ v,
-                                                       const float *__restrict__ stats, int N, float *__restrict__ xr) {
+                                                       const float *__restrict__ stats, int N, float *__restrict__ xr,
+                                                       float *__restrict__ cinv_out) {
     __shared__ __attribute__((aligned(16))) float pt[32 * SA_LDP];
     __shared__ __attribute__((aligned(16))) float vt[32 * SA_C];
     __shared__ float st[32 * 2];
@@ -409,6 +410,7 @@ __global__ __launch_bounds__(256) void sa_apply_kernel(const float *__restrict__
     }
     colsum += __shfl_xor(colsum, 32, 64);
     const float inv = 1.0f / (1e-9f + colsum);
+    if (cinv_out && h == 0 && jcol < N) cinv_out[(size_t)b * N + jcol] = inv;
     if (jcol < N) {
         float *o = xr + ((size_t)b * N + jcol) * SA_C;
 #pragma unroll
@@ -678,8 +680,19 @@ DVM_EXPORT int dvm_sa_attention_fwd_f32(const float *p, const float *v, int B, i
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((N + 127) / 128, B);
     hipLaunchKernelGGL(sa_rowstats_kernel, grid, dim3(256), 0, s, p, N, stats);
-    hipLaunchKernelGGL(sa_apply_kernel, grid, dim3(256), 0, s, p, v, stats, N, xr);
+    hipLaunchKernelGGL(sa_apply_kernel, grid, dim3(256), 0, s, p, v, stats, N, xr, (float *)nullptr);
     DVM_CHECK_LAUNCH("sa_attention");
+    return DVM_OK;
+}
+
+DVM_EXPORT int dvm_sa_attention_train_fwd_f32(const float *p, const float *v, int B, int N, float *xr, float *stats, float *cinv,
+                                              void *stream) {
+    DVM_REQUIRE(p && v && xr && stats && cinv && B >= 1 && N >= 1, "dvm_sa_attention_train_fwd_f32: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((N + 127) / 128, B);
+    hipLaunchKernelGGL(sa_rowstats_kernel, grid, dim3(256), 0, s, p, N, stats);
+    hipLaunchKernelGGL(sa_apply_kernel, grid, dim3(256), 0, s, p, v, stats, N, xr, cinv);
+    DVM_CHECK_LAUNCH("sa_attention_train_fwd");
     return DVM_OK;
 }
 

@@ -29,17 +29,32 @@ def _needs_grad(*ts):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
 
 
+class _SACore(torch.autograd.Function):
+    """SA_Layer attention core on point-major projections, forward and backward on the HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, p, v):
+        xr, stats, cinv = ops.sa_attention_train_fwd(p, v)
+        ctx.save_for_backward(p.detach(), v.detach(), xr, stats, cinv)
+        return xr
+
+    @staticmethod
+    def backward(ctx, gxr):
+        p, v, xr, stats, cinv = ctx.saved_tensors
+        return ops.sa_attention_bwd(p, v, xr, stats, cinv, gxr.contiguous())
+
+
 def sa_attention(x, w_qk, w_v, b_v):
-    """SA_Layer's x_r.  Inference: fused HIP kernels (no N x N in HBM).  Training: the same math with
-    torch ops so autograd supplies the backward (interim, see the header comment further down)."""
+    """SA_Layer's x_r (B,64,N).  The 1x1 projections are GEMMs under autograd; the attention core (energy,
+    row softmax, column renormalisation, weighted sum) runs on the fused HIP kernels both ways — no N x N
+    tensor in HBM."""
     if not _needs_grad(x, w_qk, w_v, b_v):
         return ops.sa_attention(x, w_qk, w_v, b_v)
-    ops._need_gpu(x, w_qk, w_v)  # the training path is a device path too: never a CPU fallback
-    p = torch.matmul(w_qk[:, :, 0], x)                       # 1x1 convs as the GEMMs they are
-    v = torch.matmul(w_v[:, :, 0], x) + b_v[:, None]
-    att = torch.softmax(torch.bmm(p.transpose(1, 2), p), dim=-1)
-    att = att / (1e-9 + att.sum(dim=1, keepdim=True))
-    return torch.bmm(v, att)
+    ops._need_gpu(x, w_qk, w_v)
+    xt = x.transpose(1, 2).contiguous()
+    p = torch.nn.functional.linear(xt, w_qk.reshape(w_qk.shape[0], -1))
+    v = torch.nn.functional.linear(xt, w_v.reshape(w_v.shape[0], -1), b_v)
+    return _SACore.apply(p, v).transpose(1, 2)
 
 
 class _N2PCore(torch.autograd.Function):

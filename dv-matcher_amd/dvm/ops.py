@@ -414,6 +414,33 @@ def sa_attention_pm(p, v):
     return xr
 
 
+def sa_attention_train_fwd(p, v):
+    """-> xr (B,N,64), stats (B,N,2), cinv (B,N)."""
+    _need_gpu(p, v)
+    p, v = _f(p), _f(v)
+    B, N, _ = p.shape
+    xr = torch.empty(B, N, 64, dtype=torch.float32, device=p.device)
+    stats = torch.empty(B, N, 2, dtype=torch.float32, device=p.device)
+    cinv = torch.empty(B, N, dtype=torch.float32, device=p.device)
+    check(_lib.load().dvm_sa_attention_train_fwd_f32(_p(p), _p(v), B, N, _p(xr), _p(stats), _p(cinv), _stream()),
+          "dvm_sa_attention_train_fwd_f32")
+    return xr, stats, cinv
+
+
+def sa_attention_bwd(p, v, xr, stats, cinv, gxr):
+    """-> d_p (B,N,16), d_v (B,N,64)."""
+    _need_gpu(p, v, gxr)
+    p, v, gxr = _f(p), _f(v), _f(gxr)
+    B, N, _ = p.shape
+    dp, dv = torch.empty_like(p), torch.empty_like(v)
+    lib = _lib.load()
+    nb = lib.dvm_sa_attention_bwd_workspace_bytes(B, N)
+    ws = workspace(nb, p.device, "sa_bwd")
+    check(lib.dvm_sa_attention_bwd_f32(_p(p), _p(v), _p(xr), _p(stats), _p(cinv), _p(gxr), B, N, _p(dp), _p(dv), _p(ws), nb,
+                                       _stream()), "dvm_sa_attention_bwd_f32")
+    return dp, dv
+
+
 def sa_attention(x, w_qk, w_v, b_v):
     """x (B,64,N) channel-major like the reference; returns x_r (B,64,N)."""
     xt = x.transpose(1, 2).contiguous()

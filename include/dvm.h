@@ -191,6 +191,17 @@ size_t dvm_sa_attention_workspace_bytes(int B, int N);
 int dvm_sa_attention_fwd_f32(const float *p, const float *v, int B, int N, float *xr, void *ws, size_t ws_bytes,
                              void *stream);
 
+/* Training twins of the SA attention core.  train_fwd: as dvm_sa_attention_fwd_f32, also returning what the
+ * backward recomputes from: stats [B,N,2] = (row max m_i, 1/l_i) and cinv [B,N] = 1/(1e-9 + column sum).
+ * bwd: g_xr [B,N,64] -> d_p [B,N,16], d_v [B,N,64] (overwritten).  Nothing N x N is stored: two
+ * tile-recompute passes on the fp32 matrix cores (E is symmetric, so both dE_ij and dE_ji come from one tile). */
+int dvm_sa_attention_train_fwd_f32(const float *p, const float *v, int B, int N, float *xr, float *stats, float *cinv,
+                                   void *stream);
+size_t dvm_sa_attention_bwd_workspace_bytes(int B, int N);
+int dvm_sa_attention_bwd_f32(const float *p, const float *v, const float *xr, const float *stats, const float *cinv,
+                             const float *g_xr, int B, int N, float *d_p, float *d_v, void *ws, size_t ws_bytes,
+                             void *stream);
+
 /* N2PAttention[_DIM] attention core — models/model.py:339-350, 375-386.  q/kp/vp [B,N,C] =
  * Wq x, Wk x, Wv x (point-major; k(x_j - x_i) = kp_j - kp_i by linearity), idx [B,N,K] the
  * feature-space neighbours -> out [B,N,C] = sum_j softmax_j(q.(kp_j-kp_i)/sqrt(D)) (vp_j - vp_i)

@@ -167,3 +167,20 @@ def test_chamfer_bwd_vs_autograd(ops):
     D = ((a64[:, :, None] - b64[:, None]) ** 2).sum(-1)
     ((D.min(2)[0] * g1.double()).sum() + (D.min(1)[0] * g2.double()).sum()).backward()
     assert rel(a.grad, a64.grad) < 1e-5 and rel(b.grad, b64.grad) < 1e-5
+
+
+@pytest.mark.parametrize("B,N", [(2, 300), (1, 128), (1, 1000), (3, 77)])
+def test_sa_core_fwd_bwd_vs_fp64_autograd(ops, B, N):
+    g = torch.Generator().manual_seed(N)
+    p = torch.randn(B, N, 16, generator=g) * 0.7
+    v = torch.randn(B, N, 64, generator=g)
+    gx = torch.randn(B, N, 64, generator=g)
+    xr, stats, cinv = ops.sa_attention_train_fwd(p.cuda(), v.cuda())
+    dp, dv = ops.sa_attention_bwd(p.cuda(), v.cuda(), xr, stats, cinv, gx.cuda())
+    p64, v64 = p.double().requires_grad_(True), v.double().requires_grad_(True)   # models/model.py:113-121, point-major
+    att = torch.softmax(torch.bmm(p64, p64.transpose(1, 2)), dim=-1)
+    att = att / (1e-9 + att.sum(dim=1, keepdim=True))
+    ref = torch.bmm(att.transpose(1, 2), v64)
+    (ref * gx.double()).sum().backward()
+    assert rel(xr, ref) < 1e-5
+    assert rel(dv, v64.grad) < 1e-4 and rel(dp, p64.grad) < 1e-4, (rel(dv, v64.grad), rel(dp, p64.grad))
