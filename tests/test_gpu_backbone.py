@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import torch
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
 from weights_init import reinit  # noqa: E402
 
@@ -303,3 +304,41 @@ def test_training_driver_runs():
     assert res["grad_bucket_floats"] == 2122644  # 1 822 592 backbone + 300 052 Deformer
     assert all(np.isfinite(res["first_losses"])) and all(np.isfinite(res["last_losses"]))
     assert res["first_losses"] != res["last_losses"]
+
+
+def test_inference_driver_writes_reference_outputs(tmp_path, ops):
+    """SURVEY §8a row 18 (test.py:95-133): T_<a>_<b>.txt 1-based '%i', usefeature_<a>.mat {'uphi'}; the maps equal
+    the oracle's exact arg-min on the features the driver saved."""
+    import scipy.io
+    sys.path.insert(0, os.path.join(ROOT, "dv-matcher_amd"))
+    import test_driver
+    out = str(tmp_path / "res")
+    test_driver.main(["--synthetic", "1", "--points", "300", "--out", out])
+    f1 = scipy.io.loadmat(os.path.join(out, "feature", "usefeature_s000a.mat"))["uphi"]
+    f2 = scipy.io.loadmat(os.path.join(out, "feature", "usefeature_s000b.mat"))["uphi"]
+    T12 = np.loadtxt(os.path.join(out, "T", "T_s000a_s000b.txt"), dtype=np.int64)
+    T21 = np.loadtxt(os.path.join(out, "T", "T_s000b_s000a.txt"), dtype=np.int64)
+    assert f1.shape == (300, 128) and T12.shape == (300,) and T12.min() >= 1 and T12.max() <= 300
+    o12, _ = O.argmin_exact(f1.astype(np.float32), f2.astype(np.float32))
+    o21, _ = O.argmin_exact(f2.astype(np.float32), f1.astype(np.float32))
+    assert np.array_equal(T12, o12 + 1) and np.array_equal(T21, o21 + 1)
+
+
+def test_deform_driver_fused_equals_reference_sequence(tmp_path, ops):
+    """deform.py:219-262: the fused C-ABI path and the call-by-call reference sequence (dense Pi, gathered
+    (B,N,k,128) features, per-shape graph objects) write the same deformed cloud."""
+    sys.path.insert(0, os.path.join(ROOT, "dv-matcher_amd"))
+    import deform_driver
+
+    def read_off(p):
+        lines = open(p).read().split("\n")
+        assert lines[0] == "OFF"
+        n = int(lines[1].split()[0])
+        return np.array([[float(x) for x in ln.split()] for ln in lines[2:2 + n]])
+
+    a, b = str(tmp_path / "fused"), str(tmp_path / "seq")
+    deform_driver.main(["--synthetic", "1", "--points", "256", "--out", a])
+    deform_driver.main(["--synthetic", "1", "--points", "256", "--out", b, "--reference-sequence"])
+    pa, pb = read_off(os.path.join(a, "deform_s000a_s000b.off")), read_off(os.path.join(b, "deform_s000a_s000b.off"))
+    assert pa.shape == (256, 3)
+    np.testing.assert_allclose(pa, pb, rtol=0, atol=1e-4)
