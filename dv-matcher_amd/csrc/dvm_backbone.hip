@@ -583,18 +583,14 @@ __global__ void gather_rows_kernel(const float *__restrict__ src, const int32_t 
     dst[((size_t)b * nR + r) * C + c] = src[((size_t)b * N + rows[r]) * C + c];
 }
 
-__global__ void rownorm2_kernel2(const float *__restrict__ x, int rows, int K, float *__restrict__ out) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows) return;
-    out[i] = aten_sumsq_row(x + (size_t)i * K, K);
-}
+void launch_rownorm2(const float *x, int rows, int K, float *out, hipStream_t s);  // dvm_softcorr.hip
 
 int launch_reduce_partials(const double *partial, int B, int nparts, float scale, float *out, int stride, int off, hipStream_t s);
 
 int launch_knn_neg(const float *a, const float *bq, int B, int N, int M, int C, int k, int32_t *idx, float *na, float *nb,
                    float *S, hipStream_t s) {
-    hipLaunchKernelGGL(rownorm2_kernel2, dim3((B * N + 255) / 256), dim3(256), 0, s, a, B * N, C, na);
-    hipLaunchKernelGGL(rownorm2_kernel2, dim3((B * M + 255) / 256), dim3(256), 0, s, bq, B * M, C, nb);
+    launch_rownorm2(a, B * N, C, na, s);
+    launch_rownorm2(bq, B * M, C, nb, s);
     if (C == 128)
         hipLaunchKernelGGL(knn_scores_mfma_kernel<128>, dim3((N + KS_QB - 1) / KS_QB, B), dim3(KS_THREADS), 0, s, a, bq, na, nb, N,
                            M, S);

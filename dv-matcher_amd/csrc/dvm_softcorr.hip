@@ -28,6 +28,29 @@ __global__ void rownorm2_kernel(const float *__restrict__ x, int rows, int K, fl
     out[i] = aten_sumsq_row(x + (size_t)i * K, K);
 }
 
+// K = 128, coalesced: 32 lanes per row.  Same additions in the same order as aten_sumsq_row (K = 128:
+// vec_size 16, size_ilp 4 -> lane l, ILP slot k accumulate x[(4i+k)*8 + l]^2 over i = 0..3, then
+// ((k0 + k1) + k2) + k3, then lanes 0..7 added in order): element 32 i + 8 k + l sits in lane 8 k + l.
+__global__ __launch_bounds__(256) void rownorm2_k128_kernel(const float *__restrict__ x, int rows, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63, l32 = lane & 31, base = lane & 32;
+    const long row0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const long row = row0 < rows ? row0 : rows - 1;
+    const float *p = x + row * 128 + l32;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float v = p[32 * i];
+        s = s + v * v;
+    }
+    const float s1 = __shfl(s, base + ((l32 + 8) & 31), 64), s2 = __shfl(s, base + ((l32 + 16) & 31), 64),
+                s3 = __shfl(s, base + ((l32 + 24) & 31), 64);
+    const float r = ((s + s1) + s2) + s3;  // valid in lanes l32 < 8 (k = 0)
+    float fin = 0.f;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) fin = fin + __shfl(r, base + l, 64);
+    if (l32 == 0 && row0 < rows) out[row0] = fin;
+}
+
 // ------------------------------------------------------- per-row running state
 template <int TOPK>
 struct RowState {
@@ -558,7 +581,10 @@ int launch_softcorr_both(const float *f1, const float *f2, const float *n1, cons
 }
 
 void launch_rownorm2(const float *x, int rows, int K, float *out, hipStream_t s) {
-    hipLaunchKernelGGL(rownorm2_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, x, rows, K, out);
+    if (K == 128)
+        hipLaunchKernelGGL(rownorm2_k128_kernel, dim3((unsigned)(((long)rows * 32 + 255) / 256)), dim3(256), 0, s, x, rows, out);
+    else
+        hipLaunchKernelGGL(rownorm2_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, x, rows, K, out);
 }
 
 }  // namespace dvm
@@ -568,7 +594,7 @@ using namespace dvm;
 DVM_EXPORT int dvm_rownorm2_f32(const float *x, int rows, int K, float *out, void *stream) {
     DVM_REQUIRE(x && out && rows >= 0 && K >= 1, "dvm_rownorm2_f32: bad arguments");
     if (rows == 0) return DVM_OK;
-    hipLaunchKernelGGL(rownorm2_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, rows, K, out);
+    launch_rownorm2(x, rows, K, out, (hipStream_t)stream);
     DVM_CHECK_LAUNCH("rownorm2");
     return DVM_OK;
 }
@@ -596,8 +622,8 @@ DVM_EXPORT int dvm_softcorr_fwd_f32(const float *f1, const float *f2, int B, int
         return DVM_ENOSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(rownorm2_kernel, dim3((B * N + 255) / 256), dim3(256), 0, s, f1, B * N, d, n1);
-    hipLaunchKernelGGL(rownorm2_kernel, dim3((B * M + 255) / 256), dim3(256), 0, s, f2, B * M, d, n2);
+    launch_rownorm2(f1, B * N, d, n1, s);
+    launch_rownorm2(f2, B * M, d, n2, s);
     bool mfma = (variant == 2) || (variant == 0 && d == MF_D);
     prof_begin(s);
     if (mfma) {
