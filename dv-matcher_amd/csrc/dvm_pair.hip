@@ -156,6 +156,9 @@ namespace dvm {
 int launch_softcorr_both(const float *f1, const float *f2, const float *n1, const float *n2, int B, int N, int M,
                          float neg_alpha, float *val12, int32_t *idx12, float *val21, int32_t *idx21, hipStream_t s);
 void launch_rownorm2(const float *x, int rows, int K, float *out, hipStream_t s);
+size_t softcorr_pair_ws_bytes(int B, int N, int M);
+int launch_softcorr_pair(const float *f1, const float *f2, float *n1, float *n2, int B, int N, int M, float neg_alpha, float *val12,
+                         int32_t *idx12, float *val21, int32_t *idx21, void *ws, size_t ws_bytes, hipStream_t s);
 void launch_pool_all(const float *feat, const int32_t *idx, int B, int P, int k, const float *cw, const float *cb, float *out,
                      hipStream_t s);
 void launch_assemble_pooled(const float *vsrc, const float *vcorr, const float *gsrc, const float *gtgt, const float *pi_val,
@@ -173,6 +176,8 @@ struct Pair2Ws {
     float *dists[2], *weights[2], *pval[2], *nrm[2], *gall[2];
     double *nnd[2], *partial[2];
     float *z, *def9, *R, *T, *wp;
+    char *k1ws;  // soft-correspondence scratch (fp16 planes, candidates, flags)
+    size_t k1ws_bytes;
     float *cd[8];
     GridBuf gv[2], gn[2], gw[2], gc[2];  // vertices, nodes, warped clouds, Pi-mapped clouds
     GridBuf gvcat, gncat;                // 2B-shape grids when N == M
@@ -201,6 +206,8 @@ static size_t carve_pair2(Arena &ar, int B, int N, int M, Pair2Ws &w) {
     w.R = ar.take<float>(rows * 9);
     w.T = ar.take<float>(rows * 3);
     w.wp = ar.take<float>(mlp_pack_floats());
+    w.k1ws_bytes = softcorr_pair_ws_bytes(B, N, M);
+    w.k1ws = ar.take<char>(w.k1ws_bytes);
     const int cdn[8] = {N, M, N, M, M, N, M, N};
     for (int q = 0; q < 8; ++q) w.cd[q] = ar.take<float>((size_t)B * cdn[q]);
     if (N == M) {
@@ -278,9 +285,9 @@ DVM_EXPORT int dvm_pair_fwd_f32(const float *feat1, const float *feat2, const fl
         }
     }
     // ---- soft correspondence, both directions in one launch
-    launch_rownorm2(feat1, B * N, 128, w.nrm[0], s);
-    launch_rownorm2(feat2, B * M, 128, w.nrm[1], s);
-    launch_softcorr_both(feat1, feat2, w.nrm[0], w.nrm[1], B, N, M, neg_alpha, w.pval[0], w.pidx[0], w.pval[1], w.pidx[1], s);
+    rc = launch_softcorr_pair(feat1, feat2, w.nrm[0], w.nrm[1], B, N, M, neg_alpha, w.pval[0], w.pidx[0], w.pval[1], w.pidx[1], w.k1ws,
+                              w.k1ws_bytes, s);
+    if (rc != DVM_OK) return rc;
     hipLaunchKernelGGL(take_col0_kernel, dim3((B * N + 255) / 256), dim3(256), 0, s, w.pidx[0], B * N, 10, T12);
     hipLaunchKernelGGL(take_col0_kernel, dim3((B * M + 255) / 256), dim3(256), 0, s, w.pidx[1], B * M, 10, T21);
     rc = dvm_softcorr_apply_f32(w.pval[0], w.pidx[0], verts2, B, N, M, 10, 3, verts12, s);

@@ -11,6 +11,8 @@
 // (4 waves x 32) and sweeps all M keys through a double-buffered, k-deinterleaved LDS tile;
 // the accumulator tile is [key][query] so that a query's candidates sit in one lane's
 // registers (top-k insertion and online softmax need no cross-lane traffic until the end).
+#include <stdlib.h>
+
 #include "dvm_common.h"
 
 namespace dvm {
@@ -31,16 +33,25 @@ __global__ void rownorm2_kernel(const float *__restrict__ x, int rows, int K, fl
 // K = 128, coalesced: 32 lanes per row.  Same additions in the same order as aten_sumsq_row (K = 128:
 // vec_size 16, size_ilp 4 -> lane l, ILP slot k accumulate x[(4i+k)*8 + l]^2 over i = 0..3, then
 // ((k0 + k1) + k2) + k3, then lanes 0..7 added in order): element 32 i + 8 k + l sits in lane 8 k + l.
-__global__ __launch_bounds__(256) void rownorm2_k128_kernel(const float *__restrict__ x, int rows, float *__restrict__ out) {
+__global__ __launch_bounds__(256) void rownorm2_k128_kernel(const float *__restrict__ x, int rows, float *__restrict__ out,
+                                                            int *__restrict__ absmax) {
     const int lane = threadIdx.x & 63, l32 = lane & 31, base = lane & 32;
     const long row0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
     const long row = row0 < rows ? row0 : rows - 1;
     const float *p = x + row * 128 + l32;
-    float s = 0.f;
+    float s = 0.f, am = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float v = p[32 * i];
         s = s + v * v;
+        am = fmaxf(am, fabsf(v));
+    }
+    if (absmax) {  // optional: bit pattern of max |x| of the tensor (the fp16 split's scale, dvm_softcorr_bf16.hip)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
+        // 256 slots (one address would serialise 262k waves); only waves that would raise a slot's maximum touch it
+        int *slot = absmax + (blockIdx.x & 255);
+        if (lane == 0 && __float_as_int(am) > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, __float_as_int(am));
     }
     const float s1 = __shfl(s, base + ((l32 + 8) & 31), 64), s2 = __shfl(s, base + ((l32 + 16) & 31), 64),
                 s3 = __shfl(s, base + ((l32 + 24) & 31), 64);
@@ -580,9 +591,64 @@ int launch_softcorr_both(const float *f1, const float *f2, const float *n1, cons
     return DVM_OK;
 }
 
+// dvm_softcorr_bf16.hip
+size_t softcorr_bf16_ws_bytes(int B, int N, int M, bool both);
+int launch_softcorr_bf16(const float *f1, const float *f2, const float *n1, const float *n2, int B, int N, int M, float neg_alpha,
+                         int topk, float *val12, int32_t *idx12, float *smax12, float *sum12, float *val21, int32_t *idx21,
+                         float *smax21, float *sum21, const int *amax, void *ws, size_t ws_bytes, hipStream_t s);
+
+// K == 128 only: also maxes the bit pattern of max |x| into the 256 slots of `absmax_slots` (zero them first);
+// launch_absmax_finalize folds nt x 256 slots into nt values
+void launch_rownorm2_absmax(const float *x, int rows, float *out, int *absmax_slots, hipStream_t s) {
+    hipLaunchKernelGGL(rownorm2_k128_kernel, dim3((unsigned)(((long)rows * 32 + 255) / 256)), dim3(256), 0, s, x, rows, out,
+                       absmax_slots);
+}
+__global__ void absmax_finalize_kernel(const int *__restrict__ slots, int *__restrict__ out) {
+    int v = 0;
+    for (int i = threadIdx.x; i < 256; i += 64) v = max(v, slots[blockIdx.x * 256 + i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    if (threadIdx.x == 0) out[blockIdx.x] = v;
+}
+void launch_absmax_finalize(const int *slots, int nt, int *out, hipStream_t s) {
+    hipLaunchKernelGGL(absmax_finalize_kernel, dim3(nt), dim3(64), 0, s, slots, out);
+}
+
+void launch_rownorm2(const float *x, int rows, int K, float *out, hipStream_t s);
+
+// norms of both sides + soft correspondence in both directions for the fused pair path (d = 128, top-10)
+size_t softcorr_pair_ws_bytes(int B, int N, int M) { return align_up(514 * sizeof(int)) + softcorr_bf16_ws_bytes(B, N, M, true); }
+int launch_softcorr_pair(const float *f1, const float *f2, float *n1, float *n2, int B, int N, int M, float neg_alpha, float *val12,
+                         int32_t *idx12, float *val21, int32_t *idx21, void *ws, size_t ws_bytes, hipStream_t s) {
+    static const int forced = [] {
+        const char *e = getenv("DVM_SOFTCORR_VARIANT");
+        return e ? atoi(e) : 3;
+    }();
+    if (forced == 2) {
+        launch_rownorm2(f1, B * N, 128, n1, s);
+        launch_rownorm2(f2, B * M, 128, n2, s);
+        return launch_softcorr_both(f1, f2, n1, n2, B, N, M, neg_alpha, val12, idx12, val21, idx21, s);
+    }
+    Arena ar(ws, ws_bytes);
+    int *slots = ar.take<int>(2 * 256 + 2);
+    int *amax = slots + 512;
+    char *bws = ar.take<char>(0);
+    if (!ar.ok()) {
+        set_error("softcorr (pair): workspace too small (%zu < %zu)", ws_bytes, ar.off);
+        return DVM_ENOSPACE;
+    }
+    (void)hipMemsetAsync(slots, 0, 512 * sizeof(int), s);
+    launch_rownorm2_absmax(f1, B * N, n1, slots, s);
+    launch_rownorm2_absmax(f2, B * M, n2, slots + 256, s);
+    launch_absmax_finalize(slots, 2, amax, s);
+    return launch_softcorr_bf16(f1, f2, n1, n2, B, N, M, neg_alpha, 10, val12, idx12, nullptr, nullptr, val21, idx21, nullptr, nullptr,
+                                amax, bws, ws_bytes - ar.off, s);
+}
+
 void launch_rownorm2(const float *x, int rows, int K, float *out, hipStream_t s) {
     if (K == 128)
-        hipLaunchKernelGGL(rownorm2_k128_kernel, dim3((unsigned)(((long)rows * 32 + 255) / 256)), dim3(256), 0, s, x, rows, out);
+        hipLaunchKernelGGL(rownorm2_k128_kernel, dim3((unsigned)(((long)rows * 32 + 255) / 256)), dim3(256), 0, s, x, rows, out,
+                           (int *)nullptr);
     else
         hipLaunchKernelGGL(rownorm2_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, x, rows, K, out);
 }
@@ -600,8 +666,8 @@ DVM_EXPORT int dvm_rownorm2_f32(const float *x, int rows, int K, float *out, voi
 }
 
 DVM_EXPORT size_t dvm_softcorr_workspace_bytes(int B, int N, int M, int d) {
-    (void)d;
-    return align_up((size_t)B * N * sizeof(float)) + align_up((size_t)B * M * sizeof(float));
+    return align_up((size_t)B * N * sizeof(float)) + align_up((size_t)B * M * sizeof(float)) +
+           (d == MF_D ? align_up(514 * sizeof(int)) + softcorr_bf16_ws_bytes(B, N, M, false) : 0);
 }
 
 DVM_EXPORT int dvm_softcorr_fwd_f32(const float *f1, const float *f2, int B, int N, int M, int d, float neg_alpha,
@@ -612,8 +678,9 @@ DVM_EXPORT int dvm_softcorr_fwd_f32(const float *f1, const float *f2, int B, int
     DVM_REQUIRE(d >= 4 && d % 4 == 0 && d <= 512, "dvm_softcorr_fwd_f32: d=%d unsupported (need d%%4==0, 4<=d<=512)", d);
     DVM_REQUIRE(topk >= 1 && topk <= 16, "dvm_softcorr_fwd_f32: topk=%d unsupported (1..16)", topk);
     DVM_REQUIRE(neg_alpha < 0.f, "dvm_softcorr_fwd_f32: neg_alpha must be negative (got %g)", (double)neg_alpha);
-    DVM_REQUIRE(variant >= 0 && variant <= 2, "dvm_softcorr_fwd_f32: bad variant %d", variant);
-    DVM_REQUIRE(variant != 2 || d == MF_D, "dvm_softcorr_fwd_f32: MFMA variant needs d == 128");
+    DVM_REQUIRE(variant >= 0 && variant <= 3, "dvm_softcorr_fwd_f32: bad variant %d", variant);
+    DVM_REQUIRE(variant < 2 || d == MF_D, "dvm_softcorr_fwd_f32: the matrix-core variants need d == 128");
+    DVM_REQUIRE(variant != 3 || topk <= 10, "dvm_softcorr_fwd_f32: the bf16 variant keeps 12 candidates (topk <= 10)");
     Arena ar(ws, ws_bytes);
     float *n1 = ar.take<float>((size_t)B * N);
     float *n2 = ar.take<float>((size_t)B * M);
@@ -622,6 +689,31 @@ DVM_EXPORT int dvm_softcorr_fwd_f32(const float *f1, const float *f2, int B, int
         return DVM_ENOSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
+    if (variant == 0 && d == MF_D && topk <= 10) {  // auto: the fp16-split sweep unless DVM_SOFTCORR_VARIANT (debug, A/B) says otherwise
+        static const int forced = [] {
+            const char *e = getenv("DVM_SOFTCORR_VARIANT");
+            return e ? atoi(e) : 3;
+        }();
+        variant = forced >= 1 && forced <= 3 ? forced : 3;
+    }
+    if (variant == 3) {
+        int *slots = ar.take<int>(2 * 256 + 2);
+        int *amax = slots + 512;
+        char *bws = ar.take<char>(0);
+        if (!ar.ok()) {
+            set_error("dvm_softcorr_fwd_f32: workspace too small (%zu < %zu)", ws_bytes, ar.off);
+            return DVM_ENOSPACE;
+        }
+        (void)hipMemsetAsync(slots, 0, 512 * sizeof(int), s);
+        launch_rownorm2_absmax(f1, B * N, n1, slots, s);
+        launch_rownorm2_absmax(f2, B * M, n2, slots + 256, s);
+        launch_absmax_finalize(slots, 2, amax, s);
+        int rc = launch_softcorr_bf16(f1, f2, n1, n2, B, N, M, neg_alpha, topk, pi_val, pi_idx, row_smax, row_sum, nullptr, nullptr,
+                                      nullptr, nullptr, amax, bws, ws_bytes - ar.off, s);
+        if (rc != DVM_OK) return rc;
+        DVM_CHECK_LAUNCH("softcorr (bf16)");
+        return DVM_OK;
+    }
     launch_rownorm2(f1, B * N, d, n1, s);
     launch_rownorm2(f2, B * M, d, n2, s);
     bool mfma = (variant == 2) || (variant == 0 && d == MF_D);

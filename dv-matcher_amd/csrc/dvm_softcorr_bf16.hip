@@ -1,0 +1,691 @@
+// dvm_softcorr_bf16.hip — the soft-correspondence kernel (K1) on the 16-bit matrix cores, exact results.
+//
+// gfx950's fp32 MFMA runs at the vector rate on the vector ALUs; the 16-bit MFMA is a separate
+// pipe and 16x faster.  The N x M distance sweep is done on an exact 2-way fp16 split of the (power-of-two
+// scaled) features, x s = h + m + r with |r| <= 2^-22 |x s|: the three partial products hh + hm + mh with fp32
+// accumulation reproduce the dot product to 2^-22 relative per term — the accuracy class of the fp32 chain —
+// at 3/16 of its matrix time, with the LDS traffic and register footprint of the fp32 kernel ("pass A").
+// (A 3-way bf16 split needs six products and, worse, 96 VGPRs of query fragments and 1.5x the LDS reads.)
+// Pass A keeps, per row, the 12 best columns by approximate squared distance and the softmax sum over all
+// OTHER columns.  "Pass B" re-evaluates those 12 with the reference's own arithmetic (the k-ordered fp32 fma
+// chain, correctly rounded sqrt: bit-identical to the fp32-MFMA kernel and the oracle), ranks them by
+// (distance, column), adds their exact softmax terms and writes the top-10.  A row is certified when its
+// exact 10th distance lies below the approximate 12th by more than the error bound of pass A; the few rows
+// that are not (ties, duplicates, near-degenerate clouds) are recomputed exactly by a third kernel.
+// Integer outputs (top-k columns, arg-max map) are thus bit-exact by construction, not by luck.
+// (reference: models/loss.py:110-114, 1339-1347, 1404-1407)
+#include <stdlib.h>
+
+#include "dvm_common.h"
+
+namespace dvm {
+
+void launch_rownorm2(const float *x, int rows, int K, float *out, hipStream_t s);
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr int HB_D = 128;
+constexpr int HB_ROWB = 2 * HB_D * 2;   // 512 B per row: planes h | m, 128 fp16 each
+constexpr int HB_KT = 64;               // keys per LDS tile (two 32-key sub-tiles)
+constexpr int HB_WAVES = 8, HB_QB = 32 * HB_WAVES, HB_THREADS = 64 * HB_WAVES;
+constexpr int HB_GLDS_PER_WAVE = HB_KT * HB_ROWB / 1024 / HB_WAVES;  // 4 LDS-DMA pieces (1 KiB = 2 rows) per wave per tile
+constexpr int HB_STAGE = 16 * 64;       // floats per wave
+constexpr int HB_KC = 12;               // candidates kept per row (top-10 + 2 of margin)
+constexpr size_t HB_LDS_BYTES = (size_t)2 * HB_KT * HB_ROWB + 2 * HB_KT * sizeof(float) + (size_t)HB_WAVES * HB_STAGE * sizeof(float);
+constexpr float HB_ERR = 2e-5f;  // |d2_passA - d2_chain| <= HB_ERR (|q|^2 + |k|^2): gamma_128 of both fp32 accumulations
+                                 // (2 x 7.7e-6) + the dropped split terms (1.4e-6), see DESIGN.md
+
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+    int q = nwg / 8, r = nwg % 8, xcd = orig % 8;
+    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + orig / 8;
+}
+
+// ---------------------------------------------------------------- scale + split: fp32 rows -> fp16 planes
+// largest |x| of a tensor as its bit pattern (non-negative floats order like integers)
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, long n4, int *__restrict__ out) {
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = *(const f32x4 *)(x + 4 * i);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && __float_as_int(m) > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, __float_as_int(m));
+}
+
+// power of two s with max|x| * s in [2^14, 2^15): well inside fp16's range, and the m-plane of every element
+// within 2^-11 of the largest stays a normal fp16 number
+__device__ __forceinline__ int scale_exp(int maxbits) {  // log2(s)
+    const int e = ((maxbits >> 23) & 0xff) - 127;
+    int k = 14 - e;
+    k = k > 100 ? 100 : (k < -100 ? -100 : k);
+    return maxbits == 0 ? 0 : k;
+}
+__device__ __forceinline__ float pow2i(int k) { return __int_as_float((127 + k) << 23); }
+
+// Sorted candidate list with (key, column) packed into one double: high word = the float key's bits, low word =
+// the column.  Doubles with the same sign order like their bit patterns, so a compare-swap of two entries is
+// v_min_f64 + v_max_f64 (instead of a compare and four selects) and ties break on the column for free.
+// Keys are squared distances: >= 0 up to rounding (a slightly negative key only reverses its own tie order).
+// (plain v_min_f64 / v_max_f64: the C fmin/fmax add a canonicalising v_max_f64 x, x per operand; no NaNs here)
+__device__ __forceinline__ double min64(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double max64(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+template <int K>
+struct PackedBest {
+    double e[K];
+    static __device__ __forceinline__ double pack(float key, int col) { return __hiloint2double(__float_as_int(key), col); }
+    static __device__ __forceinline__ float key_of(double x) { return __int_as_float(__double2hiint(x)); }
+    static __device__ __forceinline__ int col_of(double x) { return __double2loint(x); }
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int t = 0; t < K; ++t) e[t] = pack(INFINITY, 0x7fffffff);
+    }
+    __device__ __forceinline__ float key(int t) const { return key_of(e[t]); }
+    // returns the entry that is outside the list afterwards (the evicted worst, or x itself)
+    __device__ __forceinline__ double insert(double x) {
+        const double out = max64(e[K - 1], x);
+        e[K - 1] = min64(e[K - 1], x);
+#pragma unroll
+        for (int p = K - 1; p > 0; --p) {
+            const double lo = min64(e[p - 1], e[p]), hi = max64(e[p - 1], e[p]);
+            e[p - 1] = lo;
+            e[p] = hi;
+        }
+        return out;
+    }
+};
+
+__global__ __launch_bounds__(256) void split_planes_kernel(const float *__restrict__ x, long rows, const int *__restrict__ maxbits,
+                                                           char *__restrict__ planes) {
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 per thread
+    if (g >= rows * (HB_D / 4)) return;
+    const float sc = pow2i(scale_exp(*maxbits));
+    const long row = g / (HB_D / 4);
+    const int c = (int)(g % (HB_D / 4));
+    const f32x4 v = *(const f32x4 *)(x + row * HB_D + 4 * c);
+    f16x4 h, m;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float xv = v[e] * sc;            // exact
+        const _Float16 hh = (_Float16)xv;      // round to nearest even
+        h[e] = hh, m[e] = (_Float16)(xv - (float)hh);
+    }
+    char *p = planes + row * HB_ROWB + 8 * c;
+    *(f16x4 *)(p) = h;
+    *(f16x4 *)(p + 256) = m;
+}
+
+// norms padded to whole key tiles with +inf: out [B][Mpad]
+__global__ void pad_norms_kernel(const float *__restrict__ nrm, int M, int Mpad, float *__restrict__ out) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < Mpad) out[(size_t)b * Mpad + i] = i < M ? nrm[(size_t)b * M + i] : INFINITY;
+}
+
+// max of the row norms of every batch element (positive floats order like their bit patterns)
+__global__ void norm_max_kernel(const float *__restrict__ nrm, int rows_per_batch, float *__restrict__ out) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float v = i < rows_per_batch ? nrm[(size_t)b * rows_per_batch + i] : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax((int *)out + b, __float_as_int(v));
+}
+
+// ---------------------------------------------------------------- pass A
+struct HBGroup {
+    const char *qp, *kp;     // planes of the query / key side [B][rows][512]
+    const int *qmax, *kmax;  // bit patterns of max|x| of either side (the split's scale)
+    const float *nq, *nk;    // |.|^2 (ATen order); nk padded to whole tiles with +inf: [B][Mpad]
+    int N, M, Mpad, tiles;
+    int32_t *cidx;           // [B][N][HB_KC]
+    float *cd2;              // [B][N][HB_KC] approximate squared distances, ascending
+    float *lsum;             // [B][N][2] = (sum exp(s - cref), cref)
+};
+struct HBArgs {
+    HBGroup g[2];
+    int blocks0;
+    float neg_alpha, cutw;
+};
+
+template <bool LEAN>
+__global__ __launch_bounds__(HB_THREADS, 2) void softcorr_bf16_kernel(const HBArgs args) {
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+    char *const ktile0 = smem_b;                                             // [2][HB_KT][512], 16-B chunks XOR-swizzled
+    float *const knorm0 = (float *)(smem_b + (size_t)2 * HB_KT * HB_ROWB);   // [2][HB_KT]
+    float *const stage = knorm0 + 2 * HB_KT + (threadIdx.x >> 6) * HB_STAGE + (threadIdx.x & 63);
+
+    int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int grp = lid >= args.blocks0 ? 1 : 0;
+    lid -= grp ? args.blocks0 : 0;
+    const HBGroup &G = args.g[grp];
+    const int N = G.N, M = G.M;
+    const int b = lid / G.tiles, qt = lid % G.tiles;
+    const float neg_alpha = args.neg_alpha;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r32 = lane & 31, h = lane >> 5;
+
+    const char *kbase = G.kp + (size_t)b * M * HB_ROWB;
+    const float *knb = G.nk + (size_t)b * G.Mpad;
+    const int qrow = qt * HB_QB + wave * 32 + r32;
+    const int qrc = qrow < N ? qrow : N - 1;
+    const char *qptr = G.qp + ((size_t)b * N + qrc) * HB_ROWB + 16 * h;
+    f16x8 qh[8], qm[8];  // B-operand fragments: k = 16 s + 8 h + j
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        qh[s] = *(const f16x8 *)(qptr + 32 * s);
+        qm[s] = *(const f16x8 *)(qptr + 256 + 32 * s);
+    }
+    const float na = G.nq[(size_t)b * N + qrc];
+    const float cfac = -2.f * pow2i(-(scale_exp(*G.qmax) + scale_exp(*G.kmax)));  // -2 / (s_q s_k), exact
+
+    PackedBest<HB_KC> kb;  // keyed on the approximate squared distance
+    kb.init();
+    float cref = -INFINITY, l = 0.f;
+    float lim2 = INFINITY;
+    const float a2 = neg_alpha * LOG2E, cutw = args.cutw;
+
+    const int ntiles = (M + HB_KT - 1) / HB_KT;
+    // Key tiles go global -> LDS by LDS-DMA (no VGPRs, in flight for a whole iteration).  The DMA writes
+    // lane-linearly (base + lane * 16), so rows are unpadded and the bank spread comes from an XOR swizzle of the
+    // 16-B chunk index with the row number, applied to the per-lane SOURCE address here and to the reads below.
+    auto stage_tile = [&](int t, int buf) {
+        const int j0 = t * HB_KT;
+        char *kt = ktile0 + (size_t)buf * HB_KT * HB_ROWB;
+#pragma unroll
+        for (int e = 0; e < HB_GLDS_PER_WAVE; ++e) {
+            const int piece = wave * HB_GLDS_PER_WAVE + e;       // 2 rows
+            const int r = 2 * piece + h;                          // lanes 0-31: first row, 32-63: second
+            const int jr = j0 + r < M ? j0 + r : M - 1;           // padding keys re-read the last row (their norm is +inf)
+            const char *src = kbase + (size_t)jr * HB_ROWB + ((r32 ^ (r & 31)) << 4);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(kt + piece * 1024), 16, 0, 0);
+        }
+        if (wave == 0)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(knb + j0 + lane),
+                                             (__attribute__((address_space(3))) void *)(knorm0 + buf * HB_KT), 4, 0, 0);
+    };
+
+    auto add_term = [&](float d2v) {  // l += exp(s - cref) for squared distance d2v (+inf: nothing)
+        const bool live = d2v < INFINITY;
+        const float s = __builtin_amdgcn_sqrtf(fmaxf(d2v, 0.f)) * neg_alpha;
+        const float cnew = live ? fmaxf(cref, s) : cref;
+        const float sc = (cnew == cref) ? 1.f : __builtin_amdgcn_exp2f((cref - cnew) * LOG2E);
+        const float term = live ? __builtin_amdgcn_exp2f((s - cnew) * LOG2E) : 0.f;
+        l = l * sc + term;
+        cref = cnew;
+    };
+
+    auto subtile = [&](const char *kt, int sub, int buf, int jbase) {
+        const char *arow = kt + (sub * 32 + r32) * HB_ROWB;
+        const int t16 = (h ^ r32) << 4;  // chunk 2s + h of plane p sits at ((2s + 16p) ^ h ^ row) * 16
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // all 16 A fragments of the sub-tile are requested up front (64 VGPRs, free during this phase)
+        f16x8 ah[8], am[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            ah[s] = *(const f16x8 *)(arow + ((32 * s) ^ t16));
+            am[s] = *(const f16x8 *)(arow + ((32 * s) ^ t16 ^ 256));
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {  // (one accumulation chain of this instruction needs no interleaving)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(am[s], qh[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], qm[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], qh[s], acc, 0, 0, 0);
+        }
+        // this lane's 16 keys: local key = (r&3) + 8*(r>>2) + 4*h
+        const float *kn = knorm0 + buf * HB_KT + sub * 32 + 4 * h;
+        unsigned mask = 0;
+        if (LEAN) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 nb = *(const f32x4 *)(kn + 8 * g4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g4 + e;
+                    const float v = fmaf(cfac, acc[r], na) + nb[e];
+                    stage[r * 64] = v;
+                    mask |= (v <= lim2) ? (1u << r) : 0u;
+                }
+            }
+        } else {
+            float df[16], tminf = INFINITY;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 nb = *(const f32x4 *)(kn + 8 * g4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g4 + e;
+                    const float v = fmaf(cfac, acc[r], na) + nb[e];
+                    stage[r * 64] = v;
+                    const bool fl = v <= lim2;
+                    mask |= fl ? (1u << r) : 0u;
+                    const float f = __builtin_amdgcn_sqrtf(fmaxf(v, 0.f));  // +inf for padding keys
+                    df[r] = fl ? INFINITY : f;  // flagged ones are accounted for when they leave the list (below)
+                    tminf = fminf(tminf, f);
+                }
+            }
+            const float cnew = tminf * neg_alpha;
+            if (cnew > cref) {
+                l = l * exp2f((cref - cnew) * LOG2E);
+                cref = cnew;
+            }
+            const float c2 = cref * LOG2E;
+            float lsum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lsum += __builtin_amdgcn_exp2f(fmaf(df[r], a2, -c2));
+            l += lsum;
+        }
+        // The softmax sum l covers every column EXCEPT the current members of the list: a column's term is added
+        // when it leaves the list (or fails to enter it), so pass B can add the exact terms of the final
+        // candidates without subtracting approximations of them.
+        // (a counted loop with a wave-uniform trip count: the `while (__any(mask))` form makes the compiler copy the
+        // whole list — 50 v_mov — around a structurised exit on every iteration)
+        int iters = __popc(mask);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) iters = max(iters, __shfl_xor(iters, o, 64));
+        iters = __builtin_amdgcn_readfirstlane(iters);
+        for (int it = 0; it < iters; ++it) {
+            const bool act = mask != 0;
+            const int bpos = act ? (__ffs(mask) - 1) : 0;
+            mask &= mask - 1;
+            float v2 = stage[bpos * 64];
+            v2 = act ? v2 : INFINITY;
+            const double out = kb.insert(PackedBest<HB_KC>::pack(v2, jbase + (bpos & 3) + 8 * (bpos >> 2)));
+            add_term(PackedBest<HB_KC>::key_of(out));  // what is outside the list after this step
+        }
+        // bound for the next sub-tile: the row's KC-th best is at most min(a_K, b_K, max(a_m, b_m)), m = KC/2
+        {
+            const float wk = kb.key(HB_KC - 1), wm = kb.key(HB_KC / 2 - 1), w0 = kb.key(0);
+            const float pk = __shfl_xor(wk, 32, 64), pm = __shfl_xor(wm, 32, 64);
+            const float thr2 = fminf(fminf(wk, pk), fmaxf(wm, pm));
+            if (LEAN) {
+                const float dmin = __builtin_amdgcn_sqrtf(fmaxf(fminf(w0, __shfl_xor(w0, 32, 64)), 0.f));
+                const float cut = dmin + cutw;  // beyond this the softmax term is < e^-20 of the largest
+                lim2 = fmaxf(thr2, (cut * cut) * 1.000001f);
+            } else {
+                lim2 = thr2;
+            }
+        }
+    };
+
+    stage_tile(0, 0);
+    __syncthreads();  // (drains the DMA: vmcnt(0))
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        const char *kt = ktile0 + (size_t)buf * HB_KT * HB_ROWB;
+        if (t + 1 < ntiles) stage_tile(t + 1, buf ^ 1);  // the other buffer was last read before the previous barrier
+        subtile(kt, 0, buf, t * HB_KT + 4 * h);
+        subtile(kt, 1, buf, t * HB_KT + 32 + 4 * h);
+        __syncthreads();
+    }
+
+    // merge the two half-lanes that share a query (lane, lane^32)
+    {
+        const float co = __shfl_xor(cref, 32, 64), lo = __shfl_xor(l, 32, 64);
+        const float cm = fmaxf(cref, co);
+        const float a = (cref == -INFINITY) ? 0.f : l * exp2f((cref - cm) * LOG2E);
+        const float bb = (co == -INFINITY) ? 0.f : lo * exp2f((co - cm) * LOG2E);
+        l = a + bb;
+        cref = cm;
+        double other[HB_KC];
+#pragma unroll
+        for (int t = 0; t < HB_KC; ++t)
+            other[t] = __hiloint2double(__shfl_xor(__double2hiint(kb.e[t]), 32, 64), __shfl_xor(__double2loint(kb.e[t]), 32, 64));
+#pragma unroll
+        for (int t = 0; t < HB_KC; ++t) add_term(PackedBest<HB_KC>::key_of(kb.insert(other[t])));  // dropped from the union
+    }
+    if (h == 0 && qrow < N) {
+        const size_t row = (size_t)b * N + qrow;
+#pragma unroll
+        for (int t = 0; t < HB_KC; ++t) {
+            G.cidx[row * HB_KC + t] = PackedBest<HB_KC>::col_of(kb.e[t]);
+            G.cd2[row * HB_KC + t] = kb.key(t);
+        }
+        G.lsum[row * 2] = l;
+        G.lsum[row * 2 + 1] = cref;
+    }
+}
+
+// the reference's squared distance: k-ordered fp32 fma chain of (-2 q) . k, then + |q|^2, + |k|^2
+__device__ __forceinline__ float exact_d2(const float *__restrict__ q, const float *__restrict__ k, float na, float nb) {
+    float acc = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < HB_D; c += 4) {
+        const f32x4 qv = *(const f32x4 *)(q + c), kv = *(const f32x4 *)(k + c);
+        acc = fmaf(-2.f * qv.x, kv.x, acc);
+        acc = fmaf(-2.f * qv.y, kv.y, acc);
+        acc = fmaf(-2.f * qv.z, kv.z, acc);
+        acc = fmaf(-2.f * qv.w, kv.w, acc);
+    }
+    const float d2 = (acc + na) + nb;
+    return d2 > 0.f ? d2 : 0.f;
+}
+
+// ---------------------------------------------------------------- pass B: exact re-evaluation of the candidates
+struct HRGroup {
+    const float *q, *k, *nq, *nk;  // fp32 rows and norms
+    const float *nkmax;            // [B] max |k|^2 of the batch element
+    int N, M;
+    const int32_t *cidx;
+    const float *cd2, *lsum;
+    float *val;
+    int32_t *idx;
+    float *smax, *sum;
+    int32_t *flagged;              // rows (b*N + i) that need the exact full recompute; flagged[-1..] see below
+    int32_t *nflagged;
+};
+struct HRArgs {
+    HRGroup g[2];
+    long rows0;       // B * g[0].N
+    long rows_total;
+    float neg_alpha;
+    int topk;
+};
+
+__global__ __launch_bounds__(256) void softcorr_refine_kernel(const HRArgs args) {
+    const int lane = threadIdx.x & 63, l16 = lane & 15, base = lane & 48;
+    long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const bool rvalid = row < args.rows_total;
+    if (!rvalid) row = args.rows_total - 1;
+    const int grp = row >= args.rows0 ? 1 : 0;
+    row -= grp ? args.rows0 : 0;
+    const HRGroup &G = args.g[grp];
+    const int N = G.N, M = G.M;
+    const int b = (int)(row / N);
+    const float neg_alpha = args.neg_alpha;
+    const bool cand = l16 < HB_KC;
+    const int j = cand ? G.cidx[row * HB_KC + l16] : 0x7fffffff;
+    const bool valid = cand && j >= 0 && j < M;
+    const float na = G.nq[row];
+    // (bandwidth-bound on the 12 x 512 B gathered rows per query — 3.2 GB per 256 pairs; staging them through LDS
+    // as whole 128-B segments was measured slower than each lane streaming its own row)
+    float v = INFINITY, va = INFINITY;
+    if (valid) {
+        v = exact_d2(G.q + (size_t)row * HB_D, G.k + ((size_t)b * M + j) * HB_D, na, G.nk[(size_t)b * M + j]);
+        va = G.cd2[row * HB_KC + l16];
+    }
+    const float de = valid ? sqrt_rn(v) : INFINITY;
+    int rank = 0;
+#pragma unroll
+    for (int t = 0; t < HB_KC; ++t) {
+        const float dt = __shfl(de, base + t, 64);
+        const int jt = __shfl(j, base + t, 64);
+        rank += (dt < de || (dt == de && jt < j)) ? 1 : 0;
+    }
+    // exact softmax terms relative to the exact maximum; swap the candidates' approximate terms for them
+    float dmin = de;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) dmin = fminf(dmin, __shfl_xor(dmin, o, 64));
+    const float smax = dmin * neg_alpha;
+    const float s = de * neg_alpha;
+    const float ex = valid ? exp2f((s - smax) * LOG2E) : 0.f;
+    float esum = ex;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) esum += __shfl_xor(esum, o, 64);
+    // pass A's sum covers exactly the columns outside the candidate list
+    const float lsm = G.lsum[row * 2] * exp2f((G.lsum[row * 2 + 1] - smax) * LOG2E) + esum;
+    // certification: every column outside the candidate set has approximate d2 >= theta = the worst kept one
+    const int topk = args.topk;
+    const int need = topk < M ? topk : M;        // entries that must be exact
+    float vlast = (rank == need - 1) ? v : -INFINITY;  // exact d2 of the last needed entry
+    float theta = va;                                   // max over valid candidates = approximate KC-th best
+    if (!valid) theta = -INFINITY;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        vlast = fmaxf(vlast, __shfl_xor(vlast, o, 64));
+        theta = fmaxf(theta, __shfl_xor(theta, o, 64));
+    }
+    const float delta = HB_ERR * (na + G.nkmax[b]);
+    const bool certain = (M <= HB_KC) || (vlast < theta - 2.f * delta);
+    if (!rvalid) return;
+    if (!certain) {
+        if (l16 == 0) G.flagged[atomicAdd(G.nflagged, 1)] = (int32_t)row;
+        return;  // the exact kernel writes this row
+    }
+    if (cand && rank < topk) {
+        G.val[row * topk + rank] = valid ? ex / lsm : 0.f;
+        G.idx[row * topk + rank] = valid ? j : 0;
+    }
+    if (l16 == 0) {
+        if (G.smax) G.smax[row] = smax;
+        if (G.sum) G.sum[row] = lsm;
+    }
+}
+
+// ---------------------------------------------------------------- exact recompute of the uncertified rows
+// One workgroup per flagged row: every lane sweeps its share of the keys with the exact arithmetic, keeps its own
+// top-10 (ascending j, so ties keep the lower column) and online softmax; each wave's 64 lists are merged by
+// repeated wave arg-min over the list heads, the four waves by ranking their 40 entries.
+struct HXGroup {
+    const float *q, *k, *nq, *nk;
+    int N, M;
+    float *val;
+    int32_t *idx;
+    float *smax, *sum;
+    const int32_t *flagged, *nflagged;
+};
+struct HXArgs {
+    HXGroup g[2];
+    float neg_alpha;
+    int topk;
+};
+
+__global__ __launch_bounds__(256) void softcorr_exact_rows_kernel(const HXArgs args) {
+    __shared__ float sk[4][10], sm[4], sl[4];
+    __shared__ int sj[4][10];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float neg_alpha = args.neg_alpha;
+    const int topk = args.topk;
+    for (int grp = 0; grp < 2; ++grp) {
+        const HXGroup &G = args.g[grp];
+        if (!G.flagged) continue;
+        const int cnt = *G.nflagged;
+        const int N = G.N, M = G.M;
+        for (int f = blockIdx.x; f < cnt; f += gridDim.x) {  // one workgroup per row: the sweep is latency-bound
+            const long row = G.flagged[f];
+            const int b = (int)(row / N);
+            const float *q = G.q + (size_t)row * HB_D;
+            const float na = G.nq[row];
+            KBest<10, float> kb;
+            kb.init(INFINITY);
+            float m = -INFINITY, l = 0.f;
+            for (int j0 = wave * 64 + lane; j0 < M; j0 += 1024) {  // four independent chains per lane in flight
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                const float *kr[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) kr[u] = G.k + ((size_t)b * M + (j0 + 256 * u < M ? j0 + 256 * u : j0)) * HB_D;
+#pragma unroll 8
+                for (int c = 0; c < HB_D; c += 4) {
+                    const f32x4 qv = *(const f32x4 *)(q + c);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const f32x4 kv = *(const f32x4 *)(kr[u] + c);
+                        acc[u] = fmaf(-2.f * qv.x, kv.x, acc[u]);
+                        acc[u] = fmaf(-2.f * qv.y, kv.y, acc[u]);
+                        acc[u] = fmaf(-2.f * qv.z, kv.z, acc[u]);
+                        acc[u] = fmaf(-2.f * qv.w, kv.w, acc[u]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + 256 * u;
+                    if (j < M) {
+                        const float d2 = (acc[u] + na) + G.nk[(size_t)b * M + j];
+                        const float de = sqrt_rn(d2 > 0.f ? d2 : 0.f);
+                        const float s = de * neg_alpha;
+                        const float mn = fmaxf(m, s);
+                        l = l * exp2f((m - mn) * LOG2E) + exp2f((s - mn) * LOG2E);  // m = -inf, l = 0 -> 0 * 0
+                        m = mn;
+                        kb.insert(de, j);
+                    }
+                }
+            }
+            float mm = m;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o, 64));
+            float lt = (m == -INFINITY) ? 0.f : l * exp2f((m - mm) * LOG2E);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) lt += __shfl_xor(lt, o, 64);
+            // the wave's 10 best: pop the minimum of the 64 list heads ten times
+            for (int t = 0; t < 10; ++t) {
+                float bd = kb.key[0];
+                int bj = kb.idx[0];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float od = __shfl_xor(bd, o, 64);
+                    const int oj = __shfl_xor(bj, o, 64);
+                    if (od < bd || (od == bd && oj < bj)) bd = od, bj = oj;
+                }
+                if (kb.idx[0] == bj && kb.key[0] == bd) {  // the owner pops its head
+#pragma unroll
+                    for (int p = 0; p < 9; ++p) kb.key[p] = kb.key[p + 1], kb.idx[p] = kb.idx[p + 1];
+                    kb.key[9] = INFINITY, kb.idx[9] = 0x7fffffff;
+                }
+                if (lane == 0) sk[wave][t] = bd, sj[wave][t] = bj;
+            }
+            if (lane == 0) sm[wave] = mm, sl[wave] = lt;
+            __syncthreads();
+            if (wave == 0) {  // merge the four waves: rank the 40 entries by (distance, column)
+                const float gm = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));  // = max_j s_j exactly (s monotone in de)
+                float gl = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) gl += (sm[w] == -INFINITY) ? 0.f : sl[w] * exp2f((sm[w] - gm) * LOG2E);
+                const float md = lane < 40 ? sk[lane / 10][lane % 10] : INFINITY;
+                const int mj = lane < 40 ? sj[lane / 10][lane % 10] : 0x7fffffff;
+                int rank = 0;
+                for (int t = 0; t < 40; ++t) {
+                    const float od = sk[t / 10][t % 10];
+                    const int oj = sj[t / 10][t % 10];
+                    rank += (od < md || (od == md && oj < mj)) ? 1 : 0;
+                }
+                if (lane < 40 && rank < topk) {
+                    const bool live = md != INFINITY;
+                    G.val[row * topk + rank] = live ? exp2f((md * neg_alpha - gm) * LOG2E) / gl : 0.f;
+                    G.idx[row * topk + rank] = live ? mj : 0;
+                }
+                if (lane == 0) {
+                    if (G.smax) G.smax[row] = gm;
+                    if (G.sum) G.sum[row] = gl;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace
+
+// workspace of the bf16 path for (B, N, M): planes of both sides, candidates of both directions, flags
+size_t softcorr_bf16_ws_bytes(int B, int N, int M, bool both) {
+    const size_t Np = (size_t)(N + HB_KT - 1) / HB_KT * HB_KT, Mp = (size_t)(M + HB_KT - 1) / HB_KT * HB_KT;
+    size_t n = align_up((size_t)B * N * HB_ROWB) + align_up((size_t)B * M * HB_ROWB) + 2 * align_up((size_t)B * sizeof(float)) +
+               align_up(2 * sizeof(int)) + align_up(B * Np * sizeof(float)) + align_up(B * Mp * sizeof(float));
+    const int dirs = both ? 2 : 1;
+    for (int d = 0; d < dirs; ++d) {
+        const size_t R = (size_t)B * (d == 0 ? N : M);
+        n += align_up(R * HB_KC * sizeof(int32_t)) + align_up(R * HB_KC * sizeof(float)) + align_up(R * 2 * sizeof(float)) +
+             align_up((R + 1) * sizeof(int32_t));
+    }
+    return n;
+}
+
+// f1 [B][N][128], f2 [B][M][128] with norms n1, n2; direction 0 = rows of f1 against f2; direction 1 (optional) the
+// reverse.  Outputs as the fp32 kernel: top-`topk` values/columns (topk <= 10), optional row stats.
+int launch_softcorr_bf16(const float *f1, const float *f2, const float *n1, const float *n2, int B, int N, int M, float neg_alpha,
+                         int topk, float *val12, int32_t *idx12, float *smax12, float *sum12, float *val21, int32_t *idx21,
+                         float *smax21, float *sum21, const int *amax_in, void *ws, size_t ws_bytes, hipStream_t s) {
+    const bool both = val21 != nullptr;
+    Arena ar(ws, ws_bytes);
+    char *p1 = ar.take<char>((size_t)B * N * HB_ROWB), *p2 = ar.take<char>((size_t)B * M * HB_ROWB);
+    float *nmax1 = ar.take<float>(B), *nmax2 = ar.take<float>(B);
+    int *amax_own = ar.take<int>(2);  // bit patterns of max|f1|, max|f2| when the caller did not fuse them into the norms
+    const int *amax = amax_in ? amax_in : amax_own;
+    const int Np = (N + HB_KT - 1) / HB_KT * HB_KT, Mp = (M + HB_KT - 1) / HB_KT * HB_KT;
+    float *n1p = ar.take<float>((size_t)B * Np), *n2p = ar.take<float>((size_t)B * Mp);
+    int32_t *cidx[2] = {nullptr, nullptr}, *flag[2] = {nullptr, nullptr};
+    float *cd2[2] = {nullptr, nullptr}, *lsum[2] = {nullptr, nullptr};
+    for (int d = 0; d < (both ? 2 : 1); ++d) {
+        const size_t R = (size_t)B * (d == 0 ? N : M);
+        cidx[d] = ar.take<int32_t>(R * HB_KC);
+        cd2[d] = ar.take<float>(R * HB_KC);
+        lsum[d] = ar.take<float>(R * 2);
+        flag[d] = ar.take<int32_t>(R + 1);  // [0] = counter, [1..] = rows
+    }
+    if (!ar.ok()) {
+        set_error("softcorr (bf16 path): workspace too small (%zu < %zu)", ws_bytes, ar.off);
+        return DVM_ENOSPACE;
+    }
+    const long r1 = (long)B * N, r2 = (long)B * M;
+    (void)hipMemsetAsync(nmax1, 0, 2 * align_up((size_t)B * sizeof(float)) + 2 * sizeof(int), s);
+    if (!amax_in) {
+        hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, s, f1, r1 * 32, amax_own);
+        hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, s, f2, r2 * 32, amax_own + 1);
+    }
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((r1 * 32 + 255) / 256)), dim3(256), 0, s, f1, r1, amax, p1);
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((r2 * 32 + 255) / 256)), dim3(256), 0, s, f2, r2, amax + 1, p2);
+    hipLaunchKernelGGL(norm_max_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, n1, N, nmax1);
+    hipLaunchKernelGGL(norm_max_kernel, dim3((M + 255) / 256, B), dim3(256), 0, s, n2, M, nmax2);
+    for (int d = 0; d < (both ? 2 : 1); ++d) (void)hipMemsetAsync(flag[d], 0, sizeof(int32_t), s);
+    hipLaunchKernelGGL(pad_norms_kernel, dim3((Mp + 255) / 256, B), dim3(256), 0, s, n2, M, Mp, n2p);
+    if (both) hipLaunchKernelGGL(pad_norms_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, s, n1, N, Np, n1p);
+
+    HBArgs a;
+    a.g[0] = HBGroup{p1, p2, amax, amax + 1, n1, n2p, N, M, Mp, (N + HB_QB - 1) / HB_QB, cidx[0], cd2[0], lsum[0]};
+    a.g[1] = both ? HBGroup{p2, p1, amax + 1, amax, n2, n1p, M, N, Np, (M + HB_QB - 1) / HB_QB, cidx[1], cd2[1], lsum[1]} : a.g[0];
+    a.blocks0 = B * a.g[0].tiles;
+    a.neg_alpha = neg_alpha;
+    a.cutw = 20.f / -neg_alpha;
+    const int blocks = a.blocks0 + (both ? B * a.g[1].tiles : 0);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)softcorr_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)HB_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)softcorr_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)HB_LDS_BYTES);
+        attr_set = true;
+    }
+    prof_begin(s);
+    if (-neg_alpha >= 32.f)
+        hipLaunchKernelGGL(softcorr_bf16_kernel<true>, dim3(blocks), dim3(HB_THREADS), HB_LDS_BYTES, s, a);
+    else
+        hipLaunchKernelGGL(softcorr_bf16_kernel<false>, dim3(blocks), dim3(HB_THREADS), HB_LDS_BYTES, s, a);
+    prof_end(s);
+
+    HRArgs r;
+    r.g[0] = HRGroup{f1, f2, n1, n2, nmax2, N, M, cidx[0], cd2[0], lsum[0], val12, idx12, smax12, sum12, flag[0] + 1, flag[0]};
+    r.g[1] = both ? HRGroup{f2, f1, n2, n1, nmax1, M, N, cidx[1], cd2[1], lsum[1], val21, idx21, smax21, sum21, flag[1] + 1, flag[1]}
+                  : r.g[0];
+    r.rows0 = r1;
+    r.rows_total = r1 + (both ? r2 : 0);
+    r.neg_alpha = neg_alpha;
+    r.topk = topk;
+    hipLaunchKernelGGL(softcorr_refine_kernel, dim3((unsigned)((r.rows_total * 16 + 255) / 256)), dim3(256), 0, s, r);
+
+    HXArgs x;
+    x.g[0] = HXGroup{f1, f2, n1, n2, N, M, val12, idx12, smax12, sum12, flag[0] + 1, flag[0]};
+    x.g[1] = both ? HXGroup{f2, f1, n2, n1, M, N, val21, idx21, smax21, sum21, flag[1] + 1, flag[1]}
+                  : HXGroup{nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    x.neg_alpha = neg_alpha;
+    x.topk = topk;
+    hipLaunchKernelGGL(softcorr_exact_rows_kernel, dim3(512), dim3(256), 0, s, x);
+    return DVM_OK;
+}
+
+}  // namespace dvm

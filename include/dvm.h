@@ -62,7 +62,9 @@ int dvm_rownorm2_f32(const float *x, int rows, int K, float *out, void *stream);
  *   pi_val [B,N,topk], pi_idx [B,N,topk];
  *   row_smax [B,N] = max_j s_ij, row_sum [B,N] = sum_j exp(s_ij - smax)  (s = D*neg_alpha)
  * f1 [B,N,d], f2 [B,M,d]; neg_alpha = (float)(-alpha) < 0; 1 <= topk <= 16; d % 4 == 0, d <= 512.
- * variant: 0 = auto, 1 = scalar-FMA kernel, 2 = fp32-MFMA kernel (d == 128). */
+ * variant: 0 = auto, 1 = scalar-FMA kernel, 2 = fp32-MFMA kernel (d == 128), 3 = bf16-split matrix-core sweep
+ * with exact fp32 re-evaluation of the 12 best columns per row and exact recompute of uncertified rows
+ * (d == 128, topk <= 10); all variants give identical columns and row_smax. */
 size_t dvm_softcorr_workspace_bytes(int B, int N, int M, int d);
 int dvm_softcorr_fwd_f32(const float *f1, const float *f2, int B, int N, int M, int d, float neg_alpha, int topk,
                          float *pi_val, int32_t *pi_idx, float *row_smax, float *row_sum, int variant, void *ws,
