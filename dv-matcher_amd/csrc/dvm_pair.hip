@@ -1,6 +1,8 @@
 // dvm_pair.hip — one direction of GraphDeformLoss_Neural.deform() for a batch of pairs as a
 // single stream of launches with no host round trip (reference models/loss.py:1228-1296,
 // 1401-1410; deform.py:232-257).  This is BASELINE config 2, "correspondence + deform forward".
+#include <stdlib.h>
+
 #include "dvm_common.h"
 
 namespace dvm {
@@ -268,7 +270,29 @@ DVM_EXPORT int dvm_pair_fwd_f32(const float *feat1, const float *feat2, const fl
     const int32_t *start[2] = {start1, start2};
     int rc;
     const bool both = (N == M) && contiguous_sides(B, N);
-    // ---- per-cloud geometry: graph + xyz kNN
+    // ---- per-cloud geometry: graph + xyz kNN.  It depends on the coordinates only and is latency-bound (FPS: N/2
+    // sequential steps per cloud), the soft correspondence on the features only and is ALU-bound: the two chains run
+    // concurrently, the geometry on a helper stream forked from / joined back into the caller's stream by events.
+    static hipStream_t side = nullptr;
+    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    static const bool overlap = [] {
+        const char *e = getenv("DVM_PAIR_OVERLAP");
+        return !(e && atoi(e) == 0);
+    }();
+    if (overlap && !side) {
+        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) {
+            set_error("dvm_pair_fwd_f32: cannot create the helper stream");
+            return DVM_ELAUNCH;
+        }
+    }
+    const hipStream_t caller = s;
+    if (overlap) {
+        (void)hipEventRecord(ev_fork, caller);
+        (void)hipStreamWaitEvent(side, ev_fork, 0);
+        s = side;
+    }
     if (both) {
         (void)hipMemcpyAsync(w.vcat, verts1, (size_t)B * N * 3 * sizeof(float), hipMemcpyDeviceToDevice, s);
         (void)hipMemcpyAsync(w.vcat + (size_t)B * N * 3, verts2, (size_t)B * N * 3 * sizeof(float), hipMemcpyDeviceToDevice, s);
@@ -284,6 +308,10 @@ DVM_EXPORT int dvm_pair_fwd_f32(const float *feat1, const float *feat2, const fl
             launch_grid_knn_self(w.gv[sd], B, 10, w.idxk[sd], s);
         }
     }
+    if (overlap) {
+        (void)hipEventRecord(ev_join, side);
+        s = caller;
+    }
     // ---- soft correspondence, both directions in one launch
     rc = launch_softcorr_pair(feat1, feat2, w.nrm[0], w.nrm[1], B, N, M, neg_alpha, w.pval[0], w.pidx[0], w.pval[1], w.pidx[1], w.k1ws,
                               w.k1ws_bytes, s);
@@ -294,6 +322,7 @@ DVM_EXPORT int dvm_pair_fwd_f32(const float *feat1, const float *feat2, const fl
     if (rc != DVM_OK) return rc;
     rc = dvm_softcorr_apply_f32(w.pval[1], w.pidx[1], verts1, B, M, N, 10, 3, verts21, s);
     if (rc != DVM_OK) return rc;
+    if (overlap) (void)hipStreamWaitEvent(caller, ev_join, 0);  // join: everything below needs the graphs / kNN
     // ---- Deformer: pooled features once per cloud, z for both directions, one MLP launch
     launch_pool_all(feat1, w.idxk[0], B, N, 10, conv_w, conv_b, w.gall[0], s);
     launch_pool_all(feat2, w.idxk[1], B, M, 10, conv_w, conv_b, w.gall[1], s);
