@@ -128,6 +128,18 @@ def main():
     ms, nl = ctypes.c_double(), ctypes.c_int()
     ops.check(lib.dvm_profile_read(ctypes.byref(ms), ctypes.byref(nl)), "dvm_profile_read")
     lib.dvm_profile_disable()
+    # the sweep kernel alone: the same launches with the helper-stream overlap switched off (outside the timed region)
+    lib.dvm_pair_set_overlap(0)
+    step()
+    torch.cuda.synchronize()
+    ops.check(lib.dvm_profile_enable(8), "dvm_profile_enable")
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    ms1, nl1 = ctypes.c_double(), ctypes.c_int()
+    ops.check(lib.dvm_profile_read(ctypes.byref(ms1), ctypes.byref(nl1)), "dvm_profile_read")
+    lib.dvm_profile_disable()
+    lib.dvm_pair_set_overlap(1)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -166,7 +178,13 @@ def main():
                          "traffic": traffic, "launch_ms": k1_ms, "launches_timed": nl.value,
                          "flops_per_launch": flops_launch, "performed_f16_tflops": 6.0 * achieved, "f16_peak": 2500.0,
                          "f16_frac": 6.0 * achieved / 2500.0,
-                         "share_of_step": (ms.value * 1e-3) / dt if dt > 0 else None},
+                         "share_of_step": (ms.value * 1e-3) / dt if dt > 0 else None,
+                         # in the timed region the sweep shares the CUs with the geometry chain on the helper stream
+                         # (FPS / graph / kNN), which stretches its launch; alone (overlap off, 3 launches after the
+                         # timed region) it takes `launch_ms` below
+                         "standalone": {"launch_ms": ms1.value / max(nl1.value, 1),
+                                        "achieved": flops_launch / (ms1.value / max(nl1.value, 1) * 1e-3) / 1e12,
+                                        "frac": flops_launch / (ms1.value / max(nl1.value, 1) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}},
         }
         if world == 1 and args.cpu_sample > 0:
             res["cpu_baseline"] = cpu_baseline(args.cpu_sample)

@@ -245,6 +245,18 @@ DVM_EXPORT size_t dvm_pair_workspace_bytes(int B, int N, int M) {
     return carve_pair2(ar, B, N, M, w);
 }
 
+// 1 (default): the geometry chain runs on a helper stream next to the soft-correspondence chain; 0: one stream
+static int g_pair_overlap = [] {
+    const char *e = getenv("DVM_PAIR_OVERLAP");
+    return (e && atoi(e) == 0) ? 0 : 1;
+}();
+
+DVM_EXPORT int dvm_pair_set_overlap(int on) {
+    const int prev = g_pair_overlap;
+    g_pair_overlap = on ? 1 : 0;
+    return prev;
+}
+
 DVM_EXPORT int dvm_pair_fwd_f32(const float *feat1, const float *feat2, const float *verts1, const float *verts2, int B, int N,
                                 int M, float neg_alpha, const int32_t *start1, const int32_t *start2, const float *conv_w,
                                 const float *conv_b, const float *W0, const float *b0, const float *W1, const float *b1,
@@ -275,10 +287,7 @@ DVM_EXPORT int dvm_pair_fwd_f32(const float *feat1, const float *feat2, const fl
     // concurrently, the geometry on a helper stream forked from / joined back into the caller's stream by events.
     static hipStream_t side = nullptr;
     static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    static const bool overlap = [] {
-        const char *e = getenv("DVM_PAIR_OVERLAP");
-        return !(e && atoi(e) == 0);
-    }();
+    const bool overlap = g_pair_overlap != 0;
     if (overlap && !side) {
         if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||

@@ -275,6 +275,12 @@ int dvm_pair_fwd_f32(const float *feat1, const float *feat2, const float *verts1
                      float *verts12, int32_t *T12, float *losses12, float *warped21, float *verts21, int32_t *T21,
                      float *losses21, void *ws, size_t ws_bytes, void *stream);
 
+/* dvm_pair_fwd_f32 runs its coordinate-only chain (FPS, graph, xyz kNN) on an internal helper stream, forked from
+ * and joined back into `stream` by events, concurrently with the feature-only soft-correspondence chain.
+ * dvm_pair_set_overlap(0) keeps everything on `stream` (A/B measurements); returns the previous setting.
+ * Environment default: DVM_PAIR_OVERLAP=0. */
+int dvm_pair_set_overlap(int on);
+
 #ifdef __cplusplus
 }
 #endif
