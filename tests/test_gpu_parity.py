@@ -275,3 +275,31 @@ def test_errors_are_loud(ops):
         ops.softcorr(torch.randn(1, 8, 130).cuda(), torch.randn(1, 8, 130).cuda(), 10.0)
     with pytest.raises(DvmError):
         ops.softcorr(f.cuda(), f.cuda(), -10.0)
+
+
+@pytest.mark.parametrize("case", ["wide_range", "zeros", "tiny_M", "single_row", "huge_scale", "tiny_scale", "clustered"])
+def test_softcorr_fp16_split_edge_cases(ops, case):
+    """Variant 3 (fp16x2-split sweep + exact re-evaluation): inputs chosen to stress the split's scaling, the
+    certification and the exact-recompute fallback; outputs must still equal the oracle's (columns bit-exact)."""
+    import zlib
+    g = np.random.default_rng(zlib.crc32(case.encode()))
+    N, M, d = 150, 210, 128
+    f1 = g.standard_normal((N, d)).astype(np.float32)
+    f2 = g.standard_normal((M, d)).astype(np.float32)
+    alpha = 40.0
+    if case == "wide_range":       # one coordinate 1e4 times the others, some 1e-6
+        f1[:, 3] *= 1e4; f2[:, 3] *= 1e4; f1[:, 7] *= 1e-6; f2[:, 9] *= 1e-6
+        alpha = 0.01
+    elif case == "zeros":          # every distance ties: nothing can be certified, all rows take the exact kernel
+        f1[:], f2[:] = 0.0, 0.0
+    elif case == "tiny_M":
+        f2 = f2[:5]
+    elif case == "single_row":
+        f1, f2 = f1[:1], f2[:13]
+    elif case == "huge_scale":
+        f1 *= 3e5; f2 *= 3e5; alpha = 1e-5
+    elif case == "tiny_scale":
+        f1 *= 1e-12; f2 *= 1e-12; alpha = 1e13
+    elif case == "clustered":      # many near-duplicates: dense ties around the 10th neighbour
+        f2 = np.repeat(f2[:21], 10, axis=0) + (1e-7 * g.standard_normal((210, d))).astype(np.float32)
+    check_softcorr(ops, f1, f2, alpha, 3)
