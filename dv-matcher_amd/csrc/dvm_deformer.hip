@@ -400,18 +400,28 @@ void launch_assemble_pooled(const float *vsrc, const float *vcorr, const float *
 size_t mlp_bf16_pack_bytes();
 void launch_mlp_rows_bf16(const float *z, int rows, const float *W0, const float *b0, const float *W1, const float *b1,
                           const float *W2, const float *b2, const float *W3, const float *b3, void *scratch, float *out,
-                          hipStream_t s);
+                          hipStream_t s, const int *gate);
+size_t mlp_f16_pack_bytes();
+int *launch_mlp_rows_f16(const float *z, int rows, const float *W0, const float *b0, const float *W1, const float *b1,
+                         const float *W2, const float *b2, const float *W3, const float *b3, void *scratch, float *out,
+                         hipStream_t s);
 size_t mlp_pack_floats() {
     size_t f32 = (size_t)16 * 132 * 64 + (size_t)8 * 256 * 64 + (size_t)4 * 128 * 64 + (size_t)64 * 64;
-    size_t b16 = (mlp_bf16_pack_bytes() + 3) / 4;
-    return f32 > b16 ? f32 : b16;
+    size_t h16 = (mlp_f16_pack_bytes() + mlp_bf16_pack_bytes() + 3) / 4;  // variant 0 keeps both packings
+    return f32 > h16 ? f32 : h16;
 }
 // z [rows][264] -> out [rows][9]; wp = scratch of mlp_pack_floats() floats.
-// variant 0: bf16x3-split matrix-core kernel (dvm_mlp_bf16.hip); 2: fp32-MFMA kernel (k-ordered fma chain)
+// variant 0: fp16x2-split matrix-core kernel, 64 nodes per workgroup (dvm_mlp_f16.hip), followed by the bf16x3 kernel
+//            gated on its out-of-range flag; 3: bf16x3-split kernel (dvm_mlp_bf16.hip); 2: fp32-MFMA kernel
 void launch_mlp_rows(const float *z, int rows, const float *W0, const float *b0, const float *W1, const float *b1, const float *W2,
                      const float *b2, const float *W3, const float *b3, float *wp, float *out, hipStream_t s, int variant) {
     if (variant == 0) {
-        launch_mlp_rows_bf16(z, rows, W0, b0, W1, b1, W2, b2, W3, b3, wp, out, s);
+        const int *flag = launch_mlp_rows_f16(z, rows, W0, b0, W1, b1, W2, b2, W3, b3, wp, out, s);
+        launch_mlp_rows_bf16(z, rows, W0, b0, W1, b1, W2, b2, W3, b3, (char *)wp + mlp_f16_pack_bytes(), out, s, flag);
+        return;
+    }
+    if (variant == 3) {
+        launch_mlp_rows_bf16(z, rows, W0, b0, W1, b1, W2, b2, W3, b3, wp, out, s, nullptr);
         return;
     }
     float *Wp0 = wp, *Wp1 = Wp0 + (size_t)16 * 132 * 64, *Wp2 = Wp1 + (size_t)8 * 256 * 64, *Wp3 = Wp2 + (size_t)4 * 128 * 64;
@@ -458,7 +468,7 @@ DVM_EXPORT int dvm_deformer_fwd_f32(const float *feat1, const float *feat2, cons
     DVM_REQUIRE(conv_w && conv_b && W0 && b0 && W1 && b1 && W2 && b2 && W3 && b3, "dvm_deformer_fwd_f32: null weight pointer");
     DVM_REQUIRE(B >= 1 && N >= 1 && M >= 1 && Nn >= 1, "dvm_deformer_fwd_f32: empty input");
     DVM_REQUIRE(k >= 1 && k <= 64 && topk >= 1 && topk <= 16, "dvm_deformer_fwd_f32: k=%d topk=%d out of range", k, topk);
-    DVM_REQUIRE(variant >= 0 && variant <= 2, "dvm_deformer_fwd_f32: bad variant %d", variant);
+    DVM_REQUIRE(variant >= 0 && variant <= 3, "dvm_deformer_fwd_f32: bad variant %d", variant);
     int rc = launch_deformer(feat1, feat2, verts1, verts12, idx11, idx22, pi_val, pi_idx, fps1, B, N, M, Nn, k, topk, conv_w,
                              conv_b, W0, b0, W1, b1, W2, b2, W3, b3, out, variant, ws, ws_bytes, (hipStream_t)stream);
     if (rc != DVM_OK) return rc;

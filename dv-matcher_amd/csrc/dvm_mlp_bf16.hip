@@ -59,13 +59,15 @@ __global__ void pack_weights_bf16_kernel(const float *__restrict__ W, int O, int
 __device__ __forceinline__ f32x16 mlp_tile_bf16(const char *__restrict__ act_row /* node row + 16*hh */, int plane_bytes,
                                                 const __bf16 *__restrict__ wp /* tile base + lane*8 */, int steps) {
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // weight fragments come straight from L2 (every workgroup streams all 1.8 MB): keep two k-steps in flight
     bf16x8 bh = *(const bf16x8 *)(wp), bm = *(const bf16x8 *)(wp + 512), bl = *(const bf16x8 *)(wp + 1024);
+    const __bf16 *w1 = wp + (size_t)(1 < steps ? 1 : 0) * 1536;
+    bf16x8 ch = *(const bf16x8 *)(w1), cm = *(const bf16x8 *)(w1 + 512), cl = *(const bf16x8 *)(w1 + 1024);
     for (int s = 0; s < steps; ++s) {
         const bf16x8 ah = *(const bf16x8 *)(act_row + 32 * s);
         const bf16x8 am = *(const bf16x8 *)(act_row + plane_bytes + 32 * s);
         const bf16x8 al = *(const bf16x8 *)(act_row + 2 * plane_bytes + 32 * s);
-        // prefetch the next step's weight fragments (the last iteration re-reads its own: in bounds)
-        const __bf16 *wn = wp + (size_t)(s + 1 < steps ? s + 1 : s) * 1536;
+        const __bf16 *wn = wp + (size_t)(s + 2 < steps ? s + 2 : steps - 1) * 1536;
         const bf16x8 nh = *(const bf16x8 *)(wn), nm = *(const bf16x8 *)(wn + 512), nl = *(const bf16x8 *)(wn + 1024);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);  // small terms first
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
@@ -73,7 +75,8 @@ __device__ __forceinline__ f32x16 mlp_tile_bf16(const char *__restrict__ act_row
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
-        bh = nh, bm = nm, bl = nl;
+        bh = ch, bm = cm, bl = cl;
+        ch = nh, cm = nm, cl = nl;
     }
     return acc;
 }
@@ -104,7 +107,8 @@ __global__ __launch_bounds__(MB_THREADS) void mlp_bf16x3_kernel(const float *__r
                                                                 const __bf16 *__restrict__ Wp1, const float *__restrict__ b1,
                                                                 const __bf16 *__restrict__ Wp2, const float *__restrict__ b2,
                                                                 const __bf16 *__restrict__ Wp3, const float *__restrict__ b3,
-                                                                float *__restrict__ out) {
+                                                                float *__restrict__ out, const int *__restrict__ gate) {
+    if (gate && *gate == 0) return;  // fallback launch behind the fp16x2 kernel: runs only if that one left fp16's range
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *bufA = smem;                        // [32][MB_SA]
     char *bufB = smem + MB_NODES * MB_SA;     // [32][MB_SB]
@@ -173,7 +177,7 @@ size_t mlp_bf16_pack_bytes() {
 // z [rows][264] fp32 -> out [rows][9]; scratch = mlp_bf16_pack_bytes() bytes
 void launch_mlp_rows_bf16(const float *z, int rows, const float *W0, const float *b0, const float *W1, const float *b1,
                           const float *W2, const float *b2, const float *W3, const float *b3, void *scratch, float *out,
-                          hipStream_t s) {
+                          hipStream_t s, const int *gate) {
     __bf16 *Wp0 = (__bf16 *)scratch;
     __bf16 *Wp1 = Wp0 + (size_t)16 * (MB_K0 / 16) * 1536;
     __bf16 *Wp2 = Wp1 + (size_t)8 * (MB_K1 / 16) * 1536;
@@ -192,7 +196,7 @@ void launch_mlp_rows_bf16(const float *z, int rows, const float *W0, const float
         attr_set = true;
     }
     hipLaunchKernelGGL(mlp_bf16x3_kernel, dim3((rows + MB_NODES - 1) / MB_NODES), dim3(MB_THREADS), MB_LDS_BYTES, s, z, rows, Wp0,
-                       b0, Wp1, b1, Wp2, b2, Wp3, b3, out);
+                       b0, Wp1, b1, Wp2, b2, Wp3, b3, out, gate);
 }
 
 }  // namespace dvm

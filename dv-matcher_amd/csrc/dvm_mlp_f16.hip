@@ -1,0 +1,237 @@
+// dvm_mlp_f16.hip — the Deformer's decoder MLP (262 -> 512 -> 256 -> 128 -> 9, ELU) on the 16-bit matrix cores
+// with fp32-level accuracy, 64 nodes per workgroup.
+//
+// The bf16x3 kernel (dvm_mlp_bf16.hip) is bound by streaming its pre-split weights from L2: every 32-node
+// workgroup reads all 1.8 MB (13 TB/s of L2 -> CU traffic at 256 pairs).  Here
+//   * operands are split 2-way into fp16 planes, x*s = h + m (+ r, |r| <= 2^-22 |x*s|), with fixed power-of-two
+//     scales (activations 2^5, weights 2^8): three partial products hh + hm + mh instead of six, 2 planes of
+//     weights instead of 3;
+//   * a workgroup carries 64 nodes (two 32-row MFMA tiles), so a weight fragment is loaded once per two tiles;
+//     the 512-wide hidden layer is produced in two halves that layer 1 consumes immediately (split-K, its
+//     accumulators stay in registers), which is what lets 64 nodes fit: LDS = z/h1 (70 KB) + h0-half/h2 (66 KB).
+//   -> 0.6 MB of weights per 32 nodes instead of 1.8 MB, half the matrix work.
+// fp16 has a narrow range: an activation or weight beyond +-60000/scale raises a flag and the caller re-runs the
+// launch with the bf16x3 kernel (gated on that flag, so it costs one empty launch otherwise).  Values below
+// 2^-3/scale lose relative — not absolute — precision in the m plane (<= 2^-24 of the scale).
+// (reference models/model.py:433-452, 476-477; floats only, no integer output depends on it)
+#include "dvm_common.h"
+
+namespace dvm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int MH_NODES = 64, MH_WAVES = 8, MH_THREADS = 64 * MH_WAVES;
+constexpr int MH_ZS = 264;                                     // z row stride in HBM (floats)
+constexpr int MH_K0 = 272, MH_K1 = 512, MH_K2 = 256, MH_K3 = 128;  // K padded to multiples of 16
+constexpr int MH_SZ = 2 * MH_K0 * 2 + 16;   // 1104 B: z (2 planes of 272) and later h1 (2 x 256)
+constexpr int MH_SH = 2 * 256 * 2 + 16;     // 1040 B: one half of h0 (2 x 256) and later h2 (2 x 128)
+constexpr size_t MH_LDS_BYTES = (size_t)MH_NODES * (MH_SZ + MH_SH);
+constexpr float MH_SA = 32.f, MH_SW = 256.f, MH_INV = 1.f / (32.f * 256.f);  // activation / weight scales
+constexpr float MH_LIMIT = 60000.f;
+
+__device__ __forceinline__ void split2(float xs, _Float16 &h, _Float16 &m) {
+    h = (_Float16)xs;
+    m = (_Float16)(xs - (float)h);
+}
+
+// Packed weights: Wp[otile][step][plane][lane][8] fp16, element j of lane (o = lane&31, hh = lane>>5)
+// = plane(S_w * W[otile*32 + o][16*step + 8*hh + j])  (0 outside the matrix)
+__global__ void pack_weights_f16_kernel(const float *__restrict__ W, int O, int I, int otiles, int steps, _Float16 *__restrict__ Wp,
+                                        int *__restrict__ flag) {
+    long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)otiles * steps * 64 * 8;
+    if (g >= total) return;
+    int j = (int)(g & 7);
+    int lane = (int)((g >> 3) & 63);
+    int step = (int)((g >> 9) % steps);
+    int ot = (int)(g / (512L * steps));
+    int o = ot * 32 + (lane & 31), c = 16 * step + 8 * (lane >> 5) + j;
+    float w = (o < O && c < I) ? W[(size_t)o * I + c] * MH_SW : 0.f;
+    if (!(fabsf(w) <= MH_LIMIT)) atomicOr(flag, 1);
+    _Float16 h, m;
+    split2(w, h, m);
+    size_t base = (((size_t)ot * steps + step) * 2) * 512 + (size_t)lane * 8 + j;
+    Wp[base] = h;
+    Wp[base + 512] = m;
+}
+
+// acc[t][node][out] += sum_k act_t[node][k] W[out][k] over `steps` k-steps, for NT 32-node tiles sharing the weight
+// fragments.  a0: this lane's row of tile 0 (+ 16*hh); tile t is 32 rows further.  Weight fragments two steps ahead.
+template <int NT>
+__device__ __forceinline__ void mma_tiles(const char *__restrict__ a0, int row_stride, int plane_bytes,
+                                          const _Float16 *__restrict__ wp /* (otile, first step) base + lane*8 */, int steps,
+                                          f32x16 (&acc)[NT]) {
+    f16x8 bh = *(const f16x8 *)(wp), bm = *(const f16x8 *)(wp + 512);
+    const _Float16 *w1 = wp + (size_t)(1 < steps ? 1 : 0) * 1024;
+    f16x8 ch = *(const f16x8 *)(w1), cm = *(const f16x8 *)(w1 + 512);
+    for (int s = 0; s < steps; ++s) {
+        const _Float16 *wn = wp + (size_t)(s + 2 < steps ? s + 2 : steps - 1) * 1024;
+        const f16x8 nh = *(const f16x8 *)(wn), nm = *(const f16x8 *)(wn + 512);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const char *ar = a0 + t * 32 * row_stride + 32 * s;
+            const f16x8 ah = *(const f16x8 *)(ar), am = *(const f16x8 *)(ar + plane_bytes);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, bh, acc[t], 0, 0, 0);  // small terms first
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bm, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+        }
+        bh = ch, bm = cm;
+        ch = nh, cm = nm;
+    }
+}
+
+__device__ __forceinline__ float elu_fast(float x) {
+    return x > 0.f ? x : __builtin_amdgcn_exp2f(x * 1.4426950408889634f) - 1.f;
+}
+
+// bias + ELU on the un-scaled accumulator, then scale, split and store the two planes of this lane's 16 (node, out) values
+__device__ __forceinline__ void store_act(const f32x16 &acc, float bv, int col, char *dst /* tile's first row */, int stride,
+                                          int plane_bytes, int hh, int &bad) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int node = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const float a = elu_fast(acc[r] * MH_INV + bv) * MH_SA;
+        bad |= !(fabsf(a) <= MH_LIMIT);
+        _Float16 h, m;
+        split2(a, h, m);
+        char *p = dst + node * stride + 2 * col;
+        *(_Float16 *)(p) = h;
+        *(_Float16 *)(p + plane_bytes) = m;
+    }
+}
+
+__global__ __launch_bounds__(MH_THREADS) void mlp_f16x2_kernel(const float *__restrict__ z, int rows,
+                                                               const _Float16 *__restrict__ Wp0, const float *__restrict__ b0,
+                                                               const _Float16 *__restrict__ Wp1, const float *__restrict__ b1,
+                                                               const _Float16 *__restrict__ Wp2, const float *__restrict__ b2,
+                                                               const _Float16 *__restrict__ Wp3, const float *__restrict__ b3,
+                                                               float *__restrict__ out, int *__restrict__ flag) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *bufZ = smem;                       // [64][MH_SZ]
+    char *bufH = smem + MH_NODES * MH_SZ;    // [64][MH_SH]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int row0 = blockIdx.x * MH_NODES;
+    int bad = 0;
+
+    // stage z: scale, split into the two planes (columns 262..271 are zero)
+    for (int e = tid; e < MH_NODES * (MH_K0 / 4); e += MH_THREADS) {
+        const int r = e / (MH_K0 / 4), c = e % (MH_K0 / 4);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row0 + r < rows && 4 * c < MH_ZS) v = *(const f32x4 *)(z + (size_t)(row0 + r) * MH_ZS + 4 * c);
+        char *p = bufZ + r * MH_SZ + 8 * c;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float a = (4 * c + q < 262 ? v[q] : 0.f) * MH_SA;
+            bad |= !(fabsf(a) <= MH_LIMIT);
+            _Float16 h, m;
+            split2(a, h, m);
+            *(_Float16 *)(p + 2 * q) = h;
+            *(_Float16 *)(p + 2 * MH_K0 + 2 * q) = m;
+        }
+    }
+    __syncthreads();
+
+    // layer 0 in two halves of 256 outputs; layer 1 consumes each half at once (split-K, accumulators in registers)
+    f32x16 acc1[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[t][r] = 0.f;
+    for (int hlf = 0; hlf < 2; ++hlf) {
+        {
+            const int ot = 8 * hlf + wave;  // of 16 output tiles
+            f32x16 acc0[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc0[t][r] = 0.f;
+            mma_tiles<2>(bufZ + r32 * MH_SZ + 16 * hh, MH_SZ, 2 * MH_K0, Wp0 + (size_t)ot * (MH_K0 / 16) * 1024 + lane * 8, MH_K0 / 16,
+                         acc0);
+            const float bv = b0[ot * 32 + r32];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) store_act(acc0[t], bv, wave * 32 + r32, bufH + t * 32 * MH_SH, MH_SH, 2 * 256, hh, bad);
+        }
+        __syncthreads();
+        // layer 1, K-half hlf: out tile = wave (8 tiles = 256 outputs), k-steps 16*hlf .. 16*hlf+15
+        mma_tiles<2>(bufH + r32 * MH_SH + 16 * hh, MH_SH, 2 * 256, Wp1 + ((size_t)wave * (MH_K1 / 16) + 16 * hlf) * 1024 + lane * 8, 16,
+                     acc1);
+        __syncthreads();
+    }
+    {   // h1 -> bufZ (z is dead)
+        const float bv = b1[wave * 32 + r32];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) store_act(acc1[t], bv, wave * 32 + r32, bufZ + t * 32 * MH_SZ, MH_SZ, 2 * MH_K2, hh, bad);
+    }
+    __syncthreads();
+    // layer 2: 256 -> 128 : 4 output tiles x 2 node tiles, one pair per wave
+    {
+        const int ot = wave & 3, nt = wave >> 2;
+        f32x16 acc2[1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[0][r] = 0.f;
+        mma_tiles<1>(bufZ + (nt * 32 + r32) * MH_SZ + 16 * hh, MH_SZ, 2 * MH_K2, Wp2 + (size_t)ot * (MH_K2 / 16) * 1024 + lane * 8,
+                     MH_K2 / 16, acc2);
+        store_act(acc2[0], b2[ot * 32 + r32], ot * 32 + r32, bufH + nt * 32 * MH_SH, MH_SH, 2 * MH_K3, hh, bad);
+    }
+    __syncthreads();
+    // layer 3: 128 -> 9 : one output tile per node tile, straight to HBM
+    if (wave < 2) {
+        f32x16 acc3[1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc3[0][r] = 0.f;
+        mma_tiles<1>(bufH + (wave * 32 + r32) * MH_SH + 16 * hh, MH_SH, 2 * MH_K3, Wp3 + lane * 8, MH_K3 / 16, acc3);
+        const int o = r32;
+        const float bv = o < 9 ? b3[o] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int node = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (o < 9 && row0 + node < rows) out[(size_t)(row0 + node) * 9 + o] = acc3[0][r] * MH_INV + bv;
+        }
+    }
+    if (__any(bad) && lane == 0) atomicOr(flag, 1);
+}
+
+}  // namespace
+
+size_t mlp_f16_pack_bytes() {
+    return align_up(((size_t)16 * (MH_K0 / 16) + (size_t)8 * (MH_K1 / 16) + (size_t)4 * (MH_K2 / 16) + (size_t)1 * (MH_K3 / 16)) * 1024 *
+                    sizeof(_Float16)) +
+           align_up(sizeof(int));
+}
+
+// z [rows][264] fp32 -> out [rows][9]; scratch = mlp_f16_pack_bytes() bytes.  Returns the device flag that is non-zero
+// when a value left fp16's range (the results are then invalid and the bf16x3 kernel must overwrite them).
+int *launch_mlp_rows_f16(const float *z, int rows, const float *W0, const float *b0, const float *W1, const float *b1,
+                         const float *W2, const float *b2, const float *W3, const float *b3, void *scratch, float *out,
+                         hipStream_t s) {
+    _Float16 *Wp0 = (_Float16 *)scratch;
+    _Float16 *Wp1 = Wp0 + (size_t)16 * (MH_K0 / 16) * 1024;
+    _Float16 *Wp2 = Wp1 + (size_t)8 * (MH_K1 / 16) * 1024;
+    _Float16 *Wp3 = Wp2 + (size_t)4 * (MH_K2 / 16) * 1024;
+    int *flag = (int *)((char *)scratch + mlp_f16_pack_bytes() - align_up(sizeof(int)));
+    (void)hipMemsetAsync(flag, 0, sizeof(int), s);
+    auto pack = [&](const float *W, int O, int I, int otiles, int steps, _Float16 *Wp) {
+        long th = (long)otiles * steps * 512;
+        hipLaunchKernelGGL(pack_weights_f16_kernel, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, W, O, I, otiles, steps, Wp,
+                           flag);
+    };
+    pack(W0, 512, 262, 16, MH_K0 / 16, Wp0);
+    pack(W1, 256, 512, 8, MH_K1 / 16, Wp1);
+    pack(W2, 128, 256, 4, MH_K2 / 16, Wp2);
+    pack(W3, 9, 128, 1, MH_K3 / 16, Wp3);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)mlp_f16x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MH_LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(mlp_f16x2_kernel, dim3((rows + MH_NODES - 1) / MH_NODES), dim3(MH_THREADS), MH_LDS_BYTES, s, z, rows, Wp0, b0,
+                       Wp1, b1, Wp2, b2, Wp3, b3, out, flag);
+    return flag;
+}
+
+}  // namespace dvm

@@ -164,8 +164,10 @@ int dvm_chamfer_bwd_f32(const float *a, const float *b, const int32_t *idx1, con
  * feat1 [B,N,128], feat2 [B,M,128], verts1 [B,N,3], verts12 [B,N,3], idx11 [B,N,k],
  * idx22 [B,M,k], pi_val/pi_idx [B,N,topk], fps1 [B,Nn]; weights: conv_w [k], conv_b [1],
  * W0 [512,262] b0, W1 [256,512] b1, W2 [128,256] b2, W3 [9,128] b3 -> out [B,Nn,9].
- * variant: 0 = bf16x3-split matrix-core MLP (fp32-accurate), 2 = fp32-MFMA MLP (k-ordered fma
- * chain, bit-identical to the oracle's), 1 = scalar-FMA MLP (cross-check). */
+ * variant: 0 = fp16x2-split matrix-core MLP, 64 nodes per workgroup (fp32-accurate; a value outside fp16's range
+ * raises a device flag and the bf16x3 kernel, gated on it, overwrites the result), 3 = bf16x3-split matrix-core MLP
+ * (fp32-accurate, any range), 2 = fp32-MFMA MLP (k-ordered fma chain, bit-identical to the oracle's),
+ * 1 = scalar-FMA MLP (cross-check). */
 size_t dvm_deformer_workspace_bytes(int B, int N, int M, int Nn);
 int dvm_deformer_fwd_f32(const float *feat1, const float *feat2, const float *verts1, const float *verts12,
                          const int32_t *idx11, const int32_t *idx22, const float *pi_val, const int32_t *pi_idx,

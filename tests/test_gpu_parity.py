@@ -165,7 +165,7 @@ def test_fps_batched_and_large(ops):
             assert np.array_equal(out[b], O.fps(v[b], N // 2, int(start[b])))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("name", ["deformer_256x256", "deformer_300x200"])
 def test_deformer_and_chamfer(ops, golden, name, variant):
     g = golden(name)
@@ -303,3 +303,24 @@ def test_softcorr_fp16_split_edge_cases(ops, case):
     elif case == "clustered":      # many near-duplicates: dense ties around the 10th neighbour
         f2 = np.repeat(f2[:21], 10, axis=0) + (1e-7 * g.standard_normal((210, d))).astype(np.float32)
     check_softcorr(ops, f1, f2, alpha, 3)
+
+
+def test_deformer_mlp_fp16_range_fallback(ops, golden):
+    """Variant 0's fp16x2 MLP raises its flag when an activation leaves fp16's range; the gated bf16x3 launch must
+    then deliver the result (compared with the fp32-MFMA variant on inputs scaled far outside the range)."""
+    w = golden("deformer_scape_r_weights")
+    wl = ops.deformer_weight_list(dict(w), "cuda")
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(2, 100, 262, generator=g).cuda()
+    z[0, :50] *= 4000.0          # |z * 32| > 60000
+    ref = ops.deformer_mlp(wl, z * 1.0)  # variant 0 path (with fallback)
+    # reference: fp64 MLP on the host
+    W = [w["deformation_decoder_layer__linear__%d__weight" % i].astype(np.float64) for i in (0, 2, 4, 6)]
+    bb = [w["deformation_decoder_layer__linear__%d__bias" % i].astype(np.float64) for i in (0, 2, 4, 6)]
+    x = host(z).astype(np.float64)
+    for i in range(4):
+        x = x @ W[i].T + bb[i]
+        if i < 3:
+            x = np.where(x > 0, x, np.expm1(x))
+    # outputs of the blown-up rows are O(1e4) sums of O(1e5) terms: fp32-level agreement is relative to that scale
+    np.testing.assert_allclose(host(ref), x, rtol=2e-5, atol=2e-5 * np.abs(x).max())
