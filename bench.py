@@ -173,7 +173,7 @@ def main():
             # kernel's launch time, priced against the fp32 matrix peak as §8d prescribes.  The kernel reaches it by
             # running the contraction as 3 exact fp16 partial products per direction on the 16-bit matrix pipe:
             # `performed_f16_tflops` / `f16_peak` is that pipe's own utilisation.
-            "roofline": {"bound": "mfma", "kernel": "softcorr_bf16_kernel (K1 pass A, fp16x2-split sweep)", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": "softcorr_sweep_f16_kernel (K1 pass A, fp16x2-split sweep)", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                          "traffic": traffic, "launch_ms": k1_ms, "launches_timed": nl.value,
                          "flops_per_launch": flops_launch, "performed_f16_tflops": 6.0 * achieved, "f16_peak": 2500.0,

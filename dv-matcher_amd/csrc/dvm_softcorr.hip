@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void rownorm2_k128_kernel(const float *__restr
         s = s + v * v;
         am = fmaxf(am, fabsf(v));
     }
-    if (absmax) {  // optional: bit pattern of max |x| of the tensor (the fp16 split's scale, dvm_softcorr_bf16.hip)
+    if (absmax) {  // optional: bit pattern of max |x| of the tensor (the fp16 split's scale, dvm_softcorr_f16.hip)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
         // 256 slots (one address would serialise 262k waves); only waves that would raise a slot's maximum touch it
@@ -591,9 +591,9 @@ int launch_softcorr_both(const float *f1, const float *f2, const float *n1, cons
     return DVM_OK;
 }
 
-// dvm_softcorr_bf16.hip
-size_t softcorr_bf16_ws_bytes(int B, int N, int M, bool both);
-int launch_softcorr_bf16(const float *f1, const float *f2, const float *n1, const float *n2, int B, int N, int M, float neg_alpha,
+// dvm_softcorr_f16.hip
+size_t softcorr_f16_ws_bytes(int B, int N, int M, bool both);
+int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const float *n2, int B, int N, int M, float neg_alpha,
                          int topk, float *val12, int32_t *idx12, float *smax12, float *sum12, float *val21, int32_t *idx21,
                          float *smax21, float *sum21, const int *amax, void *ws, size_t ws_bytes, hipStream_t s);
 
@@ -617,7 +617,7 @@ void launch_absmax_finalize(const int *slots, int nt, int *out, hipStream_t s) {
 void launch_rownorm2(const float *x, int rows, int K, float *out, hipStream_t s);
 
 // norms of both sides + soft correspondence in both directions for the fused pair path (d = 128, top-10)
-size_t softcorr_pair_ws_bytes(int B, int N, int M) { return align_up(514 * sizeof(int)) + softcorr_bf16_ws_bytes(B, N, M, true); }
+size_t softcorr_pair_ws_bytes(int B, int N, int M) { return align_up(514 * sizeof(int)) + softcorr_f16_ws_bytes(B, N, M, true); }
 int launch_softcorr_pair(const float *f1, const float *f2, float *n1, float *n2, int B, int N, int M, float neg_alpha, float *val12,
                          int32_t *idx12, float *val21, int32_t *idx21, void *ws, size_t ws_bytes, hipStream_t s) {
     static const int forced = [] {
@@ -641,7 +641,7 @@ int launch_softcorr_pair(const float *f1, const float *f2, float *n1, float *n2,
     launch_rownorm2_absmax(f1, B * N, n1, slots, s);
     launch_rownorm2_absmax(f2, B * M, n2, slots + 256, s);
     launch_absmax_finalize(slots, 2, amax, s);
-    return launch_softcorr_bf16(f1, f2, n1, n2, B, N, M, neg_alpha, 10, val12, idx12, nullptr, nullptr, val21, idx21, nullptr, nullptr,
+    return launch_softcorr_f16(f1, f2, n1, n2, B, N, M, neg_alpha, 10, val12, idx12, nullptr, nullptr, val21, idx21, nullptr, nullptr,
                                 amax, bws, ws_bytes - ar.off, s);
 }
 
@@ -667,7 +667,7 @@ DVM_EXPORT int dvm_rownorm2_f32(const float *x, int rows, int K, float *out, voi
 
 DVM_EXPORT size_t dvm_softcorr_workspace_bytes(int B, int N, int M, int d) {
     return align_up((size_t)B * N * sizeof(float)) + align_up((size_t)B * M * sizeof(float)) +
-           (d == MF_D ? align_up(514 * sizeof(int)) + softcorr_bf16_ws_bytes(B, N, M, false) : 0);
+           (d == MF_D ? align_up(514 * sizeof(int)) + softcorr_f16_ws_bytes(B, N, M, false) : 0);
 }
 
 DVM_EXPORT int dvm_softcorr_fwd_f32(const float *f1, const float *f2, int B, int N, int M, int d, float neg_alpha,
@@ -708,10 +708,10 @@ DVM_EXPORT int dvm_softcorr_fwd_f32(const float *f1, const float *f2, int B, int
         launch_rownorm2_absmax(f1, B * N, n1, slots, s);
         launch_rownorm2_absmax(f2, B * M, n2, slots + 256, s);
         launch_absmax_finalize(slots, 2, amax, s);
-        int rc = launch_softcorr_bf16(f1, f2, n1, n2, B, N, M, neg_alpha, topk, pi_val, pi_idx, row_smax, row_sum, nullptr, nullptr,
+        int rc = launch_softcorr_f16(f1, f2, n1, n2, B, N, M, neg_alpha, topk, pi_val, pi_idx, row_smax, row_sum, nullptr, nullptr,
                                       nullptr, nullptr, amax, bws, ws_bytes - ar.off, s);
         if (rc != DVM_OK) return rc;
-        DVM_CHECK_LAUNCH("softcorr (bf16)");
+        DVM_CHECK_LAUNCH("softcorr (fp16)");
         return DVM_OK;
     }
     launch_rownorm2(f1, B * N, d, n1, s);

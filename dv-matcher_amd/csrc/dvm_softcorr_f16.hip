@@ -1,4 +1,4 @@
-// dvm_softcorr_bf16.hip — the soft-correspondence kernel (K1) on the 16-bit matrix cores, exact results.
+// dvm_softcorr_f16.hip — the soft-correspondence kernel (K1) on the 16-bit matrix cores, exact results.
 //
 // gfx950's fp32 MFMA runs at the vector rate on the vector ALUs; the 16-bit MFMA is a separate
 // pipe and 16x faster.  The N x M distance sweep is done on an exact 2-way fp16 split of the (power-of-two
@@ -165,7 +165,7 @@ struct HBArgs {
 };
 
 template <bool LEAN>
-__global__ __launch_bounds__(HB_THREADS, 2) void softcorr_bf16_kernel(const HBArgs args) {
+__global__ __launch_bounds__(HB_THREADS, 2) void softcorr_sweep_f16_kernel(const HBArgs args) {
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
     char *const ktile0 = smem_b;                                             // [2][HB_KT][512], 16-B chunks XOR-swizzled
     float *const knorm0 = (float *)(smem_b + (size_t)2 * HB_KT * HB_ROWB);   // [2][HB_KT]
@@ -592,8 +592,8 @@ __global__ __launch_bounds__(256) void softcorr_exact_rows_kernel(const HXArgs a
 
 }  // namespace
 
-// workspace of the bf16 path for (B, N, M): planes of both sides, candidates of both directions, flags
-size_t softcorr_bf16_ws_bytes(int B, int N, int M, bool both) {
+// workspace of the fp16 path for (B, N, M): planes of both sides, candidates of both directions, flags
+size_t softcorr_f16_ws_bytes(int B, int N, int M, bool both) {
     const size_t Np = (size_t)(N + HB_KT - 1) / HB_KT * HB_KT, Mp = (size_t)(M + HB_KT - 1) / HB_KT * HB_KT;
     size_t n = align_up((size_t)B * N * HB_ROWB) + align_up((size_t)B * M * HB_ROWB) + 2 * align_up((size_t)B * sizeof(float)) +
                align_up(2 * sizeof(int)) + align_up(B * Np * sizeof(float)) + align_up(B * Mp * sizeof(float));
@@ -608,7 +608,7 @@ size_t softcorr_bf16_ws_bytes(int B, int N, int M, bool both) {
 
 // f1 [B][N][128], f2 [B][M][128] with norms n1, n2; direction 0 = rows of f1 against f2; direction 1 (optional) the
 // reverse.  Outputs as the fp32 kernel: top-`topk` values/columns (topk <= 10), optional row stats.
-int launch_softcorr_bf16(const float *f1, const float *f2, const float *n1, const float *n2, int B, int N, int M, float neg_alpha,
+int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const float *n2, int B, int N, int M, float neg_alpha,
                          int topk, float *val12, int32_t *idx12, float *smax12, float *sum12, float *val21, int32_t *idx21,
                          float *smax21, float *sum21, const int *amax_in, void *ws, size_t ws_bytes, hipStream_t s) {
     const bool both = val21 != nullptr;
@@ -629,7 +629,7 @@ int launch_softcorr_bf16(const float *f1, const float *f2, const float *n1, cons
         flag[d] = ar.take<int32_t>(R + 1);  // [0] = counter, [1..] = rows
     }
     if (!ar.ok()) {
-        set_error("softcorr (bf16 path): workspace too small (%zu < %zu)", ws_bytes, ar.off);
+        set_error("softcorr (fp16 path): workspace too small (%zu < %zu)", ws_bytes, ar.off);
         return DVM_ENOSPACE;
     }
     const long r1 = (long)B * N, r2 = (long)B * M;
@@ -655,17 +655,17 @@ int launch_softcorr_bf16(const float *f1, const float *f2, const float *n1, cons
     const int blocks = a.blocks0 + (both ? B * a.g[1].tiles : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)softcorr_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void *)softcorr_sweep_f16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)HB_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void *)softcorr_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void *)softcorr_sweep_f16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)HB_LDS_BYTES);
         attr_set = true;
     }
     prof_begin(s);
     if (-neg_alpha >= 32.f)
-        hipLaunchKernelGGL(softcorr_bf16_kernel<true>, dim3(blocks), dim3(HB_THREADS), HB_LDS_BYTES, s, a);
+        hipLaunchKernelGGL(softcorr_sweep_f16_kernel<true>, dim3(blocks), dim3(HB_THREADS), HB_LDS_BYTES, s, a);
     else
-        hipLaunchKernelGGL(softcorr_bf16_kernel<false>, dim3(blocks), dim3(HB_THREADS), HB_LDS_BYTES, s, a);
+        hipLaunchKernelGGL(softcorr_sweep_f16_kernel<false>, dim3(blocks), dim3(HB_THREADS), HB_LDS_BYTES, s, a);
     prof_end(s);
 
     HRArgs r;
