@@ -218,6 +218,99 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const float *__restric
     for (int t = tid; t < k; t += 256) idx[row * k + t] = (int32_t)(sel[t] & 0xffffffffu);
 }
 
+// k <= 64: one WAVE per row, no workgroup barriers (the block kernel above spends ~50 of them per row).
+//   1. every lane keeps its EPL keys (columns e*64 + lane) and their two smallest;
+//   2. Tc = the k-th smallest of those 128 lane minima, by a 32-step bit search with ballots: an upper bound of the
+//      row's k-th smallest key, and tight (it is exact unless some lane holds three of the row's k best);
+//   3. the keys <= Tc (about k of them) are compacted in column order into (key << 32 | column) words and bitonic-
+//      sorted across the wave; the first k are the answer, ties already in column order.
+//   If more than 128 keys pass (heavy ties) the exact k-th key is searched over all keys instead and only the
+//   winners are compacted.
+template <int EPL>
+__global__ __launch_bounds__(256) void topk_wave_kernel(const float *__restrict__ S, int M, int k, long rows,
+                                                        int32_t *__restrict__ idx) {
+    __shared__ unsigned long long cand[4][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const float *s = S + row * M;
+    unsigned key[EPL];
+    unsigned m1 = 0xffffffffu, m2 = 0xffffffffu;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int j = e * 64 + lane;
+        const unsigned x = j < M ? desc_key(s[j]) : 0xffffffffu;
+        key[e] = x;
+        m2 = min(m2, max(m1, x));
+        m1 = min(m1, x);
+    }
+    unsigned T = 0;
+    for (int bit = 31; bit >= 0; --bit) {  // largest T with count(minima < T) < k  ==  their k-th smallest
+        const unsigned c = T | (1u << bit);
+        const int cnt = __popcll(__ballot(m1 < c)) + __popcll(__ballot(m2 < c));
+        if (cnt < k) T = c;
+    }
+    int C = 0;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) C += __popcll(__ballot(key[e] <= T));
+    int ties = 0x7fffffff;  // how many keys == T may be taken (fast path: all of them, the sort decides)
+    if (C > 128) {          // heavy ties: exact k-th key over all keys, then only the winners
+        T = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned c = T | (1u << bit);
+            int cnt = 0;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) cnt += __popcll(__ballot(key[e] < c));
+            if (cnt < k) T = c;
+        }
+        int lt = 0;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) lt += __popcll(__ballot(key[e] < T));
+        ties = k - lt;
+    }
+    unsigned long long *cw = cand[wave];
+    cw[lane] = ~0ull;
+    cw[lane + 64] = ~0ull;
+    int base = 0, tbase = 0;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const bool eq = key[e] == T;
+        const unsigned long long meq = __ballot(eq);
+        const int teq = tbase + __popcll(meq & ((1ull << lane) - 1ull));  // this key's rank among the ties, column order
+        const bool take = key[e] < T || (eq && teq < ties);
+        const unsigned long long mt = __ballot(take);
+        if (take) cw[base + __popcll(mt & ((1ull << lane) - 1ull))] = ((unsigned long long)key[e] << 32) | (unsigned)(e * 64 + lane);
+        base += __popcll(mt);
+        tbase += __popcll(meq);
+    }
+    // bitonic sort of 128 words, element i = lane + 64 * slot (LDS operations of one wave execute in order)
+    unsigned long long a0 = cw[lane], a1 = cw[lane + 64];
+    const bool small = base <= 64;  // everything sits in slot 0 then (slot 1 is all ~0)
+    for (int size = 2; size <= (small ? 64 : 128); size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (stride == 64) {  // partner is the other slot of this lane; i = lane (slot 0) is the lower index, ascending
+                const unsigned long long lo = a0 < a1 ? a0 : a1, hi = a0 < a1 ? a1 : a0;
+                a0 = lo, a1 = hi;
+            } else {
+                const bool lower = (lane & stride) == 0;
+#pragma unroll
+                for (int slot = 0; slot < 2; ++slot) {
+                    if (slot == 1 && small) break;
+                    unsigned long long &x = slot ? a1 : a0;
+                    const int i = lane + 64 * slot;
+                    const bool up = (i & size) == 0 || size == 128;
+                    const unsigned long long y =
+                        ((unsigned long long)__shfl_xor((unsigned)(x >> 32), stride, 64) << 32) | __shfl_xor((unsigned)x, stride, 64);
+                    const bool keep_min = (lower == up);
+                    x = keep_min ? (x < y ? x : y) : (x < y ? y : x);
+                }
+            }
+        }
+    }
+    if (lane < k) idx[row * k + lane] = (int32_t)(unsigned)a0;
+    if (!small && lane + 64 < k) idx[row * k + lane + 64] = (int32_t)(unsigned)a1;
+}
+
 // ============================================================== positional encoding
 __global__ void minmax_partial_kernel(const float *__restrict__ x, long n, float *__restrict__ part) {
     __shared__ float smn[256], smx[256];
@@ -599,6 +692,17 @@ int launch_knn_neg(const float *a, const float *bq, int B, int N, int M, int C, 
                            M, S);
     else
         hipLaunchKernelGGL(knn_scores_scalar_kernel, dim3((N + 127) / 128, B), dim3(128), 0, s, a, bq, na, nb, N, M, C, S);
+    if (k <= 64 && M <= 8192) {
+        const long rows = (long)B * N;
+        const dim3 wgrid((unsigned)((rows + 3) / 4));
+        if (M <= 2048)
+            hipLaunchKernelGGL(topk_wave_kernel<32>, wgrid, dim3(256), 0, s, S, M, k, rows, idx);
+        else if (M <= 4096)
+            hipLaunchKernelGGL(topk_wave_kernel<64>, wgrid, dim3(256), 0, s, S, M, k, rows, idx);
+        else
+            hipLaunchKernelGGL(topk_wave_kernel<128>, wgrid, dim3(256), 0, s, S, M, k, rows, idx);
+        return DVM_OK;
+    }
     int ept = (M + 255) / 256;
     dim3 grid((unsigned)((size_t)B * N));
     if (ept <= 8)

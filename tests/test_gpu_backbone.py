@@ -342,3 +342,15 @@ def test_deform_driver_fused_equals_reference_sequence(tmp_path, ops):
     pa, pb = read_off(os.path.join(a, "deform_s000a_s000b.off")), read_off(os.path.join(b, "deform_s000a_s000b.off"))
     assert pa.shape == (256, 3)
     np.testing.assert_allclose(pa, pb, rtol=0, atol=1e-4)
+
+
+def test_knn_neg_heavy_ties(ops):
+    """Small-integer features make most scores collide: the wave top-k's tie paths (more than 128 keys at the
+    threshold -> exact k-th key search, ties taken in column order) against the oracle, k <= 64 and k > 64."""
+    g = torch.Generator().manual_seed(12)
+    for (N, M, C, k) in [(40, 700, 64, 40), (33, 2048, 128, 64), (20, 2500, 64, 17), (16, 300, 64, 100)]:
+        a = torch.randint(-1, 2, (1, N, C), generator=g).float()
+        b = torch.randint(-1, 2, (1, M, C), generator=g).float()
+        b[0, M // 2:] = b[0, : M - M // 2]   # every key twice
+        idx = host(ops.knn_neg(a.cuda(), b.cuda(), k))[0]
+        assert np.array_equal(idx, O.knn_neg(a[0].numpy(), b[0].numpy(), k)), (N, M, C, k)
