@@ -354,3 +354,25 @@ def test_knn_neg_heavy_ties(ops):
         b[0, M // 2:] = b[0, : M - M // 2]   # every key twice
         idx = host(ops.knn_neg(a.cuda(), b.cuda(), k))[0]
         assert np.array_equal(idx, O.knn_neg(a[0].numpy(), b[0].numpy(), k)), (N, M, C, k)
+
+
+def test_geodesic_eval_uses_the_exact_map(ops):
+    """SURVEY §8d 'geodesic error': identical features give error 0; the device map equals the oracle's, so the
+    geodesic error of any feature pair equals the one computed from the oracle's map."""
+    sys.path.insert(0, os.path.join(ROOT, "dv-matcher_amd"))
+    import eval_geodesic as eg
+    rng = np.random.default_rng(3)
+    n = 8
+    xs, ys = np.meshgrid(np.arange(n, dtype=np.float64), np.arange(n, dtype=np.float64), indexing="ij")
+    verts = np.stack([xs.ravel(), ys.ravel(), 0.1 * rng.standard_normal(n * n)], 1)
+    faces = np.array([[i * n + j, (i + 1) * n + j, i * n + j + 1] for i in range(n - 1) for j in range(n - 1)] +
+                     [[(i + 1) * n + j, (i + 1) * n + j + 1, i * n + j + 1] for i in range(n - 1) for j in range(n - 1)])
+    M = eg.geodesic_distmat(verts, faces)
+    phi = rng.standard_normal((n * n, 128)).astype(np.float32)
+    lm = np.arange(n * n)
+    assert eg.mean_geodesic_error(phi, phi, lm, lm, M) == 0.0
+    noisy = (phi + 0.9 * rng.standard_normal(phi.shape)).astype(np.float32)
+    T = eg.match(noisy, phi)
+    To, _ = O.argmin_exact(noisy, phi)
+    assert np.array_equal(T, To)
+    assert eg.mean_geodesic_error(noisy, phi, lm, lm, M) == float(eg.geodesic_errors(To, lm, lm, M).mean())

@@ -80,3 +80,32 @@ def test_torch_ref_n2p(golden, name, C, mode):
         y = blk.bn1(x + att)
         out = blk.bn2(y + blk.ff(y))
     np.testing.assert_allclose(out.numpy(), g["out"], rtol=0, atol=2e-5)
+
+
+def test_geodesic_eval_host_side():
+    """eval/geo_mat.py + eval/main.m restatement (host parts): a flat 6 x 6 grid mesh — edge-path geodesics, area
+    normalisation, and the error of a map that is exact except for two landmarks."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dv-matcher_amd"))
+    import eval_geodesic as eg
+    n = 6
+    xs, ys = np.meshgrid(np.arange(n, dtype=np.float64), np.arange(n, dtype=np.float64), indexing="ij")
+    verts = np.stack([xs.ravel(), ys.ravel(), np.zeros(n * n)], 1)
+    vid = lambda i, j: i * n + j
+    faces = []
+    for i in range(n - 1):
+        for j in range(n - 1):
+            faces += [[vid(i, j), vid(i + 1, j), vid(i, j + 1)], [vid(i + 1, j), vid(i + 1, j + 1), vid(i, j + 1)]]
+    faces = np.array(faces)
+    assert abs(eg.mesh_area(verts, faces) - 25.0) < 1e-12
+    M = eg.geodesic_distmat(verts, faces, normalize=False)
+    assert abs(M[vid(0, 0), vid(0, 5)] - 5.0) < 1e-12           # along an edge row
+    assert abs(M[vid(0, 0), vid(5, 0)] - 5.0) < 1e-12
+    assert abs(M[vid(0, 5), vid(5, 0)] - 5.0 * np.sqrt(2)) < 1e-9  # the mesh diagonals run that way
+    Mn = eg.geodesic_distmat(verts, faces)
+    assert np.allclose(Mn, M / 5.0)
+    T = np.arange(n * n)
+    T[3], T[10] = 4, 16                                           # two wrong matches, one edge away each
+    lm = np.arange(n * n)
+    err = eg.geodesic_errors(T, lm, lm, Mn)
+    assert np.count_nonzero(err) == 2 and abs(err.sum() - 2 * (1.0 / 5.0)) < 1e-12
