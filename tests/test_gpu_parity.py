@@ -199,7 +199,7 @@ def _pair_inputs(B, N, M, seed):
     return f1, f2, v1, v2, start
 
 
-@pytest.mark.parametrize("shape", [(2, 256, 256), (2, 300, 170), (1, 1024, 1024)])
+@pytest.mark.parametrize("shape", [(2, 256, 256), (2, 300, 170), (1, 1024, 1024), (1, 2200, 4995), (1, 4995, 2200)])
 def test_pair_direction_vs_oracle(ops, golden, shape):
     B, N, M = shape
     w = golden("deformer_scape_r_weights")
