@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=256, help="pairs per GPU per step (resident batch)")
+    ap.add_argument("--pairs", type=int, default=512, help="pairs per GPU per step (resident batch)")
     ap.add_argument("--cpu-sample", type=int, default=48, help="pairs timed for cpu_baseline (0 = skip)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="per-launch HBM bytes of the dominant kernel from the PMC passes (default: profiles/k1_traffic.json)")
@@ -156,8 +156,10 @@ def main():
         # once per direction, i.e. performs twice that)
         traffic = args.traffic_bytes
         tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
-        if traffic is None and P == 256 and os.path.exists(tpath):  # measured for this exact launch shape
-            traffic = json.load(open(tpath)).get("bytes_per_launch")
+        if traffic is None and os.path.exists(tpath):  # measured for one exact launch shape
+            tj = json.load(open(tpath))
+            if tj.get("pairs") == P:
+                traffic = tj.get("bytes_per_launch")
         k1_ms = ms.value / max(nl.value, 1)
         flops_launch = P * (2.0 * N_PTS * M_PTS * DIM)
         achieved = flops_launch / (k1_ms * 1e-3) / 1e12 if k1_ms > 0 else 0.0
