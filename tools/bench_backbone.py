@@ -1,0 +1,18 @@
+"""Uni3FC forward (eval) throughput: B shapes of N points with supplied 1152-d visual features."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "dv-matcher_amd"))
+import torch
+from models.model import Uni3FC
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+torch.manual_seed(0)
+net = Uni3FC(k=40).cuda().eval()
+x = torch.rand(B, 3, N).cuda(); dino = torch.randn(B, N, 1152).cuda()
+with torch.no_grad():
+    for _ in range(3): net(x, dino, None)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(reps): net(x, dino, None)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t) / reps
+print("Uni3FC eval forward: B=%d N=%d: %.2f ms (%.1f shapes/s)" % (B, N, dt * 1e3, B / dt))
