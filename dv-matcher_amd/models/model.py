@@ -55,6 +55,22 @@ class PointwiseConv1d(nn.Conv1d):
         return y if self.bias is None else y + self.bias[:, None]
 
 
+def _bn_affine(bn):
+    """Eval-mode BatchNorm as y = x * s + t (per channel)."""
+    s = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+    return s, bn.bias - bn.running_mean * s
+
+
+def _conv_bn_pm(conv, bn, xt, act=None):
+    """Inference, point-major: 1x1 conv with the eval-mode BatchNorm folded into its weights — ONE (B*N) x Cin x Cout
+    GEMM with bias — then the activation.  xt (B,N,Cin) -> (B,N,Cout)."""
+    s, t = _bn_affine(bn)
+    w = conv.weight[:, :, 0] * s[:, None]
+    b = t if conv.bias is None else conv.bias * s + t
+    y = F.linear(xt, w, b)
+    return y if act is None else act(y)
+
+
 # ------------------------------------------------------------------ attention blocks
 class SA_Layer(nn.Module):
     """Offset self-attention with shared q/k weights and column re-normalisation."""
@@ -76,6 +92,13 @@ class SA_Layer(nn.Module):
     def forward(self, x):
         x_r = nn_ops.sa_attention(x, self.k_conv.weight, self.v_conv.weight, self.v_conv.bias)
         return x + self.act(self.after_norm(self.trans_conv(x - x_r)))
+
+    def infer_pm(self, xt):
+        """Inference on point-major activations (B,N,64): no transposes, BatchNorm folded into trans_conv."""
+        p = F.linear(xt, self.k_conv.weight[:, :, 0])
+        v = F.linear(xt, self.v_conv.weight[:, :, 0], self.v_conv.bias)
+        x_r = ops.sa_attention_pm(p, v)
+        return xt + _conv_bn_pm(self.trans_conv, self.after_norm, xt - x_r, self.act)
 
 
 class _N2P(nn.Module):
@@ -99,6 +122,20 @@ class _N2P(nn.Module):
         att = nn_ops.n2p_attention(x, self.K, self.q_conv.weight, self.k_conv.weight, self.v_conv.weight, self.heads)
         x = self.bn1(x + att)
         return self.bn2(x + self.ff(x))
+
+    def infer_pm(self, xt):
+        """Inference on point-major activations (B,N,C): q/k/v by ONE GEMM, gather-attention on the HIP kernel, the two
+        eval-mode BatchNorms as per-channel affines."""
+        C = xt.shape[-1]
+        xt = xt.contiguous()
+        idx = ops.knn_neg(xt, xt, self.K)
+        w = torch.cat([self.q_conv.weight.reshape(C, C), self.k_conv.weight.reshape(C, C), self.v_conv.weight.reshape(C, C)], 0)
+        att = ops.n2p_core_fwd(F.linear(xt, w), idx, self.heads)[0]
+        s1, t1 = _bn_affine(self.bn1)
+        xt = torch.addcmul(t1, xt + att, s1)
+        ff = F.linear(self.ff[1](F.linear(xt, self.ff[0].weight[:, :, 0])), self.ff[2].weight[:, :, 0])
+        s2, t2 = _bn_affine(self.bn2)
+        return torch.addcmul(t2, xt + ff, s2)
 
     @staticmethod
     def split_heads(x, heads):
@@ -208,12 +245,41 @@ class Uni3FC(nn.Module):
         """64-octave sin/cos encoding of the batch-normalised coordinates: (B,3,N) -> (B,384,N)."""
         return nn_ops.pos_encoding(coor)
 
+    def _forward_infer(self, x, dino_feat):
+        """Eval-mode forward with activations kept point-major (B,N,C): every conv + BatchNorm is one GEMM with bias,
+        neighbour rows are contiguous for the gather kernels, nothing is transposed between layers.  (Training keeps the
+        reference's (B,C,N) layout: there MIOpen's BatchNorm kernels want it and the step is GEMM/launch-bound.)"""
+        B, _, N = x.shape
+        with torch.no_grad():
+            lrelu = lambda y: F.leaky_relu(y, 0.2)  # noqa: E731
+            blk = lambda seq, xt: _conv_bn_pm(seq[0], seq[1], xt, lrelu)  # noqa: E731
+            f = blk(self.conv, dino_feat)
+            tmp = blk(self.conv0, f + self.pos_encoding_sin_wave(x).transpose(1, 2))
+            x1, x1g = self.n2p_attention1.infer_pm(tmp), self.sa1.infer_pm(tmp)
+            x2, x2g = self.n2p_attention2.infer_pm(x1), self.sa2.infer_pm(x1g)
+            x3, x3g = self.n2p_attention3.infer_pm(x2), self.sa3.infer_pm(x2g)
+            x4, x4g = self.n2p_attention4.infer_pm(x3), self.sa4.infer_pm(x3g)
+            loc = torch.cat((x1, x2, x3, x4), dim=-1)
+            glo = torch.cat((x1g, x2g, x3g, x4g), dim=-1)
+            lmax = blk(self.conv1, loc).max(dim=1, keepdim=True)[0].expand(-1, N, -1)
+            gmax = blk(self.conv2, glo).max(dim=1, keepdim=True)[0].expand(-1, N, -1)
+            y = torch.cat((blk(self.conv3, torch.cat((lmax, loc), dim=-1)), blk(self.conv4, torch.cat((gmax, glo), dim=-1))), dim=-1)
+            y1 = blk(self.conv5, y)
+            y2 = self.n2p_attention5.infer_pm(y1)
+            y3 = self.n2p_attention6.infer_pm(y2)
+            y4 = self.n2p_attention7.infer_pm(y3)
+            out = blk(self.conv6, torch.cat((y1, y2, y3, y4), dim=-1))
+            return out.contiguous().view(B, N, self.out), tmp
+
     def forward(self, x, dino_feat, upsampler=None):
         """x (B,3,N), dino_feat (B,N,1152) -> (feat (B,N,128), cfeats (B,N,64))."""
         if dino_feat is None:
             raise NotImplementedError("the point->image->DINOv2 projection branch is outside this path "
                                       "(SURVEY §8f-1); pass per-point visual features as dino_feat")
         B, _, N = x.shape
+        if not self.training and not (torch.is_grad_enabled() and (dino_feat.requires_grad or x.requires_grad)) \
+                and PointwiseConv1d.accumulate == "f32":
+            return self._forward_infer(x, dino_feat)
         f = self.conv(dino_feat.permute(0, 2, 1))
         tmp = self.conv0(f + self.pos_encoding_sin_wave(x))
         x1 = self.n2p_attention1(tmp)

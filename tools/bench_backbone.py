@@ -16,3 +16,21 @@ with torch.no_grad():
     for _ in range(reps): net(x, dino, None)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t) / reps
 print("Uni3FC eval forward: B=%d N=%d: %.2f ms (%.1f shapes/s)" % (B, N, dt * 1e3, B / dt))
+if len(sys.argv) > 4 and sys.argv[4] == "graph":
+    # the same forward captured into a HIP graph (launch-bound at B = 1: ~250 launches per forward)
+    sx, sd = x.clone(), dino.clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s), torch.no_grad():
+        for _ in range(3): net(sx, sd, None)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.graph(g):
+        out = net(sx, sd, None)
+    ref = net(x, dino, None)[0]
+    g.replay(); torch.cuda.synchronize()
+    print("graph replay equals eager:", bool(torch.equal(out[0], ref)))
+    t = time.perf_counter()
+    for _ in range(reps): g.replay()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t) / reps
+    print("  as a HIP graph: %.2f ms (%.1f shapes/s)" % (dt * 1e3, B / dt))
