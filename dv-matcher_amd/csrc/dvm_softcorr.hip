@@ -269,9 +269,6 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
     return base + orig / 8;
 }
 
-#ifdef DVM_COUNT_ITERS
-__device__ unsigned long long g_dbg_counters[4];
-#endif
 
 // One launch covers up to two "groups" (the two directions of a pair batch: (f1 -> f2) and
 // (f2 -> f1)), each with its own query/key tensors and outputs.
@@ -382,9 +379,6 @@ __global__ __launch_bounds__(MF_THREADS, 2) void softcorr_mfma_kernel(const SCAr
     auto mfma_chain = [&](const float *kt, int sub, f32x16 &acc, float (&nbv)[16], int buf) {
         const float *arow = kt + (sub * 32 + r32) * MF_LDK + h * 64;
         acc = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#ifdef DVM_ABL_NOMFMA
-        for (int c = 0; c < 16; ++c) acc[c] = arow[4 * c] * q[c] + 100.f + (float)c;
-#else
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             f32x4 a = *(const f32x4 *)(arow + 4 * c);
@@ -393,7 +387,6 @@ __global__ __launch_bounds__(MF_THREADS, 2) void softcorr_mfma_kernel(const SCAr
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, q[4 * c + 2], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, q[4 * c + 3], acc, 0, 0, 0);
         }
-#endif
         // |key|^2 of this lane's 16 keys: local key = (r&3) + 8*(r>>2) + 4*h
         const float *kn = knorm0 + buf * MF_KT + sub * 32 + 4 * h;
 #pragma unroll
@@ -413,10 +406,6 @@ __global__ __launch_bounds__(MF_THREADS, 2) void softcorr_mfma_kernel(const SCAr
     float lim2 = INFINITY;
     const float cutw = args.cutw;
     auto epilogue = [&](const f32x16 &acc, const float (&nbv)[16], int jbase) {
-#ifdef DVM_ABL_NOEPI
-        for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[r]), "v"(nbv[r]));
-        return;
-#endif
         unsigned mask = 0;
         float c2 = 0.f;
         if (LEAN) {
@@ -455,14 +444,10 @@ __global__ __launch_bounds__(MF_THREADS, 2) void softcorr_mfma_kernel(const SCAr
         }
         // Branch-free body (inactive lanes process +inf, a no-op): keeps the top-k registers in place
         // instead of copying them around a divergent region every iteration.
-#ifdef DVM_COUNT_ITERS
-        if (lane == 0) atomicAdd(&g_dbg_counters[1], 1ull);
-        atomicAdd(&g_dbg_counters[2], (unsigned long long)__popc(mask));
-#endif
-        while (__any(mask != 0)) {
-#ifdef DVM_COUNT_ITERS
-            if (lane == 0) atomicAdd(&g_dbg_counters[0], 1ull);
-#endif
+        // (counted, wave-uniform trip count: a `while (__any(mask))` loop makes the compiler copy the whole list — 60
+        // v_mov — around a structurised exit on every iteration)
+        const int iters = (int)__reduce_max_sync(~0ull, (unsigned)__popc(mask));
+        for (int it = 0; it < iters; ++it) {
             const bool act = mask != 0;
             const int bpos = act ? (__ffs(mask) - 1) : 0;
             mask &= mask - 1;
@@ -787,12 +772,3 @@ DVM_EXPORT int dvm_softcorr_dense_f32(const float *f1, const float *f2, int B, i
     return DVM_OK;
 }
 
-#ifdef DVM_COUNT_ITERS
-DVM_EXPORT int dvm_debug_counters(unsigned long long *out4) {
-    hipDeviceSynchronize();
-    hipMemcpyFromSymbol(out4, HIP_SYMBOL(dvm::g_dbg_counters), 32);
-    unsigned long long z[4] = {0, 0, 0, 0};
-    hipMemcpyToSymbol(HIP_SYMBOL(dvm::g_dbg_counters), z, 32);
-    return 0;
-}
-#endif
