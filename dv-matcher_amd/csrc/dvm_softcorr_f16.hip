@@ -416,12 +416,19 @@ __global__ __launch_bounds__(256) void softcorr_refine_kernel(const HRArgs args)
     const float na = G.nq[row];
     // (bandwidth-bound on the 12 x 512 B gathered rows per query — 3.2 GB per 256 pairs; staging them through LDS
     // as whole 128-B segments was measured slower than each lane streaming its own row)
-    float v = INFINITY, va = INFINITY;
-    if (valid) {
-        v = exact_d2(G.q + (size_t)row * HB_D, G.k + ((size_t)b * M + j) * HB_D, na, G.nk[(size_t)b * M + j]);
-        va = G.cd2[row * HB_KC + l16];
-    }
-    const float de = valid ? sqrt_rn(v) : INFINITY;
+    const int topk = args.topk;
+    const int need = topk < M ? topk : M;        // entries that must be exact
+    const float delta = HB_ERR * (na + G.nkmax[b]);
+    const float va = valid ? G.cd2[row * HB_KC + l16] : INFINITY;
+    // Candidates beyond the `need`-th whose approximate distance exceeds the need-th's by more than the error band
+    // cannot rank among the first `need` (their exact value is above every one of those): their rows are not fetched
+    // (usually the two margin candidates: 1/6 of the gather) and they keep their approximate softmax term.
+    const float va_need = __shfl(va, base + need - 1, 64);
+    const bool skip = valid && l16 >= need && va > va_need + 2.f * delta;
+    const bool eval = valid && !skip;
+    float v = INFINITY;
+    if (eval) v = exact_d2(G.q + (size_t)row * HB_D, G.k + ((size_t)b * M + j) * HB_D, na, G.nk[(size_t)b * M + j]);
+    const float de = eval ? sqrt_rn(v) : INFINITY;
     int rank = 0;
 #pragma unroll
     for (int t = 0; t < HB_KC; ++t) {
@@ -429,37 +436,36 @@ __global__ __launch_bounds__(256) void softcorr_refine_kernel(const HRArgs args)
         const int jt = __shfl(j, base + t, 64);
         rank += (dt < de || (dt == de && jt < j)) ? 1 : 0;
     }
-    // exact softmax terms relative to the exact maximum; swap the candidates' approximate terms for them
+    // exact softmax terms relative to the exact maximum (pass A's sum covers exactly the columns outside the list)
     float dmin = de;
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) dmin = fminf(dmin, __shfl_xor(dmin, o, 64));
     const float smax = dmin * neg_alpha;
-    const float s = de * neg_alpha;
+    const float s = (eval ? de : __builtin_amdgcn_sqrtf(fmaxf(va, 0.f))) * neg_alpha;
     const float ex = valid ? exp2f((s - smax) * LOG2E) : 0.f;
     float esum = ex;
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) esum += __shfl_xor(esum, o, 64);
-    // pass A's sum covers exactly the columns outside the candidate list
     const float lsm = G.lsum[row * 2] * exp2f((G.lsum[row * 2 + 1] - smax) * LOG2E) + esum;
-    // certification: every column outside the candidate set has approximate d2 >= theta = the worst kept one
-    const int topk = args.topk;
-    const int need = topk < M ? topk : M;        // entries that must be exact
+    // certification: every column that was not evaluated exactly — outside the list, or skipped — has approximate
+    // d2 >= theta
     float vlast = (rank == need - 1) ? v : -INFINITY;  // exact d2 of the last needed entry
-    float theta = va;                                   // max over valid candidates = approximate KC-th best
-    if (!valid) theta = -INFINITY;
+    float tmax = valid ? va : -INFINITY;                // approximate KC-th best
+    float tskip = skip ? va : INFINITY;
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) {
         vlast = fmaxf(vlast, __shfl_xor(vlast, o, 64));
-        theta = fmaxf(theta, __shfl_xor(theta, o, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, o, 64));
+        tskip = fminf(tskip, __shfl_xor(tskip, o, 64));
     }
-    const float delta = HB_ERR * (na + G.nkmax[b]);
+    const float theta = fminf(tmax, tskip);
     const bool certain = (M <= HB_KC) || (vlast < theta - 2.f * delta);
     if (!rvalid) return;
     if (!certain) {
         if (l16 == 0) G.flagged[atomicAdd(G.nflagged, 1)] = (int32_t)row;
         return;  // the exact kernel writes this row
     }
-    if (cand && rank < topk) {
+    if (cand && rank < topk && !skip) {
         G.val[row * topk + rank] = valid ? ex / lsm : 0.f;
         G.idx[row * topk + rank] = valid ? j : 0;
     }
