@@ -391,6 +391,56 @@ __global__ __launch_bounds__(256) void map_term_kernel(const float *__restrict__
     }
 }
 
+// Two-level gathers flattened (fused pair path): nbr[b][j][s][3] = verts[b][idx[b][j][s]] once per cloud, then the map
+// term reads ONE contiguous 12*k-byte row per correspondence instead of k (index, coordinate) pairs.
+__global__ void gather_nbr_xyz_kernel(const float *__restrict__ verts, const int32_t *__restrict__ idx, int M, int k,
+                                      float *__restrict__ nbr) {
+    const int b = blockIdx.y;
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (long)M * k) return;
+    const float *p = verts + ((size_t)b * M + idx[(size_t)b * M * k + g]) * 3;
+    float *o = nbr + ((size_t)b * M * k + g) * 3;
+    o[0] = p[0], o[1] = p[1], o[2] = p[2];
+}
+
+template <int TOPK>
+__global__ __launch_bounds__(256) void map_term_nbr_kernel(const float *__restrict__ verts12, const float *__restrict__ nbr2,
+                                                           const int32_t *__restrict__ idx11, const float *__restrict__ pi_val,
+                                                           const int32_t *__restrict__ pi_idx, int N, int M, int k, int topk,
+                                                           double *__restrict__ partial) {
+    const int b = blockIdx.y;
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    float e2 = 0.f;
+    if (g < (long)N * k) {
+        const int i = (int)(g / k), s = (int)(g % k);
+        const size_t row = (size_t)b * N + i;
+        const float *nb2 = nbr2 + (size_t)b * M * k * 3 + 3 * s;
+        float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < TOPK; ++t) {
+            if (t < topk) {
+                const float *p = nb2 + (size_t)pi_idx[row * topk + t] * k * 3;
+                const float w = pi_val[row * topk + t];
+                acc[0] = fmaf(w, p[0], acc[0]);
+                acc[1] = fmaf(w, p[1], acc[1]);
+                acc[2] = fmaf(w, p[2], acc[2]);
+            }
+        }
+        const float *p12 = verts12 + ((size_t)b * N + idx11[row * k + s]) * 3;
+        float e0 = p12[0] - acc[0], e1 = p12[1] - acc[1], e2c = p12[2] - acc[2];
+        e2 = (e0 * e0 + e1 * e1) + e2c * e2c;
+    }
+    __shared__ double red[256 / 64];
+    double w = wave_sum((double)e2);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sum = 0.0;
+        for (int q = 0; q < (int)(blockDim.x >> 6); ++q) sum += red[q];
+        partial[(size_t)b * gridDim.x + blockIdx.x] = sum;
+    }
+}
+
 // out[b] = scale * sum_q partial[b,q]   (one block per b, fixed order)
 __global__ void reduce_partials_kernel(const double *__restrict__ partial, int nparts, float scale, float *__restrict__ out,
                                        int out_stride, int out_off) {
@@ -611,6 +661,16 @@ int launch_chamfer_grouped(const float *const *a, const float *const *b, const i
     return DVM_OK;
 }
 int map_term_blocks(int N, int k) { return (int)(((long)N * k + 255) / 256); }
+void launch_gather_nbr_xyz(const float *verts, const int32_t *idx, int B, int M, int k, float *nbr, hipStream_t s) {
+    hipLaunchKernelGGL(gather_nbr_xyz_kernel, dim3((unsigned)(((long)M * k + 255) / 256), B), dim3(256), 0, s, verts, idx, M, k, nbr);
+}
+int launch_map_term_nbr(const float *verts12, const float *nbr2, const int32_t *idx11, const float *pi_val, const int32_t *pi_idx,
+                        int B, int N, int M, int k, int topk, double *partial, hipStream_t s) {
+    int nblk = map_term_blocks(N, k);
+    hipLaunchKernelGGL(map_term_nbr_kernel<10>, dim3(nblk, B), dim3(256), 0, s, verts12, nbr2, idx11, pi_val, pi_idx, N, M, k, topk,
+                       partial);
+    return DVM_OK;
+}
 int launch_map_term(const float *verts12, const float *verts2, const int32_t *idx11, const int32_t *idx22,
                     const float *pi_val, const int32_t *pi_idx, int B, int N, int M, int k, int topk, double *partial,
                     hipStream_t s) {

@@ -10,6 +10,9 @@ namespace dvm {
 int launch_mean(const float *in, int B, int n, float scale, float *out, int stride, int off, int accumulate, hipStream_t s);
 int launch_reduce_partials(const double *partial, int B, int nparts, float scale, float *out, int stride, int off, hipStream_t s);
 int map_term_blocks(int N, int k);
+void launch_gather_nbr_xyz(const float *verts, const int32_t *idx, int B, int M, int k, float *nbr, hipStream_t s);
+int launch_map_term_nbr(const float *verts12, const float *nbr2, const int32_t *idx11, const float *pi_val, const int32_t *pi_idx,
+                        int B, int N, int M, int k, int topk, double *partial, hipStream_t s);
 int launch_map_term(const float *verts12, const float *verts2, const int32_t *idx11, const int32_t *idx22, const float *pi_val,
                     const int32_t *pi_idx, int B, int N, int M, int k, int topk, double *partial, hipStream_t s);
 int launch_dg_build(const float *xyz, int B, int N, const int32_t *start, int32_t *nodes_idx, int32_t *ring, int32_t *infl_idx,
@@ -178,6 +181,7 @@ struct Pair2Ws {
     float *dists[2], *weights[2], *pval[2], *nrm[2], *gall[2];
     double *nnd[2], *partial[2];
     float *z, *def9, *R, *T, *wp;
+    float *nbrxyz[2];  // [B][P][10][3] coordinates of every point's xyz neighbours (map term)
     char *k1ws;  // soft-correspondence scratch (fp16 planes, candidates, flags)
     size_t k1ws_bytes;
     float *cd[8];
@@ -208,6 +212,7 @@ static size_t carve_pair2(Arena &ar, int B, int N, int M, Pair2Ws &w) {
     w.R = ar.take<float>(rows * 9);
     w.T = ar.take<float>(rows * 3);
     w.wp = ar.take<float>(mlp_pack_floats());
+    for (int sd = 0; sd < 2; ++sd) w.nbrxyz[sd] = ar.take<float>((size_t)B * P[sd] * 30);
     w.k1ws_bytes = softcorr_pair_ws_bytes(B, N, M);
     w.k1ws = ar.take<char>(w.k1ws_bytes);
     const int cdn[8] = {N, M, N, M, M, N, M, N};
@@ -363,9 +368,11 @@ DVM_EXPORT int dvm_pair_fwd_f32(const float *feat1, const float *feat2, const fl
     }
     // ---- map terms (losses[:,5])
     if (with_map) {
-        launch_map_term(verts12, verts2, w.idxk[0], w.idxk[1], w.pval[0], w.pidx[0], B, N, M, 10, 10, w.partial[0], s);
+        launch_gather_nbr_xyz(verts2, w.idxk[1], B, M, 10, w.nbrxyz[1], s);
+        launch_gather_nbr_xyz(verts1, w.idxk[0], B, N, 10, w.nbrxyz[0], s);
+        launch_map_term_nbr(verts12, w.nbrxyz[1], w.idxk[0], w.pval[0], w.pidx[0], B, N, M, 10, 10, w.partial[0], s);
         launch_reduce_partials(w.partial[0], B, map_term_blocks(N, 10), 1.f, losses12, 6, 5, s);
-        launch_map_term(verts21, verts1, w.idxk[1], w.idxk[0], w.pval[1], w.pidx[1], B, M, N, 10, 10, w.partial[1], s);
+        launch_map_term_nbr(verts21, w.nbrxyz[0], w.idxk[1], w.pval[1], w.pidx[1], B, M, N, 10, 10, w.partial[1], s);
         launch_reduce_partials(w.partial[1], B, map_term_blocks(M, 10), 1.f, losses21, 6, 5, s);
     } else {
         launch_mean(w.cd[0], B, 1, 0.f, losses12, 6, 5, 0, s);
