@@ -21,15 +21,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int DF_C = 128;
 
-// pooled[r,:] = sum_s w[s]*feat[idx[row(r),s],:] + bias ; row(r) = rowmap ? rowmap[r] : r
+// pooled[r,:] = sum_s w[s]*feat[idx[row(r),s],:] + bias ; row(r) = rowmap ? rowmap[r] : r.
+// order (optional, with rowmap == nullptr): a permutation of the points; thread group t handles point order[t] (and
+// writes its row) — in grid-cell order consecutive groups are spatial neighbours, their neighbour lists overlap and the
+// gathered rows hit in L1/L2.
 __global__ __launch_bounds__(256) void pool_kernel(const float *__restrict__ feat, const int32_t *__restrict__ idx,
                                                    const int32_t *__restrict__ rowmap, int P, int nrows, int k,
                                                    const float *__restrict__ cw, const float *__restrict__ cb,
-                                                   float *__restrict__ out, int out_stride, int out_off) {
+                                                   float *__restrict__ out, int out_stride, int out_off,
+                                                   const int32_t *__restrict__ order) {
     const int b = blockIdx.y;
     const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= (long)nrows * (DF_C / 4)) return;
-    const int r = (int)(g / (DF_C / 4)), c4 = (int)(g % (DF_C / 4));
+    int r = (int)(g / (DF_C / 4));
+    const int c4 = (int)(g % (DF_C / 4));
+    if (order) r = order[(size_t)b * nrows + r];
     const int v = rowmap ? rowmap[(size_t)b * nrows + r] : r;
     const float *fb = feat + (size_t)b * P * DF_C;
     const int32_t *ix = idx + ((size_t)b * P + v) * k;
@@ -355,9 +361,9 @@ int launch_deformer(const float *feat1, const float *feat2, const float *verts1,
     const int rows = B * Nn;
     // g2 for every target point; g1 only at the graph nodes (written straight into z[:,3:131])
     hipLaunchKernelGGL(pool_kernel, dim3((unsigned)(((long)M * 32 + 255) / 256), B), dim3(256), 0, s, feat2, idx22,
-                       (const int32_t *)nullptr, M, M, k, conv_w, conv_b, w.g2, DF_C, 0);
+                       (const int32_t *)nullptr, M, M, k, conv_w, conv_b, w.g2, DF_C, 0, (const int32_t *)nullptr);
     hipLaunchKernelGGL(pool_kernel, dim3((unsigned)(((long)Nn * 32 + 255) / 256), B), dim3(256), 0, s, feat1, idx11, fps1, N,
-                       Nn, k, conv_w, conv_b, w.z, DF_ZS, 3);
+                       Nn, k, conv_w, conv_b, w.z, DF_ZS, 3, (const int32_t *)nullptr);
     if (topk <= 10)
         hipLaunchKernelGGL(assemble_kernel<10>, dim3((unsigned)(((long)Nn * 32 + 255) / 256), B), dim3(256), 0, s, verts1,
                            verts12, w.g2, pi_val, pi_idx, fps1, N, M, Nn, topk, w.z);
@@ -388,9 +394,9 @@ __global__ void pad_rows_kernel(const float *__restrict__ in, int rows, int I, i
 }
 
 void launch_pool_all(const float *feat, const int32_t *idx, int B, int P, int k, const float *cw, const float *cb, float *out,
-                     hipStream_t s) {
+                     hipStream_t s, const int32_t *order) {
     hipLaunchKernelGGL(pool_kernel, dim3((unsigned)(((long)P * 32 + 255) / 256), B), dim3(256), 0, s, feat, idx,
-                       (const int32_t *)nullptr, P, P, k, cw, cb, out, DF_C, 0);
+                       (const int32_t *)nullptr, P, P, k, cw, cb, out, DF_C, 0, order);
 }
 void launch_assemble_pooled(const float *vsrc, const float *vcorr, const float *gsrc, const float *gtgt, const float *pi_val,
                             const int32_t *pi_idx, const int32_t *fps, int B, int N, int M, int Nn, float *z, hipStream_t s) {

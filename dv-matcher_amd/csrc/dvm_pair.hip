@@ -165,7 +165,7 @@ size_t softcorr_pair_ws_bytes(int B, int N, int M);
 int launch_softcorr_pair(const float *f1, const float *f2, float *n1, float *n2, int B, int N, int M, float neg_alpha, float *val12,
                          int32_t *idx12, float *val21, int32_t *idx21, void *ws, size_t ws_bytes, hipStream_t s);
 void launch_pool_all(const float *feat, const int32_t *idx, int B, int P, int k, const float *cw, const float *cb, float *out,
-                     hipStream_t s);
+                     hipStream_t s, const int32_t *order = nullptr);
 void launch_assemble_pooled(const float *vsrc, const float *vcorr, const float *gsrc, const float *gtgt, const float *pi_val,
                             const int32_t *pi_idx, const int32_t *fps, int B, int N, int M, int Nn, float *z, hipStream_t s);
 size_t mlp_pack_floats();
@@ -338,8 +338,8 @@ DVM_EXPORT int dvm_pair_fwd_f32(const float *feat1, const float *feat2, const fl
     if (rc != DVM_OK) return rc;
     if (overlap) (void)hipStreamWaitEvent(caller, ev_join, 0);  // join: everything below needs the graphs / kNN
     // ---- Deformer: pooled features once per cloud, z for both directions, one MLP launch
-    launch_pool_all(feat1, w.idxk[0], B, N, 10, conv_w, conv_b, w.gall[0], s);
-    launch_pool_all(feat2, w.idxk[1], B, M, 10, conv_w, conv_b, w.gall[1], s);
+    launch_pool_all(feat1, w.idxk[0], B, N, 10, conv_w, conv_b, w.gall[0], s, w.gv[0].ids);  // points in grid-cell order
+    launch_pool_all(feat2, w.idxk[1], B, M, 10, conv_w, conv_b, w.gall[1], s, w.gv[1].ids);
     const int Nn1 = N / 2, Nn2 = M / 2;
     float *z21 = w.z + (size_t)B * Nn1 * 264;
     launch_assemble_pooled(verts1, verts12, w.gall[0], w.gall[1], w.pval[0], w.pidx[0], w.nodes[0], B, N, M, Nn1, w.z, s);
