@@ -57,10 +57,16 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float *__restrict__ xy
             ArgMax c = {dist[q], tid + q * FPS_T};
             best = (c.v > best.v) ? c : best;  // ascending index within the thread: strict keeps the first
         }
-#pragma unroll
-        for (int ofs = 32; ofs > 0; ofs >>= 1) {
-            ArgMax o2 = {__shfl_xor(best.v, ofs, 64), __shfl_xor(best.i, ofs, 64)};
-            best = better(best, o2);
+        // wave arg-max by two DPP reductions (distances are >= 0 or -inf: order-preserving as sign-flipped integers):
+        // the largest value, then the lowest index among its holders — instead of six dependent (value, index)
+        // shuffle pairs through the LDS crossbar, which dominated this latency-bound loop
+        {
+            const int vb = __float_as_int(best.v);
+            const unsigned key = (unsigned)(vb >= 0 ? vb | 0x80000000 : ~vb);
+            const unsigned kmax = __reduce_max_sync(~0ull, key);
+            const unsigned imin = __reduce_min_sync(~0ull, key == kmax ? (unsigned)best.i : 0xffffffffu);
+            best.v = __int_as_float((int)(kmax & 0x80000000u ? kmax & 0x7fffffffu : ~kmax));
+            best.i = (int)imin;
         }
         ArgMax *slot = part + (it & 1) * (FPS_T / 64);
         if ((tid & 63) == 0) slot[tid >> 6] = best;
