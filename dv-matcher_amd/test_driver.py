@@ -5,8 +5,10 @@
     T12 = search_t(feat1, feat2) + 1;  T21 = search_t(feat2, feat1) + 1                           (test.py:19-28)
     result/<exp>_<dataset>/T/T_<a>_<b>.txt ('%i', 1-based), .../feature/usefeature_<a>.mat {'uphi': feat}
 
-Pairs come from --pairs (an .npz with verts1, verts2 (N,3), dino1, dino2 (N,1152), name1, name2 — the dataset
-reader and the DINOv2 feature pipeline are outside this path) or are synthetic (--synthetic P).
+Pairs come from --data-root (a dataset directory in the reference's layout, read by models/dataset.py's
+testDataset, with the visual features in feat/<shape>.mat), from --pairs (an .npz with verts1, verts2 (N,3),
+dino1, dino2 (N,1152), name1, name2) or are synthetic (--synthetic P).  The DINOv2 feature pipeline that
+produces the .mat files is outside this path.
 
   python dv-matcher_amd/test_driver.py --synthetic 2 --points 1024 --out result/demo [--ckpt ep_val_best.pth]
 """
@@ -28,7 +30,17 @@ from models.model import Uni3FC  # noqa: E402
 
 
 def load_pairs(args):
-    if args.pairs:
+    if args.data_root:                                   # the reference's loop over testDataset (test.py:66-100)
+        import scipy.io as sio
+        from models.dataset import testDataset
+        data = testDataset(args.data_root, name=args.data_name, train=False)
+        for item in data:
+            out = []
+            for s in ("shape1", "shape2"):
+                path = os.path.join(args.data_root, "feat", item[s]["name"] + ".mat")
+                out.append((item[s]["name"], item[s]["xyz"].numpy(), np.asarray(sio.loadmat(path)["feat"], dtype=np.float32)))
+            yield (out[0][0], out[1][0], out[0][1], out[1][1], out[0][2], out[1][2])
+    elif args.pairs:
         for path in args.pairs:
             d = np.load(path, allow_pickle=False)
             yield (str(d["name1"]), str(d["name2"]), d["verts1"], d["verts2"], d["dino1"], d["dino2"])
@@ -55,6 +67,8 @@ def write_results(save_path, name1, name2, T12, T21, feat1, feat2):
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--pairs", nargs="*", default=None, help=".npz files, one pair each")
+    ap.add_argument("--data-root", default=None, help="dataset directory in the reference's layout (shapes_test/, feat/)")
+    ap.add_argument("--data-name", default="scape_r")
     ap.add_argument("--synthetic", type=int, default=2)
     ap.add_argument("--points", type=int, default=1024)
     ap.add_argument("--seed", type=int, default=0)

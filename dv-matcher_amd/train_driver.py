@@ -5,8 +5,10 @@
     loss,... = criterion(feat1, feat2, dist1, dist2, verts1, verts2, alpha_i, deformer)
     loss.backward(); optimizer.step(); optimizer.zero_grad()
 
-with the reference's hyper-parameters read from its YAML (config/scape_r.yaml layout) and
-synthetic pairs (the dataset / DINO feature pipeline is outside this path: SURVEY §8f).  One process
+with the reference's hyper-parameters read from its YAML (config/scape_r.yaml layout) and either
+synthetic pairs or a dataset directory in the reference's layout (`--data-root`: models/dataset.py
+reads `shapes_train/*.off` or its `.pt` cache, and `feat/<shape>.mat` visual features; producing those
+features is outside this path).  One process
 per GPU; with WORLD_SIZE > 1 the pair batch is sharded and the gradients are averaged with ONE
 all-reduce over a flat fp32 bucket (RCCL over xGMI).  BatchNorm uses local batch statistics and the
 positional encoding the local min/max (SURVEY §8e caveats).
@@ -51,6 +53,9 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="global pair batch (default: training.batch_size)")
     ap.add_argument("--points", type=int, default=1024)
     ap.add_argument("--epoch", type=int, default=1, help="which epoch's alpha to use (1-based)")
+    ap.add_argument("--data-root", default=None, help="dataset directory (shapes_train/, feat/, cache_*.pt); default: synthetic")
+    ap.add_argument("--data-name", default="scape_r")
+    ap.add_argument("--random-feat", action="store_true", help="with --data-root: random visual features instead of feat/*.mat")
     args = ap.parse_args()
     cfg = DEFAULT_CFG
     if args.config:
@@ -80,14 +85,43 @@ def main():
     g = torch.Generator().manual_seed(100 + rank)
     random.seed(200 + rank)
     torch.manual_seed(300 + rank)
-    v1, v2 = torch.rand(B, N, 3, generator=g).to(dev), torch.rand(B, N, 3, generator=g).to(dev)
-    d1, d2 = torch.randn(B, N, 1152, generator=g).to(dev), torch.randn(B, N, 1152, generator=g).to(dev)
-    dist1, dist2 = torch.cdist(v1, v1), torch.cdist(v2, v2)
+    if args.data_root:
+        from models.dataset import Dataset
+        data = Dataset(args.data_root, name=args.data_name, train=True, with_dino=not args.random_feat, feat_mat=True)
+        order = torch.randperm(len(data), generator=torch.Generator().manual_seed(7)).tolist()      # same on every rank
+
+        def batches():
+            at = 0
+            while True:                                      # this rank's slice [lo, hi) of every global batch
+                items = [data[order[(at + j) % len(order)]] for j in range(lo, hi)]
+                at += Bg
+                cols = []
+                for s in ("shape1", "shape2"):
+                    n = min(it[s]["xyz"].shape[0] for it in items)
+                    n = min(n, N)
+                    xyz = torch.stack([it[s]["xyz"][:n] for it in items]).float().to(dev)
+                    dd = torch.stack([it[s]["dist"][:n, :n] for it in items]).float().to(dev)
+                    if args.random_feat:
+                        ft = torch.randn(len(items), n, 1152, generator=g).to(dev)
+                    else:
+                        ft = torch.stack([it[s]["feat"][:n] for it in items]).float().to(dev)
+                    cols.append((xyz, ft, dd))
+                yield cols[0][0], cols[1][0], cols[0][1], cols[1][1], cols[0][2], cols[1][2]
+    else:
+        sv1, sv2 = torch.rand(B, N, 3, generator=g).to(dev), torch.rand(B, N, 3, generator=g).to(dev)
+        sd1, sd2 = torch.randn(B, N, 1152, generator=g).to(dev), torch.randn(B, N, 1152, generator=g).to(dev)
+        sdist1, sdist2 = torch.cdist(sv1, sv1), torch.cdist(sv2, sv2)
+
+        def batches():
+            while True:
+                yield sv1, sv2, sd1, sd2, sdist1, sdist2
+    feed = batches()
     net.train()
     dfm.train()
     losses = []
 
     def step():
+        v1, v2, d1, d2, dist1, dist2 = next(feed)
         f1, _ = net(v1.permute(0, 2, 1), d1, None)
         f2, _ = net(v2.permute(0, 2, 1), d2, None)
         out = crit(f1, f2, dist1, dist2, v1, v2, alpha, dfm)
