@@ -23,7 +23,7 @@ constexpr int KS_KT = 64, KS_WAVES = 4, KS_QB = 128, KS_THREADS = 256;
 template <int D>
 __global__ __launch_bounds__(KS_THREADS, 2) void knn_scores_mfma_kernel(const float *__restrict__ a, const float *__restrict__ bq,
                                                                        const float *__restrict__ na, const float *__restrict__ nb,
-                                                                       int N, int M, float *__restrict__ S) {
+                                                                       int N, int M, int kchunk, float *__restrict__ S) {
     constexpr int LDK = D + 4, H = D / 2;
     __shared__ __attribute__((aligned(16))) float kt[KS_KT * LDK];
     __shared__ float kn[KS_KT];
@@ -47,7 +47,8 @@ __global__ __launch_bounds__(KS_THREADS, 2) void knn_scores_mfma_kernel(const fl
         nq[r] = na[(size_t)b * N + (row < N ? row : N - 1)];
     }
     const float *kb = bq + (size_t)b * M * D;
-    for (int j0 = 0; j0 < M; j0 += KS_KT) {
+    const int jbeg = blockIdx.z * kchunk, jend = jbeg + kchunk < M ? jbeg + kchunk : M;  // this workgroup's key range
+    for (int j0 = jbeg; j0 < jend; j0 += KS_KT) {
         __syncthreads();
         for (int e = tid; e < KS_KT * D / 4; e += KS_THREADS) {
             int r = e / (D / 4), c = e % (D / 4);
@@ -369,11 +370,17 @@ __global__ void posenc_kernel(const float *__restrict__ x, const float *__restri
 //   pass 2: for every column j:  x_r[j,:] = sum_i v_i w_ij / (1e-9 + sum_i w_ij),  w_ij = exp(E_ij - m_i)/l_i
 constexpr int SA_P = 16, SA_C = 64, SA_LDP = 20;
 
+// Both passes: one workgroup owns 32 query rows / output columns; its 4 waves take the four 32-key tiles of every
+// staged 128-key block and their partial results are merged through LDS at the end, so that B*N/32 workgroups
+// (512 at B = 8, N = 2048) keep all 256 CUs busy where 128-row workgroups left half of them idle.
+constexpr int SA_KB = 128;  // keys staged per iteration
+
 __global__ __launch_bounds__(256) void sa_rowstats_kernel(const float *__restrict__ p, int N, float *__restrict__ stats) {
-    __shared__ __attribute__((aligned(16))) float pt[64 * SA_LDP];
+    __shared__ __attribute__((aligned(16))) float pt[SA_KB * SA_LDP];
+    __shared__ float red[4][32][2];
     const int b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r32 = lane & 31, h = lane >> 5;
-    const int irow = blockIdx.x * 128 + wave * 32 + r32;
+    const int irow = blockIdx.x * 32 + r32;
     const int irc = irow < N ? irow : N - 1;
     const float *pb = p + (size_t)b * N * SA_P;
     float pi[8];
@@ -384,10 +391,11 @@ __global__ __launch_bounds__(256) void sa_rowstats_kernel(const float *__restric
         pi[2 * c + 1] = h ? v.w : v.z;
     }
     float m = -INFINITY, l = 0.f;
-    for (int j0 = 0; j0 < N; j0 += 64) {
+    for (int j0 = 0; j0 < N; j0 += SA_KB) {
         __syncthreads();
-        {
-            int r = tid >> 2, c = tid & 3;  // 64 rows x 4 float4
+#pragma unroll
+        for (int e = tid; e < SA_KB * 4; e += 256) {
+            int r = e >> 2, c = e & 3;  // 128 rows x 4 float4
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (j0 + r < N) v = *(const f32x4 *)(pb + (size_t)(j0 + r) * SA_P + 4 * c);
             float2 ev = {v.x, v.z}, od = {v.y, v.w};
@@ -395,56 +403,68 @@ __global__ __launch_bounds__(256) void sa_rowstats_kernel(const float *__restric
             *(float2 *)(pt + r * SA_LDP + 8 + 2 * c) = od;
         }
         __syncthreads();
+        const int jt = j0 + wave * 32;
+        if (jt >= N) continue;
+        const float *jr = pt + (wave * 32 + r32) * SA_LDP + h * 8;
+        f32x4 a0 = *(const f32x4 *)(jr), a1 = *(const f32x4 *)(jr + 4);
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, pi[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, pi[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, pi[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, pi[3], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, pi[4], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, pi[5], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, pi[6], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, pi[7], acc, 0, 0, 0);
+        // this lane: row i = irow, 16 columns j = jt + (r&3) + 8*(r>>2) + 4*h
+        float tmax = -INFINITY;
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            const float *jr = pt + (sub * 32 + r32) * SA_LDP + h * 8;
-            f32x4 a0 = *(const f32x4 *)(jr), a1 = *(const f32x4 *)(jr + 4);
-            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, pi[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, pi[1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, pi[2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, pi[3], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, pi[4], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, pi[5], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, pi[6], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, pi[7], acc, 0, 0, 0);
-            // this lane: row i = irow, 16 columns j = j0 + sub*32 + (r&3) + 8*(r>>2) + 4*h
-            float tmax = -INFINITY;
+        for (int r = 0; r < 16; ++r) {
+            int j = jt + (r & 3) + 8 * (r >> 2) + 4 * h;
+            float e = j < N ? acc[r] : -INFINITY;
+            acc[r] = e;
+            tmax = fmaxf(tmax, e);
+        }
+        if (tmax > m) {
+            l = l * __expf(m - tmax);  // m = -inf, l = 0 -> 0 * 0
+            m = tmax;
+        }
+        if (tmax != -INFINITY) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int j = j0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                float e = j < N ? acc[r] : -INFINITY;
-                acc[r] = e;
-                tmax = fmaxf(tmax, e);
-            }
-            if (tmax > m) {
-                l = l * __expf(m - tmax);  // m = -inf, l = 0 -> 0 * 0
-                m = tmax;
-            }
-            if (tmax != -INFINITY) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) l += __expf(acc[r] - m);
-            }
+            for (int r = 0; r < 16; ++r) l += __expf(acc[r] - m);
         }
     }
     float mo = __shfl_xor(m, 32, 64), lo = __shfl_xor(l, 32, 64);
     float mm = fmaxf(m, mo);
     float ll = (m == -INFINITY ? 0.f : l * __expf(m - mm)) + (mo == -INFINITY ? 0.f : lo * __expf(mo - mm));
-    if (h == 0 && irow < N) {
-        stats[((size_t)b * N + irow) * 2] = mm;
-        stats[((size_t)b * N + irow) * 2 + 1] = 1.0f / ll;
+    if (h == 0) {
+        red[wave][r32][0] = mm;
+        red[wave][r32][1] = ll;
+    }
+    __syncthreads();
+    if (tid < 32 && irow < N) {
+        float gm = fmaxf(fmaxf(red[0][tid][0], red[1][tid][0]), fmaxf(red[2][tid][0], red[3][tid][0]));
+        float gl = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            float wm = red[w][tid][0];
+            if (wm != -INFINITY) gl += red[w][tid][1] * __expf(wm - gm);
+        }
+        stats[((size_t)b * N + irow) * 2] = gm;
+        stats[((size_t)b * N + irow) * 2 + 1] = 1.0f / gl;
     }
 }
 
 __global__ __launch_bounds__(256) void sa_apply_kernel(const float *__restrict__ p, const float *__restrict__ v,
                                                        const float *__restrict__ stats, int N, float *__restrict__ xr,
                                                        float *__restrict__ cinv_out) {
-    __shared__ __attribute__((aligned(16))) float pt[32 * SA_LDP];
-    __shared__ __attribute__((aligned(16))) float vt[32 * SA_C];
-    __shared__ float st[32 * 2];
+    __shared__ __attribute__((aligned(16))) float pt[SA_KB * SA_LDP];
+    __shared__ __attribute__((aligned(16))) float vt[SA_KB * SA_C];  // reused as the [wave][reg][lane] merge buffer
+    __shared__ float st[SA_KB * 2];
+    __shared__ float csum[4][32];
     const int b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r32 = lane & 31, h = lane >> 5;
-    const int jcol = blockIdx.x * 128 + wave * 32 + r32;
+    const int jcol = blockIdx.x * 32 + r32;
     const int jc = jcol < N ? jcol : N - 1;
     const float *pb = p + (size_t)b * N * SA_P;
     const float *vb = v + (size_t)b * N * SA_C;
@@ -457,28 +477,32 @@ __global__ __launch_bounds__(256) void sa_apply_kernel(const float *__restrict__
     }
     f32x16 o0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, o1 = o0;
     float colsum = 0.f;
-    for (int i0 = 0; i0 < N; i0 += 32) {
+    for (int i0 = 0; i0 < N; i0 += SA_KB) {
         __syncthreads();
-        if (tid < 128) {
-            int r = tid >> 2, c = tid & 3;
+#pragma unroll
+        for (int e = tid; e < SA_KB * 4; e += 256) {
+            int r = e >> 2, c = e & 3;
             f32x4 q = {0.f, 0.f, 0.f, 0.f};
             if (i0 + r < N) q = *(const f32x4 *)(pb + (size_t)(i0 + r) * SA_P + 4 * c);
             float2 ev = {q.x, q.z}, od = {q.y, q.w};
             *(float2 *)(pt + r * SA_LDP + 2 * c) = ev;
             *(float2 *)(pt + r * SA_LDP + 8 + 2 * c) = od;
-        } else if (tid < 192) {
-            int r = (tid - 128) >> 1, c = (tid - 128) & 1;
+        }
+        {
+            int r = tid >> 1, c = tid & 1;
             st[r * 2 + c] = (i0 + r < N) ? stats[((size_t)b * N + i0 + r) * 2 + c] : 0.f;  // invl = 0 kills padding
         }
-        for (int e = tid; e < 32 * SA_C / 4; e += 256) {
+#pragma unroll
+        for (int e = tid; e < SA_KB * SA_C / 4; e += 256) {
             int r = e >> 4, c = e & 15;
             f32x4 q = {0.f, 0.f, 0.f, 0.f};
             if (i0 + r < N) q = *(const f32x4 *)(vb + (size_t)(i0 + r) * SA_C + 4 * c);
             *(f32x4 *)(vt + r * SA_C + 4 * c) = q;
         }
         __syncthreads();
-        // E tile: rows = keys i (A operand from LDS), cols = this lane's column j
-        const float *ir = pt + r32 * SA_LDP + h * 8;
+        if (i0 + wave * 32 >= N) continue;
+        // E tile: rows = this wave's 32 keys i (A operand from LDS), cols = this lane's column j
+        const float *ir = pt + (wave * 32 + r32) * SA_LDP + h * 8;
         f32x4 a0 = *(const f32x4 *)(ir), a1 = *(const f32x4 *)(ir + 4);
         f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, pj[0], acc, 0, 0, 0);
@@ -491,26 +515,38 @@ __global__ __launch_bounds__(256) void sa_apply_kernel(const float *__restrict__
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, pj[7], acc, 0, 0, 0);
         // w_r = exp(E - m_i) / l_i for the 16 key rows of this lane; then x_r += V^T w on the matrix cores:
         // MFMA step r pairs key rho_r (lanes h=0) with key rho_r+4 (lanes h=1) in both operands.
+        const float *stw = st + wave * 64, *vtw = vt + wave * 32 * SA_C;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int key = (r & 3) + 8 * (r >> 2) + 4 * h;
-            float w = __expf(acc[r] - st[key * 2]) * st[key * 2 + 1];
+            float w = __expf(acc[r] - stw[key * 2]) * stw[key * 2 + 1];
             colsum += w;
-            float va = vt[key * SA_C + r32], vb2 = vt[key * SA_C + 32 + r32];
+            float va = vtw[key * SA_C + r32], vb2 = vtw[key * SA_C + 32 + r32];
             o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va, w, o0, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vb2, w, o1, 0, 0, 0);
         }
     }
     colsum += __shfl_xor(colsum, 32, 64);
-    const float inv = 1.0f / (1e-9f + colsum);
-    if (cinv_out && h == 0 && jcol < N) cinv_out[(size_t)b * N + jcol] = inv;
+    __syncthreads();  // every wave is done with vt
+    if (h == 0) csum[wave][r32] = colsum;
+    float *red = vt + wave * (32 * 64);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        red[r * 64 + lane] = o0[r];
+        red[(16 + r) * 64 + lane] = o1[r];
+    }
+    __syncthreads();
+    const float inv = 1.0f / (1e-9f + ((csum[0][r32] + csum[1][r32]) + (csum[2][r32] + csum[3][r32])));
+    if (cinv_out && wave == 0 && h == 0 && jcol < N) cinv_out[(size_t)b * N + jcol] = inv;
     if (jcol < N) {
         float *o = xr + ((size_t)b * N + jcol) * SA_C;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int ch = (r & 3) + 8 * (r >> 2) + 4 * h;
-            o[ch] = o0[r] * inv;
-            o[32 + ch] = o1[r] * inv;
+        for (int q = 0; q < 8; ++q) {
+            const int r = wave * 8 + q;  // merged register index: 0..15 -> o0, 16..31 -> o1
+            const float *src = vt + r * 64 + lane;
+            float sum = (src[0] + src[32 * 64]) + (src[2 * 32 * 64] + src[3 * 32 * 64]);
+            const int rr = r & 15;
+            o[(r >> 4) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h] = sum * inv;
         }
     }
 }
@@ -684,12 +720,16 @@ int launch_knn_neg(const float *a, const float *bq, int B, int N, int M, int C, 
                    float *S, hipStream_t s) {
     launch_rownorm2(a, B * N, C, na, s);
     launch_rownorm2(bq, B * M, C, nb, s);
+    // key range split over grid.z until >= 1024 workgroups are in flight (B * N/128 alone is 128 at B = 8, N = 2048)
+    const int qtiles = (N + KS_QB - 1) / KS_QB, ktiles = (M + KS_KT - 1) / KS_KT;
+    int nz = 1;
+    while (B * qtiles * nz < 1024 && nz * 2 <= ktiles) nz *= 2;
+    const int kchunk = ((ktiles + nz - 1) / nz) * KS_KT;
+    nz = (M + kchunk - 1) / kchunk;
     if (C == 128)
-        hipLaunchKernelGGL(knn_scores_mfma_kernel<128>, dim3((N + KS_QB - 1) / KS_QB, B), dim3(KS_THREADS), 0, s, a, bq, na, nb, N,
-                           M, S);
+        hipLaunchKernelGGL(knn_scores_mfma_kernel<128>, dim3(qtiles, B, nz), dim3(KS_THREADS), 0, s, a, bq, na, nb, N, M, kchunk, S);
     else if (C == 64)
-        hipLaunchKernelGGL(knn_scores_mfma_kernel<64>, dim3((N + KS_QB - 1) / KS_QB, B), dim3(KS_THREADS), 0, s, a, bq, na, nb, N,
-                           M, S);
+        hipLaunchKernelGGL(knn_scores_mfma_kernel<64>, dim3(qtiles, B, nz), dim3(KS_THREADS), 0, s, a, bq, na, nb, N, M, kchunk, S);
     else
         hipLaunchKernelGGL(knn_scores_scalar_kernel, dim3((N + 127) / 128, B), dim3(128), 0, s, a, bq, na, nb, N, M, C, S);
     if (k <= 64 && M <= 8192) {
@@ -778,7 +818,7 @@ DVM_EXPORT int dvm_sa_attention_fwd_f32(const float *p, const float *v, int B, i
         return DVM_ENOSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((N + 127) / 128, B);
+    dim3 grid((N + 31) / 32, B);
     hipLaunchKernelGGL(sa_rowstats_kernel, grid, dim3(256), 0, s, p, N, stats);
     hipLaunchKernelGGL(sa_apply_kernel, grid, dim3(256), 0, s, p, v, stats, N, xr, (float *)nullptr);
     DVM_CHECK_LAUNCH("sa_attention");
@@ -789,7 +829,7 @@ DVM_EXPORT int dvm_sa_attention_train_fwd_f32(const float *p, const float *v, in
                                               void *stream) {
     DVM_REQUIRE(p && v && xr && stats && cinv && B >= 1 && N >= 1, "dvm_sa_attention_train_fwd_f32: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((N + 127) / 128, B);
+    dim3 grid((N + 31) / 32, B);
     hipLaunchKernelGGL(sa_rowstats_kernel, grid, dim3(256), 0, s, p, N, stats);
     hipLaunchKernelGGL(sa_apply_kernel, grid, dim3(256), 0, s, p, v, stats, N, xr, cinv);
     DVM_CHECK_LAUNCH("sa_attention_train_fwd");
