@@ -391,18 +391,29 @@ __global__ __launch_bounds__(256) void sa_rowstats_kernel(const float *__restric
         pi[2 * c + 1] = h ? v.w : v.z;
     }
     float m = -INFINITY, l = 0.f;
+    // the next 128-key block travels in registers while the current one is consumed
+    f32x4 pre[2];
+    auto fetch = [&](int j0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            int e = tid + q * 256, r = e >> 2, c = e & 3;  // 128 rows x 4 float4
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (j0 + r < N) v = *(const f32x4 *)(pb + (size_t)(j0 + r) * SA_P + 4 * c);
+            pre[q] = v;
+        }
+    };
+    fetch(0);
     for (int j0 = 0; j0 < N; j0 += SA_KB) {
         __syncthreads();
 #pragma unroll
-        for (int e = tid; e < SA_KB * 4; e += 256) {
-            int r = e >> 2, c = e & 3;  // 128 rows x 4 float4
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (j0 + r < N) v = *(const f32x4 *)(pb + (size_t)(j0 + r) * SA_P + 4 * c);
-            float2 ev = {v.x, v.z}, od = {v.y, v.w};
+        for (int q = 0; q < 2; ++q) {
+            int e = tid + q * 256, r = e >> 2, c = e & 3;
+            float2 ev = {pre[q].x, pre[q].z}, od = {pre[q].y, pre[q].w};
             *(float2 *)(pt + r * SA_LDP + 2 * c) = ev;
             *(float2 *)(pt + r * SA_LDP + 8 + 2 * c) = od;
         }
         __syncthreads();
+        if (j0 + SA_KB < N) fetch(j0 + SA_KB);
         const int jt = j0 + wave * 32;
         if (jt >= N) continue;
         const float *jr = pt + (wave * 32 + r32) * SA_LDP + h * 8;
@@ -477,29 +488,44 @@ __global__ __launch_bounds__(256) void sa_apply_kernel(const float *__restrict__
     }
     f32x16 o0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, o1 = o0;
     float colsum = 0.f;
+    // the next 128-key block (p, v, stats) travels in registers while the current one is consumed
+    f32x4 prep[2], prev[8];
+    float pres;
+    auto fetch = [&](int i0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            int e = tid + q * 256, r = e >> 2, c = e & 3;
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            if (i0 + r < N) t = *(const f32x4 *)(pb + (size_t)(i0 + r) * SA_P + 4 * c);
+            prep[q] = t;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            int e = tid + q * 256, r = e >> 4, c = e & 15;
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            if (i0 + r < N) t = *(const f32x4 *)(vb + (size_t)(i0 + r) * SA_C + 4 * c);
+            prev[q] = t;
+        }
+        pres = (i0 + (tid >> 1) < N) ? stats[((size_t)b * N + i0 + (tid >> 1)) * 2 + (tid & 1)] : 0.f;  // invl = 0 kills padding
+    };
+    fetch(0);
     for (int i0 = 0; i0 < N; i0 += SA_KB) {
         __syncthreads();
 #pragma unroll
-        for (int e = tid; e < SA_KB * 4; e += 256) {
-            int r = e >> 2, c = e & 3;
-            f32x4 q = {0.f, 0.f, 0.f, 0.f};
-            if (i0 + r < N) q = *(const f32x4 *)(pb + (size_t)(i0 + r) * SA_P + 4 * c);
-            float2 ev = {q.x, q.z}, od = {q.y, q.w};
+        for (int q = 0; q < 2; ++q) {
+            int e = tid + q * 256, r = e >> 2, c = e & 3;
+            float2 ev = {prep[q].x, prep[q].z}, od = {prep[q].y, prep[q].w};
             *(float2 *)(pt + r * SA_LDP + 2 * c) = ev;
             *(float2 *)(pt + r * SA_LDP + 8 + 2 * c) = od;
         }
-        {
-            int r = tid >> 1, c = tid & 1;
-            st[r * 2 + c] = (i0 + r < N) ? stats[((size_t)b * N + i0 + r) * 2 + c] : 0.f;  // invl = 0 kills padding
-        }
 #pragma unroll
-        for (int e = tid; e < SA_KB * SA_C / 4; e += 256) {
-            int r = e >> 4, c = e & 15;
-            f32x4 q = {0.f, 0.f, 0.f, 0.f};
-            if (i0 + r < N) q = *(const f32x4 *)(vb + (size_t)(i0 + r) * SA_C + 4 * c);
-            *(f32x4 *)(vt + r * SA_C + 4 * c) = q;
+        for (int q = 0; q < 8; ++q) {
+            int e = tid + q * 256, r = e >> 4, c = e & 15;
+            *(f32x4 *)(vt + r * SA_C + 4 * c) = prev[q];
         }
+        st[tid] = pres;
         __syncthreads();
+        if (i0 + SA_KB < N) fetch(i0 + SA_KB);
         if (i0 + wave * 32 >= N) continue;
         // E tile: rows = this wave's 32 keys i (A operand from LDS), cols = this lane's column j
         const float *ir = pt + (wave * 32 + r32) * SA_LDP + h * 8;

@@ -55,20 +55,66 @@ class PointwiseConv1d(nn.Conv1d):
         return y if self.bias is None else y + self.bias[:, None]
 
 
+def _folded(owner, tag, sources, build):
+    """Inference-time derived parameters (BatchNorm folded into a conv, stacked q/k/v weights ...) are rebuilt only when
+    one of their source tensors was written (optimizer step, load_state_dict) or moved: ~150 tiny launches per forward
+    otherwise.  Kept outside the module's parameters/buffers, so state_dict is untouched."""
+    key = tuple((t.data_ptr(), t._version) for t in sources if t is not None)
+    cache = owner.__dict__.setdefault("_dvm_folded", {})
+    hit = cache.get(tag)
+    if hit is None or hit[0] != key:
+        hit = (key, build())
+        cache[tag] = hit
+    return hit[1]
+
+
+def _bn_sources(bn):
+    return (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+
+
 def _bn_affine(bn):
     """Eval-mode BatchNorm as y = x * s + t (per channel)."""
-    s = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
-    return s, bn.bias - bn.running_mean * s
+    def build():
+        s = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+        return s, bn.bias - bn.running_mean * s
+    return _folded(bn, "affine", _bn_sources(bn), build)
 
 
 def _conv_bn_pm(conv, bn, xt, act=None):
     """Inference, point-major: 1x1 conv with the eval-mode BatchNorm folded into its weights — ONE (B*N) x Cin x Cout
     GEMM with bias — then the activation.  xt (B,N,Cin) -> (B,N,Cout)."""
-    s, t = _bn_affine(bn)
-    w = conv.weight[:, :, 0] * s[:, None]
-    b = t if conv.bias is None else conv.bias * s + t
+    def build():
+        s, t = _bn_affine(bn)
+        return (conv.weight[:, :, 0] * s[:, None]).contiguous(), (t if conv.bias is None else conv.bias * s + t)
+    w, b = _folded(conv, "conv_bn", (conv.weight, conv.bias) + _bn_sources(bn), build)
     y = F.linear(xt, w, b)
     return y if act is None else act(y)
+
+
+def _conv_bn_act_max_pm(conv, bn, xt, act):
+    """max over the points of act(conv+BN(xt)) -> (B,1,Cout).  `act` is monotone and the bias is per channel, so the
+    maximum commutes with both: the GEMM is taken channel-major ((B,Cout,N): the reduction runs over the contiguous
+    axis) and bias + activation touch B*Cout numbers instead of B*N*Cout."""
+    def build():
+        s, t = _bn_affine(bn)
+        return (conv.weight[:, :, 0] * s[:, None]).contiguous(), (t if conv.bias is None else conv.bias * s + t)
+    w, b = _folded(conv, "conv_bn", (conv.weight, conv.bias) + _bn_sources(bn), build)
+    return act(torch.matmul(w, xt.transpose(1, 2)).amax(dim=-1) + b).unsqueeze(1)
+
+
+def _conv_bn_glob_pm(conv, bn, glob, xt, act):
+    """conv+BN over cat((glob broadcast over the points, xt), channels) without building the concatenation: the
+    per-shape vector `glob` (B,1,Cg) only contributes a per-shape bias W[:, :Cg] @ glob."""
+    Cg = glob.shape[-1]
+
+    def build():
+        s, t = _bn_affine(bn)
+        w = conv.weight[:, :, 0] * s[:, None]
+        return w[:, :Cg].contiguous(), w[:, Cg:].contiguous(), (t if conv.bias is None else conv.bias * s + t)
+    wg, wx, b = _folded(conv, "conv_bn_glob%d" % Cg, (conv.weight, conv.bias) + _bn_sources(bn), build)
+    y = F.linear(xt, wx)
+    y += F.linear(glob, wg, b)
+    return act(y)
 
 
 # ------------------------------------------------------------------ attention blocks
@@ -129,7 +175,8 @@ class _N2P(nn.Module):
         C = xt.shape[-1]
         xt = xt.contiguous()
         idx = ops.knn_neg(xt, xt, self.K)
-        w = torch.cat([self.q_conv.weight.reshape(C, C), self.k_conv.weight.reshape(C, C), self.v_conv.weight.reshape(C, C)], 0)
+        w = _folded(self, "qkv", (self.q_conv.weight, self.k_conv.weight, self.v_conv.weight), lambda: torch.cat(
+            [self.q_conv.weight.reshape(C, C), self.k_conv.weight.reshape(C, C), self.v_conv.weight.reshape(C, C)], 0))
         att = ops.n2p_core_fwd(F.linear(xt, w), idx, self.heads)[0]
         s1, t1 = _bn_affine(self.bn1)
         xt = torch.addcmul(t1, xt + att, s1)
@@ -261,9 +308,10 @@ class Uni3FC(nn.Module):
             x4, x4g = self.n2p_attention4.infer_pm(x3), self.sa4.infer_pm(x3g)
             loc = torch.cat((x1, x2, x3, x4), dim=-1)
             glo = torch.cat((x1g, x2g, x3g, x4g), dim=-1)
-            lmax = blk(self.conv1, loc).max(dim=1, keepdim=True)[0].expand(-1, N, -1)
-            gmax = blk(self.conv2, glo).max(dim=1, keepdim=True)[0].expand(-1, N, -1)
-            y = torch.cat((blk(self.conv3, torch.cat((lmax, loc), dim=-1)), blk(self.conv4, torch.cat((gmax, glo), dim=-1))), dim=-1)
+            lmax = _conv_bn_act_max_pm(self.conv1[0], self.conv1[1], loc, lrelu)
+            gmax = _conv_bn_act_max_pm(self.conv2[0], self.conv2[1], glo, lrelu)
+            y = torch.cat((_conv_bn_glob_pm(self.conv3[0], self.conv3[1], lmax, loc, lrelu),
+                           _conv_bn_glob_pm(self.conv4[0], self.conv4[1], gmax, glo, lrelu)), dim=-1)
             y1 = blk(self.conv5, y)
             y2 = self.n2p_attention5.infer_pm(y1)
             y3 = self.n2p_attention6.infer_pm(y2)
