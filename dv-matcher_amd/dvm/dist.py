@@ -16,11 +16,15 @@ def shard_range(n_units, rank, world):
 
 
 class FlatGradBucket:
-    """All parameters' gradients viewed through ONE flat fp32 buffer so that a step needs a single
-    all-reduce.  Parameters that received no gradient (the reference has 12 such)
-    contribute zeros, so every rank reduces the same layout."""
+    """All parameters' gradients live in ONE flat fp32 buffer, so a step needs a single all-reduce and no
+    gather/scatter copies: `attach()` makes every `p.grad` a view into the buffer (autograd then accumulates
+    in place), `zero()` clears all of them with one fill.  Parameters that receive no gradient (the reference
+    has 12 such) simply stay zero, so every rank reduces the same layout.
 
-    def __init__(self, params):
+    Gradients that were produced before `attach()` (or re-created by `zero_grad(set_to_none=True)`) are still
+    honoured: `all_reduce_mean()` copies any `p.grad` that is not the bucket's own view into place first."""
+
+    def __init__(self, params, attach=False):
         self.params = [p for p in params if p.requires_grad]
         seen, uniq = set(), []
         for p in self.params:  # tied parameters appear once
@@ -31,37 +35,40 @@ class FlatGradBucket:
         self.numel = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else "cpu"
         self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
-
-    def pack(self):
-        off = 0
+        self.views, off = [], 0
         for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                self.flat[off:off + n].zero_()
-            else:
-                self.flat[off:off + n].copy_(p.grad.reshape(-1))
-            off += n
-        return self.flat
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        if attach:
+            self.attach()
 
-    def unpack(self):
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            g = self.flat[off:off + n].view_as(p)
+    def attach(self):
+        """Point every parameter's .grad at its slice of the flat buffer (existing gradients are kept)."""
+        for p, v in zip(self.params, self.views):
+            if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
+            p.grad = v
+
+    def zero(self):
+        """zero_grad for attached parameters: one fill instead of one per tensor."""
+        self.flat.zero_()
+
+    def _gather_foreign(self):
+        for p, v in zip(self.params, self.views):
             if p.grad is None:
-                p.grad = g.clone()
-            else:
-                p.grad.copy_(g)
-            off += n
+                v.zero_()
+                p.grad = v
+            elif p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
+                p.grad = v
 
     def all_reduce_mean(self, group=None):
         """grad <- mean over ranks of grad (what DDP computes), with one collective."""
         world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.pack()
+        self._gather_foreign()
         if world > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
             self.flat.div_(world)
-        self.unpack()
 
 
 def global_minmax(x, group=None):

@@ -8,6 +8,7 @@ test.py / deform.py call sequence runs unchanged and its checkpoints load with
 1x1 convolutions / BatchNorm stay on PyTorch-ROCm as BASELINE.json's north_star prescribes.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -50,6 +51,8 @@ class PointwiseConv1d(nn.Conv1d):
     def forward(self, x):
         if PointwiseConv1d.accumulate == "f64":
             y = torch.matmul(self.weight[:, :, 0].double(), x.double()).to(x.dtype)
+        elif x.dim() == 3 and os.environ.get("DVM_CONV_BMM", "1") == "1":
+            y = torch.bmm(self.weight[:, :, 0].unsqueeze(0).expand(x.shape[0], -1, -1), x)
         else:
             y = torch.matmul(self.weight[:, :, 0], x)
         return y if self.bias is None else y + self.bias[:, None]

@@ -64,6 +64,8 @@ def main():
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     assert torch.cuda.is_available(), "the training path needs a HIP device"
     torch.cuda.set_device(local)
+    if os.environ.get("DVM_NATIVE_BN", "0") == "1":
+        torch.backends.cudnn.enabled = False
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -81,7 +83,7 @@ def main():
                                   w_img=L["w_img"], w_rank=L["w_rank"], w_self_rec=L["w_self_rec"], w_cd=L["deform"]["w_cd"],
                                   w_arap=L["deform"]["w_arap"], save_name=cfg["expname"])
     alpha = np.linspace(L["min_alpha"], L["max_alpha"] + 1, cfg["training"]["epochs"])[args.epoch - 1]
-    bucket = FlatGradBucket(params)
+    bucket = FlatGradBucket(params, attach=True)          # every p.grad is a view into one flat buffer
     g = torch.Generator().manual_seed(100 + rank)
     random.seed(200 + rank)
     torch.manual_seed(300 + rank)
@@ -119,6 +121,7 @@ def main():
     net.train()
     dfm.train()
     losses = []
+    sync_each = os.environ.get("DVM_SYNC_EACH_STEP", "0") == "1"   # train.py logs loss.item() every iteration
 
     def step():
         v1, v2, d1, d2, dist1, dist2 = next(feed)
@@ -128,8 +131,9 @@ def main():
         out[0].backward()
         bucket.all_reduce_mean()
         opt.step()
-        opt.zero_grad()
-        return [float(torch.as_tensor(o).detach()) for o in out]
+        bucket.zero()
+        vals = torch.stack([torch.as_tensor(o, device=dev).detach().float().reshape(()) for o in out])
+        return vals.tolist() if sync_each else vals      # the 5 loss terms; read back after the timed loop by default
 
     for _ in range(args.warmup):
         step()
@@ -143,6 +147,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    losses = [l if isinstance(l, list) else l.tolist() for l in losses]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -63,3 +63,36 @@ def test_shard_range_covers_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_attached_bucket_holds_the_gradients():
+    """attach(): autograd writes straight into the flat buffer (no pack/unpack copies), zero() clears it with one
+    fill, and an optimizer stepping on those views moves the parameters exactly as with ordinary .grad tensors."""
+    sys.path.insert(0, os.path.join(ROOT, "dv-matcher_amd"))
+    from dvm.dist import FlatGradBucket
+
+    def make():
+        torch.manual_seed(1)
+        net = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Tanh(), torch.nn.Linear(3, 2))
+        return net, torch.nn.Parameter(torch.ones(5))
+    x = torch.linspace(-1, 1, 24).view(6, 4)
+    net, unused = make()
+    ref, ref_unused = make()
+    params = list(net.parameters()) + [unused]
+    bucket = FlatGradBucket(params, attach=True)
+    opt = torch.optim.Adam(params, lr=1e-2)
+    ropt = torch.optim.Adam(list(ref.parameters()) + [ref_unused], lr=1e-2)
+    lo, hi = bucket.flat.data_ptr(), bucket.flat.data_ptr() + 4 * bucket.numel
+    for _ in range(3):
+        net(x).pow(2).sum().backward()
+        assert all(lo <= p.grad.data_ptr() < hi for p in params)          # still the bucket's views
+        bucket.all_reduce_mean()                                         # world == 1: nothing to exchange
+        opt.step()
+        bucket.zero()
+        assert float(bucket.flat.abs().sum()) == 0.0 and all(float(p.grad.abs().sum()) == 0.0 for p in params)
+        ref(x).pow(2).sum().backward()
+        ropt.step()
+        ropt.zero_grad()
+    for p, q in zip(net.parameters(), ref.parameters()):
+        torch.testing.assert_close(p, q, rtol=1e-6, atol=1e-7)
+    assert torch.equal(unused, ref_unused)                               # zero gradient == no gradient for Adam
