@@ -832,6 +832,16 @@ DVM_EXPORT int dvm_pos_encoding_f32(const float *x, int B, int N, float *out, vo
     return DVM_OK;
 }
 
+DVM_EXPORT int dvm_pos_encoding_minmax_f32(const float *x, const float *minmax, int B, int N, float *out, void *stream) {
+    DVM_REQUIRE(x && minmax && out && B >= 1 && N >= 1, "dvm_pos_encoding_minmax_f32: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    long total = (long)B * 3 * 64 * N;
+    int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(posenc_kernel, dim3(blocks), dim3(256), 0, s, x, minmax, 1, B, N, out);
+    DVM_CHECK_LAUNCH("pos_encoding_minmax");
+    return DVM_OK;
+}
+
 DVM_EXPORT size_t dvm_sa_attention_workspace_bytes(int B, int N) { return align_up((size_t)B * N * 2 * sizeof(float)); }
 
 DVM_EXPORT int dvm_sa_attention_fwd_f32(const float *p, const float *v, int B, int N, float *xr, void *ws, size_t ws_bytes,

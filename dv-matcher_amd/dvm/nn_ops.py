@@ -21,7 +21,14 @@ def mlp(module, z):
     return ops.deformer_mlp(wl, z)
 
 
-def pos_encoding(coor):
+def pos_encoding(coor, group=None, sync=False):
+    """sync=True: normalise with the min/max over every rank's shard of the batch (two scalar all-reduces), so that a
+    sharded batch is encoded exactly like the same batch in one process."""
+    import torch.distributed as dist
+    if sync and dist.is_initialized() and dist.get_world_size(group) > 1:
+        from .dist import global_minmax
+        mn, mx = global_minmax(coor, group)
+        return ops.pos_encoding(coor, torch.cat([mn, mx]))
     return ops.pos_encoding(coor)
 
 

@@ -388,13 +388,18 @@ def deformer_mlp(wl, z):
     return out
 
 
-def pos_encoding(x):
-    """x (B,3,N) -> (B,384,N)."""
+def pos_encoding(x, minmax=None):
+    """x (B,3,N) -> (B,384,N).  minmax: optional device tensor (min, max) replacing the tensor's own range."""
     _need_gpu(x)
     x = _f(x)
     B, _, N = x.shape
     lib = _lib.load()
     out = torch.empty(B, 384, N, dtype=torch.float32, device=x.device)
+    if minmax is not None:
+        _need_gpu(minmax)
+        mm = _f(minmax).reshape(2)
+        check(lib.dvm_pos_encoding_minmax_f32(_p(x), _p(mm), B, N, _p(out), _stream()), "dvm_pos_encoding_minmax_f32")
+        return out
     nb = lib.dvm_pos_encoding_workspace_bytes()
     ws = workspace(nb, x.device, "posenc")
     check(lib.dvm_pos_encoding_f32(_p(x), B, N, _p(out), _p(ws), nb, _stream()), "dvm_pos_encoding_f32")

@@ -292,8 +292,9 @@ class Uni3FC(nn.Module):
         self.sa4 = SA_Layer(64)
 
     def pos_encoding_sin_wave(self, coor):
-        """64-octave sin/cos encoding of the batch-normalised coordinates: (B,3,N) -> (B,384,N)."""
-        return nn_ops.pos_encoding(coor)
+        """64-octave sin/cos encoding of the batch-normalised coordinates: (B,3,N) -> (B,384,N).  With
+        `self.sync_minmax = True` under torch.distributed the range is taken over all ranks' shards."""
+        return nn_ops.pos_encoding(coor, sync=getattr(self, "sync_minmax", False))
 
     def _forward_infer(self, x, dino_feat):
         """Eval-mode forward with activations kept point-major (B,N,C): every conv + BatchNorm is one GEMM with bias,

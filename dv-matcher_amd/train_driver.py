@@ -53,6 +53,9 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="global pair batch (default: training.batch_size)")
     ap.add_argument("--points", type=int, default=1024)
     ap.add_argument("--epoch", type=int, default=1, help="which epoch's alpha to use (1-based)")
+    ap.add_argument("--sync-stats", action="store_true", help="DDP: BatchNorm statistics and the positional encoding's min/max "
+                    "over the GLOBAL batch (SyncBatchNorm + two scalar all-reduces), i.e. the single-process semantics")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--data-root", default=None, help="dataset directory (shapes_train/, feat/, cache_*.pt); default: synthetic")
     ap.add_argument("--data-name", default="scape_r")
     ap.add_argument("--random-feat", action="store_true", help="with --data-root: random visual features instead of feat/*.mat")
@@ -69,13 +72,16 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(args.backend, **({"device_id": dev} if args.backend == "nccl" else {}))
     Bg = args.batch or cfg["training"]["batch_size"]
     lo, hi = shard_range(Bg, rank, world)
     B, N = hi - lo, args.points
     L = cfg["loss"]
     torch.manual_seed(0)  # identical initial weights on every rank
     net, dfm = Uni3FC(k=40).to(dev), Deformer(k=L["k_deform"]).to(dev)
+    if args.sync_stats and world > 1:
+        net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)
+        net.sync_minmax = True
     params = list(net.parameters()) + list(dfm.parameters())
     opt = torch.optim.Adam(params, lr=float(cfg["optimizer"]["lr"]), betas=(cfg["optimizer"]["b1"], cfg["optimizer"]["b2"]))
     crit = GraphDeformLoss_Neural(k_deform=L["k_deform"], w_dist=L["w_dist"], w_map=L["w_map"], k_dist=min(L["k_dist"], N // 2),

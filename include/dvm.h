@@ -187,6 +187,10 @@ int dvm_deformer_mlp_fwd_f32(const float *z, int rows, const float *W0, const fl
  * nc = 2*((x-min)/(max-min))-1 with the min/max of the WHOLE tensor, 64 octaves pi*2^j. */
 size_t dvm_pos_encoding_workspace_bytes(void);
 int dvm_pos_encoding_f32(const float *x, int B, int N, float *out, void *ws, size_t ws_bytes, void *stream);
+/* Same encoding with the normalisation range supplied: minmax[0] = min, minmax[1] = max (device pointer).  For a
+ * pair batch sharded over ranks the reference's whole-tensor min/max (models/model.py:548) is the min/max over
+ * ALL ranks' shards; the host reduces the two numbers (MIN / MAX all-reduce) and passes them here. */
+int dvm_pos_encoding_minmax_f32(const float *x, const float *minmax, int B, int N, float *out, void *stream);
 
 /* SA_Layer attention core — models/model.py:113-121.  p [B,N,16] = Wqk x (q and k share the
  * weight), v [B,N,64] = Wv x + bv, point-major.  energy = p p^T, row softmax, every column
