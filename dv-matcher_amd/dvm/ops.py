@@ -4,6 +4,8 @@ torch is used for device memory and streams only: every function takes
 contiguous fp32 / int32 tensors that live on a HIP device, allocates the outputs
 and the scratch there, and enqueues the kernels on torch's current stream.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -403,6 +405,36 @@ def pos_encoding(x, minmax=None):
     nb = lib.dvm_pos_encoding_workspace_bytes()
     ws = workspace(nb, x.device, "posenc")
     check(lib.dvm_pos_encoding_f32(_p(x), B, N, _p(out), _p(ws), nb, _stream()), "dvm_pos_encoding_f32")
+    return out
+
+
+def proj2img(pts):
+    """One view's point cloud (B,N,3) -> (img (B,3,224,224), pc_min (B,2), grid_size (B,), offsets (B,2))."""
+    _need_gpu(pts)
+    pts = _f(pts)
+    B, N, _ = pts.shape
+    lib = _lib.load()
+    dev = pts.device
+    img = torch.empty(B, 3, 224, 224, dtype=torch.float32, device=dev)
+    pc_min, grid, off = (torch.empty(B, 2, dtype=torch.float32, device=dev), torch.empty(B, dtype=torch.float32, device=dev),
+                         torch.empty(B, 2, dtype=torch.float32, device=dev))
+    nb = lib.dvm_proj2img_workspace_bytes(B)
+    ws = workspace(nb, dev, "proj2img")
+    check(lib.dvm_proj2img_f32(_p(pts), B, N, _p(img), _p(pc_min), _p(grid), _p(off), _p(ws), nb, _stream()), "dvm_proj2img_f32")
+    return img, pc_min, grid, off
+
+
+def i2p(pts, f, pc_min, grid, offsets, normalize=False, out=None, col=0):
+    """Image features f (B,C,H,W) sampled at every point's pixel: (B,N,C), or columns [col, col+C) of `out` (B,N,ldo)."""
+    _need_gpu(pts, f, pc_min, grid, offsets)
+    pts, f, pc_min, grid, offsets = _f(pts), _f(f), _f(pc_min), _f(grid), _f(offsets)
+    B, N, _ = pts.shape
+    C, H, W = f.shape[1:]
+    if out is None:
+        out, col = torch.empty(B, N, C, dtype=torch.float32, device=pts.device), 0
+    assert out.is_contiguous() and out.dtype == torch.float32 and out.shape[:2] == (B, N) and col + C <= out.shape[2]
+    check(_lib.load().dvm_i2p_f32(_p(pts), _p(f), _p(pc_min), _p(grid), _p(offsets), B, N, C, H, W, int(bool(normalize)),
+                                  ctypes.c_void_p(out.data_ptr() + 4 * col), out.shape[2], _stream()), "dvm_i2p_f32")
     return out
 
 

@@ -252,7 +252,72 @@ class Deformer(nn.Module):
 
 
 # ------------------------------------------------------------------ LG-Net
-class Uni3FC(nn.Module):
+def rotate_point_cloud_batch_torch(cloud, angle, axis='z'):
+    """cloud (B,3,N) -> (B,N,3) rotated about `axis` (reference models/model.py:65-94; the matrix is built from
+    float64 cos/sin and cast to float32, so cos(-pi/2) stays 6.1e-17 rather than 0)."""
+    c, s = math.cos(angle), math.sin(angle)
+    rows = {'z': [[c, -s, 0], [s, c, 0], [0, 0, 1]], 'y': [[c, 0, s], [0, 1, 0], [-s, 0, c]],
+            'x': [[1, 0, 0], [0, c, -s], [0, s, c]]}
+    if axis not in rows:
+        raise ValueError("Axis must be 'x', 'y', or 'z'")
+    rot = torch.tensor(rows[axis], dtype=torch.float64).float().to(cloud.device)
+    return torch.bmm(cloud.permute(0, 2, 1), rot[None].expand(cloud.shape[0], -1, -1))
+
+
+class _VisualProjection:
+    """Point cloud -> three depth renderings -> image backbone -> per-point visual features (SURVEY §8f-1;
+    reference models/model.py:584-710 and Uni3FC_DINO_proj 815-985).  The rendering and the back-projection are
+    HIP kernels (dvm_proj2img_f32, dvm_i2p_f32); `upsampler` — FeatUp's DINOv2 in the reference — is any callable
+    (3B,3,224,224) -> (3B,C,h,w) and runs on PyTorch-ROCm."""
+    img_size = 224
+
+    def proj2img(self, pc):
+        """pc (B,N,3) -> (img (B,3,224,224), pc_min (B,1,2), grid_size (B,1,1), (offset_x (B,1), offset_y (B,1)))."""
+        B = pc.shape[0]
+        img, pc_min, grid, off = ops.proj2img(pc)
+        return img, pc_min.view(B, 1, 2), grid.view(B, 1, 1), (off[:, 0:1], off[:, 1:2])
+
+    def I2P(self, pc, f, pc_min, grid_size, offsets):
+        """Image features f (B,C,h,w) at every point's pixel of the bicubically 224x224-resized map: (B,N,C)."""
+        B = pc.shape[0]
+        return ops.i2p(pc, f, pc_min.reshape(B, 2), grid_size.reshape(B), torch.cat(offsets, dim=1).float())
+
+    def views(self, x):
+        pts_1 = rotate_point_cloud_batch_torch(x, -math.pi / 2, axis='z')
+        pts_2 = torch.cat((pts_1[..., 2:3], pts_1[..., 0:2]), dim=-1)
+        pts_3 = torch.cat((pts_1[..., 1:3], pts_1[..., 0:1]), dim=-1)
+        return [p.contiguous() for p in (pts_1, pts_2, pts_3)]
+
+    def visual_features(self, x, upsampler):
+        """x (B,3,N) -> (B,N,3C): L2-normalised back-projected features of the three views, side by side."""
+        if upsampler is None:
+            raise ValueError("dino_feat is None: an image backbone (`upsampler`) is needed to produce the visual features")
+        B, _, N = x.shape
+        with torch.no_grad():
+            pts = self.views(x)
+            proj = [ops.proj2img(p) for p in pts]
+            img_feats = upsampler(torch.cat([pr[0] for pr in proj], dim=0))
+            C = img_feats.shape[1]
+            out = torch.empty(B, N, 3 * C, dtype=torch.float32, device=x.device)
+            for v in range(3):
+                _, pc_min, grid, off = proj[v]
+                ops.i2p(pts[v], img_feats[v * B:(v + 1) * B], pc_min, grid, off, normalize=True, out=out, col=v * C)
+        return out
+
+
+class Uni3FC_DINO_proj(nn.Module, _VisualProjection):
+    """The feature pre-computation module of the dataset build (reference models/model.py:815-985):
+    forward(x (B,3,N), upsampler) -> (B,N,3C) visual features (1152 for DINOv2 ViT-S/14 through FeatUp)."""
+
+    def __init__(self):
+        super().__init__()
+        self.device = 'cuda:0'
+
+    def forward(self, x, upsampler):
+        return self.visual_features(x, upsampler)
+
+
+class Uni3FC(nn.Module, _VisualProjection):
     def __init__(self, k=40):
         super().__init__()
         self.device = 'cuda:0'
@@ -326,8 +391,7 @@ class Uni3FC(nn.Module):
     def forward(self, x, dino_feat, upsampler=None):
         """x (B,3,N), dino_feat (B,N,1152) -> (feat (B,N,128), cfeats (B,N,64))."""
         if dino_feat is None:
-            raise NotImplementedError("the point->image->DINOv2 projection branch is outside this path "
-                                      "(SURVEY §8f-1); pass per-point visual features as dino_feat")
+            dino_feat = self.visual_features(x, upsampler)
         B, _, N = x.shape
         if not self.training and not (torch.is_grad_enabled() and (dino_feat.requires_grad or x.requires_grad)) \
                 and PointwiseConv1d.accumulate == "f32":

@@ -192,6 +192,22 @@ int dvm_pos_encoding_f32(const float *x, int B, int N, float *out, void *ws, siz
  * ALL ranks' shards; the host reduces the two numbers (MIN / MAX all-reduce) and passes them here. */
 int dvm_pos_encoding_minmax_f32(const float *x, const float *minmax, int B, int N, float *out, void *stream);
 
+/* Uni3FC.proj2img — models/model.py:584-650 (+ get_colored_depth_maps 563-581).  pts [B,N,3] (one of the three
+ * axis-permuted views) -> img [B,3,224,224]: every point adds its depth (3rd coordinate) to the 5x5 pixels around its
+ * cell, sigmoid, ImageNet-normalise, min-max rescale per image, 'PiYG' colour table, pixels whose depth sum is exactly 0
+ * -> -1.  Also returns what I2P needs: pc_min [B,2], grid_size [B], offsets [B,2] (float-valued integers).  The depth
+ * sums are accumulated in 64-bit fixed point, so the image is bit-reproducible from run to run. */
+size_t dvm_proj2img_workspace_bytes(int B);
+int dvm_proj2img_f32(const float *pts, int B, int N, float *img, float *pc_min, float *grid_size, float *offsets, void *ws,
+                     size_t ws_bytes, void *stream);
+
+/* Uni3FC.I2P (+ F.normalize) — models/model.py:653-678, 701-708.  f [B,C,H,W] image features; for every point the
+ * bicubic (A=-0.75, align_corners=False) resample of f to 224x224 is evaluated ONLY at the point's pixel — the
+ * (B,C,224,224) resized tensor is never built — and written to out[b,i,0:C] (row stride ldo >= C floats, so the three
+ * views can land side by side in one (B,N,3C) tensor); normalize != 0 divides by max(|row|_2, 1e-12). */
+int dvm_i2p_f32(const float *pts, const float *f, const float *pc_min, const float *grid_size, const float *offsets, int B,
+                int N, int C, int H, int W, int normalize, float *out, int ldo, void *stream);
+
 /* SA_Layer attention core — models/model.py:113-121.  p [B,N,16] = Wqk x (q and k share the
  * weight), v [B,N,64] = Wv x + bv, point-major.  energy = p p^T, row softmax, every column
  * divided by (1e-9 + its sum over rows), x_r = attention^T-weighted sum of v -> xr [B,N,64]. */

@@ -78,3 +78,80 @@ def softcorr_bwd(f1, f2, neg_alpha, idx, gval):
     val = torch.gather(P, 2, idx.long())
     (val * gval.double()).sum().backward()
     return val.detach(), a.grad, b.grad
+
+
+# ------------------------------------------------------------------ visual-feature injection
+_IMG = 224
+
+
+def piyg_lut():
+    """The 256 x 3 float32 'PiYG' table (ColorBrewer anchors, linear interpolation) — restated, see tools/gen_piyg_lut.py."""
+    import numpy as np
+    anchors = [(142, 1, 82), (197, 27, 125), (222, 119, 174), (241, 182, 218), (253, 224, 239), (247, 247, 247),
+               (230, 245, 208), (184, 225, 134), (127, 188, 65), (77, 146, 33), (39, 100, 25)]
+    anch = np.asarray(anchors, dtype=np.float64) / 255.0
+    n = 256
+    xs = np.linspace(0.0, 1.0, len(anch)) * (n - 1)
+    xind = np.linspace(0.0, 1.0, n) * (n - 1)
+    ind = np.searchsorted(xs, xind)[1:-1]
+    dist = (xind[1:-1] - xs[ind - 1]) / (xs[ind] - xs[ind - 1])
+    cols = [np.clip(np.concatenate([[anch[0, c]], dist * (anch[ind, c] - anch[ind - 1, c]) + anch[ind - 1, c], [anch[-1, c]]]), 0, 1)
+            for c in range(3)]
+    return torch.from_numpy(np.stack(cols, 1).astype(np.float32))
+
+
+def proj2img(pc):
+    """models/model.py:584-650 + 563-581 on CPU tensors.  pc (B,N,3) -> (img (B,3,224,224), pc_min (B,1,2),
+    grid_size (B,1,1), (offset_x (B,1), offset_y (B,1)))."""
+    B, N, _ = pc.shape
+    offs = torch.tensor([[i, j] for i in range(-2, 3) for j in range(-2, 3)], dtype=torch.float32)
+    pc_range = pc.max(dim=1)[0] - pc.min(dim=1)[0]
+    grid_size = (pc_range[:, :2].max(dim=-1)[0] / (_IMG - 3)).view(B, 1, 1)
+    pc_min = pc.min(dim=1)[0][:, :2].unsqueeze(1)
+    idx_xy = torch.floor((pc[:, :, :2] - pc_min) / grid_size)
+    dense = (idx_xy.unsqueeze(2) + offs[None, None]).view(B, N * 25, 2) + 1
+    center = torch.floor((dense.max(dim=1)[0] + dense.min(dim=1)[0]) / 2).int()
+    offset_x = _IMG / 2 - center[:, 0:1] - 1
+    offset_y = _IMG / 2 - center[:, 1:2] - 1
+    dense = dense + torch.cat([offset_x, offset_y], dim=1).unsqueeze(1)
+    z = pc[:, :, 2:3].expand(-1, -1, 25).reshape(B, N * 25)
+    dense = dense + (dense < 0).to(torch.int32) - (dense > _IMG - 1).to(torch.int32)
+    assert dense.min() >= 0 and dense.max() <= _IMG - 1
+    flat = (dense[:, :, 0] * _IMG + dense[:, :, 1]).long()
+    acc = torch.zeros(B, _IMG * _IMG, dtype=torch.float32).scatter_add_(1, flat, z)     # torch_scatter 'sum'
+    img = acc.view(B, _IMG, _IMG)
+    zero_mask = img == 0
+    v = (torch.sigmoid(img) - 0.485) / 0.229
+    lut = piyg_lut()
+    out = torch.empty(B, 3, _IMG, _IMG)
+    for b in range(B):
+        d = (v[b] - v[b].min()) / (v[b].max() - v[b].min())
+        k = torch.clamp((d * 256).long(), max=255)
+        col = lut[k]                                                                    # (224,224,3)
+        col[torch.isnan(d)] = 0
+        out[b] = col.permute(2, 0, 1)
+    out[zero_mask.unsqueeze(1).expand(-1, 3, -1, -1)] = -1
+    return out, pc_min, grid_size, (offset_x, offset_y)
+
+
+def i2p(pc, f, pc_min, grid_size, offsets):
+    """models/model.py:653-678 on CPU tensors: bicubic resize of f to 224x224, gather at each point's pixel."""
+    B, N, _ = pc.shape
+    C = f.shape[1]
+    idx = torch.floor((pc[:, :, :2] - pc_min) / grid_size) + 1 + torch.cat(offsets, dim=1).unsqueeze(1)
+    assert idx.min() >= 0 and idx.max() <= _IMG - 1
+    dense = F.interpolate(f, size=(_IMG, _IMG), mode='bicubic').reshape(B, C, -1).permute(0, 2, 1)
+    flat = (idx[:, :, 0] * _IMG + idx[:, :, 1]).long()
+    return torch.gather(dense, 1, flat.unsqueeze(-1).expand(-1, -1, C))
+
+
+def visual_features(x, upsampler):
+    """models/model.py:683-710: x (B,3,N) -> (B,N,3C)."""
+    c, s = math.cos(-math.pi / 2), math.sin(-math.pi / 2)
+    rot = torch.tensor([[c, -s, 0], [s, c, 0], [0, 0, 1]], dtype=torch.float64).float()
+    pts_1 = torch.bmm(x.permute(0, 2, 1), rot[None].repeat(x.shape[0], 1, 1))
+    pts = [pts_1, torch.cat((pts_1[..., 2:3], pts_1[..., 0:2]), -1), torch.cat((pts_1[..., 1:3], pts_1[..., 0:1]), -1)]
+    proj = [proj2img(p) for p in pts]
+    feats = upsampler(torch.cat([p[0] for p in proj], 0))
+    B = x.shape[0]
+    return torch.cat([F.normalize(i2p(pts[v], feats[v * B:(v + 1) * B], *proj[v][1:]), dim=-1) for v in range(3)], -1)

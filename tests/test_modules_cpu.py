@@ -44,8 +44,10 @@ def test_modules_refuse_cpu_tensors():
         ml.knnsearch_t(torch.randn(1, 8, 128), torch.randn(1, 8, 128))
     with pytest.raises(DvmError):
         mm.SA_Layer(64)(torch.randn(1, 64, 32))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):                      # no features and no image backbone to make them
         mm.Uni3FC()(torch.randn(1, 3, 32), None, None)
+    with pytest.raises(DvmError):                        # the rendering kernels refuse CPU tensors as well
+        mm.Uni3FC()(torch.randn(1, 3, 32), None, lambda img: img)
 
 
 def test_torch_ref_posenc(golden):
