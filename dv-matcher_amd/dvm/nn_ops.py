@@ -58,10 +58,14 @@ def sa_attention(x, w_qk, w_v, b_v):
     if not _needs_grad(x, w_qk, w_v, b_v):
         return ops.sa_attention(x, w_qk, w_v, b_v)
     ops._need_gpu(x, w_qk, w_v)
-    xt = x.transpose(1, 2).contiguous()
-    p = torch.nn.functional.linear(xt, w_qk.reshape(w_qk.shape[0], -1))
-    v = torch.nn.functional.linear(xt, w_v.reshape(w_v.shape[0], -1), b_v)
-    return _SACore.apply(p, v).transpose(1, 2)
+    # both projections as ONE channel-major batched GEMM (K-contiguous operands forward and backward: the point-major
+    # F.linear form makes the weight gradient a K-strided GEMM that runs ~10x slower), then a small transpose
+    B, C, N = x.shape
+    nq = w_qk.shape[0]
+    w = torch.cat([w_qk.reshape(nq, C), w_v.reshape(-1, C)], 0)
+    pv = torch.baddbmm(torch.cat([b_v.new_zeros(nq), b_v]).view(1, -1, 1), w.unsqueeze(0).expand(B, -1, -1), x)
+    pv = pv.transpose(1, 2)
+    return _SACore.apply(pv[..., :nq].contiguous(), pv[..., nq:].contiguous()).transpose(1, 2)
 
 
 class _N2PCore(torch.autograd.Function):
@@ -91,7 +95,7 @@ def n2p_attention(x, K, wq, wk, wv, heads):
     xt = x.transpose(1, 2).contiguous()
     idx = ops.knn_neg(xt, xt, K)
     w = torch.cat([wq.reshape(C, C), wk.reshape(C, C), wv.reshape(C, C)], 0)
-    qkv = torch.nn.functional.linear(xt, w)                                  # (B,N,3C)
+    qkv = torch.bmm(w.unsqueeze(0).expand(B, -1, -1), x).transpose(1, 2).contiguous()   # (B,N,3C); channel-major GEMM, see sa_attention
     return _N2PCore.apply(qkv, idx, heads).transpose(1, 2)
 
 
