@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void apply_kernel(const float *__restrict__ pi
 __global__ __launch_bounds__(256) void apply_bwd_kernel(const float *__restrict__ pi_val, const int32_t *__restrict__ pi_idx,
                                                         const float *__restrict__ V, const float *__restrict__ gout, int N, int M,
                                                         int topk, int C, int gp2, float *__restrict__ dval,
-                                                        float *__restrict__ dV) {
+                                                        float *__restrict__ dV /* nullptr: d_V comes from the gather pass */) {
     const int groups = (C + 3) / 4;
     const int b = blockIdx.y;
     const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -249,10 +249,103 @@ __global__ __launch_bounds__(256) void apply_bwd_kernel(const float *__restrict_
         for (int e = 0; e < 4; ++e)
             if (ok && c0 + e < C) {
                 part = fmaf(gv[e], V[vr + e], part);
-                unsafeAtomicAdd(dV + vr + e, w * gv[e]);
+                if (dV) unsafeAtomicAdd(dV + vr + e, w * gv[e]);
             }
         for (int o = 1; o < gp2; o <<= 1) part += __shfl_xor(part, o, 64);
         if (cg == 0 && i0 < N) dval[row * topk + t] = part;
+    }
+}
+
+// d_V without float atomics: the (row, slot) -> target lists are reversed by a counting sort (one int atomic per
+// entry), then one wave per target row sums its in-edges, lanes over channels.
+__global__ void rev_count_kernel(const int32_t *__restrict__ idx, long E, int M, int32_t *__restrict__ cnt) {
+    const int b = blockIdx.y;
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int j = idx[(size_t)b * E + e];
+    if (j >= 0 && j < M) atomicAdd(cnt + (size_t)b * (M + 1) + j, 1);
+}
+
+// exclusive scan of cnt[b][0..M) in place (cnt[b][M] = total); cursor = copy of the offsets
+__global__ __launch_bounds__(1024) void rev_scan_kernel(int32_t *__restrict__ cnt, int M, int32_t *__restrict__ cursor) {
+    __shared__ int part[1024];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int32_t *c = cnt + (size_t)b * (M + 1);
+    const int per = (M + 1023) / 1024;
+    const int lo = min(M, tid * per), hi = min(M, lo + per);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += c[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        int v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - s;
+    for (int i = lo; i < hi; ++i) {
+        const int v = c[i];
+        c[i] = run;
+        cursor[(size_t)b * M + i] = run;
+        run += v;
+    }
+    if (tid == 1023) c[M] = part[1023];
+}
+
+__global__ void rev_fill_kernel(const int32_t *__restrict__ idx, long E, int M, int32_t *__restrict__ cursor,
+                                int32_t *__restrict__ edges) {
+    const int b = blockIdx.y;
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int j = idx[(size_t)b * E + e];
+    if (j < 0 || j >= M) return;
+    const int pos = atomicAdd(cursor + (size_t)b * M + j, 1);
+    edges[(size_t)b * E + pos] = (int32_t)e;  // e = row * topk + slot
+}
+
+__global__ __launch_bounds__(256) void apply_bwd_gather_kernel(const float *__restrict__ pi_val, const float *__restrict__ gout,
+                                                               const int32_t *__restrict__ offs, const int32_t *__restrict__ edges,
+                                                               int N, int M, int topk, int C, float *__restrict__ dV) {
+    const int lane = threadIdx.x & 63;
+    const long j = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= M) return;
+    const int b = blockIdx.y;
+    const long E = (long)N * topk;
+    const int beg = offs[(size_t)b * (M + 1) + j], end = offs[(size_t)b * (M + 1) + j + 1];
+    const int32_t *ed = edges + (size_t)b * E;
+    const float *vb = pi_val + (size_t)b * E, *gb = gout + (size_t)b * N * C;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};  // C <= 256: channels lane, lane+64, lane+128, lane+192
+    int e = beg;
+    for (; e + 1 < end; e += 2) {  // two in-edges in flight
+        const int e0 = ed[e], e1 = ed[e + 1];
+        const float w0 = vb[e0], w1 = vb[e1];
+        const float *g0 = gb + (size_t)(e0 / topk) * C, *g1 = gb + (size_t)(e1 / topk) * C;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = lane + 64 * q;
+            if (c < C) {
+                const float a = g0[c], bb = g1[c];
+                acc[q] = fmaf(w0, a, acc[q]);
+                acc[q] = fmaf(w1, bb, acc[q]);
+            }
+        }
+    }
+    if (e < end) {
+        const int e0 = ed[e];
+        const float w0 = vb[e0];
+        const float *g0 = gb + (size_t)(e0 / topk) * C;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = lane + 64 * q;
+            if (c < C) acc[q] = fmaf(w0, g0[c], acc[q]);
+        }
+    }
+    float *o = dV + ((size_t)b * M + j) * C;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = lane + 64 * q;
+        if (c < C) o[c] = acc[q];
     }
 }
 
@@ -556,8 +649,14 @@ DVM_EXPORT int dvm_softcorr_apply_f32(const float *pi_val, const int32_t *pi_idx
     return DVM_OK;
 }
 
+DVM_EXPORT size_t dvm_softcorr_apply_bwd_workspace_bytes(int B, int N, int M, int topk) {
+    return align_up((size_t)B * (M + 1) * sizeof(int32_t)) + align_up((size_t)B * M * sizeof(int32_t)) +
+           align_up((size_t)B * N * topk * sizeof(int32_t));
+}
+
 DVM_EXPORT int dvm_softcorr_apply_bwd_f32(const float *pi_val, const int32_t *pi_idx, const float *V, const float *g_out, int B,
-                                          int N, int M, int topk, int C, float *d_val, float *d_V, void *stream) {
+                                          int N, int M, int topk, int C, float *d_val, float *d_V, void *ws, size_t ws_bytes,
+                                          void *stream) {
     DVM_REQUIRE(pi_val && pi_idx && V && g_out && d_val && d_V, "dvm_softcorr_apply_bwd_f32: null pointer");
     DVM_REQUIRE(B >= 1 && N >= 1 && M >= 1 && C >= 1, "dvm_softcorr_apply_bwd_f32: empty input");
     DVM_REQUIRE(C <= 256, "dvm_softcorr_apply_bwd_f32: C=%d unsupported (<= 256)", C);
@@ -565,9 +664,30 @@ DVM_EXPORT int dvm_softcorr_apply_bwd_f32(const float *pi_val, const int32_t *pi
     int gp2 = 1;
     while (gp2 < (C + 3) / 4) gp2 <<= 1;
     hipStream_t s = (hipStream_t)stream;
-    (void)hipMemsetAsync(d_V, 0, (size_t)B * M * C * sizeof(float), s);
     long threads = (long)N * gp2;
     dim3 grid((unsigned)((threads + 255) / 256), B), block(256);
+    if (ws != nullptr) {  // reversed lists + gather: no float atomics
+        Arena ar(ws, ws_bytes);
+        int32_t *offs = ar.take<int32_t>((size_t)B * (M + 1));
+        int32_t *cursor = ar.take<int32_t>((size_t)B * M);
+        int32_t *edges = ar.take<int32_t>((size_t)B * N * topk);
+        if (!ar.ok()) {
+            set_error("dvm_softcorr_apply_bwd_f32: workspace too small (%zu < %zu)", ws_bytes, ar.off);
+            return DVM_ENOSPACE;
+        }
+        const long E = (long)N * topk;
+        dim3 egrid((unsigned)((E + 255) / 256), B);
+        (void)hipMemsetAsync(offs, 0, (size_t)B * (M + 1) * sizeof(int32_t), s);
+        hipLaunchKernelGGL(rev_count_kernel, egrid, dim3(256), 0, s, pi_idx, E, M, offs);
+        hipLaunchKernelGGL(rev_scan_kernel, dim3(B), dim3(1024), 0, s, offs, M, cursor);
+        hipLaunchKernelGGL(rev_fill_kernel, egrid, dim3(256), 0, s, pi_idx, E, M, cursor, edges);
+        hipLaunchKernelGGL(apply_bwd_kernel, grid, block, 0, s, pi_val, pi_idx, V, g_out, N, M, topk, C, gp2, d_val, (float *)nullptr);
+        hipLaunchKernelGGL(apply_bwd_gather_kernel, dim3((M + 3) / 4, B), dim3(256), 0, s, pi_val, g_out, offs, edges, N, M, topk, C,
+                           d_V);
+        DVM_CHECK_LAUNCH("softcorr_apply_bwd(gather)");
+        return DVM_OK;
+    }
+    (void)hipMemsetAsync(d_V, 0, (size_t)B * M * C * sizeof(float), s);
     hipLaunchKernelGGL(apply_bwd_kernel, grid, block, 0, s, pi_val, pi_idx, V, g_out, N, M, topk, C, gp2, d_val, d_V);
     DVM_CHECK_LAUNCH("softcorr_apply_bwd");
     return DVM_OK;

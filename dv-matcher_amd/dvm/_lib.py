@@ -34,7 +34,8 @@ SIGNATURES = {
     "dvm_n2p_core_fwd_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "dvm_n2p_core_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dvm_n2p_core_bwd_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_size_t, _P]),
-    "dvm_softcorr_apply_bwd_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "dvm_softcorr_apply_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "dvm_softcorr_apply_bwd_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
     "dvm_dist_loss_bwd_weights_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "dvm_rot6d_bwd_f32": (c_int, [_P, _P, c_int, _P, _P]),
     "dvm_dg_warp_arap_bwd_f32": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

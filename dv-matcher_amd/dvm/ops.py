@@ -161,16 +161,19 @@ def apply(pi_val, pi_idx, V):
     return out
 
 
-def apply_bwd(pi_val, pi_idx, V, gout):
-    """Backward of apply: -> (d_val (B,N,topk), d_V (B,M,C))."""
+def apply_bwd(pi_val, pi_idx, V, gout, atomics=False):
+    """Backward of apply: -> (d_val (B,N,topk), d_V (B,M,C)).  atomics=True: the scatter-add variant (no workspace)."""
     _need_gpu(pi_val, pi_idx, V, gout)
     pi_val, pi_idx, V, gout = _f(pi_val), _i(pi_idx), _f(V), _f(gout)
     B, N, topk = pi_val.shape
     M, C = V.shape[1], V.shape[2]
     dval = torch.empty_like(pi_val)
     dV = torch.empty_like(V)
-    check(_lib.load().dvm_softcorr_apply_bwd_f32(_p(pi_val), _p(pi_idx), _p(V), _p(gout), B, N, M, topk, C, _p(dval), _p(dV),
-                                                 _stream()), "dvm_softcorr_apply_bwd_f32")
+    lib = _lib.load()
+    nb = 0 if atomics else lib.dvm_softcorr_apply_bwd_workspace_bytes(B, N, M, topk)
+    ws = workspace(nb, V.device, "apply_bwd") if nb else None
+    check(lib.dvm_softcorr_apply_bwd_f32(_p(pi_val), _p(pi_idx), _p(V), _p(gout), B, N, M, topk, C, _p(dval), _p(dV),
+                                         _p(ws) if nb else None, nb, _stream()), "dvm_softcorr_apply_bwd_f32")
     return dval, dV
 
 

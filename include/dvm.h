@@ -115,9 +115,13 @@ int dvm_softcorr_apply_f32(const float *pi_val, const int32_t *pi_idx, const flo
                            int C, float *out, void *stream);
 
 /* Backward of dvm_softcorr_apply_f32: g_out [B,N,C] -> d_val [B,N,topk] = g_out[i] . V[idx[i,t]] and
- * d_V [B,M,C] (overwritten; scatter-accumulated with fp32 atomics).  C <= 256, topk <= 64. */
+ * d_V [B,M,C] (overwritten).  With a workspace the (row, slot) -> target lists are reversed by a counting sort
+ * and every target row gathers its in-edges (no float atomics); ws == NULL scatter-accumulates with fp32 atomics.
+ * C <= 256, topk <= 64. */
+size_t dvm_softcorr_apply_bwd_workspace_bytes(int B, int N, int M, int topk);
 int dvm_softcorr_apply_bwd_f32(const float *pi_val, const int32_t *pi_idx, const float *V, const float *g_out, int B,
-                               int N, int M, int topk, int C, float *d_val, float *d_V, void *stream);
+                               int N, int M, int topk, int C, float *d_val, float *d_V, void *ws, size_t ws_bytes,
+                               void *stream);
 
 /* farthest_point_sample — lib/deformation_graph_point.py:18-33 with the random
  * start index made an input.  xyz [B,N,3], start [B] -> out [B,npoint]. */

@@ -92,15 +92,18 @@ def test_n2p_core_fwd_bwd_vs_fp64_autograd(ops, C, K, N):
     assert rel(dqkv, x.grad) < 1e-5, rel(dqkv, x.grad)
 
 
+@pytest.mark.parametrize("atomics", [False, True])
 @pytest.mark.parametrize("C", [3, 30, 128, 64, 200])
-def test_sparse_apply_bwd_vs_fp64_autograd(ops, C):
+def test_sparse_apply_bwd_vs_fp64_autograd(ops, C, atomics):
     B, N, M, k = 2, 190, 75, 10
     g = torch.Generator().manual_seed(C)
     val = torch.rand(B, N, k, generator=g)
     idx = torch.randint(0, M, (B, N, k), generator=g, dtype=torch.int32)
+    idx[:, :, -1] = torch.where(idx[:, :, -1] > M // 2, idx[:, :, -1] - M // 2, idx[:, :, -1])   # skewed: rows 0..M/2 are hot
+    idx[1, :7] = 5                                                                            # one target with many in-edges
     V = torch.randn(B, M, C, generator=g)
     gout = torch.randn(B, N, C, generator=g)
-    dval, dV = ops.apply_bwd(val.cuda(), idx.cuda(), V.cuda(), gout.cuda())
+    dval, dV = ops.apply_bwd(val.cuda(), idx.cuda(), V.cuda(), gout.cuda(), atomics=atomics)
     v64, V64 = val.double().requires_grad_(True), V.double().requires_grad_(True)
     rows = torch.gather(V64, 1, idx.long().reshape(B, N * k, 1).expand(-1, -1, C)).view(B, N, k, C)
     ((v64.unsqueeze(-1) * rows).sum(2) * gout.double()).sum().backward()
