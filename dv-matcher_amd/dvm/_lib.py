@@ -56,6 +56,10 @@ SIGNATURES = {
     "dvm_pos_encoding_workspace_bytes": (c_size_t, []),
     "dvm_pos_encoding_f32": (c_int, [_P, c_int, c_int, _P, _P, c_size_t, _P]),
     "dvm_pos_encoding_minmax_f32": (c_int, [_P, _P, c_int, c_int, _P, _P]),
+    "dvm_bn_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dvm_bn_act_train_fwd_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P,
+                                         c_size_t, _P]),
+    "dvm_bn_act_train_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, c_size_t, _P]),
     "dvm_proj2img_workspace_bytes": (c_size_t, [c_int]),
     "dvm_proj2img_f32": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
     "dvm_i2p_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),

@@ -32,6 +32,40 @@ def pos_encoding(coor, group=None, sync=False):
     return ops.pos_encoding(coor)
 
 
+class _BNAct(torch.autograd.Function):
+    """y = act(BatchNorm_train(x + res)) on the fused HIP kernels, forward and backward."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, running_mean, running_var, momentum, eps, slope):
+        y, mean, invstd = ops.bn_act_train_fwd(x, res, gamma, beta, eps, slope, momentum, running_mean, running_var)
+        ctx.save_for_backward(x, res, y, gamma, mean, invstd)
+        ctx.slope = slope
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, res, y, gamma, mean, invstd = ctx.saved_tensors
+        dx, dgamma, dbeta = ops.bn_act_train_bwd(dy.contiguous(), y, x, res, gamma, mean, invstd, ctx.slope)
+        return dx, (dx if res is not None else None), (dgamma if gamma is not None else None), \
+            (dbeta if gamma is not None else None), None, None, None, None, None
+
+
+def bn_act(bn, x, res=None, slope=1.0):
+    """act(bn(x + res)) for an nn.BatchNorm1d `bn` over (B,C,N); slope 1: no activation, 0: ReLU, 0.2: LeakyReLU.
+    Training mode with plain batch statistics goes through the fused HIP kernels (the module's running statistics and
+    batch counter are updated as nn.BatchNorm1d does); anything else — eval mode, SyncBatchNorm, no running stats —
+    uses the module itself."""
+    fused = (type(bn) is torch.nn.BatchNorm1d and bn.training and bn.track_running_stats and bn.affine
+             and bn.momentum is not None and x.is_cuda and x.dim() == 3 and x.dtype == torch.float32)
+    if not fused:
+        z = x if res is None else x + res
+        y = bn(z)
+        return y if slope == 1.0 else torch.nn.functional.leaky_relu(y, slope) if slope != 0.0 else torch.relu(y)
+    with torch.no_grad():
+        bn.num_batches_tracked += 1
+    return _BNAct.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, slope)
+
+
 def _needs_grad(*ts):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
 

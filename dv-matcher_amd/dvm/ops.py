@@ -411,6 +411,46 @@ def pos_encoding(x, minmax=None):
     return out
 
 
+def bn_act_train_fwd(x, res, gamma, beta, eps, slope, momentum, running_mean=None, running_var=None):
+    """Training-mode BatchNorm over (B,C,N) of x (+ res) with the activation fused -> (y, save_mean, save_invstd);
+    running_mean / running_var (device tensors) are updated in place."""
+    _need_gpu(x)
+    x = _f(x)
+    res = None if res is None else _f(res)
+    B, C, N = x.shape
+    lib = _lib.load()
+    y = torch.empty_like(x)
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    nb = lib.dvm_bn_workspace_bytes(B, C, N)
+    ws = workspace(nb, x.device, "bn")
+    opt = lambda t: None if t is None else _p(t)  # noqa: E731
+    if running_mean is not None:
+        assert running_mean.is_contiguous() and running_var.is_contiguous() and running_mean.dtype == torch.float32
+    check(lib.dvm_bn_act_train_fwd_f32(_p(x), opt(res), opt(None if gamma is None else _f(gamma)), opt(None if beta is None else _f(beta)),
+                                       B, C, N, float(eps), float(slope), float(momentum), _p(y), _p(mean), _p(invstd),
+                                       opt(running_mean), opt(running_var), _p(ws), nb, _stream()), "dvm_bn_act_train_fwd_f32")
+    return y, mean, invstd
+
+
+def bn_act_train_bwd(dy, y, x, res, gamma, mean, invstd, slope):
+    """-> (dx (also the gradient of res), dgamma, dbeta)."""
+    _need_gpu(dy, y, x)
+    dy, y, x = _f(dy), _f(y), _f(x)
+    res = None if res is None else _f(res)
+    B, C, N = x.shape
+    lib = _lib.load()
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    nb = lib.dvm_bn_workspace_bytes(B, C, N)
+    ws = workspace(nb, x.device, "bn")
+    check(lib.dvm_bn_act_train_bwd_f32(_p(dy), _p(y), _p(x), None if res is None else _p(res), None if gamma is None else _p(_f(gamma)),
+                                       _p(mean), _p(invstd), B, C, N, float(slope), _p(dx), _p(dgamma), _p(dbeta), _p(ws), nb,
+                                       _stream()), "dvm_bn_act_train_bwd_f32")
+    return dx, dgamma, dbeta
+
+
 def proj2img(pts):
     """One view's point cloud (B,N,3) -> (img (B,3,224,224), pc_min (B,2), grid_size (B,), offsets (B,2))."""
     _need_gpu(pts)

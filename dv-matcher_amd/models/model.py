@@ -72,7 +72,9 @@ def _folded(owner, tag, sources, build):
 
 
 def _bn_sources(bn):
-    return (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    # num_batches_tracked: the fused training kernel writes the running statistics through raw pointers (no version
+    # bump on those two tensors); the batch counter is incremented by a torch op on every such update
+    return (bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked)
 
 
 def _bn_affine(bn):
@@ -140,7 +142,7 @@ class SA_Layer(nn.Module):
 
     def forward(self, x):
         x_r = nn_ops.sa_attention(x, self.k_conv.weight, self.v_conv.weight, self.v_conv.bias)
-        return x + self.act(self.after_norm(self.trans_conv(x - x_r)))
+        return x + nn_ops.bn_act(self.after_norm, self.trans_conv(x - x_r), slope=0.0)
 
     def infer_pm(self, xt):
         """Inference on point-major activations (B,N,64): no transposes, BatchNorm folded into trans_conv."""
@@ -169,8 +171,8 @@ class _N2P(nn.Module):
 
     def forward(self, x):
         att = nn_ops.n2p_attention(x, self.K, self.q_conv.weight, self.k_conv.weight, self.v_conv.weight, self.heads)
-        x = self.bn1(x + att)
-        return self.bn2(x + self.ff(x))
+        x = nn_ops.bn_act(self.bn1, x, att)
+        return nn_ops.bn_act(self.bn2, x, self.ff(x))
 
     def infer_pm(self, xt):
         """Inference on point-major activations (B,N,C): q/k/v by ONE GEMM, gather-attention on the HIP kernel, the two
@@ -396,8 +398,10 @@ class Uni3FC(nn.Module, _VisualProjection):
         if not self.training and not (torch.is_grad_enabled() and (dino_feat.requires_grad or x.requires_grad)) \
                 and PointwiseConv1d.accumulate == "f32":
             return self._forward_infer(x, dino_feat)
-        f = self.conv(dino_feat.permute(0, 2, 1))
-        tmp = self.conv0(f + self.pos_encoding_sin_wave(x))
+        # conv -> BatchNorm -> LeakyReLU blocks: the GEMM, then ONE fused statistics + normalise + activation pass
+        blk = lambda seq, t: nn_ops.bn_act(seq[1], seq[0](t), slope=seq[2].negative_slope)  # noqa: E731
+        f = blk(self.conv, dino_feat.permute(0, 2, 1))
+        tmp = blk(self.conv0, f + self.pos_encoding_sin_wave(x))
         x1 = self.n2p_attention1(tmp)
         x1g = self.sa1(tmp)
         x2 = self.n2p_attention2(x1)
@@ -408,12 +412,12 @@ class Uni3FC(nn.Module, _VisualProjection):
         x4g = self.sa4(x3g)
         loc = torch.cat((x1, x2, x3, x4), dim=1)
         glo = torch.cat((x1g, x2g, x3g, x4g), dim=1)
-        lmax = self.conv1(loc).max(dim=-1, keepdim=True)[0].expand(-1, -1, N)
-        gmax = self.conv2(glo).max(dim=-1, keepdim=True)[0].expand(-1, -1, N)
-        y = torch.cat((self.conv3(torch.cat((lmax, loc), dim=1)), self.conv4(torch.cat((gmax, glo), dim=1))), dim=1)
-        y1 = self.conv5(y)
+        lmax = blk(self.conv1, loc).max(dim=-1, keepdim=True)[0].expand(-1, -1, N)
+        gmax = blk(self.conv2, glo).max(dim=-1, keepdim=True)[0].expand(-1, -1, N)
+        y = torch.cat((blk(self.conv3, torch.cat((lmax, loc), dim=1)), blk(self.conv4, torch.cat((gmax, glo), dim=1))), dim=1)
+        y1 = blk(self.conv5, y)
         y2 = self.n2p_attention5(y1)
         y3 = self.n2p_attention6(y2)
         y4 = self.n2p_attention7(y3)
-        out = self.conv6(torch.cat((y1, y2, y3, y4), dim=1))
+        out = blk(self.conv6, torch.cat((y1, y2, y3, y4), dim=1))
         return out.transpose(2, 1).contiguous().view(B, N, self.out), tmp.permute(0, 2, 1)

@@ -196,6 +196,20 @@ int dvm_pos_encoding_f32(const float *x, int B, int N, float *out, void *ws, siz
  * ALL ranks' shards; the host reduces the two numbers (MIN / MAX all-reduce) and passes them here. */
 int dvm_pos_encoding_minmax_f32(const float *x, const float *minmax, int B, int N, float *out, void *stream);
 
+/* Training-mode nn.BatchNorm1d over [B,C,N] fused with the residual add in front of it and the (Leaky)ReLU behind it
+ * (models/model.py:97-123 SA_Layer, 325-395 N2PAttention, 506-529 conv blocks):
+ *   z = x (+ res);  y = act(gamma (z - mean_c) / sqrt(var_c + eps) + beta),  act(t) = t > 0 ? t : slope t
+ * (slope 1: none, 0: ReLU, 0.2: LeakyReLU).  save_mean / save_invstd [C] feed the backward; running_mean / running_var
+ * (may be NULL) get PyTorch's momentum update with the unbiased variance.  Backward: dx (= d res) [B,C,N],
+ * dgamma / dbeta [C] (may be NULL); the activation's derivative is taken from the sign of y. */
+size_t dvm_bn_workspace_bytes(int B, int C, int N);
+int dvm_bn_act_train_fwd_f32(const float *x, const float *res, const float *gamma, const float *beta, int B, int C, int N,
+                             float eps, float slope, float momentum, float *y, float *save_mean, float *save_invstd,
+                             float *running_mean, float *running_var, void *ws, size_t ws_bytes, void *stream);
+int dvm_bn_act_train_bwd_f32(const float *dy, const float *y, const float *x, const float *res, const float *gamma,
+                             const float *save_mean, const float *save_invstd, int B, int C, int N, float slope, float *dx,
+                             float *dgamma, float *dbeta, void *ws, size_t ws_bytes, void *stream);
+
 /* Uni3FC.proj2img — models/model.py:584-650 (+ get_colored_depth_maps 563-581).  pts [B,N,3] (one of the three
  * axis-permuted views) -> img [B,3,224,224]: every point adds its depth (3rd coordinate) to the 5x5 pixels around its
  * cell, sigmoid, ImageNet-normalise, min-max rescale per image, 'PiYG' colour table, pixels whose depth sum is exactly 0

@@ -187,3 +187,43 @@ def test_sa_core_fwd_bwd_vs_fp64_autograd(ops, B, N):
     (ref * gx.double()).sum().backward()
     assert rel(xr, ref) < 1e-5
     assert rel(dv, v64.grad) < 1e-4 and rel(dp, p64.grad) < 1e-4, (rel(dv, v64.grad), rel(dp, p64.grad))
+
+
+@pytest.mark.parametrize("B,C,N,slope,with_res", [(2, 64, 300, 0.2, False), (3, 128, 257, 1.0, True), (1, 384, 1024, 0.2, False),
+                                                   (8, 64, 2048, 0.0, False), (2, 16, 5, 1.0, True)])
+def test_fused_batchnorm_vs_torch(ops, B, C, N, slope, with_res):
+    """dvm_bn_act_train_{fwd,bwd}_f32 == nn.BatchNorm1d (train) around a residual add and a (Leaky)ReLU, in fp64."""
+    from dvm import nn_ops
+    g = torch.Generator().manual_seed(B * 1000 + C + N)
+    x = (torch.randn(B, C, N, generator=g) * 2.0 + torch.randn(1, C, 1, generator=g) * 3.0)
+    res = torch.randn(B, C, N, generator=g) if with_res else None
+    gout = torch.randn(B, C, N, generator=g)
+    bn = torch.nn.BatchNorm1d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g))
+        bn.running_mean.copy_(torch.randn(C, generator=g))
+        bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+    ref = torch.nn.BatchNorm1d(C).double()
+    ref.load_state_dict(bn.state_dict())
+    bn = bn.cuda().train()
+    xg, rg = x.cuda().requires_grad_(True), (res.cuda().requires_grad_(True) if with_res else None)
+    y = nn_ops.bn_act(bn, xg, rg, slope=slope)
+    (y * gout.cuda()).sum().backward()
+    xd = x.double().requires_grad_(True)
+    rd = res.double().requires_grad_(True) if with_res else None
+    t = ref(xd if rd is None else xd + rd)
+    yr = t if slope == 1.0 else torch.where(t > 0, t, t * slope)
+    (yr * gout.double()).sum().backward()
+    assert rel(y, yr) < 2e-6
+    assert rel(xg.grad, xd.grad) < 2e-5, rel(xg.grad, xd.grad)
+    if with_res:
+        assert rel(rg.grad, rd.grad) < 2e-5
+    assert rel(bn.weight.grad, ref.weight.grad) < 2e-5 and rel(bn.bias.grad, ref.bias.grad) < 2e-5
+    assert rel(bn.running_mean, ref.running_mean) < 1e-6 and rel(bn.running_var, ref.running_var) < 1e-6
+    assert int(bn.num_batches_tracked) == 1
+    # eval mode / SyncBatchNorm take the module's own path
+    bn.eval()
+    ye = nn_ops.bn_act(bn, x.cuda(), None if res is None else res.cuda(), slope=slope)
+    te = ref.eval()(x.double() if res is None else x.double() + res.double())
+    assert rel(ye, te if slope == 1.0 else torch.where(te > 0, te, te * slope)) < 2e-6
