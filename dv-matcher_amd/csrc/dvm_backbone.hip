@@ -18,7 +18,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // s_ij = (-|a_i|^2 - (-2 * a_i.b_j)) - |b_j|^2, the dot product a k-ordered fma chain.
 // MFMA orientation: A = queries, B = keys, so a lane owns one key column and a register one
 // query row: rows of S are written as contiguous 128-B segments.
-constexpr int KS_KT = 64, KS_WAVES = 4, KS_QB = 128, KS_THREADS = 256;
+constexpr int KS_KT = 64, KS_QB = 128, KS_THREADS = 256;  // 4 waves x 32 query rows per workgroup
 
 template <int D>
 __global__ __launch_bounds__(KS_THREADS, 2) void knn_scores_mfma_kernel(const float *__restrict__ a, const float *__restrict__ bq,

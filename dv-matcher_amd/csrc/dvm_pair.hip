@@ -283,7 +283,7 @@ DVM_EXPORT int dvm_pair_fwd_f32(const float *feat1, const float *feat2, const fl
     }
     hipStream_t s = (hipStream_t)stream;
     const int P[2] = {N, M};
-    const float *verts[2] = {verts1, verts2}, *feat[2] = {feat1, feat2};
+    const float *verts[2] = {verts1, verts2};
     const int32_t *start[2] = {start1, start2};
     int rc;
     const bool both = (N == M) && contiguous_sides(B, N);
