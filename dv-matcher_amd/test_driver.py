@@ -30,26 +30,28 @@ from models.model import Uni3FC  # noqa: E402
 
 
 def load_pairs(args):
+    """Yields (name1, name2, load1, load2); load() -> (verts (N,3), visual features (N,1152)) is only called for a shape
+    whose backbone features are not cached yet."""
     if args.data_root:                                   # the reference's loop over testDataset (test.py:66-100)
         import scipy.io as sio
         from models.dataset import testDataset
         data = testDataset(args.data_root, name=args.data_name, train=False)
-        for item in data:
-            out = []
-            for s in ("shape1", "shape2"):
-                path = os.path.join(args.data_root, "feat", item[s]["name"] + ".mat")
-                out.append((item[s]["name"], item[s]["xyz"].numpy(), np.asarray(sio.loadmat(path)["feat"], dtype=np.float32)))
-            yield (out[0][0], out[1][0], out[0][1], out[1][1], out[0][2], out[1][2])
+
+        def loader(i):
+            path = os.path.join(args.data_root, "feat", data.used_shapes[i] + ".mat")
+            return lambda: (data.verts_list[i].numpy(), np.asarray(sio.loadmat(path)["feat"], dtype=np.float32))
+        for i1, i2 in data.combinations:
+            yield data.used_shapes[i1], data.used_shapes[i2], loader(i1), loader(i2)
     elif args.pairs:
         for path in args.pairs:
             d = np.load(path, allow_pickle=False)
-            yield (str(d["name1"]), str(d["name2"]), d["verts1"], d["verts2"], d["dino1"], d["dino2"])
+            yield (str(d["name1"]), str(d["name2"]), (lambda d=d: (d["verts1"], d["dino1"])), (lambda d=d: (d["verts2"], d["dino2"])))
     else:
         g = torch.Generator().manual_seed(args.seed)
         for p in range(args.synthetic):
             v1, v2 = torch.rand(args.points, 3, generator=g), torch.rand(args.points, 3, generator=g)
             d1, d2 = torch.randn(args.points, 1152, generator=g), torch.randn(args.points, 1152, generator=g)
-            yield ("s%03da" % p, "s%03db" % p, v1.numpy(), v2.numpy(), d1.numpy(), d2.numpy())
+            yield ("s%03da" % p, "s%03db" % p, (lambda v=v1, d=d1: (v.numpy(), d.numpy())), (lambda v=v2, d=d2: (v.numpy(), d.numpy())))
 
 
 def write_results(save_path, name1, name2, T12, T21, feat1, feat2):
@@ -74,6 +76,7 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--ckpt", default=None, help="ep_val_best.pth (Uni3FC state_dict); default: random init")
     ap.add_argument("--out", default="result/dvmatcher_amd_synthetic")
+    ap.add_argument("--no-feature-cache", action="store_true", help="recompute both shapes' features for every pair, like test.py")
     args = ap.parse_args(argv)
     assert torch.cuda.is_available(), "the inference path needs a HIP device"
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
@@ -84,12 +87,22 @@ def main(argv=None):
         net.load_state_dict(torch.load(args.ckpt, map_location=dev))
     net.eval()
     n, t0 = 0, time.perf_counter()
+    feats = {}  # name -> (B=1) features: test.py re-runs the backbone for both shapes of every ordered pair; the eval-mode
+    #             forward of one shape does not depend on its partner, so S forwards serve all S(S-1) pairs
+
+    def features(name, load):
+        if name not in feats:
+            v, d = load()
+            verts = torch.from_numpy(v).float().to(dev)[None]
+            dino = torch.from_numpy(d).float().to(dev)[None]
+            feats[name] = net(verts.permute(0, 2, 1), dino, None)[0]
+        return feats[name]
+
     with torch.no_grad():
-        for name1, name2, v1, v2, d1, d2 in load_pairs(args):
-            verts1, verts2 = torch.from_numpy(v1).float().to(dev)[None], torch.from_numpy(v2).float().to(dev)[None]
-            dino1, dino2 = torch.from_numpy(d1).float().to(dev)[None], torch.from_numpy(d2).float().to(dev)[None]
-            feat1, _ = net(verts1.permute(0, 2, 1), dino1, None)
-            feat2, _ = net(verts2.permute(0, 2, 1), dino2, None)
+        for name1, name2, load1, load2 in load_pairs(args):
+            if args.no_feature_cache:
+                feats.clear()
+            feat1, feat2 = features(name1, load1), features(name2, load2)
             T12, T21 = search_t(feat1, feat2) + 1, search_t(feat2, feat1) + 1       # 1-based like test.py:19-23
             write_results(args.out, name1, name2, T12.cpu().squeeze(0).numpy(), T21.cpu().squeeze(0).numpy(),
                           feat1.cpu().squeeze(0).numpy(), feat2.cpu().squeeze(0).numpy())
