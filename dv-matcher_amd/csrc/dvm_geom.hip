@@ -574,21 +574,56 @@ __global__ void mean_kernel(const float *__restrict__ in, int n, float scale, fl
 
 using namespace dvm;
 
-DVM_EXPORT int dvm_argmin_exact_f32(const float *f1, const float *f2, int B, int N, int M, int d, int32_t *T, float *dmin,
-                                    void *stream) {
-    DVM_REQUIRE(f1 && f2 && T, "dvm_argmin_exact_f32: null pointer");
-    DVM_REQUIRE(B >= 1 && N >= 1 && M >= 1, "dvm_argmin_exact_f32: empty input (B=%d N=%d M=%d)", B, N, M);
-    DVM_REQUIRE(d >= 4 && d % 4 == 0 && d <= 512, "dvm_argmin_exact_f32: d=%d unsupported (need d%%4==0, 4<=d<=512)", d);
+namespace dvm {
+size_t argmin_f16_ws_bytes(int B, int N, int M, bool both);
+int launch_argmin_f16(const float *f1, const float *f2, int B, int N, int M, int32_t *T12, float *dmin12, int32_t *T21,
+                      float *dmin21, void *ws, size_t ws_bytes, hipStream_t s);
+}  // namespace dvm
+
+static int argmin_all_columns(const float *f1, const float *f2, int B, int N, int M, int d, int32_t *T, float *dmin, hipStream_t s) {
     size_t lds = (size_t)AM_KT * d * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)argmin_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         attr_set = true;
     }
-    hipLaunchKernelGGL(argmin_exact_kernel, dim3((N + 127) / 128, B), dim3(128), lds, (hipStream_t)stream, f1, f2, N, M, d, T,
-                       dmin);
+    hipLaunchKernelGGL(argmin_exact_kernel, dim3((N + 127) / 128, B), dim3(128), lds, s, f1, f2, N, M, d, T, dmin);
     DVM_CHECK_LAUNCH("argmin_exact");
     return DVM_OK;
+}
+
+DVM_EXPORT size_t dvm_argmin_workspace_bytes(int B, int N, int M, int d, int both_directions) {
+    return d == 128 ? argmin_f16_ws_bytes(B, N, M, both_directions != 0) : 0;
+}
+
+DVM_EXPORT int dvm_argmin_exact_f32(const float *f1, const float *f2, int B, int N, int M, int d, int32_t *T, float *dmin,
+                                    void *ws, size_t ws_bytes, void *stream) {
+    DVM_REQUIRE(f1 && f2 && T, "dvm_argmin_exact_f32: null pointer");
+    DVM_REQUIRE(B >= 1 && N >= 1 && M >= 1, "dvm_argmin_exact_f32: empty input (B=%d N=%d M=%d)", B, N, M);
+    DVM_REQUIRE(d >= 4 && d % 4 == 0 && d <= 512, "dvm_argmin_exact_f32: d=%d unsupported (need d%%4==0, 4<=d<=512)", d);
+    if (ws != nullptr && d == 128) {
+        int rc = launch_argmin_f16(f1, f2, B, N, M, T, dmin, nullptr, nullptr, ws, ws_bytes, (hipStream_t)stream);
+        if (rc != DVM_OK) return rc;
+        DVM_CHECK_LAUNCH("argmin_exact(sweep)");
+        return DVM_OK;
+    }
+    return argmin_all_columns(f1, f2, B, N, M, d, T, dmin, (hipStream_t)stream);
+}
+
+DVM_EXPORT int dvm_argmin_pair_f32(const float *f1, const float *f2, int B, int N, int M, int d, int32_t *T12, int32_t *T21,
+                                   float *dmin12, float *dmin21, void *ws, size_t ws_bytes, void *stream) {
+    DVM_REQUIRE(f1 && f2 && T12 && T21, "dvm_argmin_pair_f32: null pointer");
+    DVM_REQUIRE(B >= 1 && N >= 1 && M >= 1, "dvm_argmin_pair_f32: empty input (B=%d N=%d M=%d)", B, N, M);
+    DVM_REQUIRE(d >= 4 && d % 4 == 0 && d <= 512, "dvm_argmin_pair_f32: d=%d unsupported (need d%%4==0, 4<=d<=512)", d);
+    if (ws != nullptr && d == 128) {
+        int rc = launch_argmin_f16(f1, f2, B, N, M, T12, dmin12, T21, dmin21, ws, ws_bytes, (hipStream_t)stream);
+        if (rc != DVM_OK) return rc;
+        DVM_CHECK_LAUNCH("argmin_pair(sweep)");
+        return DVM_OK;
+    }
+    int rc = argmin_all_columns(f1, f2, B, N, M, d, T12, dmin12, (hipStream_t)stream);
+    if (rc != DVM_OK) return rc;
+    return argmin_all_columns(f2, f1, B, M, N, d, T21, dmin21, (hipStream_t)stream);
 }
 
 DVM_EXPORT size_t dvm_knn_cdist_workspace_bytes(int B, int N, int M, int C) {

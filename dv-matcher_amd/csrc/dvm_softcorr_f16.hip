@@ -596,6 +596,114 @@ __global__ __launch_bounds__(256) void softcorr_exact_rows_kernel(const HXArgs a
     }
 }
 
+// ---------------------------------------------------------------- hard map (knnsearch_t) on the same sweep
+// T[i] = argmin_j sqrt(sum_c (q_c - k_c)^2) in the reference's exact-difference form (models/loss.py:91-95,
+// test.py:19-23): sequential sub / mul / add over the feature index, ties -> lowest j.  That form cannot run on the
+// matrix cores, but it only has to be evaluated for the columns that can still be the minimum: pass A's candidate
+// list holds the 12 smallest mm-form distances up to HB_ERR (na + nk); the exact-difference value differs from the
+// real distance by at most (d + 1) ulp-relative.  A column is examined when its approximate squared distance is within
+// 2 AM_ERR (na + nkmax) of the row's smallest; a row whose 12 candidates ALL fall inside that band (duplicate points)
+// is re-done by a full exact scan.
+constexpr float AM_ERR = HB_ERR + 2e-5f;
+
+__device__ __forceinline__ float diff_d2(const float *__restrict__ q, const float *__restrict__ k) {
+    float acc = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < HB_D; c += 4) {
+        const f32x4 qv = *(const f32x4 *)(q + c), kv = *(const f32x4 *)(k + c);
+        const float e0 = qv.x - kv.x, e1 = qv.y - kv.y, e2 = qv.z - kv.z, e3 = qv.w - kv.w;
+        const float p0 = e0 * e0, p1 = e1 * e1, p2 = e2 * e2, p3 = e3 * e3;
+        acc = acc + p0;
+        acc = acc + p1;
+        acc = acc + p2;
+        acc = acc + p3;
+    }
+    return acc;
+}
+
+struct AMGroup {
+    const float *q, *k, *nq, *nkmax;
+    int N, M;
+    const int32_t *cidx;
+    const float *cd2;
+    int32_t *T;
+    float *dmin;
+    int32_t *flagged, *nflagged;
+};
+struct AMArgs {
+    AMGroup g[2];
+    long rows0, rows_total;
+};
+
+__global__ __launch_bounds__(256) void argmin_refine_kernel(const AMArgs args) {
+    long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= args.rows_total) return;
+    const int grp = row >= args.rows0 ? 1 : 0;
+    row -= grp ? args.rows0 : 0;
+    const AMGroup &G = args.g[grp];
+    const int b = (int)(row / G.N);
+    const float *q = G.q + (size_t)row * HB_D;
+    const float band = 2.f * AM_ERR * (G.nq[row] + G.nkmax[b]);
+    const float v0 = G.cd2[row * HB_KC];
+    float best = INFINITY;
+    int bj = 0x7fffffff;
+    bool open = true;  // does the band reach past the list?
+    for (int t = 0; t < HB_KC; ++t) {
+        const float v = G.cd2[row * HB_KC + t];
+        const int j = G.cidx[row * HB_KC + t];
+        if (!(v <= v0 + band) || j < 0 || j >= G.M) {
+            open = false;
+            break;
+        }
+        const float dv = sqrt_rn(diff_d2(q, G.k + ((size_t)b * G.M + j) * HB_D));
+        if (dv < best || (dv == best && j < bj)) best = dv, bj = j;
+    }
+    if (open && G.M > HB_KC) {
+        G.flagged[atomicAdd(G.nflagged, 1)] = (int32_t)row;
+        return;
+    }
+    G.T[row] = bj;
+    if (G.dmin) G.dmin[row] = best;
+}
+
+// full exact scan of the flagged rows, one workgroup per row
+__global__ __launch_bounds__(256) void argmin_exact_rows_kernel(const AMArgs args) {
+    __shared__ float sd[256];
+    __shared__ int sj[256];
+    for (int grp = 0; grp < 2; ++grp) {
+        const AMGroup &G = args.g[grp];
+        if (!G.flagged) continue;
+        const int cnt = *G.nflagged;
+        for (int f = blockIdx.x; f < cnt; f += gridDim.x) {
+            const long row = G.flagged[f];
+            const int b = (int)(row / G.N);
+            const float *q = G.q + (size_t)row * HB_D;
+            float best = INFINITY;
+            int bj = 0x7fffffff;
+            for (int j = threadIdx.x; j < G.M; j += 256) {  // ascending j per thread: strict < keeps the lowest
+                const float dv = sqrt_rn(diff_d2(q, G.k + ((size_t)b * G.M + j) * HB_D));
+                if (dv < best) best = dv, bj = j;
+            }
+            __syncthreads();
+            sd[threadIdx.x] = best;
+            sj[threadIdx.x] = bj;
+            __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) {
+                if ((int)threadIdx.x < o) {
+                    const float od = sd[threadIdx.x + o];
+                    const int oj = sj[threadIdx.x + o];
+                    if (od < sd[threadIdx.x] || (od == sd[threadIdx.x] && oj < sj[threadIdx.x])) sd[threadIdx.x] = od, sj[threadIdx.x] = oj;
+                }
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) {
+                G.T[row] = sj[0];
+                if (G.dmin) G.dmin[row] = sd[0];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // workspace of the fp16 path for (B, N, M): planes of both sides, candidates of both directions, flags
@@ -691,6 +799,72 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
     x.neg_alpha = neg_alpha;
     x.topk = topk;
     hipLaunchKernelGGL(softcorr_exact_rows_kernel, dim3(512), dim3(256), 0, s, x);
+    return DVM_OK;
+}
+
+size_t argmin_f16_ws_bytes(int B, int N, int M, bool both) {
+    return align_up((size_t)B * N * sizeof(float)) + align_up((size_t)B * M * sizeof(float)) + softcorr_f16_ws_bytes(B, N, M, both);
+}
+
+// hard maps of f1 -> f2 (T12 [B][N]) and, when T21 != nullptr, f2 -> f1 (T21 [B][M]); d = 128
+int launch_argmin_f16(const float *f1, const float *f2, int B, int N, int M, int32_t *T12, float *dmin12, int32_t *T21,
+                      float *dmin21, void *ws, size_t ws_bytes, hipStream_t s) {
+    const bool both = T21 != nullptr;
+    Arena ar(ws, ws_bytes);
+    float *n1 = ar.take<float>((size_t)B * N), *n2 = ar.take<float>((size_t)B * M);
+    char *p1 = ar.take<char>((size_t)B * N * HB_ROWB), *p2 = ar.take<char>((size_t)B * M * HB_ROWB);
+    float *nmax1 = ar.take<float>(B), *nmax2 = ar.take<float>(B);
+    int *amax = ar.take<int>(2);
+    const int Np = (N + HB_KT - 1) / HB_KT * HB_KT, Mp = (M + HB_KT - 1) / HB_KT * HB_KT;
+    float *n1p = ar.take<float>((size_t)B * Np), *n2p = ar.take<float>((size_t)B * Mp);
+    int32_t *cidx[2] = {nullptr, nullptr}, *flag[2] = {nullptr, nullptr};
+    float *cd2[2] = {nullptr, nullptr}, *lsum[2] = {nullptr, nullptr};
+    for (int d = 0; d < (both ? 2 : 1); ++d) {
+        const size_t R = (size_t)B * (d == 0 ? N : M);
+        cidx[d] = ar.take<int32_t>(R * HB_KC);
+        cd2[d] = ar.take<float>(R * HB_KC);
+        lsum[d] = ar.take<float>(R * 2);
+        flag[d] = ar.take<int32_t>(R + 1);
+    }
+    if (!ar.ok()) {
+        set_error("argmin (fp16 sweep): workspace too small (%zu < %zu)", ws_bytes, ar.off);
+        return DVM_ENOSPACE;
+    }
+    const long r1 = (long)B * N, r2 = (long)B * M;
+    launch_rownorm2(f1, (int)r1, HB_D, n1, s);
+    launch_rownorm2(f2, (int)r2, HB_D, n2, s);
+    (void)hipMemsetAsync(nmax1, 0, 2 * align_up((size_t)B * sizeof(float)) + 2 * sizeof(int), s);
+    hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, s, f1, r1 * 32, amax);
+    hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, s, f2, r2 * 32, amax + 1);
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((r1 * 32 + 255) / 256)), dim3(256), 0, s, f1, r1, amax, p1);
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((r2 * 32 + 255) / 256)), dim3(256), 0, s, f2, r2, amax + 1, p2);
+    hipLaunchKernelGGL(norm_max_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, n1, N, nmax1);
+    hipLaunchKernelGGL(norm_max_kernel, dim3((M + 255) / 256, B), dim3(256), 0, s, n2, M, nmax2);
+    for (int d = 0; d < (both ? 2 : 1); ++d) (void)hipMemsetAsync(flag[d], 0, sizeof(int32_t), s);
+    hipLaunchKernelGGL(pad_norms_kernel, dim3((Mp + 255) / 256, B), dim3(256), 0, s, n2, M, Mp, n2p);
+    if (both) hipLaunchKernelGGL(pad_norms_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, s, n1, N, Np, n1p);
+    HBArgs a;
+    a.g[0] = HBGroup{p1, p2, amax, amax + 1, n1, n2p, N, M, Mp, (N + HB_QB - 1) / HB_QB, cidx[0], cd2[0], lsum[0]};
+    a.g[1] = both ? HBGroup{p2, p1, amax + 1, amax, n2, n1p, M, N, Np, (M + HB_QB - 1) / HB_QB, cidx[1], cd2[1], lsum[1]} : a.g[0];
+    a.blocks0 = B * a.g[0].tiles;
+    a.neg_alpha = -100.f;  // only the candidate lists are used; the lean sweep keeps them exactly as the full one does
+    a.cutw = 0.f;
+    const int blocks = a.blocks0 + (both ? B * a.g[1].tiles : 0);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)softcorr_sweep_f16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)HB_LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(softcorr_sweep_f16_kernel<true>, dim3(blocks), dim3(HB_THREADS), HB_LDS_BYTES, s, a);
+    AMArgs r;
+    r.g[0] = AMGroup{f1, f2, n1, nmax2, N, M, cidx[0], cd2[0], T12, dmin12, flag[0] + 1, flag[0]};
+    r.g[1] = both ? AMGroup{f2, f1, n2, nmax1, M, N, cidx[1], cd2[1], T21, dmin21, flag[1] + 1, flag[1]}
+                  : AMGroup{nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    r.rows0 = r1;
+    r.rows_total = r1 + (both ? r2 : 0);
+    hipLaunchKernelGGL(argmin_refine_kernel, dim3((unsigned)((r.rows_total + 255) / 256)), dim3(256), 0, s, r);
+    hipLaunchKernelGGL(argmin_exact_rows_kernel, dim3(512), dim3(256), 0, s, r);
     return DVM_OK;
 }
 

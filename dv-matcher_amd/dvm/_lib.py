@@ -44,7 +44,9 @@ SIGNATURES = {
     "dvm_sa_attention_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
     "dvm_sa_attention_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, c_size_t, _P]),
     "dvm_pair_set_overlap": (c_int, [c_int]),
-    "dvm_argmin_exact_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "dvm_argmin_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "dvm_argmin_exact_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
+    "dvm_argmin_pair_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
     "dvm_knn_cdist_workspace_bytes": (c_size_t, [c_int] * 4),
     "dvm_knn_cdist_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_size_t, _P]),
     "dvm_knn_neg_workspace_bytes": (c_size_t, [c_int] * 5),

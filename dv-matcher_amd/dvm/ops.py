@@ -126,15 +126,37 @@ def n2p_core_bwd(qkv, idx, attn, gout, heads=4):
     return dqkv
 
 
-def argmin_exact(f1, f2, want_dist=False):
+def argmin_exact(f1, f2, want_dist=False, screen=True):
+    """Hard map T[b,i] = argmin_j of the exact-difference distance (ties -> lowest j).  screen=False evaluates every
+    column in that form; the default screens the columns on the matrix cores first (same result)."""
     _need_gpu(f1, f2)
     f1, f2 = _f(f1), _f(f2)
     B, N, d = f1.shape
     M = f2.shape[1]
+    lib = _lib.load()
     T = torch.empty(B, N, dtype=torch.int32, device=f1.device)
     dm = torch.empty(B, N, dtype=torch.float32, device=f1.device) if want_dist else None
-    check(_lib.load().dvm_argmin_exact_f32(_p(f1), _p(f2), B, N, M, d, _p(T), _p(dm), _stream()), "dvm_argmin_exact_f32")
+    nb = lib.dvm_argmin_workspace_bytes(B, N, M, d, 0) if screen else 0
+    ws = workspace(nb, f1.device, "argmin") if nb else None
+    check(lib.dvm_argmin_exact_f32(_p(f1), _p(f2), B, N, M, d, _p(T), _p(dm), _p(ws) if nb else None, nb, _stream()),
+          "dvm_argmin_exact_f32")
     return (T, dm) if want_dist else T
+
+
+def argmin_pair(f1, f2):
+    """Both hard maps of a pair from one sweep: (T12 (B,N) into f2, T21 (B,M) into f1)."""
+    _need_gpu(f1, f2)
+    f1, f2 = _f(f1), _f(f2)
+    B, N, d = f1.shape
+    M = f2.shape[1]
+    lib = _lib.load()
+    T12 = torch.empty(B, N, dtype=torch.int32, device=f1.device)
+    T21 = torch.empty(B, M, dtype=torch.int32, device=f1.device)
+    nb = lib.dvm_argmin_workspace_bytes(B, N, M, d, 1)
+    ws = workspace(nb, f1.device, "argmin") if nb else None
+    check(lib.dvm_argmin_pair_f32(_p(f1), _p(f2), B, N, M, d, _p(T12), _p(T21), None, None, _p(ws) if nb else None, nb, _stream()),
+          "dvm_argmin_pair_f32")
+    return T12, T21
 
 
 def knn_cdist(x, y, k):

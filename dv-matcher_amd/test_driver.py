@@ -25,7 +25,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 if HERE not in sys.path:
     sys.path.insert(0, HERE)
 
-from models.loss import search_t  # noqa: E402
+from dvm import ops  # noqa: E402
+from models.loss import search_t  # noqa: E402,F401
 from models.model import Uni3FC  # noqa: E402
 
 
@@ -103,7 +104,7 @@ def main(argv=None):
             if args.no_feature_cache:
                 feats.clear()
             feat1, feat2 = features(name1, load1), features(name2, load2)
-            T12, T21 = search_t(feat1, feat2) + 1, search_t(feat2, feat1) + 1       # 1-based like test.py:19-23
+            T12, T21 = (t.long() + 1 for t in ops.argmin_pair(feat1, feat2))     # search_t both ways, 1-based like test.py:19-23
             write_results(args.out, name1, name2, T12.cpu().squeeze(0).numpy(), T21.cpu().squeeze(0).numpy(),
                           feat1.cpu().squeeze(0).numpy(), feat2.cpu().squeeze(0).numpy())
             n += 1

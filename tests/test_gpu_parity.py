@@ -5,6 +5,7 @@ indices); floats within 1e-4 (absolute, the tolerance BASELINE.json's north_star
 most of them far tighter.
 """
 import glob
+import zlib
 import os
 
 import numpy as np
@@ -107,6 +108,52 @@ def test_argmin_exact(ops, golden, name):
     assert np.array_equal(host(T)[0], oT)
     assert np.array_equal(host(dm)[0], odm)
     assert np.array_equal(host(T)[0], g["T12"][0, :, 0])  # the reference's knnsearch_t
+
+
+@pytest.mark.parametrize("case", ["random", "duplicates", "near_ties", "tiny_M", "ragged", "clustered", "many_equal"])
+def test_argmin_screened_equals_full_scan(ops, case):
+    """The matrix-core screened hard map is the same function as the all-columns exact-difference scan and the oracle:
+    bit-exact indices (ties -> lowest column) and distances, also when whole groups of columns tie."""
+    g = torch.Generator().manual_seed(zlib.crc32(case.encode()))
+    B, N, M = 2, 300, 257
+    f1, f2 = torch.randn(B, N, 128, generator=g), torch.randn(B, M, 128, generator=g)
+    if case == "duplicates":
+        f2[:, 100:130] = f2[:, 5:6]                       # 31 identical columns: more than the candidate list holds
+        f1[:, :40] = f2[:, 5:6] + 1e-3 * torch.randn(B, 40, 128, generator=g)
+    elif case == "near_ties":
+        f2[:, 1::2] = f2[:, 0::2][:, :M // 2] + 3e-6 * torch.randn(B, M // 2, 128, generator=g)   # pairs of columns ~1 ulp apart
+        f1[:, :150] = f2[:, :150] + 1e-2 * torch.randn(B, 150, 128, generator=g)
+    elif case == "tiny_M":
+        M = 7
+        f2 = f2[:, :M].contiguous()
+    elif case == "ragged":
+        N, M = 131, 1030
+        f1, f2 = torch.randn(B, N, 128, generator=g), torch.randn(B, M, 128, generator=g)
+    elif case == "clustered":
+        f2 = 0.01 * f2 + 3.0                               # all columns nearly the same point, far from the origin
+        f1 = 0.01 * f1 + 3.0
+    elif case == "many_equal":
+        f2[:] = f2[:, :1]                                  # every column identical: the answer is column 0 everywhere
+    T, dm = ops.argmin_exact(dev(f1), dev(f2), want_dist=True)
+    Tf, dmf = ops.argmin_exact(dev(f1), dev(f2), want_dist=True, screen=False)
+    assert torch.equal(T, Tf) and torch.equal(dm, dmf)
+    for b in range(B):
+        oT, odm = O.argmin_exact(f1[b].numpy(), f2[b].numpy())
+        assert np.array_equal(host(T[b]), oT) and np.array_equal(host(dm[b]), odm)
+    T12, T21 = ops.argmin_pair(dev(f1), dev(f2))
+    assert torch.equal(T12, T) and torch.equal(T21, ops.argmin_exact(dev(f2), dev(f1), screen=False))
+    if case == "many_equal":
+        assert int(T.max()) == 0
+
+
+def test_argmin_full_size_screened(ops):
+    """N = M = 4995 (test.py's shape): screened == all-columns scan on every row."""
+    g = torch.Generator().manual_seed(77)
+    f1, f2 = torch.randn(1, 4995, 128, generator=g), torch.randn(1, 4995, 128, generator=g)
+    f1[0, :500] = f2[0, 1000:1500] + 0.05 * torch.randn(500, 128, generator=g)     # planted matches
+    T = ops.argmin_exact(dev(f1), dev(f2))
+    assert torch.equal(T, ops.argmin_exact(dev(f1), dev(f2), screen=False))
+    assert np.array_equal(host(T[0, :500]), np.arange(1000, 1500))
 
 
 @pytest.mark.parametrize("name", names("knn_"))
