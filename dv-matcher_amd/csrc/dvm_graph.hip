@@ -7,13 +7,14 @@
 // per shape with the cloud and the running distances resident in registers/LDS, the KDTree
 // queries become brute-force fp64 sweeps (exactly scipy's arithmetic), and nothing leaves HBM.
 #include "dvm_common.h"
+#include <stdlib.h>
 
 namespace dvm {
 
 // ---------------------------------------------------------------- farthest point sampling
 // One workgroup per shape; thread t owns points t, t+T, t+2T, ... (PPT of them) with their
 // running min-distance in registers; the cloud is also kept in LDS for the centroid broadcast.
-constexpr int FPS_T = 256;
+// threads per cloud: 256 / 512 / 1024 (launch_fps), points per thread matched to N
 
 struct ArgMax {
     float v;
@@ -24,7 +25,7 @@ __device__ __forceinline__ ArgMax better(ArgMax a, ArgMax b) {  // larger value,
     return tb ? b : a;
 }
 
-template <int PPT>
+template <int PPT, int FPS_T>
 __global__ __launch_bounds__(FPS_T) void fps_kernel(const float *__restrict__ xyz, int N, int npoint,
                                                     const int32_t *__restrict__ start, int32_t *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [N*3] cloud + [2][4] partial argmax
@@ -342,26 +343,40 @@ __global__ __launch_bounds__(256) void dg_arap_kernel(const float *__restrict__ 
     }
 }
 
-int launch_fps(const float *xyz, int B, int N, int npoint, const int32_t *start, int32_t *out, hipStream_t s) {
-    size_t lds = (size_t)((N * 3 + 3) & ~3) * sizeof(float) + 2 * (FPS_T / 64) * sizeof(ArgMax);
-    int ppt = (N + FPS_T - 1) / FPS_T;
+template <int PPT, int T>
+static void launch_fps_t(const float *xyz, int B, int N, int npoint, const int32_t *start, int32_t *out, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)fps_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)fps_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)fps_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)fps_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)fps_kernel<PPT, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (ppt <= 8)
-        hipLaunchKernelGGL(fps_kernel<8>, dim3(B), dim3(FPS_T), lds, s, xyz, N, npoint, start, out);
-    else if (ppt <= 16)
-        hipLaunchKernelGGL(fps_kernel<16>, dim3(B), dim3(FPS_T), lds, s, xyz, N, npoint, start, out);
-    else if (ppt <= 32)
-        hipLaunchKernelGGL(fps_kernel<32>, dim3(B), dim3(FPS_T), lds, s, xyz, N, npoint, start, out);
-    else
-        hipLaunchKernelGGL(fps_kernel<48>, dim3(B), dim3(FPS_T), lds, s, xyz, N, npoint, start, out);
-    return DVM_OK;
+    const size_t lds = (size_t)((N * 3 + 3) & ~3) * sizeof(float) + 2 * (T / 64) * sizeof(ArgMax);
+    hipLaunchKernelGGL((fps_kernel<PPT, T>), dim3(B), dim3(T), lds, s, xyz, N, npoint, start, out);
+}
+
+// Each step is a dependent chain (distance update -> arg-max -> next centre), so its latency is what counts: the
+// per-thread part shrinks with more threads per cloud (and with PPT matched to N instead of rounded up to a power of
+// two), the cross-wave part grows with the wave count.  env DVM_FPS_THREADS overrides the choice (256 / 512 / 1024).
+int launch_fps(const float *xyz, int B, int N, int npoint, const int32_t *start, int32_t *out, hipStream_t s) {
+    static const int forced = [] {
+        const char *e = getenv("DVM_FPS_THREADS");
+        return e ? atoi(e) : 0;
+    }();
+    // measured (us/step at 256 / 512 / 1024 threads): N = 2048: 0.65 / 0.71 / 1.18; 4995: 0.93 / 0.89 / 1.31; 12000: 1.63 / 1.22 / 1.63
+    int T = forced ? forced : (N <= 4096 ? 256 : 512);
+    if (N > 48 * T) T = N > 48 * 512 ? 1024 : 512;
+    const int ppt = (N + T - 1) / T;
+#define DVM_FPS_CASE(P)                                                                          \
+    if (ppt <= P) {                                                                              \
+        if (T == 256) launch_fps_t<P, 256>(xyz, B, N, npoint, start, out, s);                    \
+        else if (T == 512) launch_fps_t<P, 512>(xyz, B, N, npoint, start, out, s);               \
+        else launch_fps_t<P, 1024>(xyz, B, N, npoint, start, out, s);                            \
+        return DVM_OK;                                                                           \
+    }
+    DVM_FPS_CASE(2) DVM_FPS_CASE(4) DVM_FPS_CASE(6) DVM_FPS_CASE(8) DVM_FPS_CASE(10) DVM_FPS_CASE(12) DVM_FPS_CASE(16)
+    DVM_FPS_CASE(20) DVM_FPS_CASE(24) DVM_FPS_CASE(32) DVM_FPS_CASE(48)
+#undef DVM_FPS_CASE
+    return DVM_EINVAL;
 }
 
 // graph build on uniform grids (dvm_grid.hip): gverts = grid over all vertices (built here, reusable by
