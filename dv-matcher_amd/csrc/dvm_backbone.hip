@@ -312,6 +312,110 @@ __global__ __launch_bounds__(256) void topk_wave_kernel(const float *__restrict_
     if (!small && lane + 64 < k) idx[row * k + lane + 64] = (int32_t)(unsigned)a1;
 }
 
+// Rows longer than 2048 columns: the same algorithm without the per-lane key array (128 VGPRs at EPL = 128 left two
+// waves per SIMD and ran 7x slower per byte than EPL = 32).  The row is streamed three times instead — lane minima,
+// then count + optimistic compaction of the keys <= Tc — and stays L2-resident between the passes (20 KB at M = 4995).
+__global__ __launch_bounds__(256) void topk_wave_stream_kernel(const float *__restrict__ S, int M, int k, long rows,
+                                                               int32_t *__restrict__ idx) {
+    __shared__ unsigned long long cand[4][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const float *s = S + row * M;
+    const int E = (M + 63) / 64;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    unsigned m1 = 0xffffffffu, m2 = 0xffffffffu;
+#pragma unroll 4
+    for (int e = 0; e < E; ++e) {
+        const int j = e * 64 + lane;
+        const unsigned x = j < M ? desc_key(s[j]) : 0xffffffffu;
+        m2 = min(m2, max(m1, x));
+        m1 = min(m1, x);
+    }
+    unsigned T = 0;
+    for (int bit = 31; bit >= 0; --bit) {  // largest T with count(minima < T) < k  ==  their k-th smallest
+        const unsigned c = T | (1u << bit);
+        const int cnt = __popcll(__ballot(m1 < c)) + __popcll(__ballot(m2 < c));
+        if (cnt < k) T = c;
+    }
+    unsigned long long *cw = cand[wave];
+    cw[lane] = ~0ull;
+    cw[lane + 64] = ~0ull;
+    int base = 0;
+#pragma unroll 4
+    for (int e = 0; e < E; ++e) {  // optimistic: at most 128 keys pass unless the row has heavy ties
+        const int j = e * 64 + lane;
+        const unsigned x = j < M ? desc_key(s[j]) : 0xffffffffu;
+        const bool take = x <= T && j < M;
+        const unsigned long long mt = __ballot(take);
+        const int pos = base + __popcll(mt & below);
+        if (take && pos < 128) cw[pos] = ((unsigned long long)x << 32) | (unsigned)j;
+        base += __popcll(mt);
+    }
+    if (base > 128) {  // heavy ties: the exact k-th key over all keys, then only the winners (ties in column order)
+        T = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned c = T | (1u << bit);
+            int cnt = 0;
+            for (int e = 0; e < E; ++e) {
+                const int j = e * 64 + lane;
+                const unsigned x = j < M ? desc_key(s[j]) : 0xffffffffu;
+                cnt += __popcll(__ballot(x < c));
+            }
+            if (cnt < k) T = c;
+        }
+        int lt = 0;
+        for (int e = 0; e < E; ++e) {
+            const int j = e * 64 + lane;
+            const unsigned x = j < M ? desc_key(s[j]) : 0xffffffffu;
+            lt += __popcll(__ballot(x < T));
+        }
+        const int ties = k - lt;
+        cw[lane] = ~0ull;
+        cw[lane + 64] = ~0ull;
+        base = 0;
+        int tbase = 0;
+        for (int e = 0; e < E; ++e) {
+            const int j = e * 64 + lane;
+            const unsigned x = j < M ? desc_key(s[j]) : 0xffffffffu;
+            const bool eq = x == T && j < M;
+            const unsigned long long meq = __ballot(eq);
+            const int teq = tbase + __popcll(meq & below);
+            const bool take = (x < T && j < M) || (eq && teq < ties);
+            const unsigned long long mt = __ballot(take);
+            if (take) cw[base + __popcll(mt & below)] = ((unsigned long long)x << 32) | (unsigned)j;
+            base += __popcll(mt);
+            tbase += __popcll(meq);
+        }
+    }
+    // bitonic sort of 128 words, element i = lane + 64 * slot (LDS operations of one wave execute in order)
+    unsigned long long a0 = cw[lane], a1 = cw[lane + 64];
+    const bool small = base <= 64;
+    for (int size = 2; size <= (small ? 64 : 128); size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (stride == 64) {
+                const unsigned long long lo = a0 < a1 ? a0 : a1, hi = a0 < a1 ? a1 : a0;
+                a0 = lo, a1 = hi;
+            } else {
+                const bool lower = (lane & stride) == 0;
+#pragma unroll
+                for (int slot = 0; slot < 2; ++slot) {
+                    if (slot == 1 && small) break;
+                    unsigned long long &x = slot ? a1 : a0;
+                    const int i = lane + 64 * slot;
+                    const bool up = (i & size) == 0 || size == 128;
+                    const unsigned long long y =
+                        ((unsigned long long)__shfl_xor((unsigned)(x >> 32), stride, 64) << 32) | __shfl_xor((unsigned)x, stride, 64);
+                    const bool keep_min = (lower == up);
+                    x = keep_min ? (x < y ? x : y) : (x < y ? y : x);
+                }
+            }
+        }
+    }
+    if (lane < k) idx[row * k + lane] = (int32_t)(unsigned)a0;
+    if (!small && lane + 64 < k) idx[row * k + lane + 64] = (int32_t)(unsigned)a1;
+}
+
 // ============================================================== positional encoding
 __global__ void minmax_partial_kernel(const float *__restrict__ x, long n, float *__restrict__ part) {
     __shared__ float smn[256], smx[256];
@@ -763,10 +867,8 @@ int launch_knn_neg(const float *a, const float *bq, int B, int N, int M, int C, 
         const dim3 wgrid((unsigned)((rows + 3) / 4));
         if (M <= 2048)
             hipLaunchKernelGGL(topk_wave_kernel<32>, wgrid, dim3(256), 0, s, S, M, k, rows, idx);
-        else if (M <= 4096)
-            hipLaunchKernelGGL(topk_wave_kernel<64>, wgrid, dim3(256), 0, s, S, M, k, rows, idx);
         else
-            hipLaunchKernelGGL(topk_wave_kernel<128>, wgrid, dim3(256), 0, s, S, M, k, rows, idx);
+            hipLaunchKernelGGL(topk_wave_stream_kernel, wgrid, dim3(256), 0, s, S, M, k, rows, idx);
         return DVM_OK;
     }
     int ept = (M + 255) / 256;

@@ -61,7 +61,8 @@ def test_knn_neg(ops, golden, name):
 
 def test_knn_neg_shapes(ops):
     g = torch.Generator().manual_seed(11)
-    for (B, N, M, C, k) in [(2, 70, 300, 36, 17), (1, 129, 65, 64, 64), (1, 10, 600, 128, 500), (1, 300, 3000, 64, 40)]:
+    for (B, N, M, C, k) in [(2, 70, 300, 36, 17), (1, 129, 65, 64, 64), (1, 10, 600, 128, 500), (1, 300, 3000, 64, 40),
+                            (1, 200, 4995, 128, 40), (2, 64, 8192, 64, 64), (1, 70, 2049, 128, 40)]:
         a, b = torch.randn(B, N, C, generator=g), torch.randn(B, M, C, generator=g)
         b[:, 5] = b[:, 3]  # an exact tie
         idx = host(ops.knn_neg(a.cuda(), b.cuda(), k))
@@ -348,10 +349,11 @@ def test_knn_neg_heavy_ties(ops):
     """Small-integer features make most scores collide: the wave top-k's tie paths (more than 128 keys at the
     threshold -> exact k-th key search, ties taken in column order) against the oracle, k <= 64 and k > 64."""
     g = torch.Generator().manual_seed(12)
-    for (N, M, C, k) in [(40, 700, 64, 40), (33, 2048, 128, 64), (20, 2500, 64, 17), (16, 300, 64, 100)]:
+    for (N, M, C, k) in [(40, 700, 64, 40), (33, 2048, 128, 64), (20, 2500, 64, 17), (16, 300, 64, 100), (12, 4995, 128, 40),
+                         (8, 8000, 64, 64)]:
         a = torch.randint(-1, 2, (1, N, C), generator=g).float()
         b = torch.randint(-1, 2, (1, M, C), generator=g).float()
-        b[0, M // 2:] = b[0, : M - M // 2]   # every key twice
+        b[0, M // 2:] = b[0, : M - M // 2].clone()   # every key twice
         idx = host(ops.knn_neg(a.cuda(), b.cuda(), k))[0]
         assert np.array_equal(idx, O.knn_neg(a[0].numpy(), b[0].numpy(), k)), (N, M, C, k)
 
