@@ -479,7 +479,10 @@ constexpr int SA_P = 16, SA_C = 64, SA_LDP = 20;
 // (512 at B = 8, N = 2048) keep all 256 CUs busy where 128-row workgroups left half of them idle.
 constexpr int SA_KB = 128;  // keys staged per iteration
 
-__global__ __launch_bounds__(256) void sa_rowstats_kernel(const float *__restrict__ p, int N, float *__restrict__ stats) {
+// grid.z = key chunks of `kchunk` keys (multiple of SA_KB).  With one chunk the kernels write the final results; with
+// more (small B * N: B = 1, N = 4995 has only 157 column groups) they write per-chunk partials that two tiny merge
+// kernels combine.
+__global__ __launch_bounds__(256) void sa_rowstats_kernel(const float *__restrict__ p, int N, int kchunk, float *__restrict__ stats) {
     __shared__ __attribute__((aligned(16))) float pt[SA_KB * SA_LDP];
     __shared__ float red[4][32][2];
     const int b = blockIdx.y;
@@ -495,6 +498,8 @@ __global__ __launch_bounds__(256) void sa_rowstats_kernel(const float *__restric
         pi[2 * c + 1] = h ? v.w : v.z;
     }
     float m = -INFINITY, l = 0.f;
+    const int zbeg = blockIdx.z * kchunk, zend = zbeg + kchunk < N ? zbeg + kchunk : N;
+    const bool partial = gridDim.z > 1;
     // the next 128-key block travels in registers while the current one is consumed
     f32x4 pre[2];
     auto fetch = [&](int j0) {
@@ -506,8 +511,8 @@ __global__ __launch_bounds__(256) void sa_rowstats_kernel(const float *__restric
             pre[q] = v;
         }
     };
-    fetch(0);
-    for (int j0 = 0; j0 < N; j0 += SA_KB) {
+    fetch(zbeg);
+    for (int j0 = zbeg; j0 < zend; j0 += SA_KB) {
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -517,7 +522,7 @@ __global__ __launch_bounds__(256) void sa_rowstats_kernel(const float *__restric
             *(float2 *)(pt + r * SA_LDP + 8 + 2 * c) = od;
         }
         __syncthreads();
-        if (j0 + SA_KB < N) fetch(j0 + SA_KB);
+        if (j0 + SA_KB < zend) fetch(j0 + SA_KB);
         const int jt = j0 + wave * 32;
         if (jt >= N) continue;
         const float *jr = pt + (wave * 32 + r32) * SA_LDP + h * 8;
@@ -565,14 +570,46 @@ __global__ __launch_bounds__(256) void sa_rowstats_kernel(const float *__restric
             float wm = red[w][tid][0];
             if (wm != -INFINITY) gl += red[w][tid][1] * __expf(wm - gm);
         }
-        stats[((size_t)b * N + irow) * 2] = gm;
-        stats[((size_t)b * N + irow) * 2 + 1] = 1.0f / gl;
+        const size_t o = (((size_t)blockIdx.z * gridDim.y + b) * N + irow) * 2;  // chunk-major partials
+        stats[o] = gm;
+        stats[o + 1] = partial ? gl : 1.0f / gl;
     }
 }
 
+// (m, l) of S key chunks -> (m, 1 / l)
+__global__ void sa_stats_merge_kernel(const float *__restrict__ part, long rows, int S, float *__restrict__ stats) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    float gm = -INFINITY;
+    for (int z = 0; z < S; ++z) gm = fmaxf(gm, part[((size_t)z * rows + r) * 2]);
+    float gl = 0.f;
+    for (int z = 0; z < S; ++z) {
+        const float wm = part[((size_t)z * rows + r) * 2];
+        if (wm != -INFINITY) gl += part[((size_t)z * rows + r) * 2 + 1] * __expf(wm - gm);
+    }
+    stats[r * 2] = gm;
+    stats[r * 2 + 1] = 1.0f / gl;
+}
+
+// sum of S partial (unnormalised x_r, column sum) -> x_r, 1 / (1e-9 + column sum)
+__global__ void sa_apply_merge_kernel(const float *__restrict__ po, const float *__restrict__ pc, long rows, int S,
+                                      float *__restrict__ xr, float *__restrict__ cinv_out) {
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= rows * SA_C) return;
+    const long r = g / SA_C;
+    float cs = 0.f, acc = 0.f;
+    for (int z = 0; z < S; ++z) {
+        cs += pc[(size_t)z * rows + r];
+        acc += po[(size_t)z * rows * SA_C + g];
+    }
+    const float inv = 1.0f / (1e-9f + cs);
+    xr[g] = acc * inv;
+    if (cinv_out && (g % SA_C) == 0) cinv_out[r] = inv;
+}
+
 __global__ __launch_bounds__(256) void sa_apply_kernel(const float *__restrict__ p, const float *__restrict__ v,
-                                                       const float *__restrict__ stats, int N, float *__restrict__ xr,
-                                                       float *__restrict__ cinv_out) {
+                                                       const float *__restrict__ stats, int N, int kchunk, float *__restrict__ xr,
+                                                       float *__restrict__ cinv_out /* partial mode: column sums */) {
     __shared__ __attribute__((aligned(16))) float pt[SA_KB * SA_LDP];
     __shared__ __attribute__((aligned(16))) float vt[SA_KB * SA_C];  // reused as the [wave][reg][lane] merge buffer
     __shared__ float st[SA_KB * 2];
@@ -592,6 +629,8 @@ __global__ __launch_bounds__(256) void sa_apply_kernel(const float *__restrict__
     }
     f32x16 o0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, o1 = o0;
     float colsum = 0.f;
+    const int zbeg = blockIdx.z * kchunk, zend = zbeg + kchunk < N ? zbeg + kchunk : N;
+    const bool partial = gridDim.z > 1;
     // the next 128-key block (p, v, stats) travels in registers while the current one is consumed
     f32x4 prep[2], prev[8];
     float pres;
@@ -612,8 +651,8 @@ __global__ __launch_bounds__(256) void sa_apply_kernel(const float *__restrict__
         }
         pres = (i0 + (tid >> 1) < N) ? stats[((size_t)b * N + i0 + (tid >> 1)) * 2 + (tid & 1)] : 0.f;  // invl = 0 kills padding
     };
-    fetch(0);
-    for (int i0 = 0; i0 < N; i0 += SA_KB) {
+    fetch(zbeg);
+    for (int i0 = zbeg; i0 < zend; i0 += SA_KB) {
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -629,7 +668,7 @@ __global__ __launch_bounds__(256) void sa_apply_kernel(const float *__restrict__
         }
         st[tid] = pres;
         __syncthreads();
-        if (i0 + SA_KB < N) fetch(i0 + SA_KB);
+        if (i0 + SA_KB < zend) fetch(i0 + SA_KB);
         if (i0 + wave * 32 >= N) continue;
         // E tile: rows = this wave's 32 keys i (A operand from LDS), cols = this lane's column j
         const float *ir = pt + (wave * 32 + r32) * SA_LDP + h * 8;
@@ -666,10 +705,12 @@ __global__ __launch_bounds__(256) void sa_apply_kernel(const float *__restrict__
         red[(16 + r) * 64 + lane] = o1[r];
     }
     __syncthreads();
-    const float inv = 1.0f / (1e-9f + ((csum[0][r32] + csum[1][r32]) + (csum[2][r32] + csum[3][r32])));
-    if (cinv_out && wave == 0 && h == 0 && jcol < N) cinv_out[(size_t)b * N + jcol] = inv;
+    const float cs = (csum[0][r32] + csum[1][r32]) + (csum[2][r32] + csum[3][r32]);
+    const float inv = partial ? 1.0f : 1.0f / (1e-9f + cs);
+    const size_t orow = ((size_t)blockIdx.z * gridDim.y + b) * N + jcol;  // chunk-major partials (chunk 0 = the output itself)
+    if (cinv_out && wave == 0 && h == 0 && jcol < N) cinv_out[orow] = partial ? cs : inv;
     if (jcol < N) {
-        float *o = xr + ((size_t)b * N + jcol) * SA_C;
+        float *o = xr + orow * SA_C;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int r = wave * 8 + q;  // merged register index: 0..15 -> o0, 16..31 -> o1
@@ -944,32 +985,68 @@ DVM_EXPORT int dvm_pos_encoding_minmax_f32(const float *x, const float *minmax, 
     return DVM_OK;
 }
 
-DVM_EXPORT size_t dvm_sa_attention_workspace_bytes(int B, int N) { return align_up((size_t)B * N * 2 * sizeof(float)); }
+namespace dvm {
+// key chunks per column group: enough workgroups to fill the chip (B * N/32 alone: 157 at B = 1, N = 4995)
+static int sa_splits(int B, int N) {
+    const int groups = B * ((N + 31) / 32);
+    if (groups >= 400) return 1;  // measured: at 512 groups (B = 8, N = 2048) the merge passes cost more than the split gains
+    int S = 1;
+    while (groups * S < 1024 && S < 8 && (N + 2 * S - 1) / (2 * S) >= 4 * SA_KB) S *= 2;
+    return S;
+}
+static size_t sa_partial_floats(int B, int N) {
+    const int S = sa_splits(B, N);
+    return S > 1 ? (size_t)S * B * N * (2 + SA_C + 1) : 0;
+}
+// stats [B][N][2] and xr [B][N][64] (and cinv [B][N] when given) from p, v; `part` holds sa_partial_floats(B, N) floats
+static void launch_sa_forward(const float *p, const float *v, int B, int N, float *xr, float *stats, float *cinv, float *part,
+                              hipStream_t s) {
+    const int S = sa_splits(B, N);
+    const int kchunk = ((N + S - 1) / S + SA_KB - 1) / SA_KB * SA_KB;
+    const int Z = (N + kchunk - 1) / kchunk;
+    dim3 grid((N + 31) / 32, B, Z);
+    if (Z == 1) {
+        hipLaunchKernelGGL(sa_rowstats_kernel, grid, dim3(256), 0, s, p, N, kchunk, stats);
+        hipLaunchKernelGGL(sa_apply_kernel, grid, dim3(256), 0, s, p, v, stats, N, kchunk, xr, cinv);
+        return;
+    }
+    const long rows = (long)B * N;
+    float *pstats = part, *po = pstats + (size_t)Z * rows * 2, *pc = po + (size_t)Z * rows * SA_C;
+    hipLaunchKernelGGL(sa_rowstats_kernel, grid, dim3(256), 0, s, p, N, kchunk, pstats);
+    hipLaunchKernelGGL(sa_stats_merge_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, pstats, rows, Z, stats);
+    hipLaunchKernelGGL(sa_apply_kernel, grid, dim3(256), 0, s, p, v, stats, N, kchunk, po, pc);
+    hipLaunchKernelGGL(sa_apply_merge_kernel, dim3((unsigned)((rows * SA_C + 255) / 256)), dim3(256), 0, s, po, pc, rows, Z, xr, cinv);
+}
+}  // namespace dvm
+
+DVM_EXPORT size_t dvm_sa_attention_workspace_bytes(int B, int N) {
+    return align_up((size_t)B * N * 2 * sizeof(float)) + align_up(sa_partial_floats(B, N) * sizeof(float));
+}
 
 DVM_EXPORT int dvm_sa_attention_fwd_f32(const float *p, const float *v, int B, int N, float *xr, void *ws, size_t ws_bytes,
                                         void *stream) {
     DVM_REQUIRE(p && v && xr && B >= 1 && N >= 1, "dvm_sa_attention_fwd_f32: bad arguments");
     Arena ar(ws, ws_bytes);
     float *stats = ar.take<float>((size_t)B * N * 2);
+    float *part = ar.take<float>(sa_partial_floats(B, N));
     if (!ar.ok()) {
-        set_error("dvm_sa_attention_fwd_f32: workspace too small");
+        set_error("dvm_sa_attention_fwd_f32: workspace too small (%zu < %zu)", ws_bytes, ar.off);
         return DVM_ENOSPACE;
     }
-    hipStream_t s = (hipStream_t)stream;
-    dim3 grid((N + 31) / 32, B);
-    hipLaunchKernelGGL(sa_rowstats_kernel, grid, dim3(256), 0, s, p, N, stats);
-    hipLaunchKernelGGL(sa_apply_kernel, grid, dim3(256), 0, s, p, v, stats, N, xr, (float *)nullptr);
+    launch_sa_forward(p, v, B, N, xr, stats, nullptr, part, (hipStream_t)stream);
     DVM_CHECK_LAUNCH("sa_attention");
     return DVM_OK;
 }
 
+DVM_EXPORT size_t dvm_sa_attention_train_fwd_workspace_bytes(int B, int N) { return align_up(sa_partial_floats(B, N) * sizeof(float)); }
+
 DVM_EXPORT int dvm_sa_attention_train_fwd_f32(const float *p, const float *v, int B, int N, float *xr, float *stats, float *cinv,
-                                              void *stream) {
+                                              void *ws, size_t ws_bytes, void *stream) {
     DVM_REQUIRE(p && v && xr && stats && cinv && B >= 1 && N >= 1, "dvm_sa_attention_train_fwd_f32: bad arguments");
-    hipStream_t s = (hipStream_t)stream;
-    dim3 grid((N + 31) / 32, B);
-    hipLaunchKernelGGL(sa_rowstats_kernel, grid, dim3(256), 0, s, p, N, stats);
-    hipLaunchKernelGGL(sa_apply_kernel, grid, dim3(256), 0, s, p, v, stats, N, xr, cinv);
+    const size_t need = sa_partial_floats(B, N) * sizeof(float);
+    DVM_REQUIRE(need == 0 || (ws != nullptr && ws_bytes >= need), "dvm_sa_attention_train_fwd_f32: workspace too small (%zu < %zu)",
+                ws_bytes, need);
+    launch_sa_forward(p, v, B, N, xr, stats, cinv, (float *)ws, (hipStream_t)stream);
     DVM_CHECK_LAUNCH("sa_attention_train_fwd");
     return DVM_OK;
 }

@@ -40,7 +40,8 @@ SIGNATURES = {
     "dvm_rot6d_bwd_f32": (c_int, [_P, _P, c_int, _P, _P]),
     "dvm_dg_warp_arap_bwd_f32": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dvm_chamfer_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
-    "dvm_sa_attention_train_fwd_f32": (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P]),
+    "dvm_sa_attention_train_fwd_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "dvm_sa_attention_train_fwd_f32": (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),
     "dvm_sa_attention_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
     "dvm_sa_attention_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, c_size_t, _P]),
     "dvm_pair_set_overlap": (c_int, [c_int]),

@@ -524,7 +524,10 @@ def sa_attention_train_fwd(p, v):
     xr = torch.empty(B, N, 64, dtype=torch.float32, device=p.device)
     stats = torch.empty(B, N, 2, dtype=torch.float32, device=p.device)
     cinv = torch.empty(B, N, dtype=torch.float32, device=p.device)
-    check(_lib.load().dvm_sa_attention_train_fwd_f32(_p(p), _p(v), B, N, _p(xr), _p(stats), _p(cinv), _stream()),
+    lib = _lib.load()
+    nb = lib.dvm_sa_attention_train_fwd_workspace_bytes(B, N)
+    ws = workspace(nb, p.device, "sa_train") if nb else None
+    check(lib.dvm_sa_attention_train_fwd_f32(_p(p), _p(v), B, N, _p(xr), _p(stats), _p(cinv), _p(ws) if nb else None, nb, _stream()),
           "dvm_sa_attention_train_fwd_f32")
     return xr, stats, cinv
 
