@@ -316,10 +316,26 @@ DVM_EXPORT int dvm_pair_fwd_f32(const float *feat1, const float *feat2, const fl
                         w.nnd[0], w.gvcat, w.gncat, true, s);
         launch_grid_knn_self(w.gvcat, 2 * B, 10, w.idxk[0], s);
     } else {
+        // N != M (or sizes that do not tile the arena): one chain per cloud set.  FPS is a one-workgroup-per-cloud
+        // sequential kernel, so the two chains go on two helper streams and overlap each other as well.
+        static hipStream_t side2 = nullptr;
+        static hipEvent_t ev_join2 = nullptr;
+        if (overlap && !side2 &&
+            (hipStreamCreateWithFlags(&side2, hipStreamNonBlocking) != hipSuccess ||
+             hipEventCreateWithFlags(&ev_join2, hipEventDisableTiming) != hipSuccess)) {
+            set_error("dvm_pair_fwd_f32: cannot create the helper stream");
+            return DVM_ELAUNCH;
+        }
+        if (overlap) (void)hipStreamWaitEvent(side2, ev_fork, 0);
         for (int sd = 0; sd < 2; ++sd) {
+            const hipStream_t cs = (overlap && sd == 1) ? side2 : s;
             launch_dg_build(verts[sd], B, P[sd], start[sd], w.nodes[sd], w.ring[sd], w.infl[sd], w.dists[sd], w.weights[sd],
-                            nullptr, w.nnd[sd], w.gv[sd], w.gn[sd], true, s);
-            launch_grid_knn_self(w.gv[sd], B, 10, w.idxk[sd], s);
+                            nullptr, w.nnd[sd], w.gv[sd], w.gn[sd], true, cs);
+            launch_grid_knn_self(w.gv[sd], B, 10, w.idxk[sd], cs);
+        }
+        if (overlap) {
+            (void)hipEventRecord(ev_join2, side2);
+            (void)hipStreamWaitEvent(side, ev_join2, 0);  // ev_join (below) then covers both chains
         }
     }
     if (overlap) {
