@@ -304,18 +304,9 @@ __global__ void rev_fill_kernel(const int32_t *__restrict__ idx, long E, int M, 
     edges[(size_t)b * E + pos] = (int32_t)e;  // e = row * topk + slot
 }
 
-__global__ __launch_bounds__(256) void apply_bwd_gather_kernel(const float *__restrict__ pi_val, const float *__restrict__ gout,
-                                                               const int32_t *__restrict__ offs, const int32_t *__restrict__ edges,
-                                                               int N, int M, int topk, int C, float *__restrict__ dV) {
-    const int lane = threadIdx.x & 63;
-    const long j = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (j >= M) return;
-    const int b = blockIdx.y;
-    const long E = (long)N * topk;
-    const int beg = offs[(size_t)b * (M + 1) + j], end = offs[(size_t)b * (M + 1) + j + 1];
-    const int32_t *ed = edges + (size_t)b * E;
-    const float *vb = pi_val + (size_t)b * E, *gb = gout + (size_t)b * N * C;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};  // C <= 256: channels lane, lane+64, lane+128, lane+192
+// sum of val[e] * gout[row(e)] over the in-edges ed[beg..end) of one target, lanes over channels
+__device__ __forceinline__ void gather_edges(const int32_t *__restrict__ ed, int beg, int end, const float *__restrict__ vb,
+                                             const float *__restrict__ gb, int topk, int C, int lane, float (&acc)[4]) {
     int e = beg;
     for (; e + 1 < end; e += 2) {  // two in-edges in flight
         const int e0 = ed[e], e1 = ed[e + 1];
@@ -341,11 +332,49 @@ __global__ __launch_bounds__(256) void apply_bwd_gather_kernel(const float *__re
             if (c < C) acc[q] = fmaf(w0, g0[c], acc[q]);
         }
     }
-    float *o = dV + ((size_t)b * M + j) * C;
+}
+
+// One wave per target row; a target with more than AG_HEAVY in-edges (the hubs of a soft correspondence collect
+// thousands) is shared by the four waves of its workgroup instead, each taking a quarter of the list.
+constexpr int AG_HEAVY = 96;
+
+__global__ __launch_bounds__(256) void apply_bwd_gather_kernel(const float *__restrict__ pi_val, const float *__restrict__ gout,
+                                                               const int32_t *__restrict__ offs, const int32_t *__restrict__ edges,
+                                                               int N, int M, int topk, int C, float *__restrict__ dV) {
+    __shared__ float red[4][256];
+    __shared__ int sbeg[4], send[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long j = (long)blockIdx.x * 4 + wave;
+    const int b = blockIdx.y;
+    const long E = (long)N * topk;
+    const int32_t *ed = edges + (size_t)b * E;
+    const float *vb = pi_val + (size_t)b * E, *gb = gout + (size_t)b * N * C;
+    int beg = 0, end = 0;
+    if (j < M) beg = offs[(size_t)b * (M + 1) + j], end = offs[(size_t)b * (M + 1) + j + 1];
+    if (lane == 0) sbeg[wave] = beg, send[wave] = end;
+    const bool heavy = end - beg > AG_HEAVY;
+    if (j < M && !heavy) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};  // C <= 256: channels lane, lane+64, lane+128, lane+192
+        gather_edges(ed, beg, end, vb, gb, topk, C, lane, acc);
+        float *o = dV + ((size_t)b * M + j) * C;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int c = lane + 64 * q;
-        if (c < C) o[c] = acc[q];
+        for (int q = 0; q < 4; ++q)
+            if (lane + 64 * q < C) o[lane + 64 * q] = acc[q];
+    }
+    __syncthreads();
+    for (int t = 0; t < 4; ++t) {  // workgroup-uniform: the heavy targets of this workgroup, one after the other
+        const int tb = sbeg[t], te = send[t];
+        if (te - tb <= AG_HEAVY) continue;
+        const int part = (te - tb + 3) / 4;
+        const int pb = tb + wave * part, pe = pb + part < te ? pb + part : te;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (pb < pe) gather_edges(ed, pb, pe, vb, gb, topk, C, lane, acc);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[wave][lane + 64 * q] = acc[q];
+        __syncthreads();
+        const int c = threadIdx.x;
+        if (c < C) dV[((size_t)b * M + (long)blockIdx.x * 4 + t) * C + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
     }
 }
 

@@ -100,7 +100,7 @@ def test_sparse_apply_bwd_vs_fp64_autograd(ops, C, atomics):
     val = torch.rand(B, N, k, generator=g)
     idx = torch.randint(0, M, (B, N, k), generator=g, dtype=torch.int32)
     idx[:, :, -1] = torch.where(idx[:, :, -1] > M // 2, idx[:, :, -1] - M // 2, idx[:, :, -1])   # skewed: rows 0..M/2 are hot
-    idx[1, :7] = 5                                                                            # one target with many in-edges
+    idx[1, :40] = 5                                                                           # a hub: 400 in-edges, shared by the four waves of its workgroup
     V = torch.randn(B, M, C, generator=g)
     gout = torch.randn(B, N, C, generator=g)
     dval, dV = ops.apply_bwd(val.cuda(), idx.cuda(), V.cuda(), gout.cuda(), atomics=atomics)
