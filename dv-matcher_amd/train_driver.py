@@ -66,9 +66,8 @@ def main():
         cfg = yaml.safe_load(open(args.config))
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     assert torch.cuda.is_available(), "the training path needs a HIP device"
+    local = local % torch.cuda.device_count()   # more ranks than devices (gloo tests on one GPU): share them round-robin
     torch.cuda.set_device(local)
-    if os.environ.get("DVM_NATIVE_BN", "0") == "1":
-        torch.backends.cudnn.enabled = False
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

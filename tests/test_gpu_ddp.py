@@ -78,3 +78,20 @@ def test_sharded_step_equals_single_process(sync):
     print("relative gradient error %.2e" % rel)
     assert rel < 5e-2, rel
     torch.testing.assert_close(ret[0][2], net.bn0.running_mean.cpu(), rtol=1e-4, atol=1e-5)
+
+
+def test_training_driver_two_ranks_on_one_gpu():
+    """train_driver.py under torch.distributed.run with two ranks (gloo, both on cuda:0): shards the pair batch, keeps
+    batch-global statistics (--sync-stats), averages the gradients through the flat bucket and reports one line."""
+    import json
+    import subprocess
+    port = 29900 + os.getpid() % 1000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "dv-matcher_amd", "train_driver.py"), "--steps", "2", "--warmup", "0",
+           "--batch", "4", "--points", "256", "--backend", "gloo", "--sync-stats"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["global_batch"] == 4 and res["grad_bucket_floats"] == 2122644
+    assert all(map(lambda v: v == v and abs(v) < 1e9, res["first_losses"] + res["last_losses"]))
