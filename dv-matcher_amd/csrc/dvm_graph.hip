@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void dg_warp_kernel(const float *__restrict__ 
 __global__ __launch_bounds__(256) void dg_arap_kernel(const float *__restrict__ xyz, int N, int Nn,
                                                       const int32_t *__restrict__ nodes_idx, const int32_t *__restrict__ ring,
                                                       const float *__restrict__ R, const float *__restrict__ T,
-                                                      float *__restrict__ arap, int arap_stride, float *__restrict__ sr) {
+                                                      float *__restrict__ arap, int arap_stride, float *__restrict__ sr, int K) {
     __shared__ double red[2][256];
     const int b = blockIdx.x;
     const float *p = xyz + (size_t)b * N * 3;
@@ -307,8 +307,8 @@ __global__ __launch_bounds__(256) void dg_arap_kernel(const float *__restrict__ 
         const float *ra = R + na * 9, *ta = T + na * 3;
         float gax = p[3 * va], gay = p[3 * va + 1], gaz = p[3 * va + 2];
         float ga[3] = {gax, gay, gaz};
-        for (int q = 0; q < 9; ++q) {
-            int nb = ring[na * 9 + q];
+        for (int q = 0; q < K; ++q) {  // ring width: 9 (point-cloud graph) or 18 (mesh graph, padded with the node itself)
+            int nb = ring[na * K + q];
             size_t nbg = (size_t)b * Nn + nb;
             int vb = nodes_idx[nbg];
             const float *rb = R + nbg * 9, *tb = T + nbg * 3;
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void dg_arap_kernel(const float *__restrict__ 
     }
     if (threadIdx.x == 0) {
         arap[(size_t)b * arap_stride] = (float)(red[0][0] / (double)Nn);
-        if (sr) sr[b] = (float)(red[1][0] / ((double)Nn * 81.0));
+        if (sr) sr[b] = (float)(red[1][0] / ((double)Nn * K * 9.0));
     }
 }
 
@@ -400,7 +400,7 @@ int launch_dg_warp_rt(const float *xyz, int B, int N, const int32_t *nodes_idx, 
     const int Nn = N / 2;
     hipLaunchKernelGGL(dg_warp_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, xyz, N, Nn, nodes_idx, infl_idx, weights, R, T,
                        warped);
-    hipLaunchKernelGGL(dg_arap_kernel, dim3(B), dim3(256), 0, s, xyz, N, Nn, nodes_idx, ring, R, T, arap, arap_stride, sr);
+    hipLaunchKernelGGL(dg_arap_kernel, dim3(B), dim3(256), 0, s, xyz, N, Nn, nodes_idx, ring, R, T, arap, arap_stride, sr, 9);
     return DVM_OK;
 }
 
@@ -411,7 +411,7 @@ int launch_dg_warp(const float *xyz, int B, int N, const int32_t *nodes_idx, con
     hipLaunchKernelGGL(rot6d_kernel, dim3((B * Nn + 255) / 256), dim3(256), 0, s, def9, B * Nn, R, T);
     hipLaunchKernelGGL(dg_warp_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, xyz, N, Nn, nodes_idx, infl_idx, weights, R, T,
                        warped);
-    hipLaunchKernelGGL(dg_arap_kernel, dim3(B), dim3(256), 0, s, xyz, N, Nn, nodes_idx, ring, R, T, arap, arap_stride, sr);
+    hipLaunchKernelGGL(dg_arap_kernel, dim3(B), dim3(256), 0, s, xyz, N, Nn, nodes_idx, ring, R, T, arap, arap_stride, sr, 9);
     return DVM_OK;
 }
 
@@ -467,5 +467,20 @@ DVM_EXPORT int dvm_dg_warp_arap_fwd_f32(const float *xyz, int B, int N, const in
     DVM_REQUIRE(B >= 1 && N >= 2, "dvm_dg_warp_arap_fwd_f32: bad sizes (B=%d N=%d)", B, N);
     launch_dg_warp_rt(xyz, B, N, nodes_idx, ring, infl_idx, weights, R, T, warped, arap, 1, sr, (hipStream_t)stream);
     DVM_CHECK_LAUNCH("dg_warp_arap");
+    return DVM_OK;
+}
+
+DVM_EXPORT int dvm_dg_warp_arap_graph_f32(const float *xyz, int B, int N, int Nn, int ring_width, const int32_t *nodes_idx,
+                                          const int32_t *ring, const int32_t *infl_idx, const float *weights, const float *R,
+                                          const float *T, float *warped, float *arap, float *sr, void *stream) {
+    DVM_REQUIRE(xyz && nodes_idx && ring && infl_idx && weights && R && T && warped && arap,
+                "dvm_dg_warp_arap_graph_f32: null pointer");
+    DVM_REQUIRE(B >= 1 && N >= 1 && Nn >= 1 && Nn <= N && ring_width >= 1 && ring_width <= 64,
+                "dvm_dg_warp_arap_graph_f32: bad sizes (B=%d N=%d Nn=%d ring=%d)", B, N, Nn, ring_width);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(dg_warp_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, xyz, N, Nn, nodes_idx, infl_idx, weights, R, T,
+                       warped);
+    hipLaunchKernelGGL(dg_arap_kernel, dim3(B), dim3(256), 0, s, xyz, N, Nn, nodes_idx, ring, R, T, arap, 1, sr, ring_width);
+    DVM_CHECK_LAUNCH("dg_warp_arap_graph");
     return DVM_OK;
 }

@@ -77,6 +77,7 @@ SIGNATURES = {
     "dvm_dg_build_f32": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "dvm_rot6d_f32": (c_int, [_P, c_int, _P, _P]),
     "dvm_dg_warp_arap_fwd_f32": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dvm_dg_warp_arap_graph_f32": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dvm_chamfer_workspace_bytes": (c_size_t, [c_int] * 3),
     "dvm_chamfer_fwd_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
     "dvm_deformer_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),

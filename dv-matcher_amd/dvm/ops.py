@@ -286,6 +286,24 @@ def dg_warp_arap(xyz, g, R, T):
     return warped, arap, sr
 
 
+def dg_warp_arap_graph(xyz, g, R, T):
+    """As dg_warp_arap for a graph whose node count and ring width are whatever g holds (the mesh-mode graph:
+    nodes_idx (B,Nn), one_ring (B,Nn,K), infl_idx / weights (B,N,3))."""
+    _need_gpu(xyz, R, T)
+    xyz, R, T = _f(xyz), _f(R), _f(T)
+    B, N, _ = xyz.shape
+    nodes, ring = _i(g["nodes_idx"]), _i(g["one_ring"])
+    Nn, K = nodes.shape[1], ring.shape[2]
+    dev = xyz.device
+    warped = torch.empty(B, N, 3, dtype=torch.float32, device=dev)
+    arap = torch.empty(B, dtype=torch.float32, device=dev)
+    sr = torch.empty(B, dtype=torch.float32, device=dev)
+    check(_lib.load().dvm_dg_warp_arap_graph_f32(_p(xyz), B, N, Nn, K, _p(nodes), _p(ring), _p(_i(g["infl_idx"])),
+                                                 _p(_f(g["weights"])), _p(R), _p(T), _p(warped), _p(arap), _p(sr), _stream()),
+          "dvm_dg_warp_arap_graph_f32")
+    return warped, arap, sr
+
+
 def chamfer(a, b, want_idx=True):
     _need_gpu(a, b)
     a, b = _f(a), _f(b)

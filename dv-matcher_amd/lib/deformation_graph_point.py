@@ -22,6 +22,13 @@ def farthest_point_sample(xyz, npoint, start=None):
     return ops.fps(xyz, npoint, start).long()
 
 
+def compute_edge_lengths(vertices, faces):
+    """(F,3) lengths of the edges leaving each face corner (reference lib/deformation_graph_point.py:325-341)."""
+    face_vertices = vertices[faces]
+    edge_vectors = torch.roll(face_vertices, -1, dims=1) - face_vertices
+    return torch.norm(edge_vectors, dim=2)
+
+
 class DeformationGraph_geod(nn.Module):
     """Same public surface as the reference class; the graph tensors live on the device.
 
@@ -80,11 +87,51 @@ class DeformationGraph_geod(nn.Module):
         self._publish(v)
 
     def construct_graph(self, vertices=None, faces=None, geod=None, device=None):
-        raise NotImplementedError("mesh-mode graph (QSlim decimation) is outside this path (SURVEY §8f-4)")
+        """Mesh-mode graph (reference lib/deformation_graph_point.py:203-231, used by deform.py:167-216): the nodes are
+        the vertices that survive a QSlim decimation to half the vertex count, a node's ring is its neighbours in the
+        decimated mesh (padded to max_neigh_num = 18 with the node itself), every vertex is skinned to its 3 geodesically
+        nearest nodes (`geod`: the (V,V) geodesic matrix the caller supplies) with Gaussian weights of width
+        20 x the decimated mesh's mean edge length.  The build is host code, as in the reference (lib/mesh_sampling.py);
+        the graph then lives on the device and forward() runs on the HIP kernels."""
+        if self.sampling_strategy != 'qslim':
+            raise NotImplementedError("only the 'qslim' sampling of the reference is implemented")
+        from lib.mesh_sampling import Mesh, generate_transform_matrices
+        v_host = torch.as_tensor(vertices).detach().cpu().double().numpy()
+        faces = np.asarray(faces, dtype=np.int64)
+        self.faces = faces
+        self.max_neigh_num = 18
+        M, A, D = generate_transform_matrices(Mesh(v=v_host, f=faces), [2])
+        self.graph = M[1]
+        self.nodes_idx = D[0].nonzero()[1]
+        adj = A[1].toarray()
+        ring = []
+        for i in range(adj.shape[0]):
+            nb = adj[i].nonzero()[0].tolist()
+            if len(nb) > self.max_neigh_num:
+                raise ValueError("node %d has %d neighbours (max_neigh_num = %d)" % (i, len(nb), self.max_neigh_num))
+            ring.append(nb + [i] * (self.max_neigh_num - len(nb)))
+        self.one_ring_neigh = torch.tensor(ring)
+        geod_mat = torch.from_numpy(-np.asarray(geod)[self.nodes_idx]).transpose(1, 0)
+        dists, infl = geod_mat.topk(self.k, dim=-1)
+        self.dists = -dists
+        self.pre_idx = geod_mat.topk(1, dim=-1)[1]
+        gv, gf = torch.tensor(self.graph.v), torch.tensor(self.graph.f.astype(np.int64))
+        self.sigma = 20 * torch.mean(compute_edge_lengths(gv, gf))
+        w = torch.exp(-(self.dists ** 2) / (2 * self.sigma * self.sigma))
+        self.weights = (w / w.sum(1).reshape(-1, 1)).float()
+        dev = torch.device(device) if device is not None else (vertices.device if torch.is_tensor(vertices) and vertices.is_cuda
+                                                                 else torch.device("cuda"))
+        self.influence_nodes_idx = infl.to(dev)
+        self.weights = self.weights.to(dev)
+        self._g = dict(nodes_idx=torch.from_numpy(np.asarray(self.nodes_idx)).int().to(dev)[None],
+                       one_ring=self.one_ring_neigh.int().to(dev)[None], infl_idx=infl.int().to(dev)[None],
+                       weights=self.weights[None], dists=self.dists.float().to(dev)[None])
+        self._mesh_mode = True
 
     def forward(self, vertices, opt_d_rotations, opt_d_translations):
         """vertices (N,3), rotations (1,Nn,3,3), translations (1,Nn,3) -> (warped (1,N,3), arap, sr)."""
         if self._g is None:
             raise RuntimeError("construct_graph_euclidean() has not been called")
-        warped, arap, sr = ops.dg_warp_arap(vertices[None], self._g, opt_d_rotations, opt_d_translations)
+        fn = ops.dg_warp_arap_graph if getattr(self, "_mesh_mode", False) else ops.dg_warp_arap
+        warped, arap, sr = fn(vertices[None], self._g, opt_d_rotations, opt_d_translations)
         return warped, arap[0], sr[0]

@@ -153,6 +153,12 @@ int dvm_rot6d_bwd_f32(const float *d6, const float *g_R, int rows, float *g_d6, 
 int dvm_dg_warp_arap_fwd_f32(const float *xyz, int B, int N, const int32_t *nodes_idx, const int32_t *ring,
                              const int32_t *infl_idx, const float *weights, const float *R, const float *T,
                              float *warped, float *arap, float *sr, void *stream);
+/* The same forward for a graph with an explicit node count and ring width — the mesh-mode graph of
+ * DeformationGraph_geod.construct_graph (lib/deformation_graph_point.py:203-231): Nn decimated vertices, rings of
+ * max_neigh_num = 18 adjacent nodes padded with the node itself.  nodes_idx [B,Nn], ring [B,Nn,ring_width]. */
+int dvm_dg_warp_arap_graph_f32(const float *xyz, int B, int N, int Nn, int ring_width, const int32_t *nodes_idx,
+                               const int32_t *ring, const int32_t *infl_idx, const float *weights, const float *R,
+                               const float *T, float *warped, float *arap, float *sr, void *stream);
 /* Backward of dvm_dg_warp_arap_fwd_f32 w.r.t. the node transforms: g_warped [B,N,3], g_arap [B] ->
  * d_R [B,Nn,9], d_T [B,Nn,3] (overwritten; fp32 atomics).  The vertices carry no gradient (inputs). */
 int dvm_dg_warp_arap_bwd_f32(const float *xyz, int B, int N, const int32_t *nodes_idx, const int32_t *ring,
