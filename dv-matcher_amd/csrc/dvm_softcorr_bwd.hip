@@ -175,7 +175,9 @@ __global__ __launch_bounds__(BW_THREADS, 2) void softcorr_bwd_mfma_kernel(const 
                     const float D = sqrt_rn(v);
                     const float e = __builtin_amdgcn_exp2f(fmaf(D, a2, -(c2_o + cc[u])));
                     const float wv = (coef_o * cf[u]) * e * __builtin_amdgcn_rcpf(D);
-                    w[r] = v > 0.f ? wv : 0.f;
+                    // padding rows of the last tile carry coef 0 but zero features: their "distance" |f_o| can be far
+                    // below the row minimum, e overflows to +inf and 0 * inf would poison the whole output row
+                    w[r] = (v > 0.f && cf[u] != 0.f) ? wv : 0.f;
                     rl += w[r];
                 }
             }

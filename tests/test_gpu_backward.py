@@ -43,6 +43,23 @@ def test_softcorr_bwd_vs_fp64_autograd(ops, shape, alpha, variant):
     assert rel(df1, rf1) < tol and rel(df2, rf2) < tol, (rel(df1, rf1), rel(df2, rf2))
 
 
+@pytest.mark.parametrize("shape,alpha", [((2, 300, 250, 128), 50.0), ((1, 333, 130, 128), 100.0), ((2, 2048, 2200, 128), 50.0),
+                                         ((1, 4995, 2200, 128), 50.0)])
+def test_softcorr_bwd_padded_tiles_stay_finite(ops, shape, alpha):
+    """Unit-scale features and a large alpha: the zero-filled padding rows of the last key tile sit much closer than any
+    real column (|f| ~ 11 vs a minimum distance ~ 14), their softmax factor overflows, and it must not reach the
+    output (0 * inf).  The matrix-core kernel against the scalar one, both passes, sizes that do not tile."""
+    B, N, M, d = shape
+    g = torch.Generator().manual_seed(N + M)
+    f1, f2 = torch.randn(B, N, d, generator=g).cuda(), torch.randn(B, M, d, generator=g).cuda()
+    gval = torch.randn(B, N, 10, generator=g).cuda()
+    val, idx, smax, ssum = ops.softcorr(f1, f2, alpha)
+    a1, a2 = ops.softcorr_bwd(f1, f2, alpha, val, idx, smax, ssum, gval, variant=2)
+    s1, s2 = ops.softcorr_bwd(f1, f2, alpha, val, idx, smax, ssum, gval, variant=1)
+    assert torch.isfinite(a1).all() and torch.isfinite(a2).all()
+    assert rel(a1, s1) < 2e-3 and rel(a2, s2) < 2e-3, (rel(a1, s1), rel(a2, s2))
+
+
 def test_softcorr_bwd_other_dims_and_duplicates(ops):
     g = torch.Generator().manual_seed(5)
     f1 = torch.randn(1, 70, 36, generator=g)
