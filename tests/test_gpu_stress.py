@@ -1,0 +1,32 @@
+"""Inputs the fixture-based parity tests do not reach: degenerate point clouds for the grid searches, attention logits
+far from unit scale, sizes that do not tile.  Runs tools/stress_*.py (also usable by hand) and checks their verdicts."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(name):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", name)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return out.stdout
+
+
+def test_grid_searches_on_degenerate_clouds():
+    text = _run("stress_geometry.py")
+    assert "mismatches: 0" in text, text
+    assert len(re.findall(r"chamfer True  knn True  graph True", text)) == 8, text
+
+
+def test_attention_cores_far_from_unit_scale():
+    text = _run("stress_scales.py")
+    lines = [ln for ln in text.splitlines() if ln.startswith(("SA ", "N2P"))]
+    assert len(lines) == 7 and all("finite True" in ln for ln in lines), text
+    for ln in lines:
+        errs = [float(x) for x in re.findall(r"(\d\.\de-\d+)", ln)]
+        assert errs and max(errs) < 5e-5, ln
