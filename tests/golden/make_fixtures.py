@@ -177,14 +177,18 @@ def group_deformer(rl, rm):
              chamfer_loss=crit.chamfer_loss(v12, v2))
 
 
-def run_loss(rl, rm, crit_cls, kw, B, n, m, seed, alpha, with_grad=True, scape=False):
+def run_loss(rl, rm, crit_cls, kw, B, n, m, seed, alpha, with_grad=True, scape=False, unit=False):
     sd = deformer_weights()
     dfm = rm.Deformer(10)
     dfm.load_state_dict(sd)
     dfm.train()
     g = torch.Generator().manual_seed(500 + seed)
-    f1 = (0.3 * torch.relu(torch.randn(B, n, 128, generator=g))).requires_grad_(with_grad)
-    f2 = (0.3 * torch.relu(torch.randn(B, m, 128, generator=g))).requires_grad_(with_grad)
+    if unit:  # unit-scale features: |f| ~ 11 is BELOW the smallest pairwise distance (~14), sizes that do not tile
+        f1 = torch.randn(B, n, 128, generator=g).requires_grad_(with_grad)
+        f2 = torch.randn(B, m, 128, generator=g).requires_grad_(with_grad)
+    else:
+        f1 = (0.3 * torch.relu(torch.randn(B, n, 128, generator=g))).requires_grad_(with_grad)
+        f2 = (0.3 * torch.relu(torch.randn(B, m, 128, generator=g))).requires_grad_(with_grad)
     if scape:
         v1 = torch.from_numpy(np.stack([scape_verts(2 * b, n, seed + b) for b in range(B)]))
         v2 = torch.from_numpy(np.stack([scape_verts(2 * b + 1, m, seed + 10 + b) for b in range(B)]))
@@ -215,7 +219,7 @@ def run_loss(rl, rm, crit_cls, kw, B, n, m, seed, alpha, with_grad=True, scape=F
     return out
 
 
-def group_loss(rl, rm):
+def group_loss(rl, rm, only_unit=False):
     """rows 16,17,18 + everything composed: the criterion forward (+backward)."""
     kw = dict(k_deform=10, w_dist=0.02, w_map=0.005, k_dist=50, N_dist=100, partial=False, w_deform=0.5, w_img=0,
               w_rank=0, w_self_rec=0.5, w_cd=0.1, w_arap=0.01)
@@ -223,10 +227,13 @@ def group_loss(rl, rm):
     with tempfile.TemporaryDirectory() as td:
         os.chdir(td)
         try:
-            save("loss_full_256", **run_loss(rl, rm, rl.GraphDeformLoss_Neural, kw, 2, 256, 256, 0, 40.0))
-            save("loss_full_scape_384", **run_loss(rl, rm, rl.GraphDeformLoss_Neural, kw, 2, 384, 384, 1, 85.6, scape=True))
             kwp = dict(kw, w_deform=1000, w_self_rec=1000, k_dist=30, N_dist=60, partial=True)
-            save("loss_partial_256x120", **run_loss(rl, rm, rl.GraphDeformLoss_Neural_Partial, kwp, 2, 256, 120, 2, 25.0))
+            if not only_unit:
+                save("loss_full_256", **run_loss(rl, rm, rl.GraphDeformLoss_Neural, kw, 2, 256, 256, 0, 40.0))
+                save("loss_full_scape_384", **run_loss(rl, rm, rl.GraphDeformLoss_Neural, kw, 2, 384, 384, 1, 85.6, scape=True))
+                save("loss_partial_256x120", **run_loss(rl, rm, rl.GraphDeformLoss_Neural_Partial, kwp, 2, 256, 120, 2, 25.0))
+            save("loss_full_300_unit", **run_loss(rl, rm, rl.GraphDeformLoss_Neural, kw, 2, 300, 300, 3, 80.0, unit=True))
+            save("loss_partial_300x170_unit", **run_loss(rl, rm, rl.GraphDeformLoss_Neural_Partial, kwp, 2, 300, 170, 4, 60.0, unit=True))
         finally:
             os.chdir(cwd)
 
@@ -250,6 +257,8 @@ def main():
             group_deformer(rl, rm)
         elif gname == "loss":
             group_loss(rl, rm)
+        elif gname == "loss_unit":
+            group_loss(rl, rm, only_unit=True)
         elif gname == "backbone":
             import make_fixtures_backbone
             make_fixtures_backbone.run(rm, save)

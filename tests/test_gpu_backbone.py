@@ -176,7 +176,7 @@ def _criterion_case(golden, name, cls_name, kw):
 def test_criterion_full(golden):
     kw = dict(k_deform=10, w_dist=0.02, w_map=0.005, k_dist=50, N_dist=100, partial=False, w_deform=0.5, w_img=0,
               w_rank=0, w_self_rec=0.5, w_cd=0.1, w_arap=0.01)
-    for name in ("loss_full_256", "loss_full_scape_384"):
+    for name in ("loss_full_256", "loss_full_scape_384", "loss_full_300_unit"):
         g, out = _criterion_case(golden, name, "GraphDeformLoss_Neural", kw)
         ref = [float(g[k]) for k in ("loss", "dist_loss", "deform_loss", "map_loss", "self_rec_loss")]
         np.testing.assert_allclose(out, ref, rtol=2e-4, err_msg=name)
@@ -185,15 +185,20 @@ def test_criterion_full(golden):
 def test_criterion_partial(golden):
     kw = dict(k_deform=10, w_dist=0.02, w_map=0.005, k_dist=30, N_dist=60, partial=True, w_deform=1000, w_img=0,
               w_rank=0, w_self_rec=1000, w_cd=0.1, w_arap=0.01)
-    g, out = _criterion_case(golden, "loss_partial_256x120", "GraphDeformLoss_Neural_Partial", kw)
-    ref = [float(g[k]) for k in ("loss", "dist_loss", "deform_loss", "map_loss", "self_rec_loss")]
-    np.testing.assert_allclose(out, ref, rtol=2e-4)
+    for name in ("loss_partial_256x120", "loss_partial_300x170_unit"):
+        g, out = _criterion_case(golden, name, "GraphDeformLoss_Neural_Partial", kw)
+        ref = [float(g[k]) for k in ("loss", "dist_loss", "deform_loss", "map_loss", "self_rec_loss")]
+        np.testing.assert_allclose(out, ref, rtol=2e-4, err_msg=name)
 
 
 @pytest.mark.parametrize("name,cls,kw", [
     ("loss_full_256", "GraphDeformLoss_Neural", dict(k_dist=50, N_dist=100, partial=False, w_deform=0.5, w_self_rec=0.5)),
     ("loss_partial_256x120", "GraphDeformLoss_Neural_Partial", dict(k_dist=30, N_dist=60, partial=True, w_deform=1000,
                                                                  w_self_rec=1000)),
+    # unit-scale features (|f| below the smallest pairwise distance), alpha 80 / 60, sizes that do not tile
+    ("loss_full_300_unit", "GraphDeformLoss_Neural", dict(k_dist=50, N_dist=100, partial=False, w_deform=0.5, w_self_rec=0.5)),
+    ("loss_partial_300x170_unit", "GraphDeformLoss_Neural_Partial", dict(k_dist=30, N_dist=60, partial=True, w_deform=1000,
+                                                                      w_self_rec=1000)),
 ])
 def test_criterion_backward_matches_reference(golden, name, cls, kw):
     """Training step parity: loss and gradients w.r.t. feat1, feat2 and every Deformer parameter against the
