@@ -30,3 +30,11 @@ def test_attention_cores_far_from_unit_scale():
     for ln in lines:
         errs = [float(x) for x in re.findall(r"(\d\.\de-\d+)", ln)]
         assert errs and max(errs) < 5e-5, ln
+
+
+def test_knn_k500_and_dist_loss_at_shipped_sizes():
+    text = _run("stress_knn_dist.py")
+    knn = [ln for ln in text.splitlines() if ln.startswith("knn ")]
+    assert len(knn) == 5 and all(ln.endswith("equal: True") for ln in knn), text
+    errs = [float(x) for x in re.findall(r"rel_err (\S+)", text)]
+    assert len(errs) == 2 and max(errs) < 1e-5, text
