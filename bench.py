@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=512, help="pairs per GPU per step (resident batch)")
     ap.add_argument("--cpu-sample", type=int, default=48, help="pairs timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo for the "
+                    "two-ranks-on-one-GPU test of this script)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="per-launch HBM bytes of the dominant kernel from the PMC passes (default: profiles/k1_traffic.json)")
     args = ap.parse_args()
@@ -92,11 +94,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    local = local % torch.cuda.device_count()  # (more ranks than devices only happens in the gloo test)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
     lib = _lib.load()
 
     P = args.pairs

@@ -95,3 +95,22 @@ def test_training_driver_two_ranks_on_one_gpu():
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["global_batch"] == 4 and res["grad_bucket_floats"] == 2122644
     assert all(map(lambda v: v == v and abs(v) < 1e9, res["first_losses"] + res["last_losses"]))
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's N > 1 path (barriers, MAX-over-ranks time, one JSON line from rank 0, whole-job value) with two gloo
+    ranks sharing cuda:0 — the 8-GPU run itself belongs to the driver."""
+    import json
+    import subprocess
+    port = 29950 + os.getpid() % 1000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs", "16",
+           "--backend", "gloo"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout                                   # rank 0 only
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 2 and res["scaling"] == "weak" and res["cpu_baseline"] is None
+    assert abs(res["value"] - 2 * 16 * 2 / (res["ms_per_step"] * 2e-3)) < 1e-6 * res["value"]   # pairs of BOTH ranks / time
+    assert res["roofline"]["frac"] > 0
