@@ -63,6 +63,7 @@ SIGNATURES = {
     "dvm_bn_act_train_fwd_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P,
                                          c_size_t, _P]),
     "dvm_bn_act_train_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, c_size_t, _P]),
+    "dvm_graph_geodesics_f64": (c_int, [_P, _P, c_int, c_int, _P, _P]),
     "dvm_proj2img_workspace_bytes": (c_size_t, [c_int]),
     "dvm_proj2img_f32": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
     "dvm_i2p_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),

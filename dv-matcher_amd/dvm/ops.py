@@ -491,6 +491,16 @@ def bn_act_train_bwd(dy, y, x, res, gamma, mean, invstd, slope):
     return dx, dgamma, dbeta
 
 
+def graph_geodesics(nbr, w):
+    """nbr (N,K) int32 neighbour lists (-1 padded), w (N,K) float64 edge lengths, on the device -> (N,N) float64."""
+    _need_gpu(nbr, w)
+    nbr, w = nbr.contiguous().int(), w.contiguous().double()
+    N, K = nbr.shape
+    D = torch.empty(N, N, dtype=torch.float64, device=nbr.device)
+    check(_lib.load().dvm_graph_geodesics_f64(_p(nbr), _p(w), N, K, _p(D), _stream()), "dvm_graph_geodesics_f64")
+    return D
+
+
 def proj2img(pts):
     """One view's point cloud (B,N,3) -> (img (B,3,224,224), pc_min (B,2), grid_size (B,), offsets (B,2))."""
     _need_gpu(pts)

@@ -223,6 +223,11 @@ int dvm_bn_act_train_bwd_f32(const float *dy, const float *y, const float *x, co
                              const float *save_mean, const float *save_invstd, int B, int C, int N, float slope, float *dx,
                              float *dgamma, float *dbeta, void *ws, size_t ws_bytes, void *stream);
 
+/* cal_geo — models/dataset.py:49-54 (potpourri3d heat method in the reference; graph shortest paths here, as in the
+ * reference's eval/geo_mat.py:15-41).  All-pairs shortest paths of an undirected graph given as padded neighbour lists:
+ * nbr [N,K] (-1 ends a list), w [N,K] fp64 edge lengths -> D [N,N] fp64 (+inf between components).  N <= 19200. */
+int dvm_graph_geodesics_f64(const int32_t *nbr, const double *w, int N, int K, double *D, void *stream);
+
 /* Uni3FC.proj2img — models/model.py:584-650 (+ get_colored_depth_maps 563-581).  pts [B,N,3] (one of the three
  * axis-permuted views) -> img [B,3,224,224]: every point adds its depth (3rd coordinate) to the 5x5 pixels around its
  * cell, sigmoid, ImageNet-normalise, min-max rescale per image, 'PiYG' colour table, pixels whose depth sum is exactly 0

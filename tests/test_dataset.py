@@ -249,3 +249,32 @@ def test_drivers_read_a_dataset_directory(tmp_path):
             if a != b:
                 T = np.loadtxt(os.path.join(res_dir, "T", "T_%s_%s.txt" % (a, b)), dtype=np.int64)
                 assert T.shape == (320,) and T.min() >= 1 and T.max() <= 320
+
+
+@pytest.mark.gpu
+def test_gpu_geodesics_equal_dijkstra():
+    """dvm_graph_geodesics_f64 (one workgroup per source, in-LDS relaxation) against scipy's Dijkstra on the same graph:
+    a k-NN graph of a cloud, a mesh, and two disconnected pieces (+inf between them)."""
+    from scipy.sparse.csgraph import shortest_path
+    rs = np.random.RandomState(4)
+    V = rs.rand(1500, 3)
+    g = ds._dedup_min(*_knn_edges(V, 8), len(V))
+    want = shortest_path(g, method="D", directed=False)
+    got = ds._shortest_paths_gpu(g, len(V))
+    assert np.array_equal(got, want)                                   # the same fp64 path sums, bit for bit
+    two = np.concatenate([rs.rand(40, 3), rs.rand(40, 3) + 10.0])
+    g2 = ds._dedup_min(*_knn_edges(two, 3), len(two))
+    got2 = ds._shortest_paths_gpu(g2, len(two))
+    assert np.array_equal(got2, shortest_path(g2, method="D", directed=False)) and np.isinf(got2[0, 50])
+    d = ds.cal_geo(V).numpy()                                          # the public entry takes the GPU path on this box
+    assert np.array_equal(d, want.astype(np.float32))
+
+
+def _knn_edges(V, k):
+    from scipy.spatial import cKDTree
+    n = len(V)
+    _, nbr = cKDTree(V).query(V, k + 1)
+    src, dst = np.repeat(np.arange(n), k + 1), nbr.reshape(-1)
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    return src, dst, np.linalg.norm(V[src] - V[dst], axis=1)
