@@ -31,7 +31,12 @@ def geodesic_distmat(verts, faces, normalize=True):
     w = np.linalg.norm(verts[e[:, 0]] - verts[e[:, 1]], axis=1)
     n = verts.shape[0]
     adj = coo_matrix((np.concatenate([w, w]), (np.concatenate([e[:, 0], e[:, 1]]), np.concatenate([e[:, 1], e[:, 0]]))), shape=(n, n))
-    geo = shortest_path(adj.tocsr(), directed=False)
+    import torch
+    if torch.cuda.is_available() and n * 8 <= 150 * 1024:   # same values as scipy's Dijkstra, one workgroup per source
+        from models.dataset import _shortest_paths_gpu
+        geo = _shortest_paths_gpu(adj.tocsr(), n)
+    else:
+        geo = shortest_path(adj.tocsr(), directed=False)
     if np.isinf(geo).any():
         raise ValueError("mesh graph is not connected")
     return geo / np.sqrt(mesh_area(verts, faces)) if normalize else geo
