@@ -88,7 +88,9 @@ def main():
                                   w_img=L["w_img"], w_rank=L["w_rank"], w_self_rec=L["w_self_rec"], w_cd=L["deform"]["w_cd"],
                                   w_arap=L["deform"]["w_arap"], save_name=cfg["expname"])
     alpha = np.linspace(L["min_alpha"], L["max_alpha"] + 1, cfg["training"]["epochs"])[args.epoch - 1]
-    bucket = FlatGradBucket(params, attach=True)          # every p.grad is a view into one flat buffer
+    # world > 1: every p.grad is a view into one flat buffer (one all-reduce, no pack/unpack); a single rank has nothing to
+    # exchange and lets autograd hand Adam its gradient tensors directly (no accumulate-into-zeros adds either)
+    bucket = FlatGradBucket(params, attach=world > 1)
     g = torch.Generator().manual_seed(100 + rank)
     random.seed(200 + rank)
     torch.manual_seed(300 + rank)
@@ -134,9 +136,13 @@ def main():
         f2, _ = net(v2.permute(0, 2, 1), d2, None)
         out = crit(f1, f2, dist1, dist2, v1, v2, alpha, dfm)
         out[0].backward()
-        bucket.all_reduce_mean()
+        if world > 1:
+            bucket.all_reduce_mean()
         opt.step()
-        bucket.zero()
+        if world > 1:
+            bucket.zero()
+        else:
+            opt.zero_grad(set_to_none=True)
         vals = torch.stack([torch.as_tensor(o, device=dev).detach().float().reshape(()) for o in out])
         return vals.tolist() if sync_each else vals      # the 5 loss terms; read back after the timed loop by default
 
