@@ -219,6 +219,37 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const float *__restric
     for (int t = tid; t < k; t += 256) idx[row * k + t] = (int32_t)(sel[t] & 0xffffffffu);
 }
 
+// Tail shared by the wave top-k kernels: the (key << 32 | column) words compacted into cw[0..base) (rest ~0) are
+// bitonic-sorted across the wave, element i = lane + 64 * slot (LDS operations of one wave execute in order), and the
+// first k columns written out.
+__device__ __forceinline__ void wave_sort_and_store(const unsigned long long *cw, int base, int lane, int k, int32_t *__restrict__ out) {
+    unsigned long long a0 = cw[lane], a1 = cw[lane + 64];
+    const bool small = base <= 64;  // everything sits in slot 0 then (slot 1 is all ~0)
+    for (int size = 2; size <= (small ? 64 : 128); size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (stride == 64) {  // partner is the other slot of this lane; i = lane (slot 0) is the lower index, ascending
+                const unsigned long long lo = a0 < a1 ? a0 : a1, hi = a0 < a1 ? a1 : a0;
+                a0 = lo, a1 = hi;
+            } else {
+                const bool lower = (lane & stride) == 0;
+#pragma unroll
+                for (int slot = 0; slot < 2; ++slot) {
+                    if (slot == 1 && small) break;
+                    unsigned long long &x = slot ? a1 : a0;
+                    const int i = lane + 64 * slot;
+                    const bool up = (i & size) == 0 || size == 128;
+                    const unsigned long long y =
+                        ((unsigned long long)__shfl_xor((unsigned)(x >> 32), stride, 64) << 32) | __shfl_xor((unsigned)x, stride, 64);
+                    const bool keep_min = (lower == up);
+                    x = keep_min ? (x < y ? x : y) : (x < y ? y : x);
+                }
+            }
+        }
+    }
+    if (lane < k) out[lane] = (int32_t)(unsigned)a0;
+    if (!small && lane + 64 < k) out[lane + 64] = (int32_t)(unsigned)a1;
+}
+
 // k <= 64: one WAVE per row, no workgroup barriers (the block kernel above spends ~50 of them per row).
 //   1. every lane keeps its EPL keys (columns e*64 + lane) and their two smallest;
 //   2. Tc = the k-th smallest of those 128 lane minima, by a 32-step bit search with ballots: an upper bound of the
@@ -284,32 +315,7 @@ __global__ __launch_bounds__(256) void topk_wave_kernel(const float *__restrict_
         base += __popcll(mt);
         tbase += __popcll(meq);
     }
-    // bitonic sort of 128 words, element i = lane + 64 * slot (LDS operations of one wave execute in order)
-    unsigned long long a0 = cw[lane], a1 = cw[lane + 64];
-    const bool small = base <= 64;  // everything sits in slot 0 then (slot 1 is all ~0)
-    for (int size = 2; size <= (small ? 64 : 128); size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            if (stride == 64) {  // partner is the other slot of this lane; i = lane (slot 0) is the lower index, ascending
-                const unsigned long long lo = a0 < a1 ? a0 : a1, hi = a0 < a1 ? a1 : a0;
-                a0 = lo, a1 = hi;
-            } else {
-                const bool lower = (lane & stride) == 0;
-#pragma unroll
-                for (int slot = 0; slot < 2; ++slot) {
-                    if (slot == 1 && small) break;
-                    unsigned long long &x = slot ? a1 : a0;
-                    const int i = lane + 64 * slot;
-                    const bool up = (i & size) == 0 || size == 128;
-                    const unsigned long long y =
-                        ((unsigned long long)__shfl_xor((unsigned)(x >> 32), stride, 64) << 32) | __shfl_xor((unsigned)x, stride, 64);
-                    const bool keep_min = (lower == up);
-                    x = keep_min ? (x < y ? x : y) : (x < y ? y : x);
-                }
-            }
-        }
-    }
-    if (lane < k) idx[row * k + lane] = (int32_t)(unsigned)a0;
-    if (!small && lane + 64 < k) idx[row * k + lane + 64] = (int32_t)(unsigned)a1;
+    wave_sort_and_store(cw, base, lane, k, idx + row * k);
 }
 
 // Rows longer than 2048 columns: the same algorithm without the per-lane key array (128 VGPRs at EPL = 128 left two
@@ -388,32 +394,7 @@ __global__ __launch_bounds__(256) void topk_wave_stream_kernel(const float *__re
             tbase += __popcll(meq);
         }
     }
-    // bitonic sort of 128 words, element i = lane + 64 * slot (LDS operations of one wave execute in order)
-    unsigned long long a0 = cw[lane], a1 = cw[lane + 64];
-    const bool small = base <= 64;
-    for (int size = 2; size <= (small ? 64 : 128); size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            if (stride == 64) {
-                const unsigned long long lo = a0 < a1 ? a0 : a1, hi = a0 < a1 ? a1 : a0;
-                a0 = lo, a1 = hi;
-            } else {
-                const bool lower = (lane & stride) == 0;
-#pragma unroll
-                for (int slot = 0; slot < 2; ++slot) {
-                    if (slot == 1 && small) break;
-                    unsigned long long &x = slot ? a1 : a0;
-                    const int i = lane + 64 * slot;
-                    const bool up = (i & size) == 0 || size == 128;
-                    const unsigned long long y =
-                        ((unsigned long long)__shfl_xor((unsigned)(x >> 32), stride, 64) << 32) | __shfl_xor((unsigned)x, stride, 64);
-                    const bool keep_min = (lower == up);
-                    x = keep_min ? (x < y ? x : y) : (x < y ? y : x);
-                }
-            }
-        }
-    }
-    if (lane < k) idx[row * k + lane] = (int32_t)(unsigned)a0;
-    if (!small && lane + 64 < k) idx[row * k + lane + 64] = (int32_t)(unsigned)a1;
+    wave_sort_and_store(cw, base, lane, k, idx + row * k);
 }
 
 // ============================================================== positional encoding
@@ -940,7 +921,6 @@ DVM_EXPORT int dvm_knn_neg_f32(const float *a, const float *b, int B, int N, int
     DVM_REQUIRE(B >= 1 && N >= 1 && M >= 1 && C >= 1, "dvm_knn_neg_f32: empty input (B=%d N=%d M=%d C=%d)", B, N, M, C);
     DVM_REQUIRE(k >= 1 && k <= 512 && k <= M, "dvm_knn_neg_f32: k=%d unsupported (1..min(512,M=%d))", k, M);
     DVM_REQUIRE(M <= 8192, "dvm_knn_neg_f32: M=%d exceeds 8192", M);
-    DVM_REQUIRE((C != 64 && C != 128) || true, "unreachable");
     Arena ar(ws, ws_bytes);
     float *na = ar.take<float>((size_t)B * N);
     float *nb = ar.take<float>((size_t)B * M);
