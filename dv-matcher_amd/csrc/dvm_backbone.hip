@@ -8,6 +8,7 @@
 // Layout: all activations are point-major [B][N][C] fp32 in HBM (the host transposes the
 // reference's (B,C,N) once per block), so neighbour rows are contiguous 256/512-B gathers.
 #include "dvm_common.h"
+#include <stdlib.h>
 
 namespace dvm {
 
@@ -978,29 +979,57 @@ static size_t sa_partial_floats(int B, int N) {
     const int S = sa_splits(B, N);
     return S > 1 ? (size_t)S * B * N * (2 + SA_C + 1) : 0;
 }
-// stats [B][N][2] and xr [B][N][64] (and cinv [B][N] when given) from p, v; `part` holds sa_partial_floats(B, N) floats
+// fp16x2-split kernels (dvm_sa_f16.hip)
+size_t sa_f16_ws_bytes(int B, int N);
+void sa_f16_carve(void *ws, int B, int N, _Float16 *&pp, _Float16 *&vp);
+void launch_sa_split_f16(const float *p, const float *v, int B, int N, _Float16 *pp, _Float16 *vp, hipStream_t s);
+void launch_sa_rowstats_f16(const _Float16 *pp, int B, int N, int kchunk, int Z, float *stats, hipStream_t s);
+void launch_sa_apply_f16(const _Float16 *pp, const _Float16 *vp, const float *stats, int B, int N, int kchunk, int Z, float *xr,
+                         float *cinv, hipStream_t s);
+
+static bool sa_use_f16() {  // env DVM_SA_VARIANT=f32 keeps both contractions on the fp32 matrix instruction
+    static const bool v = [] {
+        const char *e = getenv("DVM_SA_VARIANT");
+        return !(e && e[0] == 'f' && e[1] == '3');
+    }();
+    return v;
+}
+
+// stats [B][N][2] and xr [B][N][64] (and cinv [B][N] when given) from p, v; `part` holds sa_partial_floats(B, N) floats,
+// `f16ws` sa_f16_ws_bytes(B, N) bytes
 static void launch_sa_forward(const float *p, const float *v, int B, int N, float *xr, float *stats, float *cinv, float *part,
-                              hipStream_t s) {
+                              void *f16ws, hipStream_t s) {
     const int S = sa_splits(B, N);
     const int kchunk = ((N + S - 1) / S + SA_KB - 1) / SA_KB * SA_KB;
     const int Z = (N + kchunk - 1) / kchunk;
     dim3 grid((N + 31) / 32, B, Z);
-    if (Z == 1) {
-        hipLaunchKernelGGL(sa_rowstats_kernel, grid, dim3(256), 0, s, p, N, kchunk, stats);
-        hipLaunchKernelGGL(sa_apply_kernel, grid, dim3(256), 0, s, p, v, stats, N, kchunk, xr, cinv);
-        return;
-    }
     const long rows = (long)B * N;
-    float *pstats = part, *po = pstats + (size_t)Z * rows * 2, *pc = po + (size_t)Z * rows * SA_C;
-    hipLaunchKernelGGL(sa_rowstats_kernel, grid, dim3(256), 0, s, p, N, kchunk, pstats);
-    hipLaunchKernelGGL(sa_stats_merge_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, pstats, rows, Z, stats);
-    hipLaunchKernelGGL(sa_apply_kernel, grid, dim3(256), 0, s, p, v, stats, N, kchunk, po, pc);
-    hipLaunchKernelGGL(sa_apply_merge_kernel, dim3((unsigned)((rows * SA_C + 255) / 256)), dim3(256), 0, s, po, pc, rows, Z, xr, cinv);
+    float *pstats = part, *po = Z > 1 ? pstats + (size_t)Z * rows * 2 : nullptr, *pc = Z > 1 ? po + (size_t)Z * rows * SA_C : nullptr;
+    const bool f16 = sa_use_f16() && f16ws != nullptr;
+    _Float16 *pp = nullptr, *vp = nullptr;
+    if (f16) {
+        sa_f16_carve(f16ws, B, N, pp, vp);
+        launch_sa_split_f16(p, v, B, N, pp, vp, s);
+    }
+    // pass 1
+    float *st1 = Z == 1 ? stats : pstats;
+    if (f16)
+        launch_sa_rowstats_f16(pp, B, N, kchunk, Z, st1, s);
+    else
+        hipLaunchKernelGGL(sa_rowstats_kernel, grid, dim3(256), 0, s, p, N, kchunk, st1);
+    if (Z > 1) hipLaunchKernelGGL(sa_stats_merge_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, pstats, rows, Z, stats);
+    // pass 2
+    float *xo = Z == 1 ? xr : po, *co = Z == 1 ? cinv : pc;
+    if (f16)
+        launch_sa_apply_f16(pp, vp, stats, B, N, kchunk, Z, xo, co, s);
+    else
+        hipLaunchKernelGGL(sa_apply_kernel, grid, dim3(256), 0, s, p, v, stats, N, kchunk, xo, co);
+    if (Z > 1) hipLaunchKernelGGL(sa_apply_merge_kernel, dim3((unsigned)((rows * SA_C + 255) / 256)), dim3(256), 0, s, po, pc, rows, Z, xr, cinv);
 }
 }  // namespace dvm
 
 DVM_EXPORT size_t dvm_sa_attention_workspace_bytes(int B, int N) {
-    return align_up((size_t)B * N * 2 * sizeof(float)) + align_up(sa_partial_floats(B, N) * sizeof(float));
+    return align_up((size_t)B * N * 2 * sizeof(float)) + align_up(sa_partial_floats(B, N) * sizeof(float)) + sa_f16_ws_bytes(B, N);
 }
 
 DVM_EXPORT int dvm_sa_attention_fwd_f32(const float *p, const float *v, int B, int N, float *xr, void *ws, size_t ws_bytes,
@@ -1009,15 +1038,19 @@ DVM_EXPORT int dvm_sa_attention_fwd_f32(const float *p, const float *v, int B, i
     Arena ar(ws, ws_bytes);
     float *stats = ar.take<float>((size_t)B * N * 2);
     float *part = ar.take<float>(sa_partial_floats(B, N));
+    char *f16ws = ar.take<char>(sa_f16_ws_bytes(B, N));
     if (!ar.ok()) {
         set_error("dvm_sa_attention_fwd_f32: workspace too small (%zu < %zu)", ws_bytes, ar.off);
         return DVM_ENOSPACE;
     }
-    launch_sa_forward(p, v, B, N, xr, stats, nullptr, part, (hipStream_t)stream);
+    launch_sa_forward(p, v, B, N, xr, stats, nullptr, part, f16ws, (hipStream_t)stream);
     DVM_CHECK_LAUNCH("sa_attention");
     return DVM_OK;
 }
 
+// The training forward stays on the fp32 matrix instruction: the backward kernels recompute E in fp32 and take the row
+// statistics and column sums from here — with the fp16-split E (2.4e-7 * sum|p_i p_j| off) the two would disagree by
+// up to 1e-4 relative in dp at large logits.  Inference (dvm_sa_attention_fwd_f32) has no such coupling.
 DVM_EXPORT size_t dvm_sa_attention_train_fwd_workspace_bytes(int B, int N) { return align_up(sa_partial_floats(B, N) * sizeof(float)); }
 
 DVM_EXPORT int dvm_sa_attention_train_fwd_f32(const float *p, const float *v, int B, int N, float *xr, float *stats, float *cinv,
@@ -1026,7 +1059,7 @@ DVM_EXPORT int dvm_sa_attention_train_fwd_f32(const float *p, const float *v, in
     const size_t need = sa_partial_floats(B, N) * sizeof(float);
     DVM_REQUIRE(need == 0 || (ws != nullptr && ws_bytes >= need), "dvm_sa_attention_train_fwd_f32: workspace too small (%zu < %zu)",
                 ws_bytes, need);
-    launch_sa_forward(p, v, B, N, xr, stats, cinv, (float *)ws, (hipStream_t)stream);
+    launch_sa_forward(p, v, B, N, xr, stats, cinv, (float *)ws, nullptr, (hipStream_t)stream);
     DVM_CHECK_LAUNCH("sa_attention_train_fwd");
     return DVM_OK;
 }

@@ -255,7 +255,7 @@ int dvm_sa_attention_fwd_f32(const float *p, const float *v, int B, int N, float
  * backward recomputes from: stats [B,N,2] = (row max m_i, 1/l_i) and cinv [B,N] = 1/(1e-9 + column sum).
  * bwd: g_xr [B,N,64] -> d_p [B,N,16], d_v [B,N,64] (overwritten).  Nothing N x N is stored: two
  * tile-recompute passes on the fp32 matrix cores (E is symmetric, so both dE_ij and dE_ji come from one tile). */
-size_t dvm_sa_attention_train_fwd_workspace_bytes(int B, int N);  /* 0 unless the key range is split (small B * N) */
+size_t dvm_sa_attention_train_fwd_workspace_bytes(int B, int N);
 int dvm_sa_attention_train_fwd_f32(const float *p, const float *v, int B, int N, float *xr, float *stats, float *cinv,
                                    void *ws, size_t ws_bytes, void *stream);
 size_t dvm_sa_attention_bwd_workspace_bytes(int B, int N);

@@ -25,8 +25,8 @@ def test_grid_searches_on_degenerate_clouds():
 
 def test_attention_cores_far_from_unit_scale():
     text = _run("stress_scales.py")
-    lines = [ln for ln in text.splitlines() if ln.startswith(("SA ", "N2P"))]
-    assert len(lines) == 7 and all("finite True" in ln for ln in lines), text
+    lines = [ln for ln in text.splitlines() if ln.startswith(("SA ", "SAev", "N2P"))]
+    assert len(lines) == 11 and all("finite True" in ln for ln in lines), text
     for ln in lines:
         errs = [float(x) for x in re.findall(r"(\d\.\de-\d+)", ln)]
         assert errs and max(errs) < 5e-5, ln

@@ -26,6 +26,8 @@ for (B, N, sc) in ((1, 257, 1.0), (2, 1000, 2.5), (1, 4995, 2.0), (2, 333, 4.0))
     A = A / (1e-9 + A.sum(1, keepdim=True))
     ref = (vd.transpose(1, 2) @ A).transpose(1, 2)
     (ref * gx.double()).sum().backward()
+    xe = ops.sa_attention_pm(p.to(dev), v.to(dev))       # the inference path: both contractions as fp16x2-split products
+    print("SAev B=%d N=%d scale %.1f: finite %s  fwd %.1e" % (B, N, sc, bool(torch.isfinite(xe).all()), rel(xe, ref)))
     print("SA   B=%d N=%d scale %.1f: finite %s  fwd %.1e  dp %.1e  dv %.1e" %
           (B, N, sc, bool(torch.isfinite(xr).all() and torch.isfinite(dp).all() and torch.isfinite(dv).all()), rel(xr, ref), rel(dp, pd.grad),
            rel(dv, vd.grad)))
