@@ -283,11 +283,39 @@ __global__ __launch_bounds__(256) void topk_wave_kernel(const float *__restrict_
         const int cnt = __popcll(__ballot(m1 < c)) + __popcll(__ballot(m2 < c));
         if (cnt < k) T = c;
     }
-    int C = 0;
+    unsigned long long *cw = cand[wave];
+    cw[lane] = ~0ull;
+    cw[lane + 64] = ~0ull;
+    int base = 0;
+    // Each lane marks its own keys <= Tc (about one per lane); a wave prefix sum gives every lane its slots and the lane
+    // writes its few winners itself — the final sort orders by (key, column), so the compaction order is free.  (The
+    // previous form ranked all EPL key slots with two ballots + two lane counts each: 12 VALU x 32 slots.)
+    static_assert(EPL <= 32, "one 32-bit pass mask per lane");
+    unsigned pm = 0;
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) C += __popcll(__ballot(key[e] <= T));
-    int ties = 0x7fffffff;  // how many keys == T may be taken (fast path: all of them, the sort decides)
-    if (C > 128) {          // heavy ties: exact k-th key over all keys, then only the winners
+    for (int e = 0; e < EPL; ++e) pm |= key[e] <= T ? (1u << e) : 0u;
+    const int mine = __popc(pm);
+    int incl = mine;  // inclusive prefix over lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    const int C = __shfl(incl, 63, 64);
+    if (C <= 128) {
+        int pos = incl - mine;
+        const int iters = __reduce_max_sync(~0ull, mine);
+        for (int it = 0; it < iters; ++it) {
+            if (pm) {
+                const int e = __ffs(pm) - 1;
+                pm &= pm - 1;
+                const int j = e * 64 + lane;
+                const unsigned x = j < M ? desc_key(s[j]) : 0xffffffffu;  // re-read (L1 hit): no dynamic register index
+                cw[pos++] = ((unsigned long long)x << 32) | (unsigned)j;
+            }
+        }
+        base = C;
+    } else {  // heavy ties: exact k-th key over all keys, then only the winners (ties in column order)
         T = 0;
         for (int bit = 31; bit >= 0; --bit) {
             const unsigned c = T | (1u << bit);
@@ -299,22 +327,19 @@ __global__ __launch_bounds__(256) void topk_wave_kernel(const float *__restrict_
         int lt = 0;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) lt += __popcll(__ballot(key[e] < T));
-        ties = k - lt;
-    }
-    unsigned long long *cw = cand[wave];
-    cw[lane] = ~0ull;
-    cw[lane + 64] = ~0ull;
-    int base = 0, tbase = 0;
+        const int ties = k - lt;
+        int tbase = 0;
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-        const bool eq = key[e] == T;
-        const unsigned long long meq = __ballot(eq);
-        const int teq = tbase + __popcll(meq & ((1ull << lane) - 1ull));  // this key's rank among the ties, column order
-        const bool take = key[e] < T || (eq && teq < ties);
-        const unsigned long long mt = __ballot(take);
-        if (take) cw[base + __popcll(mt & ((1ull << lane) - 1ull))] = ((unsigned long long)key[e] << 32) | (unsigned)(e * 64 + lane);
-        base += __popcll(mt);
-        tbase += __popcll(meq);
+        for (int e = 0; e < EPL; ++e) {
+            const bool eq = key[e] == T;
+            const unsigned long long meq = __ballot(eq);
+            const int teq = tbase + __popcll(meq & ((1ull << lane) - 1ull));  // this key's rank among the ties, column order
+            const bool take = key[e] < T || (eq && teq < ties);
+            const unsigned long long mt = __ballot(take);
+            if (take) cw[base + __popcll(mt & ((1ull << lane) - 1ull))] = ((unsigned long long)key[e] << 32) | (unsigned)(e * 64 + lane);
+            base += __popcll(mt);
+            tbase += __popcll(meq);
+        }
     }
     wave_sort_and_store(cw, base, lane, k, idx + row * k);
 }
