@@ -1,0 +1,356 @@
+// dvm_gemm.hip — the 1x1 convolutions / linear layers of LG-Net as a k-ordered fp32 chain on
+// v_mfma_f32_32x32x2_f32, with the layer's bias, residual, eval-mode BatchNorm affine and (Leaky)ReLU
+// fused into the epilogue.
+//
+// Why not the BLAS library: the reference's nn.Conv1d(kernel_size=1) (models/model.py:506-529, the ff /
+// q / k / v projections of 325-395 and SA_Layer 97-123) evaluated by one CPU thread is, bit for bit,
+// acc = fma(w[co][k], x[k][n], acc) for k = 0..K-1 (verified against torch.matmul, which is that chain at
+// every thread count; oneDNN's multi-threaded conv splits K across threads and is NOT reproducible
+// against itself).  v_mfma_f32_32x32x2_f32 computes exactly this chain, so the activations that feed the
+// feature-space kNNs carry no reduction-order noise relative to the reference's deterministic form, and
+// results do not depend on batch size, tile choice or launch geometry.
+//
+// Mapping: D[i][j] = sum_k P[i][k] Q[k][j].  P is always K-contiguous ([row][k]).
+//   point-major   (inference):        P = x [B*N][K],  Q = w [Co][K] (also K-contiguous), y [B*N][Co]
+//   channel-major (training forward): P = w [Co][K],   Q = x[b] [K][N] (N-contiguous),    y [b][Co][N]
+// A workgroup = 4 waves, each wave TM x TN accumulator tiles of 32x32 (16 VGPRs each); k-step 32 staged
+// through LDS with the even / odd k of a row de-interleaved so that a lane's half-wave (k parity) reads its
+// four next operands with one ds_read_b128; the next k-step's global loads are in flight during the MFMAs.
+// The fp32 matrix instruction issues at the vector rate (64 cycles per 32x32x2), so LDS and global traffic
+// are far below their limits: the kernel is bound by MFMA issue.
+#include "dvm_common.h"
+
+#include <stdlib.h>
+
+namespace dvm {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int GK = 32;       // k-step
+constexpr int GLD = GK + 4;  // LDS row stride of a [row][evens | odds] tile
+constexpr int GEMM_MAX_KB = 24;
+
+struct LinArgs {
+    const float *P, *Q;
+    float *Y;
+    const float *bias, *res, *alpha, *beta;  // per output channel (bias, alpha, beta); res laid out like Y
+    int I, J, K;                             // rows of P, columns of Q, reduction length
+    long q_bs, y_bs;                         // batch strides (channel-major); 0 otherwise
+    int ldy;
+    float slope;                             // 1: no activation; 0: ReLU; else LeakyReLU(slope)
+    int tiles_i, tiles_j;
+    int qvec;                                // channel-major: rows of Q are 16-byte aligned (N % 4 == 0)
+    int kvec;                                // every K-block starts and ends on a multiple of 4
+    int nkb, kb[GEMM_MAX_KB + 1];            // K-blocks [kb[b], kb[b+1]) of the reference's CPU sgemm (gemm_kblocks)
+    const float *G;                          // point-major: per-shape row prefix [B][Cg] (NULL: none): row i of the
+    int Cg, Nrow, ldp;                       // operand is [G[i / Nrow] (Cg) | P[i] (K - Cg)]; ldp = row stride of P
+};
+
+// K-blocking of the CPU sgemm behind torch.matmul / nn.Conv1d(k=1) (MKL / oneDNN, one thread; probed K = 5..3000, see
+// oracle/dvm_oracle.c dvo_gemm_kblocks): blocks of 384 while more than 768 remain, then one block or two halves.  Every
+// block is a k-ordered fma chain started at 0; block results are added in order.  LG-Net: K = 1152 -> 3 x 384,
+// 768 -> 2 x 384, 512 -> 2 x 256, K <= 384 -> one chain.
+static int gemm_kblocks(int K, int *starts) {
+    int n = 0, k = 0;
+    starts[0] = 0;
+    while (K - k > 768 && n < GEMM_MAX_KB - 2) starts[++n] = (k += 384);
+    if (K - k > 384 && n < GEMM_MAX_KB - 1) starts[++n] = (k += (K - k + 1) / 2);
+    starts[++n] = K;
+    return n;
+}
+
+template <bool CM, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int QSZ = CM ? GK * BN : BN * GLD;
+    constexpr int PL = BM / 32;                     // f32x4 chunks of P per thread and k-step
+    constexpr int QL = CM ? (GK * BN / 4) / 256 : BN / 32;
+    __shared__ __attribute__((aligned(16))) float Ps[BM * GLD];
+    __shared__ __attribute__((aligned(16))) float Qs[QSZ];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r32 = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    // XCD-aware tile order: the workgroups of one XCD (blockIdx % 8) walk consecutive tiles, column tiles of a row
+    // tile first, so the P rows a row tile streams are shared in that XCD's L2 by all its column tiles
+    int t = blockIdx.x;
+    const int total = a.tiles_i * a.tiles_j;
+    if ((total & 7) == 0) t = (t & 7) * (total >> 3) + (t >> 3);
+    const int ti = t / a.tiles_j, tj = t % a.tiles_j;
+    const int i0 = ti * BM, j0 = tj * BN, b = blockIdx.y;
+    const float *__restrict__ P = a.P;
+    const float *__restrict__ Q = a.Q + (size_t)b * a.q_bs;
+    const int K = a.K, I = a.I, J = a.J;
+
+    f32x4 pp[PL], pq[QL];
+    // 4 consecutive k of one K-contiguous row, zero beyond the block's end (fma(0, 0, acc) == acc)
+    auto ldk = [&](const float *row, int k, int kend) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < kend) {
+            if (a.kvec) {
+                v = *(const f32x4 *)(row + k);
+            } else {
+                v.x = row[k];
+                if (k + 1 < kend) v.y = row[k + 1];
+                if (k + 2 < kend) v.z = row[k + 2];
+                if (k + 3 < kend) v.w = row[k + 3];
+            }
+        }
+        return v;
+    };
+    auto fetch = [&](int k0, int kend) {
+#pragma unroll
+        for (int u = 0; u < PL; ++u) {
+            const int r = (tid >> 3) + 32 * u, c = tid & 7;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            const int i = i0 + r, k = k0 + 4 * c;
+            if (i < I) {
+                if (!CM && a.G && k < a.Cg)  // broadcast prefix (Cg and every block edge are multiples of 4 here)
+                    v = ldk(a.G + (size_t)(i / a.Nrow) * a.Cg, k, kend);
+                else
+                    v = ldk(P + (size_t)i * a.ldp - (CM ? 0 : a.Cg), k, kend);
+            }
+            pp[u] = v;
+        }
+        if (CM) {
+#pragma unroll
+            for (int u = 0; u < QL; ++u) {
+                const int e = tid + 256 * u, kk = e / (BN / 4), c = e % (BN / 4);
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                const int j = j0 + 4 * c;
+                if (k0 + kk < kend && j < J) {
+                    const float *src = Q + (size_t)(k0 + kk) * J + j;
+                    if (a.qvec && j + 3 < J) {
+                        v = *(const f32x4 *)src;
+                    } else {
+                        v.x = src[0];
+                        if (j + 1 < J) v.y = src[1];
+                        if (j + 2 < J) v.z = src[2];
+                        if (j + 3 < J) v.w = src[3];
+                    }
+                }
+                pq[u] = v;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < QL; ++u) {
+                const int r = (tid >> 3) + 32 * u, c = tid & 7;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (j0 + r < J) v = ldk(Q + (size_t)(j0 + r) * K, k0 + 4 * c, kend);
+                pq[u] = v;
+            }
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int u = 0; u < PL; ++u) {
+            const int r = (tid >> 3) + 32 * u, c = tid & 7;
+            float2 ev = {pp[u].x, pp[u].z}, od = {pp[u].y, pp[u].w};
+            *(float2 *)(Ps + r * GLD + 2 * c) = ev;
+            *(float2 *)(Ps + r * GLD + GK / 2 + 2 * c) = od;
+        }
+        if (CM) {
+#pragma unroll
+            for (int u = 0; u < QL; ++u) {
+                const int e = tid + 256 * u, kk = e / (BN / 4), c = e % (BN / 4);
+                *(f32x4 *)(Qs + kk * BN + 4 * c) = pq[u];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < QL; ++u) {
+                const int r = (tid >> 3) + 32 * u, c = tid & 7;
+                float2 ev = {pq[u].x, pq[u].z}, od = {pq[u].y, pq[u].w};
+                *(float2 *)(Qs + r * GLD + 2 * c) = ev;
+                *(float2 *)(Qs + r * GLD + GK / 2 + 2 * c) = od;
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int x = 0; x < TM; ++x)
+#pragma unroll
+        for (int y = 0; y < TN; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+    float *__restrict__ Y = a.Y + (size_t)b * a.y_bs;
+
+    for (int blk = 0; blk < a.nkb; ++blk) {
+        const int kbeg = a.kb[blk], kend = a.kb[blk + 1];
+        fetch(kbeg, kend);
+        for (int k0 = kbeg; k0 < kend; k0 += GK) {
+            __syncthreads();
+            stage();
+            __syncthreads();
+            if (k0 + GK < kend) fetch(k0 + GK, kend);
+#pragma unroll
+            for (int cc = 0; cc < GK / 8; ++cc) {
+                // the inner loop is MFMA + ds_read only: on gfx950 the fp32 matrix instruction and the vector ALU share the
+                // issue slot, so every VALU instruction in here would cost matrix time
+                f32x4 av[TM], bv[TN];
+#pragma unroll
+                for (int x = 0; x < TM; ++x) av[x] = *(const f32x4 *)(Ps + ((wm * TM + x) * 32 + r32) * GLD + h * (GK / 2) + 4 * cc);
+                if (!CM) {
+#pragma unroll
+                    for (int y = 0; y < TN; ++y) bv[y] = *(const f32x4 *)(Qs + ((wn * TN + y) * 32 + r32) * GLD + h * (GK / 2) + 4 * cc);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float bs[TN];
+#pragma unroll
+                    for (int y = 0; y < TN; ++y) bs[y] = CM ? Qs[(2 * (4 * cc + e) + h) * BN + (wn * TN + y) * 32 + r32] : bv[y][e];
+#pragma unroll
+                    for (int x = 0; x < TM; ++x)
+#pragma unroll
+                        for (int y = 0; y < TN; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x][e], bs[y], acc[x][y], 0, 0, 0);
+                }
+            }
+        }
+        if (a.nkb > 1) {
+            // close the block: total += block, restart the chain at 0.  The running total lives in the output buffer
+            // between blocks (every lane re-reads exactly the words it wrote) instead of a second accumulator set — 16
+            // registers per tile that the large tiles do not have; 2 extra passes over the output at K = 1152.
+            const bool last = blk == a.nkb - 1;
+#pragma unroll
+            for (int x = 0; x < TM; ++x)
+#pragma unroll
+                for (int y = 0; y < TN; ++y) {
+                    const int j = j0 + (wn * TN + y) * 32 + r32;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int i = i0 + (wm * TM + x) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (i >= I || j >= J) continue;
+                        const size_t off = (size_t)i * a.ldy + j;
+                        float t = acc[x][y][r];
+                        if (blk) t = Y[off] + t;
+                        if (last) {
+                            acc[x][y][r] = t;
+                        } else {
+                            Y[off] = t;
+                            acc[x][y][r] = 0.f;
+                        }
+                    }
+                }
+        }
+    }
+
+    // epilogue: conv bias (added after the chain, as oneDNN does), residual, y = fma(y, alpha, beta) (ATen's eval-mode
+    // BatchNorm is exactly this fma with alpha = w / sqrt(var + eps), beta = fma(-mean, alpha, b)), activation
+    const float slope = a.slope;
+    const float *__restrict__ R = a.res ? a.res + (size_t)b * a.y_bs : nullptr;
+#pragma unroll
+    for (int x = 0; x < TM; ++x)
+#pragma unroll
+        for (int y = 0; y < TN; ++y) {
+            const int j = j0 + (wn * TN + y) * 32 + r32;
+            float cb = 0.f, ca = 1.f, ct = 0.f;
+            if (!CM && j < J) {
+                if (a.bias) cb = a.bias[j];
+                if (a.alpha) ca = a.alpha[j], ct = a.beta[j];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + (wm * TM + x) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (i >= I || j >= J) continue;
+                if (CM) {
+                    cb = a.bias ? a.bias[i] : 0.f;
+                    if (a.alpha) ca = a.alpha[i], ct = a.beta[i];
+                }
+                float v = acc[x][y][r];
+                if (a.bias) v = v + cb;
+                const size_t off = (size_t)i * a.ldy + j;
+                if (R) v = v + R[off];
+                if (a.alpha) v = fmaf(v, ca, ct);
+                if (slope != 1.f) v = v > 0.f ? v : (slope == 0.f ? 0.f : v * slope);
+                Y[off] = v;
+            }
+        }
+}
+
+template <bool CM, int WM, int WN, int TM, int TN>
+static void launch_cfg(LinArgs &a, int B, hipStream_t s) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    a.tiles_i = (a.I + BM - 1) / BM;
+    a.tiles_j = (a.J + BN - 1) / BN;
+    hipLaunchKernelGGL((linear_mfma_kernel<CM, WM, WN, TM, TN>), dim3((unsigned)(a.tiles_i * a.tiles_j), (unsigned)B), dim3(256), 0, s, a);
+}
+
+// Tile choice (measured on MI355X at 16384 points, tools/bench_linear_cfg.py; us for conv 1152->384 / conv0 384->64 /
+// conv6 512->128): 64x64 workgroup tiles — one 32x32 accumulator per wave, 3-4 workgroups per CU — win everywhere
+// (196 / 20 / 35) over 64x128 (219 / 31 / 42) and 128x128 (340 / 50 / 94): this kernel stages through a single LDS
+// buffer with a one-step register prefetch, so it relies on co-resident workgroups to cover each other's staging phases,
+// and small tiles keep more of them resident.  At 64x64 the big layers are bound by L2 -> LDS operand traffic
+// (0.9 GB for conv 1152->384 = 4.6 TB/s); the larger tiles that would cut it need LDS double buffering first.
+// DVM_LINEAR_CFG=<index> forces an entry of the table (tuning knob).
+struct TileCfg {
+    int wm, wn, tm, tn;
+};
+static int pick_cfg(int n, long rows_out_narrow) {
+    if (const char *force = getenv("DVM_LINEAR_CFG")) {
+        const int c = atoi(force);
+        if (c >= 0 && c < n) return c;
+    }
+    return rows_out_narrow <= 32 ? 0 : 1;
+}
+
+void launch_linear(const float *x, const float *w, int B, int N, int K, int Co, int channel_major, const float *bias,
+                   const float *res, const float *alpha, const float *beta, float slope, float *y, hipStream_t s,
+                   const float *xg = nullptr, int Cg = 0) {
+    LinArgs a;
+    a.G = xg, a.Cg = xg ? Cg : 0, a.Nrow = N, a.ldp = K - a.Cg;
+    a.bias = bias, a.res = res, a.alpha = alpha, a.beta = beta, a.slope = slope, a.K = K, a.Y = y;
+    a.nkb = gemm_kblocks(K, a.kb);
+    a.kvec = 1;
+    for (int i = 0; i <= a.nkb; ++i)
+        if (a.kb[i] % 4) a.kvec = 0;
+    if (!channel_major) {
+        a.P = x, a.Q = w, a.I = B * N, a.J = Co, a.q_bs = 0, a.y_bs = 0, a.ldy = Co, a.qvec = 1;
+        switch (pick_cfg(4, Co)) {   // {4,1,1,1} 128x32, {2,2,1,1} 64x64, {2,2,1,2} 64x128, {2,2,2,2} 128x128
+            case 0: launch_cfg<false, 4, 1, 1, 1>(a, 1, s); break;
+            case 1: launch_cfg<false, 2, 2, 1, 1>(a, 1, s); break;
+            case 2: launch_cfg<false, 2, 2, 1, 2>(a, 1, s); break;
+            default: launch_cfg<false, 2, 2, 2, 2>(a, 1, s); break;
+        }
+    } else {
+        a.P = w, a.Q = x, a.I = Co, a.J = N, a.q_bs = (long)K * N, a.y_bs = (long)Co * N, a.ldy = N, a.qvec = (N % 4 == 0);
+        switch (pick_cfg(4, Co)) {   // {1,4,1,1} 32x128, {2,2,1,1} 64x64, {2,2,2,1} 128x64, {2,2,2,2} 128x128
+            case 0: launch_cfg<true, 1, 4, 1, 1>(a, B, s); break;
+            case 1: launch_cfg<true, 2, 2, 1, 1>(a, B, s); break;
+            case 2: launch_cfg<true, 2, 2, 2, 1>(a, B, s); break;
+            default: launch_cfg<true, 2, 2, 2, 2>(a, B, s); break;
+        }
+    }
+}
+
+}  // namespace dvm
+
+using namespace dvm;
+
+DVM_EXPORT int dvm_linear_prefix_f32(const float *xg, int Cg, const float *x, const float *w, int B, int N, int K, int Co,
+                                     const float *bias, const float *res, const float *bn_alpha, const float *bn_beta, float slope,
+                                     float *y, void *stream) {
+    DVM_REQUIRE(xg && x && w && y, "dvm_linear_prefix_f32: null pointer");
+    DVM_REQUIRE(B >= 1 && N >= 1 && Co >= 1 && Cg >= 4 && Cg < K, "dvm_linear_prefix_f32: bad sizes (B=%d N=%d K=%d Cg=%d Co=%d)", B, N,
+                K, Cg, Co);
+    DVM_REQUIRE((bn_alpha == nullptr) == (bn_beta == nullptr), "dvm_linear_prefix_f32: bn_alpha and bn_beta go together");
+    DVM_REQUIRE(K <= 384 * (GEMM_MAX_KB - 2), "dvm_linear_prefix_f32: K=%d exceeds %d", K, 384 * (GEMM_MAX_KB - 2));
+    int kb[GEMM_MAX_KB + 1];
+    const int nkb = gemm_kblocks(K, kb);
+    bool vec = Cg % 4 == 0;
+    for (int i = 0; i <= nkb; ++i) vec = vec && kb[i] % 4 == 0;
+    DVM_REQUIRE(vec, "dvm_linear_prefix_f32: Cg=%d and the K-block edges of K=%d must be multiples of 4", Cg, K);
+    launch_linear(x, w, B, N, K, Co, 0, bias, res, bn_alpha, bn_beta, slope, y, (hipStream_t)stream, xg, Cg);
+    DVM_CHECK_LAUNCH("linear_prefix");
+    return DVM_OK;
+}
+
+DVM_EXPORT int dvm_linear_f32(const float *x, const float *w, int B, int N, int K, int Co, int channel_major, const float *bias,
+                              const float *res, const float *bn_alpha, const float *bn_beta, float slope, float *y, void *stream) {
+    DVM_REQUIRE(x && w && y, "dvm_linear_f32: null pointer");
+    DVM_REQUIRE(B >= 1 && N >= 1 && K >= 1 && Co >= 1, "dvm_linear_f32: empty input (B=%d N=%d K=%d Co=%d)", B, N, K, Co);
+    DVM_REQUIRE(K <= 384 * (GEMM_MAX_KB - 2), "dvm_linear_f32: K=%d exceeds %d", K, 384 * (GEMM_MAX_KB - 2));
+    DVM_REQUIRE((bn_alpha == nullptr) == (bn_beta == nullptr), "dvm_linear_f32: bn_alpha and bn_beta go together");
+    DVM_REQUIRE((long)B * N < (1L << 31) && (long)B * N * (Co > K ? Co : K) < (1L << 40), "dvm_linear_f32: too large");
+    launch_linear(x, w, B, N, K, Co, channel_major, bias, res, bn_alpha, bn_beta, slope, y, (hipStream_t)stream);
+    DVM_CHECK_LAUNCH("linear");
+    return DVM_OK;
+}

@@ -25,6 +25,8 @@ SIGNATURES = {
     "dvm_profile_read": (c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),
     "dvm_profile_disable": (c_int, []),
     "dvm_rownorm2_f32": (c_int, [_P, c_int, c_int, _P, _P]),
+    "dvm_linear_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_float, _P, _P]),
+    "dvm_linear_prefix_f32": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_float, _P, _P]),
     "dvm_softcorr_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dvm_softcorr_fwd_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P, _P, _P, _P, c_int, _P,
                                      c_size_t, _P]),

@@ -21,6 +21,36 @@ def mlp(module, z):
     return ops.deformer_mlp(wl, z)
 
 
+class _Conv1x1(torch.autograd.Function):
+    """y[b] = W x[b] (+ bias) over (B,Cin,N): forward on dvm_linear_f32 (the reference's fp32 chain), backward as the
+    two library GEMMs dX = W^T dY, dW = sum_b dY x^T."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return ops.linear(x, w, bias=bias, channel_major=True)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        B = gy.shape[0]
+        w2 = w.reshape(w.shape[0], -1)
+        gx = torch.bmm(w2.t().unsqueeze(0).expand(B, -1, -1), gy) if ctx.needs_input_grad[0] else None
+        gw = torch.bmm(gy, x.transpose(1, 2)).sum(0).view_as(w) if ctx.needs_input_grad[1] else None
+        gb = gy.sum(dim=(0, 2)) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+def conv1x1(x, w, bias=None):
+    """nn.Conv1d(kernel_size=1) over x (B,Cin,N) with weight (Cout,Cin[,1]) -> (B,Cout,N), autograd included."""
+    ops._need_gpu(x, w)
+    if not _needs_grad(x, w, bias):
+        return ops.linear(x, w, bias=bias, channel_major=True)
+    return _Conv1x1.apply(x.contiguous(), w, bias)
+
+
 def pos_encoding(coor, group=None, sync=False):
     """sync=True: normalise with the min/max over every rank's shard of the batch (two scalar all-reduces), so that a
     sharded batch is encoded exactly like the same batch in one process."""
@@ -97,8 +127,7 @@ def sa_attention(x, w_qk, w_v, b_v):
     B, C, N = x.shape
     nq = w_qk.shape[0]
     w = torch.cat([w_qk.reshape(nq, C), w_v.reshape(-1, C)], 0)
-    pv = torch.baddbmm(torch.cat([b_v.new_zeros(nq), b_v]).view(1, -1, 1), w.unsqueeze(0).expand(B, -1, -1), x)
-    pv = pv.transpose(1, 2)
+    pv = conv1x1(x, w, torch.cat([b_v.new_zeros(nq), b_v])).transpose(1, 2)
     return _SACore.apply(pv[..., :nq].contiguous(), pv[..., nq:].contiguous()).transpose(1, 2)
 
 
@@ -129,7 +158,7 @@ def n2p_attention(x, K, wq, wk, wv, heads):
     xt = x.transpose(1, 2).contiguous()
     idx = ops.knn_neg(xt, xt, K)
     w = torch.cat([wq.reshape(C, C), wk.reshape(C, C), wv.reshape(C, C)], 0)
-    qkv = torch.bmm(w.unsqueeze(0).expand(B, -1, -1), x).transpose(1, 2).contiguous()   # (B,N,3C); channel-major GEMM, see sa_attention
+    qkv = conv1x1(x, w).transpose(1, 2).contiguous()   # (B,N,3C); channel-major GEMM, see sa_attention
     return _N2PCore.apply(qkv, idx, heads).transpose(1, 2)
 
 

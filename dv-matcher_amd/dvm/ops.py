@@ -63,6 +63,51 @@ def rownorm2(x):
     return out
 
 
+def linear(x, w, bias=None, res=None, bn=None, slope=1.0, channel_major=False, out=None, prefix=None):
+    """1x1 conv / linear layer with its fused epilogue (dvm_linear_f32): act(bn(x W^T + bias + res)).
+    point-major (default): x (..., K) -> (..., Co); channel_major: x (B,K,N) -> (B,Co,N) (nn.Conv1d's layout).
+    w (Co,K[,1]); bn = (alpha, beta) of the eval-mode BatchNorm (models.model._bn_affine); slope 1 = no activation,
+    0 = ReLU, else LeakyReLU.  The contraction is the reference's single-thread fp32 chain, bit for bit."""
+    _need_gpu(x, w, bias, res)
+    x, w = _f(x), _f(w)
+    Co = w.shape[0]
+    w = w.reshape(Co, -1)
+    K = w.shape[1]
+    Cg = 0
+    if channel_major:
+        B, Kx, N = x.shape
+        shape = (B, Co, N)
+    elif prefix is not None:   # rows [prefix[b] | x[b, n]]: a conv over cat((g broadcast over the points, x), channels)
+        _need_gpu(prefix)
+        B, N, Kx = x.shape
+        prefix = _f(prefix).reshape(B, -1)
+        Cg = prefix.shape[1]
+        Kx += Cg
+        shape = (B, N, Co)
+    else:
+        Kx = x.shape[-1]
+        B, N = 1, x.numel() // Kx
+        shape = x.shape[:-1] + (Co,)
+    if Kx != K:
+        raise DvmError("linear: x has %d input channels, w expects %d" % (Kx, K))
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != tuple(shape) or not out.is_contiguous() or out.dtype != torch.float32:
+        raise DvmError("linear: bad `out`")
+    bias = None if bias is None else _f(bias)
+    res = None if res is None else _f(res)
+    if res is not None and tuple(res.shape) != tuple(shape):
+        raise DvmError("linear: residual shape %s != output shape %s" % (tuple(res.shape), tuple(shape)))
+    al, be = (None, None) if bn is None else (_f(bn[0]), _f(bn[1]))
+    if Cg:
+        check(_lib.load().dvm_linear_prefix_f32(_p(prefix), Cg, _p(x), _p(w), B, N, K, Co, _p(bias), _p(res), _p(al), _p(be),
+                                                float(slope), _p(out), _stream()), "dvm_linear_prefix_f32")
+        return out
+    check(_lib.load().dvm_linear_f32(_p(x), _p(w), B, N, K, Co, 1 if channel_major else 0, _p(bias), _p(res), _p(al), _p(be),
+                                     float(slope), _p(out), _stream()), "dvm_linear_f32")
+    return out
+
+
 def softcorr(f1, f2, alpha, topk=10, variant=0, stats=True):
     """f1 (B,N,d), f2 (B,M,d) -> pi_val (B,N,topk), pi_idx (B,N,topk) int32, row_smax (B,N), row_sum (B,N)."""
     _need_gpu(f1, f2)
@@ -577,9 +622,7 @@ def sa_attention_bwd(p, v, xr, stats, cinv, gxr):
 def sa_attention(x, w_qk, w_v, b_v):
     """x (B,64,N) channel-major like the reference; returns x_r (B,64,N)."""
     xt = x.transpose(1, 2).contiguous()
-    p = torch.nn.functional.linear(xt, w_qk.reshape(w_qk.shape[0], -1))
-    v = torch.nn.functional.linear(xt, w_v.reshape(w_v.shape[0], -1), b_v)
-    return sa_attention_pm(p, v).transpose(1, 2)
+    return sa_attention_pm(linear(xt, w_qk), linear(xt, w_v, bias=b_v)).transpose(1, 2)
 
 
 def n2p_attention_pm(q, kp, vp, idx, heads=4):
@@ -599,7 +642,7 @@ def n2p_attention(x, K, wq, wk, wv, heads=4):
     xt = x.transpose(1, 2).contiguous()
     idx = knn_neg(xt, xt, K)
     w = torch.cat([wq.reshape(C, C), wk.reshape(C, C), wv.reshape(C, C)], 0)
-    qkv = torch.nn.functional.linear(xt, w)
+    qkv = linear(xt, w)
     out = n2p_attention_pm(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], idx, heads)
     return out.transpose(1, 2)
 

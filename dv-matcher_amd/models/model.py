@@ -8,8 +8,8 @@ test.py / deform.py call sequence runs unchanged and its checkpoints load with
 1x1 convolutions / BatchNorm stay on PyTorch-ROCm as BASELINE.json's north_star prescribes.
 """
 import math
-import os
 
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -42,20 +42,12 @@ def farthest_point_sample(xyz, npoint):
 
 
 class PointwiseConv1d(nn.Conv1d):
-    """nn.Conv1d(kernel_size=1) with the reference's parameter names/shapes (weight (Cout,Cin,1)), evaluated
-    as the GEMM it is: W @ x over (B,Cin,N).  Going through the convolution library costs ~10x here (MIOpen
-    has no tuned fp32 1x1-conv1d path on gfx950 and falls back to its naive kernels, fwd and bwd)."""
-
-    accumulate = "f32"   # "f64": accumulate in double (what MIOpen's naive kernels do) — for wiring tests only
+    """nn.Conv1d(kernel_size=1) with the reference's parameter names/shapes (weight (Cout,Cin,1)), evaluated as the GEMM
+    it is on the library's own fp32 matrix-core kernel (dvm_linear_f32: the reference's single-thread fma chain, bit for
+    bit — no BLAS / convolution library in the forward; the two backward GEMMs are library calls)."""
 
     def forward(self, x):
-        if PointwiseConv1d.accumulate == "f64":
-            y = torch.matmul(self.weight[:, :, 0].double(), x.double()).to(x.dtype)
-        elif x.dim() == 3 and os.environ.get("DVM_CONV_BMM", "1") == "1":
-            y = torch.bmm(self.weight[:, :, 0].unsqueeze(0).expand(x.shape[0], -1, -1), x)
-        else:
-            y = torch.matmul(self.weight[:, :, 0], x)
-        return y if self.bias is None else y + self.bias[:, None]
+        return nn_ops.conv1x1(x, self.weight, self.bias)
 
 
 def _folded(owner, tag, sources, build):
@@ -78,48 +70,23 @@ def _bn_sources(bn):
 
 
 def _bn_affine(bn):
-    """Eval-mode BatchNorm as y = x * s + t (per channel)."""
+    """Eval-mode BatchNorm as ATen's CPU kernel evaluates it: y = fma(x, alpha, beta) with alpha = w / sqrt(var + eps)
+    (correctly rounded fp32 sqrt and divide), beta = fma(-mean, alpha, b).  The 4 x C numbers are folded on the host
+    (numpy's fp32 sqrt / divide are IEEE; device rsqrt is not) once per parameter version."""
     def build():
-        s = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
-        return s, bn.bias - bn.running_mean * s
+        w, b, m, v = (t.detach().cpu().numpy().astype(np.float32) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+        alpha = (np.float32(1) / np.sqrt(v + np.float32(bn.eps))) * w
+        beta = (b.astype(np.float64) - m.astype(np.float64) * alpha.astype(np.float64)).astype(np.float32)
+        dev = bn.weight.device
+        return torch.from_numpy(alpha).to(dev), torch.from_numpy(beta).to(dev)
     return _folded(bn, "affine", _bn_sources(bn), build)
 
 
-def _conv_bn_pm(conv, bn, xt, act=None):
-    """Inference, point-major: 1x1 conv with the eval-mode BatchNorm folded into its weights — ONE (B*N) x Cin x Cout
-    GEMM with bias — then the activation.  xt (B,N,Cin) -> (B,N,Cout)."""
-    def build():
-        s, t = _bn_affine(bn)
-        return (conv.weight[:, :, 0] * s[:, None]).contiguous(), (t if conv.bias is None else conv.bias * s + t)
-    w, b = _folded(conv, "conv_bn", (conv.weight, conv.bias) + _bn_sources(bn), build)
-    y = F.linear(xt, w, b)
-    return y if act is None else act(y)
-
-
-def _conv_bn_act_max_pm(conv, bn, xt, act):
-    """max over the points of act(conv+BN(xt)) -> (B,1,Cout).  `act` is monotone and the bias is per channel, so the
-    maximum commutes with both: the GEMM is taken channel-major ((B,Cout,N): the reduction runs over the contiguous
-    axis) and bias + activation touch B*Cout numbers instead of B*N*Cout."""
-    def build():
-        s, t = _bn_affine(bn)
-        return (conv.weight[:, :, 0] * s[:, None]).contiguous(), (t if conv.bias is None else conv.bias * s + t)
-    w, b = _folded(conv, "conv_bn", (conv.weight, conv.bias) + _bn_sources(bn), build)
-    return act(torch.matmul(w, xt.transpose(1, 2)).amax(dim=-1) + b).unsqueeze(1)
-
-
-def _conv_bn_glob_pm(conv, bn, glob, xt, act):
-    """conv+BN over cat((glob broadcast over the points, xt), channels) without building the concatenation: the
-    per-shape vector `glob` (B,1,Cg) only contributes a per-shape bias W[:, :Cg] @ glob."""
-    Cg = glob.shape[-1]
-
-    def build():
-        s, t = _bn_affine(bn)
-        w = conv.weight[:, :, 0] * s[:, None]
-        return w[:, :Cg].contiguous(), w[:, Cg:].contiguous(), (t if conv.bias is None else conv.bias * s + t)
-    wg, wx, b = _folded(conv, "conv_bn_glob%d" % Cg, (conv.weight, conv.bias) + _bn_sources(bn), build)
-    y = F.linear(xt, wx)
-    y += F.linear(glob, wg, b)
-    return act(y)
+def _conv_bn_pm(conv, bn, xt, slope=0.2, res=None, prefix=None):
+    """Inference, point-major: 1x1 conv -> [+ res] -> eval-mode BatchNorm -> (Leaky)ReLU in ONE launch (dvm_linear_f32:
+    the reference's single-thread fp32 chain on the matrix cores, epilogue fused).  xt (B,N,Cin) -> (B,N,Cout); with
+    `prefix` (B,1,Cg) the conv runs over cat((prefix broadcast over the points, xt), channels) without building it."""
+    return ops.linear(xt, conv.weight, bias=conv.bias, res=res, bn=_bn_affine(bn), slope=slope, prefix=prefix)
 
 
 # ------------------------------------------------------------------ attention blocks
@@ -146,10 +113,10 @@ class SA_Layer(nn.Module):
 
     def infer_pm(self, xt):
         """Inference on point-major activations (B,N,64): no transposes, BatchNorm folded into trans_conv."""
-        p = F.linear(xt, self.k_conv.weight[:, :, 0])
-        v = F.linear(xt, self.v_conv.weight[:, :, 0], self.v_conv.bias)
+        p = ops.linear(xt, self.k_conv.weight)
+        v = ops.linear(xt, self.v_conv.weight, bias=self.v_conv.bias)
         x_r = ops.sa_attention_pm(p, v)
-        return xt + _conv_bn_pm(self.trans_conv, self.after_norm, xt - x_r, self.act)
+        return xt + _conv_bn_pm(self.trans_conv, self.after_norm, xt - x_r, slope=0.0)
 
 
 class _N2P(nn.Module):
@@ -182,12 +149,11 @@ class _N2P(nn.Module):
         idx = ops.knn_neg(xt, xt, self.K)
         w = _folded(self, "qkv", (self.q_conv.weight, self.k_conv.weight, self.v_conv.weight), lambda: torch.cat(
             [self.q_conv.weight.reshape(C, C), self.k_conv.weight.reshape(C, C), self.v_conv.weight.reshape(C, C)], 0))
-        att = ops.n2p_core_fwd(F.linear(xt, w), idx, self.heads)[0]
+        att = ops.n2p_core_fwd(ops.linear(xt, w), idx, self.heads)[0]
         s1, t1 = _bn_affine(self.bn1)
         xt = torch.addcmul(t1, xt + att, s1)
-        ff = F.linear(self.ff[1](F.linear(xt, self.ff[0].weight[:, :, 0])), self.ff[2].weight[:, :, 0])
-        s2, t2 = _bn_affine(self.bn2)
-        return torch.addcmul(t2, xt + ff, s2)
+        h = ops.linear(xt, self.ff[0].weight, slope=self.ff[1].negative_slope)
+        return _conv_bn_pm(self.ff[2], self.bn2, h, slope=1.0, res=xt)     # bn2(x + ff(x)), one launch
 
     @staticmethod
     def split_heads(x, heads):
@@ -369,8 +335,7 @@ class Uni3FC(nn.Module, _VisualProjection):
         reference's (B,C,N) layout: there MIOpen's BatchNorm kernels want it and the step is GEMM/launch-bound.)"""
         B, _, N = x.shape
         with torch.no_grad():
-            lrelu = lambda y: F.leaky_relu(y, 0.2)  # noqa: E731
-            blk = lambda seq, xt: _conv_bn_pm(seq[0], seq[1], xt, lrelu)  # noqa: E731
+            blk = lambda seq, xt, **kw: _conv_bn_pm(seq[0], seq[1], xt, seq[2].negative_slope, **kw)  # noqa: E731
             f = blk(self.conv, dino_feat)
             tmp = blk(self.conv0, f + self.pos_encoding_sin_wave(x).transpose(1, 2))
             x1, x1g = self.n2p_attention1.infer_pm(tmp), self.sa1.infer_pm(tmp)
@@ -379,10 +344,9 @@ class Uni3FC(nn.Module, _VisualProjection):
             x4, x4g = self.n2p_attention4.infer_pm(x3), self.sa4.infer_pm(x3g)
             loc = torch.cat((x1, x2, x3, x4), dim=-1)
             glo = torch.cat((x1g, x2g, x3g, x4g), dim=-1)
-            lmax = _conv_bn_act_max_pm(self.conv1[0], self.conv1[1], loc, lrelu)
-            gmax = _conv_bn_act_max_pm(self.conv2[0], self.conv2[1], glo, lrelu)
-            y = torch.cat((_conv_bn_glob_pm(self.conv3[0], self.conv3[1], lmax, loc, lrelu),
-                           _conv_bn_glob_pm(self.conv4[0], self.conv4[1], gmax, glo, lrelu)), dim=-1)
+            lmax = blk(self.conv1, loc).amax(dim=1, keepdim=True)
+            gmax = blk(self.conv2, glo).amax(dim=1, keepdim=True)
+            y = torch.cat((blk(self.conv3, loc, prefix=lmax), blk(self.conv4, glo, prefix=gmax)), dim=-1)
             y1 = blk(self.conv5, y)
             y2 = self.n2p_attention5.infer_pm(y1)
             y3 = self.n2p_attention6.infer_pm(y2)
@@ -395,8 +359,11 @@ class Uni3FC(nn.Module, _VisualProjection):
         if dino_feat is None:
             dino_feat = self.visual_features(x, upsampler)
         B, _, N = x.shape
-        if not self.training and not (torch.is_grad_enabled() and (dino_feat.requires_grad or x.requires_grad)) \
-                and PointwiseConv1d.accumulate == "f32":
+        # the no-autograd path: eval mode AND nothing that could want a gradient (eval-mode fine-tuning with
+        # frozen BatchNorm statistics must still reach the parameters)
+        wants_grad = torch.is_grad_enabled() and (dino_feat.requires_grad or x.requires_grad or
+                                                  any(p.requires_grad for p in self.parameters()))
+        if not self.training and not wants_grad:
             return self._forward_infer(x, dino_feat)
         # conv -> BatchNorm -> LeakyReLU blocks: the GEMM, then ONE fused statistics + normalise + activation pass
         blk = lambda seq, t: nn_ops.bn_act(seq[1], seq[0](t), slope=seq[2].negative_slope)  # noqa: E731

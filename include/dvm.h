@@ -54,6 +54,29 @@ int dvm_profile_disable(void);
  * x [rows,K] -> out [rows]. */
 int dvm_rownorm2_f32(const float *x, int rows, int K, float *out, void *stream);
 
+/* 1x1 convolution / linear layer with its epilogue: nn.Conv1d(kernel_size=1) (+bias) -> [+ residual] ->
+ * eval-mode nn.BatchNorm1d -> (Leaky)ReLU of LG-Net (models/model.py:506-529 conv..conv6 blocks, the ff / q / k / v
+ * projections of N2PAttention[_DIM] 325-395, SA_Layer's q/k/v/trans_conv 97-123).
+ * The contraction is the k-ordered fp32 fma chain acc = fma(w[co][k], x[k], acc) on v_mfma_f32_32x32x2_f32, restarted
+ * and summed per K-block exactly like the CPU sgemm behind the reference's Conv1d / matmul (blocks of 384 while more
+ * than 768 remain, then one block or two halves): bit-identical to the reference evaluated by one CPU thread,
+ * independent of B, N and of the tile configuration.  Then, in this order:
+ *   y += bias[co];  y += res;  y = fma(y, bn_alpha[co], bn_beta[co]);  y = y > 0 ? y : y * slope
+ * (each step skipped when its pointer is NULL / slope == 1; slope 0 = ReLU).
+ *   channel_major == 0: x [B*N, K], y / res [B*N, Co]          (inference, activations point-major)
+ *   channel_major == 1: x [B, K, N], y / res [B, Co, N]        (the reference's Conv1d layout, training forward)
+ * w [Co, K]; K <= 8448 (16-byte aligned rows, K % 4 == 0, take the vector-load path). */
+int dvm_linear_f32(const float *x, const float *w, int B, int N, int K, int Co, int channel_major, const float *bias,
+                   const float *res, const float *bn_alpha, const float *bn_beta, float slope, float *y, void *stream);
+
+/* The same layer (point-major) on rows [xg[b] (Cg) | x[b,n] (K - Cg)]: a 1x1 conv over torch.cat((g.repeat(1,1,N), x), 1)
+ * without building the concatenation — conv3 / conv4 of Uni3FC.forward (models/model.py:735-747: the max-pooled
+ * 512-vector of a shape in front of its 256 per-point channels), same K-blocked chain over the K = Cg + (K - Cg)
+ * concatenated channels.  xg [B, Cg], x [B*N, K - Cg], w [Co, K], y / res [B*N, Co]; Cg % 4 == 0. */
+int dvm_linear_prefix_f32(const float *xg, int Cg, const float *x, const float *w, int B, int N, int K, int Co,
+                          const float *bias, const float *res, const float *bn_alpha, const float *bn_beta, float slope,
+                          float *y, void *stream);
+
 /* knnsearch_t_grad + topk_pi (+ the argmax map)  —  models/loss.py:110-114,
  * 1339-1347, 1404-1407.   D = cdist(f1,f2) (matmul form, bit-identical squared
  * distances); P = softmax(D*neg_alpha) over M; keep the `topk` largest of each

@@ -218,3 +218,24 @@ def dot_chain(a, b):
     out = np.empty((a.shape[0], b.shape[0]), np.float32)
     lib().dvo_dot_chain(_p(a), _p(b), a.shape[0], b.shape[0], a.shape[1], _p(out))
     return out
+
+
+def linear(x, w, bias=None, res=None, alpha=None, beta=None, slope=1.0):
+    """Point-major 1x1 conv / linear layer + epilogue: x (M,K), w (Co,K) -> (M,Co) (dvo_linear)."""
+    x, w = _f(x), _f(w)
+    M, K = x.shape
+    Co = w.shape[0]
+    opt = [None if t is None else _f(t) for t in (bias, res, alpha, beta)]
+    out = np.empty((M, Co), np.float32)
+    lib().dvo_linear(_p(x), _p(w), M, K, Co, *[_p(t) for t in opt], ctypes.c_float(slope), _p(out))
+    return out
+
+
+def bn_eval_affine(weight, bias, mean, var, eps):
+    """Eval-mode BatchNorm as ATen's CPU kernel folds it: alpha = w / sqrt(var + eps) with a correctly rounded fp32
+    sqrt and divide, beta = fma(-mean, alpha, b); applied as y = fma(x, alpha, beta)."""
+    w, b, m, v = (np.asarray(t, np.float32) for t in (weight, bias, mean, var))
+    inv = np.float32(1) / np.sqrt(v + np.float32(eps))
+    alpha = (inv * w).astype(np.float32)
+    beta = (b.astype(np.float64) - m.astype(np.float64) * alpha.astype(np.float64)).astype(np.float32)
+    return alpha, beta

@@ -55,6 +55,61 @@ def n2p_attention(x, idx, wq, wk, wv, heads=4):
     return (att @ v).squeeze(3).permute(0, 1, 3, 2).reshape(B, C, N)
 
 
+def _bn(sd, name, x, train, eps=1e-5):
+    if train:
+        return F.batch_norm(x, None, None, sd[name + ".weight"], sd[name + ".bias"], True, 0.1, eps)
+    return F.batch_norm(x, sd[name + ".running_mean"], sd[name + ".running_var"], sd[name + ".weight"], sd[name + ".bias"],
+                        False, 0.1, eps)
+
+
+def sa_layer(sd, name, x, train):
+    """SA_Layer.forward (models/model.py:113-123) from a state_dict."""
+    xr = sa_attention(x, sd[name + ".k_conv.weight"], sd[name + ".v_conv.weight"], sd[name + ".v_conv.bias"])
+    t = F.conv1d(x - xr, sd[name + ".trans_conv.weight"], sd[name + ".trans_conv.bias"])
+    return x + torch.relu(_bn(sd, name + ".after_norm", t, train))
+
+
+def n2p_block(sd, name, x, train, K=40, idx=None, log=None):
+    """N2PAttention[_DIM].forward (models/model.py:339-354 / 375-390) from a state_dict; `idx` forces the neighbour
+    sets (teacher forcing), `log` receives the sets used."""
+    if idx is None:
+        xt = x.transpose(1, 2)
+        idx = knn_scores(xt, xt).topk(K, dim=-1)[1]
+    if log is not None:
+        log.append(idx)
+    att = n2p_attention(x, idx, sd[name + ".q_conv.weight"], sd[name + ".k_conv.weight"], sd[name + ".v_conv.weight"])
+    x = _bn(sd, name + ".bn1", x + att, train)
+    ff = F.conv1d(F.leaky_relu(F.conv1d(x, sd[name + ".ff.0.weight"]), 0.2), sd[name + ".ff.2.weight"])
+    return _bn(sd, name + ".bn2", x + ff, train)
+
+
+def uni3fc(sd, x, dino, train=False, knn_idx=None, log=None):
+    """Uni3FC.forward with dino_feat given (models/model.py:711-761) from a state_dict, in plain torch ops and the
+    reference's (B,C,N) layout.  x (B,3,N), dino (B,N,1152) -> (feat (B,N,128), cfeats (B,N,64)).
+    knn_idx: optional sequence of 7 (B,N,K) index tensors used instead of the network's own kNN searches."""
+    take = (lambda i: None) if knn_idx is None else (lambda i: torch.as_tensor(knn_idx[i]).long())
+
+    def blk(n, t):
+        return F.leaky_relu(_bn(sd, "bn" + n, F.conv1d(t, sd["conv%s.0.weight" % n]), train), 0.2)
+
+    f = blk("", dino.permute(0, 2, 1))
+    tmp = blk("0", f + pos_encoding(x))
+    xs, gs = [tmp], [tmp]
+    for i in range(4):
+        xs.append(n2p_block(sd, "n2p_attention%d" % (i + 1), xs[-1], train, idx=take(i), log=log))
+        gs.append(sa_layer(sd, "sa%d" % (i + 1), gs[-1], train))
+    loc, glo = torch.cat(xs[1:], 1), torch.cat(gs[1:], 1)
+    N = x.shape[2]
+    lmax = blk("1", loc).max(dim=-1, keepdim=True)[0].repeat(1, 1, N)
+    gmax = blk("2", glo).max(dim=-1, keepdim=True)[0].repeat(1, 1, N)
+    y = torch.cat((blk("3", torch.cat((lmax, loc), 1)), blk("4", torch.cat((gmax, glo), 1))), 1)
+    ys = [blk("5", y)]
+    for i in range(3):
+        ys.append(n2p_block(sd, "n2p_attention%d" % (i + 5), ys[-1], train, idx=take(4 + i), log=log))
+    out = blk("6", torch.cat(ys, 1))
+    return out.transpose(2, 1).contiguous(), tmp.permute(0, 2, 1)
+
+
 def dist_loss_term(feat, dist, anchors, k):
     """(B,N,C), (B,N,N), (nA,) -> (B,)   (models/loss.py:1361-1394)."""
     f1 = feat[:, anchors]

@@ -259,9 +259,9 @@ def main():
             group_loss(rl, rm)
         elif gname == "loss_unit":
             group_loss(rl, rm, only_unit=True)
-        elif gname == "backbone":
+        elif gname == "backbone" or gname.startswith("backbone:"):   # backbone:<fixture>,<fixture> regenerates a subset
             import make_fixtures_backbone
-            make_fixtures_backbone.run(rm, save)
+            make_fixtures_backbone.run(rm, save, only=gname.split(":", 1)[1].split(",") if ":" in gname else None)
         else:
             raise SystemExit("unknown group " + gname)
 

@@ -109,31 +109,6 @@ def test_n2p_block(ops, golden, name, C, mode):
     np.testing.assert_allclose(host(out), g["out"], rtol=0, atol=1e-4)
 
 
-@pytest.mark.parametrize("mode", ["eval", "train"])
-@pytest.mark.parametrize("accum", ["f64", "f32"])
-def test_uni3fc(ops, golden, mode, accum, monkeypatch):
-    import models.model as mm
-    g = golden("bb_uni3fc_" + mode)
-    net = reinit(mm.Uni3FC(k=40), salt=4).cuda()
-    getattr(net, mode)()
-    monkeypatch.setattr(mm.PointwiseConv1d, "accumulate", accum)
-    with torch.no_grad():
-        feat, cf = net(dev(g["xyz"]), dev(g["dino"]).float(), None)
-    assert feat.shape == g["feat"].shape and cf.shape == g["cfeats"].shape
-    np.testing.assert_allclose(host(cf), g["cfeats"], rtol=0, atol=1e-4)
-    err = np.abs(host(feat) - g["feat"])
-    # kNN neighbourhoods are discrete: an fp32-level near-tie flip (GEMM rounding differs between the CPU
-    # reference and rocBLAS) swaps one of a point's 40 neighbours and changes that point's feature visibly.
-    # A flip then propagates (that point is a neighbour of others in the 6 later N2P layers), so the bound on
-    # affected points is loose (measured: 0 with MIOpen's double-accumulating naive conv, 18/256 with rocBLAS
-    # fp32 GEMMs); the wiring check is the tight median over ALL entries — a mis-wired layer gives O(1).
-    row_err = err.reshape(-1, err.shape[-1]).max(axis=1)
-    flipped = row_err > 2e-3
-    # (the same 18/256 points flip with fp32 and with double accumulation: the near-tie sits in the CPU
-    # reference's own rounding, not in ours)
-    assert np.median(err) < 1e-4 and flipped.mean() <= 0.15, (np.median(err), int(flipped.sum()), err.max())
-
-
 def test_deformer_reference_signature(ops, golden):
     """Deformer.forward with the reference's own (B,N,k,128) / dense-Pi arguments."""
     import models.loss as ml
@@ -229,52 +204,6 @@ def test_criterion_backward_matches_reference(golden, name, cls, kw):
     close(f2.grad, g["g_feat2"], "feat2")
     for k, p in d.named_parameters():
         close(p.grad, g["g_" + k.replace(".", "__")], k)
-
-
-def test_full_training_step_matches_reference(golden, monkeypatch):
-    """Uni3FC x2 -> criterion -> backward, BN in train mode, against the reference's own
-    step (losses, features, gradients of backbone and Deformer parameters)."""
-    import models.loss as ml
-    import models.model as mm
-    g = golden("bb_trainstep")
-    w = golden("deformer_scape_r_weights")
-    # gradient parity is a wiring check: evaluate the 1x1 convs with double accumulation so that no kNN
-    # near-tie flips relative to the CPU reference (test_uni3fc covers the fp32-GEMM production path)
-    monkeypatch.setattr(mm.PointwiseConv1d, "accumulate", "f64")
-    net = reinit(mm.Uni3FC(k=40), salt=5).cuda().train()
-    d = mm.Deformer(10)
-    d.load_state_dict({k.replace("__", "."): torch.from_numpy(v) for k, v in w.items()})
-    d = d.cuda().train()
-    crit = ml.GraphDeformLoss_Neural(k_deform=10, w_dist=0.02, w_map=0.005, k_dist=40, N_dist=64, partial=False, w_deform=0.5,
-                                     w_img=0, w_rank=0, w_self_rec=0.5, w_cd=0.1, w_arap=0.01, save_name="t")
-    v1, v2 = dev(g["verts1"]), dev(g["verts2"])
-    random.seed(9001)
-    torch.manual_seed(9002)
-    f1, _ = net(v1.permute(0, 2, 1), dev(g["dino1"]).float(), None)
-    f2, _ = net(v2.permute(0, 2, 1), dev(g["dino2"]).float(), None)
-    e1 = np.abs(host(f1) - g["feat1"])
-    assert np.median(e1) < 5e-5 and np.quantile(e1, 0.999) < 5e-3, (np.median(e1), e1.max())
-    out = crit(f1, f2, torch.cdist(v1, v1), torch.cdist(v2, v2), v1, v2, np.float64(g["alpha"]), d)
-    np.testing.assert_allclose([float(o.detach()) for o in out], g["losses"], rtol=2e-3)
-    out[0].backward()
-    named = dict(net.named_parameters())
-    no_grad = sum(1 for p in net.parameters() if p.grad is None)
-    assert no_grad == int(g["n_params_without_grad"])  # the 12 parameters the reference never trains
-    gn = torch.sqrt(sum((p.grad ** 2).sum() for p in net.parameters() if p.grad is not None))
-    np.testing.assert_allclose(float(gn), float(g["gnorm_backbone"]), rtol=2e-2)
-    for key in g:
-        if key.startswith("g_"):
-            p = named[key[2:].replace("__", ".")]
-            ref = g[key]
-            if np.linalg.norm(ref) < 1e-4:  # e.g. a conv bias in front of train-mode BN: exactly 0 in exact arithmetic
-                assert float(p.grad.norm()) < 1e-3, key
-                continue
-            rel = np.linalg.norm(host(p.grad) - ref) / (np.linalg.norm(ref) + 1e-30)
-            assert rel < 5e-2, (key, rel)
-    for k, p in d.named_parameters():
-        ref = g["gd_" + k.replace(".", "__")]
-        rel = np.linalg.norm(host(p.grad) - ref) / (np.linalg.norm(ref) + 1e-30)
-        assert rel < 5e-2, (k, rel)
 
 
 def test_dist_loss_vs_torch(ops):

@@ -135,3 +135,51 @@ def test_aten_sum_order():
     for K in (1, 3, 5, 7, 8, 9, 31, 64, 100, 128, 130, 257, 1000, 1152, 2048, 5000):
         x = torch.randn(257, K, generator=g)
         assert np.array_equal(O.rownorm2(x.numpy()), x.pow(2).sum(-1).numpy()), K
+
+
+def _linear_chain_cases(g):
+    for i in range(int(g["n"])):
+        yield (g["x%d" % i], g["w%d" % i][:, :, 0], g.get("b%d" % i), g["bn%d" % i], g["y%d" % i], g["z%d" % i])
+
+
+def test_linear_chain_pinned_to_reference_conv(golden):
+    """dvo_linear (the checker of dvm_linear_f32) against nn.Conv1d(k=1) [+ eval BatchNorm + LeakyReLU] outputs recorded
+    from torch evaluated by ONE thread in the build container, bit for bit, at every reduction length of LG-Net: a
+    K-blocked fma chain (blocks of 384 while more than 768 remain, then one block or two halves), bias after the chain,
+    BatchNorm as fma(y, alpha, beta)."""
+    g = golden("linear_chain")
+    for x, w, b, bn, y, z in _linear_chain_cases(g):
+        a, be = O.bn_eval_affine(bn[0], bn[1], bn[2], bn[3], 1e-5)
+        for bb in range(x.shape[0]):
+            xt = np.ascontiguousarray(x[bb].T)
+            assert np.array_equal(O.linear(xt, w, bias=b).T, y[bb]), w.shape
+            assert np.array_equal(O.linear(xt, w, bias=b, alpha=a, beta=be, slope=0.2).T, z[bb]), w.shape
+
+
+def test_linear_chain_vs_live_torch():
+    """The same rule against torch.matmul on THIS host for many K (MKL's sgemm: identical on every x86 host we saw);
+    Conv1d goes through oneDNN whose kernels vary with the CPU: compared only where this host's single-thread Conv1d
+    equals its own matmul.  Also shows that the multi-threaded Conv1d is a different function."""
+    import torch
+    nt = torch.get_num_threads()
+    g = torch.Generator().manual_seed(3)
+    try:
+        torch.set_num_threads(1)
+        for K in [4, 20, 64, 128, 256, 384, 385, 400, 512, 700, 768, 769, 772, 1000, 1152, 1156, 2048, 2304]:
+            W = torch.randn(40, K, generator=g) / K ** 0.5
+            x = torch.randn(K, 70, generator=g)
+            mm = torch.matmul(W, x)
+            if not np.array_equal(O.linear(x.t().contiguous().numpy(), W.numpy()).T, mm.numpy()):
+                pytest.skip("this host's sgemm blocks K differently from the build container's (K=%d)" % K)
+            conv = torch.nn.functional.conv1d(x[None], W[:, :, None])[0]
+            if torch.equal(conv, mm):
+                assert np.array_equal(O.linear(x.t().contiguous().numpy(), W.numpy()).T, conv.numpy())
+        conv = torch.nn.Conv1d(1152, 384, 1, bias=False)
+        x = torch.randn(1, 1152, 2048, generator=g)
+        with torch.no_grad():
+            y1 = conv(x)
+            torch.set_num_threads(8)
+            y8 = conv(x)
+        print("1-thread vs 8-thread Conv1d identical on this host:", torch.equal(y1, y8))
+    finally:
+        torch.set_num_threads(nt)
