@@ -17,6 +17,15 @@ namespace dvm {
 void set_error(const char *fmt, ...);
 void prof_begin(hipStream_t s);  // dvm_api.cpp: optional event bracket around K1 launches
 void prof_end(hipStream_t s);
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (current device, kernel) — dvm_api.cpp
+void ensure_dyn_lds(const void *kernel, int bytes);
+// helper streams / events of dvm_pair_fwd_f32 for one (device, caller stream), made by dvm_pair_init — dvm_api.cpp
+struct PairCtx {
+    int device = 0;
+    hipStream_t side = nullptr, side2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
+};
+PairCtx *pair_ctx_find(hipStream_t caller);
 
 #define DVM_REQUIRE(cond, ...)            \
     do {                                  \

@@ -439,11 +439,7 @@ void launch_mlp_rows(const float *z, int rows, const float *W0, const float *b0,
     pack(W1, 256, 512, 8, 256, Wp1);
     pack(W2, 128, 256, 4, 128, Wp2);
     pack(W3, 9, 128, 1, 64, Wp3);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)mlp_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_LDS_BYTES);
-        attr_set = true;
-    }
+    ensure_dyn_lds((const void *)mlp_mfma_kernel, (int)ML_LDS_BYTES);
     hipLaunchKernelGGL(mlp_mfma_kernel, dim3((rows + ML_NODES - 1) / ML_NODES), dim3(ML_THREADS), ML_LDS_BYTES, s, z, rows, Wp0, b0,
                        Wp1, b1, Wp2, b2, Wp3, b3, out);
 }

@@ -56,11 +56,7 @@ DVM_EXPORT int dvm_graph_geodesics_f64(const int32_t *nbr, const double *w, int 
     DVM_REQUIRE(N >= 1 && K >= 1, "dvm_graph_geodesics_f64: empty graph (N=%d K=%d)", N, K);
     DVM_REQUIRE((size_t)N * sizeof(double) <= 150 * 1024, "dvm_graph_geodesics_f64: N=%d exceeds the %d nodes that fit in LDS", N,
                 150 * 1024 / 8);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)graph_sssp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-        attr_set = true;
-    }
+    ensure_dyn_lds((const void *)graph_sssp_kernel, 152 * 1024);
     hipLaunchKernelGGL(graph_sssp_kernel, dim3(N), dim3(256), (size_t)N * sizeof(double), (hipStream_t)stream, nbr, w, N, K, D);
     DVM_CHECK_LAUNCH("graph_geodesics");
     return DVM_OK;

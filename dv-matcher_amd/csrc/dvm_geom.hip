@@ -611,11 +611,7 @@ int launch_argmin_f16(const float *f1, const float *f2, int B, int N, int M, int
 
 static int argmin_all_columns(const float *f1, const float *f2, int B, int N, int M, int d, int32_t *T, float *dmin, hipStream_t s) {
     size_t lds = (size_t)AM_KT * d * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)argmin_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        attr_set = true;
-    }
+    ensure_dyn_lds((const void *)argmin_exact_kernel, 65536);
     hipLaunchKernelGGL(argmin_exact_kernel, dim3((N + 127) / 128, B), dim3(128), lds, s, f1, f2, N, M, d, T, dmin);
     DVM_CHECK_LAUNCH("argmin_exact");
     return DVM_OK;

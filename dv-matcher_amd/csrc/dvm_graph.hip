@@ -345,11 +345,7 @@ __global__ __launch_bounds__(256) void dg_arap_kernel(const float *__restrict__ 
 
 template <int PPT, int T>
 static void launch_fps_t(const float *xyz, int B, int N, int npoint, const int32_t *start, int32_t *out, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)fps_kernel<PPT, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    ensure_dyn_lds((const void *)fps_kernel<PPT, T>, 160 * 1024);
     const size_t lds = (size_t)((N * 3 + 3) & ~3) * sizeof(float) + 2 * (T / 64) * sizeof(ArgMax);
     hipLaunchKernelGGL((fps_kernel<PPT, T>), dim3(B), dim3(T), lds, s, xyz, N, npoint, start, out);
 }

@@ -190,11 +190,7 @@ void launch_mlp_rows_bf16(const float *z, int rows, const float *W0, const float
     pack(W1, 256, 512, 8, MB_K1 / 16, Wp1);
     pack(W2, 128, 256, 4, MB_K2 / 16, Wp2);
     pack(W3, 9, 128, 1, MB_K3 / 16, Wp3);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)mlp_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MB_LDS_BYTES);
-        attr_set = true;
-    }
+    ensure_dyn_lds((const void *)mlp_bf16x3_kernel, (int)MB_LDS_BYTES);
     hipLaunchKernelGGL(mlp_bf16x3_kernel, dim3((rows + MB_NODES - 1) / MB_NODES), dim3(MB_THREADS), MB_LDS_BYTES, s, z, rows, Wp0,
                        b0, Wp1, b1, Wp2, b2, Wp3, b3, out, gate);
 }

@@ -290,22 +290,16 @@ DVM_EXPORT int dvm_pair_fwd_f32(const float *feat1, const float *feat2, const fl
     // ---- per-cloud geometry: graph + xyz kNN.  It depends on the coordinates only and is latency-bound (FPS: N/2
     // sequential steps per cloud), the soft correspondence on the features only and is ALU-bound: the two chains run
     // concurrently, the geometry on a helper stream forked from / joined back into the caller's stream by events.
-    static hipStream_t side = nullptr;
-    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    const bool overlap = g_pair_overlap != 0;
-    if (overlap && !side) {
-        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) {
-            set_error("dvm_pair_fwd_f32: cannot create the helper stream");
-            return DVM_ELAUNCH;
-        }
-    }
+    // The helper streams and events belong to a context made by dvm_pair_init for (current device, caller stream):
+    // nothing is created here, two caller streams / host threads / devices never share an event, and without a context
+    // (or with dvm_pair_set_overlap(0)) everything runs on the caller's stream.
+    PairCtx *cx = g_pair_overlap != 0 ? pair_ctx_find(s) : nullptr;
+    const bool overlap = cx != nullptr;
     const hipStream_t caller = s;
     if (overlap) {
-        (void)hipEventRecord(ev_fork, caller);
-        (void)hipStreamWaitEvent(side, ev_fork, 0);
-        s = side;
+        (void)hipEventRecord(cx->ev_fork, caller);
+        (void)hipStreamWaitEvent(cx->side, cx->ev_fork, 0);
+        s = cx->side;
     }
     if (both) {
         (void)hipMemcpyAsync(w.vcat, verts1, (size_t)B * N * 3 * sizeof(float), hipMemcpyDeviceToDevice, s);
@@ -318,41 +312,39 @@ DVM_EXPORT int dvm_pair_fwd_f32(const float *feat1, const float *feat2, const fl
     } else {
         // N != M (or sizes that do not tile the arena): one chain per cloud set.  FPS is a one-workgroup-per-cloud
         // sequential kernel, so the two chains go on two helper streams and overlap each other as well.
-        static hipStream_t side2 = nullptr;
-        static hipEvent_t ev_join2 = nullptr;
-        if (overlap && !side2 &&
-            (hipStreamCreateWithFlags(&side2, hipStreamNonBlocking) != hipSuccess ||
-             hipEventCreateWithFlags(&ev_join2, hipEventDisableTiming) != hipSuccess)) {
-            set_error("dvm_pair_fwd_f32: cannot create the helper stream");
-            return DVM_ELAUNCH;
-        }
-        if (overlap) (void)hipStreamWaitEvent(side2, ev_fork, 0);
+        if (overlap) (void)hipStreamWaitEvent(cx->side2, cx->ev_fork, 0);
         for (int sd = 0; sd < 2; ++sd) {
-            const hipStream_t cs = (overlap && sd == 1) ? side2 : s;
+            const hipStream_t cs = (overlap && sd == 1) ? cx->side2 : s;
             launch_dg_build(verts[sd], B, P[sd], start[sd], w.nodes[sd], w.ring[sd], w.infl[sd], w.dists[sd], w.weights[sd],
                             nullptr, w.nnd[sd], w.gv[sd], w.gn[sd], true, cs);
             launch_grid_knn_self(w.gv[sd], B, 10, w.idxk[sd], cs);
         }
         if (overlap) {
-            (void)hipEventRecord(ev_join2, side2);
-            (void)hipStreamWaitEvent(side, ev_join2, 0);  // ev_join (below) then covers both chains
+            (void)hipEventRecord(cx->ev_join2, cx->side2);
+            (void)hipStreamWaitEvent(cx->side, cx->ev_join2, 0);  // ev_join (below) then covers both chains
         }
     }
     if (overlap) {
-        (void)hipEventRecord(ev_join, side);
+        (void)hipEventRecord(cx->ev_join, cx->side);
         s = caller;
     }
+    // from here to the join the caller's stream must wait for the helper streams on EVERY exit path: the caller may reuse
+    // the workspace as soon as this function returns
+    auto fail = [&](int code) {
+        if (overlap) (void)hipStreamWaitEvent(caller, cx->ev_join, 0);
+        return code;
+    };
     // ---- soft correspondence, both directions in one launch
     rc = launch_softcorr_pair(feat1, feat2, w.nrm[0], w.nrm[1], B, N, M, neg_alpha, w.pval[0], w.pidx[0], w.pval[1], w.pidx[1], w.k1ws,
                               w.k1ws_bytes, s);
-    if (rc != DVM_OK) return rc;
+    if (rc != DVM_OK) return fail(rc);
     hipLaunchKernelGGL(take_col0_kernel, dim3((B * N + 255) / 256), dim3(256), 0, s, w.pidx[0], B * N, 10, T12);
     hipLaunchKernelGGL(take_col0_kernel, dim3((B * M + 255) / 256), dim3(256), 0, s, w.pidx[1], B * M, 10, T21);
     rc = dvm_softcorr_apply_f32(w.pval[0], w.pidx[0], verts2, B, N, M, 10, 3, verts12, s);
-    if (rc != DVM_OK) return rc;
+    if (rc != DVM_OK) return fail(rc);
     rc = dvm_softcorr_apply_f32(w.pval[1], w.pidx[1], verts1, B, M, N, 10, 3, verts21, s);
-    if (rc != DVM_OK) return rc;
-    if (overlap) (void)hipStreamWaitEvent(caller, ev_join, 0);  // join: everything below needs the graphs / kNN
+    if (rc != DVM_OK) return fail(rc);
+    if (overlap) (void)hipStreamWaitEvent(caller, cx->ev_join, 0);  // join: everything below needs the graphs / kNN
     // ---- Deformer: pooled features once per cloud, z for both directions, one MLP launch
     launch_pool_all(feat1, w.idxk[0], B, N, 10, conv_w, conv_b, w.gall[0], s, w.gv[0].ids);  // points in grid-cell order
     launch_pool_all(feat2, w.idxk[1], B, M, 10, conv_w, conv_b, w.gall[1], s, w.gv[1].ids);

@@ -545,14 +545,8 @@ constexpr float LEAN_MIN_ALPHA = 32.f;
 
 template <int TOPK>
 static void launch_softcorr_mfma(SCArgs &a, int blocks, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)softcorr_mfma_kernel<TOPK, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)MF_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void *)softcorr_mfma_kernel<TOPK, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)MF_LDS_BYTES);
-        attr_set = true;
-    }
+    ensure_dyn_lds((const void *)softcorr_mfma_kernel<TOPK, true>, (int)MF_LDS_BYTES);
+ensure_dyn_lds((const void *)softcorr_mfma_kernel<TOPK, false>, (int)MF_LDS_BYTES);
     const float alpha = -a.neg_alpha;
     a.cutw = 20.f / alpha;
     if (alpha >= LEAN_MIN_ALPHA)
@@ -717,14 +711,8 @@ DVM_EXPORT int dvm_softcorr_fwd_f32(const float *f1, const float *f2, int B, int
     } else {
         dim3 grid((N + 127) / 128, B);
         size_t lds = (size_t)(SC_KT * d + SC_KT) * sizeof(float);
-        static bool sattr_set = false;
-        if (!sattr_set) {
-            (void)hipFuncSetAttribute((const void *)softcorr_scalar_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      66 * 1024);
-            (void)hipFuncSetAttribute((const void *)softcorr_scalar_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      66 * 1024);
-            sattr_set = true;
-        }
+        ensure_dyn_lds((const void *)softcorr_scalar_kernel<10>, 66 * 1024);
+        ensure_dyn_lds((const void *)softcorr_scalar_kernel<16>, 66 * 1024);
         if (topk <= 10)
             hipLaunchKernelGGL(softcorr_scalar_kernel<10>, grid, dim3(128), lds, s, f1, f2, n1, n2, N, M, d, neg_alpha, topk,
                                pi_val, pi_idx, row_smax, row_sum);

@@ -385,12 +385,7 @@ DVM_EXPORT int dvm_softcorr_bwd_f32(const float *f1, const float *f2, int B, int
         a.split = split;
         a.blocks0 = B * a.g[0].tiles_o * split;
         a.a2 = a2;
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void *)softcorr_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)BW_LDS_BYTES);
-            attr_set = true;
-        }
+        ensure_dyn_lds((const void *)softcorr_bwd_mfma_kernel, (int)BW_LDS_BYTES);
         hipLaunchKernelGGL(softcorr_bwd_mfma_kernel, dim3(base * split), dim3(BW_THREADS), BW_LDS_BYTES, s, a);
     } else {
         SBScalarArgs a;

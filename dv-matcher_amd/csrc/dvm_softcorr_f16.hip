@@ -767,14 +767,8 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
     a.neg_alpha = neg_alpha;
     a.cutw = 20.f / -neg_alpha;
     const int blocks = a.blocks0 + (both ? B * a.g[1].tiles : 0);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)softcorr_sweep_f16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)HB_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void *)softcorr_sweep_f16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)HB_LDS_BYTES);
-        attr_set = true;
-    }
+    ensure_dyn_lds((const void *)softcorr_sweep_f16_kernel<true>, (int)HB_LDS_BYTES);
+ensure_dyn_lds((const void *)softcorr_sweep_f16_kernel<false>, (int)HB_LDS_BYTES);
     prof_begin(s);
     if (-neg_alpha >= 32.f)
         hipLaunchKernelGGL(softcorr_sweep_f16_kernel<true>, dim3(blocks), dim3(HB_THREADS), HB_LDS_BYTES, s, a);
@@ -850,12 +844,7 @@ int launch_argmin_f16(const float *f1, const float *f2, int B, int N, int M, int
     a.neg_alpha = -100.f;  // only the candidate lists are used; the lean sweep keeps them exactly as the full one does
     a.cutw = 0.f;
     const int blocks = a.blocks0 + (both ? B * a.g[1].tiles : 0);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)softcorr_sweep_f16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)HB_LDS_BYTES);
-        attr_set = true;
-    }
+    ensure_dyn_lds((const void *)softcorr_sweep_f16_kernel<true>, (int)HB_LDS_BYTES);
     hipLaunchKernelGGL(softcorr_sweep_f16_kernel<true>, dim3(blocks), dim3(HB_THREADS), HB_LDS_BYTES, s, a);
     AMArgs r;
     r.g[0] = AMGroup{f1, f2, n1, nmax2, N, M, cidx[0], cd2[0], T12, dmin12, flag[0] + 1, flag[0]};

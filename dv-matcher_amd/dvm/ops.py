@@ -12,15 +12,25 @@ from . import _lib
 from ._lib import DvmError, check
 
 _ws_cache = {}
+_pair_ctx = set()
 
 
 def _need_gpu(*ts):
+    """Every wrapper starts here: all tensors on ONE HIP device, which becomes the current device (the C ABI launches on
+    `torch.cuda.current_stream()` and keeps its per-device state — kernel attributes, helper streams — by current device)."""
+    dev = None
     for t in ts:
         if t is None:
             continue
         if not isinstance(t, torch.Tensor) or not t.is_cuda:
             raise DvmError("dvm ops need tensors on a HIP device (got %s); there is no CPU fallback"
                            % (t.device if isinstance(t, torch.Tensor) else type(t)))
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise DvmError("dvm ops need all tensors on one device (got %s and %s)" % (dev, t.device))
+    if dev is not None and dev.index != torch.cuda.current_device():
+        torch.cuda.set_device(dev)
 
 
 def _f(t):
@@ -40,8 +50,9 @@ def _stream():
 
 
 def workspace(nbytes, device, tag="ws"):
-    """Grow-only scratch buffer per (device, tag); reused across calls on the same stream."""
-    key = (device, tag)
+    """Grow-only scratch buffer per (device, current stream, tag): calls on one stream are ordered and may share it,
+    calls on different streams (or devices) never do."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream, tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
@@ -694,6 +705,10 @@ def pair_forward(wl, feat1, feat2, verts1, verts2, alpha, start1, start2, with_m
     o12, o21 = out if out is not None else (alloc(N), alloc(M))
     nb = lib.dvm_pair_workspace_bytes(B, N, M)
     ws = workspace(nb, dev, "pair2")
+    ctx = (dev.index, _stream())
+    if ctx not in _pair_ctx:   # helper streams / events for this (device, stream): made once, outside the compute call
+        check(lib.dvm_pair_init(_stream()), "dvm_pair_init")
+        _pair_ctx.add(ctx)
     check(lib.dvm_pair_fwd_f32(_p(feat1), _p(feat2), _p(verts1), _p(verts2), B, N, M, neg_alpha_f32(alpha), _p(start1),
                                _p(start2), *[_p(w) for w in wl], int(with_map), _p(o12["warped"]), _p(o12["verts12"]),
                                _p(o12["T12"]), _p(o12["losses"]), _p(o21["warped"]), _p(o21["verts12"]), _p(o21["T12"]),

@@ -16,7 +16,11 @@
  *    row-major, fp32 / int32 (double where stated), 16-byte aligned;
  *  - `stream` is a hipStream_t (NULL = default stream); calls are
  *    asynchronous on it, never synchronise, never allocate (graph-capturable);
- *    scratch comes from the caller: query the size with *_workspace_bytes;
+ *    scratch comes from the caller: query the size with *_workspace_bytes.
+ *    The library keeps no per-call global state: kernel attributes are set once
+ *    per (device, kernel) under a lock, and the only HIP objects it owns are the
+ *    helper streams of dvm_pair_init / the events of dvm_profile_enable;
+ *  - calls on distinct streams or devices may come from different host threads;
  *  - B is the batch (pairs or shapes); per-batch tensors are stacked on dim 0;
  *  - indices are 0-based int32.
  */
@@ -85,9 +89,10 @@ int dvm_linear_prefix_f32(const float *xg, int Cg, const float *x, const float *
  *   pi_val [B,N,topk], pi_idx [B,N,topk];
  *   row_smax [B,N] = max_j s_ij, row_sum [B,N] = sum_j exp(s_ij - smax)  (s = D*neg_alpha)
  * f1 [B,N,d], f2 [B,M,d]; neg_alpha = (float)(-alpha) < 0; 1 <= topk <= 16; d % 4 == 0, d <= 512.
- * variant: 0 = auto, 1 = scalar-FMA kernel, 2 = fp32-MFMA kernel (d == 128), 3 = bf16-split matrix-core sweep
- * with exact fp32 re-evaluation of the 12 best columns per row and exact recompute of uncertified rows
- * (d == 128, topk <= 10); all variants give identical columns and row_smax. */
+ * variant: 0 = auto, 1 = scalar-FMA kernel, 2 = fp32-MFMA kernel (d == 128), 3 = sweep on the 16-bit matrix cores
+ * over an exact 2-way fp16 split of the scaled features (3 partial products, fp32 accumulate) with exact fp32
+ * re-evaluation of the 12 best columns per row and exact recompute of uncertified rows (d == 128, topk <= 10);
+ * all variants give identical columns and row_smax. */
 size_t dvm_softcorr_workspace_bytes(int B, int N, int M, int d);
 int dvm_softcorr_fwd_f32(const float *f1, const float *f2, int B, int N, int M, int d, float neg_alpha, int topk,
                          float *pi_val, int32_t *pi_idx, float *row_smax, float *row_sum, int variant, void *ws,
@@ -357,10 +362,17 @@ int dvm_pair_fwd_f32(const float *feat1, const float *feat2, const float *verts1
                      float *verts12, int32_t *T12, float *losses12, float *warped21, float *verts21, int32_t *T21,
                      float *losses21, void *ws, size_t ws_bytes, void *stream);
 
-/* dvm_pair_fwd_f32 runs its coordinate-only chain (FPS, graph, xyz kNN) on an internal helper stream, forked from
- * and joined back into `stream` by events, concurrently with the feature-only soft-correspondence chain.
- * dvm_pair_set_overlap(0) keeps everything on `stream` (A/B measurements); returns the previous setting.
+/* dvm_pair_fwd_f32 can run its coordinate-only chain (FPS, graph, xyz kNN: latency-bound) on helper streams, forked
+ * from and joined back into `stream` by events, next to the feature-only soft-correspondence chain.  The helper streams
+ * and events are NOT created by the compute call: dvm_pair_init(stream) makes them for (current device, `stream`) —
+ * idempotent, the one call of this library that allocates HIP objects — and dvm_pair_destroy() frees every context of
+ * the process.  A dvm_pair_fwd_f32 on a (device, stream) without a context runs everything on `stream`: same results,
+ * no overlap.  Contexts are per caller stream, so calls on distinct streams / devices / host threads never share an
+ * event; calls on the SAME stream must come from one thread at a time (as for any stream-ordered API).
+ * dvm_pair_set_overlap(0) ignores the contexts (A/B measurements); returns the previous setting.
  * Environment default: DVM_PAIR_OVERLAP=0. */
+int dvm_pair_init(void *stream);
+int dvm_pair_destroy(void);
 int dvm_pair_set_overlap(int on);
 
 #ifdef __cplusplus

@@ -17,8 +17,11 @@ __global__ void k(const float* Q, const float* Kf, float* D, int scaleq) {
 int main() {
     float *Q, *Kf, *D;
     hipMallocManaged(&Q, 32 * 128 * 4); hipMallocManaged(&Kf, 32 * 128 * 4); hipMallocManaged(&D, 4096);
-    FILE* f = fopen("gpurun_probe_f1.bin", "rb"); fread(Q, 4, 32 * 128, f); fclose(f);
-    f = fopen("gpurun_probe_f2.bin", "rb"); fread(Kf, 4, 32 * 128, f); fclose(f);
+    // inputs generated here (no binary fixtures in the tree): a 32-bit LCG mapped to roughly N(0,1)-scaled values
+    unsigned st = 12345u;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) / 16777216.0f - 0.5f) * 3.4f; };
+    for (int i = 0; i < 32 * 128; ++i) Q[i] = rnd();
+    for (int i = 0; i < 32 * 128; ++i) Kf[i] = rnd();
     for (int scaleq = 0; scaleq < 2; ++scaleq) {
         hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, Q, Kf, D, scaleq);
         hipDeviceSynchronize();
