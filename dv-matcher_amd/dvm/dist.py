@@ -63,12 +63,22 @@ class FlatGradBucket:
                 p.grad = v
 
     def all_reduce_mean(self, group=None):
-        """grad <- mean over ranks of grad (what DDP computes), with one collective."""
+        """grad <- mean over ranks of grad (what DDP computes for a loss that is a mean over the batch), one collective."""
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._gather_foreign()
         if world > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
             self.flat.div_(world)
+
+    def all_reduce_sum(self, group=None, async_op=False):
+        """grad <- sum over ranks of grad, one collective.  With every rank back-propagating
+        `criterion.data_parallel_loss(B_shard / B_global)` this is the single-process gradient of the global batch
+        (the criterion mixes per-batch sums and means, so a plain mean would shrink its sum-type terms by 1/world).
+        async_op=True returns the work handle (wait() before the optimizer step)."""
+        self._gather_foreign()
+        if dist.is_initialized() and dist.get_world_size(group) > 1:
+            return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        return None
 
 
 def global_minmax(x, group=None):

@@ -25,22 +25,32 @@ class Mesh:
         self.f = np.asarray(f, dtype=np.int64)
 
 
+def _directed_face_edges(faces):
+    """(3F,) sources and targets of the faces' directed edges, in corner order 0->1, 1->2, 2->0."""
+    f = np.asarray(faces, dtype=np.int64)
+    return f.reshape(-1), np.roll(f, -1, axis=1).reshape(-1)
+
+
 def get_vert_connectivity(mesh_v, mesh_f):
-    """Sparse #verts x #verts matrix with a nonzero wherever two vertices share an edge."""
+    """Sparse #verts x #verts adjacency (csc): entry (a, b) counts how often a-b occurs as a face edge, either way round
+    (lib/mesh_sampling.py:12-30 of the reference; only the non-zero pattern is used downstream)."""
     n = len(mesh_v)
-    vpv = sp.csc_matrix((n, n))
-    for i in range(3):
-        IS, JS = mesh_f[:, i], mesh_f[:, (i + 1) % 3]
-        mtx = sp.csc_matrix((np.ones(len(IS)), (IS.flatten(), JS.flatten())), shape=(n, n))
-        vpv = vpv + mtx + mtx.T
-    return vpv
+    src, dst = _directed_face_edges(mesh_f)
+    key, cnt = np.unique(np.concatenate([dst * n + src, src * n + dst]), return_counts=True)   # column-major keys
+    col, row = np.divmod(key, n)
+    indptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(indptr, col + 1, 1)
+    return sp.csc_matrix((cnt.astype(np.float64), row, np.cumsum(indptr)), shape=(n, n))
 
 
 def get_vertices_per_edge(mesh_v, mesh_f):
-    """E x 2 array of vertex pairs, every edge once (lower index first)."""
-    vc = sp.coo_matrix(get_vert_connectivity(mesh_v, mesh_f))
-    result = np.stack([vc.row, vc.col], axis=1)
-    return result[result[:, 0] < result[:, 1]]
+    """E x 2 array of vertex pairs, every undirected edge once with the lower index first, ordered by the higher index
+    (then the lower) — the order in which a column-major adjacency lists them."""
+    src, dst = _directed_face_edges(mesh_f)
+    lo, hi = np.minimum(src, dst), np.maximum(src, dst)
+    n = len(mesh_v)
+    key = np.unique(hi * n + lo)
+    return np.stack([key % n, key // n], axis=1)
 
 
 def vertex_quadrics(mesh):
@@ -58,19 +68,18 @@ def vertex_quadrics(mesh):
 
 
 def _get_sparse_transform(faces, num_original_verts):
-    verts_left = np.unique(faces.flatten())
-    IS = np.arange(len(verts_left))
-    mp = np.arange(0, np.max(faces.flatten()) + 1)
-    mp[verts_left] = IS
-    new_faces = mp[faces.copy().flatten()].reshape((-1, 3))
-    mtx = sp.csc_matrix((np.ones(len(verts_left)), (IS, verts_left)), shape=(len(verts_left), num_original_verts))
-    return new_faces, mtx
+    """Faces re-indexed to the surviving vertices (in ascending original order) and the V' x V selection matrix."""
+    survivors = np.unique(faces)
+    new_faces = np.searchsorted(survivors, faces).reshape(-1, 3)
+    pick = sp.csc_matrix((np.ones(len(survivors)), (np.arange(len(survivors)), survivors)),
+                         shape=(len(survivors), num_original_verts))
+    return new_faces, pick
 
 
 def qslim_decimator_transformer(mesh, factor=None, n_verts_desired=None):
     """-> (new_faces (F',3), mtx (V' x V) selecting the surviving vertices)."""
     if factor is None and n_verts_desired is None:
-        raise Exception('Need either factor or n_verts_desired.')
+        raise ValueError("qslim_decimator_transformer: give `factor` or `n_verts_desired`")
     if n_verts_desired is None:
         n_verts_desired = math.ceil(len(mesh.v) * factor)
     Qv = vertex_quadrics(mesh)
@@ -98,14 +107,16 @@ def qslim_decimator_transformer(mesh, factor=None, n_verts_desired=None):
         def __lt__(self, other):
             return self.key() < other.key()
 
-    one = np.array([1]).reshape(-1, 1)
+    homog = np.concatenate([v, np.ones((len(v), 1))], axis=1)          # (V,4) homogeneous coordinates
+
+    def quadric_error(Q, i):
+        """h_i^T Q h_i, evaluated as the (1x4)(4x4)(4x1) matrix chain so that near-equal costs order as in the reference."""
+        h = homog[i:i + 1]
+        return float((h @ Q @ h.T)[0, 0])
 
     def collapse_cost(r, c):
-        Qsum = Qv[r, :, :] + Qv[c, :, :]
-        p1 = np.vstack((v[r].reshape(-1, 1), one))
-        p2 = np.vstack((v[c].reshape(-1, 1), one))
-        destroy_c = float(p1.T.dot(Qsum).dot(p1)[0, 0])
-        destroy_r = float(p2.T.dot(Qsum).dot(p2)[0, 0])
+        Qsum = Qv[r] + Qv[c]
+        destroy_c, destroy_r = quadric_error(Qsum, r), quadric_error(Qsum, c)
         return destroy_c, destroy_r, min(destroy_c, destroy_r), Qsum
 
     edges = get_vertices_per_edge(mesh.v, mesh.f)

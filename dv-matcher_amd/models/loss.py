@@ -75,6 +75,24 @@ class SparsePi:
         return ops.apply(self.val, self.idx, V)
 
 
+def rank_term(pval, pidx, M):
+    """||P P^T - I||_F per batch element for the sparse top-k correspondence P (val/idx (B,N,k), M columns) —
+    models/loss.py:1427-1433 — without the dense (B,N,M) P or the (B,N,N) product:
+        ||P P^T - I||_F^2 = ||P^T P||_F^2 - sum_i d_i^2 + sum_i (d_i - 1)^2,   d_i = sum_t val[i,t]^2 = (P P^T)_ii,
+    with G = P^T P (M x M) accumulated from the k x k outer product of every row.  Accumulated in float64: for a
+    near-permutation P the two large terms cancel.  Differentiable w.r.t. pval (plain torch ops; the term is off in every
+    shipped config, so it has no kernel of its own)."""
+    B, N, k = pval.shape
+    v = pval.double()
+    i = pidx.long()
+    outer = (v.unsqueeze(-1) * v.unsqueeze(-2)).reshape(B, -1)
+    flat = (i.unsqueeze(-1) * M + i.unsqueeze(-2)).reshape(B, -1)
+    G = torch.zeros(B, M * M, dtype=torch.float64, device=pval.device).scatter_add_(1, flat, outer)
+    d = (v * v).sum(-1)
+    frob2 = (G * G).sum(1) - (d * d).sum(1) + ((d - 1) ** 2).sum(1)
+    return torch.sqrt(frob2.clamp_min(0)).float()
+
+
 class GraphDeformLoss_Neural(nn.Module):
     partial_variant = False
 
@@ -177,6 +195,7 @@ class GraphDeformLoss_Neural(nn.Module):
         """-> (loss, dist_loss, deform_loss, map_loss, self_rec_loss), like the reference.
         fps_starts=(s1 (B,), s2 (B,)) and anchors=(a1, a2) pin the draws the reference makes at random."""
         loss = 0
+        self._sum_part = self._mean_part = 0
         B, N, _ = verts1.shape
         M = verts2.shape[1]
         train = torch.is_grad_enabled() and (feat1.requires_grad or feat2.requires_grad or
@@ -190,6 +209,7 @@ class GraphDeformLoss_Neural(nn.Module):
             a2 = torch.as_tensor(np.asarray(anchors[1]), device=feat2.device)
             self.dist_loss = (dist_term(feat1, dist1, a1) + dist_term(feat2, dist2, a2)) * self.w_dist
             loss = loss + self.dist_loss
+            self._sum_part = self._sum_part + self.dist_loss
         if self.w_deform > 0 or not self.partial_variant:
             s1, s2 = fps_starts if fps_starts is not None else (None, None)
             k = self.k_deform
@@ -222,16 +242,34 @@ class GraphDeformLoss_Neural(nn.Module):
             scale = 1 if self.partial_variant else N
             self.deform_loss = (cross12 + cross21) * scale * self.w_deform / 2
             loss = loss + self.deform_loss
+            self._sum_part = self._sum_part + (a12 + a21) * (self.w_arap * scale * self.w_deform / 2)
+            self._mean_part = self._mean_part + (c12 + c21) * (self.w_cd * scale * self.w_deform / 2)
             if self.w_map > 0 and not self.partial_variant:
                 # FrobeniusLoss: sum over (N,k), mean over (B,3)
                 self.map_loss = self.w_map * (m12.sum() / (3 * B) + m21.sum() / (3 * B)) / 2
                 loss = loss + self.map_loss
+                self._mean_part = self._mean_part + self.map_loss
             if self.w_self_rec > 0:
                 self.self_rec_loss = (s12 + s21) * scale * self.w_self_rec / 2
                 loss = loss + self.self_rec_loss
+                self._mean_part = self._mean_part + self.self_rec_loss
             if self.w_rank > 0:
-                raise NotImplementedError("w_rank > 0 is off in every shipped config (needs the dense Pi Pi^T)")
+                if N != M:   # the reference compares the M x M product of the reverse direction with an N x N identity
+                    raise ValueError("w_rank > 0 needs N == M (got %d, %d), as in the reference" % (N, M))
+                self.rank_loss = (rank_term(ex12["pval"], ex12["pidx"], M).mean() +
+                                  rank_term(ex21["pval"], ex21["pidx"], N).mean()) * self.w_rank / 2
+                loss = loss + self.rank_loss
+                self._mean_part = self._mean_part + self.rank_loss
         return loss, self.dist_loss, self.deform_loss, self.map_loss, self.self_rec_loss
+
+    def data_parallel_loss(self, fraction):
+        """The loss to back-propagate on ONE SHARD of a data-parallel batch (call after forward): the reference's
+        criterion mixes reductions over the batch — the dist term and ARAP are SUMS over the pairs (models/loss.py:1392-1394,
+        1269-1273), Chamfer / map / self-reconstruction / rank are MEANS (1216-1226, 476-482) — so with
+        fraction = B_shard / B_global the sum-type terms enter as they are and the mean-type terms are weighted by the
+        shard's share; the SUM of the shards' gradients (one all-reduce) is then the gradient of this same criterion
+        evaluated on the whole batch by one process.  fraction = 1 gives the plain loss."""
+        return self._sum_part + fraction * self._mean_part
 
 
 class GraphDeformLoss_Neural_Partial(GraphDeformLoss_Neural):

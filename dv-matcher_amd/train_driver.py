@@ -1,22 +1,35 @@
 #!/usr/bin/env python3
-"""Thin training driver reproducing the reference's step (train.py:93-112) on the MI355X path.
+"""Training driver: the reference's training loop (train.py:75-169, train_partial.py:74-164) on the MI355X path.
+
+Per epoch e = 1..epochs:  alpha = linspace(min_alpha, max_alpha + 1, epochs)[e-1];  lr *= decay_factor when
+e % decay_iter == 0;  train pass (BatchNorm in train mode)
 
     feat1,_ = Uni3FC(verts1^T, dino1, upsampler); feat2,_ = Uni3FC(verts2^T, dino2, upsampler)
-    loss,... = criterion(feat1, feat2, dist1, dist2, verts1, verts2, alpha_i, deformer)
+    loss,... = criterion(feat1, feat2, dist1, dist2, verts1, verts2, alpha, deformer)
     loss.backward(); optimizer.step(); optimizer.zero_grad()
 
-with the reference's hyper-parameters read from its YAML (config/scape_r.yaml layout) and either
-synthetic pairs or a dataset directory in the reference's layout (`--data-root`: models/dataset.py
-reads `shapes_train/*.off` or its `.pt` cache, and `feat/<shape>.mat` visual features; producing those
-features is outside this path).  One process
-per GPU; with WORLD_SIZE > 1 the pair batch is sharded and the gradients are averaged with ONE
-all-reduce over a flat fp32 bucket (RCCL over xGMI).  BatchNorm uses local batch statistics and the
-positional encoding the local min/max (SURVEY §8e caveats).
+then a no-grad validation pass in eval mode with the same alpha, and the reference's checkpoints under
+ckpt/<expname>/: ep_{e}.pth + ep_deformer{e}.pth every misc.checkpoint_interval, ep_val_best.pth +
+ep_deformer_val_best.pth whenever the validation loss does not get worse, ep_train_best.pth +
+ep_deformer_train_best.pth every misc.log_interval iterations (state_dicts only, as the reference writes them;
+test_driver.py / deform_driver.py load them).  `--partial` trains GraphDeformLoss_Neural_Partial on N != M pairs
+(config/scape_partial.yaml).  Hyper-parameters come from a reference YAML (`--config`) or its shipped values.
 
-  python dv-matcher_amd/train_driver.py --steps 5 --batch 2 --points 1024
+Data: synthetic pairs (default), or a dataset directory in the reference's layout (`--data-root`, read by
+models/dataset.py's Dataset / PartialDataset).
+
+One process per GPU.  With WORLD_SIZE > 1 every global batch is sharded over the ranks and the gradients are exchanged
+with ONE all-reduce (sum) over a flat fp32 bucket (RCCL over xGMI), started as soon as backward has produced them and
+overlapped with the host-side bookkeeping; each rank back-propagates `criterion.data_parallel_loss(B_shard / B_global)`,
+so the reduced gradient is that of the criterion on the whole batch (its dist / ARAP terms are sums over the pairs, the
+rest are means).  `--sync-stats` makes BatchNorm statistics and the positional encoding's min / max batch-global too.
+
+  python dv-matcher_amd/train_driver.py --epochs 2 --pairs-per-epoch 8 --batch 2 --points 1024 --ckpt-dir /tmp/ck
+  python dv-matcher_amd/train_driver.py --steps 10 --warmup 3 --batch 8 --points 2048          # timing mode (one JSON line)
   python -m torch.distributed.run --nproc-per-node 8 dv-matcher_amd/train_driver.py --batch 8 --points 2048
 """
 import argparse
+import copy
 import json
 import os
 import random
@@ -32,145 +45,311 @@ if HERE not in sys.path:
     sys.path.insert(0, HERE)
 
 from dvm.dist import FlatGradBucket, shard_range  # noqa: E402
-from models.loss import GraphDeformLoss_Neural  # noqa: E402
+from models.loss import GraphDeformLoss_Neural, GraphDeformLoss_Neural_Partial  # noqa: E402
 from models.model import Deformer, Uni3FC  # noqa: E402
 
-DEFAULT_CFG = {  # the values of the reference's config/scape_r.yaml
-    "expname": "dvmatcher_scape_r_std",
+FULL_CFG = {  # the values of the reference's config/scape_r.yaml
+    "expname": "dvmatcher_scape_r_std", "with_dino": True, "feat_mat": True,
     "optimizer": {"lr": 2e-3, "b1": 0.9, "b2": 0.99, "decay_iter": 10, "decay_factor": 0.5},
     "training": {"batch_size": 2, "epochs": 20},
     "loss": {"k_deform": 10, "k_dist": 500, "N_dist": 1000, "partial": False, "min_alpha": 10, "max_alpha": 100,
              "w_dist": 0.02, "w_map": 0.005, "w_deform": 0.5, "w_self_rec": 0.5, "w_rank": 0, "w_img": 0,
              "deform": {"w_cd": 0.1, "w_arap": 0.01}},
+    "misc": {"checkpoint_interval": 1, "log_interval": 5000},
 }
+PARTIAL_CFG = copy.deepcopy(FULL_CFG)  # ... and of config/scape_partial.yaml
+PARTIAL_CFG.update(expname="dvmatcher_scape_partial", with_dino=False, feat_mat=False)
+PARTIAL_CFG["training"]["batch_size"] = 5
+PARTIAL_CFG["loss"].update(k_dist=300, N_dist=500, partial=True, w_deform=1000, w_self_rec=1000)
 
 
-def main():
+def rank_env():
+    """(world, rank, local_rank) of this process under torch.distributed.run (1, 0, 0 when run alone)."""
+    return tuple(int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+
+
+def pick_device(local_rank, n_devices):
+    """One process per GPU: LOCAL_RANK selects the device; more ranks than devices (the gloo tests on one GPU) share them
+    round-robin."""
+    if n_devices < 1:
+        raise RuntimeError("the training path needs a HIP device")
+    return local_rank % n_devices
+
+
+def rank_seeds(rank):
+    """Distinct, reproducible RNG streams per rank: (data generator, python `random`, torch global)."""
+    return 100 + rank, 200 + rank, 300 + rank
+
+
+def alpha_schedule(cfg):
+    return np.linspace(cfg["loss"]["min_alpha"], cfg["loss"]["max_alpha"] + 1, cfg["training"]["epochs"])
+
+
+def lr_at_epoch(cfg, epoch):
+    """The learning rate in force DURING epoch `epoch` (1-based): multiplied by decay_factor at the start of every epoch
+    divisible by decay_iter (train.py:78-82)."""
+    return float(cfg["optimizer"]["lr"]) * float(cfg["optimizer"]["decay_factor"]) ** (epoch // int(cfg["optimizer"]["decay_iter"]))
+
+
+def ckpt_paths(ckpt_dir, expname, tag):
+    """The reference's file names (train.py:40-42, 124-126, 161-169): tag in {'val_best', 'train_best', <epoch>}."""
+    d = os.path.join(ckpt_dir, str(expname))
+    dtag = "deformer_%s" % tag if isinstance(tag, str) else "deformer%d" % tag
+    return os.path.join(d, "ep_%s.pth" % tag), os.path.join(d, "ep_%s.pth" % dtag)
+
+
+def save_ckpt(net, dfm, ckpt_dir, expname, tag):
+    pb, pd = ckpt_paths(ckpt_dir, expname, tag)
+    os.makedirs(os.path.dirname(pb), exist_ok=True)
+    torch.save(net.state_dict(), pb)
+    torch.save(dfm.state_dict(), pd)
+    return pb, pd
+
+
+class SyntheticPairs:
+    """`pairs` fixed random pairs per split, N source / M target points, seeded per rank; dist = Euclidean cdist."""
+
+    def __init__(self, pairs, N, M, seed, dev):
+        g = torch.Generator().manual_seed(seed)
+        self.v1, self.v2 = torch.rand(pairs, N, 3, generator=g).to(dev), torch.rand(pairs, M, 3, generator=g).to(dev)
+        self.d1, self.d2 = torch.randn(pairs, N, 1152, generator=g).to(dev), torch.randn(pairs, M, 1152, generator=g).to(dev)
+        self.dist1, self.dist2 = torch.cdist(self.v1, self.v1), torch.cdist(self.v2, self.v2)
+        self.pairs = pairs
+
+    def batch(self, idx):
+        i = torch.as_tensor(idx, device=self.v1.device)
+        return self.v1[i], self.v2[i], self.d1[i], self.d2[i], self.dist1[i], self.dist2[i]
+
+
+class DatasetPairs:
+    """Pairs of a dataset directory (models/dataset.py), truncated to the first `N` / `M` points of each shape."""
+
+    def __init__(self, data, N, M, dev, random_feat, seed):
+        self.data, self.N, self.M, self.dev, self.random_feat = data, N, M, dev, random_feat
+        self.g = torch.Generator().manual_seed(seed)
+        self.pairs = len(data)
+
+    def batch(self, idx):
+        items = [self.data[i] for i in idx]
+        out = []
+        for s, cap in (("shape1", self.N), ("shape2", self.M)):
+            n = min(min(it[s]["xyz"].shape[0] for it in items), cap)
+            xyz = torch.stack([it[s]["xyz"][:n] for it in items]).float().to(self.dev)
+            dd = torch.stack([it[s]["dist"][:n, :n] for it in items]).float().to(self.dev)
+            if self.random_feat or "feat" not in items[0][s]:
+                ft = torch.randn(len(items), n, 1152, generator=self.g).to(self.dev)
+            else:
+                ft = torch.stack([it[s]["feat"][:n] for it in items]).float().to(self.dev)
+            out.append((xyz, ft, dd))
+        return out[0][0], out[1][0], out[0][1], out[1][1], out[0][2], out[1][2]
+
+
+def global_batches(n_pairs, Bg, shuffle_seed=None):
+    """Index lists of the global batches of one pass (the last partial batch is dropped when it cannot be sharded)."""
+    order = list(range(n_pairs))
+    if shuffle_seed is not None:
+        order = torch.randperm(n_pairs, generator=torch.Generator().manual_seed(shuffle_seed)).tolist()
+    return [order[i:i + Bg] for i in range(0, n_pairs - Bg + 1, Bg)]
+
+
+def build_criterion(cfg, partial, n_points):
+    L = cfg["loss"]
+    cls = GraphDeformLoss_Neural_Partial if partial else GraphDeformLoss_Neural
+    # anchors / neighbours are drawn among the points that actually exist (ADVICE r1: clamp from the real count)
+    k_dist, n_dist = min(int(L["k_dist"]), n_points // 2), min(int(L["N_dist"]), n_points // 2)
+    return cls(k_deform=L["k_deform"], w_dist=L["w_dist"], w_map=L["w_map"], k_dist=k_dist, N_dist=n_dist, partial=L["partial"],
+               w_deform=L["w_deform"], w_img=L["w_img"], w_rank=L["w_rank"], w_self_rec=L["w_self_rec"], w_cd=L["deform"]["w_cd"],
+               w_arap=L["deform"]["w_arap"], save_name=cfg["expname"])
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", default=None, help="a reference-style YAML (config/scape_r.yaml); default: its shipped values")
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--config", default=None, help="a reference-style YAML (config/scape_r.yaml / scape_partial.yaml); default: its shipped values")
+    ap.add_argument("--partial", action="store_true", help="GraphDeformLoss_Neural_Partial on N != M pairs (train_partial.py)")
+    ap.add_argument("--epochs", type=int, default=0, help="run the full loop for this many epochs (0: timing mode, see --steps)")
+    ap.add_argument("--pairs-per-epoch", type=int, default=None, help="synthetic data: pairs per training pass (default 4 global batches)")
+    ap.add_argument("--val-pairs", type=int, default=None, help="synthetic data: pairs of the validation pass (default 1 global batch)")
+    ap.add_argument("--ckpt-dir", default="ckpt", help="checkpoints go to <ckpt-dir>/<expname>/ (reference names)")
+    ap.add_argument("--steps", type=int, default=5, help="timing mode: timed steps")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=None, help="global pair batch (default: training.batch_size)")
-    ap.add_argument("--points", type=int, default=1024)
-    ap.add_argument("--epoch", type=int, default=1, help="which epoch's alpha to use (1-based)")
+    ap.add_argument("--batch", type=int, default=None, help="GLOBAL pair batch (default: training.batch_size)")
+    ap.add_argument("--points", type=int, default=1024, help="source points N")
+    ap.add_argument("--points-target", type=int, default=None, help="target points M (default: N; with --partial 0.44 N like 4995 / 2200)")
+    ap.add_argument("--epoch", type=int, default=1, help="timing mode: which epoch's alpha / lr to use (1-based)")
     ap.add_argument("--sync-stats", action="store_true", help="DDP: BatchNorm statistics and the positional encoding's min/max "
-                    "over the GLOBAL batch (SyncBatchNorm + two scalar all-reduces), i.e. the single-process semantics")
+                    "over the GLOBAL batch (SyncBatchNorm + two scalar all-reduces)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
-    ap.add_argument("--data-root", default=None, help="dataset directory (shapes_train/, feat/, cache_*.pt); default: synthetic")
-    ap.add_argument("--data-name", default="scape_r")
+    ap.add_argument("--data-root", default=None, help="dataset directory (shapes_train/, shapes_test/, feat/, cache_*.pt); default: synthetic")
+    ap.add_argument("--data-name", default=None)
     ap.add_argument("--random-feat", action="store_true", help="with --data-root: random visual features instead of feat/*.mat")
-    args = ap.parse_args()
-    cfg = DEFAULT_CFG
+    args = ap.parse_args(argv)
+    cfg = copy.deepcopy(PARTIAL_CFG if args.partial else FULL_CFG)
     if args.config:
         import yaml
         cfg = yaml.safe_load(open(args.config))
-    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
-    assert torch.cuda.is_available(), "the training path needs a HIP device"
-    local = local % torch.cuda.device_count()   # more ranks than devices (gloo tests on one GPU): share them round-robin
+        cfg.setdefault("misc", {}).setdefault("checkpoint_interval", 1)
+        cfg["misc"].setdefault("log_interval", 5000)
+    partial = args.partial or bool(cfg["loss"].get("partial"))
+    world, rank, local = rank_env()
+    local = pick_device(local, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.backend, **({"device_id": dev} if args.backend == "nccl" else {}))
-    Bg = args.batch or cfg["training"]["batch_size"]
+    Bg = args.batch or int(cfg["training"]["batch_size"])
+    if Bg < world:
+        raise SystemExit("global batch %d < world size %d: every rank needs at least one pair" % (Bg, world))
     lo, hi = shard_range(Bg, rank, world)
-    B, N = hi - lo, args.points
-    L = cfg["loss"]
+    N = args.points
+    M = args.points_target or (max(32, int(round(N * 2200 / 4995))) if partial else N)
+    seed_data, seed_py, seed_torch = rank_seeds(rank)
     torch.manual_seed(0)  # identical initial weights on every rank
-    net, dfm = Uni3FC(k=40).to(dev), Deformer(k=L["k_deform"]).to(dev)
+    net, dfm = Uni3FC(k=40).to(dev), Deformer(k=cfg["loss"]["k_deform"]).to(dev)
     if args.sync_stats and world > 1:
         net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)
         net.sync_minmax = True
     params = list(net.parameters()) + list(dfm.parameters())
     opt = torch.optim.Adam(params, lr=float(cfg["optimizer"]["lr"]), betas=(cfg["optimizer"]["b1"], cfg["optimizer"]["b2"]))
-    crit = GraphDeformLoss_Neural(k_deform=L["k_deform"], w_dist=L["w_dist"], w_map=L["w_map"], k_dist=min(L["k_dist"], N // 2),
-                                  N_dist=min(L["N_dist"], N // 2), partial=L["partial"], w_deform=L["w_deform"],
-                                  w_img=L["w_img"], w_rank=L["w_rank"], w_self_rec=L["w_self_rec"], w_cd=L["deform"]["w_cd"],
-                                  w_arap=L["deform"]["w_arap"], save_name=cfg["expname"])
-    alpha = np.linspace(L["min_alpha"], L["max_alpha"] + 1, cfg["training"]["epochs"])[args.epoch - 1]
     # world > 1: every p.grad is a view into one flat buffer (one all-reduce, no pack/unpack); a single rank has nothing to
-    # exchange and lets autograd hand Adam its gradient tensors directly (no accumulate-into-zeros adds either)
+    # exchange and lets autograd hand Adam its gradient tensors directly
     bucket = FlatGradBucket(params, attach=world > 1)
-    g = torch.Generator().manual_seed(100 + rank)
-    random.seed(200 + rank)
-    torch.manual_seed(300 + rank)
+    random.seed(seed_py)
+    torch.manual_seed(seed_torch)
+    timing = args.epochs <= 0
     if args.data_root:
-        from models.dataset import Dataset
-        data = Dataset(args.data_root, name=args.data_name, train=True, with_dino=not args.random_feat, feat_mat=True)
-        order = torch.randperm(len(data), generator=torch.Generator().manual_seed(7)).tolist()      # same on every rank
-
-        def batches():
-            at = 0
-            while True:                                      # this rank's slice [lo, hi) of every global batch
-                items = [data[order[(at + j) % len(order)]] for j in range(lo, hi)]
-                at += Bg
-                cols = []
-                for s in ("shape1", "shape2"):
-                    n = min(it[s]["xyz"].shape[0] for it in items)
-                    n = min(n, N)
-                    xyz = torch.stack([it[s]["xyz"][:n] for it in items]).float().to(dev)
-                    dd = torch.stack([it[s]["dist"][:n, :n] for it in items]).float().to(dev)
-                    if args.random_feat:
-                        ft = torch.randn(len(items), n, 1152, generator=g).to(dev)
-                    else:
-                        ft = torch.stack([it[s]["feat"][:n] for it in items]).float().to(dev)
-                    cols.append((xyz, ft, dd))
-                yield cols[0][0], cols[1][0], cols[0][1], cols[1][1], cols[0][2], cols[1][2]
+        from models import dataset as ds
+        name = args.data_name or ("scape_partial" if partial else "scape_r")
+        cls = ds.PartialDataset if partial else ds.Dataset
+        kw = dict(with_dino=bool(cfg.get("with_dino", True)) and not args.random_feat, feat_mat=bool(cfg.get("feat_mat", True)))
+        train_set = DatasetPairs(cls(args.data_root, name=name, train=True, **kw), N, M, dev, args.random_feat, seed_data)
+        try:
+            val_set = DatasetPairs(cls(args.data_root, name=name, train=False, **kw), N, M, dev, args.random_feat, seed_data + 1)
+        except Exception:  # noqa: BLE001  (a dataset directory without a test split: validate on the training pairs)
+            val_set = train_set
     else:
-        sv1, sv2 = torch.rand(B, N, 3, generator=g).to(dev), torch.rand(B, N, 3, generator=g).to(dev)
-        sd1, sd2 = torch.randn(B, N, 1152, generator=g).to(dev), torch.randn(B, N, 1152, generator=g).to(dev)
-        sdist1, sdist2 = torch.cdist(sv1, sv1), torch.cdist(sv2, sv2)
-
-        def batches():
-            while True:
-                yield sv1, sv2, sd1, sd2, sdist1, sdist2
-    feed = batches()
-    net.train()
-    dfm.train()
-    losses = []
+        n_train = args.pairs_per_epoch or (Bg if timing else 4 * Bg)
+        train_set = SyntheticPairs(n_train, N, M, seed_data if timing else 1000, dev)   # full loop: every rank holds the same pairs
+        val_set = train_set if timing else SyntheticPairs(args.val_pairs or Bg, N, M, 2000, dev)
+    crit = build_criterion(cfg, partial, min(N, M))
+    frac = (hi - lo) / Bg
     sync_each = os.environ.get("DVM_SYNC_EACH_STEP", "0") == "1"   # train.py logs loss.item() every iteration
 
-    def step():
-        v1, v2, d1, d2, dist1, dist2 = next(feed)
+    def train_step(batch, alpha):
+        v1, v2, d1, d2, dist1, dist2 = batch
         f1, _ = net(v1.permute(0, 2, 1), d1, None)
         f2, _ = net(v2.permute(0, 2, 1), d2, None)
         out = crit(f1, f2, dist1, dist2, v1, v2, alpha, dfm)
-        out[0].backward()
         if world > 1:
-            bucket.all_reduce_mean()
+            crit.data_parallel_loss(frac).backward()
+            work = bucket.all_reduce_sum(async_op=True)      # one 8.5 MB collective on RCCL's stream ...
+        else:
+            out[0].backward()
+            work = None
+        # ... overlapped with the host-side bookkeeping of the step (5 loss terms; local values, as the reference logs them)
+        vals = torch.stack([torch.as_tensor(o, device=dev).detach().float().reshape(()) for o in out])
+        if work is not None:
+            work.wait()
         opt.step()
         if world > 1:
             bucket.zero()
         else:
             opt.zero_grad(set_to_none=True)
-        vals = torch.stack([torch.as_tensor(o, device=dev).detach().float().reshape(()) for o in out])
-        return vals.tolist() if sync_each else vals      # the 5 loss terms; read back after the timed loop by default
+        return vals.tolist() if sync_each else vals
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        losses.append(step())
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    losses = [l if isinstance(l, list) else l.tolist() for l in losses]
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+    def shard(idx):
+        return idx[lo:hi]
+
+    # ------------------------------------------------------------------ timing mode: K steps on one resident batch
+    if timing:
+        alpha = alpha_schedule(cfg)[args.epoch - 1]
+        for grp in opt.param_groups:
+            grp["lr"] = lr_at_epoch(cfg, args.epoch)
+        net.train()
+        dfm.train()
+        if args.data_root:
+            feed = [train_set.batch(shard(b)) for b in global_batches(train_set.pairs, Bg)[:max(1, args.steps)]]
+        else:   # every rank owns its own Bg/world pairs (weak-scaling shape of the forward bench)
+            feed = [train_set.batch(list(range(lo, hi)) if train_set.pairs >= Bg else list(range(hi - lo)))]
+        losses = []
+        for i in range(args.warmup):
+            train_step(feed[i % len(feed)], alpha)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            losses.append(train_step(feed[i % len(feed)], alpha))
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        losses = [l if isinstance(l, list) else l.tolist() for l in losses]
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t)
+        if rank == 0:
+            print(json.dumps({"metric": "training pairs/sec (fwd+loss+bwd+Adam)", "value": Bg * args.steps / dt, "unit": "pairs/s",
+                              "n_gpus": world, "steps": args.steps, "ms_per_step": dt / args.steps * 1e3, "global_batch": Bg,
+                              "points": N, "points_target": M, "criterion": type(crit).__name__, "alpha": float(alpha),
+                              "grad_bucket_floats": bucket.numel, "first_losses": losses[0], "last_losses": losses[-1]}))
+        if world > 1:
+            dist.destroy_process_group()
+        return 0
+
+    # ------------------------------------------------------------------ the reference's loop
+    alphas = alpha_schedule(cfg)
+    epochs = min(args.epochs, len(alphas))
+    best_val = float("inf")
+    history = []
+    it_total = 0
+    for epoch in range(1, epochs + 1):
+        lr = lr_at_epoch(cfg, epoch)
+        for grp in opt.param_groups:
+            grp["lr"] = lr
+        alpha = alphas[epoch - 1]
+        net.train()
+        dfm.train()
+        sums, iters = torch.zeros(5, device=dev), 0
+        for b in global_batches(train_set.pairs, Bg, shuffle_seed=1000 * epoch):        # the same order on every rank
+            sums += torch.as_tensor(train_step(train_set.batch(shard(b)), alpha), device=dev)
+            iters += 1
+            it_total += 1
+            if rank == 0 and it_total % int(cfg["misc"]["log_interval"]) == 0:
+                save_ckpt(net, dfm, args.ckpt_dir, cfg["expname"], "train_best")
+        # validation: eval mode, no gradients, this epoch's alpha (train.py:135-156)
+        net.eval()
+        dfm.eval()
+        vsum, viters = torch.zeros((), device=dev), 0
+        with torch.no_grad():
+            for b in global_batches(val_set.pairs, Bg):
+                v1, v2, d1, d2, dist1, dist2 = val_set.batch(shard(b))
+                f1, _ = net(v1.permute(0, 2, 1), d1, None)
+                f2, _ = net(v2.permute(0, 2, 1), d2, None)
+                vsum += crit(f1, f2, dist1, dist2, v1, v2, alpha, dfm)[0].detach().float()
+                viters += 1
+        if world > 1:    # the validation loss that decides 'val_best' is the mean over all shards
+            dist.all_reduce(vsum, op=dist.ReduceOp.SUM)
+            vsum /= world
+        val = float(vsum) / max(viters, 1)
+        mean = (sums / max(iters, 1)).tolist()
+        history.append(dict(epoch=epoch, alpha=float(alpha), lr=lr, train=mean, val=val))
+        if rank == 0:
+            print("epoch:%d, loss:%.6g, dist_loss:%.6g, deform_loss:%.6g, map_loss:%.6g, self_rec_loss:%.6g, val_loss:%.6g (alpha %.3f, lr %.3g)"
+                  % ((epoch,) + tuple(mean) + (val, alpha, lr)), flush=True)
+            if (epoch + 1) % int(cfg["misc"]["checkpoint_interval"]) == 0:
+                save_ckpt(net, dfm, args.ckpt_dir, cfg["expname"], epoch)
+            if val <= best_val:
+                best_val = val
+                save_ckpt(net, dfm, args.ckpt_dir, cfg["expname"], "val_best")
     if rank == 0:
-        print(json.dumps({"metric": "training pairs/sec (fwd+loss+bwd+Adam)", "value": Bg * args.steps / dt, "unit": "pairs/s",
-                          "n_gpus": world, "steps": args.steps, "ms_per_step": dt / args.steps * 1e3, "global_batch": Bg,
-                          "points": N, "alpha": float(alpha), "grad_bucket_floats": bucket.numel,
-                          "first_losses": losses[0], "last_losses": losses[-1]}))
+        print(json.dumps({"epochs": epochs, "history": history, "best_val": best_val, "criterion": type(crit).__name__,
+                          "ckpt": list(ckpt_paths(args.ckpt_dir, cfg["expname"], "val_best"))}))
     if world > 1:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -198,6 +198,7 @@ def run_loss(rl, rm, crit_cls, kw, B, n, m, seed, alpha, with_grad=True, scape=F
     dist1 = torch.cdist(v1, v1)
     dist2 = torch.cdist(v2, v2)
     crit = crit_cls(save_name="fx", **kw)
+    crit.device = "cpu"   # only read by the rank term's torch.eye(device=self.device) (models/loss.py:1429)
     random.seed(7000 + seed)
     torch.manual_seed(8000 + seed)
     st_py = random.getstate()
@@ -217,6 +218,22 @@ def run_loss(rl, rm, crit_cls, kw, B, n, m, seed, alpha, with_grad=True, scape=F
         for k, p in dfm.named_parameters():
             out["g_" + k.replace(".", "__")] = p.grad
     return out
+
+
+def group_loss_rank(rl, rm):
+    """The rank term (models/loss.py:1427-1433 / 1065-1071): ||Pi Pi^T - I||_F on the top-10 correspondence, w_rank > 0
+    (off in the shipped configs, but it is the constructor default)."""
+    kw = dict(k_deform=10, w_dist=0.02, w_map=0.005, k_dist=30, N_dist=60, partial=False, w_deform=0.5, w_img=0,
+              w_rank=0.3, w_self_rec=0.5, w_cd=0.1, w_arap=0.01)
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as td:
+        os.chdir(td)
+        try:
+            save("loss_full_rank_160", **run_loss(rl, rm, rl.GraphDeformLoss_Neural, kw, 2, 160, 160, 5, 30.0))
+            kwp = dict(kw, w_deform=1000, w_self_rec=1000, partial=True)
+            save("loss_partial_rank_144", **run_loss(rl, rm, rl.GraphDeformLoss_Neural_Partial, kwp, 2, 144, 144, 6, 45.0))
+        finally:
+            os.chdir(cwd)
 
 
 def group_loss(rl, rm, only_unit=False):
@@ -257,6 +274,8 @@ def main():
             group_deformer(rl, rm)
         elif gname == "loss":
             group_loss(rl, rm)
+        elif gname == "loss_rank":
+            group_loss_rank(rl, rm)
         elif gname == "loss_unit":
             group_loss(rl, rm, only_unit=True)
         elif gname == "backbone" or gname.startswith("backbone:"):   # backbone:<fixture>,<fixture> regenerates a subset

@@ -96,3 +96,48 @@ def test_attached_bucket_holds_the_gradients():
     for p, q in zip(net.parameters(), ref.parameters()):
         torch.testing.assert_close(p, q, rtol=1e-6, atol=1e-7)
     assert torch.equal(unused, ref_unused)                               # zero gradient == no gradient for Adam
+
+
+def test_driver_rank_device_seed_helpers(monkeypatch):
+    """What the 8-GPU launch relies on, without GPUs: RANK / LOCAL_RANK / WORLD_SIZE parsing, device choice, distinct
+    seeds and disjoint shards per rank, the reference's schedules and checkpoint names."""
+    sys.path.insert(0, os.path.join(ROOT, "dv-matcher_amd"))
+    import train_driver as td
+    from dvm.dist import shard_range
+    seen_dev, seen_seed, covered = set(), set(), []
+    for r in range(8):
+        for k, v in (("WORLD_SIZE", 8), ("RANK", r), ("LOCAL_RANK", r)):
+            monkeypatch.setenv(k, str(v))
+        world, rank, local = td.rank_env()
+        assert (world, rank, local) == (8, r, r)
+        seen_dev.add(td.pick_device(local, 8))
+        assert td.pick_device(local, 1) == 0                       # more ranks than devices: shared
+        seen_seed.add(td.rank_seeds(rank))
+        covered += list(range(*shard_range(64, rank, world)))
+    assert seen_dev == set(range(8)) and len(seen_seed) == 8 and covered == list(range(64))
+    assert len({s for t in seen_seed for s in t}) == 24               # no two ranks / streams share a seed
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k)
+    assert td.rank_env() == (1, 0, 0)
+    with pytest.raises(RuntimeError):
+        td.pick_device(0, 0)
+    cfg = td.FULL_CFG
+    al = td.alpha_schedule(cfg)
+    assert len(al) == 20 and al[0] == 10 and al[-1] == 101             # np.linspace(min_alpha, max_alpha + 1, epochs)
+    assert [td.lr_at_epoch(cfg, e) for e in (1, 9, 10, 19, 20)] == [2e-3, 2e-3, 1e-3, 1e-3, 5e-4]
+    assert td.ckpt_paths("ckpt", "exp", "val_best") == ("ckpt/exp/ep_val_best.pth", "ckpt/exp/ep_deformer_val_best.pth")
+    assert td.ckpt_paths("ckpt", "exp", 3) == ("ckpt/exp/ep_3.pth", "ckpt/exp/ep_deformer3.pth")
+    assert td.global_batches(10, 4) == [[0, 1, 2, 3], [4, 5, 6, 7]]
+    a, b = td.global_batches(16, 4, shuffle_seed=5), td.global_batches(16, 4, shuffle_seed=5)
+    assert a == b and sorted(sum(a, [])) == list(range(16))            # the same order on every rank
+    assert td.PARTIAL_CFG["loss"]["w_deform"] == 1000 and td.PARTIAL_CFG["training"]["batch_size"] == 5
+    assert td.FULL_CFG["loss"]["w_deform"] == 0.5
+
+
+def test_bench_rank_helpers(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    for k, v in (("WORLD_SIZE", 4), ("RANK", 2), ("LOCAL_RANK", 2)):
+        monkeypatch.setenv(k, str(v))
+    if hasattr(bench, "rank_env"):
+        assert bench.rank_env() == (4, 2, 2)

@@ -174,6 +174,10 @@ def test_criterion_partial(golden):
     ("loss_full_300_unit", "GraphDeformLoss_Neural", dict(k_dist=50, N_dist=100, partial=False, w_deform=0.5, w_self_rec=0.5)),
     ("loss_partial_300x170_unit", "GraphDeformLoss_Neural_Partial", dict(k_dist=30, N_dist=60, partial=True, w_deform=1000,
                                                                       w_self_rec=1000)),
+    # the rank term ||Pi Pi^T - I||_F switched on (models/loss.py:1427-1433; the constructor's default)
+    ("loss_full_rank_160", "GraphDeformLoss_Neural", dict(k_dist=30, N_dist=60, partial=False, w_deform=0.5, w_self_rec=0.5, w_rank=0.3)),
+    ("loss_partial_rank_144", "GraphDeformLoss_Neural_Partial", dict(k_dist=30, N_dist=60, partial=True, w_deform=1000,
+                                                                  w_self_rec=1000, w_rank=0.3)),
 ])
 def test_criterion_backward_matches_reference(golden, name, cls, kw):
     """Training step parity: loss and gradients w.r.t. feat1, feat2 and every Deformer parameter against the
@@ -185,7 +189,8 @@ def test_criterion_backward_matches_reference(golden, name, cls, kw):
     d = mm.Deformer(10)
     d.load_state_dict({k.replace("__", "."): torch.from_numpy(v) for k, v in w.items()})
     d = d.cuda().train()
-    crit = getattr(ml, cls)(save_name="t", k_deform=10, w_dist=0.02, w_map=0.005, w_img=0, w_rank=0, w_cd=0.1, w_arap=0.01, **kw)
+    kw = dict(dict(w_rank=0), **kw)
+    crit = getattr(ml, cls)(save_name="t", k_deform=10, w_dist=0.02, w_map=0.005, w_img=0, w_cd=0.1, w_arap=0.01, **kw)
     f1, f2 = dev(g["feat1"]).requires_grad_(True), dev(g["feat2"]).requires_grad_(True)
     v1, v2 = dev(g["verts1"]), dev(g["verts2"])
     random.seed(int(g["py_seed"]))
@@ -193,6 +198,8 @@ def test_criterion_backward_matches_reference(golden, name, cls, kw):
     out = crit(f1, f2, torch.cdist(v1, v1), torch.cdist(v2, v2), v1, v2, np.float64(g["alpha"]), d)
     ref = [float(g[k]) for k in ("loss", "dist_loss", "deform_loss", "map_loss", "self_rec_loss")]
     np.testing.assert_allclose([float(o) for o in out], ref, rtol=2e-4)
+    if kw["w_rank"] > 0:   # not part of the 5-tuple: loss - (the four returned terms)
+        np.testing.assert_allclose(float(crit.rank_loss), ref[0] - sum(ref[1:]), rtol=1e-4)
     out[0].backward()
 
     def close(a, b, what):

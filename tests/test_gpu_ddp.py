@@ -114,3 +114,113 @@ def test_bench_two_ranks_on_one_gpu():
     assert res["n_gpus"] == 2 and res["steps"] == 2 and res["scaling"] == "weak" and res["cpu_baseline"] is None
     assert abs(res["value"] - 2 * 16 * 2 / (res["ms_per_step"] * 2e-3)) < 1e-6 * res["value"]   # pairs of BOTH ranks / time
     assert res["roofline"]["frac"] > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The criterion under data parallelism: its dist / ARAP terms are SUMS over the pairs, the others MEANS, so a
+# plain gradient mean shrinks the sum-type terms by 1/world.  Each rank back-propagates data_parallel_loss(B_shard/B_global)
+# and the flat bucket is all-reduced with SUM: the result must be the single-process gradient of the whole batch.
+def _crit_inputs(golden_dir):
+    import numpy as np
+    g = torch.Generator().manual_seed(17)
+    B, N = 4, 256
+    f1 = 0.3 * torch.relu(torch.randn(B, N, 128, generator=g))
+    f2 = 0.3 * torch.relu(torch.randn(B, N, 128, generator=g))
+    v1, v2 = torch.rand(B, N, 3, generator=g), torch.rand(B, N, 3, generator=g)
+    w = dict(np.load(os.path.join(golden_dir, "deformer_scape_r_weights.npz")))
+    anchors = (list(range(0, 120, 2)), list(range(1, 121, 2)))
+    starts = (torch.arange(B), torch.arange(B) + 3)
+    return f1, f2, v1, v2, w, anchors, starts
+
+
+def _crit_run(dev, lo, hi, Bg, golden_dir, reduce_fn=None):
+    sys.path.insert(0, os.path.join(ROOT, "dv-matcher_amd"))
+    import models.loss as ml
+    import models.model as mm
+    from dvm.dist import FlatGradBucket
+    f1, f2, v1, v2, w, anchors, starts = _crit_inputs(golden_dir)
+    d = mm.Deformer(10)
+    d.load_state_dict({k.replace("__", "."): torch.from_numpy(v) for k, v in w.items()})
+    d = d.to(dev).train()
+    bucket = FlatGradBucket(list(d.parameters()), attach=True)
+    crit = ml.GraphDeformLoss_Neural(k_deform=10, w_dist=0.02, w_map=0.005, k_dist=40, N_dist=60, partial=False, w_deform=0.5,
+                                     w_img=0, w_rank=0.1, w_self_rec=0.5, w_cd=0.1, w_arap=0.01, save_name="t")
+    sl = slice(lo, hi)
+    a, b = f1[sl].to(dev).requires_grad_(True), f2[sl].to(dev).requires_grad_(True)
+    x1, x2 = v1[sl].to(dev), v2[sl].to(dev)
+    out = crit(a, b, torch.cdist(x1, x1), torch.cdist(x2, x2), x1, x2, 40.0, d, fps_starts=(starts[0][sl], starts[1][sl]), anchors=anchors)
+    crit.data_parallel_loss((hi - lo) / Bg).backward()
+    if reduce_fn is not None:
+        reduce_fn(bucket)
+    return float(out[0]), a.grad.cpu(), b.grad.cpu(), bucket.flat.cpu()
+
+
+def _crit_worker(rank, world, port, ret, golden_dir):
+    sys.path.insert(0, os.path.join(ROOT, "dv-matcher_amd"))
+    from dvm.dist import shard_range
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = shard_range(4, rank, world)
+        ret[rank] = _crit_run(torch.device("cuda", 0), lo, hi, 4, golden_dir, reduce_fn=lambda bk: bk.all_reduce_sum())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_criterion_gradient_equals_global_batch():
+    golden_dir = os.path.join(ROOT, "tests", "golden")
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_crit_worker, args=(world, 29300 + os.getpid() % 2000, ret, golden_dir), nprocs=world, join=True)
+    loss, g1, g2, flat = _crit_run(torch.device("cuda", 0), 0, 4, 4, golden_dir)
+    assert torch.equal(ret[0][3], ret[1][3])                                   # both ranks hold the same reduced gradient
+    rel = float((ret[0][3] - flat).norm() / flat.norm())
+    print("Deformer gradient, sharded vs global batch: rel %.2e" % rel)
+    assert rel < 2e-3, rel
+    # a plain mean of per-shard `loss.backward()` gradients would NOT give this: show the size of the error it makes
+    for got, want in ((torch.cat([ret[0][1], ret[1][1]]), g1), (torch.cat([ret[0][2], ret[1][2]]), g2)):
+        r = float((got - want).norm() / want.norm())
+        assert r < 2e-3, r
+
+
+def test_training_driver_full_loop_checkpoints_round_trip(tmp_path):
+    """The reference's loop (train.py:75-169): epochs, alpha schedule, LR decay, validation pass, checkpoints under the
+    reference's names; ep_val_best.pth then loads into the inference driver and ep_deformer_val_best.pth into a Deformer."""
+    import json
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "dv-matcher_amd"))
+    ck = str(tmp_path / "ckpt")
+    cmd = [sys.executable, os.path.join(ROOT, "dv-matcher_amd", "train_driver.py"), "--epochs", "2", "--pairs-per-epoch", "4", "--val-pairs", "2",
+           "--batch", "2", "--points", "192", "--ckpt-dir", ck]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    h = res["history"]
+    assert [e["epoch"] for e in h] == [1, 2] and h[0]["alpha"] == 10.0 and abs(h[1]["alpha"] - (10 + 91 / 19)) < 1e-9
+    assert h[0]["lr"] == 2e-3 and all(v == v for e in h for v in e["train"] + [e["val"]])
+    d = os.path.join(ck, "dvmatcher_scape_r_std")
+    for f in ("ep_val_best.pth", "ep_deformer_val_best.pth", "ep_1.pth", "ep_deformer1.pth"):
+        assert os.path.exists(os.path.join(d, f)), os.listdir(d)
+    import models.model as mm
+    sd = torch.load(os.path.join(d, "ep_val_best.pth"), weights_only=True, map_location="cpu")
+    assert len(sd) == 281
+    mm.Uni3FC(k=40).load_state_dict(sd)
+    mm.Deformer(10).load_state_dict(torch.load(os.path.join(d, "ep_deformer_val_best.pth"), weights_only=True, map_location="cpu"))
+    import test_driver
+    outdir = str(tmp_path / "res")
+    test_driver.main(["--synthetic", "1", "--points", "200", "--out", outdir, "--ckpt", os.path.join(d, "ep_val_best.pth")])
+    assert os.path.exists(os.path.join(outdir, "T", "T_s000a_s000b.txt"))
+
+
+def test_training_driver_partial_mode():
+    """train_partial.py's step: GraphDeformLoss_Neural_Partial on N != M pairs (one-sided Chamfer, no map term, no x N)."""
+    import json
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "dv-matcher_amd", "train_driver.py"), "--partial", "--steps", "3", "--warmup", "0", "--batch", "2",
+           "--points", "454", "--points-target", "200"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert res["criterion"] == "GraphDeformLoss_Neural_Partial" and res["points"] == 454 and res["points_target"] == 200
+    assert res["first_losses"][3] == 0.0                      # no map loss in the partial variant
+    assert all(v == v and abs(v) < 1e12 for v in res["first_losses"] + res["last_losses"]) and res["first_losses"] != res["last_losses"]
