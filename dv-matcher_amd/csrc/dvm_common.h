@@ -61,6 +61,13 @@ struct Arena {
     bool ok() const { return base != nullptr && off <= cap; }
 };
 
+// p + n that stays null for a null p: workspace layouts are also carved over a null base to compute their size, and
+// offsetting a null pointer is undefined behaviour (found by the UBSan build, csrc/san/)
+template <typename T>
+static inline T *offset_ptr(T *p, size_t n) {
+    return p ? p + n : nullptr;
+}
+
 constexpr int WAVE = 64;
 
 // uniform-grid neighbour search (dvm_grid.hip)
@@ -76,10 +83,10 @@ size_t grid_bytes(int B, int P);
 static inline GridBuf grid_slice(const GridBuf &g, int b0) {
     GridBuf r = g;
     const int G3 = g.G * g.G * g.G;
-    r.pts = g.pts + (size_t)b0 * g.P;
-    r.ids = g.ids + (size_t)b0 * g.P;
-    r.start = g.start + (size_t)b0 * (G3 + 1);
-    r.params = g.params + (size_t)b0 * 8;
+    r.pts = offset_ptr(g.pts, (size_t)b0 * g.P);
+    r.ids = offset_ptr(g.ids, (size_t)b0 * g.P);
+    r.start = offset_ptr(g.start, (size_t)b0 * (G3 + 1));
+    r.params = offset_ptr(g.params, (size_t)b0 * 8);
     return r;
 }
 GridBuf grid_carve(Arena &ar, int B, int P);

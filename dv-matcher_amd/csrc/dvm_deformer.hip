@@ -337,9 +337,9 @@ static size_t carve(Arena &ar, int B, int M, int Nn, DeformerWs &w) {
     w.g2 = ar.take<float>((size_t)B * M * DF_C);
     w.z = ar.take<float>((size_t)B * Nn * DF_ZS);
     w.Wp0 = ar.take<float>(mlp_pack_floats());  // packed weights of all layers (either kernel's format)
-    w.Wp1 = w.Wp0 + (size_t)16 * 132 * 64;
-    w.Wp2 = w.Wp1 + (size_t)8 * 256 * 64;
-    w.Wp3 = w.Wp2 + (size_t)4 * 128 * 64;
+    w.Wp1 = offset_ptr(w.Wp0, (size_t)16 * 132 * 64);
+    w.Wp2 = offset_ptr(w.Wp1, (size_t)8 * 256 * 64);
+    w.Wp3 = offset_ptr(w.Wp2, (size_t)4 * 128 * 64);
     w.h0 = ar.take<float>((size_t)B * Nn * 512);
     w.h1 = ar.take<float>((size_t)B * Nn * 256);
     w.h2 = ar.take<float>((size_t)B * Nn * 128);
