@@ -286,3 +286,257 @@ DVM_EXPORT int dvm_i2p_f32(const float *pts, const float *f, const float *pc_min
     DVM_CHECK_LAUNCH("i2p");
     return DVM_OK;
 }
+
+
+// ---------------------------------------------------------------- adaptive convolution of the JBU upsampler
+// out[b,c,h,w] = sum_{i,j < d} in[b,c,h+i,w+j] * kern[b,h,w,i,j]   — the per-pixel d x d filtering step of FeatUp's joint
+// bilateral upsampler (its `AdaptiveConv` CUDA op; here a gfx950 kernel).  `in` is the reflect-padded bicubic upsample
+// [B,C,H+d-1,W+d-1], `kern` the combined spatial x range kernel [B,H,W,d,d].
+// One workgroup = one row segment of 64 pixels x 4 channel lanes: the segment's d*d kernel weights (the same for every
+// channel) are staged once in LDS as [tap][pixel]; every thread then walks its channels, reading input rows that its
+// 63 neighbours read at adjacent addresses (coalesced, L1/L2-resident across the d vertical taps).
+namespace dvm {
+namespace {
+constexpr int AC_PIX = 64, AC_CL = 4;
+// kern_cm: the kernel tensor is [B,d*d,H,W] (tap-major, what dvm_jbu_kernel_f32 writes) instead of [B,H,W,d,d]
+__global__ __launch_bounds__(AC_PIX * AC_CL) void adaptive_conv_kernel(const float *__restrict__ in, const float *__restrict__ kern, int C,
+                                                                        int H, int W, int d, int kern_cm, float *__restrict__ out) {
+    extern __shared__ float kw[];   // [d*d][AC_PIX]
+    const int px = threadIdx.x & (AC_PIX - 1), cl = threadIdx.x / AC_PIX;
+    const int w0 = blockIdx.x * AC_PIX, h = blockIdx.y, b = blockIdx.z;
+    const int taps = d * d, Wp = W + d - 1, Hp = H + d - 1;
+    if (kern_cm) {
+        for (int e = threadIdx.x; e < taps * AC_PIX; e += AC_PIX * AC_CL) {
+            const int t = e / AC_PIX, p = e % AC_PIX;   // consecutive threads read consecutive pixels of a tap (contiguous)
+            kw[e] = (w0 + p < W) ? kern[(((size_t)b * taps + t) * H + h) * W + w0 + p] : 0.f;
+        }
+    } else {
+        for (int e = threadIdx.x; e < taps * AC_PIX; e += AC_PIX * AC_CL) {
+            const int p = e / taps, t = e % taps;   // consecutive threads read consecutive taps of a pixel (contiguous)
+            kw[t * AC_PIX + p] = (w0 + p < W) ? kern[(((size_t)b * H + h) * W + w0 + p) * taps + t] : 0.f;
+        }
+    }
+    __syncthreads();
+    const int w = w0 + px;
+    if (w >= W) return;
+    for (int c = cl; c < C; c += AC_CL) {
+        const float *ip = in + (((size_t)b * C + c) * Hp + h) * Wp + w;
+        float acc = 0.f;
+        for (int i = 0; i < d; ++i)
+            for (int j = 0; j < d; ++j) acc = fmaf(ip[(size_t)i * Wp + j], kw[(i * d + j) * AC_PIX + px], acc);
+        out[(((size_t)b * C + c) * H + h) * W + w] = acc;
+    }
+}
+}  // namespace
+}  // namespace dvm
+
+// Bicubic resize (A = -0.75, align_corners = False, border-clamped taps: torch's upsample_bicubic2d) written straight into
+// its reflect-padded frame: out[b,c,h',w'] = up(in)[reflect(h' - pad), reflect(w' - pad)], h' < Ho + 2 pad.  One pass, one
+// thread per output element (coalesced along w); the low-resolution source is small and cache-resident.  Replaces
+// F.interpolate(mode='bicubic') + F.pad(mode='reflect') in front of the adaptive convolution (the generic ATen resize kernel
+// took 16 ms for 24 x 384 x 256^2; this is bound by the 2.5 GB it writes).
+namespace dvm {
+namespace {
+__device__ __forceinline__ void cubic_w(float t, float w[4]) {
+    const float A = -0.75f;
+    const float x0 = t + 1.f, x1 = t, x2 = 1.f - t, x3 = 2.f - t;
+    w[0] = ((A * x0 - 5.f * A) * x0 + 8.f * A) * x0 - 4.f * A;
+    w[1] = ((A + 2.f) * x1 - (A + 3.f)) * x1 * x1 + 1.f;
+    w[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
+    w[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
+}
+__global__ __launch_bounds__(256) void bicubic_pad_kernel(const float *__restrict__ in, int Hi, int Wi, int Ho, int Wo, int pad,
+                                                          float *__restrict__ out) {
+    const int Wp = Wo + 2 * pad, Hp = Ho + 2 * pad;
+    const int wq = blockIdx.x * 256 + threadIdx.x, hq = blockIdx.y;
+    const size_t bc = blockIdx.z;
+    if (wq >= Wp) return;
+    int h = hq - pad, w = wq - pad;
+    h = h < 0 ? -h : (h >= Ho ? 2 * Ho - 2 - h : h);
+    w = w < 0 ? -w : (w >= Wo ? 2 * Wo - 2 - w : w);
+    const float sh = (float)Hi / Ho, sw = (float)Wi / Wo;
+    const float fy = sh * (h + 0.5f) - 0.5f, fx = sw * (w + 0.5f) - 0.5f;
+    const int iy = (int)floorf(fy), ix = (int)floorf(fx);
+    float wy[4], wx[4];
+    cubic_w(fy - iy, wy);
+    cubic_w(fx - ix, wx);
+    const float *src = in + bc * Hi * Wi;
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int yy = min(max(iy - 1 + a, 0), Hi - 1);
+        float row = 0.f;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) row = fmaf(wx[b], src[(size_t)yy * Wi + min(max(ix - 1 + b, 0), Wi - 1)], row);
+        acc = fmaf(wy[a], row, acc);
+    }
+    out[(bc * Hp + hq) * Wp + wq] = acc;
+}
+}  // namespace
+}  // namespace dvm
+
+DVM_EXPORT int dvm_bicubic_resize_pad_f32(const float *in, int BC, int Hi, int Wi, int Ho, int Wo, int pad, float *out, void *stream) {
+    DVM_REQUIRE(in && out, "dvm_bicubic_resize_pad_f32: null pointer");
+    DVM_REQUIRE(BC >= 1 && Hi >= 1 && Wi >= 1 && Ho >= 1 && Wo >= 1 && pad >= 0 && pad < Ho && pad < Wo, "dvm_bicubic_resize_pad_f32: bad sizes");
+    DVM_REQUIRE(BC <= 65535 * 1 && Ho + 2 * pad <= 65535, "dvm_bicubic_resize_pad_f32: B*C=%d or height exceeds the grid limit", BC);
+    hipLaunchKernelGGL(dvm::bicubic_pad_kernel, dim3((Wo + 2 * pad + 255) / 256, Ho + 2 * pad, BC), dim3(256), 0, (hipStream_t)stream, in, Hi, Wi,
+                       Ho, Wo, pad, out);
+    DVM_CHECK_LAUNCH("bicubic_resize_pad");
+    return DVM_OK;
+}
+
+// The combined kernel of one JBU stage before its learned correction: for every pixel p and tap t (offset (i,j) in the
+// d x d window, reflect padding), softmax_t(temp * <proj[p], proj[p + t]>) * exp(-|t|^2 / (2 sigma^2)), renormalised over
+// the taps.  A workgroup owns a 32 x 8 pixel tile: the key vectors of the tile and its 3-pixel halo (32 x 14 x 38 floats,
+// 68 KB) are staged in LDS once — straight from L2 the 1568 loads per pixel were the whole cost (9.9 ms per 24 x 256^2
+// images) — then every thread holds its own key vector and the d*d logits in registers.  Written tap-major so that the
+// 1x1 "fixup" convolutions and the adaptive convolution read it coalesced.  Replaces an unfold of key_dim*d*d floats per
+// pixel (400 MB per 256^2 image).
+namespace dvm {
+namespace {
+constexpr int JT_W = 32, JT_H = 8;
+template <int KD, int D>
+__global__ __launch_bounds__(256) void jbu_kernel_kernel(const float *__restrict__ proj, const float *__restrict__ temp_p,
+                                                         const float *__restrict__ sigma_p, int H, int W, float *__restrict__ out) {
+    constexpr int R = D / 2, TAPS = D * D, LW = JT_W + 2 * R, LH = JT_H + 2 * R;
+    extern __shared__ float tile[];   // [KD][LH][LW]
+    const int tx = threadIdx.x & (JT_W - 1), ty = threadIdx.x / JT_W;
+    const int w0 = blockIdx.x * JT_W, h0 = blockIdx.y * JT_H, b = blockIdx.z;
+    const size_t plane = (size_t)H * W;
+    const float *pb = proj + (size_t)b * KD * plane;
+    for (int e = threadIdx.x; e < KD * LH * LW; e += 256) {
+        const int c = e / (LH * LW), r = e % (LH * LW), y = r / LW, x = r % LW;
+        int hh = h0 + y - R, ww = w0 + x - R;
+        hh = hh < 0 ? -hh : (hh >= H ? 2 * H - 2 - hh : hh);       // reflect (no edge repeat), like F.pad(mode='reflect')
+        ww = ww < 0 ? -ww : (ww >= W ? 2 * W - 2 - ww : ww);
+        hh = min(max(hh, 0), H - 1);                               // (rows / columns of a partial tile beyond the reflection)
+        ww = min(max(ww, 0), W - 1);
+        tile[e] = pb[c * plane + (size_t)hh * W + ww];
+    }
+    __syncthreads();
+    const int w = w0 + tx, h = h0 + ty;
+    if (w >= W || h >= H) return;
+    float q[KD];
+#pragma unroll
+    for (int c = 0; c < KD; ++c) q[c] = tile[(c * LH + ty + R) * LW + tx + R];
+    float temp = expf(*temp_p);
+    temp = fminf(fmaxf(temp, 1e-4f), 1e4f);
+    const float sig = *sigma_p, inv2s2 = 1.f / (2.f * sig * sig);
+    float logit[TAPS];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const float *nb = tile + (ty + i) * LW + tx + j;
+            float dot = 0.f;
+#pragma unroll
+            for (int c = 0; c < KD; ++c) dot = fmaf(q[c], nb[c * LH * LW], dot);
+            const float l = temp * dot;
+            logit[i * D + j] = l;
+            mx = fmaxf(mx, l);
+        }
+    float se = 0.f;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+        logit[t] = expf(logit[t] - mx);
+        se += logit[t];
+    }
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            // spatial kernel on linspace(-1, 1, D) coordinates
+            const float y = -1.f + 2.f * i / (D - 1), x = -1.f + 2.f * j / (D - 1);
+            const float v = (logit[i * D + j] / se) * expf(-(x * x + y * y) * inv2s2);
+            logit[i * D + j] = v;
+            tot += v;
+        }
+    const float inv = 1.f / fmaxf(tot, 1e-7f);
+    float *ob = out + (size_t)b * TAPS * plane + (size_t)h * W + w;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) ob[t * plane] = logit[t] * inv;
+}
+
+// Adaptive convolution, d = 7: 32 x 8 pixel tiles; a thread keeps its pixel's 49 weights in registers for all channels and
+// reads the inputs of 8 channels at a time from an LDS tile (the first version read weights from LDS and inputs from
+// L1 / L2: 12.5 ms per 24 x 384 x 256^2; the inputs' 49-fold reuse now stays inside the CU).
+constexpr int AT_CC = 8;
+__global__ __launch_bounds__(256) void adaptive_conv7_kernel(const float *__restrict__ in, const float *__restrict__ kern, int C, int H, int W,
+                                                             int kern_cm, int csplit, float *__restrict__ out) {
+    constexpr int D = 7, R = 3, LW = JT_W + 2 * R, LH = JT_H + 2 * R;
+    __shared__ float tile[AT_CC * LH * LW];
+    const int tx = threadIdx.x & (JT_W - 1), ty = threadIdx.x / JT_W;
+    const int w0 = blockIdx.x * JT_W, h0 = blockIdx.y * JT_H;
+    const int b = blockIdx.z / csplit, cs = blockIdx.z % csplit;
+    const int cper = (C + csplit - 1) / csplit, c_beg = cs * cper, c_end = min(C, c_beg + cper);
+    const int w = w0 + tx, h = h0 + ty, Wp = W + 2 * R, Hp = H + 2 * R;
+    const bool live = w < W && h < H;
+    float kw[D * D];
+    if (live) {
+#pragma unroll
+        for (int t = 0; t < D * D; ++t)
+            kw[t] = kern_cm ? kern[(((size_t)b * D * D + t) * H + h) * W + w] : kern[(((size_t)b * H + h) * W + w) * D * D + t];
+    }
+    for (int c0 = c_beg; c0 < c_end; c0 += AT_CC) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < AT_CC * LH * LW; e += 256) {
+            const int cc = e / (LH * LW), r = e % (LH * LW), y = r / LW, x = r % LW;
+            const int hh = h0 + y, ww = w0 + x;   // padded coordinates
+            tile[e] = (c0 + cc < c_end && hh < Hp && ww < Wp) ? in[(((size_t)b * C + c0 + cc) * Hp + hh) * Wp + ww] : 0.f;
+        }
+        __syncthreads();
+        if (live) {
+#pragma unroll
+            for (int cc = 0; cc < AT_CC; ++cc) {
+                if (c0 + cc >= c_end) break;
+                const float *tp = tile + (cc * LH + ty) * LW + tx;
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) acc = fmaf(tp[i * LW + j], kw[i * D + j], acc);
+                out[(((size_t)b * C + c0 + cc) * H + h) * W + w] = acc;
+            }
+        }
+    }
+}
+}  // namespace
+}  // namespace dvm
+
+DVM_EXPORT int dvm_jbu_kernel_f32(const float *proj, const float *range_temp, const float *sigma_spatial, int B, int key_dim, int H, int W, int d,
+                                  float *out, void *stream) {
+    DVM_REQUIRE(proj && range_temp && sigma_spatial && out, "dvm_jbu_kernel_f32: null pointer");
+    DVM_REQUIRE(B >= 1 && H >= 4 && W >= 4 && B <= 65535 && H <= 65535, "dvm_jbu_kernel_f32: bad sizes (B=%d H=%d W=%d)", B, H, W);
+    DVM_REQUIRE(key_dim == 32 && d == 7, "dvm_jbu_kernel_f32: only FeatUp's key_dim = 32, radius = 3 (got key_dim=%d d=%d)", key_dim, d);
+    const size_t lds = (size_t)32 * (dvm::JT_H + 6) * (dvm::JT_W + 6) * sizeof(float);
+    dvm::ensure_dyn_lds((const void *)dvm::jbu_kernel_kernel<32, 7>, (int)lds);
+    hipLaunchKernelGGL((dvm::jbu_kernel_kernel<32, 7>), dim3((W + dvm::JT_W - 1) / dvm::JT_W, (H + dvm::JT_H - 1) / dvm::JT_H, B), dim3(256), lds,
+                       (hipStream_t)stream, proj, range_temp, sigma_spatial, H, W, out);
+    DVM_CHECK_LAUNCH("jbu_kernel");
+    return DVM_OK;
+}
+
+DVM_EXPORT int dvm_adaptive_conv_f32(const float *in, const float *kern, int B, int C, int H, int W, int d, int kern_tap_major, float *out,
+                                     void *stream) {
+    DVM_REQUIRE(in && kern && out, "dvm_adaptive_conv_f32: null pointer");
+    DVM_REQUIRE(B >= 1 && C >= 1 && H >= 1 && W >= 1 && d >= 1 && d <= 15 && (d & 1), "dvm_adaptive_conv_f32: bad sizes (B=%d C=%d H=%d W=%d d=%d)", B,
+                C, H, W, d);
+    DVM_REQUIRE(B <= 65535 && H <= 65535, "dvm_adaptive_conv_f32: B or H exceeds the grid limit");
+    if (d == 7) {
+        const int tiles = ((W + dvm::JT_W - 1) / dvm::JT_W) * ((H + dvm::JT_H - 1) / dvm::JT_H) * B;
+        int csplit = 1;   // small maps: split the channels over more workgroups until the chip is covered
+        while (tiles * csplit < 1024 && csplit * 2 * dvm::AT_CC <= C) csplit *= 2;
+        DVM_REQUIRE((long)B * csplit <= 65535, "dvm_adaptive_conv_f32: B exceeds the grid limit");
+        hipLaunchKernelGGL(dvm::adaptive_conv7_kernel, dim3((W + dvm::JT_W - 1) / dvm::JT_W, (H + dvm::JT_H - 1) / dvm::JT_H, B * csplit),
+                           dim3(256), 0, (hipStream_t)stream, in, kern, C, H, W, kern_tap_major, csplit, out);
+        DVM_CHECK_LAUNCH("adaptive_conv7");
+        return DVM_OK;
+    }
+    const size_t lds = (size_t)d * d * dvm::AC_PIX * sizeof(float);
+    hipLaunchKernelGGL(dvm::adaptive_conv_kernel, dim3((W + dvm::AC_PIX - 1) / dvm::AC_PIX, H, B), dim3(dvm::AC_PIX * dvm::AC_CL), lds,
+                       (hipStream_t)stream, in, kern, C, H, W, d, kern_tap_major, out);
+    DVM_CHECK_LAUNCH("adaptive_conv");
+    return DVM_OK;
+}

@@ -71,6 +71,9 @@ SIGNATURES = {
     "dvm_proj2img_workspace_bytes": (c_size_t, [c_int]),
     "dvm_proj2img_f32": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
     "dvm_i2p_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),
+    "dvm_adaptive_conv_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "dvm_bicubic_resize_pad_f32": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "dvm_jbu_kernel_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "dvm_sa_attention_workspace_bytes": (c_size_t, [c_int, c_int]),
     "dvm_sa_attention_fwd_f32": (c_int, [_P, _P, c_int, c_int, _P, _P, c_size_t, _P]),
     "dvm_n2p_attention_fwd_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),

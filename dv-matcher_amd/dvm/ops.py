@@ -587,6 +587,49 @@ def i2p(pts, f, pc_min, grid, offsets, normalize=False, out=None, col=0):
     return out
 
 
+def adaptive_conv(x_padded, kernel, tap_major=False):
+    """FeatUp's AdaptiveConv: x_padded (B,C,H+d-1,W+d-1), kernel (B,H,W,d,d) — or (B,d*d,H,W) with tap_major — -> (B,C,H,W)."""
+    _need_gpu(x_padded, kernel)
+    x_padded, kernel = _f(x_padded), _f(kernel)
+    B, C, Hp, Wp = x_padded.shape
+    if tap_major:
+        _, d2, H, W = kernel.shape
+        d = int(round(d2 ** 0.5))
+        ok = d * d == d2
+    else:
+        _, H, W, d, dd = kernel.shape
+        ok = d == dd
+    if not ok or Hp != H + d - 1 or Wp != W + d - 1 or kernel.shape[0] != B:
+        raise DvmError("adaptive_conv: shapes %s and %s do not match" % (tuple(x_padded.shape), tuple(kernel.shape)))
+    out = torch.empty(B, C, H, W, dtype=torch.float32, device=x_padded.device)
+    check(_lib.load().dvm_adaptive_conv_f32(_p(x_padded), _p(kernel), B, C, H, W, d, 1 if tap_major else 0, _p(out), _stream()),
+          "dvm_adaptive_conv_f32")
+    return out
+
+
+def bicubic_resize_pad(x, size, pad=0):
+    """F.pad(F.interpolate(x, size, mode='bicubic', align_corners=False), [pad]*4, mode='reflect') in one kernel:
+    x (B,C,Hi,Wi) -> (B,C,Ho+2pad,Wo+2pad)."""
+    _need_gpu(x)
+    x = _f(x)
+    B, C, Hi, Wi = x.shape
+    Ho, Wo = size
+    out = torch.empty(B, C, Ho + 2 * pad, Wo + 2 * pad, dtype=torch.float32, device=x.device)
+    check(_lib.load().dvm_bicubic_resize_pad_f32(_p(x), B * C, Hi, Wi, Ho, Wo, pad, _p(out), _stream()), "dvm_bicubic_resize_pad_f32")
+    return out
+
+
+def jbu_kernel(proj, range_temp, sigma_spatial, d=7):
+    """Normalised range x spatial kernel of a joint-bilateral stage: proj (B,32,H,W) -> (B,d*d,H,W) (dvm_jbu_kernel_f32)."""
+    _need_gpu(proj, range_temp, sigma_spatial)
+    proj = _f(proj)
+    B, Kd, H, W = proj.shape
+    out = torch.empty(B, d * d, H, W, dtype=torch.float32, device=proj.device)
+    check(_lib.load().dvm_jbu_kernel_f32(_p(proj), _p(_f(range_temp)), _p(_f(sigma_spatial)), B, Kd, H, W, d, _p(out), _stream()),
+          "dvm_jbu_kernel_f32")
+    return out
+
+
 def sa_attention_pm(p, v):
     """point-major p (B,N,16), v (B,N,64) -> x_r (B,N,64)."""
     _need_gpu(p, v)

@@ -265,6 +265,26 @@ size_t dvm_proj2img_workspace_bytes(int B);
 int dvm_proj2img_f32(const float *pts, int B, int N, float *img, float *pc_min, float *grid_size, float *offsets, void *ws,
                      size_t ws_bytes, void *stream);
 
+/* The per-pixel filtering step of the FeatUp joint-bilateral upsampler that stands between proj2img and I2P (the
+ * `upsampler` of models/model.py:693, train.py:72; FeatUp's `AdaptiveConv` CUDA op):
+ *   out[b,c,h,w] = sum_{i,j<d} in[b,c,h+i,w+j] * kern[b,h,w,i,j]
+ * in [B,C,H+d-1,W+d-1] (the padded, bicubically upsampled features), kern [B,H,W,d,d] — or [B,d*d,H,W] when
+ * kern_tap_major != 0 —, out [B,C,H,W]; d odd, <= 15. */
+int dvm_adaptive_conv_f32(const float *in, const float *kern, int B, int C, int H, int W, int d, int kern_tap_major, float *out,
+                          void *stream);
+
+/* F.interpolate(x, size=(Ho,Wo), mode='bicubic', align_corners=False) followed by F.pad(.., [pad]*4, mode='reflect') in
+ * one pass (the high-resolution source of a joint-bilateral stage): in [BC,Hi,Wi] -> out [BC,Ho+2*pad,Wo+2*pad]. */
+int dvm_bicubic_resize_pad_f32(const float *in, int BC, int Hi, int Wi, int Ho, int Wo, int pad, float *out, void *stream);
+
+/* The combined range x spatial kernel of one joint-bilateral stage, before its learned correction (FeatUp
+ * JBULearnedRange: get_range_kernel, get_spatial_kernel and their normalised product): for pixel p and tap t of the
+ * d x d window (reflect padding)  k[p,t] ~ softmax_t(exp(range_temp) * <proj[p], proj[p+t]>) * exp(-|t|^2 / (2 sigma^2)),
+ * normalised over t.  proj [B,key_dim,H,W] (the guidance image through range_proj); range_temp, sigma_spatial: device
+ * scalars (the module's parameters); out [B,d*d,H,W].  key_dim = 32, d = 7 (FeatUp's JBU stack). */
+int dvm_jbu_kernel_f32(const float *proj, const float *range_temp, const float *sigma_spatial, int B, int key_dim, int H, int W, int d,
+                       float *out, void *stream);
+
 /* Uni3FC.I2P (+ F.normalize) — models/model.py:653-678, 701-708.  f [B,C,H,W] image features; for every point the
  * bicubic (A=-0.75, align_corners=False) resample of f to 224x224 is evaluated ONLY at the point's pixel — the
  * (B,C,224,224) resized tensor is never built — and written to out[b,i,0:C] (row stride ldo >= C floats, so the three

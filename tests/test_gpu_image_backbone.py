@@ -1,0 +1,111 @@
+"""-m gpu: the image backbone of the visual-feature injection path (BASELINE configs[4]) — a random-init
+DINOv2 ViT-S/14 + FeatUp JBU stack (parity unpinned for the network: its packages and weights are not in the reference
+tree; see models/image_backbone.py) — and `Uni3FC.forward(x, None, upsampler)` end to end."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def test_adaptive_conv_matches_unfold():
+    from dvm import ops
+    g = torch.Generator().manual_seed(0)
+    for (B, C, H, W, d) in [(2, 5, 9, 70, 7), (1, 384, 32, 32, 7), (3, 4, 17, 130, 3)]:
+        x = torch.randn(B, C, H + d - 1, W + d - 1, generator=g).cuda()
+        k = torch.randn(B, H, W, d, d, generator=g).cuda()
+        out = ops.adaptive_conv(x, k)
+        win = F.unfold(x.double(), d).view(B, C, d * d, H, W)
+        ref = (win * k.double().reshape(B, 1, H, W, d * d).permute(0, 1, 4, 2, 3)).sum(2)
+        assert (out.double() - ref).abs().max() < 2e-5 * (1 + ref.abs().max())
+
+
+def test_adaptive_conv_tap_major_and_fused_jbu_kernel():
+    from dvm import ops
+    from models.image_backbone import JBULearnedRange
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 6, 20 + 6, 33 + 6, generator=g).cuda()
+    k = torch.randn(2, 20, 33, 7, 7, generator=g).cuda()
+    assert torch.equal(ops.adaptive_conv(x, k), ops.adaptive_conv(x, k.reshape(2, 20, 33, 49).permute(0, 3, 1, 2).contiguous(), tap_major=True))
+    torch.manual_seed(9)
+    jbu = JBULearnedRange(3, 16, 32, radius=3).cuda().eval()
+    with torch.no_grad():
+        jbu.range_temp.fill_(0.7)
+        jbu.sigma_spatial.fill_(0.8)
+        for (B, H, W) in [(2, 32, 32), (1, 37, 70), (1, 8, 5)]:
+            guid = torch.rand(B, 3, H, W, generator=g).cuda() * 2 - 1
+            ref = jbu.combined_kernel_torch(guid)
+            got = ops.jbu_kernel(jbu.range_proj(guid), jbu.range_temp, jbu.sigma_spatial)
+            assert got.shape == ref.shape and (got - ref).abs().max() < 2e-6, (got - ref).abs().max()
+
+
+def test_bicubic_resize_pad_matches_torch():
+    from dvm import ops
+    g = torch.Generator().manual_seed(6)
+    for (B, C, Hi, Wi, Ho, Wo, pad) in [(2, 5, 16, 16, 32, 32, 3), (1, 3, 9, 13, 18, 26, 3), (1, 2, 7, 5, 224, 224, 0), (1, 4, 128, 128, 256, 256, 3)]:
+        x = torch.randn(B, C, Hi, Wi, generator=g).cuda()
+        ref = F.interpolate(x, size=(Ho, Wo), mode="bicubic", align_corners=False)
+        if pad:
+            ref = F.pad(ref, [pad] * 4, mode="reflect")
+        got = ops.bicubic_resize_pad(x, (Ho, Wo), pad)
+        assert got.shape == ref.shape and (got - ref).abs().max() < 1e-5, (got - ref).abs().max()
+
+
+def test_jbu_stage_fused_equals_plain_torch():
+    """One JBU stage through the HIP kernels (1x1 convs on dvm_linear_f32, fused range/spatial kernel, fused resize + pad,
+    adaptive convolution) against the same stage in plain torch ops."""
+    from models.image_backbone import JBULearnedRange
+    torch.manual_seed(11)
+    jbu = JBULearnedRange(3, 24, 32, radius=3).cuda().eval()
+    g = torch.Generator().manual_seed(12)
+    src = torch.randn(2, 24, 16, 16, generator=g).cuda()
+    guid = torch.rand(2, 3, 32, 32, generator=g).cuda() * 2 - 1
+    with torch.no_grad():
+        fused = jbu(src, guid)
+        k = jbu.combined_kernel_torch(guid)
+        k = k + 0.1 * jbu.fixup_proj(torch.cat([k, guid], dim=1))
+        hr = F.pad(F.interpolate(src, size=(32, 32), mode="bicubic", align_corners=False), [3] * 4, mode="reflect")
+        win = F.unfold(hr, 7).view(2, 24, 49, 32, 32)
+        ref = (win * k.unsqueeze(1)).sum(2)
+    assert (fused - ref).abs().max() < 1e-4, (fused - ref).abs().max()
+
+
+def test_upsampler_interface_and_state_dict_layout():
+    from models.image_backbone import load_upsampler
+    up = load_upsampler(seed=3)
+    keys = list(up.state_dict().keys())
+    # the hub model's layout: ViT under model.0.model, ChannelNorm under model.1.norm, 4 JBU stages + fixup under upsampler
+    for k in ("model.0.model.cls_token", "model.0.model.pos_embed", "model.0.model.patch_embed.proj.weight",
+              "model.0.model.blocks.11.attn.qkv.weight", "model.0.model.blocks.0.ls1.gamma", "model.0.model.blocks.5.mlp.fc2.bias",
+              "model.0.model.norm.weight", "model.1.norm.weight", "upsampler.up1.range_temp", "upsampler.up4.range_proj.3.weight",
+              "upsampler.up2.fixup_proj.0.weight", "upsampler.up3.sigma_spatial", "upsampler.fixup_proj.1.weight"):
+        assert k in keys, k
+    sd = up.state_dict()
+    assert tuple(sd["model.0.model.pos_embed"].shape) == (1, 1370, 384) and tuple(sd["model.0.model.blocks.0.attn.qkv.weight"].shape) == (1152, 384)
+    assert sum(v.numel() for k, v in sd.items() if k.startswith("model.0.model.")) == 22056576      # ViT-S/14 (with mask token): 22.06 M
+    img = torch.rand(3, 3, 224, 224, generator=torch.Generator().manual_seed(1)).cuda() * 2 - 1
+    out = up(img)
+    assert out.shape == (3, 384, 256, 256) and bool(torch.isfinite(out).all())
+    again = up(img)
+    assert torch.equal(out, again)                                    # eval mode: dropout off, deterministic
+    one = up(img[:1])
+    assert (one - out[:1]).abs().max() < 1e-3                         # batch-independent (up to GEMM tile choices)
+
+
+def test_uni3fc_forward_without_precomputed_features():
+    """BASELINE configs[4]: Uni3FC.forward(x, None, upsampler) — three depth renderings per shape, image backbone,
+    back-projection, LG-Net — runs end to end and equals feeding the same visual features explicitly."""
+    import models.model as mm
+    from models.image_backbone import load_upsampler
+    up = load_upsampler(seed=5)
+    net = mm.Uni3FC(k=40).cuda().eval()
+    g = torch.Generator().manual_seed(2)
+    x = (torch.rand(2, 3, 1024, generator=g) - 0.5).cuda()
+    with torch.no_grad():
+        feat, cf = net(x, None, up)
+        dino = net.visual_features(x, up)
+        feat2, _ = net(x, dino, None)
+    assert feat.shape == (2, 1024, 128) and dino.shape == (2, 1024, 1152) and bool(torch.isfinite(feat).all())
+    assert torch.equal(feat, feat2)
+    np.testing.assert_allclose(dino.norm(dim=-1).cpu().numpy(), np.sqrt(3.0), rtol=1e-4)   # three L2-normalised 384-d blocks
