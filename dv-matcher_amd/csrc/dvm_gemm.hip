@@ -14,7 +14,7 @@
 //   point-major   (inference):        P = x [B*N][K],  Q = w [Co][K] (also K-contiguous), y [B*N][Co]
 //   channel-major (training forward): P = w [Co][K],   Q = x[b] [K][N] (N-contiguous),    y [b][Co][N]
 // A workgroup = 4 waves, each wave TM x TN accumulator tiles of 32x32 (16 VGPRs each); k-step 32 staged
-// through LDS with the even / odd k of a row de-interleaved so that a lane's half-wave (k parity) reads its
+// through two alternating LDS buffers with the even / odd k of a row de-interleaved so that a lane's half-wave (k parity) reads its
 // four next operands with one ds_read_b128; the next k-step's global loads are in flight during the MFMAs.
 // The fp32 matrix instruction issues at the vector rate (64 cycles per 32x32x2), so LDS and global traffic
 // are far below their limits: the kernel is bound by MFMA issue.
@@ -66,8 +66,9 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a) {
     constexpr int QSZ = CM ? GK * BN : BN * GLD;
     constexpr int PL = BM / 32;                     // f32x4 chunks of P per thread and k-step
     constexpr int QL = CM ? (GK * BN / 4) / 256 : BN / 32;
-    __shared__ __attribute__((aligned(16))) float Ps[BM * GLD];
-    __shared__ __attribute__((aligned(16))) float Qs[QSZ];
+    // two LDS buffers per operand: the next k-step is written while the current one is read, one barrier per step
+    extern __shared__ __attribute__((aligned(16))) float lds_gemm[];
+    float *const Ps0 = lds_gemm, *const Qs0 = lds_gemm + 2 * BM * GLD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r32 = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     // XCD-aware tile order: the workgroups of one XCD (blockIdx % 8) walk consecutive tiles, column tiles of a row
@@ -140,7 +141,44 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a) {
             }
         }
     };
-    auto stage = [&]() {
+    // Fast path of the fetch: per-thread row pointers made once; a k-step then costs one 16-byte load per chunk and no
+    // address arithmetic or bounds test (the guarded lambda above compiles to ~30 VALU + 20 SALU and a branch per chunk —
+    // as much issue time as the step's 16 matrix instructions, which share the vector issue slot on gfx950).  Rows beyond
+    // the matrix are clamped to its last row: their products land in accumulator rows the epilogue never stores.
+    const float *pfast[PL], *gfast[PL], *qfast[QL];
+#pragma unroll
+    for (int u = 0; u < PL; ++u) {
+        const int r = (tid >> 3) + 32 * u, c = tid & 7;
+        const int i = i0 + r < I ? i0 + r : I - 1;
+        pfast[u] = P + (size_t)i * a.ldp - (CM ? 0 : a.Cg) + 4 * c;
+        gfast[u] = (!CM && a.G) ? a.G + (size_t)(i / a.Nrow) * a.Cg + 4 * c : pfast[u];
+    }
+#pragma unroll
+    for (int u = 0; u < QL; ++u) {
+        if (CM) {
+            const int e = tid + 256 * u, kk = e / (BN / 4), c = e % (BN / 4);
+            qfast[u] = Q + (size_t)kk * J + j0 + 4 * c;
+        } else {
+            const int r = (tid >> 3) + 32 * u, c = tid & 7;
+            const int j = j0 + r < J ? j0 + r : J - 1;
+            qfast[u] = Q + (size_t)j * K + 4 * c;
+        }
+    }
+    const bool q_interior = !CM || (a.qvec && j0 + BN <= J);
+    auto fetch_step = [&](int k0, int kend) {
+        const int Cg = CM ? 0 : a.Cg;
+        if (a.kvec && q_interior && k0 + GK <= kend && (k0 >= Cg || k0 + GK <= Cg)) {
+            const bool in_prefix = k0 < Cg;
+#pragma unroll
+            for (int u = 0; u < PL; ++u) pp[u] = *(const f32x4 *)((in_prefix ? gfast[u] : pfast[u]) + k0);
+#pragma unroll
+            for (int u = 0; u < QL; ++u) pq[u] = *(const f32x4 *)(qfast[u] + (CM ? (size_t)k0 * J : (size_t)k0));
+        } else {
+            fetch(k0, kend);
+        }
+    };
+    auto stage = [&](int buf) {
+        float *const Ps = Ps0 + buf * BM * GLD, *const Qs = Qs0 + buf * QSZ;
 #pragma unroll
         for (int u = 0; u < PL; ++u) {
             const int r = (tid >> 3) + 32 * u, c = tid & 7;
@@ -174,14 +212,23 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a) {
             for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
     float *__restrict__ Y = a.Y + (size_t)b * a.y_bs;
 
-    for (int blk = 0; blk < a.nkb; ++blk) {
-        const int kbeg = a.kb[blk], kend = a.kb[blk + 1];
-        fetch(kbeg, kend);
-        for (int k0 = kbeg; k0 < kend; k0 += GK) {
-            __syncthreads();
-            stage();
-            __syncthreads();
-            if (k0 + GK < kend) fetch(k0 + GK, kend);
+    // Flat walk over the k-steps of all K-blocks.  Step s+1's global loads are issued before step s's MFMAs and written to
+    // the other LDS buffer after them; the single barrier at the end of a step both publishes that buffer and retires the
+    // reads of the current one.
+    int blk = 0, k0 = a.kb[0], cur = 0;
+    fetch_step(k0, a.kb[1]);
+    stage(0);
+    __syncthreads();
+    while (blk < a.nkb) {
+        int nblk = blk, nk = k0 + GK;
+        if (nk >= a.kb[blk + 1]) {
+            ++nblk;
+            nk = a.kb[nblk];     // (kb[nkb] == K: unused when nblk == nkb)
+        }
+        const bool has_next = nblk < a.nkb;
+        if (has_next) fetch_step(nk, a.kb[nblk + 1]);
+        {
+            const float *const Ps = Ps0 + cur * BM * GLD, *const Qs = Qs0 + cur * QSZ;
 #pragma unroll
             for (int cc = 0; cc < GK / 8; ++cc) {
                 // the inner loop is MFMA + ds_read only: on gfx950 the fp32 matrix instruction and the vector ALU share the
@@ -205,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a) {
                 }
             }
         }
-        if (a.nkb > 1) {
+        if (a.nkb > 1 && nblk != blk) {
             // close the block: total += block, restart the chain at 0.  The running total lives in the output buffer
             // between blocks (every lane re-reads exactly the words it wrote) instead of a second accumulator set — 16
             // registers per tile that the large tiles do not have; 2 extra passes over the output at K = 1152.
@@ -231,6 +278,11 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a) {
                     }
                 }
         }
+        if (has_next) stage(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+        blk = nblk;
+        k0 = nk;
     }
 
     // epilogue: conv bias (added after the chain, as oneDNN does), residual, y = fma(y, alpha, beta) (ATen's eval-mode
@@ -271,7 +323,10 @@ static void launch_cfg(LinArgs &a, int B, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     a.tiles_i = (a.I + BM - 1) / BM;
     a.tiles_j = (a.J + BN - 1) / BN;
-    hipLaunchKernelGGL((linear_mfma_kernel<CM, WM, WN, TM, TN>), dim3((unsigned)(a.tiles_i * a.tiles_j), (unsigned)B), dim3(256), 0, s, a);
+    constexpr int QSZ = CM ? GK * BN : BN * GLD;
+    constexpr size_t lds = (size_t)2 * (BM * GLD + QSZ) * sizeof(float);
+    ensure_dyn_lds((const void *)linear_mfma_kernel<CM, WM, WN, TM, TN>, (int)lds);
+    hipLaunchKernelGGL((linear_mfma_kernel<CM, WM, WN, TM, TN>), dim3((unsigned)(a.tiles_i * a.tiles_j), (unsigned)B), dim3(256), lds, s, a);
 }
 
 // Tile choice (measured on MI355X at 16384 points, tools/bench_linear_cfg.py; us for conv 1152->384 / conv0 384->64 /

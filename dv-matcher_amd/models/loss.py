@@ -109,6 +109,14 @@ class GraphDeformLoss_Neural(nn.Module):
         self.save_name = save_name
         self.dump = dump  # the reference writes 4 OFF files + a print per deform() call; opt-in here
 
+    def _identity6(self, device):
+        """[1,0,0,0,1,0]: the identity rotation in the 6D parametrisation (models/loss.py:1258-1262), made once per device."""
+        key = str(device)
+        cache = self.__dict__.setdefault("_iden6", {})
+        if key not in cache:
+            cache[key] = torch.tensor([1, 0, 0, 0, 1, 0], dtype=torch.float32, device=device)
+        return cache[key]
+
     # ---- pieces with the reference's names -------------------------------------------------
     def chamfer_loss(self, pos1, pos2):
         d1, d2, _, _ = ops.chamfer(pos1, pos2, want_idx=False)
@@ -139,8 +147,7 @@ class GraphDeformLoss_Neural(nn.Module):
         pval, pidx, _, _ = ops.softcorr(feat1, feat2, alpha, topk=10, stats=False)
         verts12 = ops.apply(pval, pidx, verts2)
         def9 = deformer.forward_sparse(feat1, feat2, verts1, verts12, idx11, idx22, pval, pidx, g1["nodes_idx"])
-        iden = torch.tensor([1, 0, 0, 0, 1, 0], dtype=torch.float32, device=def9.device)
-        R = rotation_6d_to_matrix(def9[..., 3:] + iden)
+        R = rotation_6d_to_matrix(def9[..., 3:] + self._identity6(def9.device))
         warped, arap, _ = ops.dg_warp_arap(verts1, g1, R, def9[..., :3].contiguous())
         cd_warp = self.chamfer_loss(warped, verts2)
         cd_self = self.chamfer_loss(verts12, verts2)
@@ -169,8 +176,7 @@ class GraphDeformLoss_Neural(nn.Module):
         pick = lambda t: torch.gather(t, 1, fps.expand(-1, -1, t.shape[-1]))  # noqa: E731
         z = torch.cat([pick(verts1), pick(g1p), pick(verts12), pick(g2t)], dim=-1)
         def9 = deformer.deformation_decoder_layer(z)
-        iden = torch.tensor([1, 0, 0, 0, 1, 0], dtype=torch.float32, device=def9.device)
-        R = nn_ops.rot6d(def9[..., 3:] + iden)
+        R = nn_ops.rot6d(def9[..., 3:] + self._identity6(def9.device))
         warped, arap = nn_ops.dg_warp_arap(verts1, g1, R, def9[..., :3])
         cd_warp = self._chamfer_train(warped, verts2)
         cd_self = self._chamfer_train(verts12, verts2)
@@ -205,8 +211,9 @@ class GraphDeformLoss_Neural(nn.Module):
         if self.w_dist > 0:
             if anchors is None:
                 anchors = (random.sample(range(dist1.shape[1]), self.N_dist), random.sample(range(dist2.shape[1]), self.N_dist))
-            a1 = torch.as_tensor(np.asarray(anchors[0]), device=feat1.device)
-            a2 = torch.as_tensor(np.asarray(anchors[1]), device=feat2.device)
+            # (device tensors pass through untouched: no host-to-device copy inside a captured step)
+            a1 = anchors[0] if torch.is_tensor(anchors[0]) and anchors[0].is_cuda else torch.as_tensor(np.asarray(anchors[0]), device=feat1.device)
+            a2 = anchors[1] if torch.is_tensor(anchors[1]) and anchors[1].is_cuda else torch.as_tensor(np.asarray(anchors[1]), device=feat2.device)
             self.dist_loss = (dist_term(feat1, dist1, a1) + dist_term(feat2, dist2, a2)) * self.w_dist
             loss = loss + self.dist_loss
             self._sum_part = self._sum_part + self.dist_loss

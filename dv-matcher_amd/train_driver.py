@@ -176,6 +176,8 @@ def main(argv=None):
     ap.add_argument("--points", type=int, default=1024, help="source points N")
     ap.add_argument("--points-target", type=int, default=None, help="target points M (default: N; with --partial 0.44 N like 4995 / 2200)")
     ap.add_argument("--epoch", type=int, default=1, help="timing mode: which epoch's alpha / lr to use (1-based)")
+    ap.add_argument("--graph", action="store_true", help="timing mode, one rank: capture the whole step (forward, criterion, backward, "
+                    "Adam) into ONE HIP graph and replay it — ~2000 kernel launches per step become one graph launch")
     ap.add_argument("--sync-stats", action="store_true", help="DDP: BatchNorm statistics and the positional encoding's min/max "
                     "over the GLOBAL batch (SyncBatchNorm + two scalar all-reduces)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
@@ -210,10 +212,13 @@ def main(argv=None):
         net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)
         net.sync_minmax = True
     params = list(net.parameters()) + list(dfm.parameters())
-    opt = torch.optim.Adam(params, lr=float(cfg["optimizer"]["lr"]), betas=(cfg["optimizer"]["b1"], cfg["optimizer"]["b2"]))
+    use_graph = bool(args.graph) and world == 1 and args.epochs <= 0
+    opt = torch.optim.Adam(params, lr=float(cfg["optimizer"]["lr"]), betas=(cfg["optimizer"]["b1"], cfg["optimizer"]["b2"]),
+                           capturable=use_graph)
     # world > 1: every p.grad is a view into one flat buffer (one all-reduce, no pack/unpack); a single rank has nothing to
-    # exchange and lets autograd hand Adam its gradient tensors directly
-    bucket = FlatGradBucket(params, attach=world > 1)
+    # exchange and lets autograd hand Adam its gradient tensors directly — unless the step is captured into a graph, whose
+    # gradient tensors must keep their addresses
+    bucket = FlatGradBucket(params, attach=world > 1 or use_graph)
     random.seed(seed_py)
     torch.manual_seed(seed_torch)
     timing = args.epochs <= 0
@@ -272,6 +277,39 @@ def main(argv=None):
         else:   # every rank owns its own Bg/world pairs (weak-scaling shape of the forward bench)
             feed = [train_set.batch(list(range(lo, hi)) if train_set.pairs >= Bg else list(range(hi - lo)))]
         losses = []
+        if use_graph:
+            # every draw the criterion makes on the host (dist-loss anchors, FPS starts) becomes a device-resident input of
+            # the captured step; a training loop would refresh them with copy_() between replays
+            batch = feed[0]
+            n1, n2 = batch[0].shape[1], batch[1].shape[1]
+            anchors = tuple(torch.as_tensor(random.sample(range(n), crit.N_dist), device=dev) for n in (n1, n2))
+            starts = tuple(torch.randint(0, n, (hi - lo,), device=dev) for n in (n1, n2))
+
+            def graph_step():
+                v1, v2, d1, d2, dist1, dist2 = batch
+                f1, _ = net(v1.permute(0, 2, 1), d1, None)
+                f2, _ = net(v2.permute(0, 2, 1), d2, None)
+                out = crit(f1, f2, dist1, dist2, v1, v2, alpha, dfm, fps_starts=starts, anchors=anchors)
+                out[0].backward()
+                vals = torch.stack([torch.as_tensor(o, device=dev).detach().float().reshape(()) for o in out])
+                opt.step()
+                bucket.zero()
+                return vals
+
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(max(3, args.warmup)):
+                    graph_step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_vals = graph_step()
+
+            def train_step(_batch, _alpha):   # noqa: F811  (the replay stands in for the eager step)
+                graph.replay()
+                return static_vals.clone()
         for i in range(args.warmup):
             train_step(feed[i % len(feed)], alpha)
         torch.cuda.synchronize()
@@ -293,6 +331,7 @@ def main(argv=None):
             print(json.dumps({"metric": "training pairs/sec (fwd+loss+bwd+Adam)", "value": Bg * args.steps / dt, "unit": "pairs/s",
                               "n_gpus": world, "steps": args.steps, "ms_per_step": dt / args.steps * 1e3, "global_batch": Bg,
                               "points": N, "points_target": M, "criterion": type(crit).__name__, "alpha": float(alpha),
+                              "hip_graph": use_graph,
                               "grad_bucket_floats": bucket.numel, "first_losses": losses[0], "last_losses": losses[-1]}))
         if world > 1:
             dist.destroy_process_group()
