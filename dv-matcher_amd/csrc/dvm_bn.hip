@@ -170,6 +170,175 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restri
     }
 }
 
+// ---------------------------------------------------------------- point-major (rows x C) variants
+// The training path keeps activations point-major [B*N][C] (the layout of the attention / kNN kernels and of
+// dvm_linear_f32's inference mode), so that no transposes sit between the operators.  Same arithmetic as above: fp64
+// (sum, sum of squares) per channel in a fixed order (row chunk by row chunk), one elementwise pass.
+constexpr int PM_CG = 8, PM_SL = 32;   // finalize kernels: 8 channels per workgroup, 32 lanes over the partials of each
+
+// grid (S, C / CG): rows [s * chunk, (s+1) * chunk) of one group of CG channels (pm_group_for: 128, 64 or all of them).
+// A thread owns 4 consecutive channels (one 16-byte load per operand and row) of every RPP-th row, RPP = 256 / (CG/4)
+// rows per pass; partial[(s * C + c) * 2 + {0,1}].
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_pm_reduce_kernel(const float *__restrict__ x, const float *__restrict__ res,
+                                                           const float *__restrict__ dy, const float *__restrict__ y,
+                                                           const float *__restrict__ mean, const float *__restrict__ invstd /* BWD */, long R,
+                                                           int C, int CG, long chunk, float slope, double *__restrict__ partial) {
+    __shared__ double sa[1024], sq[1024];     // [rl][c], RPP * CG <= 1024
+    const int C4 = CG >> 2, RPP = 256 / C4;
+    const int c4 = threadIdx.x % C4, rl = threadIdx.x / C4, cl = c4 * 4, c = blockIdx.y * CG + cl;
+    const long lo = (long)blockIdx.x * chunk, hi = lo + chunk < R ? lo + chunk : R;
+    double da[4] = {0.0, 0.0, 0.0, 0.0}, dq[4] = {0.0, 0.0, 0.0, 0.0};
+    if (rl < RPP) {
+        f32x4 mf = {0.f, 0.f, 0.f, 0.f}, is = mf;
+        if (BWD) mf = *(const f32x4 *)(mean + c), is = *(const f32x4 *)(invstd + c);
+        auto body = [&](long r) {
+            const size_t off = (size_t)r * C + c;
+            f32x4 v = *(const f32x4 *)(x + off);
+            if (res) v += *(const f32x4 *)(res + off);
+            if (BWD) {
+                const f32x4 g4 = *(const f32x4 *)(dy + off), y4 = *(const f32x4 *)(y + off);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float dz = g4[k] * (y4[k] > 0.f ? 1.f : slope);
+                    da[k] += (double)dz;
+                    dq[k] = fma((double)dz, (double)((v[k] - mf[k]) * is[k]), dq[k]);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    da[k] += (double)v[k];
+                    dq[k] = fma((double)v[k], (double)v[k], dq[k]);
+                }
+            }
+        };
+        long r = lo + rl;
+        for (; r + 3L * RPP < hi; r += 4L * RPP) {   // 4 rows in flight
+            body(r);
+            body(r + RPP);
+            body(r + 2L * RPP);
+            body(r + 3L * RPP);
+        }
+        for (; r < hi; r += RPP) body(r);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sa[rl * CG + cl + k] = da[k], sq[rl * CG + cl + k] = dq[k];
+    }
+    __syncthreads();
+    for (int cc = threadIdx.x; cc < CG; cc += 256) {
+        double ta = 0.0, tq = 0.0;
+        for (int q = 0; q < RPP; ++q) ta += sa[q * CG + cc], tq += sq[q * CG + cc];
+        const size_t o = ((size_t)blockIdx.x * C + blockIdx.y * CG + cc) * 2;
+        partial[o] = ta;
+        partial[o + 1] = tq;
+    }
+}
+
+// sum of the S partials of 8 channels by one workgroup (32 lanes per channel, fixed order) -> (ta, tq) in lanes sl == 0
+__device__ inline bool pm_sum_partials(const double *__restrict__ partial, int S, int C, int c, int cl, int sl, double &ta, double &tq) {
+    __shared__ double pa[PM_SL][PM_CG], pq[PM_SL][PM_CG];
+    double a = 0.0, q = 0.0;
+    if (c < C)
+        for (int s = sl; s < S; s += PM_SL) {
+            const double2 v = *(const double2 *)(partial + ((size_t)s * C + c) * 2);
+            a += v.x, q += v.y;
+        }
+    pa[sl][cl] = a, pq[sl][cl] = q;
+    __syncthreads();
+    if (sl != 0 || c >= C) return false;
+    ta = 0.0, tq = 0.0;
+#pragma unroll
+    for (int k = 0; k < PM_SL; ++k) ta += pa[k][cl], tq += pq[k][cl];
+    return true;
+}
+
+// grid (ceil(C / 8)) x 256 threads: partials -> fin[c] = {mean, invstd, gamma * invstd, beta} (forward; + running
+// statistics) or {mean(dz), mean(dz xhat), gamma * invstd, -} (backward; + dgamma, dbeta)
+__global__ __launch_bounds__(256) void bn_pm_finalize_fwd_kernel(const double *__restrict__ partial, int S, long R, int C,
+                                                                 const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                                                 float momentum, float *__restrict__ fin, float *__restrict__ mean_out,
+                                                                 float *__restrict__ invstd_out, float *__restrict__ running_mean,
+                                                                 float *__restrict__ running_var) {
+    const int cl = threadIdx.x & (PM_CG - 1), sl = threadIdx.x / PM_CG, c = blockIdx.x * PM_CG + cl;
+    double ta, tq;
+    if (!pm_sum_partials(partial, S, C, c, cl, sl, ta, tq)) return;
+    const double mean = ta / (double)R;
+    double var = tq / (double)R - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps)), mf = (float)mean;
+    mean_out[c] = mf;
+    invstd_out[c] = invstd;
+    if (running_mean) {
+        const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mf;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+    fin[c * 4] = mf;
+    fin[c * 4 + 1] = invstd;
+    fin[c * 4 + 2] = (gamma ? gamma[c] : 1.f) * invstd;
+    fin[c * 4 + 3] = beta ? beta[c] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void bn_pm_finalize_bwd_kernel(const double *__restrict__ partial, int S, long R, int C,
+                                                                 const float *__restrict__ gamma, const float *__restrict__ mean,
+                                                                 const float *__restrict__ invstd, float *__restrict__ fin,
+                                                                 float *__restrict__ dgamma, float *__restrict__ dbeta, int accumulate) {
+    const int cl = threadIdx.x & (PM_CG - 1), sl = threadIdx.x / PM_CG, c = blockIdx.x * PM_CG + cl;
+    double ta, tq;
+    if (!pm_sum_partials(partial, S, C, c, cl, sl, ta, tq)) return;
+    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)tq;
+    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)ta;
+    fin[c * 4] = (float)(ta / (double)R);
+    fin[c * 4 + 1] = (float)(tq / (double)R);
+    fin[c * 4 + 2] = (gamma ? gamma[c] : 1.f) * invstd[c];
+    fin[c * 4 + 3] = 0.f;
+}
+
+// elementwise pass, 4 consecutive channels per thread (C % 4 == 0)
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_pm_apply_kernel(const float *__restrict__ x, const float *__restrict__ res,
+                                                          const float *__restrict__ dy, const float *__restrict__ y_in,
+                                                          const float *__restrict__ fin, const float *__restrict__ mean,
+                                                          const float *__restrict__ invstd, long R, int C, float slope,
+                                                          float *__restrict__ out) {
+    const long q0 = (long)blockIdx.x * 256 + threadIdx.x;   // float4 index
+    const long e0 = q0 * 4;
+    if (e0 >= R * C) return;
+    const int c = 4 * (q0 < (1L << 32) ? (int)((unsigned)q0 % (unsigned)(C >> 2)) : (int)(q0 % (C >> 2)));
+    f32x4 v = *(const f32x4 *)(x + e0);
+    if (res) v += *(const f32x4 *)(res + e0);
+    f32x4 o;
+    if (BWD) {
+        const f32x4 g4 = *(const f32x4 *)(dy + e0), y4 = *(const f32x4 *)(y_in + e0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float dz = g4[k] * (y4[k] > 0.f ? 1.f : slope);
+            o[k] = fin[(c + k) * 4 + 2] * ((dz - fin[(c + k) * 4]) - ((v[k] - mean[c + k]) * invstd[c + k]) * fin[(c + k) * 4 + 1]);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float t = (v[k] - fin[(c + k) * 4]) * fin[(c + k) * 4 + 2] + fin[(c + k) * 4 + 3];
+            o[k] = t > 0.f ? t : t * slope;
+        }
+    }
+    *(f32x4 *)(out + e0) = o;
+}
+
+// channel group of one reduction workgroup: 512- or 256-byte row segments, else the whole row (C <= 1024)
+int pm_group_for(int C) { return C % 128 == 0 ? 128 : C % 64 == 0 ? 64 : C; }
+// row chunks of the point-major reduction: ~256 workgroups in all, every thread row (256 / (CG/4) per workgroup) >= 4 rows
+long pm_chunk_for(long R, int C) {
+    const int CG = pm_group_for(C), groups = C / CG;
+    const long rpp = 256 / (CG >> 2);
+    long chunk = 4 * rpp;
+    while (((R + chunk - 1) / chunk) * groups > 256) chunk *= 2;
+    return chunk;
+}
+int pm_splits_for(long R, int C) {
+    const long chunk = pm_chunk_for(R, C);
+    return (int)((R + chunk - 1) / chunk);
+}
+
 int splits_for(int B, int C, int N) {  // enough workgroups to fill the chip, at least ~1k elements each
     const long total = (long)B * N;
     int S = 1;
@@ -227,5 +396,61 @@ DVM_EXPORT int dvm_bn_act_train_bwd_f32(const float *dy, const float *y, const f
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((total + 1023) / 1024), C), dim3(256), 0, s, dy, y, x, res, save_mean,
                        save_invstd, gamma, partial, S, B, C, N, slope, dx, dgamma, dbeta);
     DVM_CHECK_LAUNCH("bn_act_train_bwd");
+    return DVM_OK;
+}
+
+DVM_EXPORT size_t dvm_bn_pm_workspace_bytes(long R, int C) {
+    if (R < 1 || C < 4 || C % 4 != 0 || C > 1024) return 0;
+    return align_up((size_t)C * pm_splits_for(R, C) * 2 * sizeof(double)) + align_up((size_t)C * 4 * sizeof(float));
+}
+
+DVM_EXPORT int dvm_bn_act_train_fwd_pm_f32(const float *x, const float *res, const float *gamma, const float *beta, long R, int C, float eps,
+                                           float slope, float momentum, float *y, float *save_mean, float *save_invstd,
+                                           float *running_mean, float *running_var, void *ws, size_t ws_bytes, void *stream) {
+    DVM_REQUIRE(x && y && save_mean && save_invstd, "dvm_bn_act_train_fwd_pm_f32: null pointer");
+    DVM_REQUIRE(R >= 1 && C >= 4 && C % 4 == 0 && C <= 1024, "dvm_bn_act_train_fwd_pm_f32: need R >= 1 and C a multiple of 4, at most 1024 (R=%ld C=%d)", R, C);
+    DVM_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "dvm_bn_act_train_fwd_pm_f32: running_mean/var go together");
+    const int S = pm_splits_for(R, C);
+    Arena ar(ws, ws_bytes);
+    double *partial = ar.take<double>((size_t)C * S * 2);
+    float *fin = ar.take<float>((size_t)C * 4);
+    if (!ar.ok()) {
+        set_error("dvm_bn_act_train_fwd_pm_f32: workspace too small (%zu < %zu)", ws_bytes, ar.off);
+        return DVM_ENOSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int CG = pm_group_for(C);
+    hipLaunchKernelGGL(bn_pm_reduce_kernel<false>, dim3(S, C / CG), dim3(256), 0, s, x, res, nullptr, nullptr, nullptr, nullptr, R, C, CG,
+                       pm_chunk_for(R, C), slope, partial);
+    hipLaunchKernelGGL(bn_pm_finalize_fwd_kernel, dim3((C + PM_CG - 1) / PM_CG), dim3(256), 0, s, partial, S, R, C, gamma, beta, eps, momentum, fin,
+                       save_mean, save_invstd, running_mean, running_var);
+    hipLaunchKernelGGL(bn_pm_apply_kernel<false>, dim3((unsigned)((R * C / 4 + 255) / 256)), dim3(256), 0, s, x, res, nullptr, nullptr, fin,
+                       nullptr, nullptr, R, C, slope, y);
+    DVM_CHECK_LAUNCH("bn_act_train_fwd_pm");
+    return DVM_OK;
+}
+
+DVM_EXPORT int dvm_bn_act_train_bwd_pm_f32(const float *dy, const float *y, const float *x, const float *res, const float *gamma,
+                                           const float *save_mean, const float *save_invstd, long R, int C, float slope, float *dx,
+                                           float *dgamma, float *dbeta, int accumulate, void *ws, size_t ws_bytes, void *stream) {
+    DVM_REQUIRE(dy && y && x && save_mean && save_invstd && dx, "dvm_bn_act_train_bwd_pm_f32: null pointer");
+    DVM_REQUIRE(R >= 1 && C >= 4 && C % 4 == 0 && C <= 1024, "dvm_bn_act_train_bwd_pm_f32: need R >= 1 and C a multiple of 4, at most 1024 (R=%ld C=%d)", R, C);
+    const int S = pm_splits_for(R, C);
+    Arena ar(ws, ws_bytes);
+    double *partial = ar.take<double>((size_t)C * S * 2);
+    float *fin = ar.take<float>((size_t)C * 4);
+    if (!ar.ok()) {
+        set_error("dvm_bn_act_train_bwd_pm_f32: workspace too small (%zu < %zu)", ws_bytes, ar.off);
+        return DVM_ENOSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int CG = pm_group_for(C);
+    hipLaunchKernelGGL(bn_pm_reduce_kernel<true>, dim3(S, C / CG), dim3(256), 0, s, x, res, dy, y, save_mean, save_invstd, R, C, CG,
+                       pm_chunk_for(R, C), slope, partial);
+    hipLaunchKernelGGL(bn_pm_finalize_bwd_kernel, dim3((C + PM_CG - 1) / PM_CG), dim3(256), 0, s, partial, S, R, C, gamma, save_mean, save_invstd, fin,
+                       dgamma, dbeta, accumulate);
+    hipLaunchKernelGGL(bn_pm_apply_kernel<true>, dim3((unsigned)((R * C / 4 + 255) / 256)), dim3(256), 0, s, x, res, dy, y, fin, save_mean,
+                       save_invstd, R, C, slope, dx);
+    DVM_CHECK_LAUNCH("bn_act_train_bwd_pm");
     return DVM_OK;
 }

@@ -376,6 +376,74 @@ void launch_linear(const float *x, const float *w, int B, int N, int K, int Co, 
     }
 }
 
+// ---------------------------------------------------------------- weight gradient of a point-major linear layer
+// dW[co][k] = sum_r gy[r][co] * x[r][k]  (r over the B*N rows): a "TN" product whose reduction runs over the ROWS, so both
+// operands are read exactly as they lie in memory — the A fragment of v_mfma_f32_32x32x2_f32 wants, per k-step, 32
+// consecutive `co` of one row (lanes 0-31) and of the next row (lanes 32-63): contiguous 128-byte reads of gy; B likewise
+// from x.  (rocBLAS runs this shape — reduction length 16384, outputs 64..1152 wide, K-strided operands — at ~1 TFLOP/s.)
+// A workgroup = 4 waves = a 64 x 64 tile of dW over one chunk of rows; chunks are combined with fp32 atomics (dW zeroed
+// by the caller).  Gradient sums carry no ordering contract.
+constexpr int WG_ROWS = 32;   // rows staged per step
+__global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(const float *__restrict__ gy, const float *__restrict__ x, long R, int Co, int K,
+                                                              long rchunk, float *__restrict__ dW) {
+    __shared__ __attribute__((aligned(16))) float gs[2][WG_ROWS * 64], xs[2][WG_ROWS * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r32 = lane & 31, h = lane >> 5;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int tiles_k = (K + 63) / 64;
+    const int co0 = (blockIdx.x / tiles_k) * 64, k0 = (blockIdx.x % tiles_k) * 64;
+    const long rbeg = (long)blockIdx.y * rchunk, rend = rbeg + rchunk < R ? rbeg + rchunk : R;
+    // staging: 32 rows x 64 floats per operand = 512 float4: 2 per thread
+    f32x4 pg[2], px[2];
+    auto fetch = [&](long r0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + 256 * u, rr = e >> 4, c = (e & 15) * 4;
+            const long r = r0 + rr;
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+            if (r < rend) {
+                const float *ga = gy + (size_t)r * Co + co0 + c, *xa = x + (size_t)r * K + k0 + c;
+                if (co0 + c + 3 < Co && (Co & 3) == 0) a = *(const f32x4 *)ga;
+                else
+                    for (int q = 0; q < 4; ++q) if (co0 + c + q < Co) a[q] = ga[q];
+                if (k0 + c + 3 < K && (K & 3) == 0) b = *(const f32x4 *)xa;
+                else
+                    for (int q = 0; q < 4; ++q) if (k0 + c + q < K) b[q] = xa[q];
+            }
+            pg[u] = a, px[u] = b;
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + 256 * u;
+            *(f32x4 *)(gs[buf] + 4 * e) = pg[u];
+            *(f32x4 *)(xs[buf] + 4 * e) = px[u];
+        }
+    };
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int cur = 0;
+    fetch(rbeg);
+    stage(0);
+    __syncthreads();
+    for (long r0 = rbeg; r0 < rend; r0 += WG_ROWS) {
+        const bool has_next = r0 + WG_ROWS < rend;
+        if (has_next) fetch(r0 + WG_ROWS);
+        const float *ga = gs[cur] + wi * 32 + r32, *xa = xs[cur] + wj * 32 + r32;
+#pragma unroll
+        for (int t = 0; t < WG_ROWS / 2; ++t)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[(2 * t + h) * 64], xa[(2 * t + h) * 64], acc, 0, 0, 0);
+        if (has_next) stage(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    const int k = k0 + wj * 32 + r32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (co < Co && k < K) atomicAdd(dW + (size_t)co * K + k, acc[r]);
+    }
+}
+
 }  // namespace dvm
 
 using namespace dvm;
@@ -407,5 +475,20 @@ DVM_EXPORT int dvm_linear_f32(const float *x, const float *w, int B, int N, int 
     DVM_REQUIRE((long)B * N < (1L << 31) && (long)B * N * (Co > K ? Co : K) < (1L << 40), "dvm_linear_f32: too large");
     launch_linear(x, w, B, N, K, Co, channel_major, bias, res, bn_alpha, bn_beta, slope, y, (hipStream_t)stream);
     DVM_CHECK_LAUNCH("linear");
+    return DVM_OK;
+}
+
+DVM_EXPORT int dvm_linear_wgrad_f32(const float *gy, const float *x, long R, int Co, int K, float *dW, void *stream) {
+    DVM_REQUIRE(gy && x && dW, "dvm_linear_wgrad_f32: null pointer");
+    DVM_REQUIRE(R >= 1 && Co >= 1 && K >= 1, "dvm_linear_wgrad_f32: empty input (R=%ld Co=%d K=%d)", R, Co, K);
+    const int tiles = ((Co + 63) / 64) * ((K + 63) / 64);
+    long chunks = 1;   // row chunks until the chip is covered twice over, each at least 64 rows
+    while (tiles * chunks < 512 && R / (chunks * 2) >= 64) chunks *= 2;
+    long rchunk = (R + chunks - 1) / chunks;
+    rchunk = (rchunk + WG_ROWS - 1) / WG_ROWS * WG_ROWS;
+    chunks = (R + rchunk - 1) / rchunk;
+    DVM_REQUIRE(chunks <= 65535, "dvm_linear_wgrad_f32: too many row chunks");
+    hipLaunchKernelGGL(linear_wgrad_kernel, dim3((unsigned)tiles, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, gy, x, R, Co, K, rchunk, dW);
+    DVM_CHECK_LAUNCH("linear_wgrad");
     return DVM_OK;
 }

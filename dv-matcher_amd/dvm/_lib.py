@@ -27,6 +27,10 @@ SIGNATURES = {
     "dvm_rownorm2_f32": (c_int, [_P, c_int, c_int, _P, _P]),
     "dvm_linear_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_float, _P, _P]),
     "dvm_linear_prefix_f32": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_float, _P, _P]),
+    "dvm_linear_wgrad_f32": (c_int, [_P, _P, ctypes.c_long, c_int, c_int, _P, _P]),
+    "dvm_bn_pm_workspace_bytes": (c_size_t, [ctypes.c_long, c_int]),
+    "dvm_bn_act_train_fwd_pm_f32": (c_int, [_P, _P, _P, _P, ctypes.c_long, c_int, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "dvm_bn_act_train_bwd_pm_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, ctypes.c_long, c_int, c_float, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "dvm_softcorr_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dvm_softcorr_fwd_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P, _P, _P, _P, c_int, _P,
                                      c_size_t, _P]),

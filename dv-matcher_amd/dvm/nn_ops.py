@@ -51,6 +51,136 @@ def conv1x1(x, w, bias=None):
     return _Conv1x1.apply(x.contiguous(), w, bias)
 
 
+# ------------------------------------------------------------------------------------------
+# Point-major training path: activations stay (B,N,C) between the operators — the layout of the kNN / attention cores and of
+# dvm_linear_f32's inference mode — so no transposes (6 % of the round-1 step) and no ATen glue sit between them.
+# Gradient accumulation fusion: when a leaf parameter already holds a .grad buffer (a zeroed flat bucket, or the
+# gradient of an earlier call in the same step — the criterion calls the network once per shape), the backward kernels add
+# into that buffer and hand autograd `None`: same sums as autograd's own `p.grad += g`, without a zero-fill and an add
+# launch per parameter and call.  It must stay off for torch.autograd.grad() (which promises not to touch .grad), hence
+# opt-in: the training driver switches it on.
+_FUSE_GRAD_ACCUMULATION = False
+
+
+def fuse_grad_accumulation(on=True):
+    global _FUSE_GRAD_ACCUMULATION
+    prev, _FUSE_GRAD_ACCUMULATION = _FUSE_GRAD_ACCUMULATION, bool(on)
+    return prev
+
+
+def _grad_buffer(p):
+    g = p.grad if (_FUSE_GRAD_ACCUMULATION and p.is_leaf) else None
+    return g if (g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.device == p.device) else None
+
+
+class _LinearPM(torch.autograd.Function):
+    """y = act(x W^T + bias) on point-major x (..., K): forward = the reference's fp32 chain (dvm_linear_f32), backward on the
+    library's own kernels too: dX = (dY act') W through dvm_linear_f32 with the operands' roles swapped, dW through
+    dvm_linear_wgrad_f32 (reduction over the rows, operands read as they lie)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, slope):
+        y = ops.linear(x, w, bias=bias, slope=slope)
+        ctx.save_for_backward(x, w, y if slope != 1.0 else None)
+        ctx.slope, ctx.has_bias = slope, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        gy = gy.contiguous()
+        if ctx.slope != 1.0:
+            gy = torch.ops.aten.leaky_relu_backward(gy, y, ctx.slope, True)     # y is the activation's OUTPUT
+        Co = w.shape[0]
+        w2 = w.reshape(Co, -1)
+        K = w2.shape[1]
+        g2, x2 = gy.reshape(-1, Co), x.reshape(-1, K)
+        gx = ops.linear(w2.reshape(1, Co, K), g2, channel_major=True).view(x.shape) if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            buf = _grad_buffer(w)
+            if buf is not None:
+                ops.linear_wgrad(g2, x2, out=buf)
+            else:
+                gw = ops.linear_wgrad(g2, x2).view_as(w)
+        gb = g2.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gx, gw, gb, None
+
+
+def linear_pm(x, w, bias=None, slope=1.0):
+    """Point-major 1x1 conv / linear layer with autograd: x (..., K), w (Co,K[,1]) -> (..., Co)."""
+    if not _needs_grad(x, w, bias):
+        return ops.linear(x, w, bias=bias, slope=slope)
+    return _LinearPM.apply(x.contiguous(), w, bias, slope)
+
+
+class _BNActPM(torch.autograd.Function):
+    """y = act(BatchNorm_train(x + res)) over the rows of point-major x (..., C), forward and backward on the fused kernels."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, running_mean, running_var, momentum, eps, slope):
+        y, mean, invstd = ops.bn_act_train_fwd_pm(x, res, gamma, beta, eps, slope, momentum, running_mean, running_var)
+        ctx.save_for_backward(x, res, y, gamma, beta, mean, invstd)
+        ctx.slope = slope
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, res, y, gamma, beta, mean, invstd = ctx.saved_tensors
+        bufs = (_grad_buffer(gamma), _grad_buffer(beta))
+        fused = bufs[0] is not None and bufs[1] is not None
+        dx, dgamma, dbeta = ops.bn_act_train_bwd_pm(dy.contiguous(), y, x, res, gamma, mean, invstd, ctx.slope, grads=bufs if fused else None)
+        if fused:
+            dgamma = dbeta = None
+        return dx, (dx if res is not None else None), dgamma, dbeta, None, None, None, None, None
+
+
+_counter_sink = None     # while a list: BatchNorm batch counters to bump in ONE launch (Uni3FC's point-major training forward)
+
+
+def bump_batch_counters(counters):
+    if counters:
+        with torch.no_grad():
+            torch._foreach_add_(counters, 1)
+
+
+def bn_act_pm(bn, x, res=None, slope=1.0):
+    """act(bn(x + res)) for an nn.BatchNorm1d `bn` applied to point-major x (B,N,C) (the module's channel axis is the LAST
+    one here).  Training mode with plain batch statistics: fused kernels; otherwise (eval mode, SyncBatchNorm, ...) the
+    module itself on a transposed view."""
+    fused = (type(bn) is torch.nn.BatchNorm1d and bn.training and bn.track_running_stats and bn.affine
+             and bn.momentum is not None and x.is_cuda and x.dtype == torch.float32 and x.shape[-1] % 4 == 0 and x.shape[-1] <= 1024)
+    if not fused:
+        z = x if res is None else x + res
+        y = bn(z.transpose(1, 2)).transpose(1, 2)
+        return y if slope == 1.0 else torch.nn.functional.leaky_relu(y, slope) if slope != 0.0 else torch.relu(y)
+    if _counter_sink is not None:
+        _counter_sink.append(bn.num_batches_tracked)
+    else:
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+    return _BNActPM.apply(x.contiguous(), None if res is None else res.contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                          bn.momentum, bn.eps, slope)
+
+
+def sa_attention_pm(xt, w_qk, w_v, b_v):
+    """SA_Layer's x_r on point-major xt (B,N,64) with autograd: ONE projection GEMM (q/k and v stacked), the fused attention
+    core both ways."""
+    nq = w_qk.shape[0]
+    C = xt.shape[-1]
+    w = torch.cat([w_qk.reshape(nq, C), w_v.reshape(-1, C)], 0)
+    pv = linear_pm(xt, w, torch.cat([b_v.new_zeros(nq), b_v]))
+    return _SACore.apply(pv[..., :nq].contiguous(), pv[..., nq:].contiguous())
+
+
+def n2p_attention_pm(xt, K, wq, wk, wv, heads):
+    """N2PAttention's attention output on point-major xt (B,N,C) with autograd."""
+    C = xt.shape[-1]
+    idx = ops.knn_neg(xt, xt, K)
+    w = torch.cat([wq.reshape(C, C), wk.reshape(C, C), wv.reshape(C, C)], 0)
+    return _N2PCore.apply(linear_pm(xt, w), idx, heads)
+
+
 def pos_encoding(coor, group=None, sync=False):
     """sync=True: normalise with the min/max over every rank's shard of the batch (two scalar all-reduces), so that a
     sharded batch is encoded exactly like the same batch in one process."""

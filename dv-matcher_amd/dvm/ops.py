@@ -119,6 +119,64 @@ def linear(x, w, bias=None, res=None, bn=None, slope=1.0, channel_major=False, o
     return out
 
 
+def linear_wgrad(gy, x, out=None):
+    """dW = gy^T x over the rows: gy (R,Co), x (R,K) -> (Co,K) (dvm_linear_wgrad_f32; fp32 atomics over row chunks).
+    With `out` (Co,K) the product is ADDED to it in place."""
+    _need_gpu(gy, x, out)
+    gy, x = _f(gy), _f(x)
+    R, Co = gy.shape
+    K = x.shape[1]
+    if out is None:
+        dW = torch.zeros(Co, K, dtype=torch.float32, device=gy.device)
+    else:
+        dW = out
+        if dW.dtype != torch.float32 or not dW.is_contiguous() or dW.numel() != Co * K:
+            raise ValueError("linear_wgrad: out must be a contiguous float32 tensor of %d x %d elements" % (Co, K))
+    check(_lib.load().dvm_linear_wgrad_f32(_p(gy), _p(x), R, Co, K, _p(dW), _stream()), "dvm_linear_wgrad_f32")
+    return dW
+
+
+def bn_act_train_fwd_pm(x, res, gamma, beta, eps, slope, momentum, running_mean=None, running_var=None):
+    """Fused training-mode BatchNorm on point-major x (..., C): y = act(bn(x + res)); returns (y, mean, invstd)."""
+    _need_gpu(x, res, gamma, beta)
+    x = _f(x)
+    C = x.shape[-1]
+    R = x.numel() // C
+    res = None if res is None else _f(res)
+    y = torch.empty_like(x)
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    invstd = torch.empty_like(mean)
+    lib = _lib.load()
+    nb = lib.dvm_bn_pm_workspace_bytes(R, C)
+    ws = workspace(nb, x.device, "bn_pm")
+    check(lib.dvm_bn_act_train_fwd_pm_f32(_p(x), _p(res), _p(gamma), _p(beta), R, C, float(eps), float(slope), float(momentum), _p(y), _p(mean),
+                                          _p(invstd), _p(running_mean), _p(running_var), _p(ws), nb, _stream()), "dvm_bn_act_train_fwd_pm_f32")
+    return y, mean, invstd
+
+
+def bn_act_train_bwd_pm(dy, y, x, res, gamma, mean, invstd, slope, grads=None):
+    """-> (dx, dgamma, dbeta); with grads = (dgamma, dbeta) given, the parameter gradients are ADDED to those tensors."""
+    _need_gpu(dy, y, x)
+    dy, x = _f(dy), _f(x)
+    C = x.shape[-1]
+    R = x.numel() // C
+    dx = torch.empty_like(x)
+    if grads is None:
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty_like(dgamma)
+    else:
+        dgamma, dbeta = grads
+        for t in grads:
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != C:
+                raise ValueError("bn_act_train_bwd_pm: grads must be contiguous float32 tensors of %d elements" % C)
+    lib = _lib.load()
+    nb = lib.dvm_bn_pm_workspace_bytes(R, C)
+    ws = workspace(nb, x.device, "bn_pm")
+    check(lib.dvm_bn_act_train_bwd_pm_f32(_p(dy), _p(y), _p(x), _p(res), _p(gamma), _p(mean), _p(invstd), R, C, float(slope), _p(dx), _p(dgamma),
+                                          _p(dbeta), int(grads is not None), _p(ws), nb, _stream()), "dvm_bn_act_train_bwd_pm_f32")
+    return dx, dgamma, dbeta
+
+
 def softcorr(f1, f2, alpha, topk=10, variant=0, stats=True):
     """f1 (B,N,d), f2 (B,M,d) -> pi_val (B,N,topk), pi_idx (B,N,topk) int32, row_smax (B,N), row_sum (B,N)."""
     _need_gpu(f1, f2)

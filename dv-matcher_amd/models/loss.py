@@ -60,6 +60,19 @@ class FrobeniusLoss(nn.Module):
         return torch.mean(torch.sum(torch.abs(a - b) ** 2, axis=(1, 2)))
 
 
+def _host_draw_to_device(values, device):
+    """The host's random draws (dist-loss anchors, FPS starts) as a device tensor WITHOUT stalling the host: a copy from
+    pageable memory blocks until the stream has drained, which would serialise the host behind the whole network forward
+    every step; a pinned staging buffer and a non-blocking copy keep it enqueueing.  Device tensors pass through untouched
+    (no host-to-device copy inside a captured step)."""
+    if torch.is_tensor(values) and values.device.type == "cuda":
+        return values
+    t = torch.as_tensor(np.asarray(values))
+    if torch.device(device).type != "cuda":
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 class SparsePi:
     """Top-k rows of the soft correspondence: val/idx (B,N,k); stands in for the dense (B,N,M) Pi."""
 
@@ -135,7 +148,7 @@ class GraphDeformLoss_Neural(nn.Module):
         B, N, _ = verts1.shape
         if starts is None:  # one torch.randint(0,N,(1,)) per batch element, in order, like the reference
             starts = torch.cat([torch.randint(0, N, (1,), dtype=torch.long) for _ in range(B)])
-        g = ops.dg_build(verts1, torch.as_tensor(starts).to(verts1.device))
+        g = ops.dg_build(verts1, _host_draw_to_device(starts, verts1.device))
         dg_list = [DeformationGraph_geod.from_batch(g, b, verts1[b]) for b in range(B)] if self.dump else []
         return g["nodes_idx"].float(), dg_list, g
 
@@ -212,8 +225,7 @@ class GraphDeformLoss_Neural(nn.Module):
             if anchors is None:
                 anchors = (random.sample(range(dist1.shape[1]), self.N_dist), random.sample(range(dist2.shape[1]), self.N_dist))
             # (device tensors pass through untouched: no host-to-device copy inside a captured step)
-            a1 = anchors[0] if torch.is_tensor(anchors[0]) and anchors[0].is_cuda else torch.as_tensor(np.asarray(anchors[0]), device=feat1.device)
-            a2 = anchors[1] if torch.is_tensor(anchors[1]) and anchors[1].is_cuda else torch.as_tensor(np.asarray(anchors[1]), device=feat2.device)
+            a1, a2 = _host_draw_to_device(anchors[0], feat1.device), _host_draw_to_device(anchors[1], feat2.device)
             self.dist_loss = (dist_term(feat1, dist1, a1) + dist_term(feat2, dist2, a2)) * self.w_dist
             loss = loss + self.dist_loss
             self._sum_part = self._sum_part + self.dist_loss

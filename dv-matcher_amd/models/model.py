@@ -8,6 +8,7 @@ test.py / deform.py call sequence runs unchanged and its checkpoints load with
 1x1 convolutions / BatchNorm stay on PyTorch-ROCm as BASELINE.json's north_star prescribes.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -111,6 +112,12 @@ class SA_Layer(nn.Module):
         x_r = nn_ops.sa_attention(x, self.k_conv.weight, self.v_conv.weight, self.v_conv.bias)
         return x + nn_ops.bn_act(self.after_norm, self.trans_conv(x - x_r), slope=0.0)
 
+    def train_pm(self, xt):
+        """Autograd path on point-major activations (B,N,64)."""
+        x_r = nn_ops.sa_attention_pm(xt, self.k_conv.weight, self.v_conv.weight, self.v_conv.bias)
+        t = nn_ops.linear_pm(xt - x_r, self.trans_conv.weight, self.trans_conv.bias)
+        return xt + nn_ops.bn_act_pm(self.after_norm, t, slope=0.0)
+
     def infer_pm(self, xt):
         """Inference on point-major activations (B,N,64): no transposes, BatchNorm folded into trans_conv."""
         p = ops.linear(xt, self.k_conv.weight)
@@ -140,6 +147,13 @@ class _N2P(nn.Module):
         att = nn_ops.n2p_attention(x, self.K, self.q_conv.weight, self.k_conv.weight, self.v_conv.weight, self.heads)
         x = nn_ops.bn_act(self.bn1, x, att)
         return nn_ops.bn_act(self.bn2, x, self.ff(x))
+
+    def train_pm(self, xt):
+        """Autograd path on point-major activations (B,N,C)."""
+        att = nn_ops.n2p_attention_pm(xt, self.K, self.q_conv.weight, self.k_conv.weight, self.v_conv.weight, self.heads)
+        xt = nn_ops.bn_act_pm(self.bn1, xt, att)
+        h = nn_ops.linear_pm(xt, self.ff[0].weight, slope=self.ff[1].negative_slope)
+        return nn_ops.bn_act_pm(self.bn2, xt, nn_ops.linear_pm(h, self.ff[2].weight))
 
     def infer_pm(self, xt):
         """Inference on point-major activations (B,N,C): q/k/v by ONE GEMM, gather-attention on the HIP kernel, the two
@@ -285,6 +299,30 @@ class Uni3FC_DINO_proj(nn.Module, _VisualProjection):
         return self.visual_features(x, upsampler)
 
 
+_side_streams = {}
+
+
+def _two_branches(x, main, side):
+    """LG-Net's local (kNN attention) and global (self-attention) chains share only their input `x`: `main()` runs on the
+    current stream, `side()` concurrently on a per-device helper stream, joined before returning (main(), side()).  Neither
+    chain fills 256 CUs on its own (their kernels are one workgroup per CU or fewer at 8 x 2048 points); autograd replays
+    each chain's backward on the stream its forward ran on.  DVM_BRANCH_STREAMS=0 runs them back to back."""
+    if not x.is_cuda or os.environ.get("DVM_BRANCH_STREAMS", "1") != "1":
+        return main(), side()
+    cur = torch.cuda.current_stream(x.device)
+    helper = _side_streams.get((x.device, cur.cuda_stream))
+    if helper is None:
+        helper = _side_streams[(x.device, cur.cuda_stream)] = torch.cuda.Stream(x.device)
+    helper.wait_stream(cur)
+    x.record_stream(helper)
+    with torch.cuda.stream(helper):
+        b = side()
+    a = main()
+    cur.wait_stream(helper)
+    b.record_stream(cur)
+    return a, b
+
+
 class Uni3FC(nn.Module, _VisualProjection):
     def __init__(self, k=40):
         super().__init__()
@@ -338,21 +376,69 @@ class Uni3FC(nn.Module, _VisualProjection):
             blk = lambda seq, xt, **kw: _conv_bn_pm(seq[0], seq[1], xt, seq[2].negative_slope, **kw)  # noqa: E731
             f = blk(self.conv, dino_feat)
             tmp = blk(self.conv0, f + self.pos_encoding_sin_wave(x).transpose(1, 2))
-            x1, x1g = self.n2p_attention1.infer_pm(tmp), self.sa1.infer_pm(tmp)
-            x2, x2g = self.n2p_attention2.infer_pm(x1), self.sa2.infer_pm(x1g)
-            x3, x3g = self.n2p_attention3.infer_pm(x2), self.sa3.infer_pm(x2g)
-            x4, x4g = self.n2p_attention4.infer_pm(x3), self.sa4.infer_pm(x3g)
-            loc = torch.cat((x1, x2, x3, x4), dim=-1)
-            glo = torch.cat((x1g, x2g, x3g, x4g), dim=-1)
-            lmax = blk(self.conv1, loc).amax(dim=1, keepdim=True)
-            gmax = blk(self.conv2, glo).amax(dim=1, keepdim=True)
-            y = torch.cat((blk(self.conv3, loc, prefix=lmax), blk(self.conv4, glo, prefix=gmax)), dim=-1)
+
+            def global_branch():
+                x1g = self.sa1.infer_pm(tmp)
+                x2g = self.sa2.infer_pm(x1g)
+                x3g = self.sa3.infer_pm(x2g)
+                glo = torch.cat((x1g, x2g, x3g, self.sa4.infer_pm(x3g)), dim=-1)
+                return blk(self.conv4, glo, prefix=blk(self.conv2, glo).amax(dim=1, keepdim=True))
+
+            def local_branch():
+                x1 = self.n2p_attention1.infer_pm(tmp)
+                x2 = self.n2p_attention2.infer_pm(x1)
+                x3 = self.n2p_attention3.infer_pm(x2)
+                loc = torch.cat((x1, x2, x3, self.n2p_attention4.infer_pm(x3)), dim=-1)
+                return blk(self.conv3, loc, prefix=blk(self.conv1, loc).amax(dim=1, keepdim=True))
+
+            y = torch.cat(_two_branches(tmp, local_branch, global_branch), dim=-1)
             y1 = blk(self.conv5, y)
             y2 = self.n2p_attention5.infer_pm(y1)
             y3 = self.n2p_attention6.infer_pm(y2)
             y4 = self.n2p_attention7.infer_pm(y3)
             out = blk(self.conv6, torch.cat((y1, y2, y3, y4), dim=-1))
             return out.contiguous().view(B, N, self.out), tmp
+
+    def _forward_train_pm(self, x, dino_feat):
+        """Autograd forward with activations kept point-major (B,N,C), the layout dino_feat arrives in and the kNN /
+        attention cores work in: the convs are dvm_linear_f32 GEMMs forward, dvm_linear_f32 / dvm_linear_wgrad_f32
+        backward, the BatchNorms the fused row-major kernels; one transpose (the position encoding) in the whole pass."""
+        B, _, N = x.shape
+        blk = lambda seq, xt: nn_ops.bn_act_pm(seq[1], nn_ops.linear_pm(xt, seq[0].weight), slope=seq[2].negative_slope)  # noqa: E731
+        counters, nn_ops._counter_sink = nn_ops._counter_sink, []
+        try:
+            return self._train_pm_body(x, dino_feat, blk, B, N)
+        finally:
+            pending, nn_ops._counter_sink = nn_ops._counter_sink, counters
+            nn_ops.bump_batch_counters(pending)       # 52 `num_batches_tracked += 1` as one launch
+
+    def _train_pm_body(self, x, dino_feat, blk, B, N):
+        f = blk(self.conv, dino_feat)
+        tmp = blk(self.conv0, f + self.pos_encoding_sin_wave(x).transpose(1, 2))
+
+        def global_branch():
+            x1g = self.sa1.train_pm(tmp)
+            x2g = self.sa2.train_pm(x1g)
+            x3g = self.sa3.train_pm(x2g)
+            glo = torch.cat((x1g, x2g, x3g, self.sa4.train_pm(x3g)), dim=-1)
+            gmax = blk(self.conv2, glo).max(dim=1, keepdim=True)[0].expand(-1, N, -1)
+            return blk(self.conv4, torch.cat((gmax, glo), dim=-1))
+
+        def local_branch():
+            x1 = self.n2p_attention1.train_pm(tmp)
+            x2 = self.n2p_attention2.train_pm(x1)
+            x3 = self.n2p_attention3.train_pm(x2)
+            loc = torch.cat((x1, x2, x3, self.n2p_attention4.train_pm(x3)), dim=-1)
+            lmax = blk(self.conv1, loc).max(dim=1, keepdim=True)[0].expand(-1, N, -1)
+            return blk(self.conv3, torch.cat((lmax, loc), dim=-1))
+
+        y = torch.cat(_two_branches(tmp, local_branch, global_branch), dim=-1)
+        y1 = blk(self.conv5, y)
+        y2 = self.n2p_attention5.train_pm(y1)
+        y3 = self.n2p_attention6.train_pm(y2)
+        y4 = self.n2p_attention7.train_pm(y3)
+        out = blk(self.conv6, torch.cat((y1, y2, y3, y4), dim=-1))
+        return out.view(B, N, self.out), tmp
 
     def forward(self, x, dino_feat, upsampler=None):
         """x (B,3,N), dino_feat (B,N,1152) -> (feat (B,N,128), cfeats (B,N,64))."""
@@ -365,6 +451,10 @@ class Uni3FC(nn.Module, _VisualProjection):
                                                   any(p.requires_grad for p in self.parameters()))
         if not self.training and not wants_grad:
             return self._forward_infer(x, dino_feat)
+        if self.training and os.environ.get("DVM_TRAIN_LAYOUT", "pm") == "pm" and \
+                all(type(m) is nn.BatchNorm1d for m in self.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)):
+            return self._forward_train_pm(x, dino_feat.contiguous())
+        # channel-major fallback (eval-mode fine-tuning, SyncBatchNorm): the reference's own layout.
         # conv -> BatchNorm -> LeakyReLU blocks: the GEMM, then ONE fused statistics + normalise + activation pass
         blk = lambda seq, t: nn_ops.bn_act(seq[1], seq[0](t), slope=seq[2].negative_slope)  # noqa: E731
         f = blk(self.conv, dino_feat.permute(0, 2, 1))

@@ -240,10 +240,17 @@ def main(argv=None):
     frac = (hi - lo) / Bg
     sync_each = os.environ.get("DVM_SYNC_EACH_STEP", "0") == "1"   # train.py logs loss.item() every iteration
 
+    from dvm import nn_ops
+    nn_ops.fuse_grad_accumulation(os.environ.get("DVM_FUSE_GRAD_ACC", "1") == "1")   # .backward() only below, never autograd.grad()
+
+    def forward_pair(v1, d1, v2, d2):
+        # two calls, as in the reference (train-mode BatchNorm statistics are per call); inside each, LG-Net's local and
+        # global chains already run on two streams (models/model.py:_two_branches)
+        return net(v1.permute(0, 2, 1), d1, None)[0], net(v2.permute(0, 2, 1), d2, None)[0]
+
     def train_step(batch, alpha):
         v1, v2, d1, d2, dist1, dist2 = batch
-        f1, _ = net(v1.permute(0, 2, 1), d1, None)
-        f2, _ = net(v2.permute(0, 2, 1), d2, None)
+        f1, f2 = forward_pair(v1, d1, v2, d2)
         out = crit(f1, f2, dist1, dist2, v1, v2, alpha, dfm)
         if world > 1:
             crit.data_parallel_loss(frac).backward()
@@ -287,8 +294,7 @@ def main(argv=None):
 
             def graph_step():
                 v1, v2, d1, d2, dist1, dist2 = batch
-                f1, _ = net(v1.permute(0, 2, 1), d1, None)
-                f2, _ = net(v2.permute(0, 2, 1), d2, None)
+                f1, f2 = forward_pair(v1, d1, v2, d2)
                 out = crit(f1, f2, dist1, dist2, v1, v2, alpha, dfm, fps_starts=starts, anchors=anchors)
                 out[0].backward()
                 vals = torch.stack([torch.as_tensor(o, device=dev).detach().float().reshape(()) for o in out])
@@ -318,6 +324,7 @@ def main(argv=None):
         t0 = time.perf_counter()
         for i in range(args.steps):
             losses.append(train_step(feed[i % len(feed)], alpha))
+        t_host = time.perf_counter() - t0          # all steps enqueued; the rest of dt is the GPU catching up
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -329,7 +336,8 @@ def main(argv=None):
             dt = float(t)
         if rank == 0:
             print(json.dumps({"metric": "training pairs/sec (fwd+loss+bwd+Adam)", "value": Bg * args.steps / dt, "unit": "pairs/s",
-                              "n_gpus": world, "steps": args.steps, "ms_per_step": dt / args.steps * 1e3, "global_batch": Bg,
+                              "n_gpus": world, "steps": args.steps, "ms_per_step": dt / args.steps * 1e3,
+                              "host_enqueue_ms_per_step": t_host / args.steps * 1e3, "global_batch": Bg,
                               "points": N, "points_target": M, "criterion": type(crit).__name__, "alpha": float(alpha),
                               "hip_graph": use_graph,
                               "grad_bucket_floats": bucket.numel, "first_losses": losses[0], "last_losses": losses[-1]}))

@@ -81,6 +81,12 @@ int dvm_linear_prefix_f32(const float *xg, int Cg, const float *x, const float *
                           const float *bias, const float *res, const float *bn_alpha, const float *bn_beta, float slope,
                           float *y, void *stream);
 
+/* Weight gradient of the point-major layer above (what autograd computes for nn.Conv1d.weight in `loss.backward()`,
+ * train.py:110):  dW[co][k] += sum_r gy[r][co] * x[r][k]  over the R = B*N rows; gy [R, Co], x [R, K], dW [Co, K] must be
+ * ZEROED by the caller (row chunks are combined with fp32 atomics: summation order not fixed).  The input gradient of the
+ * same layer needs no entry point of its own: dX = gy W is dvm_linear_f32(x := W as [1, Co, K], w := gy, channel_major = 1). */
+int dvm_linear_wgrad_f32(const float *gy, const float *x, long R, int Co, int K, float *dW, void *stream);
+
 /* knnsearch_t_grad + topk_pi (+ the argmax map)  —  models/loss.py:110-114,
  * 1339-1347, 1404-1407.   D = cdist(f1,f2) (matmul form, bit-identical squared
  * distances); P = softmax(D*neg_alpha) over M; keep the `topk` largest of each
@@ -244,6 +250,16 @@ int dvm_pos_encoding_minmax_f32(const float *x, const float *minmax, int B, int 
  * (may be NULL) get PyTorch's momentum update with the unbiased variance.  Backward: dx (= d res) [B,C,N],
  * dgamma / dbeta [C] (may be NULL); the activation's derivative is taken from the sign of y. */
 size_t dvm_bn_workspace_bytes(int B, int C, int N);
+/* The same fused BatchNorm (forward and backward below) on POINT-MAJOR activations x [R, C] (R = B*N rows, C % 4 == 0), the
+ * layout of the training path: statistics per column, in a fixed summation order (row chunk by row chunk).  The backward
+ * with accumulate = 1 ADDS the parameter gradients to dgamma / dbeta (autograd's `p.grad += g` without the extra launches). */
+size_t dvm_bn_pm_workspace_bytes(long R, int C);
+int dvm_bn_act_train_fwd_pm_f32(const float *x, const float *res, const float *gamma, const float *beta, long R, int C, float eps,
+                                float slope, float momentum, float *y, float *save_mean, float *save_invstd, float *running_mean,
+                                float *running_var, void *ws, size_t ws_bytes, void *stream);
+int dvm_bn_act_train_bwd_pm_f32(const float *dy, const float *y, const float *x, const float *res, const float *gamma,
+                                const float *save_mean, const float *save_invstd, long R, int C, float slope, float *dx,
+                                float *dgamma, float *dbeta, int accumulate, void *ws, size_t ws_bytes, void *stream);
 int dvm_bn_act_train_fwd_f32(const float *x, const float *res, const float *gamma, const float *beta, int B, int C, int N,
                              float eps, float slope, float momentum, float *y, float *save_mean, float *save_invstd,
                              float *running_mean, float *running_var, void *ws, size_t ws_bytes, void *stream);
