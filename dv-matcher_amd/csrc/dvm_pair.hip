@@ -324,6 +324,15 @@ DVM_EXPORT int dvm_pair_fwd_f32(const float *feat1, const float *feat2, const fl
             (void)hipStreamWaitEvent(cx->side, cx->ev_join2, 0);  // ev_join (below) then covers both chains
         }
     }
+    // still on the geometry side: what depends on the xyz kNN and the input features only — the Deformer's pooled features
+    // (once per cloud, points in grid-cell order) and the neighbours' coordinates of the map term — so that the L2-bound
+    // gathers run next to the ALU-bound sweep instead of after it
+    launch_pool_all(feat1, w.idxk[0], B, N, 10, conv_w, conv_b, w.gall[0], s, w.gv[0].ids);
+    launch_pool_all(feat2, w.idxk[1], B, M, 10, conv_w, conv_b, w.gall[1], s, w.gv[1].ids);
+    if (with_map) {
+        launch_gather_nbr_xyz(verts2, w.idxk[1], B, M, 10, w.nbrxyz[1], s);
+        launch_gather_nbr_xyz(verts1, w.idxk[0], B, N, 10, w.nbrxyz[0], s);
+    }
     if (overlap) {
         (void)hipEventRecord(cx->ev_join, cx->side);
         s = caller;
@@ -345,9 +354,7 @@ DVM_EXPORT int dvm_pair_fwd_f32(const float *feat1, const float *feat2, const fl
     rc = dvm_softcorr_apply_f32(w.pval[1], w.pidx[1], verts1, B, M, N, 10, 3, verts21, s);
     if (rc != DVM_OK) return fail(rc);
     if (overlap) (void)hipStreamWaitEvent(caller, cx->ev_join, 0);  // join: everything below needs the graphs / kNN
-    // ---- Deformer: pooled features once per cloud, z for both directions, one MLP launch
-    launch_pool_all(feat1, w.idxk[0], B, N, 10, conv_w, conv_b, w.gall[0], s, w.gv[0].ids);  // points in grid-cell order
-    launch_pool_all(feat2, w.idxk[1], B, M, 10, conv_w, conv_b, w.gall[1], s, w.gv[1].ids);
+    // ---- Deformer: z for both directions from the pooled features (made above), one MLP launch
     const int Nn1 = N / 2, Nn2 = M / 2;
     float *z21 = w.z + (size_t)B * Nn1 * 264;
     launch_assemble_pooled(verts1, verts12, w.gall[0], w.gall[1], w.pval[0], w.pidx[0], w.nodes[0], B, N, M, Nn1, w.z, s);
@@ -376,8 +383,6 @@ DVM_EXPORT int dvm_pair_fwd_f32(const float *feat1, const float *feat2, const fl
     }
     // ---- map terms (losses[:,5])
     if (with_map) {
-        launch_gather_nbr_xyz(verts2, w.idxk[1], B, M, 10, w.nbrxyz[1], s);
-        launch_gather_nbr_xyz(verts1, w.idxk[0], B, N, 10, w.nbrxyz[0], s);
         launch_map_term_nbr(verts12, w.nbrxyz[1], w.idxk[0], w.pval[0], w.pidx[0], B, N, M, 10, 10, w.partial[0], s);
         launch_reduce_partials(w.partial[0], B, map_term_blocks(N, 10), 1.f, losses12, 6, 5, s);
         launch_map_term_nbr(verts21, w.nbrxyz[0], w.idxk[1], w.pval[1], w.pidx[1], B, M, N, 10, 10, w.partial[1], s);

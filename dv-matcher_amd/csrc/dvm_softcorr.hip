@@ -33,33 +33,60 @@ __global__ void rownorm2_kernel(const float *__restrict__ x, int rows, int K, fl
 // K = 128, coalesced: 32 lanes per row.  Same additions in the same order as aten_sumsq_row (K = 128:
 // vec_size 16, size_ilp 4 -> lane l, ILP slot k accumulate x[(4i+k)*8 + l]^2 over i = 0..3, then
 // ((k0 + k1) + k2) + k3, then lanes 0..7 added in order): element 32 i + 8 k + l sits in lane 8 k + l.
+// All cross-lane traffic stays on the DPP network / v_permlane16_swap (17 dependent ds_bpermute round trips per wave
+// otherwise: the kernel ran at 1.3 TB/s).
+__device__ __forceinline__ float dpp_ror8(float v) {      // lane j of a 16-lane row <- lane (j + 8) % 16
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_shr1_zero(float v) {  // lane j <- lane j - 1 of its row; lane 0 of a row <- 0
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, false));
+}
+constexpr int RN_ROWS = 8;   // rows per 32-lane half: 4 KB of loads in flight per half before the first reduction
 __global__ __launch_bounds__(256) void rownorm2_k128_kernel(const float *__restrict__ x, int rows, float *__restrict__ out,
                                                             int *__restrict__ absmax) {
-    const int lane = threadIdx.x & 63, l32 = lane & 31, base = lane & 32;
-    const long row0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-    const long row = row0 < rows ? row0 : rows - 1;
-    const float *p = x + row * 128 + l32;
-    float s = 0.f, am = 0.f;
+    const int lane = threadIdx.x & 63, l32 = lane & 31;
+    const long half = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;   // 32-lane half -> rows [half * 8, half * 8 + 8)
+    float v[RN_ROWS][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float v = p[32 * i];
-        s = s + v * v;
-        am = fmaxf(am, fabsf(v));
+    for (int q = 0; q < RN_ROWS; ++q) {
+        const long row0 = half * RN_ROWS + q, row = row0 < rows ? row0 : rows - 1;
+        const float *p = x + row * 128 + l32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[q][i] = p[32 * i];
+    }
+    float am = 0.f;
+#pragma unroll
+    for (int q = 0; q < RN_ROWS; ++q) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s = s + v[q][i] * v[q][i];
+            am = fmaxf(am, fabsf(v[q][i]));
+        }
+        // lanes 8k + l of a 32-lane half: k = 1 is 8 lanes up in the same 16-lane row, k = 2, 3 sit in the next row
+        const unsigned su = __float_as_uint(s);
+        const auto sw = __builtin_amdgcn_permlane16_swap(su, su, false, false);   // sw[1]: even rows <- the odd row above them
+        const float up = __uint_as_float(sw[1]);
+        const float r = ((s + dpp_ror8(s)) + up) + dpp_ror8(up);  // valid in lanes l32 < 8 (k = 0)
+        // fin = (((r0 + r1) + r2) ... + r7): u_j <- u_{j-1} + r_j seven times leaves it in lane 7 of the half
+        float u = r;
+#pragma unroll
+        for (int st = 0; st < 7; ++st) u = dpp_shr1_zero(u) + r;
+        const long row0 = half * RN_ROWS + q;
+        if (l32 == 7 && row0 < rows) out[row0] = u;
     }
     if (absmax) {  // optional: bit pattern of max |x| of the tensor (the fp16 split's scale, dvm_softcorr_f16.hip)
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
-        // 256 slots (one address would serialise 262k waves); only waves that would raise a slot's maximum touch it
+        int m = __float_as_int(am);   // non-negative floats order like their bit patterns
+        m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x111, 0xf, 0xf, false));  // row_shr:1
+        m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x112, 0xf, 0xf, false));  // row_shr:2
+        m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x114, 0xf, 0xf, false));  // row_shr:4
+        m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x118, 0xf, 0xf, false));  // row_shr:8
+        m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x142, 0xa, 0xf, false));  // row_bcast:15
+        m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x143, 0xc, 0xf, false));  // row_bcast:31 -> lane 63 = the wave's max
+        // 256 slots (one address would serialise the waves); only waves that would raise a slot's maximum touch it
         int *slot = absmax + (blockIdx.x & 255);
-        if (lane == 0 && __float_as_int(am) > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, __float_as_int(am));
+        if (lane == 63 && m > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, m);
     }
-    const float s1 = __shfl(s, base + ((l32 + 8) & 31), 64), s2 = __shfl(s, base + ((l32 + 16) & 31), 64),
-                s3 = __shfl(s, base + ((l32 + 24) & 31), 64);
-    const float r = ((s + s1) + s2) + s3;  // valid in lanes l32 < 8 (k = 0)
-    float fin = 0.f;
-#pragma unroll
-    for (int l = 0; l < 8; ++l) fin = fin + __shfl(r, base + l, 64);
-    if (l32 == 0 && row0 < rows) out[row0] = fin;
 }
 
 // ------------------------------------------------------- per-row running state
@@ -579,7 +606,7 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
 // K == 128 only: also maxes the bit pattern of max |x| into the 256 slots of `absmax_slots` (zero them first);
 // launch_absmax_finalize folds nt x 256 slots into nt values
 void launch_rownorm2_absmax(const float *x, int rows, float *out, int *absmax_slots, hipStream_t s) {
-    hipLaunchKernelGGL(rownorm2_k128_kernel, dim3((unsigned)(((long)rows * 32 + 255) / 256)), dim3(256), 0, s, x, rows, out,
+    hipLaunchKernelGGL(rownorm2_k128_kernel, dim3((unsigned)((((long)rows + RN_ROWS - 1) / RN_ROWS * 32 + 255) / 256)), dim3(256), 0, s, x, rows, out,
                        absmax_slots);
 }
 __global__ void absmax_finalize_kernel(const int *__restrict__ slots, int *__restrict__ out) {
@@ -626,7 +653,7 @@ int launch_softcorr_pair(const float *f1, const float *f2, float *n1, float *n2,
 
 void launch_rownorm2(const float *x, int rows, int K, float *out, hipStream_t s) {
     if (K == 128)
-        hipLaunchKernelGGL(rownorm2_k128_kernel, dim3((unsigned)(((long)rows * 32 + 255) / 256)), dim3(256), 0, s, x, rows, out,
+        hipLaunchKernelGGL(rownorm2_k128_kernel, dim3((unsigned)((((long)rows + RN_ROWS - 1) / RN_ROWS * 32 + 255) / 256)), dim3(256), 0, s, x, rows, out,
                            (int *)nullptr);
     else
         hipLaunchKernelGGL(rownorm2_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, x, rows, K, out);

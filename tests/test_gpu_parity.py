@@ -371,3 +371,14 @@ def test_deformer_mlp_fp16_range_fallback(ops, golden):
             x = np.where(x > 0, x, np.expm1(x))
     # outputs of the blown-up rows are O(1e4) sums of O(1e5) terms: fp32-level agreement is relative to that scale
     np.testing.assert_allclose(host(ref), x, rtol=2e-5, atol=2e-5 * np.abs(x).max())
+
+
+@pytest.mark.parametrize("rows,K", [(1, 128), (7, 128), (4096 + 3, 128), (2 * 2048, 128), (513, 64), (300, 262), (64, 3)])
+def test_rownorm2_bit_exact(ops, rows, K):
+    """|x|^2 per row in ATen's summation order (the norms cdist's matmul form adds to the products): the K = 128 kernel's
+    DPP / permlane reduction tree and the generic kernel against the oracle's restatement, bit for bit, at row counts that
+    leave the last wave partly filled."""
+    g = torch.Generator().manual_seed(rows * 131 + K)
+    x = torch.randn(rows, K, generator=g) * torch.rand(rows, 1, generator=g) * 3
+    got = ops.rownorm2(x.cuda()).cpu().numpy()
+    assert np.array_equal(got, O.rownorm2(x.numpy())), (rows, K)
