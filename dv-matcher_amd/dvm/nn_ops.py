@@ -442,31 +442,3 @@ class _WarpArap(torch.autograd.Function):
 def dg_warp_arap(verts, g, R, T):
     """verts (B,N,3), batched graph dict, R (B,Nn,3,3), T (B,Nn,3) -> warped (B,N,3), arap (B,), with autograd."""
     return _WarpArap.apply(verts, R, T.contiguous(), g["nodes_idx"], g["one_ring"], g["infl_idx"], g["weights"])
-
-
-def rot6d_torch(d6):
-    a1, a2 = d6[..., :3], d6[..., 3:]
-    b1 = torch.nn.functional.normalize(a1, dim=-1)
-    b2 = torch.nn.functional.normalize(a2 - (b1 * a2).sum(-1, keepdim=True) * b1, dim=-1)
-    return torch.stack((b1, b2, torch.cross(b1, b2, dim=-1)), dim=-2)
-
-
-def dg_warp_arap_torch(verts, g, R, T):
-    """Differentiable (w.r.t. R, T) embedded-deformation warp + ARAP for a batch.
-    verts (B,N,3), g: batched graph dict (int32 tensors), R (B,Nn,3,3), T (B,Nn,3) -> warped (B,N,3), arap (B,)."""
-    B, N, _ = verts.shape
-    Nn = R.shape[1]
-    nodes = torch.gather(verts, 1, g["nodes_idx"].long().unsqueeze(-1).expand(-1, -1, 3))      # (B,Nn,3)
-    infl = g["infl_idx"].long()                                                                # (B,N,3)
-    flat = infl.reshape(B, N * 3)
-    gn = torch.gather(nodes, 1, flat.unsqueeze(-1).expand(-1, -1, 3)).view(B, N, 3, 3)         # influencing node coords
-    Rn = torch.gather(R.reshape(B, Nn, 9), 1, flat.unsqueeze(-1).expand(-1, -1, 9)).view(B, N, 3, 3, 3)
-    Tn = torch.gather(T, 1, flat.unsqueeze(-1).expand(-1, -1, 3)).view(B, N, 3, 3)
-    diff = verts.unsqueeze(2) - gn
-    warped = ((torch.einsum('bnsij,bnsj->bnsi', Rn, diff) + gn + Tn) * g["weights"].unsqueeze(-1)).sum(2)
-    ring = g["one_ring"].long().reshape(B, Nn * 9)
-    nb = torch.gather(nodes, 1, ring.unsqueeze(-1).expand(-1, -1, 3)).view(B, Nn, 9, 3)
-    tb = torch.gather(T, 1, ring.unsqueeze(-1).expand(-1, -1, 3)).view(B, Nn, 9, 3)
-    e = (nodes + T).unsqueeze(2) - (nb + tb) - torch.einsum('bnij,bnqj->bnqi', R, nodes.unsqueeze(2) - nb)
-    arap = (e ** 2).sum(dim=(1, 2, 3)) / Nn
-    return warped, arap

@@ -210,3 +210,37 @@ def visual_features(x, upsampler):
     feats = upsampler(torch.cat([p[0] for p in proj], 0))
     B = x.shape[0]
     return torch.cat([F.normalize(i2p(pts[v], feats[v * B:(v + 1) * B], *proj[v][1:]), dim=-1) for v in range(3)], -1)
+
+
+def rot6d(d6):
+    """6D -> rotation matrix by Gram-Schmidt (reference models/loss.py:39-45): rows b1, b2, b1 x b2.  Any dtype; under
+    autograd this is the checker of dvm_rot6d_{fwd,bwd}_f32."""
+    first, second = d6[..., 0:3], d6[..., 3:6]
+    b1 = F.normalize(first, dim=-1)
+    b2 = F.normalize(second - (b1 * second).sum(dim=-1, keepdim=True) * b1, dim=-1)
+    return torch.stack([b1, b2, torch.linalg.cross(b1, b2, dim=-1)], dim=-2)
+
+
+def dg_warp_arap(verts, g, R, T):
+    """Embedded-deformation warp and ARAP energy of a batch of graphs, differentiable w.r.t. R and T (the reference's
+    DeformationGraph_geod.forward, lib/deformation_graph_point.py:233-261, batched): every point moves with its 3
+    influencing nodes, weighted; ARAP compares each node's 9 ring neighbours after the motion with their rotated rest
+    offsets, summed and divided by the node count.  verts (B,N,3); g: dict of nodes_idx (B,Nn), infl_idx (B,N,3),
+    weights (B,N,3), one_ring (B,Nn,9); R (B,Nn,3,3); T (B,Nn,3) -> warped (B,N,3), arap (B,).  Checker of
+    dvm_dg_warp_{fwd,bwd}_f32 (tests/test_gpu_backward.py), pinned by tests/golden/dg_grad_*.npz."""
+    B, N, _ = verts.shape
+    Nn = R.shape[1]
+    take = lambda src, idx: torch.gather(src, 1, idx.unsqueeze(-1).expand(-1, -1, src.shape[-1]))  # noqa: E731
+    nodes = take(verts, g["nodes_idx"].long())                                   # (B,Nn,3) rest positions of the nodes
+    infl = g["infl_idx"].long().reshape(B, N * 3)
+    node_of = take(nodes, infl).view(B, N, 3, 3)
+    rot_of = take(R.reshape(B, Nn, 9), infl).view(B, N, 3, 3, 3)
+    shift_of = take(T, infl).view(B, N, 3, 3)
+    moved = torch.einsum("bnsij,bnsj->bnsi", rot_of, verts.unsqueeze(2) - node_of) + node_of + shift_of
+    warped = (moved * g["weights"].unsqueeze(-1)).sum(dim=2)
+    ring = g["one_ring"].long().reshape(B, Nn * 9)
+    ring_rest = take(nodes, ring).view(B, Nn, 9, 3)
+    ring_shift = take(T, ring).view(B, Nn, 9, 3)
+    rest_offset = nodes.unsqueeze(2) - ring_rest
+    residual = (nodes + T).unsqueeze(2) - (ring_rest + ring_shift) - torch.einsum("bnij,bnqj->bnqi", R, rest_offset)
+    return warped, residual.square().sum(dim=(1, 2, 3)) / Nn

@@ -141,6 +141,26 @@ def group_dg(rl, rdg):
              arap=arap, sr=sr)
 
 
+def group_dg_grad(rl, rdg):
+    """Gradients of the reference's OWN rot6d -> warp + ARAP chain (its autograd, fp32) w.r.t. the Deformer's outputs:
+    the pin for the HIP backward kernels and for oracle/torch_ref.py's fp64 restatement (tests/test_gpu_backward.py)."""
+    for name, n, seed in [("scape", 512, 1), ("rand", 256, 0)]:
+        g = torch.Generator().manual_seed(300 + seed)
+        v = torch.from_numpy(scape_verts(seed, n, seed)) if name == "scape" else torch.rand(n, 3, generator=g)
+        dg = build_graph(rdg, v, 1234 + seed)
+        nn_ = n // 2
+        iden = torch.tensor([1, 0, 0, 0, 1, 0], dtype=torch.float32).view(1, 1, 6)
+        d6 = (0.3 * torch.randn(1, nn_, 6, generator=g) + iden).requires_grad_(True)
+        T = (0.05 * torch.randn(1, nn_, 3, generator=g)).requires_grad_(True)
+        gw = torch.randn(n, 3, generator=g)
+        ga = torch.randn((), generator=g)
+        warped, arap, _sr = dg(v, rl.rotation_6d_to_matrix(d6), T)
+        ((warped * gw).sum() + arap * ga).backward()
+        save("dg_grad_%s_%d" % (name, n), verts=v, fps_start=np.int64(dg.nodes_idx[0]), nodes_idx=dg.nodes_idx.astype(np.int32),
+             one_ring=np.asarray(dg.one_ring_neigh).astype(np.int32), infl_idx=dg.influence_nodes_idx.int(), weights=dg.weights,
+             d6=d6, T=T, gw=gw, ga=ga, warped=warped, arap=arap, d6_grad=d6.grad, T_grad=T.grad)
+
+
 def deformer_weights():
     sd = torch.load(os.path.join(REF, "ckpt/dvmatcher_scape_r/ep_deformer_val_best.pth"), weights_only=True,
                     map_location="cpu")
@@ -270,6 +290,8 @@ def main():
             group_knn(rl, rm)
         elif gname == "dg":
             group_dg(rl, rdg)
+        elif gname == "dg_grad":
+            group_dg_grad(rl, rdg)
         elif gname == "deformer":
             group_deformer(rl, rm)
         elif gname == "loss":

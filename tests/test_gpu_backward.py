@@ -165,14 +165,40 @@ def test_rot6d_warp_arap_bwd_vs_fp64_autograd(ops):
     ga = torch.randn(B, generator=g).cuda()
     warped, arap = nn_ops.dg_warp_arap(verts, graph, nn_ops.rot6d(d6), T)
     ((warped * gw).sum() + (arap * ga).sum()).backward()
-    # fp64 reference: the torch formulation of the same math (nn_ops.*_torch) under autograd
+    # fp64 checker: the oracle's torch restatement under autograd (itself pinned by the reference's gradients below)
     d64 = d6.detach().double().requires_grad_(True)
     t64 = T.detach().double().requires_grad_(True)
     g64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in graph.items() if torch.is_tensor(v)}
-    w_ref, a_ref = nn_ops.dg_warp_arap_torch(verts.double(), g64, nn_ops.rot6d_torch(d64), t64)
+    w_ref, a_ref = TR.dg_warp_arap(verts.double(), g64, TR.rot6d(d64), t64)
     ((w_ref * gw.double()).sum() + (a_ref * ga.double()).sum()).backward()
     assert rel(warped, w_ref) < 1e-5 and rel(arap, a_ref) < 1e-5
     assert rel(d6.grad, d64.grad) < 1e-4 and rel(T.grad, t64.grad) < 1e-4, (rel(d6.grad, d64.grad), rel(T.grad, t64.grad))
+
+
+@pytest.mark.parametrize("name", ["dg_grad_scape_512", "dg_grad_rand_256"])
+def test_rot6d_warp_arap_bwd_vs_reference_gradients(ops, name):
+    """The reference's own autograd through rotation_6d_to_matrix -> DeformationGraph_geod.forward (fp32, recorded by
+    tests/golden/make_fixtures.py dg_grad) against the HIP forward + backward kernels on the reference's graph, and
+    against the oracle's fp64 restatement, which is what the other backward tests check with."""
+    import os
+    from dvm import nn_ops
+    fx = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz")))
+    cu = lambda k, dt=None: torch.from_numpy(fx[k] if dt is None else fx[k].astype(dt)).cuda()   # noqa: E731
+    verts = cu("verts")[None]
+    graph = {"nodes_idx": cu("nodes_idx", np.int32)[None], "one_ring": cu("one_ring", np.int32)[None],
+             "infl_idx": cu("infl_idx", np.int32)[None], "weights": cu("weights", np.float32)[None]}
+    d6 = cu("d6").requires_grad_(True)
+    T = cu("T").requires_grad_(True)
+    gw, ga = cu("gw")[None], cu("ga").reshape(1)
+    warped, arap = nn_ops.dg_warp_arap(verts, graph, nn_ops.rot6d(d6), T)
+    ((warped * gw).sum() + (arap * ga).sum()).backward()
+    assert rel(warped, cu("warped")) < 2e-6 and rel(arap, cu("arap").reshape(1)) < 1e-5
+    assert rel(d6.grad, cu("d6_grad")) < 2e-5 and rel(T.grad, cu("T_grad")) < 2e-5, (rel(d6.grad, cu("d6_grad")), rel(T.grad, cu("T_grad")))
+    d64, t64 = cu("d6").double().requires_grad_(True), cu("T").double().requires_grad_(True)
+    g64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in graph.items()}
+    w_ref, a_ref = TR.dg_warp_arap(verts.double(), g64, TR.rot6d(d64), t64)
+    ((w_ref * gw.double()).sum() + (a_ref * ga.double()).sum()).backward()
+    assert rel(cu("d6_grad"), d64.grad) < 2e-5 and rel(cu("T_grad"), t64.grad) < 2e-5
 
 
 def test_chamfer_bwd_vs_autograd(ops):

@@ -183,3 +183,21 @@ def test_linear_chain_vs_live_torch():
         print("1-thread vs 8-thread Conv1d identical on this host:", torch.equal(y1, y8))
     finally:
         torch.set_num_threads(nt)
+
+
+@pytest.mark.parametrize("name", ["dg_grad_scape_512", "dg_grad_rand_256"])
+def test_torch_ref_warp_arap_gradients_pinned(name):
+    """oracle/torch_ref.py's rot6d + warp/ARAP restatement (the fp64 checker of the HIP backward kernels) against the
+    reference's own outputs and autograd gradients (tests/golden/make_fixtures.py dg_grad)."""
+    import torch
+    from oracle import torch_ref as TR
+    fx = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz")))
+    t = lambda k: torch.from_numpy(fx[k])   # noqa: E731
+    g = {"nodes_idx": t("nodes_idx")[None], "one_ring": t("one_ring")[None], "infl_idx": t("infl_idx")[None],
+         "weights": t("weights").double()[None]}
+    d6, T = t("d6").double().requires_grad_(True), t("T").double().requires_grad_(True)
+    w, a = TR.dg_warp_arap(t("verts").double()[None], g, TR.rot6d(d6), T)
+    ((w * t("gw").double()[None]).sum() + (a * t("ga").double().reshape(1)).sum()).backward()
+    rel = lambda x, y: float((x.detach().double() - y.double()).norm() / y.double().norm())   # noqa: E731
+    assert rel(w, t("warped").reshape(w.shape)) < 1e-6 and rel(a, t("arap").reshape(1)) < 1e-6
+    assert rel(d6.grad, t("d6_grad")) < 2e-6 and rel(T.grad, t("T_grad")) < 2e-6
