@@ -227,7 +227,7 @@ def dg_warp_arap(verts, g, R, T):
     influencing nodes, weighted; ARAP compares each node's 9 ring neighbours after the motion with their rotated rest
     offsets, summed and divided by the node count.  verts (B,N,3); g: dict of nodes_idx (B,Nn), infl_idx (B,N,3),
     weights (B,N,3), one_ring (B,Nn,9); R (B,Nn,3,3); T (B,Nn,3) -> warped (B,N,3), arap (B,).  Checker of
-    dvm_dg_warp_{fwd,bwd}_f32 (tests/test_gpu_backward.py), pinned by tests/golden/dg_grad_*.npz."""
+    dvm_dg_warp_{fwd,bwd}_f32 (tests/test_gpu_backward.py), pinned by tests/golden/graddg_*.npz."""
     B, N, _ = verts.shape
     Nn = R.shape[1]
     take = lambda src, idx: torch.gather(src, 1, idx.unsqueeze(-1).expand(-1, -1, src.shape[-1]))  # noqa: E731

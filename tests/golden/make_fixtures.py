@@ -156,7 +156,7 @@ def group_dg_grad(rl, rdg):
         ga = torch.randn((), generator=g)
         warped, arap, _sr = dg(v, rl.rotation_6d_to_matrix(d6), T)
         ((warped * gw).sum() + arap * ga).backward()
-        save("dg_grad_%s_%d" % (name, n), verts=v, fps_start=np.int64(dg.nodes_idx[0]), nodes_idx=dg.nodes_idx.astype(np.int32),
+        save("graddg_%s_%d" % (name, n), verts=v, fps_start=np.int64(dg.nodes_idx[0]), nodes_idx=dg.nodes_idx.astype(np.int32),
              one_ring=np.asarray(dg.one_ring_neigh).astype(np.int32), infl_idx=dg.influence_nodes_idx.int(), weights=dg.weights,
              d6=d6, T=T, gw=gw, ga=ga, warped=warped, arap=arap, d6_grad=d6.grad, T_grad=T.grad)
 

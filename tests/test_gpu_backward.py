@@ -175,7 +175,7 @@ def test_rot6d_warp_arap_bwd_vs_fp64_autograd(ops):
     assert rel(d6.grad, d64.grad) < 1e-4 and rel(T.grad, t64.grad) < 1e-4, (rel(d6.grad, d64.grad), rel(T.grad, t64.grad))
 
 
-@pytest.mark.parametrize("name", ["dg_grad_scape_512", "dg_grad_rand_256"])
+@pytest.mark.parametrize("name", ["graddg_scape_512", "graddg_rand_256"])
 def test_rot6d_warp_arap_bwd_vs_reference_gradients(ops, name):
     """The reference's own autograd through rotation_6d_to_matrix -> DeformationGraph_geod.forward (fp32, recorded by
     tests/golden/make_fixtures.py dg_grad) against the HIP forward + backward kernels on the reference's graph, and

@@ -185,7 +185,7 @@ def test_linear_chain_vs_live_torch():
         torch.set_num_threads(nt)
 
 
-@pytest.mark.parametrize("name", ["dg_grad_scape_512", "dg_grad_rand_256"])
+@pytest.mark.parametrize("name", ["graddg_scape_512", "graddg_rand_256"])
 def test_torch_ref_warp_arap_gradients_pinned(name):
     """oracle/torch_ref.py's rot6d + warp/ARAP restatement (the fp64 checker of the HIP backward kernels) against the
     reference's own outputs and autograd gradients (tests/golden/make_fixtures.py dg_grad)."""
