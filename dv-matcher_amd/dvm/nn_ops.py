@@ -3,6 +3,8 @@
 Each function here is what one of the reference-named modules calls; it owns the
 `torch.autograd.Function` (where a backward exists) and the tensor-layout glue.
 """
+import threading
+
 import torch
 
 from . import ops
@@ -135,13 +137,28 @@ class _BNActPM(torch.autograd.Function):
         return dx, (dx if res is not None else None), dgamma, dbeta, None, None, None, None, None
 
 
-_counter_sink = None     # while a list: BatchNorm batch counters to bump in ONE launch (Uni3FC's point-major training forward)
+class _CounterSink(threading.local):
+    """Per thread: while `pending` is a list, fused BatchNorm calls append their `num_batches_tracked` to it instead of
+    bumping it, and the owner of the list bumps them all in ONE launch (Uni3FC's point-major training forward: 52 -> 1)."""
+    pending = None
 
 
-def bump_batch_counters(counters):
-    if counters:
-        with torch.no_grad():
-            torch._foreach_add_(counters, 1)
+_counter_sink = _CounterSink()
+
+
+class batched_counter_updates:
+    """Context manager around a forward pass made of bn_act_pm calls."""
+
+    def __enter__(self):
+        self._outer, _counter_sink.pending = _counter_sink.pending, []
+        return self
+
+    def __exit__(self, *exc):
+        mine, _counter_sink.pending = _counter_sink.pending, self._outer
+        if mine:
+            with torch.no_grad():
+                torch._foreach_add_(mine, 1)
+        return False
 
 
 def bn_act_pm(bn, x, res=None, slope=1.0):
@@ -154,8 +171,8 @@ def bn_act_pm(bn, x, res=None, slope=1.0):
         z = x if res is None else x + res
         y = bn(z.transpose(1, 2)).transpose(1, 2)
         return y if slope == 1.0 else torch.nn.functional.leaky_relu(y, slope) if slope != 0.0 else torch.relu(y)
-    if _counter_sink is not None:
-        _counter_sink.append(bn.num_batches_tracked)
+    if _counter_sink.pending is not None:
+        _counter_sink.pending.append(bn.num_batches_tracked)
     else:
         with torch.no_grad():
             bn.num_batches_tracked += 1

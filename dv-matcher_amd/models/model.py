@@ -405,12 +405,8 @@ class Uni3FC(nn.Module, _VisualProjection):
         backward, the BatchNorms the fused row-major kernels; one transpose (the position encoding) in the whole pass."""
         B, _, N = x.shape
         blk = lambda seq, xt: nn_ops.bn_act_pm(seq[1], nn_ops.linear_pm(xt, seq[0].weight), slope=seq[2].negative_slope)  # noqa: E731
-        counters, nn_ops._counter_sink = nn_ops._counter_sink, []
-        try:
+        with nn_ops.batched_counter_updates():       # 52 `num_batches_tracked += 1` as one launch
             return self._train_pm_body(x, dino_feat, blk, B, N)
-        finally:
-            pending, nn_ops._counter_sink = nn_ops._counter_sink, counters
-            nn_ops.bump_batch_counters(pending)       # 52 `num_batches_tracked += 1` as one launch
 
     def _train_pm_body(self, x, dino_feat, blk, B, N):
         f = blk(self.conv, dino_feat)

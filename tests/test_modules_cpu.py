@@ -145,3 +145,36 @@ def test_reference_noise_summary_is_what_the_docs_say(golden):
     self_err = np.abs(g["feat_t8"] - g["feat"]).max(-1)
     assert (self_err > 1e-4).mean() < 0.05 and self_err.max() < 2e-3
     assert 0 < (self_err > 1e-4).sum()          # ... but even there single neighbour flips happen
+
+
+def test_bn_act_pm_module_fallback_and_counter_batching():
+    """bn_act_pm away from the fused kernels (CPU tensors here; SyncBatchNorm / eval mode on a GPU take the same branch):
+    the module itself on a transposed view — statistics, running buffers and activation as nn.BatchNorm1d over (B,C,N)
+    gives them; and the batched counter context leaves module-path counters to the module."""
+    from dvm import nn_ops
+    torch.manual_seed(3)
+    x, res = torch.randn(2, 50, 8), torch.randn(2, 50, 8)
+    a, b = torch.nn.BatchNorm1d(8), torch.nn.BatchNorm1d(8)
+    b.load_state_dict(a.state_dict())
+    with nn_ops.batched_counter_updates():
+        y = nn_ops.bn_act_pm(a, x, res, slope=0.2)
+    ref = torch.nn.functional.leaky_relu(b((x + res).transpose(1, 2)), 0.2).transpose(1, 2)
+    assert torch.equal(y, ref)
+    assert torch.equal(a.running_var, b.running_var) and int(a.num_batches_tracked) == int(b.num_batches_tracked) == 1
+    a.eval(), b.eval()
+    assert torch.equal(nn_ops.bn_act_pm(a, x, None, slope=0.0), torch.relu(b(x.transpose(1, 2))).transpose(1, 2))
+
+
+def test_grad_accumulation_switch_roundtrip():
+    from dvm import nn_ops
+    prev = nn_ops.fuse_grad_accumulation(True)
+    try:
+        p = torch.nn.Parameter(torch.zeros(3))
+        assert nn_ops._grad_buffer(p) is None                       # no .grad yet: autograd's own path
+        p.grad = torch.ones(3)
+        assert nn_ops._grad_buffer(p) is p.grad
+        assert nn_ops._grad_buffer(p * 2) is None                   # not a leaf
+        nn_ops.fuse_grad_accumulation(False)
+        assert nn_ops._grad_buffer(p) is None
+    finally:
+        nn_ops.fuse_grad_accumulation(prev)
