@@ -345,22 +345,13 @@ __device__ __forceinline__ void cubic_w(float t, float w[4]) {
     w[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
     w[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
 }
-__global__ __launch_bounds__(256) void bicubic_pad_kernel(const float *__restrict__ in, int Hi, int Wi, int Ho, int Wo, int pad,
-                                                          float *__restrict__ out) {
-    const int Wp = Wo + 2 * pad, Hp = Ho + 2 * pad;
-    const int wq = blockIdx.x * 256 + threadIdx.x, hq = blockIdx.y;
-    const size_t bc = blockIdx.z;
-    if (wq >= Wp) return;
-    int h = hq - pad, w = wq - pad;
-    h = h < 0 ? -h : (h >= Ho ? 2 * Ho - 2 - h : h);
-    w = w < 0 ? -w : (w >= Wo ? 2 * Wo - 2 - w : w);
-    const float sh = (float)Hi / Ho, sw = (float)Wi / Wo;
+// one output element, any scale: ATen's upsample_bicubic2d (align_corners = False, A = -0.75, source index clamped)
+__device__ __forceinline__ float bicubic_at(const float *__restrict__ src, int Hi, int Wi, float sh, float sw, int h, int w) {
     const float fy = sh * (h + 0.5f) - 0.5f, fx = sw * (w + 0.5f) - 0.5f;
     const int iy = (int)floorf(fy), ix = (int)floorf(fx);
     float wy[4], wx[4];
     cubic_w(fy - iy, wy);
     cubic_w(fx - ix, wx);
-    const float *src = in + bc * Hi * Wi;
     float acc = 0.f;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -370,7 +361,70 @@ __global__ __launch_bounds__(256) void bicubic_pad_kernel(const float *__restric
         for (int b = 0; b < 4; ++b) row = fmaf(wx[b], src[(size_t)yy * Wi + min(max(ix - 1 + b, 0), Wi - 1)], row);
         acc = fmaf(wy[a], row, acc);
     }
-    out[(bc * Hp + hq) * Wp + wq] = acc;
+    return acc;
+}
+__device__ __forceinline__ int reflect_idx(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+__global__ __launch_bounds__(256) void bicubic_pad_kernel(const float *__restrict__ in, int Hi, int Wi, int Ho, int Wo, int pad,
+                                                          float *__restrict__ out) {
+    const int Wp = Wo + 2 * pad, Hp = Ho + 2 * pad;
+    const int wq = blockIdx.x * 256 + threadIdx.x, hq = blockIdx.y;
+    const size_t bc = blockIdx.z;
+    if (wq >= Wp) return;
+    out[(bc * Hp + hq) * Wp + wq] = bicubic_at(in + bc * Hi * Wi, Hi, Wi, (float)Hi / Ho, (float)Wi / Wo, reflect_idx(hq - pad, Ho),
+                                               reflect_idx(wq - pad, Wo));
+}
+
+// Exactly x2 with an odd pad (every JBU stage: 16 -> 32 -> ... -> 256, pad 3): the padded outputs (2a, 2a+1) of either
+// axis are the unpadded (odd, even) pair 2a - pad, 2a + 1 - pad, which interpolate the SAME four source rows / columns
+// with the two constant weight sets t = 0.25 and t = 0.75.  A thread owns a 2 x 2 block: 16 loads for 4 outputs instead
+// of 64, weights formed once; same fma chains per output as bicubic_at, bit for bit.  Blocks that touch the reflected
+// frame take the per-element path.
+__global__ __launch_bounds__(256) void bicubic_pad_x2_kernel(const float *__restrict__ in, int Hi, int Wi, int pad,
+                                                             float *__restrict__ out) {
+    const int Ho = 2 * Hi, Wo = 2 * Wi, Wp = Wo + 2 * pad, Hp = Ho + 2 * pad;
+    const int ax = blockIdx.x * 64 + (threadIdx.x & 63), ay = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const size_t bc = blockIdx.z;
+    const int wq = 2 * ax, hq = 2 * ay;
+    if (wq >= Wp || hq >= Hp) return;
+    const float *src = in + bc * Hi * Wi;
+    float *o = out + (bc * Hp + hq) * Wp + wq;
+    const int h0 = hq - pad, w0 = wq - pad;   // odd; h0 + 1, w0 + 1 even
+    const bool interior = h0 >= 0 && h0 + 1 < Ho && w0 >= 0 && w0 + 1 < Wo && hq + 1 < Hp && wq + 1 < Wp;
+    if (!interior) {
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx)
+                if (hq + dy < Hp && wq + dx < Wp)
+                    o[(size_t)dy * Wp + dx] = bicubic_at(src, Hi, Wi, 0.5f, 0.5f, reflect_idx(h0 + dy, Ho), reflect_idx(w0 + dx, Wo));
+        return;
+    }
+    // h0 = 2k + 1: fy = k + 0.25, rows k-1 .. k+2;  h0 + 1 = 2(k+1): fy = k + 0.75, the same rows
+    const int ky = (h0 - 1) >> 1, kx = (w0 - 1) >> 1;
+    float wlo[4], whi[4];
+    cubic_w(0.25f, wlo);
+    cubic_w(0.75f, whi);
+    float v[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int yy = min(max(ky - 1 + a, 0), Hi - 1);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) v[a][b] = src[(size_t)yy * Wi + min(max(kx - 1 + b, 0), Wi - 1)];
+    }
+    float r[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        float row0 = 0.f, row1 = 0.f;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) row0 = fmaf(wlo[b], v[a][b], row0), row1 = fmaf(whi[b], v[a][b], row1);
+        r[0][0] = fmaf(wlo[a], row0, r[0][0]);
+        r[0][1] = fmaf(wlo[a], row1, r[0][1]);
+        r[1][0] = fmaf(whi[a], row0, r[1][0]);
+        r[1][1] = fmaf(whi[a], row1, r[1][1]);
+    }
+    *(float2 *)o = make_float2(r[0][0], r[0][1]);
+    *(float2 *)(o + Wp) = make_float2(r[1][0], r[1][1]);
 }
 }  // namespace
 }  // namespace dvm
@@ -379,8 +433,12 @@ DVM_EXPORT int dvm_bicubic_resize_pad_f32(const float *in, int BC, int Hi, int W
     DVM_REQUIRE(in && out, "dvm_bicubic_resize_pad_f32: null pointer");
     DVM_REQUIRE(BC >= 1 && Hi >= 1 && Wi >= 1 && Ho >= 1 && Wo >= 1 && pad >= 0 && pad < Ho && pad < Wo, "dvm_bicubic_resize_pad_f32: bad sizes");
     DVM_REQUIRE(BC <= 65535 * 1 && Ho + 2 * pad <= 65535, "dvm_bicubic_resize_pad_f32: B*C=%d or height exceeds the grid limit", BC);
-    hipLaunchKernelGGL(dvm::bicubic_pad_kernel, dim3((Wo + 2 * pad + 255) / 256, Ho + 2 * pad, BC), dim3(256), 0, (hipStream_t)stream, in, Hi, Wi,
-                       Ho, Wo, pad, out);
+    if (Ho == 2 * Hi && Wo == 2 * Wi && (pad & 1) == 1)
+        hipLaunchKernelGGL(dvm::bicubic_pad_x2_kernel, dim3(((Wo + 2 * pad + 1) / 2 + 63) / 64, ((Ho + 2 * pad + 1) / 2 + 3) / 4, BC), dim3(256), 0,
+                           (hipStream_t)stream, in, Hi, Wi, pad, out);
+    else
+        hipLaunchKernelGGL(dvm::bicubic_pad_kernel, dim3((Wo + 2 * pad + 255) / 256, Ho + 2 * pad, BC), dim3(256), 0, (hipStream_t)stream, in, Hi,
+                           Wi, Ho, Wo, pad, out);
     DVM_CHECK_LAUNCH("bicubic_resize_pad");
     return DVM_OK;
 }

@@ -43,13 +43,16 @@ def test_adaptive_conv_tap_major_and_fused_jbu_kernel():
 def test_bicubic_resize_pad_matches_torch():
     from dvm import ops
     g = torch.Generator().manual_seed(6)
-    for (B, C, Hi, Wi, Ho, Wo, pad) in [(2, 5, 16, 16, 32, 32, 3), (1, 3, 9, 13, 18, 26, 3), (1, 2, 7, 5, 224, 224, 0), (1, 4, 128, 128, 256, 256, 3)]:
+    for (B, C, Hi, Wi, Ho, Wo, pad) in [(2, 5, 16, 16, 32, 32, 3), (1, 3, 9, 13, 18, 26, 3), (1, 2, 7, 5, 224, 224, 0), (1, 4, 128, 128, 256, 256, 3),
+                                        (1, 2, 2, 3, 4, 6, 1), (2, 3, 33, 17, 66, 34, 5), (1, 2, 8, 8, 16, 16, 2)]:
         x = torch.randn(B, C, Hi, Wi, generator=g).cuda()
         ref = F.interpolate(x, size=(Ho, Wo), mode="bicubic", align_corners=False)
         if pad:
             ref = F.pad(ref, [pad] * 4, mode="reflect")
         got = ops.bicubic_resize_pad(x, (Ho, Wo), pad)
         assert got.shape == ref.shape and (got - ref).abs().max() < 1e-5, (got - ref).abs().max()
+        if pad:   # the x2 / odd-pad block kernel against the per-element kernel (pad 0) + torch's reflect pad: same fma chains
+            assert torch.equal(got, F.pad(ops.bicubic_resize_pad(x, (Ho, Wo), 0), [pad] * 4, mode="reflect"))
 
 
 def test_jbu_stage_fused_equals_plain_torch():
