@@ -152,6 +152,14 @@ def global_batches(n_pairs, Bg, shuffle_seed=None):
     return [order[i:i + Bg] for i in range(0, n_pairs - Bg + 1, Bg)]
 
 
+def loss_values(out, dev):
+    """The criterion's loss terms as one device vector.  Terms switched off by their weight are Python numbers: they become
+    device scalars through a fill kernel — torch.as_tensor(0, device=...) is a copy from pageable memory, which blocks the
+    host until the stream has drained, i.e. once per step behind the whole forward + backward."""
+    return torch.stack([o.detach().float().reshape(()) if torch.is_tensor(o) and o.is_cuda else
+                        torch.full((), float(o), dtype=torch.float32, device=dev) for o in out])
+
+
 def build_criterion(cfg, partial, n_points):
     L = cfg["loss"]
     cls = GraphDeformLoss_Neural_Partial if partial else GraphDeformLoss_Neural
@@ -259,7 +267,7 @@ def main(argv=None):
             out[0].backward()
             work = None
         # ... overlapped with the host-side bookkeeping of the step (5 loss terms; local values, as the reference logs them)
-        vals = torch.stack([torch.as_tensor(o, device=dev).detach().float().reshape(()) for o in out])
+        vals = loss_values(out, dev)
         if work is not None:
             work.wait()
         opt.step()
@@ -297,7 +305,7 @@ def main(argv=None):
                 f1, f2 = forward_pair(v1, d1, v2, d2)
                 out = crit(f1, f2, dist1, dist2, v1, v2, alpha, dfm, fps_starts=starts, anchors=anchors)
                 out[0].backward()
-                vals = torch.stack([torch.as_tensor(o, device=dev).detach().float().reshape(()) for o in out])
+                vals = loss_values(out, dev)
                 opt.step()
                 bucket.zero()
                 return vals
