@@ -198,7 +198,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void softcorr_sweep_f16_kernel(const
     PackedBest<HB_KC> kb;  // keyed on the approximate squared distance
     kb.init();
     float cref = -INFINITY, l = 0.f;
-    float lim2 = INFINITY;
+    float lim2 = INFINITY, cut2 = INFINITY;
     const float a2 = neg_alpha * LOG2E, cutw = args.cutw;
 
     const int ntiles = (M + HB_KT - 1) / HB_KT;
@@ -308,7 +308,15 @@ __global__ __launch_bounds__(HB_THREADS, 2) void softcorr_sweep_f16_kernel(const
             float v2 = stage[bpos * 64];
             v2 = act ? v2 : INFINITY;
             const double out = kb.insert(PackedBest<HB_KC>::pack(v2, jbase + (bpos & 3) + 8 * (bpos >> 2)));
-            add_term(PackedBest<HB_KC>::key_of(out));  // what is outside the list after this step
+            const float ok = PackedBest<HB_KC>::key_of(out);  // what is outside the list after this step
+            if (LEAN) {
+                // the lean sweep drops softmax terms beyond the cut (< e^-20 of the largest); an entry pushed out of the
+                // list is nearly always beyond it — the whole wave skips the two exponentials unless one lane needs them
+                const bool within = ok <= cut2;
+                if (__builtin_amdgcn_ballot_w64(within) != 0) add_term(within ? ok : INFINITY);
+            } else {
+                add_term(ok);
+            }
         }
         // bound for the next sub-tile: the row's KC-th best is at most min(a_K, b_K, max(a_m, b_m)), m = KC/2
         {
@@ -318,7 +326,8 @@ __global__ __launch_bounds__(HB_THREADS, 2) void softcorr_sweep_f16_kernel(const
             if (LEAN) {
                 const float dmin = __builtin_amdgcn_sqrtf(fmaxf(fminf(w0, __shfl_xor(w0, 32, 64)), 0.f));
                 const float cut = dmin + cutw;  // beyond this the softmax term is < e^-20 of the largest
-                lim2 = fmaxf(thr2, (cut * cut) * 1.000001f);
+                cut2 = (cut * cut) * 1.000001f;
+                lim2 = fmaxf(thr2, cut2);
             } else {
                 lim2 = thr2;
             }
