@@ -1,3 +1,4 @@
+# A/B of two builds of the library on one box: put the baseline at csrc/libdvm_old.so, the candidate at csrc/libdvm_hip.so
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 cp dv-matcher_amd/csrc/libdvm_hip.so dv-matcher_amd/csrc/libdvm_new.so
 for v in old new old new; do
