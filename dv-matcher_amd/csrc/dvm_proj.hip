@@ -520,43 +520,68 @@ __global__ __launch_bounds__(256) void jbu_kernel_kernel(const float *__restrict
 // Adaptive convolution, d = 7: 32 x 8 pixel tiles; a thread keeps its pixel's 49 weights in registers for all channels and
 // reads the inputs of 8 channels at a time from an LDS tile (the first version read weights from LDS and inputs from
 // L1 / L2: 12.5 ms per 24 x 384 x 256^2; the inputs' 49-fold reuse now stays inside the CU).
-constexpr int AT_CC = 8;
+// A thread owns TWO vertically adjacent pixels (tile 32 x 16): the 8 input rows they cover are read once and feed both
+// weight sets — 56 LDS reads per 98 fmas instead of 49 per 49 (the kernel is bound by its LDS reads).
+constexpr int AT_CC = 4, AT_TH = 16;
 __global__ __launch_bounds__(256) void adaptive_conv7_kernel(const float *__restrict__ in, const float *__restrict__ kern, int C, int H, int W,
                                                              int kern_cm, int csplit, float *__restrict__ out) {
-    constexpr int D = 7, R = 3, LW = JT_W + 2 * R, LH = JT_H + 2 * R;
-    __shared__ float tile[AT_CC * LH * LW];
+    constexpr int D = 7, R = 3, LW = JT_W + 2 * R, LH = AT_TH + 2 * R, PER = AT_CC * LH * LW, SLOTS = (PER + 255) / 256;
+    __shared__ float tile[PER];
     const int tx = threadIdx.x & (JT_W - 1), ty = threadIdx.x / JT_W;
-    const int w0 = blockIdx.x * JT_W, h0 = blockIdx.y * JT_H;
+    const int w0 = blockIdx.x * JT_W, h0 = blockIdx.y * AT_TH;
     const int b = blockIdx.z / csplit, cs = blockIdx.z % csplit;
     const int cper = (C + csplit - 1) / csplit, c_beg = cs * cper, c_end = min(C, c_beg + cper);
-    const int w = w0 + tx, h = h0 + ty, Wp = W + 2 * R, Hp = H + 2 * R;
-    const bool live = w < W && h < H;
-    float kw[D * D];
-    if (live) {
+    const int w = w0 + tx, ha = h0 + 2 * ty, Wp = W + 2 * R, Hp = H + 2 * R;
+    const bool live0 = w < W && ha < H, live1 = w < W && ha + 1 < H;
+    float k0[D * D], k1[D * D];
 #pragma unroll
-        for (int t = 0; t < D * D; ++t)
-            kw[t] = kern_cm ? kern[(((size_t)b * D * D + t) * H + h) * W + w] : kern[(((size_t)b * H + h) * W + w) * D * D + t];
+    for (int t = 0; t < D * D; ++t) {
+        const int hq = live0 ? ha : 0, hr = live1 ? ha + 1 : 0, wq = live0 ? w : 0;
+        k0[t] = kern_cm ? kern[(((size_t)b * D * D + t) * H + hq) * W + wq] : kern[(((size_t)b * H + hq) * W + wq) * D * D + t];
+        k1[t] = kern_cm ? kern[(((size_t)b * D * D + t) * H + hr) * W + wq] : kern[(((size_t)b * H + hr) * W + wq) * D * D + t];
     }
+    // the tile elements this thread stages are the same for every channel chunk: their offsets (relative to the chunk's
+    // first channel plane) are formed once, and the next chunk is fetched into registers while the current one is consumed
+    const size_t plane = (size_t)Hp * Wp;
+    int off[SLOTS];
+#pragma unroll
+    for (int q = 0; q < SLOTS; ++q) {
+        const int e = threadIdx.x + 256 * q;
+        const int cc = e / (LH * LW), r = e % (LH * LW), y = r / LW, x = r % LW;
+        const int hh = h0 + y, ww = w0 + x;   // padded coordinates
+        off[q] = (e < PER && hh < Hp && ww < Wp) ? (int)(cc * plane + (size_t)hh * Wp + ww) : -1;
+    }
+    const float *bin = in + (size_t)b * C * plane;
+    float nxt[SLOTS];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int q = 0; q < SLOTS; ++q)
+            nxt[q] = (off[q] >= 0 && c0 + (threadIdx.x + 256 * q) / (LH * LW) < c_end) ? bin[(size_t)c0 * plane + off[q]] : 0.f;
+    };
+    fetch(c_beg);
     for (int c0 = c_beg; c0 < c_end; c0 += AT_CC) {
         __syncthreads();
-        for (int e = threadIdx.x; e < AT_CC * LH * LW; e += 256) {
-            const int cc = e / (LH * LW), r = e % (LH * LW), y = r / LW, x = r % LW;
-            const int hh = h0 + y, ww = w0 + x;   // padded coordinates
-            tile[e] = (c0 + cc < c_end && hh < Hp && ww < Wp) ? in[(((size_t)b * C + c0 + cc) * Hp + hh) * Wp + ww] : 0.f;
-        }
+#pragma unroll
+        for (int q = 0; q < SLOTS; ++q)
+            if (threadIdx.x + 256 * q < PER) tile[threadIdx.x + 256 * q] = nxt[q];
         __syncthreads();
-        if (live) {
+        if (c0 + AT_CC < c_end) fetch(c0 + AT_CC);
 #pragma unroll
-            for (int cc = 0; cc < AT_CC; ++cc) {
-                if (c0 + cc >= c_end) break;
-                const float *tp = tile + (cc * LH + ty) * LW + tx;
-                float acc = 0.f;
+        for (int cc = 0; cc < AT_CC; ++cc) {
+            if (c0 + cc >= c_end) break;
+            const float *tp = tile + (cc * LH + 2 * ty) * LW + tx;
+            float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-                for (int i = 0; i < D; ++i)
+            for (int i = 0; i <= D; ++i)
 #pragma unroll
-                    for (int j = 0; j < D; ++j) acc = fmaf(tp[i * LW + j], kw[i * D + j], acc);
-                out[(((size_t)b * C + c0 + cc) * H + h) * W + w] = acc;
-            }
+                for (int j = 0; j < D; ++j) {
+                    const float v = tp[i * LW + j];
+                    if (i < D) a0 = fmaf(v, k0[i * D + j], a0);
+                    if (i > 0) a1 = fmaf(v, k1[(i - 1) * D + j], a1);
+                }
+            float *o = out + (((size_t)b * C + c0 + cc) * H + ha) * W + w;
+            if (live0) o[0] = a0;
+            if (live1) o[W] = a1;
         }
     }
 }
@@ -583,11 +608,12 @@ DVM_EXPORT int dvm_adaptive_conv_f32(const float *in, const float *kern, int B, 
                 C, H, W, d);
     DVM_REQUIRE(B <= 65535 && H <= 65535, "dvm_adaptive_conv_f32: B or H exceeds the grid limit");
     if (d == 7) {
-        const int tiles = ((W + dvm::JT_W - 1) / dvm::JT_W) * ((H + dvm::JT_H - 1) / dvm::JT_H) * B;
+        const int tiles = ((W + dvm::JT_W - 1) / dvm::JT_W) * ((H + dvm::AT_TH - 1) / dvm::AT_TH) * B;
         int csplit = 1;   // small maps: split the channels over more workgroups until the chip is covered
         while (tiles * csplit < 1024 && csplit * 2 * dvm::AT_CC <= C) csplit *= 2;
         DVM_REQUIRE((long)B * csplit <= 65535, "dvm_adaptive_conv_f32: B exceeds the grid limit");
-        hipLaunchKernelGGL(dvm::adaptive_conv7_kernel, dim3((W + dvm::JT_W - 1) / dvm::JT_W, (H + dvm::JT_H - 1) / dvm::JT_H, B * csplit),
+        DVM_REQUIRE((long)dvm::AT_CC * (H + 6) * (W + 6) < (1L << 31), "dvm_adaptive_conv_f32: image too large (H=%d W=%d)", H, W);
+        hipLaunchKernelGGL(dvm::adaptive_conv7_kernel, dim3((W + dvm::JT_W - 1) / dvm::JT_W, (H + dvm::AT_TH - 1) / dvm::AT_TH, B * csplit),
                            dim3(256), 0, (hipStream_t)stream, in, kern, C, H, W, kern_tap_major, csplit, out);
         DVM_CHECK_LAUNCH("adaptive_conv7");
         return DVM_OK;
