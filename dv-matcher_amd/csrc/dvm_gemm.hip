@@ -39,6 +39,8 @@ struct LinArgs {
     long q_bs, y_bs;                         // batch strides (channel-major); 0 otherwise
     int ldy;
     float slope;                             // 1: no activation; 0: ReLU; else LeakyReLU(slope)
+    const float *post_res;                   // NULL, or laid out like Y: y = post_res + post_scale * (what the epilogue made)
+    float post_scale;
     int tiles_i, tiles_j;
     int qvec;                                // channel-major: rows of Q are 16-byte aligned (N % 4 == 0)
     int kvec;                                // every K-block starts and ends on a multiple of 4
@@ -289,6 +291,7 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a) {
     // BatchNorm is exactly this fma with alpha = w / sqrt(var + eps), beta = fma(-mean, alpha, b)), activation
     const float slope = a.slope;
     const float *__restrict__ R = a.res ? a.res + (size_t)b * a.y_bs : nullptr;
+    const float *__restrict__ R2 = a.post_res ? a.post_res + (size_t)b * a.y_bs : nullptr;
 #pragma unroll
     for (int x = 0; x < TM; ++x)
 #pragma unroll
@@ -313,6 +316,7 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a) {
                 if (R) v = v + R[off];
                 if (a.alpha) v = fmaf(v, ca, ct);
                 if (slope != 1.f) v = v > 0.f ? v : (slope == 0.f ? 0.f : v * slope);
+                if (R2) v = __fadd_rn(__fmul_rn(v, a.post_scale), R2[off]);   // two roundings, like `conv(x) * s + r` in torch
                 Y[off] = v;
             }
         }
@@ -349,9 +353,10 @@ static int pick_cfg(int n, long rows_out_narrow) {
 
 void launch_linear(const float *x, const float *w, int B, int N, int K, int Co, int channel_major, const float *bias,
                    const float *res, const float *alpha, const float *beta, float slope, float *y, hipStream_t s,
-                   const float *xg = nullptr, int Cg = 0) {
+                   const float *xg = nullptr, int Cg = 0, const float *post_res = nullptr, float post_scale = 1.f) {
     LinArgs a;
     a.G = xg, a.Cg = xg ? Cg : 0, a.Nrow = N, a.ldp = K - a.Cg;
+    a.post_res = post_res, a.post_scale = post_scale;
     a.bias = bias, a.res = res, a.alpha = alpha, a.beta = beta, a.slope = slope, a.K = K, a.Y = y;
     a.nkb = gemm_kblocks(K, a.kb);
     a.kvec = 1;
@@ -475,6 +480,17 @@ DVM_EXPORT int dvm_linear_f32(const float *x, const float *w, int B, int N, int 
     DVM_REQUIRE((long)B * N < (1L << 31) && (long)B * N * (Co > K ? Co : K) < (1L << 40), "dvm_linear_f32: too large");
     launch_linear(x, w, B, N, K, Co, channel_major, bias, res, bn_alpha, bn_beta, slope, y, (hipStream_t)stream);
     DVM_CHECK_LAUNCH("linear");
+    return DVM_OK;
+}
+
+DVM_EXPORT int dvm_linear_scaled_residual_f32(const float *x, const float *w, int B, int N, int K, int Co, int channel_major, const float *bias,
+                                              float scale, const float *res, float *y, void *stream) {
+    DVM_REQUIRE(x && w && y && res, "dvm_linear_scaled_residual_f32: null pointer");
+    DVM_REQUIRE(B >= 1 && N >= 1 && K >= 1 && Co >= 1, "dvm_linear_scaled_residual_f32: empty input (B=%d N=%d K=%d Co=%d)", B, N, K, Co);
+    DVM_REQUIRE(K <= 384 * (GEMM_MAX_KB - 2), "dvm_linear_scaled_residual_f32: K=%d exceeds %d", K, 384 * (GEMM_MAX_KB - 2));
+    DVM_REQUIRE((long)B * N < (1L << 31) && (long)B * N * (Co > K ? Co : K) < (1L << 40), "dvm_linear_scaled_residual_f32: too large");
+    launch_linear(x, w, B, N, K, Co, channel_major, bias, nullptr, nullptr, nullptr, 1.f, y, (hipStream_t)stream, nullptr, 0, res, scale);
+    DVM_CHECK_LAUNCH("linear_scaled_residual");
     return DVM_OK;
 }
 

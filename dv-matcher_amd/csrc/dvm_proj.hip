@@ -383,10 +383,12 @@ __global__ __launch_bounds__(256) void bicubic_pad_kernel(const float *__restric
 __global__ __launch_bounds__(256) void bicubic_pad_x2_kernel(const float *__restrict__ in, int Hi, int Wi, int pad,
                                                              float *__restrict__ out) {
     const int Ho = 2 * Hi, Wo = 2 * Wi, Wp = Wo + 2 * pad, Hp = Ho + 2 * pad;
-    const int ax = blockIdx.x * 64 + (threadIdx.x & 63), ay = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const size_t bc = blockIdx.z;
+    const int nx = (Wp + 1) >> 1, ny = (Hp + 1) >> 1;            // blocks per row / column of one plane
+    const int t = blockIdx.x * 256 + threadIdx.x;               // packed: no idle lanes when nx is not a multiple of 64
+    if (t >= nx * ny) return;
+    const int ay = t / nx, ax = t - ay * nx;
+    const size_t bc = blockIdx.y;
     const int wq = 2 * ax, hq = 2 * ay;
-    if (wq >= Wp || hq >= Hp) return;
     const float *src = in + bc * Hi * Wi;
     float *o = out + (bc * Hp + hq) * Wp + wq;
     const int h0 = hq - pad, w0 = wq - pad;   // odd; h0 + 1, w0 + 1 even
@@ -434,7 +436,7 @@ DVM_EXPORT int dvm_bicubic_resize_pad_f32(const float *in, int BC, int Hi, int W
     DVM_REQUIRE(BC >= 1 && Hi >= 1 && Wi >= 1 && Ho >= 1 && Wo >= 1 && pad >= 0 && pad < Ho && pad < Wo, "dvm_bicubic_resize_pad_f32: bad sizes");
     DVM_REQUIRE(BC <= 65535 * 1 && Ho + 2 * pad <= 65535, "dvm_bicubic_resize_pad_f32: B*C=%d or height exceeds the grid limit", BC);
     if (Ho == 2 * Hi && Wo == 2 * Wi && (pad & 1) == 1)
-        hipLaunchKernelGGL(dvm::bicubic_pad_x2_kernel, dim3(((Wo + 2 * pad + 1) / 2 + 63) / 64, ((Ho + 2 * pad + 1) / 2 + 3) / 4, BC), dim3(256), 0,
+        hipLaunchKernelGGL(dvm::bicubic_pad_x2_kernel, dim3((((Wo + 2 * pad + 1) / 2) * ((Ho + 2 * pad + 1) / 2) + 255) / 256, BC), dim3(256), 0,
                            (hipStream_t)stream, in, Hi, Wi, pad, out);
     else
         hipLaunchKernelGGL(dvm::bicubic_pad_kernel, dim3((Wo + 2 * pad + 255) / 256, Ho + 2 * pad, BC), dim3(256), 0, (hipStream_t)stream, in, Hi,

@@ -27,6 +27,7 @@ SIGNATURES = {
     "dvm_rownorm2_f32": (c_int, [_P, c_int, c_int, _P, _P]),
     "dvm_linear_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_float, _P, _P]),
     "dvm_linear_prefix_f32": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_float, _P, _P]),
+    "dvm_linear_scaled_residual_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_float, _P, _P, _P]),
     "dvm_linear_wgrad_f32": (c_int, [_P, _P, ctypes.c_long, c_int, c_int, _P, _P]),
     "dvm_bn_pm_workspace_bytes": (c_size_t, [ctypes.c_long, c_int]),
     "dvm_bn_act_train_fwd_pm_f32": (c_int, [_P, _P, _P, _P, ctypes.c_long, c_int, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P, c_size_t, _P]),

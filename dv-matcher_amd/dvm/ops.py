@@ -74,11 +74,13 @@ def rownorm2(x):
     return out
 
 
-def linear(x, w, bias=None, res=None, bn=None, slope=1.0, channel_major=False, out=None, prefix=None):
+def linear(x, w, bias=None, res=None, bn=None, slope=1.0, channel_major=False, out=None, prefix=None, post=None):
     """1x1 conv / linear layer with its fused epilogue (dvm_linear_f32): act(bn(x W^T + bias + res)).
     point-major (default): x (..., K) -> (..., Co); channel_major: x (B,K,N) -> (B,Co,N) (nn.Conv1d's layout).
     w (Co,K[,1]); bn = (alpha, beta) of the eval-mode BatchNorm (models.model._bn_affine); slope 1 = no activation,
-    0 = ReLU, else LeakyReLU.  The contraction is the reference's single-thread fp32 chain, bit for bit."""
+    0 = ReLU, else LeakyReLU.  The contraction is the reference's single-thread fp32 chain, bit for bit.
+    post = (scale, r): the JBU "fixup" form r + scale * (x W^T + bias) in the same launch (dvm_linear_scaled_residual_f32;
+    excludes res / bn / slope / prefix)."""
     _need_gpu(x, w, bias, res)
     x, w = _f(x), _f(w)
     Co = w.shape[0]
@@ -110,6 +112,17 @@ def linear(x, w, bias=None, res=None, bn=None, slope=1.0, channel_major=False, o
     if res is not None and tuple(res.shape) != tuple(shape):
         raise DvmError("linear: residual shape %s != output shape %s" % (tuple(res.shape), tuple(shape)))
     al, be = (None, None) if bn is None else (_f(bn[0]), _f(bn[1]))
+    if post is not None:
+        if res is not None or bn is not None or slope != 1.0 or Cg:
+            raise DvmError("linear: `post` excludes res / bn / slope / prefix")
+        scale, r = post
+        _need_gpu(r)
+        r = _f(r)
+        if tuple(r.shape) != tuple(shape):
+            raise DvmError("linear: post residual shape %s != output shape %s" % (tuple(r.shape), tuple(shape)))
+        check(_lib.load().dvm_linear_scaled_residual_f32(_p(x), _p(w), B, N, K, Co, 1 if channel_major else 0, _p(bias), float(scale),
+                                                         _p(r), _p(out), _stream()), "dvm_linear_scaled_residual_f32")
+        return out
     if Cg:
         check(_lib.load().dvm_linear_prefix_f32(_p(prefix), Cg, _p(x), _p(w), B, N, K, Co, _p(bias), _p(res), _p(al), _p(be),
                                                 float(slope), _p(out), _stream()), "dvm_linear_prefix_f32")

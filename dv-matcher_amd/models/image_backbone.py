@@ -95,9 +95,18 @@ class DinoV2ViT(nn.Module):
         g = int(round(math.sqrt(n)))
         if (h, w) == (g, g):
             return self.pos_embed
+        # frozen weights (no autograd, eval): the resized table is a constant of (h, w) — ATen's bicubic kernel runs this
+        # small resize in ONE workgroup (0.85 ms per forward), so it is made once per version of the parameter
+        frozen = not torch.is_grad_enabled() and not self.training
+        key = (h, w, self.pos_embed.data_ptr(), self.pos_embed._version, str(self.pos_embed.device))
+        if frozen and getattr(self, "_pos_cache", (None, None))[0] == key:
+            return self._pos_cache[1]
         grid = self.pos_embed[:, 1:].reshape(1, g, g, -1).permute(0, 3, 1, 2)
         grid = F.interpolate(grid, size=(h, w), mode="bicubic", align_corners=False)
-        return torch.cat([self.pos_embed[:, :1], grid.permute(0, 2, 3, 1).reshape(1, h * w, -1)], dim=1)
+        pos = torch.cat([self.pos_embed[:, :1], grid.permute(0, 2, 3, 1).reshape(1, h * w, -1)], dim=1)
+        if frozen:
+            self._pos_cache = (key, pos.detach())
+        return pos
 
     def forward_patch_tokens(self, img):
         """(B,3,H,W), H and W multiples of 14 -> normalised patch tokens as a map (B,C,H/14,W/14)."""
@@ -134,18 +143,27 @@ class ChannelNorm(nn.Module):
 
 
 # ----------------------------------------------------------------------------------------------- joint bilateral upsampling
-def _conv1x1(conv, x):
+def _conv1x1(conv, x, post=None):
     """A 1x1 nn.Conv2d as the GEMM it is, on the library's own matrix-core kernel (MIOpen falls back to a naive fp32
-    convolution for these shapes: 15 ms per call at 24 x 256^2 pixels); anything else goes through the module."""
+    convolution for these shapes: 15 ms per call at 24 x 256^2 pixels); anything else goes through the module.
+    post = (scale, r): r + scale * conv(x), in the GEMM's epilogue on the library path."""
     if x.is_cuda and conv.kernel_size == (1, 1) and not torch.is_grad_enabled():
         B, C, H, W = x.shape
-        return ops.linear(x.reshape(B, C, H * W), conv.weight, bias=conv.bias, channel_major=True).view(B, -1, H, W)
-    return conv(x)
+        if post is not None:
+            post = (post[0], post[1].reshape(B, -1, H * W))
+        return ops.linear(x.reshape(B, C, H * W), conv.weight, bias=conv.bias, channel_major=True, post=post).view(B, -1, H, W)
+    y = conv(x)
+    return y if post is None else y * post[0] + post[1]
 
 
-def _seq1x1(seq, x):
-    for m in seq:
-        x = _conv1x1(m, x) if isinstance(m, nn.Conv2d) else m(x)
+def _seq1x1(seq, x, post=None):
+    """A Sequential of 1x1 convs / activations / dropouts; `post` applies to its LAST conv (which must end it)."""
+    mods = list(seq)
+    for i, m in enumerate(mods):
+        last = post is not None and i == len(mods) - 1
+        if last and not isinstance(m, nn.Conv2d):
+            raise ValueError("_seq1x1: `post` needs the sequence to end in a convolution")
+        x = _conv1x1(m, x, post if last else None) if isinstance(m, nn.Conv2d) else m(x)
     return x
 
 
@@ -191,7 +209,7 @@ class JBULearnedRange(nn.Module):
         B, _, H, W = guidance.shape
         if guidance.is_cuda and self.key_dim == 32 and self.diameter == 7 and not self.training:
             k = ops.jbu_kernel(_seq1x1(self.range_proj, guidance), self.range_temp, self.sigma_spatial, self.diameter)   # (B,49,H,W)
-            k = k + 0.1 * _seq1x1(self.fixup_proj, torch.cat([k, guidance], dim=1))
+            k = _seq1x1(self.fixup_proj, torch.cat([k, guidance], dim=1), post=(0.1, k))     # k + 0.1 * fixup(...)
             return ops.adaptive_conv(ops.bicubic_resize_pad(source, (H, W), self.radius), k, tap_major=True)
         k = self.combined_kernel_torch(guidance)
         k = k + 0.1 * self.fixup_proj(torch.cat([k, guidance], dim=1))
@@ -209,7 +227,7 @@ class JBUStack(nn.Module):
         for up in (self.up1, self.up2, self.up3, self.up4):
             h, w = source.shape[2] * 2, source.shape[3] * 2
             source = up(source, F.adaptive_avg_pool2d(guidance, (h, w)))
-        return _seq1x1(self.fixup_proj, source) * 0.1 + source
+        return _seq1x1(self.fixup_proj, source, post=(0.1, source))     # fixup(source) * 0.1 + source
 
 
 class UpsampledBackbone(nn.Module):

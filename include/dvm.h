@@ -81,6 +81,12 @@ int dvm_linear_prefix_f32(const float *xg, int Cg, const float *x, const float *
                           const float *bias, const float *res, const float *bn_alpha, const float *bn_beta, float slope,
                           float *y, void *stream);
 
+/* The "fixup" form of FeatUp's JBU stages (featup/upsamplers.py: `x + 0.1 * conv1x1(x')`):  y = res + scale * (x . w^T + bias)
+ * in one launch, `res` laid out like y; the product is the same chain as dvm_linear_f32, then one multiply and one add
+ * (two roundings, as the torch expression). */
+int dvm_linear_scaled_residual_f32(const float *x, const float *w, int B, int N, int K, int Co, int channel_major, const float *bias,
+                                   float scale, const float *res, float *y, void *stream);
+
 /* Weight gradient of the point-major layer above (what autograd computes for nn.Conv1d.weight in `loss.backward()`,
  * train.py:110):  dW[co][k] += sum_r gy[r][co] * x[r][k]  over the R = B*N rows; gy [R, Co], x [R, K], dW [Co, K] must be
  * ZEROED by the caller (row chunks are combined with fp32 atomics: summation order not fixed).  The input gradient of the

@@ -137,3 +137,19 @@ def test_bn_affine_fold_matches_aten(ops, golden):
         out = ops.linear(torch.from_numpy(g["x%d" % i]).cuda(), torch.from_numpy(w).cuda(), bias=None if b is None else torch.from_numpy(b).cuda(),
                          bn=mm._bn_affine(bn), slope=0.2, channel_major=True)
         assert np.array_equal(out.cpu().numpy(), g["z%d" % i]), i
+
+
+@pytest.mark.parametrize("cm", [False, True])
+def test_linear_scaled_residual_epilogue(ops, cm):
+    """r + s * (x W^T + b) in the GEMM's epilogue (dvm_linear_scaled_residual_f32, the JBU "fixup" form) == the same GEMM
+    followed by torch's multiply and add, bit for bit (one multiply and one add, not an fma)."""
+    g = torch.Generator().manual_seed(21)
+    B, N, K, Co = 3, 777, 100, 52
+    x = torch.randn(B, K, N, generator=g).cuda() if cm else torch.randn(B, N, K, generator=g).cuda()
+    w, b = torch.randn(Co, K, generator=g).cuda(), torch.randn(Co, generator=g).cuda()
+    plain = ops.linear(x, w, bias=b, channel_major=cm)
+    r = torch.randn(plain.shape, generator=g).cuda()
+    got = ops.linear(x, w, bias=b, channel_major=cm, post=(0.1, r))
+    assert torch.equal(got, plain * 0.1 + r)
+    with pytest.raises(Exception):
+        ops.linear(x, w, bias=b, channel_major=cm, post=(0.1, r), slope=0.2)
