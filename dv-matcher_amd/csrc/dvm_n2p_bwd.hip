@@ -16,6 +16,8 @@
 namespace dvm {
 namespace {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 constexpr int NP_H = 4;
 constexpr int NP_KMAX = 64;
 
@@ -161,65 +163,65 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(int32_t *__restrict__ cn
     if (tid == 1023) c[N] = part[1023];
 }
 
+// edges[pos] = (e, source point) with e = point * K + slot (the point is stored, not derived: an integer division by the
+// run-time K per edge was a fifth of the gather kernel's instructions)
 __global__ void csr_fill_kernel(const int32_t *__restrict__ idx, int N, int K, int32_t *__restrict__ cursor,
-                                int32_t *__restrict__ edges) {
+                                int2 *__restrict__ edges) {
     const int b = blockIdx.y;
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (long)N * K) return;
+    const int pt = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);   // one wave per point: K <= 64 slots
+    const int slot = threadIdx.x & 63;
+    if (pt >= N || slot >= K) return;
+    const int e = pt * K + slot;
     const int pos = atomicAdd(cursor + (size_t)b * N + idx[(size_t)b * N * K + e], 1);
-    edges[(size_t)b * N * K + pos] = (int32_t)e;  // e = point * K + slot
+    edges[(size_t)b * N * K + pos] = make_int2(e, pt);
 }
 
+// dkp_r = sum over the in-edges (i -> r) of de_i,slot * q_i (per head), dvp_r = sum a_i,slot * g_i - g_r.
+// One wave per target point; a lane owns 4 consecutive channels (16-byte loads), so a row takes C/4 lanes and the wave
+// walks 64 / (C/4) in-edges per instruction (4 at C = 64, 2 at C = 128), two such groups in flight; the partial sums of
+// the edge slots are combined at the end.  (One float per lane and one edge per instruction before: 213 / 192 us.)
 template <int C>
 __global__ __launch_bounds__(256) void n2p_bwd_gather_kernel(const float *__restrict__ qkv, const float *__restrict__ attn,
                                                              const float *__restrict__ de_buf, const float *__restrict__ gout,
-                                                             const int32_t *__restrict__ offs, const int32_t *__restrict__ edges,
+                                                             const int32_t *__restrict__ offs, const int2 *__restrict__ edges,
                                                              int N, int K, float *__restrict__ dqkv) {
-    constexpr int CPL = C / 64, LD = 3 * C;
+    constexpr int LPR = C / 4, EPW = 64 / LPR, LD = 3 * C, D = C / NP_H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long r = (long)blockIdx.x * 4 + wave;
     if (r >= N) return;
     const int b = blockIdx.y;
     const size_t base = (size_t)b * N;
-    const int hd = lane >> 4;
+    const int sub = lane / LPR, l = lane % LPR, hd = (4 * l) / D;
     const int beg = offs[(size_t)b * (N + 1) + r], end = offs[(size_t)b * (N + 1) + r + 1];
-    const int32_t *ed = edges + base * K;
+    const int2 *ed = edges + base * K;
     const float *ab = attn + base * K * NP_H, *db = de_buf + base * K * NP_H;
-    float ak[CPL], av[CPL];
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) ak[c] = 0.f, av[c] = 0.f;
-    int e = beg;
-    for (; e + 1 < end; e += 2) {  // two in-edges in flight
-        const int e0 = ed[e], e1 = ed[e + 1];
-        const int n0 = e0 / K, n1 = e1 / K;
-        const float d0 = db[(size_t)e0 * NP_H + hd], a0 = ab[(size_t)e0 * NP_H + hd];
-        const float d1 = db[(size_t)e1 * NP_H + hd], a1 = ab[(size_t)e1 * NP_H + hd];
-        const float *q0 = qkv + (base + n0) * LD + lane * CPL, *g0 = gout + (base + n0) * C + lane * CPL;
-        const float *q1 = qkv + (base + n1) * LD + lane * CPL, *g1 = gout + (base + n1) * C + lane * CPL;
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-            ak[c] = fmaf(d0, q0[c], ak[c]);
-            av[c] = fmaf(a0, g0[c], av[c]);
-            ak[c] = fmaf(d1, q1[c], ak[c]);
-            av[c] = fmaf(a1, g1[c], av[c]);
-        }
+    f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
+    auto edge = [&](int e, f32x4 &k_acc, f32x4 &v_acc) {
+        const int2 en = ed[e];
+        const float d = db[(size_t)en.x * NP_H + hd], a = ab[(size_t)en.x * NP_H + hd];
+        const f32x4 q = *(const f32x4 *)(qkv + (base + en.y) * LD + 4 * l);
+        const f32x4 g = *(const f32x4 *)(gout + (base + en.y) * C + 4 * l);
+        k_acc += d * q;
+        v_acc += a * g;
+    };
+    int e = beg + sub;
+    f32x4 ak2 = ak, av2 = av;
+    for (; e + EPW < end; e += 2 * EPW) {
+        edge(e, ak, av);
+        edge(e + EPW, ak2, av2);
     }
-    if (e < end) {
-        const int e0 = ed[e];
-        const int n0 = e0 / K;
-        const float d0 = db[(size_t)e0 * NP_H + hd], a0 = ab[(size_t)e0 * NP_H + hd];
-        const float *q0 = qkv + (base + n0) * LD + lane * CPL, *g0 = gout + (base + n0) * C + lane * CPL;
+    if (e < end) edge(e, ak, av);
+    ak += ak2, av += av2;
+    // combine the EPW edge slots (lanes l, l + LPR, ...)
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-            ak[c] = fmaf(d0, q0[c], ak[c]);
-            av[c] = fmaf(a0, g0[c], av[c]);
-        }
-    }
-    float *dst = dqkv + (base + r) * LD + lane * CPL;
+    for (int o = LPR; o < 64; o <<= 1)
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) {
-        dst[C + c] = ak[c];
-        dst[2 * C + c] = av[c] - gout[(base + r) * C + lane * CPL + c];
+        for (int c = 0; c < 4; ++c) ak[c] += __shfl_xor(ak[c], o, 64), av[c] += __shfl_xor(av[c], o, 64);
+    if (sub == 0) {
+        float *dst = dqkv + (base + r) * LD + 4 * l;
+        const f32x4 gr = *(const f32x4 *)(gout + (base + r) * C + 4 * l);
+        *(f32x4 *)(dst + C) = ak;
+        *(f32x4 *)(dst + 2 * C) = av - gr;
     }
 }
 
@@ -247,7 +249,7 @@ DVM_EXPORT int dvm_n2p_core_fwd_f32(const float *qkv, const int32_t *idx, int B,
 
 DVM_EXPORT size_t dvm_n2p_core_bwd_workspace_bytes(int B, int N, int K) {
     return align_up((size_t)B * N * K * NP_H * sizeof(float)) + align_up((size_t)B * (N + 1) * sizeof(int32_t)) +
-           align_up((size_t)B * N * sizeof(int32_t)) + align_up((size_t)B * N * K * sizeof(int32_t));
+           align_up((size_t)B * N * sizeof(int32_t)) + align_up((size_t)B * N * K * sizeof(int2));
 }
 
 DVM_EXPORT int dvm_n2p_core_bwd_f32(const float *qkv, const int32_t *idx, const float *attn, const float *g_out, int B, int N, int C,
@@ -261,7 +263,7 @@ DVM_EXPORT int dvm_n2p_core_bwd_f32(const float *qkv, const int32_t *idx, const 
     float *de = ar.take<float>((size_t)B * N * K * NP_H);
     int32_t *offs = ar.take<int32_t>((size_t)B * (N + 1));
     int32_t *cursor = ar.take<int32_t>((size_t)B * N);
-    int32_t *edges = ar.take<int32_t>((size_t)B * N * K);
+    int2 *edges = ar.take<int2>((size_t)B * N * K);
     if (!ar.ok()) {
         set_error("dvm_n2p_core_bwd_f32: workspace too small (%zu < %zu)", ws_bytes, ar.off);
         return DVM_ENOSPACE;
@@ -271,7 +273,7 @@ DVM_EXPORT int dvm_n2p_core_bwd_f32(const float *qkv, const int32_t *idx, const 
     (void)hipMemsetAsync(offs, 0, (size_t)B * (N + 1) * sizeof(int32_t), s);
     hipLaunchKernelGGL(csr_count_kernel, egrid, dim3(256), 0, s, idx, N, K, offs);
     hipLaunchKernelGGL(csr_scan_kernel, dim3(B), dim3(1024), 0, s, offs, N, cursor);
-    hipLaunchKernelGGL(csr_fill_kernel, egrid, dim3(256), 0, s, idx, N, K, cursor, edges);
+    hipLaunchKernelGGL(csr_fill_kernel, dim3((N + 3) / 4, B), dim3(256), 0, s, idx, N, K, cursor, edges);
     if (C == 64) {
         hipLaunchKernelGGL(n2p_bwd_point_kernel<64>, grid, dim3(256), 0, s, qkv, idx, attn, g_out, N, K, de, d_qkv);
         hipLaunchKernelGGL(n2p_bwd_gather_kernel<64>, grid, dim3(256), 0, s, qkv, attn, de, g_out, offs, edges, N, K, d_qkv);

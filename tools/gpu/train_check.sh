@@ -1,0 +1,7 @@
+# training-path tests + step timing (B = 8 x 2048, B = 2 x 1024 eager and graph)
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+timeout 1200 python -m pytest tests/test_gpu_backward.py tests/test_gpu_train_pm.py tests/test_gpu_network.py tests/test_gpu_ddp.py -q -x 2>&1 | tail -3
+cd dv-matcher_amd
+python train_driver.py --steps 10 --warmup 3 --batch 8 --points 2048 2>&1 | tail -1 | cut -c60-250
+python train_driver.py --steps 10 --warmup 3 --batch 2 --points 1024 2>&1 | tail -1 | cut -c60-250
+python train_driver.py --steps 10 --warmup 3 --batch 2 --points 1024 --graph 2>&1 | tail -1 | cut -c60-250
