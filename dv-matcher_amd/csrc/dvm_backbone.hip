@@ -779,7 +779,7 @@ __global__ __launch_bounds__(256) void n2p_attention_kernel(const float *__restr
 // ============================================================== K10: dist loss term
 // per (b, anchor n): x_j = |feat[idx_j] - feat[a_n]|_2, y_j = dist[b, idx_j, a_n], j < k;
 // term = 1 - |cos(x, y)|;  out[b] = sum_n term.   One wave per (b, n).
-__global__ __launch_bounds__(256) void dist_loss_kernel(const float *__restrict__ feat, const float *__restrict__ dist,
+__global__ __launch_bounds__(256) void dist_loss_generic_kernel(const float *__restrict__ feat, const float *__restrict__ dist,
                                                         const int32_t *__restrict__ anchors, const int32_t *__restrict__ idx,
                                                         int N, int C, int nA, int k, double *__restrict__ partial) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -829,7 +829,7 @@ __global__ __launch_bounds__(256) void dist_loss_kernel(const float *__restrict_
 //     d feat[a_n] += rowsum(W)_n feat[a_n] - (W feat)_n
 // (k = 500 neighbours x 128 channels per anchor as atomics would be 0.5 G atomics per shape batch).
 // W [B][nA][N] must be zero-filled by the caller.  One wave per (b, n), k <= 512.
-__global__ __launch_bounds__(256) void dist_loss_bwd_weights_kernel(const float *__restrict__ feat, const float *__restrict__ dist,
+__global__ __launch_bounds__(256) void dist_loss_bwd_weights_generic_kernel(const float *__restrict__ feat, const float *__restrict__ dist,
                                                                     const int32_t *__restrict__ anchors,
                                                                     const int32_t *__restrict__ idx, const float *__restrict__ gterm,
                                                                     int N, int C, int nA, int k, float *__restrict__ W) {
@@ -864,6 +864,106 @@ __global__ __launch_bounds__(256) void dist_loss_bwd_weights_kernel(const float 
             sxx = fmaf(xs[u], xs[u], sxx);
             syy = fmaf(ys[u], ys[u], syy);
         }
+    }
+    sxy = wave_sum(sxy);
+    sxx = wave_sum(sxx);
+    syy = wave_sum(syy);
+    const float nx = fmaxf(sqrt_rn(sxx), 1e-8f), ny = fmaxf(sqrt_rn(syy), 1e-8f);
+    const float cosv = sxy / (nx * ny);
+    const float sg = cosv > 0.f ? -1.f : (cosv < 0.f ? 1.f : 0.f);  // d(1 - |cos|)/d cos
+    const float g = gterm[b] * sg;
+    const float inv = 1.f / (nx * ny), cx = cosv / (nx * nx);
+    float *Wr = W + ((size_t)b * nA + n) * N;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int j = lane + 64 * u;
+        if (j < k && xs[u] > 0.f) Wr[ix[j]] = g * (ys[u] * inv - cx * xs[u]) / xs[u];
+    }
+}
+
+// C = 128 (LG-Net's feature width), k <= 512: the rows above are read by 64 lanes streaming 64 DIFFERENT rows, 16 bytes
+// each per instruction — 64 cache lines per load, every line fetched 8 times (0.55 ms per call at 8 x 1000 anchors x 500
+// neighbours).  Here a 32-lane half reads ONE whole row per instruction (512 contiguous bytes), the half's partial sums
+// are combined on the DPP network, and lane j % 64 keeps x_j, so that what follows is the arithmetic of the kernels above.
+__device__ __forceinline__ void dist_rows128(const float *__restrict__ featb, const float *__restrict__ distb, int N, int a,
+                                             const int32_t *__restrict__ ix, int k, int lane, float (&xs)[8], float (&ys)[8]) {
+    const int half = lane >> 5, l = lane & 31;
+    const f32x4 q = *(const f32x4 *)(featb + (size_t)a * 128 + 4 * l);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {   // the geodesic column entries: scattered 4-byte reads, all requested up front
+        const int j = lane + 64 * u;
+        xs[u] = 0.f;
+        ys[u] = j < k ? distb[(size_t)ix[j] * N + a] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        if (64 * u >= k) break;
+#pragma unroll 4
+        for (int jj = 0; jj < 64; jj += 2) {
+            if (64 * u + jj >= k) break;
+            const int j = 64 * u + jj + half;
+            const int v = ix[j < k ? j : k - 1];
+            const f32x4 p = *(const f32x4 *)(featb + (size_t)v * 128 + 4 * l);
+            const float d0 = p.x - q.x, d1 = p.y - q.y, d2 = p.z - q.z, d3 = p.w - q.w;
+            float s2 = d0 * d0;
+            s2 = fmaf(d1, d1, s2);
+            s2 = fmaf(d2, d2, s2);
+            s2 = fmaf(d3, d3, s2);
+            s2 = sum32(s2);
+            const float x = j < k ? sqrt_rn(s2) : 0.f;
+            const float o = lane_xor32(x);
+            if (lane == jj) xs[u] = half ? o : x;
+            if (lane == jj + 1) xs[u] = half ? x : o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void dist_loss_kernel(const float *__restrict__ feat, const float *__restrict__ dist,
+                                                        const int32_t *__restrict__ anchors, const int32_t *__restrict__ idx,
+                                                        int N, int nA, int k, double *__restrict__ partial) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * (blockDim.x >> 6) + wave;
+    const int b = blockIdx.y;
+    __shared__ double red[4];
+    double term = 0.0;
+    if (n < nA) {
+        float xs[8], ys[8];
+        dist_rows128(feat + (size_t)b * N * 128, dist + (size_t)b * N * N, N, anchors[n], idx + ((size_t)b * nA + n) * k, k, lane, xs, ys);
+        float sxy = 0.f, sxx = 0.f, syy = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            sxy = fmaf(xs[u], ys[u], sxy);
+            sxx = fmaf(xs[u], xs[u], sxx);
+            syy = fmaf(ys[u], ys[u], syy);
+        }
+        sxy = wave_sum(sxy);
+        sxx = wave_sum(sxx);
+        syy = wave_sum(syy);
+        const float nx = fmaxf(sqrt_rn(sxx), 1e-8f), ny = fmaxf(sqrt_rn(syy), 1e-8f);
+        term = 1.0 - (double)fabsf(sxy / (nx * ny));
+    }
+    if (lane == 0) red[wave] = term;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(size_t)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void dist_loss_bwd_weights_kernel(const float *__restrict__ feat, const float *__restrict__ dist,
+                                                                    const int32_t *__restrict__ anchors,
+                                                                    const int32_t *__restrict__ idx, const float *__restrict__ gterm,
+                                                                    int N, int nA, int k, float *__restrict__ W) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * (blockDim.x >> 6) + wave;
+    const int b = blockIdx.y;
+    if (n >= nA) return;
+    const int32_t *ix = idx + ((size_t)b * nA + n) * k;
+    float xs[8], ys[8];
+    dist_rows128(feat + (size_t)b * N * 128, dist + (size_t)b * N * N, N, anchors[n], ix, k, lane, xs, ys);
+    float sxy = 0.f, sxx = 0.f, syy = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        sxy = fmaf(xs[u], ys[u], sxy);
+        sxx = fmaf(xs[u], xs[u], sxx);
+        syy = fmaf(ys[u], ys[u], syy);
     }
     sxy = wave_sum(sxy);
     sxx = wave_sum(sxx);
@@ -1112,8 +1212,11 @@ DVM_EXPORT int dvm_dist_loss_bwd_weights_f32(const float *feat, const float *dis
     DVM_REQUIRE(k >= 1 && k <= 512 && k <= N, "dvm_dist_loss_bwd_weights_f32: k=%d unsupported", k);
     hipStream_t s = (hipStream_t)stream;
     (void)hipMemsetAsync(W, 0, (size_t)B * nA * N * sizeof(float), s);
-    hipLaunchKernelGGL(dist_loss_bwd_weights_kernel, dim3((nA + 3) / 4, B), dim3(256), 0, s, feat, dist, anchors, idx, g_out, N, C, nA,
-                       k, W);
+    if (C == 128)
+        hipLaunchKernelGGL(dist_loss_bwd_weights_kernel, dim3((nA + 3) / 4, B), dim3(256), 0, s, feat, dist, anchors, idx, g_out, N, nA, k, W);
+    else
+        hipLaunchKernelGGL(dist_loss_bwd_weights_generic_kernel, dim3((nA + 3) / 4, B), dim3(256), 0, s, feat, dist, anchors, idx, g_out, N, C, nA,
+                           k, W);
     DVM_CHECK_LAUNCH("dist_loss_bwd_weights");
     return DVM_OK;
 }
@@ -1145,7 +1248,10 @@ DVM_EXPORT int dvm_dist_loss_fwd_f32(const float *feat, const float *dist, const
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)(((long)nA * C + 255) / 256), B), dim3(256), 0, s, feat, anchors, N, C, nA,
                        fa);
     launch_knn_neg(fa, feat, B, nA, N, C, k, idx, na, nb, S, s);
-    hipLaunchKernelGGL(dist_loss_kernel, dim3(nblk, B), dim3(256), 0, s, feat, dist, anchors, idx, N, C, nA, k, partial);
+    if (C == 128 && k <= 512)
+        hipLaunchKernelGGL(dist_loss_kernel, dim3(nblk, B), dim3(256), 0, s, feat, dist, anchors, idx, N, nA, k, partial);
+    else
+        hipLaunchKernelGGL(dist_loss_generic_kernel, dim3(nblk, B), dim3(256), 0, s, feat, dist, anchors, idx, N, C, nA, k, partial);
     launch_reduce_partials(partial, B, nblk, 1.f, out, 1, 0, s);
     DVM_CHECK_LAUNCH("dist_loss");
     return DVM_OK;

@@ -292,6 +292,33 @@ __device__ __forceinline__ float d2_diff3(float ax, float ay, float az, float bx
     return (xx + yy) + zz;
 }
 
+// ---- cross-lane exchanges without the LDS round trip of __shfl_xor (ds_bpermute): DPP within a 16-lane row,
+// v_permlane16_swap / v_permlane32_swap (gfx950) across rows.  sum16 / sum32 add the SAME partners as the butterfly
+// `for (o = 1; o < n; o <<= 1) v += __shfl_xor(v, o)` — after the xor-1 and xor-2 steps a quad holds one value, so the
+// mirror within 8 / 16 lanes fetches the other quad's / half's value — and give the same bits.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_xor16(float v) {   // value of lane ^ 16
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);   // r[0]: odd rows <- the even row below, r[1]: even rows <- the odd row above
+    return __uint_as_float((threadIdx.x & 16) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float lane_xor32(float v) {   // value of lane ^ 32
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float sum16(float v) {   // sum over the 16 lanes of a DPP row, in every lane of it
+    v += dpp_move<0xB1>(v);    // quad_perm [1,0,3,2]: lane ^ 1
+    v += dpp_move<0x4E>(v);    // quad_perm [2,3,0,1]: lane ^ 2
+    v += dpp_move<0x141>(v);   // row_half_mirror: the other quad of the 8
+    v += dpp_move<0x140>(v);   // row_mirror: the other 8 of the 16
+    return v;
+}
+__device__ __forceinline__ float sum32(float v) { v = sum16(v); return v + lane_xor16(v); }   // per 32-lane half
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

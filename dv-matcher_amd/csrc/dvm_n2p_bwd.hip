@@ -191,12 +191,10 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(int32_t *__restrict__ cn
 __global__ void csr_fill_kernel(const int32_t *__restrict__ idx, int N, int K, int32_t *__restrict__ cursor,
                                 int2 *__restrict__ edges) {
     const int b = blockIdx.y;
-    const int pt = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);   // one wave per point: K <= 64 slots
-    const int slot = threadIdx.x & 63;
-    if (pt >= N || slot >= K) return;
-    const int e = pt * K + slot;
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)N * K) return;
     const int pos = atomicAdd(cursor + (size_t)b * N + idx[(size_t)b * N * K + e], 1);
-    edges[(size_t)b * N * K + pos] = make_int2(e, pt);
+    edges[(size_t)b * N * K + pos] = make_int2((int)e, (int)(e / K));
 }
 
 // dkp_r = sum over the in-edges (i -> r) of de_i,slot * q_i (per head), dvp_r = sum a_i,slot * g_i - g_r.
@@ -296,7 +294,7 @@ DVM_EXPORT int dvm_n2p_core_bwd_f32(const float *qkv, const int32_t *idx, const 
     (void)hipMemsetAsync(offs, 0, (size_t)B * (N + 1) * sizeof(int32_t), s);
     hipLaunchKernelGGL(csr_count_kernel, egrid, dim3(256), 0, s, idx, N, K, offs);
     hipLaunchKernelGGL(csr_scan_kernel, dim3(B), dim3(1024), 0, s, offs, N, cursor);
-    hipLaunchKernelGGL(csr_fill_kernel, dim3((N + 3) / 4, B), dim3(256), 0, s, idx, N, K, cursor, edges);
+    hipLaunchKernelGGL(csr_fill_kernel, egrid, dim3(256), 0, s, idx, N, K, cursor, edges);
     if (C == 64) {
         hipLaunchKernelGGL(n2p_bwd_point_kernel<64>, grid, dim3(256), 0, s, qkv, idx, attn, g_out, N, K, de, d_qkv);
         hipLaunchKernelGGL(n2p_bwd_gather_kernel<64>, grid, dim3(256), 0, s, qkv, attn, de, g_out, offs, edges, N, K, d_qkv);

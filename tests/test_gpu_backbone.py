@@ -213,9 +213,13 @@ def test_criterion_backward_matches_reference(golden, name, cls, kw):
         close(p.grad, g["g_" + k.replace(".", "__")], k)
 
 
-def test_dist_loss_vs_torch(ops):
-    g = torch.Generator().manual_seed(21)
-    B, N, C, nA, k = 2, 300, 128, 40, 25
+@pytest.mark.parametrize("N,C,nA,k", [(300, 128, 40, 25), (700, 128, 33, 64), (700, 128, 9, 130), (1100, 128, 50, 500), (600, 128, 21, 511),
+                                      (300, 64, 40, 25)])
+def test_dist_loss_vs_torch(ops, N, C, nA, k):
+    """C = 128, k <= 512: the half-wave-per-row kernel (odd / even / multi-chunk k); other widths: the
+    lane-per-row kernel (k itself is capped at 512 by the kNN selection)."""
+    g = torch.Generator().manual_seed(21 + k)
+    B = 2
     feat = torch.randn(B, N, C, generator=g).cuda()
     v = torch.rand(B, N, 3, generator=g).cuda()
     dist = torch.cdist(v, v)

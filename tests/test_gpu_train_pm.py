@@ -25,9 +25,9 @@ def test_bn_pm_matches_torch(R, C, slope, with_res):
     x = (torch.randn(1, R, C, generator=g) * 1.7 + 0.3).to(_dev()).requires_grad_(True)
     res = torch.randn(1, R, C, generator=g).to(_dev()).requires_grad_(True) if with_res else None
     bn = torch.nn.BatchNorm1d(C).to(_dev())
-    with torch.no_grad():
-        bn.weight.uniform_(0.5, 1.5, generator=None)
-        bn.bias.uniform_(-0.5, 0.5)
+    with torch.no_grad():   # (seeded: an element that lands within rounding of the activation's kink takes the other branch)
+        bn.weight.copy_(0.5 + torch.rand(C, generator=g))
+        bn.bias.copy_(torch.rand(C, generator=g) - 0.5)
     ref = torch.nn.BatchNorm1d(C).to(_dev()).double()
     ref.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
     gy = torch.randn(1, R, C, generator=g).to(_dev())
@@ -47,9 +47,14 @@ def test_bn_pm_matches_torch(R, C, slope, with_res):
 
     # the activation's kink: a value within rounding of 0 may take the other branch; exclude nothing, the tolerance covers it
     close(y, yr, 2e-5)
-    close(x.grad, xd.grad, 5e-5)
+    # gradients through the (Leaky)ReLU: elements whose pre-activation is within 1e-5 of the kink may take either slope
+    zd = z.detach()
+    pre = (zd - zd.mean(dim=(0, 1))) / torch.sqrt(zd.var(dim=(0, 1), unbiased=False) + ref.eps) * ref.weight.detach() + ref.bias.detach()
+    safe = (pre.abs() > 1e-5).to(x.grad.dtype) if slope != 1.0 else torch.ones_like(x.grad)
+    assert float(safe.mean()) > 0.999
+    close(x.grad * safe, xd.grad * safe, 5e-5)
     if with_res:
-        close(res.grad, rd.grad, 5e-5)
+        close(res.grad * safe, rd.grad * safe, 5e-5)
     close(bn.weight.grad, ref.weight.grad, 5e-5)
     close(bn.bias.grad, ref.bias.grad, 5e-5)
     close(bn.running_mean, ref.running_mean, 1e-5)
