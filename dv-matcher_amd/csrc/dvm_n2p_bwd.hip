@@ -31,10 +31,17 @@ struct NpLayout {
 };
 // sum over the LPH lanes of a head (LPH = 4 or 8: xor 1, 2[, 4] stay inside the head's lanes)
 template <int LPH>
-__device__ __forceinline__ float head_sum(float v) {
-#pragma unroll
-    for (int o = 1; o < LPH; o <<= 1) v += __shfl_xor(v, o, 64);
+__device__ __forceinline__ float head_sum(float v) {   // the xor-1, 2[, 4] butterfly on the DPP network (dvm_common.h)
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    if (LPH == 8) v += dpp_move<0x141>(v);
     return v;
+}
+// sum over the edge slots of a wave: lanes l, l + LPR, ... (LPR = 16: xor 16 and 32; LPR = 32: xor 32)
+template <int LPR>
+__device__ __forceinline__ float slot_sum(float v) {
+    if (LPR == 16) v += lane_xor16(v);
+    return v + lane_xor32(v);
 }
 
 template <int C>
@@ -90,9 +97,7 @@ __global__ __launch_bounds__(256) void n2p_core_fwd_kernel(const float *__restri
         acc += se[wave][j * NP_H + hd] * (vj - vi);
     }
 #pragma unroll
-    for (int o = L::LPR; o < 64; o <<= 1)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] += __shfl_xor(acc[c], o, 64);
+    for (int c = 0; c < 4; ++c) acc[c] = slot_sum<L::LPR>(acc[c]);
     if (valid && sub == 0) *(f32x4 *)(out + (base + pt) * C + 4 * l) = acc;
 }
 
@@ -146,9 +151,7 @@ __global__ __launch_bounds__(256) void n2p_bwd_point_kernel(const float *__restr
         dq += sd[wave][j * NP_H + hd] * kj;
     }
 #pragma unroll
-    for (int o = L::LPR; o < 64; o <<= 1)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) dq[c] += __shfl_xor(dq[c], o, 64);
+    for (int c = 0; c < 4; ++c) dq[c] = slot_sum<L::LPR>(dq[c]);
     if (valid && sub == 0) *(f32x4 *)(dqkv + (base + pt) * L::LD + 4 * l) = dq;
 }
 
@@ -235,9 +238,7 @@ __global__ __launch_bounds__(256) void n2p_bwd_gather_kernel(const float *__rest
     ak += ak2, av += av2;
     // combine the EPW edge slots (lanes l, l + LPR, ...)
 #pragma unroll
-    for (int o = LPR; o < 64; o <<= 1)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) ak[c] += __shfl_xor(ak[c], o, 64), av[c] += __shfl_xor(av[c], o, 64);
+    for (int c = 0; c < 4; ++c) ak[c] = slot_sum<LPR>(ak[c]), av[c] = slot_sum<LPR>(av[c]);
     if (sub == 0) {
         float *dst = dqkv + (base + r) * LD + 4 * l;
         const f32x4 gr = *(const f32x4 *)(gout + (base + r) * C + 4 * l);

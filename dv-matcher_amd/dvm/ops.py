@@ -17,27 +17,34 @@ _pair_ctx = set()
 
 def _need_gpu(*ts):
     """Every wrapper starts here: all tensors on ONE HIP device, which becomes the current device (the C ABI launches on
-    `torch.cuda.current_stream()` and keeps its per-device state — kernel attributes, helper streams — by current device)."""
-    dev = None
+    `torch.cuda.current_stream()` and keeps its per-device state — kernel attributes, helper streams — by current device).
+    (This and the two casts below run ~1500 times per training step on the host: they stay on attribute reads.)"""
+    dev = -1
     for t in ts:
         if t is None:
             continue
         if not isinstance(t, torch.Tensor) or not t.is_cuda:
             raise DvmError("dvm ops need tensors on a HIP device (got %s); there is no CPU fallback"
                            % (t.device if isinstance(t, torch.Tensor) else type(t)))
-        if dev is None:
-            dev = t.device
-        elif t.device != dev:
-            raise DvmError("dvm ops need all tensors on one device (got %s and %s)" % (dev, t.device))
-    if dev is not None and dev.index != torch.cuda.current_device():
+        d = t.get_device()
+        if dev < 0:
+            dev = d
+        elif d != dev:
+            raise DvmError("dvm ops need all tensors on one device (got cuda:%d and cuda:%d)" % (dev, d))
+    if dev >= 0 and dev != torch.cuda.current_device():
         torch.cuda.set_device(dev)
 
 
 def _f(t):
+    """A contiguous fp32 tensor without autograd history (the same object when it already is one)."""
+    if t.dtype is torch.float32 and not t.requires_grad and t.is_contiguous():
+        return t
     return t.detach().contiguous().float()
 
 
 def _i(t):
+    if t.dtype is torch.int32 and t.is_contiguous():
+        return t
     return t.detach().contiguous().to(torch.int32)
 
 

@@ -258,21 +258,35 @@ def main(argv=None):
         # global chains already run on two streams (models/model.py:_two_branches)
         return net(v1.permute(0, 2, 1), d1, None)[0], net(v2.permute(0, 2, 1), d2, None)[0]
 
+    host_marks = [0.0, 0.0, 0.0, 0.0, 0] if os.environ.get("DVM_STEP_BREAKDOWN", "0") == "1" else None   # host seconds per phase
+
+    def mark(i, t0):
+        if host_marks is not None:
+            host_marks[i] += time.perf_counter() - t0
+        return time.perf_counter()
+
     def train_step(batch, alpha):
         v1, v2, d1, d2, dist1, dist2 = batch
+        t = time.perf_counter()
         f1, f2 = forward_pair(v1, d1, v2, d2)
+        t = mark(0, t)
         out = crit(f1, f2, dist1, dist2, v1, v2, alpha, dfm)
+        t = mark(1, t)
         if world > 1:
             crit.data_parallel_loss(frac).backward()
             work = bucket.all_reduce_sum(async_op=True)      # one 8.5 MB collective on RCCL's stream ...
         else:
             out[0].backward()
             work = None
+        t = mark(2, t)
         # ... overlapped with the host-side bookkeeping of the step (5 loss terms; local values, as the reference logs them)
         vals = loss_values(out, dev)
         if work is not None:
             work.wait()
         opt.step()
+        t = mark(3, t)
+        if host_marks is not None:
+            host_marks[4] += 1
         if attach:
             bucket.zero()
         else:
@@ -331,6 +345,8 @@ def main(argv=None):
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
+        if host_marks is not None:
+            host_marks[:] = [0.0, 0.0, 0.0, 0.0, 0]
         t0 = time.perf_counter()
         for i in range(args.steps):
             losses.append(train_step(feed[i % len(feed)], alpha))
@@ -344,6 +360,9 @@ def main(argv=None):
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t)
+        if rank == 0 and host_marks is not None and host_marks[4]:
+            print("host ms per step (enqueue only): network forward x2 %.2f, criterion %.2f, backward %.2f, bookkeeping + Adam %.2f"
+                  % tuple(1e3 * v / host_marks[4] for v in host_marks[:4]), file=sys.stderr)
         if rank == 0:
             print(json.dumps({"metric": "training pairs/sec (fwd+loss+bwd+Adam)", "value": Bg * args.steps / dt, "unit": "pairs/s",
                               "n_gpus": world, "steps": args.steps, "ms_per_step": dt / args.steps * 1e3,
