@@ -997,7 +997,8 @@ int launch_reduce_partials(const double *partial, int B, int nparts, float scale
 int launch_knn_neg(const float *a, const float *bq, int B, int N, int M, int C, int k, int32_t *idx, float *na, float *nb,
                    float *S, hipStream_t s) {
     launch_rownorm2(a, B * N, C, na, s);
-    launch_rownorm2(bq, B * M, C, nb, s);
+    if (a == bq && N == M) nb = na;   // self-kNN (every N2P layer): one set of norms
+    else launch_rownorm2(bq, B * M, C, nb, s);
     // key range split over grid.z until >= 1024 workgroups are in flight (B * N/128 alone is 128 at B = 8, N = 2048)
     const int qtiles = (N + KS_QB - 1) / KS_QB, ktiles = (M + KS_KT - 1) / KS_KT;
     int nz = 1;
