@@ -109,9 +109,8 @@ __global__ __launch_bounds__(256) void sa_bwd_rows_kernel(const SaBwdArgs a) {
     const int irow = ot * SB_ROWS + wave * 32 + r32;
     const int irc = irow < N ? irow : N - 1;
     const float *pb = a.p + (size_t)b * N * SB_P, *vb = a.v + (size_t)b * N * SB_C, *gb = a.g + (size_t)b * N * SB_C;
-    float pi[SB_P / 2], vi[SB_C / 2];
+    float pi[SB_P / 2];
     load_frag<SB_P>(pb + (size_t)irc * SB_P, h, pi);
-    load_frag<SB_C>(vb + (size_t)irc * SB_C, h, vi);
     const float m_i = a.stats[((size_t)b * N + irc) * 2], il_i = irow < N ? a.stats[((size_t)b * N + irc) * 2 + 1] : 0.f;
     f32x16 dv0 = zero16(), dv1 = zero16();
     float ul = 0.f;
@@ -129,8 +128,10 @@ __global__ __launch_bounds__(256) void sa_bwd_rows_kernel(const SaBwdArgs a) {
                                  : which == 1 ? (ok ? a.cinv[(size_t)b * N + j] : 0.f) : (ok ? 1.f : 0.f);
         }
         __syncthreads();
+        // u_i = sum_j A_ij dA_ij with dA_ij = (G_j . v_i - t_j) / c_j, i.e. u_i = v_i . (sum_j Ah_ij G_j) - sum_j Ah_ij t_j
+        // = v_i . dv_i - (Ah t)_i: the 32 matrix instructions of the G_j . v_i tile are not needed in this pass — the
+        // first term is one dot product with the finished dv_i, the second a by-product of forming Ah.
         const f32x16 E = tile_dot<SB_P, SB_LDP>(pt, r32, h, pi);
-        const f32x16 X = tile_dot<SB_C, SB_LDC>(gt, r32, h, vi);  // dAh_ij = G_j . v_i
         float ah[16];
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
@@ -141,8 +142,8 @@ __global__ __launch_bounds__(256) void sa_bwd_rows_kernel(const SaBwdArgs a) {
             for (int e = 0; e < 4; ++e) {
                 const int r = 4 * g4 + e;
                 const float A = __expf(E[r] - m_i) * il_i * mk[e];
-                ul = fmaf(A, (X[r] - tj[e]) * cj[e], ul);
                 ah[r] = A * cj[e];
+                ul = fmaf(-ah[r], tj[e], ul);
             }
         }
         // dv_i += sum_j Ah_ij G_j : step r contracts j = (r&3) + 8*(r>>2) + 4*h; column n <-> LDS position 2n + cb
@@ -154,16 +155,23 @@ __global__ __launch_bounds__(256) void sa_bwd_rows_kernel(const SaBwdArgs a) {
             dv1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ah[r], gg.y, dv1, 0, 0, 0);
         }
     }
-    ul += __shfl_xor(ul, 32, 64);
+    ul += lane_xor32(ul);
     if (h == 0 && irow < N) unsafeAtomicAdd(a.u_out + (size_t)b * N + irow, ul);
+    const int p0 = 2 * r32, p1 = 2 * r32 + 1;  // LDS positions -> channels
+    const int c0 = p0 < 32 ? 2 * p0 : 2 * (p0 - 32) + 1, c1 = p1 < 32 ? 2 * p1 : 2 * (p1 - 32) + 1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int row = ot * SB_ROWS + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int row = ot * SB_ROWS + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;   // wave-half uniform
+        const int rc = row < N ? row : N - 1;
+        // v_row . dv_row (this split's part of dv): the 32 lanes of a half hold the row's 64 channels
+        float d = dv0[r] * vb[(size_t)rc * SB_C + c0];
+        d = fmaf(dv1[r], vb[(size_t)rc * SB_C + c1], d);
+        d = sum32(d);
         if (row >= N) continue;
+        if (r32 == 0) unsafeAtomicAdd(a.u_out + (size_t)b * N + row, d);
         float *dst = a.dv + ((size_t)b * N + row) * SB_C;
-        const int p0 = 2 * r32, p1 = 2 * r32 + 1;  // LDS positions -> channels
-        unsafeAtomicAdd(dst + (p0 < 32 ? 2 * p0 : 2 * (p0 - 32) + 1), dv0[r]);
-        unsafeAtomicAdd(dst + (p1 < 32 ? 2 * p1 : 2 * (p1 - 32) + 1), dv1[r]);
+        unsafeAtomicAdd(dst + c0, dv0[r]);
+        unsafeAtomicAdd(dst + c1, dv1[r]);
     }
 }
 
