@@ -86,7 +86,7 @@ def test_softcorr_bwd_split_and_full_size(ops):
     assert rel(a1, b1) < 2e-5 and rel(a2, b2) < 2e-5, (rel(a1, b1), rel(a2, b2))
 
 
-@pytest.mark.parametrize("C,K,N", [(64, 40, 300), (128, 40, 257), (128, 7, 50), (64, 64, 130)])
+@pytest.mark.parametrize("C,K,N", [(64, 40, 300), (128, 40, 257), (128, 7, 50), (64, 64, 130), (64, 5, 33), (64, 1, 9), (128, 1, 5)])
 def test_n2p_core_fwd_bwd_vs_fp64_autograd(ops, C, K, N):
     B, H = 2, 4
     g = torch.Generator().manual_seed(C + K)
