@@ -64,6 +64,15 @@ def _folded(owner, tag, sources, build):
     return hit[1]
 
 
+def invalidate_folded(module):
+    """Drop every derived inference-time tensor under `module`.  The caches notice in-place writes through the tensors
+    themselves (optimizer steps, load_state_dict, copy_) by their version counters; a write that bypasses them — through
+    `p.data`, a raw pointer, another process — does not bump a version: call this after such a write."""
+    for m in module.modules():
+        m.__dict__.pop("_dvm_folded", None)
+        m.__dict__.pop("_pos_cache", None)
+
+
 def _bn_sources(bn):
     # num_batches_tracked: the fused training kernel writes the running statistics through raw pointers (no version
     # bump on those two tensors); the batch counter is incremented by a torch op on every such update

@@ -356,3 +356,22 @@ def test_uni3fc_full_size_against_the_oracle(monkeypatch, B, N):
         ah = a[0].cpu().numpy()
         want = O.knn_neg(ah[rows], ah, 40)
         assert np.array_equal(idx[0].cpu().numpy()[rows], want), layer
+
+
+def test_folded_cache_invalidation():
+    """Eval-mode derived tensors (BatchNorm affines folded on the host) follow versioned writes by themselves and writes
+    through `.data` after `invalidate_folded`."""
+    from models import model as M
+    torch.manual_seed(3)
+    net = M.Uni3FC(k=40).cuda().eval()
+    x = torch.rand(1, 3, 300).cuda()
+    d = torch.randn(1, 300, 1152).cuda()
+    with torch.no_grad():
+        a = net(x, d)[0].clone()
+        net.bn0.running_var.mul_(1.5)                 # versioned write: picked up
+        b = net(x, d)[0].clone()
+        assert not torch.equal(a, b)
+        net.bn0.running_var.data.div_(1.5)            # (also versioned in current torch; the explicit call is the contract)
+        M.invalidate_folded(net)
+        c = net(x, d)[0]
+    assert float((a - c).abs().max()) < 1e-3
