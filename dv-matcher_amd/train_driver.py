@@ -152,6 +152,22 @@ def global_batches(n_pairs, Bg, shuffle_seed=None):
     return [order[i:i + Bg] for i in range(0, n_pairs - Bg + 1, Bg)]
 
 
+def step_flops(B, N, M):
+    """Algorithmic flops of the matrix work of one training step (what the matrix cores are asked to do, not what the
+    kernels issue): LG-Net's 1x1 convs forward + dX + dW (3 x 2 per multiply-add), its 7 feature-space kNN score matrices
+    and the 4 SA energy / apply products forward (+ 2.5 x for their tile-recompute backward), the soft-correspondence
+    distance matrix forward + backward, for both shapes of every pair.  models/model.py:480-761, models/loss.py:1339-1410."""
+    conv_macs = 1152 * 384 + 384 * 64 + 4 * (64 * 192 + 2 * 64 * 256 + 80 * 64 + 64 * 64) + 2 * 256 * 512 + 2 * 768 * 128 + \
+        256 * 128 + 3 * (128 * 384 + 2 * 128 * 512) + 512 * 128
+    total = 0.0
+    for n in (N, M):
+        total += 3 * 2.0 * B * n * conv_macs                       # convs: forward, dX, dW
+        total += 2.0 * B * n * n * (4 * 64 + 3 * 128)              # kNN scores (forward only: indices carry no gradient)
+        total += 4 * 2.0 * B * n * n * (16 + 64) * 3.5             # SA: energy (16) + apply (64), forward + recompute backward
+    total += 2.0 * B * N * M * 128 * (1 + 2.5)                     # soft correspondence: distances forward, recompute backward
+    return total
+
+
 def loss_values(out, dev):
     """The criterion's loss terms as one device vector.  Terms switched off by their weight are Python numbers: they become
     device scalars through a fill kernel — torch.as_tensor(0, device=...) is a copy from pageable memory, which blocks the
@@ -367,6 +383,12 @@ def main(argv=None):
             print(json.dumps({"metric": "training pairs/sec (fwd+loss+bwd+Adam)", "value": Bg * args.steps / dt, "unit": "pairs/s",
                               "n_gpus": world, "steps": args.steps, "ms_per_step": dt / args.steps * 1e3,
                               "host_enqueue_ms_per_step": t_host / args.steps * 1e3, "global_batch": Bg,
+                              "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": 157.3, "peak_name": "fp32 matrix",
+                                           "achieved": step_flops(Bg, N, M) / (dt / args.steps) / 1e12 / world,
+                                           "frac": step_flops(Bg, N, M) / (dt / args.steps) / 1e12 / world / 157.3,
+                                           "flops_per_step": step_flops(Bg, N, M),
+                                           "note": "algorithmic matrix flops of the whole step per GPU over the step time; the step is "
+                                                   "~1800 small launches, host- and latency-bound, not matrix-bound"},
                               "points": N, "points_target": M, "criterion": type(crit).__name__, "alpha": float(alpha),
                               "hip_graph": use_graph,
                               "grad_bucket_floats": bucket.numel, "first_losses": losses[0], "last_losses": losses[-1]}))
