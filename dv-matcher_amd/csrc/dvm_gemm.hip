@@ -18,6 +18,8 @@
 // four next operands with one ds_read_b128; the next k-step's global loads are in flight during the MFMAs.
 // The fp32 matrix instruction issues at the vector rate (64 cycles per 32x32x2), so LDS and global traffic
 // are far below their limits: the kernel is bound by MFMA issue.
+#include <stdint.h>
+
 #include "dvm_common.h"
 
 #include <stdlib.h>
@@ -43,6 +45,7 @@ struct LinArgs {
     float post_scale;
     int tiles_i, tiles_j;
     int qvec;                                // channel-major: rows of Q are 16-byte aligned (N % 4 == 0)
+    int yvec;                                // rows of Y / res / post_res and the per-channel vectors allow 16-byte accesses
     int kvec;                                // every K-block starts and ends on a multiple of 4
     int nkb, kb[GEMM_MAX_KB + 1];            // K-blocks [kb[b], kb[b+1]) of the reference's CPU sgemm (gemm_kblocks)
     const float *G;                          // point-major: per-shape row prefix [B][Cg] (NULL: none): row i of the
@@ -231,16 +234,34 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a) {
         if (has_next) fetch_step(nk, a.kb[nblk + 1]);
         {
             const float *const Ps = Ps0 + cur * BM * GLD, *const Qs = Qs0 + cur * QSZ;
+            // the inner loop is MFMA + ds_read only: on gfx950 the fp32 matrix instruction and the vector ALU share the
+            // issue slot, so every VALU instruction in here would cost matrix time.  All fragments of the k-step are
+            // requested before the first matrix instruction (one-accumulator tiles: 32 VGPRs), so that the reads of the
+            // later groups return under the earlier groups' matrix instructions instead of stalling between them.
+            constexpr bool FRONT = (TM * TN == 1);
+            f32x4 avf[FRONT ? GK / 8 : 1][TM], bvf[FRONT ? GK / 8 : 1][TN];
+            if (FRONT) {
+#pragma unroll
+                for (int cc = 0; cc < GK / 8; ++cc) {
+#pragma unroll
+                    for (int x = 0; x < TM; ++x) avf[cc][x] = *(const f32x4 *)(Ps + ((wm * TM + x) * 32 + r32) * GLD + h * (GK / 2) + 4 * cc);
+                    if (!CM) {
+#pragma unroll
+                        for (int y = 0; y < TN; ++y) bvf[cc][y] = *(const f32x4 *)(Qs + ((wn * TN + y) * 32 + r32) * GLD + h * (GK / 2) + 4 * cc);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks half of the reads below the first 8 MFMAs)
+            }
 #pragma unroll
             for (int cc = 0; cc < GK / 8; ++cc) {
-                // the inner loop is MFMA + ds_read only: on gfx950 the fp32 matrix instruction and the vector ALU share the
-                // issue slot, so every VALU instruction in here would cost matrix time
                 f32x4 av[TM], bv[TN];
 #pragma unroll
-                for (int x = 0; x < TM; ++x) av[x] = *(const f32x4 *)(Ps + ((wm * TM + x) * 32 + r32) * GLD + h * (GK / 2) + 4 * cc);
+                for (int x = 0; x < TM; ++x)
+                    av[x] = FRONT ? avf[FRONT ? cc : 0][x] : *(const f32x4 *)(Ps + ((wm * TM + x) * 32 + r32) * GLD + h * (GK / 2) + 4 * cc);
                 if (!CM) {
 #pragma unroll
-                    for (int y = 0; y < TN; ++y) bv[y] = *(const f32x4 *)(Qs + ((wn * TN + y) * 32 + r32) * GLD + h * (GK / 2) + 4 * cc);
+                    for (int y = 0; y < TN; ++y)
+                        bv[y] = FRONT ? bvf[FRONT ? cc : 0][y] : *(const f32x4 *)(Qs + ((wn * TN + y) * 32 + r32) * GLD + h * (GK / 2) + 4 * cc);
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -250,7 +271,8 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a) {
 #pragma unroll
                     for (int x = 0; x < TM; ++x)
 #pragma unroll
-                        for (int y = 0; y < TN; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x][e], bs[y], acc[x][y], 0, 0, 0);
+                        for (int y = 0; y < TN; ++y)   // D[column-tile index][row-tile index]: see the epilogue
+                            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(bs[y], av[x][e], acc[x][y], 0, 0, 0);
                 }
             }
         }
@@ -263,20 +285,27 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a) {
             for (int x = 0; x < TM; ++x)
 #pragma unroll
                 for (int y = 0; y < TN; ++y) {
-                    const int j = j0 + (wn * TN + y) * 32 + r32;
+                    const int i = i0 + (wm * TM + x) * 32 + r32;
+                    if (i >= I) continue;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int i = i0 + (wm * TM + x) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        if (i >= I || j >= J) continue;
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int j = j0 + (wn * TN + y) * 32 + 8 * g4 + 4 * h;
+                        if (j >= J) continue;
                         const size_t off = (size_t)i * a.ldy + j;
-                        float t = acc[x][y][r];
-                        if (blk) t = Y[off] + t;
-                        if (last) {
-                            acc[x][y][r] = t;
+                        f32x4 t = {acc[x][y][4 * g4], acc[x][y][4 * g4 + 1], acc[x][y][4 * g4 + 2], acc[x][y][4 * g4 + 3]};
+                        if (a.yvec && j + 3 < J) {
+                            if (blk) t = *(const f32x4 *)(Y + off) + t;
+                            if (!last) *(f32x4 *)(Y + off) = t;
                         } else {
-                            Y[off] = t;
-                            acc[x][y][r] = 0.f;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if (j + e >= J) continue;
+                                if (blk) t[e] = Y[off + e] + t[e];
+                                if (!last) Y[off + e] = t[e];
+                            }
                         }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[x][y][4 * g4 + e] = last ? t[e] : 0.f;
                     }
                 }
         }
@@ -288,36 +317,69 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a) {
     }
 
     // epilogue: conv bias (added after the chain, as oneDNN does), residual, y = fma(y, alpha, beta) (ATen's eval-mode
-    // BatchNorm is exactly this fma with alpha = w / sqrt(var + eps), beta = fma(-mean, alpha, b)), activation
+    // BatchNorm is exactly this fma with alpha = w / sqrt(var + eps), beta = fma(-mean, alpha, b)), activation.
+    // The matrix instructions were issued with the operands' roles swapped (products commute, the chain over k is the same):
+    // a lane owns ONE output row i and its registers 4 x 4 consecutive columns j, so the tile leaves as four 16-byte stores
+    // per lane instead of sixteen 4-byte ones (the wide-output layers were bound by store issue: 33 MB in 44 us).
     const float slope = a.slope;
     const float *__restrict__ R = a.res ? a.res + (size_t)b * a.y_bs : nullptr;
     const float *__restrict__ R2 = a.post_res ? a.post_res + (size_t)b * a.y_bs : nullptr;
+    const bool vec_ok = a.yvec != 0;
 #pragma unroll
     for (int x = 0; x < TM; ++x)
 #pragma unroll
         for (int y = 0; y < TN; ++y) {
-            const int j = j0 + (wn * TN + y) * 32 + r32;
-            float cb = 0.f, ca = 1.f, ct = 0.f;
-            if (!CM && j < J) {
-                if (a.bias) cb = a.bias[j];
-                if (a.alpha) ca = a.alpha[j], ct = a.beta[j];
+            const int i = i0 + (wm * TM + x) * 32 + r32;
+            if (i >= I) continue;
+            float rb = 0.f, ra = 1.f, rt = 0.f;   // channel-major: per output row
+            if (CM) {
+                if (a.bias) rb = a.bias[i];
+                if (a.alpha) ra = a.alpha[i], rt = a.beta[i];
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = i0 + (wm * TM + x) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (i >= I || j >= J) continue;
-                if (CM) {
-                    cb = a.bias ? a.bias[i] : 0.f;
-                    if (a.alpha) ca = a.alpha[i], ct = a.beta[i];
-                }
-                float v = acc[x][y][r];
-                if (a.bias) v = v + cb;
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int j = j0 + (wn * TN + y) * 32 + 8 * g4 + 4 * h;
+                if (j >= J) continue;
                 const size_t off = (size_t)i * a.ldy + j;
-                if (R) v = v + R[off];
-                if (a.alpha) v = fmaf(v, ca, ct);
-                if (slope != 1.f) v = v > 0.f ? v : (slope == 0.f ? 0.f : v * slope);
-                if (R2) v = __fadd_rn(__fmul_rn(v, a.post_scale), R2[off]);   // two roundings, like `conv(x) * s + r` in torch
-                Y[off] = v;
+                const bool full = vec_ok && j + 3 < J;
+                f32x4 v = {acc[x][y][4 * g4], acc[x][y][4 * g4 + 1], acc[x][y][4 * g4 + 2], acc[x][y][4 * g4 + 3]};
+                f32x4 cb = {rb, rb, rb, rb}, ca = {ra, ra, ra, ra}, ct = {rt, rt, rt, rt}, rr = {0.f, 0.f, 0.f, 0.f}, r2 = rr;
+                if (full) {
+                    if (!CM) {
+                        if (a.bias) cb = *(const f32x4 *)(a.bias + j);
+                        if (a.alpha) ca = *(const f32x4 *)(a.alpha + j), ct = *(const f32x4 *)(a.beta + j);
+                    }
+                    if (R) rr = *(const f32x4 *)(R + off);
+                    if (R2) r2 = *(const f32x4 *)(R2 + off);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (j + e >= J) continue;
+                        if (!CM) {
+                            if (a.bias) cb[e] = a.bias[j + e];
+                            if (a.alpha) ca[e] = a.alpha[j + e], ct[e] = a.beta[j + e];
+                        }
+                        if (R) rr[e] = R[off + e];
+                        if (R2) r2[e] = R2[off + e];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = v[e];
+                    if (a.bias) t = t + cb[e];
+                    if (R) t = t + rr[e];
+                    if (a.alpha) t = fmaf(t, ca[e], ct[e]);
+                    if (slope != 1.f) t = t > 0.f ? t : (slope == 0.f ? 0.f : t * slope);
+                    if (R2) t = __fadd_rn(__fmul_rn(t, a.post_scale), r2[e]);   // two roundings, like `conv(x) * s + r` in torch
+                    v[e] = t;
+                }
+                if (full) {
+                    *(f32x4 *)(Y + off) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (j + e < J) Y[off + e] = v[e];
+                }
             }
         }
 }
@@ -327,6 +389,9 @@ static void launch_cfg(LinArgs &a, int B, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     a.tiles_i = (a.I + BM - 1) / BM;
     a.tiles_j = (a.J + BN - 1) / BN;
+    const uintptr_t bits = (uintptr_t)a.Y | (uintptr_t)a.res | (uintptr_t)a.post_res | (uintptr_t)a.bias | (uintptr_t)a.alpha |
+                           (uintptr_t)a.beta | (uintptr_t)((size_t)a.y_bs * sizeof(float));
+    a.yvec = (a.ldy % 4 == 0 && bits % 16 == 0) ? 1 : 0;
     constexpr int QSZ = CM ? GK * BN : BN * GLD;
     constexpr size_t lds = (size_t)2 * (BM * GLD + QSZ) * sizeof(float);
     ensure_dyn_lds((const void *)linear_mfma_kernel<CM, WM, WN, TM, TN>, (int)lds);
