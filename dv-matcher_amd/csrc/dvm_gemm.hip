@@ -220,18 +220,22 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a) {
     // Flat walk over the k-steps of all K-blocks.  Step s+1's global loads are issued before step s's MFMAs and written to
     // the other LDS buffer after them; the single barrier at the end of a step both publishes that buffer and retires the
     // reads of the current one.
-    int blk = 0, k0 = a.kb[0], cur = 0;
-    fetch_step(k0, a.kb[1]);
+    // (the block edges live in the kernel-argument segment: a dynamically indexed a.kb[..] is a scalar memory load with its
+    // wait — two per k-step at the head of the loop in the first version; the current block's end and the next one's are
+    // carried in registers and re-read only when a block closes)
+    int blk = 0, k0 = a.kb[0], kend = a.kb[1], cur = 0;
+    fetch_step(k0, kend);
     stage(0);
     __syncthreads();
     while (blk < a.nkb) {
-        int nblk = blk, nk = k0 + GK;
-        if (nk >= a.kb[blk + 1]) {
+        int nblk = blk, nk = k0 + GK, nkend = kend;
+        if (nk >= kend) {
             ++nblk;
-            nk = a.kb[nblk];     // (kb[nkb] == K: unused when nblk == nkb)
+            nk = kend;           // blocks are contiguous: kb[nblk] is the end of the block that closes
+            if (nblk < a.nkb) nkend = a.kb[nblk + 1];
         }
         const bool has_next = nblk < a.nkb;
-        if (has_next) fetch_step(nk, a.kb[nblk + 1]);
+        if (has_next) fetch_step(nk, nkend);
         {
             const float *const Ps = Ps0 + cur * BM * GLD, *const Qs = Qs0 + cur * QSZ;
             // the inner loop is MFMA + ds_read only: on gfx950 the fp32 matrix instruction and the vector ALU share the
@@ -249,8 +253,10 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a) {
 #pragma unroll
                         for (int y = 0; y < TN; ++y) bvf[cc][y] = *(const f32x4 *)(Qs + ((wn * TN + y) * 32 + r32) * GLD + h * (GK / 2) + 4 * cc);
                     }
+                    // (keeps the reads in (A, B) pairs and above the matrix instructions: the scheduler otherwise sinks half
+                    // of them below the first 8 MFMAs; in pair order the first MFMAs wait for the first pair only)
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks half of the reads below the first 8 MFMAs)
             }
 #pragma unroll
             for (int cc = 0; cc < GK / 8; ++cc) {
@@ -314,6 +320,7 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a) {
         cur ^= 1;
         blk = nblk;
         k0 = nk;
+        kend = nkend;
     }
 
     // epilogue: conv bias (added after the chain, as oneDNN does), residual, y = fma(y, alpha, beta) (ATen's eval-mode
