@@ -497,14 +497,36 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(const float *__res
             *(f32x4 *)(xs[buf] + 4 * e) = px[u];
         }
     };
+    // fast path of the fetch (interior tiles, whole row blocks): two 16-byte loads per operand through pointers made once —
+    // the guarded lambda above costs ~35 branches and as many moves per step, beside 16 matrix instructions
+    const bool interior = co0 + 64 <= Co && k0 + 64 <= K && (Co & 3) == 0 && (K & 3) == 0;
+    const float *gfast[2], *xfast[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int e = tid + 256 * u, rr = e >> 4, c = (e & 15) * 4;
+        gfast[u] = gy + (size_t)(rbeg + rr) * Co + co0 + c;
+        xfast[u] = x + (size_t)(rbeg + rr) * K + k0 + c;
+    }
+    auto fetch_step = [&](long r0) {
+        if (interior && r0 + WG_ROWS <= rend) {
+            const size_t d = (size_t)(r0 - rbeg);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                pg[u] = *(const f32x4 *)(gfast[u] + d * Co);
+                px[u] = *(const f32x4 *)(xfast[u] + d * K);
+            }
+        } else {
+            fetch(r0);
+        }
+    };
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int cur = 0;
-    fetch(rbeg);
+    fetch_step(rbeg);
     stage(0);
     __syncthreads();
     for (long r0 = rbeg; r0 < rend; r0 += WG_ROWS) {
         const bool has_next = r0 + WG_ROWS < rend;
-        if (has_next) fetch(r0 + WG_ROWS);
+        if (has_next) fetch_step(r0 + WG_ROWS);
         const float *ga = gs[cur] + wi * 32 + r32, *xa = xs[cur] + wj * 32 + r32;
 #pragma unroll
         for (int t = 0; t < WG_ROWS / 2; ++t)
