@@ -1,0 +1,9 @@
+# A/B of two builds on the eval forward (kernel times by launch shape): csrc/libdvm_old.so vs libdvm_hip.so
+cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
+cp $R/dv-matcher_amd/csrc/libdvm_hip.so $R/dv-matcher_amd/csrc/libdvm_new.so
+for v in old new; do
+cp $R/dv-matcher_amd/csrc/libdvm_$v.so $R/dv-matcher_amd/csrc/libdvm_hip.so
+rm -rf /tmp/pb_$v
+rocprofv3 --kernel-trace -d /tmp/pb_$v -o x --output-format csv -- python3 $R/tools/bench_backbone.py 8 2048 10 > /tmp/pb_$v.log 2>&1
+echo "== $v"; tail -1 /tmp/pb_$v.log; python3 $R/tools/ktrace.py /tmp/pb_$v "${1:-knn_scores}" 6
+done
