@@ -52,14 +52,21 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """torch's current stream on the current device as the raw hipStream_t (no Stream object: this runs per launch)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
 def workspace(nbytes, device, tag="ws"):
     """Grow-only scratch buffer per (device, current stream, tag): calls on one stream are ordered and may share it,
     calls on different streams (or devices) never do."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream, tag)
+    dev_index = device.index if isinstance(device, torch.device) and device.index is not None else torch.cuda.current_device()
+    key = (dev_index, _raw_stream(dev_index) if _raw_stream is not None else torch.cuda.current_stream(device).cuda_stream, tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
@@ -156,6 +163,16 @@ def linear_wgrad(gy, x, out=None):
     return dW
 
 
+_bn_pm_sizes = {}
+
+
+def _bn_pm_bytes(lib, R, C):
+    nb = _bn_pm_sizes.get((R, C))
+    if nb is None:
+        nb = _bn_pm_sizes[(R, C)] = lib.dvm_bn_pm_workspace_bytes(R, C)
+    return nb
+
+
 def bn_act_train_fwd_pm(x, res, gamma, beta, eps, slope, momentum, running_mean=None, running_var=None):
     """Fused training-mode BatchNorm on point-major x (..., C): y = act(bn(x + res)); returns (y, mean, invstd)."""
     _need_gpu(x, res, gamma, beta)
@@ -167,7 +184,7 @@ def bn_act_train_fwd_pm(x, res, gamma, beta, eps, slope, momentum, running_mean=
     mean = torch.empty(C, dtype=torch.float32, device=x.device)
     invstd = torch.empty_like(mean)
     lib = _lib.load()
-    nb = lib.dvm_bn_pm_workspace_bytes(R, C)
+    nb = _bn_pm_bytes(lib, R, C)
     ws = workspace(nb, x.device, "bn_pm")
     check(lib.dvm_bn_act_train_fwd_pm_f32(_p(x), _p(res), _p(gamma), _p(beta), R, C, float(eps), float(slope), float(momentum), _p(y), _p(mean),
                                           _p(invstd), _p(running_mean), _p(running_var), _p(ws), nb, _stream()), "dvm_bn_act_train_fwd_pm_f32")
@@ -190,7 +207,7 @@ def bn_act_train_bwd_pm(dy, y, x, res, gamma, mean, invstd, slope, grads=None):
             if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != C:
                 raise ValueError("bn_act_train_bwd_pm: grads must be contiguous float32 tensors of %d elements" % C)
     lib = _lib.load()
-    nb = lib.dvm_bn_pm_workspace_bytes(R, C)
+    nb = _bn_pm_bytes(lib, R, C)
     ws = workspace(nb, x.device, "bn_pm")
     check(lib.dvm_bn_act_train_bwd_pm_f32(_p(dy), _p(y), _p(x), _p(res), _p(gamma), _p(mean), _p(invstd), R, C, float(slope), _p(dx), _p(dgamma),
                                           _p(dbeta), int(grads is not None), _p(ws), nb, _stream()), "dvm_bn_act_train_bwd_pm_f32")

@@ -45,7 +45,7 @@ def test_pair_forward_with_and_without_context(golden):
     try:
         s = torch.cuda.Stream()
         with torch.cuda.stream(s):
-            ws_key = (torch.device("cuda", 0), s.cuda_stream, "pair2")
+            ws_key = (0, s.cuda_stream, "pair2")            # (device index, raw stream, tag)
             plain = None
             # bypass ops.pair_forward's automatic dvm_pair_init: call with overlap off first
             lib.dvm_pair_set_overlap(0)
