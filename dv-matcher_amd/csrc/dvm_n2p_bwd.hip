@@ -218,7 +218,15 @@ __global__ __launch_bounds__(1024) void csr_build_lds_kernel(const int32_t *__re
     const int E = N * K;
     for (int i = tid; i <= N; i += 1024) cnt[i] = 0;
     __syncthreads();
-    for (int e = tid; e < E; e += 1024) atomicAdd(&cnt[ib[e]], 1);
+    // (8 index loads in flight per thread: one workgroup per cloud has only its own 16 waves to cover the load latency)
+    for (int e0 = tid; e0 < E; e0 += 8 * 1024) {
+        int t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = e0 + u * 1024 < E ? ib[e0 + u * 1024] : -1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (t[u] >= 0) atomicAdd(&cnt[t[u]], 1);
+    }
     __syncthreads();
     const int per = (N + 1023) / 1024;
     const int lo = min(N, tid * per), hi = min(N, lo + per);
@@ -243,9 +251,17 @@ __global__ __launch_bounds__(1024) void csr_build_lds_kernel(const int32_t *__re
     if (tid == 1023) ob[N] = part[1023];
     __syncthreads();
     int2 *eb = edges + (size_t)b * E;
-    for (int e = tid; e < E; e += 1024) {
-        const int pos = atomicAdd(&cursor[ib[e]], 1);
-        eb[pos] = make_int2(e, e / K);
+    for (int e0 = tid; e0 < E; e0 += 8 * 1024) {
+        int t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = e0 + u * 1024 < E ? ib[e0 + u * 1024] : -1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (t[u] < 0) continue;
+            const int e = e0 + u * 1024;
+            const int pos = atomicAdd(&cursor[t[u]], 1);
+            eb[pos] = make_int2(e, e / K);
+        }
     }
 }
 
