@@ -210,9 +210,39 @@ class GraphDeformLoss_Neural(nn.Module):
             save_off_file(path + '/' + name + n + '.off', t.detach().cpu().numpy())
 
     # ---- forward ------------------------------------------------------------------------------
-    def forward(self, feat1, feat2, dist1, dist2, verts1, verts2, alpha_i, deformer, fps_starts=None, anchors=None):
+    def geometry(self, verts1, verts2, fps_starts=None):
+        """The part of the criterion that depends on the COORDINATES only — both shapes' deformation graphs (FPS nodes, node
+        rings, skinning) and their xyz kNN — as (g1, g2, idx11, idx22).  forward() calls it itself; a driver may call it
+        earlier, on another stream, while the network is still computing the features (FPS is a chain of N/2 dependent
+        steps on one workgroup per shape: 0.65 ms during which nothing else of the criterion can start), and hand the
+        result to forward(geometry=...).  The FPS start indices are drawn here, in the reference's order."""
+        B, N, _ = verts1.shape
+        M = verts2.shape[1]
+        s1, s2 = fps_starts if fps_starts is not None else (None, None)
+        k = self.k_deform
+        if verts1.shape == verts2.shape and not self.dump:
+            # both shapes' graphs and xyz-kNN in ONE batched call each (FPS is a sequential 1-workgroup-per-shape
+            # kernel: 2B shapes cost what B do); the start indices are drawn in the reference's order
+            if s1 is None:
+                s1 = torch.cat([torch.randint(0, N, (1,), dtype=torch.long) for _ in range(B)])
+            if s2 is None:
+                s2 = torch.cat([torch.randint(0, M, (1,), dtype=torch.long) for _ in range(B)])
+            both = torch.cat([verts1, verts2], dim=0)
+            _, _, g = self.deformation_graph_node(both, torch.cat([torch.as_tensor(s1).reshape(-1), torch.as_tensor(s2).reshape(-1)]))
+            g1 = {key: (v[:B] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == 2 * B else v) for key, v in g.items()}
+            g2 = {key: (v[B:] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == 2 * B else v) for key, v in g.items()}
+            idx = ops.knn_cdist(both, both, k)
+            idx11, idx22 = idx[:B], idx[B:]
+        else:
+            _, _, g1 = self.deformation_graph_node(verts1, s1)
+            _, _, g2 = self.deformation_graph_node(verts2, s2)
+            idx11, idx22 = ops.knn_cdist(verts1, verts1, k), ops.knn_cdist(verts2, verts2, k)
+        return g1, g2, idx11, idx22
+
+    def forward(self, feat1, feat2, dist1, dist2, verts1, verts2, alpha_i, deformer, fps_starts=None, anchors=None, geometry=None):
         """-> (loss, dist_loss, deform_loss, map_loss, self_rec_loss), like the reference.
-        fps_starts=(s1 (B,), s2 (B,)) and anchors=(a1, a2) pin the draws the reference makes at random."""
+        fps_starts=(s1 (B,), s2 (B,)) and anchors=(a1, a2) pin the draws the reference makes at random; geometry = what
+        self.geometry(verts1, verts2, fps_starts) returned, when the caller made it ahead of time."""
         loss = 0
         self._sum_part = self._mean_part = 0
         B, N, _ = verts1.shape
@@ -230,25 +260,7 @@ class GraphDeformLoss_Neural(nn.Module):
             loss = loss + self.dist_loss
             self._sum_part = self._sum_part + self.dist_loss
         if self.w_deform > 0 or not self.partial_variant:
-            s1, s2 = fps_starts if fps_starts is not None else (None, None)
-            k = self.k_deform
-            if verts1.shape == verts2.shape and not self.dump:
-                # both shapes' graphs and xyz-kNN in ONE batched call each (FPS is a sequential 1-workgroup-per-shape
-                # kernel: 2B shapes cost what B do); the start indices are drawn in the reference's order
-                if s1 is None:
-                    s1 = torch.cat([torch.randint(0, N, (1,), dtype=torch.long) for _ in range(B)])
-                if s2 is None:
-                    s2 = torch.cat([torch.randint(0, M, (1,), dtype=torch.long) for _ in range(B)])
-                both = torch.cat([verts1, verts2], dim=0)
-                _, _, g = self.deformation_graph_node(both, torch.cat([torch.as_tensor(s1).reshape(-1), torch.as_tensor(s2).reshape(-1)]))
-                g1 = {key: (v[:B] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == 2 * B else v) for key, v in g.items()}
-                g2 = {key: (v[B:] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == 2 * B else v) for key, v in g.items()}
-                idx = ops.knn_cdist(both, both, k)
-                idx11, idx22 = idx[:B], idx[B:]
-            else:
-                _, _, g1 = self.deformation_graph_node(verts1, s1)
-                _, _, g2 = self.deformation_graph_node(verts2, s2)
-                idx11, idx22 = ops.knn_cdist(verts1, verts1, k), ops.knn_cdist(verts2, verts2, k)
+            g1, g2, idx11, idx22 = geometry if geometry is not None else self.geometry(verts1, verts2, fps_starts)
             m12, c12, a12, s12, ex12 = direction(feat1, feat2, verts1, verts2, alpha_i, g1, deformer, idx11, idx22)
             n12 = str(random.randint(0, 10))
             m21, c21, a21, s21, ex21 = direction(feat2, feat1, verts2, verts1, alpha_i, g2, deformer, idx22, idx11)

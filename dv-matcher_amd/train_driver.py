@@ -281,12 +281,35 @@ def main(argv=None):
             host_marks[i] += time.perf_counter() - t0
         return time.perf_counter()
 
+    # the criterion's geometry (graphs: FPS is a 0.65 ms chain of dependent steps; xyz kNN) needs the coordinates only: it is
+    # enqueued on its own stream BEFORE the network forward and joined in front of the criterion
+    geo_stream = torch.cuda.Stream() if os.environ.get("DVM_PREFETCH_GEOMETRY", "1") == "1" else None
+
+    def prefetch_geometry(v1, v2, starts=None):
+        if geo_stream is None:
+            return None
+        geo_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(geo_stream), torch.no_grad():
+            return crit.geometry(v1, v2, starts)
+
+    def join_geometry(geo):
+        if geo is None:
+            return None
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(geo_stream)
+        for part in geo:
+            for t in (part.values() if isinstance(part, dict) else (part,)):
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(cur)
+        return geo
+
     def train_step(batch, alpha):
         v1, v2, d1, d2, dist1, dist2 = batch
         t = time.perf_counter()
+        geo = prefetch_geometry(v1, v2)
         f1, f2 = forward_pair(v1, d1, v2, d2)
         t = mark(0, t)
-        out = crit(f1, f2, dist1, dist2, v1, v2, alpha, dfm)
+        out = crit(f1, f2, dist1, dist2, v1, v2, alpha, dfm, geometry=join_geometry(geo))
         t = mark(1, t)
         if world > 1:
             crit.data_parallel_loss(frac).backward()
@@ -334,8 +357,9 @@ def main(argv=None):
 
             def graph_step():
                 v1, v2, d1, d2, dist1, dist2 = batch
+                geo = prefetch_geometry(v1, v2, starts)
                 f1, f2 = forward_pair(v1, d1, v2, d2)
-                out = crit(f1, f2, dist1, dist2, v1, v2, alpha, dfm, fps_starts=starts, anchors=anchors)
+                out = crit(f1, f2, dist1, dist2, v1, v2, alpha, dfm, fps_starts=starts, anchors=anchors, geometry=join_geometry(geo))
                 out[0].backward()
                 vals = loss_values(out, dev)
                 opt.step()
