@@ -338,6 +338,7 @@ struct ChGridGroup {
 };
 struct ChGridArgs {
     ChGridGroup g[8];
+    int scan_min;   // uncertified lanes in a wave from which the whole target is scanned instead of walked
 };
 __global__ __launch_bounds__(128) void grid_chamfer_kernel(const ChGridArgs args) {
     const ChGridGroup &G = args.g[blockIdx.z];
@@ -412,9 +413,37 @@ __global__ __launch_bounds__(128) void grid_chamfer_kernel(const ChGridArgs args
             return;
         }
     }
-    // not certified within the radius-1 cube: the general walk.  (Deferring these queries to a compacted second launch
-    // made the first one 2.5x faster but the incoherent retry launch cost more than it saved — queries far outside the
-    // target's box, as the bench's untrained warps produce, need most of the grid either way.)
+    // not certified within the radius-1 cube.  (Deferring these queries to a compacted second launch made the first one
+    // 2.5x faster but the incoherent retry launch cost more than it saved — queries far outside the target's box, as the
+    // bench's untrained warps produce, need most of the grid either way.)
+    // When many lanes of the wave are in that position — a query cloud far from, or much larger than, the target: a
+    // COLLAPSED correspondence image (flat soft-max rows at small alpha) makes every query of the other cloud such a one
+    // and cost 10.7 ms per call with the walk — the wave scans the whole target in storage order instead: every lane reads
+    // the same address (one broadcast transaction per point, no per-lane cell ranges), same minimum, same tie rule.
+    const int nfall = __popcll(__ballot(1));   // lanes still here
+    if (nfall >= args.scan_min) {
+        float best = INFINITY;
+        int bs = 0;
+        const int P = G.gb.P;
+        for (int s0 = 0; s0 < P; s0 += 4) {
+            float4 pc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pc[u] = g.pts[s0 + u < P ? s0 + u : P - 1];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int sidx = s0 + u;
+                const float d = sidx < P ? met(pc[u]) : INFINITY;
+                if (d < best) {
+                    best = d, bs = sidx;
+                } else if (d == best && d < INFINITY && g.ids[sidx] < g.ids[bs]) {  // exact tie: lower original index
+                    bs = sidx;
+                }
+            }
+        }
+        G.dout[(size_t)b * Na + i] = best;
+        if (G.iout) G.iout[(size_t)b * Na + i] = g.ids[bs];
+        return;
+    }
     KBest<1, float> kb;
     kb.init(INFINITY);
     grid_search<1, MetricDiff>(g, qp.x, qp.y, qp.z, met, kb);
@@ -475,6 +504,11 @@ void launch_grid_chamfer(const GridBuf *gq, const GridBuf *gb, float *const *dou
         args.g[q] = ChGridGroup{gq[r], gb[r], dout[r], iout ? iout[r] : nullptr};
         if (q < ngroups && gq[r].P > maxN) maxN = gq[r].P;
     }
+    static const int scan_min = [] {
+        const char *e = getenv("DVM_CHAMFER_SCAN_MIN");   // tuning knob; 65 = never
+        return e ? atoi(e) : 32;   // (measured 8 .. 65 on the alpha sweep: 32 - 48 best on every case)
+    }();
+    args.scan_min = scan_min;
     hipLaunchKernelGGL(grid_chamfer_kernel, dim3((maxN + 127) / 128, B, ngroups), dim3(128), 0, s, args);
 }
 

@@ -382,3 +382,32 @@ def test_rownorm2_bit_exact(ops, rows, K):
     x = torch.randn(rows, K, generator=g) * torch.rand(rows, 1, generator=g) * 3
     got = ops.rownorm2(x.cuda()).cpu().numpy()
     assert np.array_equal(got, O.rownorm2(x.numpy())), (rows, K)
+
+
+@pytest.mark.parametrize("kind", ["collapsed_target", "far_queries", "duplicates"])
+def test_chamfer_grid_scan_path_equals_brute_force(ops, kind):
+    """The uniform-grid Chamfer at a batch large enough to take it (B * (N + M) > 65536), on the configurations where most
+    lanes of a wave fail the radius-1 certification and the kernel scans the whole target instead of walking the grid — a
+    target collapsed to a tiny cluster (what a flat soft-max row makes of the correspondence image), queries far outside
+    the target's box, duplicated target points (ties -> lowest index) — against a brute-force arg-min in torch."""
+    g = torch.Generator().manual_seed(5)
+    B, N, M = 20, 2048, 2048
+    a = torch.rand(B, N, 3, generator=g)
+    b = torch.rand(B, M, 3, generator=g)
+    if kind == "collapsed_target":
+        b = 0.5 + 1e-3 * torch.rand(B, M, 3, generator=g)
+    elif kind == "far_queries":
+        a = a + torch.tensor([3.0, -2.0, 5.0])
+    else:
+        b[:, M // 2:] = b[:, :M // 2]
+    d1, d2, i1, i2 = ops.chamfer(a.cuda(), b.cuda(), want_idx=True)
+    for q, t, d, ix in ((a, b, d1, i1), (b, a, d2, i2)):
+        diff = q[:, :, None, :].cuda() - t[:, None, :, :].cuda()
+        D = (diff[..., 0] * diff[..., 0] + diff[..., 1] * diff[..., 1]) + diff[..., 2] * diff[..., 2]   # the kernel's formula
+        ref_d, ref_i = D.min(dim=2)
+        assert torch.equal(d, ref_d), kind
+        # torch.min returns one of the minima; the kernel's index must be a minimiser, and the lowest one
+        got = torch.gather(D, 2, ix.long().unsqueeze(-1)).squeeze(-1)
+        assert torch.equal(got, ref_d), kind
+        lowest = (D == ref_d.unsqueeze(-1)).float().argmax(dim=2)
+        assert torch.equal(ix.long(), lowest), kind
