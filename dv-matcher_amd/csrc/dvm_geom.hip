@@ -419,7 +419,7 @@ __global__ __launch_bounds__(128) void chamfer_kernel(const float *__restrict__ 
     }
 }
 
-// The same search with 4 lanes per query, each scanning a quarter of the target cloud (held whole in LDS, M <= 4096), then
+// The same search with 4 lanes per query, each scanning a quarter of the target cloud (held whole in LDS, M <= 8192), then
 // the better of the four (lower distance, then lower index = lower quarter): the per-query chain of M dependent
 // compare-and-keep steps is what the kernel above waits on at training batch sizes (84 us for 8 x 2048 x 2048).
 constexpr int CH_PARTS = 4;
@@ -800,7 +800,7 @@ DVM_EXPORT int dvm_chamfer_fwd_f32(const float *a, const float *b, int B, int N,
     // by the queries farthest from the target's box (an untrained warp: most of the grid) — 279 us per call with 128
     // workgroups in flight; scanning the whole target from LDS tiles costs 2048 x 8 flops per query and finishes in a
     // fraction of that.  Same minima, same tie rule (lowest index).  The grid pays from ~100 k queries on (the pair bench).
-    const bool few = (long)B * ((d1 ? N : 0) + (d2 ? M : 0)) <= 65536 && (long)N * M <= (1L << 24);
+    const bool few = (long)B * ((d1 ? N : 0) + (d2 ? M : 0)) <= 65536 && (long)N * M <= (1L << 25);
     if (ws != nullptr && N >= 64 && M >= 64 && !few) {
         Arena ar(ws, ws_bytes);
         GridBuf ga = grid_carve(ar, B, N), gb = grid_carve(ar, B, M);
@@ -824,9 +824,9 @@ DVM_EXPORT int dvm_chamfer_fwd_f32(const float *a, const float *b, int B, int N,
         return DVM_OK;
     }
     auto nn = [&](const float *q, const float *t, int nq, int nt, float *d, int32_t *ix) {
-        if (nt <= 4096) {
+        if (nt <= 8192) {   // 16 bytes per target point: 128 KB of the CU's 160 KB at most
             const size_t lds = (size_t)nt * sizeof(float4);
-            ensure_dyn_lds((const void *)chamfer_split_kernel, 64 * 1024);
+            ensure_dyn_lds((const void *)chamfer_split_kernel, 128 * 1024);
             hipLaunchKernelGGL(chamfer_split_kernel, dim3((nq + 63) / 64, B), dim3(256), lds, s, q, t, nq, nt, d, ix);
         } else {
             hipLaunchKernelGGL(chamfer_kernel, dim3((nq + 127) / 128, B), dim3(128), 0, s, q, t, nq, nt, d, ix);

@@ -354,7 +354,8 @@ DVM_EXPORT int dvm_n2p_core_bwd_f32(const float *qkv, const int32_t *idx, const 
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((N + 3) / 4, B), egrid((unsigned)(((long)N * K + 255) / 256), B);
     const size_t csr_lds = (size_t)(2 * N + 1) * sizeof(int);
-    if (csr_lds <= 96 * 1024 && (long)N * K < (1L << 31)) {
+    // (one workgroup per cloud: from 4 clouds on; fewer, larger clouds keep the chip busier with the three-kernel form)
+    if (B >= 4 && csr_lds <= 96 * 1024 && (long)N * K < (1L << 31)) {
         ensure_dyn_lds((const void *)csr_build_lds_kernel, (int)csr_lds);
         hipLaunchKernelGGL(csr_build_lds_kernel, dim3(B), dim3(1024), csr_lds, s, idx, N, K, offs, edges);
     } else {
