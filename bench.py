@@ -1,28 +1,41 @@
 #!/usr/bin/env python3
 """bench.py — point-cloud pairs/sec of DV-Matcher's correspondence hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): synthetic random pairs, N = M = 2048 points, d = 128,
+Default workload (BASELINE.json configs[1]): synthetic random pairs, N = M = 2048 points, d = 128,
 "correspondence + deform forward only": for every pair and both directions
   graph(verts) -> soft correspondence (top-10) -> Pi@verts -> xyz kNN -> Deformer -> ED warp +
   ARAP -> 2x Chamfer (+ map term),
 i.e. GraphDeformLoss_Neural.deform() x2 without the dumps (reference models/loss.py:1401-1411).
-A "step" is one pass over a resident batch of `--pairs` pairs per GPU; inputs are in HBM before
-the timed region.  One process per GPU; pairs shard across ranks with no data-path collective
-(weak scaling: per-GPU work is fixed).
+A "step" is one pass over a resident batch of pairs; inputs are in HBM before the timed region.
 
-  python bench.py [--gpus N --steps K --warmup W --pairs P]
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py [--gpus N --steps K --warmup W --pairs P | --pairs-total T] [--workload pair|train|partial]
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the soft-correspondence
-sweep: exact fp16x2-split distances on the 16-bit matrix cores, pass A of K1), its launch time
-measured with HIP events on the launch stream inside the timed region; `frac` = flops performed on
-the f16 matrix pipe / its dense peak, `algorithmic` = SURVEY §8d's flops against the fp32 matrix peak; `cpu_baseline` is the C oracle ("port") timed on the host cores over a
-bounded sample of the same workload.
+One process per GPU.  `--gpus N` with N > 1 STARTS the N ranks itself: the parent process — which never
+imports torch and never touches the GPU — spawns N children of this script with RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, relays rank 0's JSON line and exits non-zero if any child
+did.  Under an external launcher (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`,
+WORLD_SIZE already set) the process is a rank and spawns nothing.  Pairs are independent units: they are
+sharded over the ranks with no data-path collective (barrier + MAX-over-ranks timing only).
+  --pairs P        P pairs per GPU per step: per-GPU work fixed, "scaling": "weak" (default, P = 512)
+  --pairs-total T  T pairs per step over ALL GPUs (T/N per rank): total work fixed, "scaling": "strong"
+--workload train / partial time the training step of BASELINE configs[2] / configs[3] (train_driver.py's
+timing mode: forward + criterion + backward + all-reduce + Adam), one JSON line in the same format.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the soft-correspondence sweep, pass A
+of K1), its launch time measured with HIP events on the launch stream inside the timed region; `frac` =
+flops performed on the f16 matrix pipe / its dense peak, `algorithmic` = SURVEY §8d's flops against the fp32
+matrix peak; `roofline.kernels` = the other kernels of the step, event-timed the same way over 3 extra steps
+after the timed region.  `checked_pairs`: after the timed region 4 pairs of the very batch that was timed
+are recomputed by the CPU oracle and compared (arg-max maps bit-exact, coordinates <= 1e-4, losses rtol
+1e-3); `cpu_baseline` is the same oracle ("port": a C/OpenMP restatement of the reference's algorithm)
+timed on a bounded sample of pairs of that same batch.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,8 +45,29 @@ for p in (ROOT, os.path.join(ROOT, "dv-matcher_amd")):
         sys.path.insert(0, p)
 
 N_PTS, M_PTS, DIM, ALPHA = 2048, 2048, 128, 100.0
-PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense f16 / bf16 matrix peak (same guide)
+PEAK_HBM_GBS = 8000.0          # HBM3E peak (same guide; 6.3 TB/s achievable)
+CHECK_PAIRS = 4
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=512, help="pairs per GPU per step (resident batch; weak scaling)")
+    ap.add_argument("--pairs-total", type=int, default=None, help="pairs per step over all GPUs (strong scaling: T/N per rank)")
+    ap.add_argument("--workload", default="pair", choices=["pair", "train", "partial"],
+                    help="pair: configs[1] (default); train: configs[2] training step B=8/GPU N=2048; partial: configs[3] "
+                         "training step B=2/GPU 4995 x 2200")
+    ap.add_argument("--cpu-sample", type=int, default=48, help="pairs timed for cpu_baseline (0 = skip; rank 0 at N = 1 only)")
+    ap.add_argument("--no-check", action="store_true", help="skip the oracle check of 4 pairs of the timed batch")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo for the "
+                    "two-ranks-on-one-GPU test of this script)")
+    ap.add_argument("--traffic-bytes", type=float, default=None,
+                    help="per-launch HBM bytes of the dominant kernel from the PMC passes (default: profiles/r3_k1_traffic.json)")
+    return ap.parse_args(argv)
 
 
 def rank_env():
@@ -41,16 +75,75 @@ def rank_env():
     return tuple(int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
 
 
+def shard_pairs(total, rank, world):
+    """Contiguous, balanced share of `total` pairs for `rank` (strong scaling)."""
+    base, rem = divmod(total, world)
+    return base + (1 if rank < rem else 0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Parent side of `--gpus N`: spawn N ranks.  Nothing here may import torch or touch HIP (a process that has initialised
+# the GPU must not be replaced or forked into ranks on this pool); tests/test_dist_gloo.py asserts that.
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def rank_environment(rank, world, port, base=None):
+    env = dict(os.environ if base is None else base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this pool
+    return env
+
+
+def launch_ranks(argv, world):
+    """Start `world` children of this script, one per GPU; relay rank 0's stdout; -> exit code (0 iff all children 0).
+    If one rank dies the others would wait in a barrier forever: the survivors — exactly the processes started here — are
+    ended and the failure is reported."""
+    import threading
+    port = free_port()
+    procs = []
+    for r in range(world):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=rank_environment(r, world, port),
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    try:
+        while any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs):
+                break
+            time.sleep(0.1)
+    finally:
+        for r, p in enumerate(procs):
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+                print("bench.py: rank %d ended by the launcher because another rank failed" % r, file=sys.stderr)
+            rc = rc or (p.returncode if p.returncode is not None else 1)
+    reader.join(timeout=10)
+    if out0 and out0[0]:
+        sys.stdout.write(out0[0])
+        sys.stdout.flush()
+    return 0 if rc == 0 else (rc if rc > 0 else 1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 def make_batch(P, seed, device):
+    """P synthetic pairs, generated on the device from a per-rank seed: features N(0,1), coordinates U(0,1)^3, FPS start 0
+    (explicit; the reference draws it at random)."""
     import torch
-    g = torch.Generator().manual_seed(seed)
-    f1 = torch.randn(P, N_PTS, DIM, generator=g)
-    f2 = torch.randn(P, M_PTS, DIM, generator=g)
-    v1 = torch.rand(P, N_PTS, 3, generator=g)
-    v2 = torch.rand(P, M_PTS, 3, generator=g)
-    s1 = torch.zeros(P, dtype=torch.int32)  # FPS start index 0 (explicit; the reference draws it at random)
-    s2 = torch.zeros(P, dtype=torch.int32)
-    return [t.to(device) for t in (f1, f2, v1, v2, s1, s2)]
+    g = torch.Generator(device=device).manual_seed(seed)
+    f1 = torch.randn(P, N_PTS, DIM, generator=g, device=device)
+    f2 = torch.randn(P, M_PTS, DIM, generator=g, device=device)
+    v1 = torch.rand(P, N_PTS, 3, generator=g, device=device)
+    v2 = torch.rand(P, M_PTS, 3, generator=g, device=device)
+    s1 = torch.zeros(P, dtype=torch.int32, device=device)
+    s2 = torch.zeros(P, dtype=torch.int32, device=device)
+    return [f1, f2, v1, v2, s1, s2]
 
 
 def load_weights():
@@ -59,39 +152,71 @@ def load_weights():
     return dict(np.load(path))  # the reference's shipped Deformer checkpoint (ckpt/dvmatcher_scape_r), as data
 
 
-def cpu_baseline(sample_pairs):
-    """The oracle (a C port of the reference's algorithm, OpenMP) on `sample_pairs` pairs, both directions."""
+def oracle_legs(batch, out12, out21, sample_pairs, check_pairs):
+    """The CPU oracle (oracle/dvm_oracle.c, test infrastructure) on the first pairs of the batch that was timed:
+    the first `check_pairs` are compared with the GPU outputs, the first `sample_pairs` are the cpu_baseline."""
     import numpy as np
-    import torch
     from oracle import oracle as O
     O.lib()
     w = load_weights()
-    f1, f2, v1, v2, s1, s2 = [t.numpy() for t in make_batch(sample_pairs, 4242, "cpu")]
+    npairs = max(sample_pairs, check_pairs)
+    f1, f2, v1, v2, s1, s2 = [t[:npairs].cpu().numpy() for t in batch]
     O.pair_direction(w, f1[0][:256], f2[0][:256], v1[0][:256], v2[0][:256], ALPHA, 0)  # warm the thread pool
+    check = {"T_exact": True, "max_abs_warped": 0.0, "max_abs_verts12": 0.0, "max_rel_losses": 0.0}
+    kept = []
     t0 = time.perf_counter()
-    for p in range(sample_pairs):
-        O.pair_direction(w, f1[p], f2[p], v1[p], v2[p], ALPHA, int(s1[p]))
-        O.pair_direction(w, f2[p], f1[p], v2[p], v1[p], ALPHA, int(s2[p]))
-    dt = time.perf_counter() - t0
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    omp = int(os.environ.get("OMP_NUM_THREADS", cores))
-    return {"value": sample_pairs / dt, "unit": "pairs/s", "cores": min(cores, omp), "kind": "port",
-            "sample": "%d pairs, N=M=%d, d=%d, both directions, C oracle with OpenMP (%.1f s)" % (sample_pairs, N_PTS, DIM, dt)}
+    for p in range(npairs):
+        o12 = O.pair_direction(w, f1[p], f2[p], v1[p], v2[p], ALPHA, int(s1[p]))
+        o21 = O.pair_direction(w, f2[p], f1[p], v2[p], v1[p], ALPHA, int(s2[p]))
+        if p == sample_pairs - 1:
+            dt = time.perf_counter() - t0
+        if p < check_pairs:
+            kept.append((o12, o21))
+    for p, (o12, o21) in enumerate(kept):
+        for o, g in ((o12, out12), (o21, out21)):
+            check["T_exact"] = check["T_exact"] and bool(np.array_equal(g["T12"][p].cpu().numpy(), o["T12"]))
+            check["max_abs_warped"] = max(check["max_abs_warped"], float(np.abs(g["warped"][p].cpu().numpy() - o["warped"]).max()))
+            check["max_abs_verts12"] = max(check["max_abs_verts12"], float(np.abs(g["verts12"][p].cpu().numpy() - o["verts12"]).max()))
+            gl, ol = g["losses"][p].cpu().numpy().astype(np.float64), o["losses"].astype(np.float64)
+            check["max_rel_losses"] = max(check["max_rel_losses"], float((np.abs(gl - ol) / np.maximum(np.abs(ol), 1e-12)).max()))
+    ok = check["T_exact"] and check["max_abs_warped"] <= 1e-4 and check["max_abs_verts12"] <= 1e-4 and check["max_rel_losses"] <= 1e-3
+    check["ok"] = bool(ok) if check_pairs > 0 else None
+    cpu = None
+    if sample_pairs > 0:
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        omp = int(os.environ.get("OMP_NUM_THREADS", cores))
+        cpu = {"value": sample_pairs / dt, "unit": "pairs/s", "cores": min(cores, omp), "kind": "port",
+               "sample": "the first %d pairs of the timed batch (N=M=%d, d=%d, both directions), C oracle with OpenMP (%.1f s)"
+                         % (sample_pairs, N_PTS, DIM, dt)}
+    return check, cpu
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=512, help="pairs per GPU per step (resident batch)")
-    ap.add_argument("--cpu-sample", type=int, default=48, help="pairs timed for cpu_baseline (0 = skip)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo for the "
-                    "two-ranks-on-one-GPU test of this script)")
-    ap.add_argument("--traffic-bytes", type=float, default=None,
-                    help="per-launch HBM bytes of the dominant kernel from the PMC passes (default: profiles/k1_traffic.json)")
-    args = ap.parse_args()
+def kernel_models(P):
+    """Algorithmic work of the other kernels of one step (P pairs per GPU, both directions), per LAUNCH, and what bounds each.
+    bytes = what has to cross HBM at least once (inputs read once, outputs written once); flops = performed on the pipe named."""
+    R = 2 * P * N_PTS           # query rows of both directions = all feature rows of both clouds
+    Rn = R // 2                 # deformation-graph nodes (N / 2 per cloud)
+    row = DIM * 4               # one feature row, bytes
+    return {
+        1: dict(bound="hbm", work=2 * R * row + R * 12 * 8 + R * 10 * 8,
+                note="pass B, one launch: every feature row once as a query and at least once as a candidate; the 12 candidate "
+                     "rows of 512 B gathered per query are served by L2 (6.5 x the unique bytes priced here)"),
+        2: dict(bound="mfma", work=3 * 2.0 * 299136 * Rn, peak=PEAK_F16_MFMA_TFLOPS,
+                note="Deformer MLP 262-512-256-128-9 over all nodes on the f16 pipe, 3 partial products of the exact 2-way split"),
+        3: dict(bound="hbm", work=8 * P * N_PTS * (16 + 16 + 4),
+                note="8 nearest-neighbour problems per pair in one launch; a grid walk of ~110 candidates per query: latency / VALU bound"),
+        4: dict(bound="hbm", work=2 * P * N_PTS * row,
+                note="Conv2d(k->1) pooling of one cloud set: 10 neighbour rows of 512 B gathered per point (L2), one row written"),
+        5: dict(bound="hbm", work=2 * P * N_PTS * (16 + 40), note="xyz kNN (k = 10) of all 2P clouds on the uniform grid: latency / VALU bound"),
+        6: dict(bound="hbm", work=2 * P * N_PTS * 12 + 2 * P * (N_PTS // 2) * 4,
+                note="farthest-point sampling: N/2 dependent steps per cloud, one workgroup per cloud: latency bound"),
+        7: dict(bound="hbm", work=P * (N_PTS // 2) * (264 * 4 + row + 10 * row),
+                note="Deformer input rows of one direction: 264 floats written per node, its pooled row and the 10 pooled rows of its "
+                     "correspondences gathered"),
+    }
 
+
+def run_pair(args):
     import torch
     import torch.distributed as dist
     from dvm import _lib, ops
@@ -110,9 +235,14 @@ def main():
             dist.init_process_group(args.backend)
     lib = _lib.load()
 
-    P = args.pairs
+    strong = args.pairs_total is not None
+    P = shard_pairs(args.pairs_total, rank, world) if strong else args.pairs
+    if P < 1:
+        raise SystemExit("--pairs-total %d gives rank %d of %d no pair" % (args.pairs_total, rank, world))
+    pairs_per_step = args.pairs_total if strong else P * world
     wl = ops.deformer_weight_list(load_weights(), dev)
-    f1, f2, v1, v2, s1, s2 = make_batch(P, 1000 + rank, dev)  # every rank has its own shard of pairs
+    batch = make_batch(P, 1000 + rank, dev)  # every rank has its own shard of pairs
+    f1, f2, v1, v2, s1, s2 = batch
     out12 = out21 = None
     outs = None
 
@@ -121,13 +251,18 @@ def main():
         outs = ops.pair_forward(wl, f1, f2, v1, v2, ALPHA, s1, s2, with_map=True, out=outs)
         out12, out21 = outs
 
+    def read_slot(slot):
+        ms, nl = ctypes.c_double(), ctypes.c_int()
+        ops.check(lib.dvm_profile_read_kernel(slot, ctypes.byref(ms), ctypes.byref(nl)), "dvm_profile_read_kernel")
+        return ms.value, nl.value
+
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ops.check(lib.dvm_profile_enable(args.steps + 4), "dvm_profile_enable")
+    ops.check(lib.dvm_profile_enable(args.steps + 4), "dvm_profile_enable")   # slot 0 (the sweep) only
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -136,10 +271,18 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    ms, nl = ctypes.c_double(), ctypes.c_int()
-    ops.check(lib.dvm_profile_read(ctypes.byref(ms), ctypes.byref(nl)), "dvm_profile_read")
+    k1_total_ms, k1_launches = read_slot(0)
     lib.dvm_profile_disable()
-    # the sweep kernel alone: the same launches with the helper-stream overlap switched off (outside the timed region)
+    # the other kernels of the step, bracketed the same way, over 3 extra steps (outside the timed region: 16 more event
+    # records per step)
+    ops.check(lib.dvm_profile_select((1 << 8) - 1), "dvm_profile_select")
+    ops.check(lib.dvm_profile_enable(3 * 16), "dvm_profile_enable")
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    slots = {k: read_slot(k) for k in range(1, 8)}
+    lib.dvm_profile_disable()
+    # the sweep kernel alone: the same launches with the helper-stream overlap switched off
     lib.dvm_pair_set_overlap(0)
     step()
     torch.cuda.synchronize()
@@ -147,10 +290,10 @@ def main():
     for _ in range(3):
         step()
     torch.cuda.synchronize()
-    ms1, nl1 = ctypes.c_double(), ctypes.c_int()
-    ops.check(lib.dvm_profile_read(ctypes.byref(ms1), ctypes.byref(nl1)), "dvm_profile_read")
+    alone_ms, alone_n = read_slot(0)
     lib.dvm_profile_disable()
     lib.dvm_pair_set_overlap(1)
+    local_dt = dt
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -160,28 +303,44 @@ def main():
     assert torch.isfinite(out12["losses"]).all() and torch.isfinite(out21["warped"]).all()
 
     if rank == 0:
-        pairs_total = P * args.steps * world
-        value = pairs_total / dt
-        # roofline of the dominant kernel: one launch covers BOTH directions of P pairs; its algorithmic
-        # flops are P x 2*N*M*d (SURVEY §8d counts the distance tile once per pair; the kernel evaluates it
-        # once per direction, i.e. performs twice that)
+        value = pairs_per_step * args.steps / dt
         traffic = args.traffic_bytes
-        tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
-        if traffic is None and os.path.exists(tpath):  # measured for one exact launch shape
-            tj = json.load(open(tpath))
-            if tj.get("pairs") == P:
-                traffic = tj.get("bytes_per_launch")
-        k1_ms = ms.value / max(nl.value, 1)
-        flops_launch = P * (2.0 * N_PTS * M_PTS * DIM)
-        achieved = flops_launch / (k1_ms * 1e-3) / 1e12 if k1_ms > 0 else 0.0
+        if traffic is None:
+            for name in ("r3_k1_traffic.json", "k1_traffic.json"):   # measured for one exact launch shape
+                tpath = os.path.join(ROOT, "profiles", name)
+                if os.path.exists(tpath):
+                    tj = json.load(open(tpath))
+                    if tj.get("pairs") == P:
+                        traffic = tj.get("bytes_per_launch")
+                    break
+        k1_ms = k1_total_ms / max(k1_launches, 1)
+        k1_alone = alone_ms / max(alone_n, 1)
+        flops_launch = P * (2.0 * N_PTS * M_PTS * DIM)   # the distance tile counted once per pair
+        tf = lambda ms_: flops_launch / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0  # noqa: E731
+        kernels = []
+        for k, (ms_tot, n) in sorted(slots.items()):
+            if n == 0:
+                continue
+            m = kernel_models(P)[k]
+            per_launch = ms_tot / n
+            per_step = ms_tot / 3.0
+            work = m["work"]
+            if m["bound"] == "mfma":
+                ach, peak, unit = work / (per_launch * 1e-3) / 1e12, m["peak"], "TFLOP/s"
+            else:
+                ach, peak, unit = work / (per_launch * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
+            kernels.append({"kernel": lib.dvm_profile_kernel_name(k).decode(), "bound": m["bound"], "achieved": ach, "peak": peak,
+                            "unit": unit, "frac": ach / peak, "launch_ms": per_launch, "launches_per_step": n / 3.0,
+                            "ms_per_step": per_step, "algorithmic_per_launch": work, "note": m["note"]})
         res = {
             "metric": "point-cloud pairs/sec (N=2048, d=128)", "value": value, "unit": "pairs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: synthetic random pairs N=M=2048 d=128, correspondence+deform "
-                                   "forward, both directions", "pairs_per_gpu_per_step": P, "alpha": ALPHA,
-                       "deformer_weights": "reference ckpt/dvmatcher_scape_r (fixture)", "fps_start": 0,
+                                   "forward, both directions", "pairs_per_gpu_per_step": P, "pairs_per_step": pairs_per_step,
+                       "alpha": ALPHA, "deformer_weights": "reference ckpt/dvmatcher_scape_r (fixture)", "fps_start": 0,
                        "parallelism": "pairs sharded over %d GPU(s), no collective" % world},
+            "per_gpu": {"pairs_per_s": value / world, "rank0_ms_per_step": local_dt / args.steps * 1e3},
             # The dominant kernel runs the N x M contraction on the 16-bit matrix pipe: 3 exact fp16 partial products
             # (2-way split of the scaled features, fp32 accumulate) per direction.  `achieved` / `peak` / `frac` price the
             # flops it PERFORMS (6 x the algorithmic count: 3 products x 2 directions of one distance tile) against the pipe
@@ -189,29 +348,81 @@ def main():
             # pair, the distance tile counted once, over the same launch time, against the fp32 matrix peak §8d prescribes
             # (a formulation-independent number: it can exceed what an fp32-MFMA kernel could ever reach).
             "roofline": {"bound": "mfma", "kernel": "softcorr_sweep_f16_kernel (K1 pass A, fp16x2-split sweep)",
-                         "achieved": 6.0 * achieved, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": 6.0 * achieved / PEAK_F16_MFMA_TFLOPS, "pipe": "f16 matrix (v_mfma_f32_32x32x16_f16)",
-                         "traffic": traffic, "launch_ms": k1_ms, "launches_timed": nl.value,
+                         "achieved": 6.0 * tf(k1_ms), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": 6.0 * tf(k1_ms) / PEAK_F16_MFMA_TFLOPS, "pipe": "f16 matrix (v_mfma_f32_32x32x16_f16)",
+                         "traffic": traffic, "launch_ms": k1_ms, "launches_timed": k1_launches,
                          "flops_per_launch": 6.0 * flops_launch,
-                         "algorithmic": {"flops_per_launch": flops_launch, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "peak_name": "fp32 matrix"},
-                         "share_of_step": (ms.value * 1e-3) / dt if dt > 0 else None,
+                         "algorithmic": {"flops_per_launch": flops_launch, "achieved": tf(k1_ms), "peak": PEAK_F32_MFMA_TFLOPS,
+                                         "frac": tf(k1_ms) / PEAK_F32_MFMA_TFLOPS, "peak_name": "fp32 matrix"},
+                         "share_of_step": (k1_total_ms * 1e-3) / local_dt if local_dt > 0 else None,
                          # in the timed region the sweep shares the CUs with the geometry chain on the helper stream
-                         # (FPS / graph / kNN), which stretches its launch; alone (overlap off, 3 launches after the
-                         # timed region) it takes `launch_ms` below
-                         "standalone": {"launch_ms": ms1.value / max(nl1.value, 1),
-                                        "achieved": 6.0 * flops_launch / (ms1.value / max(nl1.value, 1) * 1e-3) / 1e12,
-                                        "frac": 6.0 * flops_launch / (ms1.value / max(nl1.value, 1) * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS,
-                                        "algorithmic_frac": flops_launch / (ms1.value / max(nl1.value, 1) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}},
+                         # (FPS / graph / kNN / pooling), which stretches its launch; alone (overlap off, 3 launches after
+                         # the timed region) it takes `launch_ms` below
+                         "standalone": {"launch_ms": k1_alone, "achieved": 6.0 * tf(k1_alone),
+                                        "frac": 6.0 * tf(k1_alone) / PEAK_F16_MFMA_TFLOPS,
+                                        "algorithmic_frac": tf(k1_alone) / PEAK_F32_MFMA_TFLOPS},
+                         "kernels": kernels,
+                         # SURVEY §8d's whole-path count: 2.5 GFLOP of matrix work per pair (both directions' distance tiles,
+                         # Deformer MLP) over the step time, per GPU, against the fp32 matrix peak
+                         "whole_path": {"gflop_per_pair": 2.5, "achieved": 2.5e9 * value / world / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
+                                        "unit": "TFLOP/s", "frac": 2.5e9 * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS}},
         }
-        if world == 1 and args.cpu_sample > 0:
-            res["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+        if args.no_check and not (world == 1 and args.cpu_sample > 0):
+            res["checked_pairs"], res["check"], res["cpu_baseline"] = 0, None, None
         else:
-            res["cpu_baseline"] = None
+            ncheck = 0 if args.no_check else min(CHECK_PAIRS, P)
+            check, cpu = oracle_legs(batch, out12, out21, args.cpu_sample if world == 1 else 0, ncheck)
+            res["checked_pairs"], res["check"], res["cpu_baseline"] = ncheck, (check if ncheck else None), cpu
         print(json.dumps(res))
+        if res["check"] is not None and not res["check"]["ok"]:
+            print("bench.py: the GPU outputs of the timed batch differ from the oracle: %s" % res["check"], file=sys.stderr)
+            if world > 1:
+                dist.destroy_process_group()
+            return 3
     if world > 1:
         dist.destroy_process_group()
+    return 0
+
+
+def run_train(args):
+    """configs[2] / configs[3]: train_driver.py's timing mode (fwd + criterion + bwd + gradient all-reduce + Adam) per rank;
+    rank 0 re-emits its line in this script's format."""
+    import contextlib
+    import io
+    import train_driver
+    world, rank, _ = rank_env()
+    partial = args.workload == "partial"
+    per_gpu = 2 if partial else 8
+    batch = args.pairs_total if args.pairs_total is not None else per_gpu * world
+    argv = ["--steps", str(args.steps), "--warmup", str(args.warmup), "--batch", str(batch), "--backend", args.backend]
+    argv += ["--partial", "--points", "4995", "--points-target", "2200"] if partial else ["--points", "2048"]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        rc = train_driver.main(argv)
+    if rank == 0:
+        line = [ln for ln in buf.getvalue().splitlines() if ln.startswith("{")][-1]
+        tr = json.loads(line)
+        res = {"metric": "training pairs/sec (fwd+loss+bwd+Adam)", "value": tr["value"], "unit": "pairs/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": tr["ms_per_step"], "higher_is_better": True,
+               "scaling": "strong" if args.pairs_total is not None else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": ("BASELINE configs[3]: SCAPE-partial-shaped pairs 4995 x 2200, GraphDeformLoss_Neural_Partial"
+                                       if partial else "BASELINE configs[2]: training loop step, N=2048, GraphDeformLoss_Neural") +
+                                      ", synthetic pairs, random-init LG-Net", "global_batch": batch,
+                          "parallelism": "data parallel over %d GPU(s), one flat 8.5 MB gradient all-reduce" % world,
+                          "alpha": tr["alpha"], "criterion": tr["criterion"]},
+               "host_enqueue_ms_per_step": tr["host_enqueue_ms_per_step"], "roofline": tr["roofline"], "cpu_baseline": None,
+               "first_losses": tr["first_losses"], "last_losses": tr["last_losses"]}
+        print(json.dumps(res))
+    return rc
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(argv, args.gpus)      # parent: spawns the ranks, imports no torch
+    return run_pair(args) if args.workload == "pair" else run_train(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

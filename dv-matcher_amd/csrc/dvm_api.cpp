@@ -23,26 +23,28 @@ DVM_EXPORT int dvm_device_count(void) {
 
 // ---------------------------------------------------------------- per-device kernel attributes
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device's copy of a kernel: it has to be made
-// once per (device, kernel), not once per process.  Thread-safe; no HIP allocation.
+// per (device, kernel), not once per process, and it has to GROW when a later launch of the same kernel needs more
+// (callers whose byte count depends on a runtime size: the CSR build, the GEMM tiles, the JBU tile): the registry keeps
+// the largest value set so far and raises it when a bigger request arrives.  Thread-safe; no HIP allocation.
+#include <map>
 #include <mutex>
-#include <set>
 #include <utility>
 namespace dvm {
 static std::mutex g_attr_mu;
-static std::set<std::pair<int, const void *>> g_attr_done;
+static std::map<std::pair<int, const void *>, int> g_attr_bytes;
 void ensure_dyn_lds(const void *kernel, int bytes) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return;
     std::lock_guard<std::mutex> lock(g_attr_mu);
-    if (g_attr_done.count({dev, kernel})) return;
-    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess) g_attr_done.insert({dev, kernel});
+    auto it = g_attr_bytes.find({dev, kernel});
+    if (it != g_attr_bytes.end() && it->second >= bytes) return;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess) g_attr_bytes[{dev, kernel}] = bytes;
 }
 }  // namespace dvm
 
 // ---------------------------------------------------------------- helper streams of dvm_pair_fwd_f32
 // One context per (device, caller stream), created by dvm_pair_init — never inside a compute call, which therefore
 // stays allocation-free and capturable; without a context dvm_pair_fwd_f32 runs everything on the caller's stream.
-#include <map>
 namespace dvm {
 static std::mutex g_pair_mu;
 static std::map<std::pair<int, hipStream_t>, PairCtx *> g_pair_ctx;
@@ -99,23 +101,51 @@ DVM_EXPORT int dvm_pair_destroy(void) {
     return DVM_OK;
 }
 
-// ---------------------------------------------------------------- K1 launch timing
-// Optional HIP-event bracket around every soft-correspondence kernel launch, recorded on the
-// stream the kernel is launched on (bench.py's roofline leg).  Off by default; when off the
-// launch path records nothing.
+// ---------------------------------------------------------------- kernel launch timing
+// Optional HIP-event brackets around the launches of the pair path's kernels, recorded on the stream the kernel is
+// launched on (bench.py's roofline legs).  Slot 0 (DVM_PROF_K1_SWEEP) is the soft-correspondence sweep; the other
+// slots (include/dvm.h, DVM_PROF_*) are the remaining kernels of one step.  Off by default; when off the launch path
+// records nothing.  Only slots selected by dvm_profile_select() record (default: slot 0 only).
 #include <vector>
 namespace dvm {
-static std::vector<hipEvent_t> g_ev;
+struct ProfRec {
+    int id;
+    hipEvent_t e0, e1;
+};
+static std::vector<hipEvent_t> g_ev;      // pool, 2 per bracket
+static std::vector<ProfRec> g_rec;        // brackets of the current window
 static int g_ev_used = 0;
 static bool g_prof_on = false;
-void prof_begin(hipStream_t s) {
-    if (g_prof_on && g_ev_used + 2 <= (int)g_ev.size()) (void)hipEventRecord(g_ev[g_ev_used], s);
+static unsigned g_prof_mask = 1u;
+static thread_local int g_open_id = -1;   // (a bracket is opened and closed by the same host thread)
+void prof_begin(hipStream_t s, int id) {
+    if (!g_prof_on || !((g_prof_mask >> id) & 1u) || g_ev_used + 2 > (int)g_ev.size()) return;
+    (void)hipEventRecord(g_ev[g_ev_used], s);
+    g_open_id = id;
 }
-void prof_end(hipStream_t s) {
-    if (g_prof_on && g_ev_used + 2 <= (int)g_ev.size()) {
-        (void)hipEventRecord(g_ev[g_ev_used + 1], s);
-        g_ev_used += 2;
+void prof_end(hipStream_t s, int id) {
+    if (!g_prof_on || g_open_id != id || g_ev_used + 2 > (int)g_ev.size()) return;
+    (void)hipEventRecord(g_ev[g_ev_used + 1], s);
+    g_rec.push_back(ProfRec{id, g_ev[g_ev_used], g_ev[g_ev_used + 1]});
+    g_ev_used += 2;
+    g_open_id = -1;
+}
+static int prof_read(int id, double *total_ms, int *launches) {
+    double tot = 0.0;
+    int n = 0;
+    for (const ProfRec &r : g_rec) {
+        if (r.id != id) continue;
+        float ms = 0.f;
+        if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) {
+            set_error("dvm_profile_read: bracket %d of kernel slot %d not readable", n, id);
+            return DVM_ELAUNCH;
+        }
+        tot += ms;
+        ++n;
     }
+    *total_ms = tot;
+    *launches = n;
+    return DVM_OK;
 }
 }  // namespace dvm
 
@@ -130,31 +160,39 @@ DVM_EXPORT int dvm_profile_enable(int max_launches) {
         dvm::g_ev.push_back(e);
     }
     dvm::g_ev_used = 0;
+    dvm::g_rec.clear();
     dvm::g_prof_on = true;
+    return DVM_OK;
+}
+
+DVM_EXPORT int dvm_profile_select(unsigned kernel_mask) {
+    DVM_REQUIRE(kernel_mask != 0 && kernel_mask < (1u << DVM_PROF_COUNT), "dvm_profile_select: bad mask 0x%x", kernel_mask);
+    dvm::g_prof_mask = kernel_mask;
     return DVM_OK;
 }
 
 DVM_EXPORT int dvm_profile_read(double *total_ms, int *launches) {
     DVM_REQUIRE(total_ms && launches, "dvm_profile_read: null pointer");
-    double tot = 0.0;
-    int n = dvm::g_ev_used / 2;
-    for (int i = 0; i < n; ++i) {
-        float ms = 0.f;
-        if (hipEventSynchronize(dvm::g_ev[2 * i + 1]) != hipSuccess ||
-            hipEventElapsedTime(&ms, dvm::g_ev[2 * i], dvm::g_ev[2 * i + 1]) != hipSuccess) {
-            dvm::set_error("dvm_profile_read: event %d not readable", i);
-            return DVM_ELAUNCH;
-        }
-        tot += ms;
-    }
-    *total_ms = tot;
-    *launches = n;
-    dvm::g_ev_used = 0;
-    return DVM_OK;
+    return dvm::prof_read(DVM_PROF_K1_SWEEP, total_ms, launches);
+}
+
+DVM_EXPORT int dvm_profile_read_kernel(int kernel, double *total_ms, int *launches) {
+    DVM_REQUIRE(total_ms && launches, "dvm_profile_read_kernel: null pointer");
+    DVM_REQUIRE(kernel >= 0 && kernel < DVM_PROF_COUNT, "dvm_profile_read_kernel: bad kernel slot %d", kernel);
+    return dvm::prof_read(kernel, total_ms, launches);
+}
+
+DVM_EXPORT const char *dvm_profile_kernel_name(int kernel) {
+    static const char *const names[DVM_PROF_COUNT] = {
+        "softcorr_sweep_f16_kernel", "softcorr_refine_kernel", "mlp_f16x2_kernel", "grid_chamfer_kernel", "pool_kernel",
+        "grid_knn_self_kernel",      "fps_kernel",             "assemble_pooled_kernel"};
+    return (kernel >= 0 && kernel < DVM_PROF_COUNT) ? names[kernel] : "";
 }
 
 DVM_EXPORT int dvm_profile_disable(void) {
     dvm::g_prof_on = false;
     dvm::g_ev_used = 0;
+    dvm::g_rec.clear();
+    dvm::g_prof_mask = 1u;
     return DVM_OK;
 }

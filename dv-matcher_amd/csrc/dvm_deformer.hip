@@ -395,13 +395,17 @@ __global__ void pad_rows_kernel(const float *__restrict__ in, int rows, int I, i
 
 void launch_pool_all(const float *feat, const int32_t *idx, int B, int P, int k, const float *cw, const float *cb, float *out,
                      hipStream_t s, const int32_t *order) {
+    prof_begin(s, DVM_PROF_POOL);
     hipLaunchKernelGGL(pool_kernel, dim3((unsigned)(((long)P * 32 + 255) / 256), B), dim3(256), 0, s, feat, idx,
                        (const int32_t *)nullptr, P, P, k, cw, cb, out, DF_C, 0, order);
+    prof_end(s, DVM_PROF_POOL);
 }
 void launch_assemble_pooled(const float *vsrc, const float *vcorr, const float *gsrc, const float *gtgt, const float *pi_val,
                             const int32_t *pi_idx, const int32_t *fps, int B, int N, int M, int Nn, float *z, hipStream_t s) {
+    prof_begin(s, DVM_PROF_ASSEMBLE);
     hipLaunchKernelGGL(assemble_pooled_kernel<10>, dim3((unsigned)(((long)Nn * 32 + 255) / 256), B), dim3(256), 0, s, vsrc, vcorr,
                        gsrc, gtgt, pi_val, pi_idx, fps, N, M, Nn, 10, z);
+    prof_end(s, DVM_PROF_ASSEMBLE);
 }
 size_t mlp_bf16_pack_bytes();
 void launch_mlp_rows_bf16(const float *z, int rows, const float *W0, const float *b0, const float *W1, const float *b1,

@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void chamfer_split_kernel(const float *__restr
     const float qx = qp[0], qy = qp[1], qz = qp[2];
     const int per = (M + CH_PARTS - 1) / CH_PARTS, j0 = part * per, j1 = j0 + per < M ? j0 + per : M;
     float best = INFINITY;
-    int bj = 0x7fffffff;
+    int bj = 0x7fffffff;   // "nothing found": a part that is empty, or whose distances are all NaN / +inf
 #pragma unroll 4
     for (int j = j0; j < j1; ++j) {
         const float4 p = ch_pts[j];
@@ -449,6 +449,9 @@ __global__ __launch_bounds__(256) void chamfer_split_kernel(const float *__restr
         const int oj = __shfl_xor(bj, o, 64);
         if (od < best || (od == best && oj < bj)) best = od, bj = oj;
     }
+    // non-finite coordinates (a diverged step) leave every comparison false: the index must still be a valid row, because
+    // the backward pass gathers and scatters through it unchecked (index 0, like chamfer_kernel above)
+    bj = bj < M ? bj : 0;
     if (i < N && part == 0) {
         dout[(size_t)b * N + i] = best;
         if (iout) iout[(size_t)b * N + i] = bj;

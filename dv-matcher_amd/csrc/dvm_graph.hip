@@ -347,7 +347,9 @@ template <int PPT, int T>
 static void launch_fps_t(const float *xyz, int B, int N, int npoint, const int32_t *start, int32_t *out, hipStream_t s) {
     ensure_dyn_lds((const void *)fps_kernel<PPT, T>, 160 * 1024);
     const size_t lds = (size_t)((N * 3 + 3) & ~3) * sizeof(float) + 2 * (T / 64) * sizeof(ArgMax);
+    prof_begin(s, DVM_PROF_FPS);
     hipLaunchKernelGGL((fps_kernel<PPT, T>), dim3(B), dim3(T), lds, s, xyz, N, npoint, start, out);
+    prof_end(s, DVM_PROF_FPS);
 }
 
 // Each step is a dependent chain (distance update -> arg-max -> next centre), so its latency is what counts: the

@@ -448,7 +448,8 @@ __global__ __launch_bounds__(128) void grid_chamfer_kernel(const ChGridArgs args
     kb.init(INFINITY);
     grid_search<1, MetricDiff>(g, qp.x, qp.y, qp.z, met, kb);
     G.dout[(size_t)b * Na + i] = kb.key[0];
-    if (G.iout) G.iout[(size_t)b * Na + i] = kb.idx[0];
+    // (non-finite coordinates leave the list empty: keep the index a valid row, the backward pass gathers through it)
+    if (G.iout) G.iout[(size_t)b * Na + i] = (unsigned)kb.idx[0] < (unsigned)G.gb.P ? kb.idx[0] : 0;
 }
 
 // ---------------------------------------------------------------- host side
@@ -478,12 +479,14 @@ void launch_grid_build(const float *xyz, int B, int Nsrc, const int32_t *sel, co
 
 void launch_grid_knn_self(const GridBuf &gb, int B, int k, int32_t *idx, hipStream_t s) {
     dim3 grid((gb.P + 127) / 128, B);
+    prof_begin(s, DVM_PROF_KNN_XYZ);
     if (k <= 3)
         hipLaunchKernelGGL(grid_knn_self_kernel<3>, grid, dim3(128), 0, s, gb, k, idx);
     else if (k <= 10)
         hipLaunchKernelGGL(grid_knn_self_kernel<10>, grid, dim3(128), 0, s, gb, k, idx);
     else
         hipLaunchKernelGGL(grid_knn_self_kernel<16>, grid, dim3(128), 0, s, gb, k, idx);
+    prof_end(s, DVM_PROF_KNN_XYZ);
 }
 
 void launch_grid_ring(const GridBuf &gnodes, int B, int32_t *ring, hipStream_t s) {
@@ -509,7 +512,9 @@ void launch_grid_chamfer(const GridBuf *gq, const GridBuf *gb, float *const *dou
         return e ? atoi(e) : 32;   // (measured 8 .. 65 on the alpha sweep: 32 - 48 best on every case)
     }();
     args.scan_min = scan_min;
+    prof_begin(s, DVM_PROF_CHAMFER);
     hipLaunchKernelGGL(grid_chamfer_kernel, dim3((maxN + 127) / 128, B, ngroups), dim3(128), 0, s, args);
+    prof_end(s, DVM_PROF_CHAMFER);
 }
 
 }  // namespace dvm

@@ -225,8 +225,10 @@ int *launch_mlp_rows_f16(const float *z, int rows, const float *W0, const float 
     pack(W2, 128, 256, 4, MH_K2 / 16, Wp2);
     pack(W3, 9, 128, 1, MH_K3 / 16, Wp3);
     ensure_dyn_lds((const void *)mlp_f16x2_kernel, (int)MH_LDS_BYTES);
+    prof_begin(s, DVM_PROF_MLP);
     hipLaunchKernelGGL(mlp_f16x2_kernel, dim3((rows + MH_NODES - 1) / MH_NODES), dim3(MH_THREADS), MH_LDS_BYTES, s, z, rows, Wp0, b0,
                        Wp1, b1, Wp2, b2, Wp3, b3, out, flag);
+    prof_end(s, DVM_PROF_MLP);
     return flag;
 }
 

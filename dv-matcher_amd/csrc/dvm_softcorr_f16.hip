@@ -793,7 +793,9 @@ ensure_dyn_lds((const void *)softcorr_sweep_f16_kernel<false>, (int)HB_LDS_BYTES
     r.rows_total = r1 + (both ? r2 : 0);
     r.neg_alpha = neg_alpha;
     r.topk = topk;
+    prof_begin(s, DVM_PROF_K1_REFINE);
     hipLaunchKernelGGL(softcorr_refine_kernel, dim3((unsigned)((r.rows_total * 16 + 255) / 256)), dim3(256), 0, s, r);
+    prof_end(s, DVM_PROF_K1_REFINE);
 
     HXArgs x;
     x.g[0] = HXGroup{f1, f2, n1, n2, N, M, val12, idx12, smax12, sum12, flag[0] + 1, flag[0]};

@@ -22,7 +22,10 @@ SIGNATURES = {
     "dvm_last_error": (ctypes.c_char_p, []),
     "dvm_device_count": (c_int, []),
     "dvm_profile_enable": (c_int, [c_int]),
+    "dvm_profile_select": (c_int, [ctypes.c_uint]),
     "dvm_profile_read": (c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),
+    "dvm_profile_read_kernel": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),
+    "dvm_profile_kernel_name": (ctypes.c_char_p, [c_int]),
     "dvm_profile_disable": (c_int, []),
     "dvm_rownorm2_f32": (c_int, [_P, c_int, c_int, _P, _P]),
     "dvm_linear_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_float, _P, _P]),

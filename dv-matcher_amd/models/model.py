@@ -332,6 +332,18 @@ def _two_branches(x, main, side):
     return a, b
 
 
+def join_side_streams(device=None):
+    """Make the current stream wait for every helper stream `_two_branches` has used on `device`.  With the fused gradient
+    accumulation (dvm.nn_ops.fuse_grad_accumulation) the weight-gradient kernels of the helper-stream chain write straight
+    into `p.grad` during backward; autograd orders the caller's stream after them only through its leaf-stream
+    bookkeeping.  A training step calls this after backward() and before anything reads the gradients (all-reduce,
+    optimizer) so that the ordering is explicit."""
+    cur = torch.cuda.current_stream(device)
+    for (dev, _), helper in _side_streams.items():
+        if dev == cur.device:
+            cur.wait_stream(helper)
+
+
 class Uni3FC(nn.Module, _VisualProjection):
     def __init__(self, k=40):
         super().__init__()

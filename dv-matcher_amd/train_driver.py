@@ -46,7 +46,7 @@ if HERE not in sys.path:
 
 from dvm.dist import FlatGradBucket, shard_range  # noqa: E402
 from models.loss import GraphDeformLoss_Neural, GraphDeformLoss_Neural_Partial  # noqa: E402
-from models.model import Deformer, Uni3FC  # noqa: E402
+from models.model import Deformer, Uni3FC, join_side_streams  # noqa: E402
 
 FULL_CFG = {  # the values of the reference's config/scape_r.yaml
     "expname": "dvmatcher_scape_r_std", "with_dino": True, "feat_mat": True,
@@ -136,20 +136,32 @@ class DatasetPairs:
             n = min(min(it[s]["xyz"].shape[0] for it in items), cap)
             xyz = torch.stack([it[s]["xyz"][:n] for it in items]).float().to(self.dev)
             dd = torch.stack([it[s]["dist"][:n, :n] for it in items]).float().to(self.dev)
-            if self.random_feat or "feat" not in items[0][s]:
+            if self.random_feat:
                 ft = torch.randn(len(items), n, 1152, generator=self.g).to(self.dev)
+            elif "feat" not in items[0][s]:
+                ft = None   # with_dino = False (train_partial.py:98-104): Uni3FC computes them through the upsampler
             else:
                 ft = torch.stack([it[s]["feat"][:n] for it in items]).float().to(self.dev)
             out.append((xyz, ft, dd))
         return out[0][0], out[1][0], out[0][1], out[1][1], out[0][2], out[1][2]
 
 
-def global_batches(n_pairs, Bg, shuffle_seed=None):
-    """Index lists of the global batches of one pass (the last partial batch is dropped when it cannot be sharded)."""
+def global_batches(n_pairs, Bg, shuffle_seed=None, keep_tail=False):
+    """Index lists of the global batches of one pass.  The reference's DataLoader keeps the last, smaller batch
+    (train.py:60-66, drop_last defaults to False): keep_tail=True does the same; a sharded run drops it, because a batch
+    smaller than the world size cannot be split."""
     order = list(range(n_pairs))
     if shuffle_seed is not None:
         order = torch.randperm(n_pairs, generator=torch.Generator().manual_seed(shuffle_seed)).tolist()
-    return [order[i:i + Bg] for i in range(0, n_pairs - Bg + 1, Bg)]
+    stop = n_pairs if keep_tail else n_pairs - Bg + 1
+    return [order[i:i + Bg] for i in range(0, stop, Bg)]
+
+
+def fit_criterion(crit, cfg, n_points):
+    """Anchor / neighbour counts of the dist term for a batch of `n_points` points per shape: the configured values, clamped
+    to what the batch holds (DatasetPairs truncates a batch to its smallest shape; random.sample(range(n), N_dist) would raise)."""
+    crit.k_dist = min(int(cfg["loss"]["k_dist"]), max(1, n_points // 2))
+    crit.N_dist = min(int(cfg["loss"]["N_dist"]), max(1, n_points // 2))
 
 
 def step_flops(B, N, M):
@@ -208,6 +220,9 @@ def main(argv=None):
     ap.add_argument("--data-root", default=None, help="dataset directory (shapes_train/, shapes_test/, feat/, cache_*.pt); default: synthetic")
     ap.add_argument("--data-name", default=None)
     ap.add_argument("--random-feat", action="store_true", help="with --data-root: random visual features instead of feat/*.mat")
+    ap.add_argument("--upsampler-weights", default=None, help="state_dict of the FeatUp / DINOv2 image backbone (hub layout) for "
+                    "configurations with with_dino = False, whose visual features are rendered and back-projected on the fly "
+                    "(train_partial.py:72, 98-104); default: the seeded random initialisation (parity unpinned)")
     args = ap.parse_args(argv)
     cfg = copy.deepcopy(PARTIAL_CFG if args.partial else FULL_CFG)
     if args.config:
@@ -269,10 +284,22 @@ def main(argv=None):
     from dvm import nn_ops
     nn_ops.fuse_grad_accumulation(os.environ.get("DVM_FUSE_GRAD_ACC", "1") == "1")   # .backward() only below, never autograd.grad()
 
+    # with_dino = False on a dataset without stored features: the reference passes dino_feat = None and Uni3FC renders the
+    # shapes, runs the image backbone and back-projects (train_partial.py:98-104, models/model.py:683-710).  Built only then.
+    upsampler = None
+    if args.data_root and not args.random_feat and not bool(cfg.get("with_dino", True)):
+        from models.image_backbone import load_upsampler
+        upsampler = load_upsampler(use_norm=True, weights=args.upsampler_weights, device=dev)
+        if rank == 0 and not args.upsampler_weights:
+            print("train_driver: with_dino = False and no --upsampler-weights: the image backbone is RANDOMLY initialised "
+                  "(pass the FeatUp / DINOv2 state_dict, or --random-feat for explicit noise features)", file=sys.stderr)
+
     def forward_pair(v1, d1, v2, d2):
         # two calls, as in the reference (train-mode BatchNorm statistics are per call); inside each, LG-Net's local and
         # global chains already run on two streams (models/model.py:_two_branches)
-        return net(v1.permute(0, 2, 1), d1, None)[0], net(v2.permute(0, 2, 1), d2, None)[0]
+        if (d1 is None or d2 is None) and upsampler is None:
+            raise RuntimeError("the batch carries no visual features and no image backbone was built (use --random-feat for noise)")
+        return net(v1.permute(0, 2, 1), d1, upsampler)[0], net(v2.permute(0, 2, 1), d2, upsampler)[0]
 
     host_marks = [0.0, 0.0, 0.0, 0.0, 0] if os.environ.get("DVM_STEP_BREAKDOWN", "0") == "1" else None   # host seconds per phase
 
@@ -305,6 +332,7 @@ def main(argv=None):
 
     def train_step(batch, alpha):
         v1, v2, d1, d2, dist1, dist2 = batch
+        fit_criterion(crit, cfg, min(v1.shape[1], v2.shape[1]))
         t = time.perf_counter()
         geo = prefetch_geometry(v1, v2)
         f1, f2 = forward_pair(v1, d1, v2, d2)
@@ -313,9 +341,11 @@ def main(argv=None):
         t = mark(1, t)
         if world > 1:
             crit.data_parallel_loss(frac).backward()
+            join_side_streams(dev)                           # gradients written from the helper-stream chain are complete
             work = bucket.all_reduce_sum(async_op=True)      # one 8.5 MB collective on RCCL's stream ...
         else:
             out[0].backward()
+            join_side_streams(dev)
             work = None
         t = mark(2, t)
         # ... overlapped with the host-side bookkeeping of the step (5 loss terms; local values, as the reference logs them)
@@ -361,6 +391,7 @@ def main(argv=None):
                 f1, f2 = forward_pair(v1, d1, v2, d2)
                 out = crit(f1, f2, dist1, dist2, v1, v2, alpha, dfm, fps_starts=starts, anchors=anchors, geometry=join_geometry(geo))
                 out[0].backward()
+                join_side_streams(dev)
                 vals = loss_values(out, dev)
                 opt.step()
                 bucket.zero()
@@ -425,7 +456,6 @@ def main(argv=None):
     epochs = min(args.epochs, len(alphas))
     best_val = float("inf")
     history = []
-    it_total = 0
     for epoch in range(1, epochs + 1):
         lr = lr_at_epoch(cfg, epoch)
         for grp in opt.param_groups:
@@ -434,21 +464,20 @@ def main(argv=None):
         net.train()
         dfm.train()
         sums, iters = torch.zeros(5, device=dev), 0
-        for b in global_batches(train_set.pairs, Bg, shuffle_seed=1000 * epoch):        # the same order on every rank
-            sums += torch.as_tensor(train_step(train_set.batch(shard(b)), alpha), device=dev)
+        for b in global_batches(train_set.pairs, Bg, shuffle_seed=1000 * epoch, keep_tail=(world == 1)):   # the same order on every rank
+            sums += torch.as_tensor(train_step(train_set.batch(shard(b) if len(b) == Bg else b), alpha), device=dev)
             iters += 1
-            it_total += 1
-            if rank == 0 and it_total % int(cfg["misc"]["log_interval"]) == 0:
+            if rank == 0 and iters % int(cfg["misc"]["log_interval"]) == 0:    # per-epoch count, (i + 1) % log_interval (train.py:120-126)
                 save_ckpt(net, dfm, args.ckpt_dir, cfg["expname"], "train_best")
         # validation: eval mode, no gradients, this epoch's alpha (train.py:135-156)
         net.eval()
         dfm.eval()
         vsum, viters = torch.zeros((), device=dev), 0
         with torch.no_grad():
-            for b in global_batches(val_set.pairs, Bg):
-                v1, v2, d1, d2, dist1, dist2 = val_set.batch(shard(b))
-                f1, _ = net(v1.permute(0, 2, 1), d1, None)
-                f2, _ = net(v2.permute(0, 2, 1), d2, None)
+            for b in global_batches(val_set.pairs, Bg, keep_tail=(world == 1)):   # the reference's loader keeps the tail batch
+                v1, v2, d1, d2, dist1, dist2 = val_set.batch(shard(b) if len(b) == Bg else b)
+                fit_criterion(crit, cfg, min(v1.shape[1], v2.shape[1]))
+                f1, f2 = forward_pair(v1, d1, v2, d2)
                 vsum += crit(f1, f2, dist1, dist2, v1, v2, alpha, dfm)[0].detach().float()
                 viters += 1
         if world > 1:    # the validation loss that decides 'val_best' is the mean over all shards

@@ -46,11 +46,27 @@ const char *dvm_last_error(void);
 /* number of visible HIP devices (<=0: none) — lets callers fail loudly. */
 int dvm_device_count(void);
 
-/* Launch timing of the soft-correspondence kernel (K1) with HIP events recorded on the
- * launch stream: enable (pre-creates 2*max_launches events), run, then read the summed
- * kernel time and launch count (read synchronises on the recorded events and resets). */
+/* Launch timing of the pair path's kernels with HIP events recorded on the stream each kernel is
+ * launched on (bench.py's roofline legs; the reference has no counterpart: its profiling is
+ * wall-clock around train.py's step, train.py:93-112).  enable pre-creates 2*max_launches events
+ * and opens a window; the read functions synchronise on the window's events and return the summed
+ * kernel time and bracket count of one slot (dvm_profile_read = slot DVM_PROF_K1_SWEEP); disable
+ * closes the window.  dvm_profile_select chooses which slots record (bit k = slot k; default:
+ * the sweep only, so the timed region of bench.py carries two event records per step). */
+#define DVM_PROF_K1_SWEEP 0   /* softcorr_sweep_f16_kernel (pass A of K1) */
+#define DVM_PROF_K1_REFINE 1  /* softcorr_refine_kernel (pass B: exact re-evaluation) */
+#define DVM_PROF_MLP 2        /* mlp_f16x2_kernel (Deformer MLP) */
+#define DVM_PROF_CHAMFER 3    /* grid_chamfer_kernel */
+#define DVM_PROF_POOL 4       /* pool_kernel (Deformer Conv2d(k->1) pooling) */
+#define DVM_PROF_KNN_XYZ 5    /* grid_knn_self_kernel (xyz kNN) */
+#define DVM_PROF_FPS 6        /* fps_kernel */
+#define DVM_PROF_ASSEMBLE 7   /* assemble_pooled_kernel (Deformer input rows) */
+#define DVM_PROF_COUNT 8
 int dvm_profile_enable(int max_launches);
+int dvm_profile_select(unsigned kernel_mask);
 int dvm_profile_read(double *total_ms, int *launches);
+int dvm_profile_read_kernel(int kernel, double *total_ms, int *launches);
+const char *dvm_profile_kernel_name(int kernel);
 int dvm_profile_disable(void);
 
 /* x.pow(2).sum(-1) in ATen's summation order (the |a|^2 terms of torch.cdist's

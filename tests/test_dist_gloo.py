@@ -141,3 +141,69 @@ def test_bench_rank_helpers(monkeypatch):
         monkeypatch.setenv(k, str(v))
     if hasattr(bench, "rank_env"):
         assert bench.rank_env() == (4, 2, 2)
+
+
+def test_bench_gpus_flag_spawns_ranks_without_touching_torch():
+    """`python bench.py --gpus N` (no external launcher) must start N ranks ITSELF, from a parent that has imported no torch
+    and initialised no GPU (a process that has must never be turned into ranks on this pool): the parent's module table is
+    inspected at the moment it creates its children, and each child's environment is checked."""
+    import json
+    import subprocess
+    code = r"""
+import json, os, sys
+sys.path.insert(0, %r)
+import subprocess
+import bench
+seen = []
+class FakeProc:
+    def __init__(self, cmd, env=None, stdout=None, **kw):
+        assert 'torch' not in sys.modules and not any(m.startswith('torch.') for m in sys.modules), 'parent imported torch'
+        seen.append({k: env[k] for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'HSA_ENABLE_IPC_MODE_LEGACY')})
+        seen[-1]['cmd'] = cmd[1:]
+        self.returncode = 0
+        import io
+        self.stdout = io.StringIO('{"n_gpus": %%d}\n' %% int(env['WORLD_SIZE'])) if stdout is not None else None
+    def poll(self): return 0
+    def wait(self): return 0
+    def kill(self): pass
+subprocess.Popen = FakeProc
+os.environ.pop('WORLD_SIZE', None)
+rc = bench.main(['--gpus', '4', '--steps', '2', '--pairs-total', '64'])
+assert 'torch' not in sys.modules
+print(json.dumps({'rc': rc, 'seen': seen}), file=sys.stderr)
+""" % ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert json.loads(out.stdout.strip().splitlines()[-1]) == {"n_gpus": 4}        # rank 0's line is relayed
+    info = json.loads(out.stderr.strip().splitlines()[-1])
+    assert info["rc"] == 0 and len(info["seen"]) == 4
+    assert [e["RANK"] for e in info["seen"]] == ["0", "1", "2", "3"] == [e["LOCAL_RANK"] for e in info["seen"]]
+    assert all(e["WORLD_SIZE"] == "4" and e["MASTER_ADDR"] == "127.0.0.1" and e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for e in info["seen"])
+    assert len({e["MASTER_PORT"] for e in info["seen"]}) == 1
+    assert all(e["cmd"][0].endswith("bench.py") and e["cmd"][1:] == ["--gpus", "4", "--steps", "2", "--pairs-total", "64"] for e in info["seen"])
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    """Without a GPU every rank of `bench.py --gpus 2` stops with "needs a HIP device": the launcher must come back non-zero
+    (and not hang on the surviving ranks)."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check of the failure path")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0",
+                          "--pairs", "2"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0 and "needs a HIP device" in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_strong_scaling_shards():
+    sys.path.insert(0, ROOT)
+    import bench
+    for world in (1, 2, 4, 8):
+        shares = [bench.shard_pairs(4096, r, world) for r in range(world)]
+        assert sum(shares) == 4096 and max(shares) - min(shares) <= 1
+    assert [bench.shard_pairs(10, r, 4) for r in range(4)] == [3, 3, 2, 2]
+    a = bench.parse_args(["--gpus", "8", "--pairs-total", "4096"])
+    assert a.pairs_total == 4096 and a.workload == "pair"

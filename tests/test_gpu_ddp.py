@@ -97,23 +97,68 @@ def test_training_driver_two_ranks_on_one_gpu():
     assert all(map(lambda v: v == v and abs(v) < 1e9, res["first_losses"] + res["last_losses"]))
 
 
-def test_bench_two_ranks_on_one_gpu():
-    """bench.py's N > 1 path (barriers, MAX-over-ranks time, one JSON line from rank 0, whole-job value) with two gloo
-    ranks sharing cuda:0 — the 8-GPU run itself belongs to the driver."""
+def _bench_line(cmd):
     import json
     import subprocess
-    port = 29950 + os.getpid() % 1000
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs", "16",
-           "--backend", "gloo"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout                                   # rank 0 only
-    res = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2 --backend gloo` WITHOUT torchrun: the script itself starts two ranks (both on cuda:0 here —
+    the 8-GPU run belongs to the driver), barriers, MAX-over-ranks time, one JSON line from rank 0, whole-job value, the
+    oracle check of 4 pairs of the timed batch."""
+    res = _bench_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs", "16",
+                       "--backend", "gloo"])
     assert res["n_gpus"] == 2 and res["steps"] == 2 and res["scaling"] == "weak" and res["cpu_baseline"] is None
     assert abs(res["value"] - 2 * 16 * 2 / (res["ms_per_step"] * 2e-3)) < 1e-6 * res["value"]   # pairs of BOTH ranks / time
-    assert res["roofline"]["frac"] > 0
+    assert res["roofline"]["frac"] > 0 and len(res["roofline"]["kernels"]) >= 6
+    assert res["checked_pairs"] == 4 and res["check"]["ok"] and res["check"]["T_exact"]
+    assert res["config"]["pairs_per_gpu_per_step"] == 16 and res["config"]["pairs_per_step"] == 32
+
+
+def test_bench_strong_scaling_two_ranks():
+    """--pairs-total: the total work is fixed and split over the ranks (24 pairs -> 12 + 12), "scaling": "strong"."""
+    res = _bench_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs-total", "24",
+                       "--backend", "gloo", "--no-check"])
+    assert res["n_gpus"] == 2 and res["scaling"] == "strong" and res["config"]["pairs_per_gpu_per_step"] == 12
+    assert abs(res["value"] - 24 * 2 / (res["ms_per_step"] * 2e-3)) < 1e-6 * res["value"]
+    assert res["checked_pairs"] == 0 and res["check"] is None
+
+
+def test_bench_under_an_external_launcher():
+    """The driver's N > 1 form: torch.distributed.run starts the ranks, bench.py spawns nothing."""
+    port = 29950 + os.getpid() % 1000
+    res = _bench_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                       "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                       "--pairs", "16", "--backend", "gloo", "--no-check"])
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak"
+    assert abs(res["value"] - 2 * 16 * 2 / (res["ms_per_step"] * 2e-3)) < 1e-6 * res["value"]
+
+
+def test_bench_single_gpu_line_and_check():
+    """N = 1, in-process (what `rocprofv3 ... -- python3 bench.py` profiles): roofline + kernels[] + oracle check + cpu_baseline
+    on pairs of the timed batch."""
+    res = _bench_line([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--pairs", "8", "--cpu-sample", "4"])
+    assert res["n_gpus"] == 1 and res["checked_pairs"] == 4 and res["check"]["ok"]
+    assert res["cpu_baseline"]["kind"] == "port" and res["cpu_baseline"]["value"] > 0 and "timed batch" in res["cpu_baseline"]["sample"]
+    names = [k["kernel"] for k in res["roofline"]["kernels"]]
+    assert "softcorr_refine_kernel" in names and "mlp_f16x2_kernel" in names and "grid_chamfer_kernel" in names
+    assert all(k["launch_ms"] > 0 and 0 < k["frac"] < 1.5 for k in res["roofline"]["kernels"])
+    assert 0 < res["roofline"]["whole_path"]["frac"] < 1
+
+
+def test_bench_training_workloads():
+    """--workload train / partial: BASELINE configs[2] / configs[3] through train_driver's timing mode, same line format."""
+    for wl, crit in (("train", "GraphDeformLoss_Neural"), ("partial", "GraphDeformLoss_Neural_Partial")):
+        res = _bench_line([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", wl, "--steps", "2", "--warmup", "1"])
+        assert res["n_gpus"] == 1 and res["unit"] == "pairs/s" and res["config"]["criterion"] == crit
+        assert res["value"] > 0 and res["roofline"]["frac"] > 0
+        assert all(v == v and abs(v) < 1e12 for v in res["first_losses"] + res["last_losses"])
 
 
 # ---------------------------------------------------------------------------------------------------------------------

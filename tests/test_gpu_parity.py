@@ -311,6 +311,30 @@ def test_pair_forward_equals_two_directions(ops, golden, shape):
         assert torch.equal(o21[k], r21[k]), ("21", k)
 
 
+def test_pair_forward_full_size_vs_oracle(ops, golden):
+    """The very call bench.py times — ops.pair_forward at N = M = 2048, d = 128, randn features, alpha = 100, helper-stream
+    overlap ON — against the oracle for EVERY pair and both directions: arg-max maps bit-exact, coordinates <= 1e-4,
+    losses rtol 1e-3 (B = 4: the oracle needs ~1 s per pair and direction on the box's host cores)."""
+    w = golden("deformer_scape_r_weights")
+    wl = ops.deformer_weight_list(w, "cuda")
+    B, N = 4, 2048
+    g = torch.Generator().manual_seed(2048)
+    f1, f2 = torch.randn(B, N, 128, generator=g), torch.randn(B, N, 128, generator=g)
+    v1, v2 = torch.rand(B, N, 3, generator=g), torch.rand(B, N, 3, generator=g)
+    s1, s2 = torch.tensor([0, 5, 77, 2047], dtype=torch.int32), torch.zeros(B, dtype=torch.int32)
+    from dvm import _lib
+    assert _lib.load().dvm_pair_set_overlap(1) in (0, 1)
+    o12, o21 = ops.pair_forward(wl, f1.cuda(), f2.cuda(), v1.cuda(), v2.cuda(), 100.0, s1.cuda(), s2.cuda())
+    torch.cuda.synchronize()
+    for b in range(B):
+        for out, (fa, fb, va, vb, st) in ((o12, (f1, f2, v1, v2, s1)), (o21, (f2, f1, v2, v1, s2))):
+            o = O.pair_direction(w, fa[b].numpy(), fb[b].numpy(), va[b].numpy(), vb[b].numpy(), 100.0, int(st[b]))
+            assert np.array_equal(host(out["T12"])[b], o["T12"]), "arg-max map differs from the oracle"
+            np.testing.assert_allclose(host(out["verts12"])[b], o["verts12"], rtol=0, atol=1e-5)
+            np.testing.assert_allclose(host(out["warped"])[b], o["warped"], rtol=0, atol=1e-4)
+            np.testing.assert_allclose(host(out["losses"])[b], o["losses"], rtol=1e-3)
+
+
 def test_errors_are_loud(ops):
     from dvm._lib import DvmError
     f = torch.randn(1, 8, 128)
