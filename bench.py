@@ -210,9 +210,9 @@ def kernel_models(P):
         5: dict(bound="hbm", work=2 * P * N_PTS * (16 + 40), note="xyz kNN (k = 10) of all 2P clouds on the uniform grid: latency / VALU bound"),
         6: dict(bound="hbm", work=2 * P * N_PTS * 12 + 2 * P * (N_PTS // 2) * 4,
                 note="farthest-point sampling: N/2 dependent steps per cloud, one workgroup per cloud: latency bound"),
-        7: dict(bound="hbm", work=P * (N_PTS // 2) * (264 * 4 + row + 10 * row),
-                note="Deformer input rows of one direction: 264 floats written per node, its pooled row and the 10 pooled rows of its "
-                     "correspondences gathered"),
+        7: dict(bound="hbm", work=P * ((N_PTS // 2) * 264 * 4 + 2 * N_PTS * row),
+                note="Deformer input rows of one direction: 264 floats written per node; the pooled rows of both clouds read at least "
+                     "once (a node gathers its own pooled row and the 10 of its correspondences, mostly L2 hits)"),
     }
 
 

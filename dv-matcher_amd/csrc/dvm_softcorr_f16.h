@@ -1,0 +1,115 @@
+// dvm_softcorr_f16.h — what the two translation units of the fp16-split soft-correspondence sweep share
+// (dvm_softcorr_f16.hip: splitting, first form of pass A, pass B, launchers; dvm_softcorr_sweep2.hip: second form of pass A).
+#pragma once
+#include "dvm_common.h"
+
+namespace dvm {
+namespace k1 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr int HB_D = 128;
+constexpr int HB_ROWB = 2 * HB_D * 2;   // 512 B per row: planes h | m, 128 fp16 each
+constexpr int HB_KT = 64;               // keys per LDS tile (two 32-key sub-tiles)
+constexpr int HB_WAVES = 8, HB_QB = 32 * HB_WAVES, HB_THREADS = 64 * HB_WAVES;
+constexpr int HB_GLDS_PER_WAVE = HB_KT * HB_ROWB / 1024 / HB_WAVES;  // 4 LDS-DMA pieces (1 KiB = 2 rows) per wave per tile
+constexpr int HB_STAGE = 16 * 64;       // floats per wave
+constexpr int HB_KC = 12;               // candidates kept per row (top-10 + 2 of margin)
+constexpr size_t HB_LDS_BYTES = (size_t)2 * HB_KT * HB_ROWB + 2 * HB_KT * sizeof(float) + (size_t)HB_WAVES * HB_STAGE * sizeof(float);
+constexpr float HB_ERR = 2.5e-5f;  // |d2_passA - d2_chain| <= HB_ERR (|q|^2 + |k|^2): gamma_128 of both fp32 accumulations
+                                   // (2 x 7.7e-6) + the dropped split terms (1.4e-6) + the second form's 4 key bits that
+                                   // carry the register number (2^-19 of d2 <= 2 (|q|^2 + |k|^2): 3.8e-6), see DESIGN.md
+
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+    int q = nwg / 8, r = nwg % 8, xcd = orig % 8;
+    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + orig / 8;
+}
+
+// power of two s with max|x| * s in [2^11, 2^12): well inside fp16's range, the m-plane of every element within 2^-8 of
+// the largest stays a normal fp16 number (smaller ones keep an absolute error of 2^-25 in scaled units: far below the
+// error bound, which is relative to the largest norms), and |x s|^2 summed over 128 channels stays below 2^31 — the
+// range of the three-piece fp16 representation of the norms in the second sweep form
+__device__ __forceinline__ int scale_exp(int maxbits) {  // log2(s)
+    const int e = ((maxbits >> 23) & 0xff) - 127;
+    int k = 11 - e;
+    k = k > 100 ? 100 : (k < -100 ? -100 : k);
+    return maxbits == 0 ? 0 : k;
+}
+__device__ __forceinline__ float pow2i(int k) { return __int_as_float((127 + k) << 23); }
+
+// Sorted candidate list with (key, column) packed into one double: high word = the float key's bits, low word =
+// the column.  Doubles with the same sign order like their bit patterns, so a compare-swap of two entries is
+// v_min_f64 + v_max_f64 (instead of a compare and four selects) and ties break on the column for free.
+// Keys are squared distances: >= 0 up to rounding (a slightly negative key only reverses its own tie order).
+// (plain v_min_f64 / v_max_f64: the C fmin/fmax add a canonicalising v_max_f64 x, x per operand; no NaNs here)
+#ifdef DVM_K1_BUILTIN_MINMAX
+// (dvm_softcorr_sweep2.hip is built with -fno-honor-nans: fmin / fmax lower to the bare instructions there, and — unlike an
+// asm statement — stay visible to the instruction scheduler as vector instructions)
+__device__ __forceinline__ double min64(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ double max64(double a, double b) { return __builtin_fmax(a, b); }
+#else
+__device__ __forceinline__ double min64(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double max64(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+#endif
+
+template <int K>
+struct PackedBest {
+    double e[K];
+    static __device__ __forceinline__ double pack(float key, int col) { return __hiloint2double(__float_as_int(key), col); }
+    static __device__ __forceinline__ float key_of(double x) { return __int_as_float(__double2hiint(x)); }
+    static __device__ __forceinline__ int col_of(double x) { return __double2loint(x); }
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int t = 0; t < K; ++t) e[t] = pack(INFINITY, 0x7fffffff);
+    }
+    __device__ __forceinline__ float key(int t) const { return key_of(e[t]); }
+    // returns the entry that is outside the list afterwards (the evicted worst, or x itself)
+    __device__ __forceinline__ double insert(double x) {
+        const double out = max64(e[K - 1], x);
+        e[K - 1] = min64(e[K - 1], x);
+#pragma unroll
+        for (int p = K - 1; p > 0; --p) {
+            const double lo = min64(e[p - 1], e[p]), hi = max64(e[p - 1], e[p]);
+            e[p - 1] = lo;
+            e[p] = hi;
+        }
+        return out;
+    }
+};
+
+// ---------------------------------------------------------------- pass A arguments
+struct HBGroup {
+    const char *qp, *kp;     // planes of the query / key side [B][rows][512]
+    const int *qmax, *kmax;  // bit patterns of max|x| of either side (the split's scale)
+    const float *nq, *nk;    // |.|^2 (ATen order); nk padded to whole tiles with +inf: [B][Mpad]
+    int N, M, Mpad, tiles;
+    int32_t *cidx;           // [B][N][HB_KC]
+    float *cd2;              // [B][N][HB_KC] approximate squared distances, ascending
+    float *lsum;             // [B][N][2] = (sum exp(s - cref), cref)
+};
+struct HBArgs {
+    HBGroup g[2];
+    int blocks0;
+    float neg_alpha, cutw;
+};
+
+
+// second form of pass A (dvm_softcorr_sweep2.hip); form = sweep_form() of the caller: 1 plain, 2 pipelined, 3 pipelined + paced
+void launch_norm_frags(const float *nrm, int B, int M, int Mpad, const int *amax, char *out, hipStream_t s);
+void launch_sweep2(const HBArgs &a, const char *knf0, const char *knf1, const int *amaxc, int blocks, int form, hipStream_t s);
+
+}  // namespace k1
+}  // namespace dvm

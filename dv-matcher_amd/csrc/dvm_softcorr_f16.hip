@@ -16,7 +16,7 @@
 // (reference: models/loss.py:110-114, 1339-1347, 1404-1407)
 #include <stdlib.h>
 
-#include "dvm_common.h"
+#include "dvm_softcorr_f16.h"
 
 namespace dvm {
 
@@ -24,29 +24,7 @@ void launch_rownorm2(const float *x, int rows, int K, float *out, hipStream_t s)
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-
-constexpr float LOG2E = 1.4426950408889634f;
-constexpr int HB_D = 128;
-constexpr int HB_ROWB = 2 * HB_D * 2;   // 512 B per row: planes h | m, 128 fp16 each
-constexpr int HB_KT = 64;               // keys per LDS tile (two 32-key sub-tiles)
-constexpr int HB_WAVES = 8, HB_QB = 32 * HB_WAVES, HB_THREADS = 64 * HB_WAVES;
-constexpr int HB_GLDS_PER_WAVE = HB_KT * HB_ROWB / 1024 / HB_WAVES;  // 4 LDS-DMA pieces (1 KiB = 2 rows) per wave per tile
-constexpr int HB_STAGE = 16 * 64;       // floats per wave
-constexpr int HB_KC = 12;               // candidates kept per row (top-10 + 2 of margin)
-constexpr size_t HB_LDS_BYTES = (size_t)2 * HB_KT * HB_ROWB + 2 * HB_KT * sizeof(float) + (size_t)HB_WAVES * HB_STAGE * sizeof(float);
-constexpr float HB_ERR = 2.5e-5f;  // |d2_passA - d2_chain| <= HB_ERR (|q|^2 + |k|^2): gamma_128 of both fp32 accumulations
-                                   // (2 x 7.7e-6) + the dropped split terms (1.4e-6) + the second form's 4 key bits that
-                                   // carry the register number (2^-19 of d2 <= 2 (|q|^2 + |k|^2): 3.8e-6), see DESIGN.md
-
-__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
-    int q = nwg / 8, r = nwg % 8, xcd = orig % 8;
-    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + orig / 8;
-}
+using namespace k1;
 
 // ---------------------------------------------------------------- scale + split: fp32 rows -> fp16 planes
 // largest |x| of a tensor as its bit pattern (non-negative floats order like integers)
@@ -60,59 +38,6 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0 && __float_as_int(m) > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, __float_as_int(m));
 }
-
-// power of two s with max|x| * s in [2^11, 2^12): well inside fp16's range, the m-plane of every element within 2^-8 of
-// the largest stays a normal fp16 number (smaller ones keep an absolute error of 2^-25 in scaled units: far below the
-// error bound, which is relative to the largest norms), and |x s|^2 summed over 128 channels stays below 2^31 — the
-// range of the three-piece fp16 representation of the norms in the second sweep form
-__device__ __forceinline__ int scale_exp(int maxbits) {  // log2(s)
-    const int e = ((maxbits >> 23) & 0xff) - 127;
-    int k = 11 - e;
-    k = k > 100 ? 100 : (k < -100 ? -100 : k);
-    return maxbits == 0 ? 0 : k;
-}
-__device__ __forceinline__ float pow2i(int k) { return __int_as_float((127 + k) << 23); }
-
-// Sorted candidate list with (key, column) packed into one double: high word = the float key's bits, low word =
-// the column.  Doubles with the same sign order like their bit patterns, so a compare-swap of two entries is
-// v_min_f64 + v_max_f64 (instead of a compare and four selects) and ties break on the column for free.
-// Keys are squared distances: >= 0 up to rounding (a slightly negative key only reverses its own tie order).
-// (plain v_min_f64 / v_max_f64: the C fmin/fmax add a canonicalising v_max_f64 x, x per operand; no NaNs here)
-__device__ __forceinline__ double min64(double a, double b) {
-    double r;
-    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ double max64(double a, double b) {
-    double r;
-    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
-template <int K>
-struct PackedBest {
-    double e[K];
-    static __device__ __forceinline__ double pack(float key, int col) { return __hiloint2double(__float_as_int(key), col); }
-    static __device__ __forceinline__ float key_of(double x) { return __int_as_float(__double2hiint(x)); }
-    static __device__ __forceinline__ int col_of(double x) { return __double2loint(x); }
-    __device__ __forceinline__ void init() {
-#pragma unroll
-        for (int t = 0; t < K; ++t) e[t] = pack(INFINITY, 0x7fffffff);
-    }
-    __device__ __forceinline__ float key(int t) const { return key_of(e[t]); }
-    // returns the entry that is outside the list afterwards (the evicted worst, or x itself)
-    __device__ __forceinline__ double insert(double x) {
-        const double out = max64(e[K - 1], x);
-        e[K - 1] = min64(e[K - 1], x);
-#pragma unroll
-        for (int p = K - 1; p > 0; --p) {
-            const double lo = min64(e[p - 1], e[p]), hi = max64(e[p - 1], e[p]);
-            e[p - 1] = lo;
-            e[p] = hi;
-        }
-        return out;
-    }
-};
 
 __global__ __launch_bounds__(256) void split_planes_kernel(const float *__restrict__ x, long rows, const int *__restrict__ maxbits,
                                                            char *__restrict__ planes) {
@@ -152,21 +77,6 @@ __global__ void norm_max_kernel(const float *__restrict__ nrm, int rows_per_batc
 }
 
 // ---------------------------------------------------------------- pass A
-struct HBGroup {
-    const char *qp, *kp;     // planes of the query / key side [B][rows][512]
-    const int *qmax, *kmax;  // bit patterns of max|x| of either side (the split's scale)
-    const float *nq, *nk;    // |.|^2 (ATen order); nk padded to whole tiles with +inf: [B][Mpad]
-    int N, M, Mpad, tiles;
-    int32_t *cidx;           // [B][N][HB_KC]
-    float *cd2;              // [B][N][HB_KC] approximate squared distances, ascending
-    float *lsum;             // [B][N][2] = (sum exp(s - cref), cref)
-};
-struct HBArgs {
-    HBGroup g[2];
-    int blocks0;
-    float neg_alpha, cutw;
-};
-
 template <bool LEAN>
 __global__ __launch_bounds__(HB_THREADS, 2) void softcorr_sweep_f16_kernel(const HBArgs args) {
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
@@ -375,368 +285,11 @@ __global__ __launch_bounds__(HB_THREADS, 2) void softcorr_sweep_f16_kernel(const
     }
 }
 
-// ---------------------------------------------------------------- pass A, second form: no per-entry work
-// What the first form spends its time on is not the matrix work (24 matrix instructions per 32 x 32 sub-tile) but the ~300
-// vector instructions behind it: per entry {fma, add, compare, mask, LDS staging} and a wave-level insertion loop that
-// runs max-over-lanes(#flagged) times for a handful of active lanes.  This form removes the per-entry arithmetic and the
-// data-dependent loop from the common path:
-//  * the norms ride on the matrix pipe: one more matrix instruction per sub-tile whose 16 k-slots carry |k|^2 and |q|^2,
-//    each as three exact fp16 pieces times power-of-two constants, so that the accumulator IS the (scaled, non-negative)
-//    squared distance  acc = (|q|^2 (1 + 2^-13) + |k|^2 - 2 q.k) s^2 / 2  (one scale s for both sides; the row-constant bias
-//    keeps every accumulator >= 0, so keys order identically as floats, as ints and as the high words of doubles);
-//  * a lane's 16 entries go through a fixed selection network on their bit patterns (the register number embedded in the
-//    low 4 mantissa bits: keys are unique, the column is recovered from the key): sorted three smallest in 46 three-input
-//    integer min / med / max instructions, no comparison against a threshold per entry;
-//  * the two smallest are inserted into the sorted list of 12 unconditionally (the packed (key, column) doubles of the
-//    first form); the third only decides whether the lane may hold MORE than two entries below its threshold, in which case
-//    the wave repeats the selection on the remaining entries (a few percent of the sub-tiles once the lists have filled).
-// Everything in the common path is straight-line register code, which the compiler can place between the matrix
-// instructions of the NEXT sub-tile (PIPE): the chain of sub-tile i+1 is issued before the epilogue of sub-tile i.
-// Same outputs as the first form (candidate columns, approximate squared distances, partial softmax sums), same
-// guarantees: a column that belongs to a row's 12 smallest is never lost (every entry at or below the row's running bound
-// is inserted), the softmax sum covers every column outside the final list that lies within the cut.
-constexpr int H2_LDS_BYTES = 2 * HB_KT * HB_ROWB + 2 * HB_KT * 32;   // key tiles + norm fragments (32 B per key)
-constexpr int H2_REMOVED = 0x7f800000;                               // bit pattern of +inf: larger than every finite key
-
-struct H2Group {
-    const char *qp, *kp;      // planes of the query / key side [B][rows][512]
-    const char *knf;          // key-side norm fragments [B][Mpad][32 B]: fp16 {a1, a2, a3, 2^15, 2^4, 2^-7, 0, 0 | 0 x 8}
-    const float *nq;          // |q|^2 (ATen order)
-    int N, M, Mpad, tiles;
-    int32_t *cidx;
-    float *cd2, *lsum;
-};
-struct H2Args {
-    H2Group g[2];
-    const int *amax;          // bit pattern of max |x| over BOTH sides (the common scale)
-    int blocks0;
-    float neg_alpha, cutw;
-};
-
-__device__ __forceinline__ int imin3(int a, int b, int c) {
-    int r;
-    asm("v_min3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ int imax3(int a, int b, int c) {
-    int r;
-    asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ int imed3(int a, int b, int c) {
-    int r;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-// (x & ~15) | r in one instruction (both constants are inline operands)
-__device__ __forceinline__ int embed4(float x, int r) {
-    int o;
-    asm("v_and_or_b32 %0, %1, -16, %2" : "=v"(o) : "v"(x), "n"(0), "v"(r));
-    return o;
-}
-
-// three fp16 pieces of a non-negative fp32 value x < 2^31:  x = p1 2^15 + p2 2^4 + p3 2^-7  (exact: 33 >= 24 bits)
-__device__ __forceinline__ void norm_pieces(float x, _Float16 &p1, _Float16 &p2, _Float16 &p3) {
-    p1 = (_Float16)(x * 0x1p-15f);
-    const float r1 = x - (float)p1 * 0x1p+15f;
-    p2 = (_Float16)(r1 * 0x1p-4f);
-    const float r2 = r1 - (float)p2 * 0x1p+4f;
-    p3 = (_Float16)(r2 * 0x1p+7f);
-}
-// |x|^2 in accumulator units: n s^2 / 2, formed as (n s) (s / 2) so that no intermediate leaves the fp32 range
-__device__ __forceinline__ float norm_scaled(float n, int se) { return (n * pow2i(se)) * pow2i(se - 1); }
-
-// key-side norm fragments, padded to whole key tiles with +inf: out [B][Mpad][16 fp16]
-__global__ void norm_frags_kernel(const float *__restrict__ nrm, int M, int Mpad, const int *__restrict__ amax, char *__restrict__ out) {
-    const int b = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Mpad) return;
-    f16x8 lo = {0, 0, 0, (_Float16)0x1p+15f, (_Float16)0x1p+4f, (_Float16)0x1p-7f, 0, 0};
-    const f16x8 hi = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (i < M) {
-        _Float16 p1, p2, p3;
-        norm_pieces(norm_scaled(nrm[(size_t)b * M + i], scale_exp(*amax)), p1, p2, p3);
-        lo[0] = p1, lo[1] = p2, lo[2] = p3;
-    } else {
-        lo[0] = (_Float16)INFINITY;
-    }
-    char *p = out + ((size_t)b * Mpad + i) * 32;
-    *(f16x8 *)p = lo;
-    *(f16x8 *)(p + 16) = hi;
-}
-
 // both sides share ONE scale (the larger absmax): the norm pieces are sized for max |x s| < 2^12
 __global__ void common_absmax_kernel(const int *__restrict__ in, int *__restrict__ out) {
     const int m = max(in[0], in[1]);
     out[0] = m;
     out[1] = m;
-}
-
-// sorted (s0 <= s1 <= s2) three smallest of 16 distinct ints
-struct Top3 {
-    int s0, s1, s2;
-};
-__device__ __forceinline__ Top3 sort3(int a, int b, int c) { return Top3{imin3(a, b, c), imed3(a, b, c), imax3(a, b, c)}; }
-__device__ __forceinline__ Top3 merge3(const Top3 &a, const Top3 &b) {
-    Top3 c;
-    const int m00 = max(a.s0, b.s0);
-    c.s0 = min(a.s0, b.s0);
-    c.s1 = imin3(m00, a.s1, b.s1);
-    c.s2 = min(imin3(a.s2, b.s2, max(a.s1, b.s0)), max(a.s0, b.s1));
-    return c;
-}
-__device__ __forceinline__ Top3 top3_of_16(const int (&v)[16]) {
-    Top3 t = merge3(merge3(sort3(v[0], v[1], v[2]), sort3(v[3], v[4], v[5])),
-                    merge3(merge3(sort3(v[6], v[7], v[8]), sort3(v[9], v[10], v[11])), sort3(v[12], v[13], v[14])));
-    const int x = v[15];
-    return Top3{min(t.s0, x), imed3(t.s0, t.s1, x), imed3(t.s1, t.s2, x)};
-}
-
-template <int PIPE>
-__global__ __launch_bounds__(HB_THREADS) void softcorr_sweep2_kernel(const H2Args args) {
-    extern __shared__ __attribute__((aligned(16))) char smem_b[];
-    char *const ktile0 = smem_b;                                         // [2][HB_KT][512], 16-B chunks XOR-swizzled
-    char *const knf0 = smem_b + (size_t)2 * HB_KT * HB_ROWB;             // [2][HB_KT][32]
-
-    int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int grp = lid >= args.blocks0 ? 1 : 0;
-    lid -= grp ? args.blocks0 : 0;
-    const H2Group &G = args.g[grp];
-    const int N = G.N, M = G.M;
-    const int b = lid / G.tiles, qt = lid % G.tiles;
-    const float neg_alpha = args.neg_alpha;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r32 = lane & 31, h = lane >> 5;
-
-    const char *kbase = G.kp + (size_t)b * M * HB_ROWB;
-    const char *nfbase = G.knf + (size_t)b * G.Mpad * 32;
-    const int qrow = qt * HB_QB + wave * 32 + r32;
-    const int qrc = qrow < N ? qrow : N - 1;
-    const char *qptr = G.qp + ((size_t)b * N + qrc) * HB_ROWB + 16 * h;
-    f16x8 qh[8], qm[8];  // B-operand fragments, NEGATED (the accumulator carries + |q|^2 + |k|^2 - 2 q.k): k = 16 s + 8 h + j
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        qh[s] = -*(const f16x8 *)(qptr + 32 * s);
-        qm[s] = -*(const f16x8 *)(qptr + 256 + 32 * s);
-    }
-    const int se = scale_exp(*args.amax);
-    const float cf = pow2i(1 - 2 * se);             // 2 / s^2: accumulator units -> squared distance
-    const float icf = pow2i(2 * se - 1);
-    // the query's norm, biased by 2^-13 of itself (accumulators stay >= 0 whatever the rounding: a negative value needs
-    // |q| ~ |k|, where the bias is twice the error bound), as the B operand of the norm instruction
-    const float nas = norm_scaled(G.nq[(size_t)b * N + qrc], se);
-    const float nasb = nas + nas * 0x1p-13f;
-    const float bias = nasb - nas;                  // exact
-    f16x8 qn = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (h == 0) {
-        _Float16 p1, p2, p3;
-        norm_pieces(nasb, p1, p2, p3);
-        qn[0] = (_Float16)0x1p+15f, qn[1] = (_Float16)0x1p+4f, qn[2] = (_Float16)0x1p-7f;
-        qn[3] = p1, qn[4] = p2, qn[5] = p3;
-    }
-
-    PackedBest<HB_KC> kb;  // (key bits, sub-tile base column): the key's low 4 bits name the accumulator register
-    kb.init();
-    float cref = -INFINITY, l = 0.f;
-    int lim = 0x7fffffff, cut_i = 0x7fffffff;
-    const float cutw = args.cutw;
-
-    const int ntiles = (M + HB_KT - 1) / HB_KT;
-    auto stage_tile = [&](int t, int buf) __attribute__((always_inline)) {
-        const int j0 = t * HB_KT;
-        char *kt = ktile0 + (size_t)buf * HB_KT * HB_ROWB;
-#pragma unroll
-        for (int e = 0; e < HB_GLDS_PER_WAVE; ++e) {
-            const int piece = wave * HB_GLDS_PER_WAVE + e;       // 2 rows
-            const int r = 2 * piece + h;
-            const int jr = j0 + r < M ? j0 + r : M - 1;           // padding keys re-read the last row (their norm is +inf)
-            const char *src = kbase + (size_t)jr * HB_ROWB + ((r32 ^ (r & 15)) << 4);   // 16-B chunk c of the LDS row holds chunk c ^ (row & 15)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(kt + piece * 1024), 16, 0, 0);
-        }
-        if (wave < 2)   // 64 keys x 32 B of norm fragments = two 1-KiB pieces
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(nfbase + (size_t)j0 * 32 + wave * 1024 + lane * 16),
-                                             (__attribute__((address_space(3))) void *)(knf0 + buf * HB_KT * 32 + wave * 1024), 16, 0, 0);
-    };
-
-    auto key_d2 = [&](int key) __attribute__((always_inline)) { return fmaxf(__int_as_float(key) - bias, 0.f) * cf; };   // key -> squared distance
-    auto add_term = [&](int key) __attribute__((always_inline)) {  // l += exp(s - cref) for a finite key (otherwise nothing)
-        const bool live = key < H2_REMOVED;
-        const float s = __builtin_amdgcn_sqrtf(key_d2(key)) * neg_alpha;
-        const float cnew = live ? fmaxf(cref, s) : cref;
-        const float sc = (cnew == cref) ? 1.f : __builtin_amdgcn_exp2f((cref - cnew) * LOG2E);
-        const float term = live ? __builtin_amdgcn_exp2f((s - cnew) * LOG2E) : 0.f;
-        l = l * sc + term;
-        cref = cnew;
-    };
-
-    // The matrix work of one sub-tile: 24 product instructions + the norm instruction.  A fragment (row r32, chunk 2s + h of
-    // plane p) sits at row * 512 + ((2s ^ h ^ (row & 15)) << 4) + 256 p: the swizzle touches the low four chunk bits only (a
-    // ds_read_b128 is served in groups of 16 lanes, which then hit 16 different 16-B bank slots), so the plane, the sub-tile
-    // and the buffer are immediate offsets of eight loop-invariant address registers — no address arithmetic in the loop.
-    unsigned fadr[8];
-    {
-        const unsigned rowb = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)ktile0 + r32 * HB_ROWB;
-        const int tq = h ^ (r32 & 15);
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            fadr[s] = rowb + (((2 * s) ^ tq) << 4);
-            asm volatile("" : "+v"(fadr[s]));   // keep them: recomputing costs two vector instructions per fragment
-        }
-    }
-    unsigned nadr = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)knf0 + r32 * 32 + 16 * h;
-    asm volatile("" : "+v"(nadr));
-    auto lds16 = [](unsigned adr, int off) __attribute__((always_inline)) {
-        return *(const f16x8 *)(const __attribute__((address_space(3))) char *)(size_t)(adr + off);
-    };
-    auto chain = [&](int buf, int sub) __attribute__((always_inline)) -> f32x16 {   // buf, sub: literals after inlining
-        const int toff = buf * (HB_KT * HB_ROWB) + sub * (32 * HB_ROWB);
-        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const f16x8 an = lds16(nadr, buf * (HB_KT * 32) + sub * (32 * 32));
-        // fragments in two batches of 4 k-steps (32 VGPRs each): the 16 of a whole sub-tile at once do not fit next to the
-        // previous sub-tile's epilogue
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            f16x8 ah[4], am[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                ah[u] = lds16(fadr[4 * half + u], toff);
-                am[u] = lds16(fadr[4 * half + u], toff + 256);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int s = 4 * half + u;
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(am[u], qh[s], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[u], qm[s], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[u], qh[s], acc, 0, 0, 0);
-            }
-        }
-        // the norms last: every partial sum before it has the magnitude of q.k
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(an, qn, acc, 0, 0, 0);
-    };
-
-    // the two smallest of the lane's 16 keys go into the list; an entry that leaves the list (or fails to enter it) contributes
-    // its softmax term if it lies within the cut: nearly never at the alphas this sweep is used for — the whole wave skips
-    // the exponentials unless one lane needs them
-    auto insert2 = [&](const Top3 &w, int jb, bool paced) __attribute__((always_inline)) {
-        const int k0 = __double2hiint(kb.insert(__hiloint2double(w.s0, jb)));
-        const int k1 = __double2hiint(kb.insert(__hiloint2double(w.s1, jb)));
-        if (paced) {
-            // PIPE == 2: the block that ends here holds the matrix chain of the NEXT sub-tile (25 instructions, 17 LDS reads) and
-            // this sub-tile's selection + insertions (~115 vector instructions): ask the scheduler for one matrix instruction
-            // per five vector instructions, the first batch of fragment reads up front and the second a third of the way in
-            __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
-#pragma unroll
-            for (int i = 0; i < 25; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (i == 3) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-            }
-        }
-        if (__builtin_amdgcn_ballot_w64(min(k0, k1) <= cut_i) != 0) {
-            add_term(k0 <= cut_i ? k0 : H2_REMOVED);
-            add_term(k1 <= cut_i ? k1 : H2_REMOVED);
-        }
-    };
-
-    auto epilogue = [&](const f32x16 &acc, int jb, bool paced) __attribute__((always_inline)) {
-        int v[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = embed4(acc[r], r);
-        Top3 w = top3_of_16(v);
-        insert2(w, jb, paced);
-        // a third entry at or below the bound in some lane: the wave takes the next two of every lane, until none is left
-        // (every sub-tile while the lists fill, a few percent of them afterwards)
-        while (__builtin_amdgcn_ballot_w64(w.s2 <= lim && w.s2 < H2_REMOVED) != 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = v[r] <= w.s1 ? (H2_REMOVED | r) : v[r];
-            w = top3_of_16(v);
-            insert2(w, jb, false);
-        }
-    };
-    // bound for the following sub-tiles: the row's KC-th best is at most min(a_K, b_K, max(a_m, b_m)), m = KC/2, over the two
-    // half-lanes (a, b) that share the row; everything within the cut is processed as well (it owes a softmax term).  Any
-    // earlier bound stays valid (it only admits more entries): refreshed after every sub-tile while the lists fill, once per
-    // tile afterwards.
-    auto update_bound = [&]() __attribute__((always_inline)) {
-        const int wk = __double2hiint(kb.e[HB_KC - 1]), wm = __double2hiint(kb.e[HB_KC / 2 - 1]), w0 = __double2hiint(kb.e[0]);
-        const auto sk = __builtin_amdgcn_permlane32_swap((unsigned)wk, (unsigned)wk, false, false);
-        const auto sm = __builtin_amdgcn_permlane32_swap((unsigned)wm, (unsigned)wm, false, false);
-        const auto s0 = __builtin_amdgcn_permlane32_swap((unsigned)w0, (unsigned)w0, false, false);
-        const int pk = (int)(h ? sk[0] : sk[1]), pm = (int)(h ? sm[0] : sm[1]), p0 = (int)(h ? s0[0] : s0[1]);
-        const int thr = min(min(wk, pk), max(wm, pm));
-        const int kmin = min(w0, p0);
-        const float dmin = kmin < H2_REMOVED ? __builtin_amdgcn_sqrtf(key_d2(kmin)) : INFINITY;
-        const float cut = dmin + cutw;                      // beyond this the softmax term is < e^-20 of the largest
-        const float ck = fmaf((cut * cut) * 1.000001f, icf, bias);
-        cut_i = ck < INFINITY ? __float_as_int(ck) + 32 : 0x7fffffff;   // (+32: the embedded register number, rounding of ck)
-        lim = max(thr, cut_i);
-    };
-
-    stage_tile(0, 0);
-    __syncthreads();  // (drains the DMA: vmcnt(0))
-    if (PIPE == 0) {
-        auto tile = [&](int t, int buf) __attribute__((always_inline)) {
-            if (t + 1 < ntiles) stage_tile(t + 1, buf ^ 1);  // the other buffer was last read before the previous barrier
-            const f32x16 a0 = chain(buf, 0);
-            epilogue(a0, t * HB_KT + 4 * h, false);
-            if (t < 8) update_bound();
-            const f32x16 a1 = chain(buf, 1);
-            epilogue(a1, t * HB_KT + 32 + 4 * h, false);
-            update_bound();
-            __syncthreads();
-        };
-        for (int t = 0; t < ntiles; t += 2) {
-            tile(t, 0);
-            if (t + 1 < ntiles) tile(t + 1, 1);
-        }
-    } else {
-        // software pipeline: the matrix chain of the next sub-tile is issued ahead of the epilogue of the current one
-        f32x16 a0 = chain(0, 0);
-        auto tile = [&](int t, int buf) __attribute__((always_inline)) {
-            if (t + 1 < ntiles) stage_tile(t + 1, buf ^ 1);  // last read (second sub-tile of tile t - 1) before the previous barrier
-            const f32x16 a1 = chain(buf, 1);
-            epilogue(a0, t * HB_KT + 4 * h, PIPE == 2);
-            if (t < 8) update_bound();
-            __syncthreads();
-            if (t + 1 < ntiles) a0 = chain(buf ^ 1, 0);
-            epilogue(a1, t * HB_KT + 32 + 4 * h, false);
-            update_bound();
-        };
-        for (int t = 0; t < ntiles; t += 2) {
-            tile(t, 0);
-            if (t + 1 < ntiles) tile(t + 1, 1);
-        }
-    }
-
-    // merge the two half-lanes that share a query (lane, lane^32)
-    {
-        const float co = __shfl_xor(cref, 32, 64), lo = __shfl_xor(l, 32, 64);
-        const float cm = fmaxf(cref, co);
-        const float a = (cref == -INFINITY) ? 0.f : l * exp2f((cref - cm) * LOG2E);
-        const float bb = (co == -INFINITY) ? 0.f : lo * exp2f((co - cm) * LOG2E);
-        l = a + bb;
-        cref = cm;
-        double other[HB_KC];
-#pragma unroll
-        for (int t = 0; t < HB_KC; ++t)
-            other[t] = __hiloint2double(__shfl_xor(__double2hiint(kb.e[t]), 32, 64), __shfl_xor(__double2loint(kb.e[t]), 32, 64));
-#pragma unroll
-        for (int t = 0; t < HB_KC; ++t) add_term(__double2hiint(kb.insert(other[t])));  // dropped from the union
-    }
-    if (h == 0 && qrow < N) {
-        const size_t row = (size_t)b * N + qrow;
-#pragma unroll
-        for (int t = 0; t < HB_KC; ++t) {
-            const int key = __double2hiint(kb.e[t]), r = key & 15;
-            const bool live = key < H2_REMOVED;
-            G.cidx[row * HB_KC + t] = live ? __double2loint(kb.e[t]) + (r & 3) + 8 * (r >> 2) : 0x7fffffff;
-            G.cd2[row * HB_KC + t] = live ? key_d2(key) : INFINITY;
-        }
-        G.lsum[row * 2] = l;
-        G.lsum[row * 2 + 1] = cref;
-    }
 }
 
 // the reference's squared distance: k-ordered fp32 fma chain of (-2 q) . k, then + |q|^2, + |k|^2
@@ -1094,29 +647,6 @@ static int sweep_form() {
     return form;
 }
 
-// pass A for the groups in `a` (lean semantics), second form; knf = key-side norm fragments of either group
-static void launch_sweep2(const HBArgs &a, const char *knf0, const char *knf1, const int *amaxc, int blocks, hipStream_t s) {
-    H2Args b;
-    for (int g = 0; g < 2; ++g) {
-        const HBGroup &G = a.g[g];
-        b.g[g] = H2Group{G.qp, G.kp, g == 0 ? knf0 : knf1, G.nq, G.N, G.M, G.Mpad, G.tiles, G.cidx, G.cd2, G.lsum};
-    }
-    b.amax = amaxc;
-    b.blocks0 = a.blocks0;
-    b.neg_alpha = a.neg_alpha;
-    b.cutw = a.cutw;
-    if (sweep_form() == 1) {
-        ensure_dyn_lds((const void *)softcorr_sweep2_kernel<0>, H2_LDS_BYTES);
-        hipLaunchKernelGGL(softcorr_sweep2_kernel<0>, dim3(blocks), dim3(HB_THREADS), H2_LDS_BYTES, s, b);
-    } else if (sweep_form() == 3) {
-        ensure_dyn_lds((const void *)softcorr_sweep2_kernel<2>, H2_LDS_BYTES);
-        hipLaunchKernelGGL(softcorr_sweep2_kernel<2>, dim3(blocks), dim3(HB_THREADS), H2_LDS_BYTES, s, b);
-    } else {
-        ensure_dyn_lds((const void *)softcorr_sweep2_kernel<1>, H2_LDS_BYTES);
-        hipLaunchKernelGGL(softcorr_sweep2_kernel<1>, dim3(blocks), dim3(HB_THREADS), H2_LDS_BYTES, s, b);
-    }
-}
-
 // workspace of the fp16 path for (B, N, M): planes of both sides, candidates of both directions, flags
 size_t softcorr_f16_ws_bytes(int B, int N, int M, bool both) {
     const size_t Np = (size_t)(N + HB_KT - 1) / HB_KT * HB_KT, Mp = (size_t)(M + HB_KT - 1) / HB_KT * HB_KT;
@@ -1174,8 +704,8 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
     const bool lean = -neg_alpha >= 32.f;
     const bool form2 = lean && sweep_form() != 0;
     if (form2) {
-        hipLaunchKernelGGL(norm_frags_kernel, dim3((Mp + 255) / 256, B), dim3(256), 0, s, n2, M, Mp, amax, nf2);
-        if (both) hipLaunchKernelGGL(norm_frags_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, s, n1, N, Np, amax, nf1);
+        launch_norm_frags(n2, B, M, Mp, amax, nf2, s);
+        if (both) launch_norm_frags(n1, B, N, Np, amax, nf1, s);
     } else {
         hipLaunchKernelGGL(pad_norms_kernel, dim3((Mp + 255) / 256, B), dim3(256), 0, s, n2, M, Mp, n2p);
         if (both) hipLaunchKernelGGL(pad_norms_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, s, n1, N, Np, n1p);
@@ -1190,7 +720,7 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
     const int blocks = a.blocks0 + (both ? B * a.g[1].tiles : 0);
     prof_begin(s);
     if (form2) {
-        launch_sweep2(a, nf2, nf1, amax, blocks, s);
+        launch_sweep2(a, nf2, nf1, amax, blocks, sweep_form(), s);
     } else if (lean) {
         ensure_dyn_lds((const void *)softcorr_sweep_f16_kernel<true>, (int)HB_LDS_BYTES);
         hipLaunchKernelGGL(softcorr_sweep_f16_kernel<true>, dim3(blocks), dim3(HB_THREADS), HB_LDS_BYTES, s, a);
@@ -1265,8 +795,8 @@ int launch_argmin_f16(const float *f1, const float *f2, int B, int N, int M, int
     for (int d = 0; d < (both ? 2 : 1); ++d) (void)hipMemsetAsync(flag[d], 0, sizeof(int32_t), s);
     const bool form2 = sweep_form() != 0;
     if (form2) {
-        hipLaunchKernelGGL(norm_frags_kernel, dim3((Mp + 255) / 256, B), dim3(256), 0, s, n2, M, Mp, amax, nf2);
-        if (both) hipLaunchKernelGGL(norm_frags_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, s, n1, N, Np, amax, nf1);
+        launch_norm_frags(n2, B, M, Mp, amax, nf2, s);
+        if (both) launch_norm_frags(n1, B, N, Np, amax, nf1, s);
     } else {
         hipLaunchKernelGGL(pad_norms_kernel, dim3((Mp + 255) / 256, B), dim3(256), 0, s, n2, M, Mp, n2p);
         if (both) hipLaunchKernelGGL(pad_norms_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, s, n1, N, Np, n1p);
@@ -1279,7 +809,7 @@ int launch_argmin_f16(const float *f1, const float *f2, int B, int N, int M, int
     a.cutw = 0.f;
     const int blocks = a.blocks0 + (both ? B * a.g[1].tiles : 0);
     if (form2) {
-        launch_sweep2(a, nf2, nf1, amax, blocks, s);
+        launch_sweep2(a, nf2, nf1, amax, blocks, sweep_form(), s);
     } else {
         ensure_dyn_lds((const void *)softcorr_sweep_f16_kernel<true>, (int)HB_LDS_BYTES);
         hipLaunchKernelGGL(softcorr_sweep_f16_kernel<true>, dim3(blocks), dim3(HB_THREADS), HB_LDS_BYTES, s, a);
