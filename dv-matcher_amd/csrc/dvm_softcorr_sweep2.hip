@@ -48,6 +48,7 @@ struct H2Args {
     const int *amax;          // bit pattern of max |x| over BOTH sides (the common scale)
     int blocks0;
     float neg_alpha, cutw;
+    unsigned long long *stamps;   // diagnostic build only (DVM_K1_STAMPS): [block][wave][8] cycle totals per phase
 };
 
 // three-input integer min / max / median, written so that instruction selection forms v_min3_i32 / v_max3_i32 / v_med3_i32
@@ -108,9 +109,29 @@ __device__ __forceinline__ Top3 top3_of_16(const int (&v)[16]) {
     return Top3{min(t.s0, x), imed3(t.s0, t.s1, x), imed3(t.s1, t.s2, x)};
 }
 
-template <int PIPE>
+// STAMP: diagnostic build — every wave adds up the shader cycles (s_memtime) it spends per phase and writes the totals to
+// args.stamps; no output value depends on them.  Phases: 0 LDS-DMA issue, 1 matrix chain (fragment reads, waits, 25 matrix
+// instructions, until the accumulator is readable), 2 straight-line epilogue, 3 slow path, 4 bound update, 5 barrier
+// (incl. the wait for the wave's own DMA pieces), 6 whole sweep, 7 sub-tiles.
+template <int PIPE, bool STAMP = false>
 __global__ __launch_bounds__(HB_THREADS) void softcorr_sweep2_kernel(const H2Args args) {
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
+    unsigned long long T[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0, tstart = 0;
+    if (STAMP) tstart = tlast = __builtin_amdgcn_s_memtime();
+    auto stamp = [&](int slot) __attribute__((always_inline)) {
+        if (STAMP) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            T[slot] += now - tlast;
+            tlast = now;
+        }
+    };
+    auto stamp_after = [&](int slot, int vgpr_value) __attribute__((always_inline)) {   // after `vgpr_value` has been produced
+        if (STAMP) {
+            const int x = __builtin_amdgcn_readfirstlane(vgpr_value);
+            asm volatile("" ::"s"(x));
+            stamp(slot);
+        }
+    };
     char *const ktile0 = smem_b;                                         // [2][HB_KT][512], 16-B chunks XOR-swizzled
     char *const knf0 = smem_b + (size_t)2 * HB_KT * HB_ROWB;             // [2][HB_KT][32]
 
@@ -268,6 +289,7 @@ __global__ __launch_bounds__(HB_THREADS) void softcorr_sweep2_kernel(const H2Arg
         const int k0 = __double2hiint(kb.insert(__hiloint2double(w.s0, jb)));
         const int k1 = __double2hiint(kb.insert(__hiloint2double(w.s1, jb)));
         if (paced) pace();
+        stamp_after(2, k0 ^ k1 ^ __double2hiint(kb.e[0]));
         bool more = w.s2 <= lim && w.s2 < H2_REMOVED;
         if (__builtin_amdgcn_ballot_w64(more || min(k0, k1) <= cut_i) != 0) {
             terms2(k0, k1);
@@ -281,6 +303,7 @@ __global__ __launch_bounds__(HB_THREADS) void softcorr_sweep2_kernel(const H2Arg
                 more = w.s2 <= lim && w.s2 < H2_REMOVED;
             }
         }
+        stamp_after(3, __double2hiint(kb.e[0]));
     };
     // bound for the following sub-tiles: the row's KC-th best is at most min(a_K, b_K, max(a_m, b_m)), m = KC/2, over the two
     // half-lanes (a, b) that share the row; everything within the cut is processed as well (it owes a softmax term).  Any
@@ -299,6 +322,7 @@ __global__ __launch_bounds__(HB_THREADS) void softcorr_sweep2_kernel(const H2Arg
         const float ck = fmaf((cut * cut) * 1.000001f, icf, bias);
         cut_i = ck < INFINITY ? __float_as_int(ck) + 32 : 0x7fffffff;   // (+32: the embedded register number, rounding of ck)
         lim = max(thr, cut_i);
+        stamp_after(4, lim);
     };
 
     stage_tile(0, 0);
@@ -306,13 +330,18 @@ __global__ __launch_bounds__(HB_THREADS) void softcorr_sweep2_kernel(const H2Arg
     if (PIPE == 0) {
         auto tile = [&](int t, int buf) __attribute__((always_inline)) {
             if (t + 1 < ntiles) stage_tile(t + 1, buf ^ 1);  // the other buffer was last read before the previous barrier
+            stamp(0);
             const f32x16 a0 = chain(buf, 0);
+            stamp_after(1, __float_as_int(a0[0]));
             epilogue(a0, t * HB_KT + 4 * h, false);
             if (t < 8) update_bound();
             const f32x16 a1 = chain(buf, 1);
+            stamp_after(1, __float_as_int(a1[0]));
             epilogue(a1, t * HB_KT + 32 + 4 * h, false);
             update_bound();
             __syncthreads();
+            stamp(5);
+            T[7] += 2;
         };
         for (int t = 0; t < ntiles; t += 2) {
             tile(t, 0);
@@ -323,13 +352,16 @@ __global__ __launch_bounds__(HB_THREADS) void softcorr_sweep2_kernel(const H2Arg
         f32x16 a0 = chain(0, 0);
         auto tile = [&](int t, int buf, bool last) __attribute__((always_inline)) {   // buf, last: literals after inlining
             if (!last) stage_tile(t + 1, buf ^ 1);  // last read (second sub-tile of tile t - 1) before the previous barrier
+            stamp(0);
             const f32x16 a1 = chain(buf, 1);
             epilogue(a0, t * HB_KT + 4 * h, PIPE == 2);
             if (t < 8) update_bound();
             __syncthreads();
+            stamp(5);
             if (!last) a0 = chain(buf ^ 1, 0);
             epilogue(a1, t * HB_KT + 32 + 4 * h, PIPE == 2 && !last);
             update_bound();
+            T[7] += 2;
         };
         // (the last tile is peeled off so that inside the loop the next chain is unconditional: a branch between it and
         // the epilogue would put them into different scheduling regions)
@@ -373,6 +405,11 @@ __global__ __launch_bounds__(HB_THREADS) void softcorr_sweep2_kernel(const H2Arg
         G.lsum[row * 2] = l;
         G.lsum[row * 2 + 1] = cref;
     }
+    if (STAMP) {
+        T[6] = __builtin_amdgcn_s_memtime() - tstart;
+        if (lane == 0 && args.stamps)
+            for (int i = 0; i < 8; ++i) args.stamps[((size_t)blockIdx.x * HB_WAVES + wave) * 8 + i] = T[i];
+    }
 }
 
 }  // namespace
@@ -392,15 +429,43 @@ void launch_sweep2(const HBArgs &a, const char *knf0, const char *knf1, const in
     b.blocks0 = a.blocks0;
     b.neg_alpha = a.neg_alpha;
     b.cutw = a.cutw;
+    b.stamps = nullptr;
+    static const bool stamps_on = getenv("DVM_K1_STAMPS") != nullptr;
+    if (stamps_on) {   // diagnostic: synchronous, allocates — never taken in production
+        unsigned long long *dbuf = nullptr;
+        const size_t n = (size_t)blocks * HB_WAVES * 8;
+        if (hipMalloc(&dbuf, n * sizeof(unsigned long long)) != hipSuccess) return;
+        b.stamps = dbuf;
+        if (form == 1) {
+            ensure_dyn_lds((const void *)softcorr_sweep2_kernel<0, true>, H2_LDS_BYTES);
+            hipLaunchKernelGGL((softcorr_sweep2_kernel<0, true>), dim3(blocks), dim3(HB_THREADS), H2_LDS_BYTES, s, b);
+        } else {
+            ensure_dyn_lds((const void *)softcorr_sweep2_kernel<1, true>, H2_LDS_BYTES);
+            hipLaunchKernelGGL((softcorr_sweep2_kernel<1, true>), dim3(blocks), dim3(HB_THREADS), H2_LDS_BYTES, s, b);
+        }
+        (void)hipStreamSynchronize(s);
+        unsigned long long *hbuf = (unsigned long long *)malloc(n * sizeof(unsigned long long));
+        (void)hipMemcpy(hbuf, dbuf, n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        double tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (size_t w = 0; w < (size_t)blocks * HB_WAVES; ++w)
+            for (int i = 0; i < 8; ++i) tot[i] += (double)hbuf[w * 8 + i];
+        const double nw = (double)blocks * HB_WAVES, st = tot[7] / nw;
+        fprintf(stderr, "K1 stamps (form %d, %d blocks): per wave and sub-tile, cycles: dma %.0f  chain %.0f  epilogue %.0f  slow %.0f  bound %.0f  "
+                        "barrier %.0f  | whole sweep %.0f per sub-tile (%.0f sub-tiles per wave)\n", form, blocks, tot[0] / nw / st, tot[1] / nw / st,
+                tot[2] / nw / st, tot[3] / nw / st, tot[4] / nw / st, tot[5] / nw / st, tot[6] / nw / st, st);
+        free(hbuf);
+        (void)hipFree(dbuf);
+        return;
+    }
     if (form == 1) {
         ensure_dyn_lds((const void *)softcorr_sweep2_kernel<0>, H2_LDS_BYTES);
-        hipLaunchKernelGGL(softcorr_sweep2_kernel<0>, dim3(blocks), dim3(HB_THREADS), H2_LDS_BYTES, s, b);
+        hipLaunchKernelGGL((softcorr_sweep2_kernel<0>), dim3(blocks), dim3(HB_THREADS), H2_LDS_BYTES, s, b);
     } else if (form == 3) {
         ensure_dyn_lds((const void *)softcorr_sweep2_kernel<2>, H2_LDS_BYTES);
-        hipLaunchKernelGGL(softcorr_sweep2_kernel<2>, dim3(blocks), dim3(HB_THREADS), H2_LDS_BYTES, s, b);
+        hipLaunchKernelGGL((softcorr_sweep2_kernel<2>), dim3(blocks), dim3(HB_THREADS), H2_LDS_BYTES, s, b);
     } else {
         ensure_dyn_lds((const void *)softcorr_sweep2_kernel<1>, H2_LDS_BYTES);
-        hipLaunchKernelGGL(softcorr_sweep2_kernel<1>, dim3(blocks), dim3(HB_THREADS), H2_LDS_BYTES, s, b);
+        hipLaunchKernelGGL((softcorr_sweep2_kernel<1>), dim3(blocks), dim3(HB_THREADS), H2_LDS_BYTES, s, b);
     }
 }
 

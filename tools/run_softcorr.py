@@ -30,6 +30,7 @@ if variant == 3:
     off = al(R * 4) + al(B * M * 4) + al(514 * 4)                 # n1, n2, absmax slots + amax
     off += al(R * 512) + al(B * M * 512) + 2 * al(B * 4) + al(8)   # planes, nmax, amax_own
     off += al(B * 2048 * 4) * 2                                    # padded norms
+    off += al(B * 2048 * 32) * 2                                   # norm fragments (second sweep form)
     off += al(R * 12 * 4) * 2 + al(R * 2 * 4)                      # cidx, cd2, lsum
     ws = ops._ws_cache[(f1.device, "softcorr")]
     print("  flagged rows:", int(ws[off:off + 4].view(torch.int32).item()), "of", R)
