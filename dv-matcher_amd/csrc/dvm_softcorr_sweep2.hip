@@ -1,7 +1,7 @@
 // dvm_softcorr_sweep2.hip — pass A of the soft-correspondence kernel (K1), second form.
-// Built with -fno-honor-nans (Makefile): no NaN is ever formed here (keys are bit patterns compared as ints or as the high
-// words of finite doubles; +inf only passes through additions and one multiplication by a positive constant), and it lets
-// fmin / fmax on the packed (key, column) doubles lower to bare v_min_f64 / v_max_f64 that the scheduler can place.
+// Built with -fno-honor-nans (Makefile): no NaN is ever formed here (keys are unsigned bit patterns, list entries finite
+// positive doubles), and it lets fmin / fmax on the packed (key, column) doubles lower to bare v_min_f64 / v_max_f64 that
+// the instruction scheduler can place (an asm statement is opaque to it).
 // (reference: models/loss.py:110-114, 1339-1347, 1404-1407)
 #include <stdlib.h>
 
@@ -12,28 +12,35 @@ namespace dvm {
 namespace k1 {
 namespace {
 
-// ---------------------------------------------------------------- pass A, second form: no per-entry work
-// What the first form spends its time on is not the matrix work (24 matrix instructions per 32 x 32 sub-tile) but the ~300
-// vector instructions behind it: per entry {fma, add, compare, mask, LDS staging} and a wave-level insertion loop that
-// runs max-over-lanes(#flagged) times for a handful of active lanes.  This form removes the per-entry arithmetic and the
-// data-dependent loop from the common path:
-//  * the norms ride on the matrix pipe: one more matrix instruction per sub-tile whose 16 k-slots carry |k|^2 and |q|^2,
-//    each as three exact fp16 pieces times power-of-two constants, so that the accumulator IS the (scaled, non-negative)
-//    squared distance  acc = (|q|^2 (1 + 2^-13) + |k|^2 - 2 q.k) s^2 / 2  (one scale s for both sides; the row-constant bias
-//    keeps every accumulator >= 0, so keys order identically as floats, as ints and as the high words of doubles);
-//  * a lane's 16 entries go through a fixed selection network on their bit patterns (the register number embedded in the
-//    low 4 mantissa bits: keys are unique, the column is recovered from the key): sorted three smallest in 46 three-input
-//    integer min / med / max instructions, no comparison against a threshold per entry;
-//  * the two smallest are inserted into the sorted list of 12 unconditionally (the packed (key, column) doubles of the
-//    first form); the third only decides whether the lane may hold MORE than two entries below its threshold, in which case
-//    the wave repeats the selection on the remaining entries (a few percent of the sub-tiles once the lists have filled).
-// Everything in the common path is straight-line register code, which the compiler can place between the matrix
-// instructions of the NEXT sub-tile (PIPE): the chain of sub-tile i+1 is issued before the epilogue of sub-tile i.
+// ---------------------------------------------------------------- pass A, second form
+// Measured on the first form (s_memtime stamps per phase, profiles/r3_k1_stamps.txt): of a wave's ~4 700 cycles per
+// 32 x 32 sub-tile only ~800 are the 24 matrix instructions; the rest is the per-entry arithmetic, a wave-level insertion
+// loop that runs max-over-lanes(#flagged) times for a handful of active lanes, the barrier at which the 8 waves of the
+// workgroup wait for the one with the most trips, and the issue of the LDS-DMA pieces.  This form:
+//  * norms on the matrix pipe: one more matrix instruction per sub-tile whose 16 k-slots carry |k|^2 and |q|^2, each as
+//    three exact fp16 pieces times power-of-two constants, so that the accumulator IS the scaled squared distance plus
+//    row constants,  acc = (|q|^2 (1 + 2^-13) + |k|^2 - 2 q.k) s^2 / 2 + 4.5  (one scale s for both sides).  The row bias
+//    keeps acc >= 4 whatever the rounding, and s is such that acc < 2^33: every accumulator lies in the 30 binades above 4;
+//  * exact keys: key = ((bits(acc) - bits(4.0f)) << 4) + r — the float's 5 significant exponent bits, its whole mantissa and
+//    the accumulator register number r in 32 bits, ONE v_lshl_add_u32 per entry; keys are unique, order like the
+//    accumulators, and give the accumulator back bit for bit (nothing of the approximate distance is lost);
+//  * a fixed selection network per lane: sorted three smallest of its 16 keys in 46 three-input unsigned min / med / max
+//    instructions — no comparison against a threshold per entry, no mask, no LDS staging;
+//  * the two smallest are inserted into the sorted list of 12 unconditionally (packed (key, column) doubles as in the first
+//    form); the THIRD is only recorded (16 bits, rounded down, one LDS slot per lane and sub-tile);
+//  * no data-dependent loop in the sweep: after the last tile, a sub-tile is RE-DONE (fragments straight from global
+//    memory, the same matrix chain, then a loop over the entries at or below the bound) only if some lane's recorded third
+//    key lies at or below that lane's FINAL bound — 1-2 % of the sub-tiles on unstructured data, because the final bound is
+//    the tightest one.  Every wave of a workgroup does the same work per tile: nothing waits at the barrier for a straggler.
 // Same outputs as the first form (candidate columns, approximate squared distances, partial softmax sums), same
-// guarantees: a column that belongs to a row's 12 smallest is never lost (every entry at or below the row's running bound
-// is inserted), the softmax sum covers every column outside the final list that lies within the cut.
-constexpr int H2_LDS_BYTES = 2 * HB_KT * HB_ROWB + 2 * HB_KT * 32;   // key tiles + norm fragments (32 B per key)
-constexpr int H2_REMOVED = 0x7f800000;                               // bit pattern of +inf: larger than every finite key
+// guarantees: a column that belongs to a row's 12 smallest is never lost (an entry at or below the row's final bound is one
+// of the two smallest of its sub-tile, or its sub-tile is re-done), the softmax sum covers every column outside the final
+// list that lies within the cut (the cut never exceeds the bound).
+constexpr int H2_NREC = 64;                                          // third-key records per lane
+constexpr int H2_LDS_BYTES = 2 * HB_KT * HB_ROWB + 2 * HB_KT * 32 + HB_THREADS * H2_NREC * 2;   // key tiles + norm fragments + records
+constexpr unsigned H2_REMOVED = 0xffc00000u;   // keys >= this: removed / invalid (as a list entry: hi word 0x7fe00000, a finite double)
+constexpr unsigned H2_KBASE = 129u << 23;      // bits(4.0f): bottom of the key window
+constexpr float H2_FLOOR = 4.5f;               // added to every accumulator through the norm instruction
 
 struct H2Group {
     const char *qp, *kp;      // planes of the query / key side [B][rows][512]
@@ -51,13 +58,11 @@ struct H2Args {
     unsigned long long *stamps;   // diagnostic build only (DVM_K1_STAMPS): [block][wave][8] cycle totals per phase
 };
 
-// three-input integer min / max / median, written so that instruction selection forms v_min3_i32 / v_max3_i32 / v_med3_i32
-// (plain expressions, not asm statements: the instruction scheduler has to see them as vector instructions)
-__device__ __forceinline__ int imin3(int a, int b, int c) { return min(min(a, b), c); }
-__device__ __forceinline__ int imax3(int a, int b, int c) { return max(max(a, b), c); }
-__device__ __forceinline__ int imed3(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }
-// the accumulator's bit pattern with the register number r in its low 4 bits: (x & ~15) | r, one v_and_or_b32
-__device__ __forceinline__ int embed4(float x, int r) { return (__float_as_int(x) & ~15) | r; }
+// three-input unsigned min / max / median, written so that instruction selection forms v_min3_u32 / v_max3_u32 /
+// v_med3_u32 (plain expressions, not asm statements: the instruction scheduler has to see them as vector instructions)
+__device__ __forceinline__ unsigned umin3(unsigned a, unsigned b, unsigned c) { return min(min(a, b), c); }
+__device__ __forceinline__ unsigned umax3(unsigned a, unsigned b, unsigned c) { return max(max(a, b), c); }
+__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) { return max(min(a, b), min(max(a, b), c)); }
 
 // three fp16 pieces of a non-negative fp32 value x < 2^31:  x = p1 2^15 + p2 2^4 + p3 2^-7  (exact: 33 >= 24 bits)
 __device__ __forceinline__ void norm_pieces(float x, _Float16 &p1, _Float16 &p2, _Float16 &p3) {
@@ -70,7 +75,8 @@ __device__ __forceinline__ void norm_pieces(float x, _Float16 &p1, _Float16 &p2,
 // |x|^2 in accumulator units: n s^2 / 2, formed as (n s) (s / 2) so that no intermediate leaves the fp32 range
 __device__ __forceinline__ float norm_scaled(float n, int se) { return (n * pow2i(se)) * pow2i(se - 1); }
 
-// key-side norm fragments, padded to whole key tiles with +inf: out [B][Mpad][16 fp16]
+// key-side norm fragments, padded to whole key tiles (padding keys: zero norm; their entries are masked by column in the
+// sweep): out [B][Mpad][16 fp16]
 __global__ void norm_frags_kernel(const float *__restrict__ nrm, int M, int Mpad, const int *__restrict__ amax, char *__restrict__ out) {
     const int b = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -81,38 +87,42 @@ __global__ void norm_frags_kernel(const float *__restrict__ nrm, int M, int Mpad
         _Float16 p1, p2, p3;
         norm_pieces(norm_scaled(nrm[(size_t)b * M + i], scale_exp(*amax)), p1, p2, p3);
         lo[0] = p1, lo[1] = p2, lo[2] = p3;
-    } else {
-        lo[0] = (_Float16)INFINITY;
     }
     char *p = out + ((size_t)b * Mpad + i) * 32;
     *(f16x8 *)p = lo;
     *(f16x8 *)(p + 16) = hi;
 }
 
-// sorted (s0 <= s1 <= s2) three smallest of 16 distinct ints
+// sorted (s0 <= s1 <= s2) three smallest of 16 distinct keys
 struct Top3 {
-    int s0, s1, s2;
+    unsigned s0, s1, s2;
 };
-__device__ __forceinline__ Top3 sort3(int a, int b, int c) { return Top3{imin3(a, b, c), imed3(a, b, c), imax3(a, b, c)}; }
+__device__ __forceinline__ Top3 sort3(unsigned a, unsigned b, unsigned c) { return Top3{umin3(a, b, c), umed3(a, b, c), umax3(a, b, c)}; }
 __device__ __forceinline__ Top3 merge3(const Top3 &a, const Top3 &b) {
     Top3 c;
-    const int m00 = max(a.s0, b.s0);
+    const unsigned m00 = max(a.s0, b.s0);
     c.s0 = min(a.s0, b.s0);
-    c.s1 = imin3(m00, a.s1, b.s1);
-    c.s2 = min(imin3(a.s2, b.s2, max(a.s1, b.s0)), max(a.s0, b.s1));
+    c.s1 = umin3(m00, a.s1, b.s1);
+    c.s2 = min(umin3(a.s2, b.s2, max(a.s1, b.s0)), max(a.s0, b.s1));
     return c;
 }
-__device__ __forceinline__ Top3 top3_of_16(const int (&v)[16]) {
+__device__ __forceinline__ Top3 top3_of_16(const unsigned (&v)[16]) {
     Top3 t = merge3(merge3(sort3(v[0], v[1], v[2]), sort3(v[3], v[4], v[5])),
                     merge3(merge3(sort3(v[6], v[7], v[8]), sort3(v[9], v[10], v[11])), sort3(v[12], v[13], v[14])));
-    const int x = v[15];
-    return Top3{min(t.s0, x), imed3(t.s0, t.s1, x), imed3(t.s1, t.s2, x)};
+    const unsigned x = v[15];
+    return Top3{min(t.s0, x), umed3(t.s0, t.s1, x), umed3(t.s1, t.s2, x)};
 }
+
+// list entry of a key and its sub-tile's base column: hi = key >> 1, lo = (key's low bit << 31) | jb — a positive finite
+// double whose order is (key, jb)
+__device__ __forceinline__ double pack_entry(unsigned key, int jb) { return __hiloint2double((int)(key >> 1), (int)((key << 31) | (unsigned)jb)); }
+__device__ __forceinline__ unsigned entry_key(double e) { return ((unsigned)__double2hiint(e) << 1) | ((unsigned)__double2loint(e) >> 31); }
+__device__ __forceinline__ int entry_jb(double e) { return __double2loint(e) & 0x7fffffff; }
 
 // STAMP: diagnostic build — every wave adds up the shader cycles (s_memtime) it spends per phase and writes the totals to
 // args.stamps; no output value depends on them.  Phases: 0 LDS-DMA issue, 1 matrix chain (fragment reads, waits, 25 matrix
-// instructions, until the accumulator is readable), 2 straight-line epilogue, 3 slow path, 4 bound update, 5 barrier
-// (incl. the wait for the wave's own DMA pieces), 6 whole sweep, 7 sub-tiles.
+// instructions, until the accumulator is readable), 2 epilogue (selection + insertions), 3 softmax terms + re-done
+// sub-tiles, 4 bound update, 5 barrier (incl. the wait for the wave's own DMA pieces), 6 whole sweep, 7 sub-tiles.
 template <int PIPE, bool STAMP = false>
 __global__ __launch_bounds__(HB_THREADS) void softcorr_sweep2_kernel(const H2Args args) {
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
@@ -134,6 +144,7 @@ __global__ __launch_bounds__(HB_THREADS) void softcorr_sweep2_kernel(const H2Arg
     };
     char *const ktile0 = smem_b;                                         // [2][HB_KT][512], 16-B chunks XOR-swizzled
     char *const knf0 = smem_b + (size_t)2 * HB_KT * HB_ROWB;             // [2][HB_KT][32]
+    unsigned short *const rec0 = (unsigned short *)(knf0 + 2 * HB_KT * 32);   // [wave][H2_NREC][64 lanes]
 
     int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int grp = lid >= args.blocks0 ? 1 : 0;
@@ -142,7 +153,7 @@ __global__ __launch_bounds__(HB_THREADS) void softcorr_sweep2_kernel(const H2Arg
     const int N = G.N, M = G.M;
     const int b = lid / G.tiles, qt = lid % G.tiles;
     const float neg_alpha = args.neg_alpha;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave: a scalar register)
     const int r32 = lane & 31, h = lane >> 5;
 
     const char *kbase = G.kp + (size_t)b * M * HB_ROWB;
@@ -159,11 +170,11 @@ __global__ __launch_bounds__(HB_THREADS) void softcorr_sweep2_kernel(const H2Arg
     const int se = scale_exp(*args.amax);
     const float cf = pow2i(1 - 2 * se);             // 2 / s^2: accumulator units -> squared distance
     const float icf = pow2i(2 * se - 1);
-    // the query's norm, biased by 2^-13 of itself (accumulators stay >= 0 whatever the rounding: a negative value needs
-    // |q| ~ |k|, where the bias is twice the error bound), as the B operand of the norm instruction
+    // the query's norm, biased by 2^-13 of itself (a rounding error can only pull an accumulator below its row constants
+    // where |q| ~ |k|, and there the bias is twice the error bound), plus the floor: the B operand of the norm instruction
     const float nas = norm_scaled(G.nq[(size_t)b * N + qrc], se);
-    const float nasb = nas + nas * 0x1p-13f;
-    const float bias = nasb - nas;                  // exact
+    const float nasb = (nas + nas * 0x1p-13f) + H2_FLOOR;
+    const float rowc = nasb - nas;                  // what a key's accumulator carries on top of the scaled squared distance (exact)
     f16x8 qn = {0, 0, 0, 0, 0, 0, 0, 0};
     if (h == 0) {
         _Float16 p1, p2, p3;
@@ -172,32 +183,52 @@ __global__ __launch_bounds__(HB_THREADS) void softcorr_sweep2_kernel(const H2Arg
         qn[3] = p1, qn[4] = p2, qn[5] = p3;
     }
 
-    PackedBest<HB_KC> kb;  // (key bits, sub-tile base column): the key's low 4 bits name the accumulator register
-    kb.init();
+    PackedBest<HB_KC> kb;
+#pragma unroll
+    for (int t = 0; t < HB_KC; ++t) kb.e[t] = __hiloint2double((int)(H2_REMOVED >> 1), 0x7fffffff);
     float cref = -INFINITY, l = 0.f;
-    int lim = 0x7fffffff, cut_i = 0x7fffffff;
+    unsigned lim = 0xffffffffu, cut_k = 0xffffffffu;   // bound / cut in key space
     const float cutw = args.cutw;
 
-    const int ntiles = (M + HB_KT - 1) / HB_KT;
-    auto stage_tile = [&](int t, int buf) __attribute__((always_inline)) {
+    const int ntiles = (M + HB_KT - 1) / HB_KT, nsub = 2 * ntiles;
+    const int rgrp = (nsub + H2_NREC - 1) / H2_NREC;    // sub-tiles per record (1 up to M = 2048)
+    unsigned short *const rec = rec0 + (size_t)wave * H2_NREC * 64 + lane;
+    unsigned urec = 0xffffffffu;                        // smallest third key of the current record's sub-tiles
+
+    // Key tiles go global -> LDS by LDS-DMA (1 KiB = 2 rows per wave instruction, 4 per wave and tile).  The source address is
+    // a wave-uniform tile base (scalar registers) plus a per-lane byte offset that does not change from tile to tile — row
+    // r = 2 piece + h of the tile, 16-B chunk r32 ^ (r & 15): chunk c of an LDS row holds chunk c ^ (row & 15) of the key — so
+    // staging a tile costs no vector arithmetic.  Only a ragged last tile clamps its rows (padding keys re-read the last row;
+    // their entries are masked by column).
+    // (The per-lane offsets are re-formed for every tile from the lane number, itself re-read from the execution mask
+    // (v_mbcnt): a handful of vector instructions per piece.  Anything kept in a vector register across the tile for this is
+    // spilled — the register file is full of fragments and lists — and a scratch reload next to the DMA issue waits,
+    // through vmcnt, for every DMA piece still in flight: measured 1 300 - 2 100 cycles per sub-tile.)
+    auto stage_tile = [&](int t, int buf, bool clamp) __attribute__((always_inline)) {
+        int lane;   // (a volatile statement: otherwise the offsets are hoisted out of the loop as invariants — and spilled)
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+        const int r32 = lane & 31, h = lane >> 5;
+        const unsigned nfoff = wave * 1024 + lane * 16;
         const int j0 = t * HB_KT;
+        const char *tb = kbase + (size_t)j0 * HB_ROWB;   // wave-uniform
         char *kt = ktile0 + (size_t)buf * HB_KT * HB_ROWB;
 #pragma unroll
         for (int e = 0; e < HB_GLDS_PER_WAVE; ++e) {
-            const int piece = wave * HB_GLDS_PER_WAVE + e;       // 2 rows
-            const int r = 2 * piece + h;
-            const int jr = j0 + r < M ? j0 + r : M - 1;           // padding keys re-read the last row (their norm is +inf)
-            const char *src = kbase + (size_t)jr * HB_ROWB + ((r32 ^ (r & 15)) << 4);   // 16-B chunk c of the LDS row holds chunk c ^ (row & 15)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+            const int piece = wave * HB_GLDS_PER_WAVE + e;
+            const int r = 2 * piece + h, rc = (!clamp || j0 + r < M) ? r : M - 1 - j0;
+            const unsigned off = rc * HB_ROWB + ((r32 ^ (r & 15)) << 4);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tb + off),
                                              (__attribute__((address_space(3))) void *)(kt + piece * 1024), 16, 0, 0);
         }
         if (wave < 2)   // 64 keys x 32 B of norm fragments = two 1-KiB pieces
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(nfbase + (size_t)j0 * 32 + wave * 1024 + lane * 16),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(nfbase + (size_t)j0 * 32 + nfoff),
                                              (__attribute__((address_space(3))) void *)(knf0 + buf * HB_KT * 32 + wave * 1024), 16, 0, 0);
     };
 
-    auto key_d2 = [&](int key) __attribute__((always_inline)) { return fmaxf(__int_as_float(key) - bias, 0.f) * cf; };   // key -> squared distance
-    auto add_term = [&](int key) __attribute__((always_inline)) {  // l += exp(s - cref) for a finite key (otherwise nothing)
+    auto key_d2 = [&](unsigned key) __attribute__((always_inline)) {   // key -> squared distance
+        return fmaxf(__uint_as_float((key >> 4) + H2_KBASE) - rowc, 0.f) * cf;
+    };
+    auto add_term = [&](unsigned key) __attribute__((always_inline)) {  // l += exp(s - cref) for a live key (otherwise nothing)
         const bool live = key < H2_REMOVED;
         const float s = __builtin_amdgcn_sqrtf(key_d2(key)) * neg_alpha;
         const float cnew = live ? fmaxf(cref, s) : cref;
@@ -229,115 +260,129 @@ __global__ __launch_bounds__(HB_THREADS) void softcorr_sweep2_kernel(const H2Arg
     auto chain = [&](int buf, int sub) __attribute__((always_inline)) -> f32x16 {   // buf, sub: literals after inlining
         const int toff = buf * (HB_KT * HB_ROWB) + sub * (32 * HB_ROWB);
         f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // Fragments in four batches of 2 k-steps (16 VGPRs each), two batches in flight: the scheduler, left alone, requests
+        // all 17 reads of a sub-tile at once (68 VGPRs) next to the previous sub-tile's epilogue — and what does not fit is
+        // spilled.  The barriers below let vector, scalar and matrix instructions cross, LDS reads not.
+        f16x8 ah[4][2], am[4][2];
+        auto reads = [&](int q) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                ah[q][u] = lds16(fadr[2 * q + u], toff);
+                am[q][u] = lds16(fadr[2 * q + u], toff + 256);
+            }
+        };
+        auto products = [&](int q) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int s = 2 * q + u;
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(am[q][u], qh[s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q][u], qm[s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q][u], qh[s], acc, 0, 0, 0);
+            }
+        };
+        reads(0);
+        reads(1);
         const f16x8 an = lds16(nadr, buf * (HB_KT * 32) + sub * (32 * 32));
-        // fragments in two batches of 4 k-steps (32 VGPRs each): the 16 of a whole sub-tile at once do not fit next to the
-        // previous sub-tile's epilogue
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            f16x8 ah[4], am[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                ah[u] = lds16(fadr[4 * half + u], toff);
-                am[u] = lds16(fadr[4 * half + u], toff + 256);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int s = 4 * half + u;
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(am[u], qh[s], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[u], qm[s], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[u], qh[s], acc, 0, 0, 0);
-            }
-        }
+        __builtin_amdgcn_sched_barrier(0x00E);
+        products(0);
+        reads(2);
+        __builtin_amdgcn_sched_barrier(0x00E);
+        products(1);
+        reads(3);
+        __builtin_amdgcn_sched_barrier(0x00E);
+        products(2);
+        products(3);
         // the norms last: every partial sum before it has the magnitude of q.k
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(an, qn, acc, 0, 0, 0);
     };
 
-    // the two smallest of the lane's 16 keys go into the list; an entry that leaves the list (or fails to enter it) contributes
-    // its softmax term if it lies within the cut: nearly never at the alphas this sweep is used for — the whole wave skips
-    // the exponentials unless one lane needs them
-    auto pace = [&]() __attribute__((always_inline)) {
-        // PIPE == 2: the block that ends here holds the matrix chain of the NEXT sub-tile (25 instructions, 17 LDS reads) and
-        // this sub-tile's selection + insertions (~115 vector instructions): ask the scheduler for one matrix instruction
-        // per five vector instructions, the first batch of fragment reads up front and the second a third of the way in
-        __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+    // keys of the lane's 16 accumulators (register r holds local key (r & 3) + 8 (r >> 2) of the lane's half)
+    auto make_keys = [&](const f32x16 &acc, unsigned (&v)[16], int jb, bool mask_pads) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 25; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (i == 3) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+        for (int r = 0; r < 16; ++r) {
+            v[r] = (__float_as_uint(acc[r]) << 4) + ((unsigned)r - (H2_KBASE << 4));   // one v_lshl_add_u32 (constant in an SGPR)
+            if (mask_pads) v[r] = jb + (r & 3) + 8 * (r >> 2) < M ? v[r] : (H2_REMOVED | r);
         }
     };
     // an entry that leaves the list (or fails to enter it) owes its softmax term if it lies within the cut
-    auto terms2 = [&](int k0, int k1) __attribute__((always_inline)) {
-        if (__builtin_amdgcn_ballot_w64(min(k0, k1) <= cut_i) != 0) {
-            add_term(k0 <= cut_i ? k0 : H2_REMOVED);
-            add_term(k1 <= cut_i ? k1 : H2_REMOVED);
+    auto terms2 = [&](double o0, double o1) __attribute__((always_inline)) {
+        const unsigned k0 = entry_key(o0), k1 = entry_key(o1);
+        if (__builtin_amdgcn_ballot_w64(min(k0, k1) <= cut_k) != 0) {
+            add_term(k0 <= cut_k ? k0 : H2_REMOVED);
+            add_term(k1 <= cut_k ? k1 : H2_REMOVED);
+#pragma unroll
+            for (int t = 0; t < HB_KC; ++t) asm volatile("" : "+v"(kb.e[t]));   // (the list is "used" on this path: see epilogue)
         }
     };
 
-    // One sub-tile's 16 keys per lane.  Straight-line part: register numbers into the keys, sorted three smallest, the two
-    // smallest into the list.  ONE wave-uniform branch behind it covers everything that is rare once the lists have filled:
-    // a third entry at or below the bound in some lane (the wave then takes the next two of every lane, until none is left),
-    // or an entry within the cut that left a list (its softmax term).  The slow path uses the list, so nothing of the
-    // straight-line part can be sunk below the branch, away from the matrix instructions it is meant to run beside.
-    auto epilogue = [&](const f32x16 &acc, int jb, bool paced) __attribute__((always_inline)) {
-        int v[16];
+    // One sub-tile's 16 keys per lane, straight-line: keys, sorted three smallest, the two smallest into the list, the third
+    // into the record.  The one wave-uniform branch behind it (softmax terms of entries within the cut that left a list:
+    // nearly never taken at the alphas this sweep is used for) touches the list, so nothing of the straight-line part
+    // can be sunk below it, away from the matrix instructions it is meant to run beside.
+    auto pace = [&]() __attribute__((always_inline)) {
+        // PIPE == 2: the scheduling region that ends here holds the matrix chain of the NEXT sub-tile (25 instructions, 17 LDS
+        // reads) and this sub-tile's selection + insertions (~125 vector instructions): ask for one matrix instruction per
+        // five vector instructions, the first batch of fragment reads up front and the second a quarter of the way in
+        __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = embed4(acc[r], r);
-        Top3 w = top3_of_16(v);
-        const int k0 = __double2hiint(kb.insert(__hiloint2double(w.s0, jb)));
-        const int k1 = __double2hiint(kb.insert(__hiloint2double(w.s1, jb)));
-        if (paced) pace();
-        stamp_after(2, k0 ^ k1 ^ __double2hiint(kb.e[0]));
-        bool more = w.s2 <= lim && w.s2 < H2_REMOVED;
-        if (__builtin_amdgcn_ballot_w64(more || min(k0, k1) <= cut_i) != 0) {
-            terms2(k0, k1);
-            while (__builtin_amdgcn_ballot_w64(more) != 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = v[r] <= w.s1 ? (H2_REMOVED | r) : v[r];
-                w = top3_of_16(v);
-                const int q0 = __double2hiint(kb.insert(__hiloint2double(w.s0, jb)));
-                const int q1 = __double2hiint(kb.insert(__hiloint2double(w.s1, jb)));
-                terms2(q0, q1);
-                more = w.s2 <= lim && w.s2 < H2_REMOVED;
-            }
+        for (int i = 0; i < 25; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i == 5) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
         }
+    };
+    auto epilogue = [&](const f32x16 &acc, int s, bool mask_pads, bool paced = false) __attribute__((always_inline)) {
+        const int jb = s * 32 + 4 * h;
+        unsigned v[16];
+        make_keys(acc, v, jb, mask_pads);
+        const Top3 w = top3_of_16(v);
+        const double o0 = kb.insert(pack_entry(w.s0, jb));
+        const double o1 = kb.insert(pack_entry(w.s1, jb));
+        // (branch-free: a record is rewritten by every sub-tile of its group with the running minimum — one sub-tile per
+        // record up to M = 2048; a branch here would cut the scheduling region between the selection and the insertions)
+        urec = (s % rgrp == 0) ? w.s2 : min(urec, w.s2);
+        rec[(s / rgrp) * 64] = (unsigned short)(urec >> 16);
+        if (paced) pace();
+        stamp_after(2, (int)(w.s2 ^ (unsigned)__double2hiint(kb.e[0])));
+        terms2(o0, o1);
         stamp_after(3, __double2hiint(kb.e[0]));
     };
-    // bound for the following sub-tiles: the row's KC-th best is at most min(a_K, b_K, max(a_m, b_m)), m = KC/2, over the two
-    // half-lanes (a, b) that share the row; everything within the cut is processed as well (it owes a softmax term).  Any
-    // earlier bound stays valid (it only admits more entries): refreshed after every sub-tile while the lists fill, once per
-    // tile afterwards.
+    // bound for the final check: the row's KC-th best is at most min(a_K, b_K, max(a_m, b_m)), m = KC/2, over the two
+    // half-lanes (a, b) that share the row; everything within the cut counts as well (it owes a softmax term).  In the sweep
+    // only the cut is used (the bound itself is applied once, at the end).
     auto update_bound = [&]() __attribute__((always_inline)) {
-        const int wk = __double2hiint(kb.e[HB_KC - 1]), wm = __double2hiint(kb.e[HB_KC / 2 - 1]), w0 = __double2hiint(kb.e[0]);
-        const auto sk = __builtin_amdgcn_permlane32_swap((unsigned)wk, (unsigned)wk, false, false);
-        const auto sm = __builtin_amdgcn_permlane32_swap((unsigned)wm, (unsigned)wm, false, false);
-        const auto s0 = __builtin_amdgcn_permlane32_swap((unsigned)w0, (unsigned)w0, false, false);
-        const int pk = (int)(h ? sk[0] : sk[1]), pm = (int)(h ? sm[0] : sm[1]), p0 = (int)(h ? s0[0] : s0[1]);
-        const int thr = min(min(wk, pk), max(wm, pm));
-        const int kmin = min(w0, p0);
+        const unsigned wk = entry_key(kb.e[HB_KC - 1]), wm = entry_key(kb.e[HB_KC / 2 - 1]), w0 = entry_key(kb.e[0]);
+        const auto sk = __builtin_amdgcn_permlane32_swap(wk, wk, false, false);
+        const auto sm = __builtin_amdgcn_permlane32_swap(wm, wm, false, false);
+        const auto s0 = __builtin_amdgcn_permlane32_swap(w0, w0, false, false);
+        const unsigned pk = h ? sk[0] : sk[1], pm = h ? sm[0] : sm[1], p0 = h ? s0[0] : s0[1];
+        const unsigned thr = min(min(wk, pk), max(wm, pm));
+        const unsigned kmin = min(w0, p0);
         const float dmin = kmin < H2_REMOVED ? __builtin_amdgcn_sqrtf(key_d2(kmin)) : INFINITY;
         const float cut = dmin + cutw;                      // beyond this the softmax term is < e^-20 of the largest
-        const float ck = fmaf((cut * cut) * 1.000001f, icf, bias);
-        cut_i = ck < INFINITY ? __float_as_int(ck) + 32 : 0x7fffffff;   // (+32: the embedded register number, rounding of ck)
-        lim = max(thr, cut_i);
-        stamp_after(4, lim);
+        const float ca = fmaf((cut * cut) * 1.000001f, icf, rowc);   // the cut as an accumulator value
+        cut_k = ca < 0x1p+33f ? ((__float_as_uint(fmaxf(ca, 4.f)) - H2_KBASE) << 4) + 15u : 0xffffffffu;
+        lim = max(thr, cut_k);
+        stamp_after(4, (int)lim);
     };
 
-    stage_tile(0, 0);
+    const bool ragged = (M & (HB_KT - 1)) != 0;   // the last tile holds padding keys
+    if (ragged && ntiles == 1) stage_tile(0, 0, true); else stage_tile(0, 0, false);
     __syncthreads();  // (drains the DMA: vmcnt(0))
     if (PIPE == 0) {
         auto tile = [&](int t, int buf) __attribute__((always_inline)) {
-            if (t + 1 < ntiles) stage_tile(t + 1, buf ^ 1);  // the other buffer was last read before the previous barrier
+            if (t + 1 < ntiles) {   // the other buffer was last read before the previous barrier
+                if (ragged && t + 2 == ntiles) stage_tile(t + 1, buf ^ 1, true); else stage_tile(t + 1, buf ^ 1, false);
+            }
             stamp(0);
+            const bool pads = ragged && t + 1 == ntiles;
             const f32x16 a0 = chain(buf, 0);
             stamp_after(1, __float_as_int(a0[0]));
-            epilogue(a0, t * HB_KT + 4 * h, false);
-            if (t < 8) update_bound();
+            if (pads) epilogue(a0, 2 * t, true); else epilogue(a0, 2 * t, false);
             const f32x16 a1 = chain(buf, 1);
             stamp_after(1, __float_as_int(a1[0]));
-            epilogue(a1, t * HB_KT + 32 + 4 * h, false);
+            if (pads) epilogue(a1, 2 * t + 1, true); else epilogue(a1, 2 * t + 1, false);
             update_bound();
             __syncthreads();
             stamp(5);
@@ -351,15 +396,16 @@ __global__ __launch_bounds__(HB_THREADS) void softcorr_sweep2_kernel(const H2Arg
         // software pipeline: the matrix chain of the next sub-tile is issued ahead of the epilogue of the current one
         f32x16 a0 = chain(0, 0);
         auto tile = [&](int t, int buf, bool last) __attribute__((always_inline)) {   // buf, last: literals after inlining
-            if (!last) stage_tile(t + 1, buf ^ 1);  // last read (second sub-tile of tile t - 1) before the previous barrier
+            if (!last) {   // (that buffer was last read — second sub-tile of tile t - 1 — before the previous barrier)
+                if (ragged && t + 2 == ntiles) stage_tile(t + 1, buf ^ 1, true); else stage_tile(t + 1, buf ^ 1, false);
+            }
             stamp(0);
             const f32x16 a1 = chain(buf, 1);
-            epilogue(a0, t * HB_KT + 4 * h, PIPE == 2);
-            if (t < 8) update_bound();
+            if (last && ragged) epilogue(a0, 2 * t, true); else epilogue(a0, 2 * t, false, PIPE == 2);
             __syncthreads();
             stamp(5);
             if (!last) a0 = chain(buf ^ 1, 0);
-            epilogue(a1, t * HB_KT + 32 + 4 * h, PIPE == 2 && !last);
+            if (last && ragged) epilogue(a1, 2 * t + 1, true); else epilogue(a1, 2 * t + 1, false, PIPE == 2 && !last);
             update_bound();
             T[7] += 2;
         };
@@ -378,6 +424,53 @@ __global__ __launch_bounds__(HB_THREADS) void softcorr_sweep2_kernel(const H2Arg
         }
     }
 
+    // ---- re-do the sub-tiles in which some lane may hold MORE than two entries at or below its final bound: the same
+    // fragments (straight from global memory), the same chain, hence the same keys; the two smallest are in the list
+    // already, the rest goes through a loop that takes two per trip while any lane has one left at or below the bound
+    update_bound();
+    {
+        const unsigned limr = lim >> 16;
+        const int nrec = (nsub + rgrp - 1) / rgrp;
+        unsigned long long todo = 0;   // wave-uniform: records with a lane at or below its bound (64 independent LDS reads)
+#pragma unroll
+        for (int g = 0; g < H2_NREC; ++g)
+            if (g < nrec && __builtin_amdgcn_ballot_w64((unsigned)rec[g * 64] <= limr) != 0) todo |= 1ull << g;
+        while (todo != 0) {
+            const int g = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            if (STAMP) T[7] += 1u << 20;   // (re-done records, counted in the high bits)
+            for (int s = g * rgrp; s < (g + 1) * rgrp && s < nsub; ++s) {
+                const int j = s * 32 + r32, jc = j < M ? j : M - 1;
+                const char *arow = kbase + (size_t)jc * HB_ROWB + 16 * h;
+                const f16x8 an = *(const f16x8 *)(nfbase + (size_t)j * 32 + 16 * h);
+                f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {   // the sweep's instruction order: (m, h), (h, m), (h, h) per k-step, the norms last
+                    const f16x8 ah = *(const f16x8 *)(arow + 32 * u), am = *(const f16x8 *)(arow + 256 + 32 * u);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, qh[u], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qm[u], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[u], acc, 0, 0, 0);
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(an, qn, acc, 0, 0, 0);
+                const int jb = s * 32 + 4 * h;
+                unsigned v[16];
+                make_keys(acc, v, jb, true);
+                Top3 w = top3_of_16(v);   // w.s0, w.s1: inserted by the sweep
+                bool more = w.s2 <= lim && w.s2 < H2_REMOVED;
+                while (__builtin_amdgcn_ballot_w64(more) != 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = v[r] <= w.s1 ? (H2_REMOVED | r) : v[r];
+                    w = top3_of_16(v);
+                    const double o0 = kb.insert(pack_entry(w.s0, jb));
+                    const double o1 = kb.insert(pack_entry(w.s1, jb));
+                    terms2(o0, o1);
+                    more = w.s2 <= lim && w.s2 < H2_REMOVED;
+                }
+            }
+        }
+        stamp(3);
+    }
+
     // merge the two half-lanes that share a query (lane, lane^32)
     {
         const float co = __shfl_xor(cref, 32, 64), lo = __shfl_xor(l, 32, 64);
@@ -391,15 +484,15 @@ __global__ __launch_bounds__(HB_THREADS) void softcorr_sweep2_kernel(const H2Arg
         for (int t = 0; t < HB_KC; ++t)
             other[t] = __hiloint2double(__shfl_xor(__double2hiint(kb.e[t]), 32, 64), __shfl_xor(__double2loint(kb.e[t]), 32, 64));
 #pragma unroll
-        for (int t = 0; t < HB_KC; ++t) add_term(__double2hiint(kb.insert(other[t])));  // dropped from the union
+        for (int t = 0; t < HB_KC; ++t) add_term(entry_key(kb.insert(other[t])));  // dropped from the union
     }
     if (h == 0 && qrow < N) {
         const size_t row = (size_t)b * N + qrow;
 #pragma unroll
         for (int t = 0; t < HB_KC; ++t) {
-            const int key = __double2hiint(kb.e[t]), r = key & 15;
+            const unsigned key = entry_key(kb.e[t]), r = key & 15;
             const bool live = key < H2_REMOVED;
-            G.cidx[row * HB_KC + t] = live ? __double2loint(kb.e[t]) + (r & 3) + 8 * (r >> 2) : 0x7fffffff;
+            G.cidx[row * HB_KC + t] = live ? entry_jb(kb.e[t]) + (int)((r & 3) + 8 * (r >> 2)) : 0x7fffffff;
             G.cd2[row * HB_KC + t] = live ? key_d2(key) : INFINITY;
         }
         G.lsum[row * 2] = l;
@@ -449,10 +542,16 @@ void launch_sweep2(const HBArgs &a, const char *knf0, const char *knf1, const in
         double tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (size_t w = 0; w < (size_t)blocks * HB_WAVES; ++w)
             for (int i = 0; i < 8; ++i) tot[i] += (double)hbuf[w * 8 + i];
+        double redo = 0;
+        for (size_t w = 0; w < (size_t)blocks * HB_WAVES; ++w) {
+            redo += (double)(hbuf[w * 8 + 7] >> 20);
+            tot[7] -= (double)(hbuf[w * 8 + 7] >> 20 << 20);
+        }
         const double nw = (double)blocks * HB_WAVES, st = tot[7] / nw;
-        fprintf(stderr, "K1 stamps (form %d, %d blocks): per wave and sub-tile, cycles: dma %.0f  chain %.0f  epilogue %.0f  slow %.0f  bound %.0f  "
-                        "barrier %.0f  | whole sweep %.0f per sub-tile (%.0f sub-tiles per wave)\n", form, blocks, tot[0] / nw / st, tot[1] / nw / st,
-                tot[2] / nw / st, tot[3] / nw / st, tot[4] / nw / st, tot[5] / nw / st, tot[6] / nw / st, st);
+        fprintf(stderr, "K1 stamps: %.2f re-done records per wave\n", redo / nw);
+        fprintf(stderr, "K1 stamps (form %d, %d blocks): per wave and sub-tile, cycles: dma %.0f  chain %.0f  epilogue %.0f  terms+redo %.0f  "
+                        "bound %.0f  barrier %.0f  | whole sweep %.0f per sub-tile (%.0f sub-tiles per wave)\n", form, blocks, tot[0] / nw / st,
+                tot[1] / nw / st, tot[2] / nw / st, tot[3] / nw / st, tot[4] / nw / st, tot[5] / nw / st, tot[6] / nw / st, st);
         free(hbuf);
         (void)hipFree(dbuf);
         return;
