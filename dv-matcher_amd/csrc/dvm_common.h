@@ -292,6 +292,18 @@ __device__ __forceinline__ float d2_diff3(float ax, float ay, float az, float bx
     return (xx + yy) + zz;
 }
 
+// ---- XCD-aware block numbering.  Workgroups are dealt round-robin over the 8 XCDs (hardware block b runs on XCD b % 8),
+// and every XCD has its own 4 MiB L2.  xcd_remap turns the hardware block number into a logical one such that each XCD
+// works through ONE contiguous range of logical blocks, in order: blocks that gather from the same cloud (consecutive
+// logical blocks) then share an L2 instead of pulling the cloud's rows into all eight.  Used by the soft-correspondence
+// sweeps (a pair's key planes are re-read by its 8 query tiles).  For the gather kernels of the pair path (pass B of K1,
+// pooling, Deformer rows, xyz kNN) it was measured neutral — their L2 misses are served by the Infinity Cache — and for
+// the grid Chamfer kernel harmful (a contiguous range per XCD = whole query groups, whose costs differ: 2.5 -> 4.9 ms).
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+    int q = nwg / 8, r = nwg % 8, xcd = orig % 8;
+    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + orig / 8;
+}
 // ---- cross-lane exchanges without the LDS round trip of __shfl_xor (ds_bpermute): DPP within a 16-lane row,
 // v_permlane16_swap / v_permlane32_swap (gfx950) across rows.  sum16 / sum32 add the SAME partners as the butterfly
 // `for (o = 1; o < n; o <<= 1) v += __shfl_xor(v, o)` — after the xor-1 and xor-2 steps a quad holds one value, so the

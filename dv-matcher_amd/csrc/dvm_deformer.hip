@@ -40,13 +40,30 @@ __global__ __launch_bounds__(256) void pool_kernel(const float *__restrict__ fea
     const float *fb = feat + (size_t)b * P * DF_C;
     const int32_t *ix = idx + ((size_t)b * P + v) * k;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < k; ++s) {
-        f32x4 f = *(const f32x4 *)(fb + (size_t)ix[s] * DF_C + 4 * c4);
-        float w = cw[s];
-        acc.x = fmaf(w, f.x, acc.x);
-        acc.y = fmaf(w, f.y, acc.y);
-        acc.z = fmaf(w, f.z, acc.z);
-        acc.w = fmaf(w, f.w, acc.w);
+    if (k == 10) {   // the Deformer's k: all ten neighbour rows requested before the first is used (same fma order)
+        int nb[10];
+#pragma unroll
+        for (int s = 0; s < 10; ++s) nb[s] = ix[s];
+        f32x4 f[10];
+#pragma unroll
+        for (int s = 0; s < 10; ++s) f[s] = *(const f32x4 *)(fb + (size_t)nb[s] * DF_C + 4 * c4);
+#pragma unroll
+        for (int s = 0; s < 10; ++s) {
+            const float w = cw[s];
+            acc.x = fmaf(w, f[s].x, acc.x);
+            acc.y = fmaf(w, f[s].y, acc.y);
+            acc.z = fmaf(w, f[s].z, acc.z);
+            acc.w = fmaf(w, f[s].w, acc.w);
+        }
+    } else {
+        for (int s = 0; s < k; ++s) {
+            f32x4 f = *(const f32x4 *)(fb + (size_t)ix[s] * DF_C + 4 * c4);
+            float w = cw[s];
+            acc.x = fmaf(w, f.x, acc.x);
+            acc.y = fmaf(w, f.y, acc.y);
+            acc.z = fmaf(w, f.z, acc.z);
+            acc.w = fmaf(w, f.w, acc.w);
+        }
     }
     const float bias = cb[0];
     float *o = out + ((size_t)b * nrows + r) * out_stride + out_off + 4 * c4;

@@ -14,6 +14,8 @@
 // launch with the bf16x3 kernel (gated on that flag, so it costs one empty launch otherwise).  Values below
 // 2^-3/scale lose relative — not absolute — precision in the m plane (<= 2^-24 of the scale).
 // (reference models/model.py:433-452, 476-477; floats only, no integer output depends on it)
+#include <stdlib.h>
+
 #include "dvm_common.h"
 
 namespace dvm {
@@ -60,27 +62,38 @@ __global__ void pack_weights_f16_kernel(const float *__restrict__ W, int O, int 
 }
 
 // acc[t][node][out] += sum_k act_t[node][k] W[out][k] over `steps` k-steps, for NT 32-node tiles sharing the weight
-// fragments.  a0: this lane's row of tile 0 (+ 16*hh); tile t is 32 rows further.  Weight fragments two steps ahead.
-template <int NT>
+// fragments.  a0: this lane's row of tile 0 (+ 16*hh); tile t is 32 rows further.  The weight fragments come straight
+// from L2 (every workgroup streams the same 1.2 MB): MH_AHEAD k-steps are requested ahead of their matrix instructions —
+// with two ahead (6 - 12 matrix instructions = 200 - 400 cycles) the counters showed the waves parked on s_waitcnt for
+// 59 % of their cycles, the L2 latency under load being longer than that.
+template <int NT, int MH_AHEAD>
 __device__ __forceinline__ void mma_tiles(const char *__restrict__ a0, int row_stride, int plane_bytes,
                                           const _Float16 *__restrict__ wp /* (otile, first step) base + lane*8 */, int steps,
                                           f32x16 (&acc)[NT]) {
-    f16x8 bh = *(const f16x8 *)(wp), bm = *(const f16x8 *)(wp + 512);
-    const _Float16 *w1 = wp + (size_t)(1 < steps ? 1 : 0) * 1024;
-    f16x8 ch = *(const f16x8 *)(w1), cm = *(const f16x8 *)(w1 + 512);
-    for (int s = 0; s < steps; ++s) {
-        const _Float16 *wn = wp + (size_t)(s + 2 < steps ? s + 2 : steps - 1) * 1024;
-        const f16x8 nh = *(const f16x8 *)(wn), nm = *(const f16x8 *)(wn + 512);
+    f16x8 wh[MH_AHEAD], wm[MH_AHEAD];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const char *ar = a0 + t * 32 * row_stride + 32 * s;
-            const f16x8 ah = *(const f16x8 *)(ar), am = *(const f16x8 *)(ar + plane_bytes);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, bh, acc[t], 0, 0, 0);  // small terms first
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bm, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+    for (int u = 0; u < MH_AHEAD; ++u) {
+        const _Float16 *w = wp + (size_t)(u < steps ? u : steps - 1) * 1024;
+        wh[u] = *(const f16x8 *)(w), wm[u] = *(const f16x8 *)(w + 512);
+    }
+    for (int s0 = 0; s0 < steps; s0 += MH_AHEAD) {
+#pragma unroll
+        for (int u = 0; u < MH_AHEAD; ++u) {
+            const int s = s0 + u;
+            if (s < steps) {   // (wave-uniform)
+                const f16x8 bh = wh[u], bm = wm[u];
+                const _Float16 *wn = wp + (size_t)(s + MH_AHEAD < steps ? s + MH_AHEAD : steps - 1) * 1024;
+                wh[u] = *(const f16x8 *)(wn), wm[u] = *(const f16x8 *)(wn + 512);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const char *ar = a0 + t * 32 * row_stride + 32 * s;
+                    const f16x8 ah = *(const f16x8 *)(ar), am = *(const f16x8 *)(ar + plane_bytes);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, bh, acc[t], 0, 0, 0);  // small terms first
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bm, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+                }
+            }
         }
-        bh = ch, bm = cm;
-        ch = nh, cm = nm;
     }
 }
 
@@ -104,6 +117,7 @@ __device__ __forceinline__ void store_act(const f32x16 &acc, float bv, int col, 
     }
 }
 
+template <int AHEAD>
 __global__ __launch_bounds__(MH_THREADS) void mlp_f16x2_kernel(const float *__restrict__ z, int rows,
                                                                const _Float16 *__restrict__ Wp0, const float *__restrict__ b0,
                                                                const _Float16 *__restrict__ Wp1, const float *__restrict__ b1,
@@ -150,7 +164,7 @@ __global__ __launch_bounds__(MH_THREADS) void mlp_f16x2_kernel(const float *__re
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc0[t][r] = 0.f;
-            mma_tiles<2>(bufZ + r32 * MH_SZ + 16 * hh, MH_SZ, 2 * MH_K0, Wp0 + (size_t)ot * (MH_K0 / 16) * 1024 + lane * 8, MH_K0 / 16,
+            mma_tiles<2, AHEAD>(bufZ + r32 * MH_SZ + 16 * hh, MH_SZ, 2 * MH_K0, Wp0 + (size_t)ot * (MH_K0 / 16) * 1024 + lane * 8, MH_K0 / 16,
                          acc0);
             const float bv = b0[ot * 32 + r32];
 #pragma unroll
@@ -158,7 +172,7 @@ __global__ __launch_bounds__(MH_THREADS) void mlp_f16x2_kernel(const float *__re
         }
         __syncthreads();
         // layer 1, K-half hlf: out tile = wave (8 tiles = 256 outputs), k-steps 16*hlf .. 16*hlf+15
-        mma_tiles<2>(bufH + r32 * MH_SH + 16 * hh, MH_SH, 2 * 256, Wp1 + ((size_t)wave * (MH_K1 / 16) + 16 * hlf) * 1024 + lane * 8, 16,
+        mma_tiles<2, AHEAD>(bufH + r32 * MH_SH + 16 * hh, MH_SH, 2 * 256, Wp1 + ((size_t)wave * (MH_K1 / 16) + 16 * hlf) * 1024 + lane * 8, 16,
                      acc1);
         __syncthreads();
     }
@@ -174,7 +188,7 @@ __global__ __launch_bounds__(MH_THREADS) void mlp_f16x2_kernel(const float *__re
         f32x16 acc2[1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[0][r] = 0.f;
-        mma_tiles<1>(bufZ + (nt * 32 + r32) * MH_SZ + 16 * hh, MH_SZ, 2 * MH_K2, Wp2 + (size_t)ot * (MH_K2 / 16) * 1024 + lane * 8,
+        mma_tiles<1, AHEAD>(bufZ + (nt * 32 + r32) * MH_SZ + 16 * hh, MH_SZ, 2 * MH_K2, Wp2 + (size_t)ot * (MH_K2 / 16) * 1024 + lane * 8,
                      MH_K2 / 16, acc2);
         store_act(acc2[0], b2[ot * 32 + r32], ot * 32 + r32, bufH + nt * 32 * MH_SH, MH_SH, 2 * MH_K3, hh, bad);
     }
@@ -184,7 +198,7 @@ __global__ __launch_bounds__(MH_THREADS) void mlp_f16x2_kernel(const float *__re
         f32x16 acc3[1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc3[0][r] = 0.f;
-        mma_tiles<1>(bufH + (wave * 32 + r32) * MH_SH + 16 * hh, MH_SH, 2 * MH_K3, Wp3 + lane * 8, MH_K3 / 16, acc3);
+        mma_tiles<1, AHEAD>(bufH + (wave * 32 + r32) * MH_SH + 16 * hh, MH_SH, 2 * MH_K3, Wp3 + lane * 8, MH_K3 / 16, acc3);
         const int o = r32;
         const float bv = o < 9 ? b3[o] : 0.f;
 #pragma unroll
@@ -224,10 +238,22 @@ int *launch_mlp_rows_f16(const float *z, int rows, const float *W0, const float 
     pack(W1, 256, 512, 8, MH_K1 / 16, Wp1);
     pack(W2, 128, 256, 4, MH_K2 / 16, Wp2);
     pack(W3, 9, 128, 1, MH_K3 / 16, Wp3);
-    ensure_dyn_lds((const void *)mlp_f16x2_kernel, (int)MH_LDS_BYTES);
+    static const int ahead = [] {   // weight k-steps requested ahead of their matrix instructions (A/B: DVM_MLP_AHEAD = 2 | 4 | 8)
+        const char *e = getenv("DVM_MLP_AHEAD");
+        return e ? atoi(e) : 4;
+    }();
     prof_begin(s, DVM_PROF_MLP);
-    hipLaunchKernelGGL(mlp_f16x2_kernel, dim3((rows + MH_NODES - 1) / MH_NODES), dim3(MH_THREADS), MH_LDS_BYTES, s, z, rows, Wp0, b0,
-                       Wp1, b1, Wp2, b2, Wp3, b3, out, flag);
+    const dim3 grid((rows + MH_NODES - 1) / MH_NODES), block(MH_THREADS);
+    if (ahead <= 2) {
+        ensure_dyn_lds((const void *)mlp_f16x2_kernel<2>, (int)MH_LDS_BYTES);
+        hipLaunchKernelGGL(mlp_f16x2_kernel<2>, grid, block, MH_LDS_BYTES, s, z, rows, Wp0, b0, Wp1, b1, Wp2, b2, Wp3, b3, out, flag);
+    } else if (ahead <= 4) {
+        ensure_dyn_lds((const void *)mlp_f16x2_kernel<4>, (int)MH_LDS_BYTES);
+        hipLaunchKernelGGL(mlp_f16x2_kernel<4>, grid, block, MH_LDS_BYTES, s, z, rows, Wp0, b0, Wp1, b1, Wp2, b2, Wp3, b3, out, flag);
+    } else {
+        ensure_dyn_lds((const void *)mlp_f16x2_kernel<8>, (int)MH_LDS_BYTES);
+        hipLaunchKernelGGL(mlp_f16x2_kernel<8>, grid, block, MH_LDS_BYTES, s, z, rows, Wp0, b0, Wp1, b1, Wp2, b2, Wp3, b3, out, flag);
+    }
     prof_end(s, DVM_PROF_MLP);
     return flag;
 }

@@ -290,11 +290,6 @@ __device__ __forceinline__ float select16(const float (&v)[16], int b) {
 // XCD-aware block remap (bijective for any grid): blocks that share `orig % 8` share an L2;
 // give each XCD a contiguous range of logical ids so the row tiles of one pair reuse its keys
 // from that L2.
-__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
-    int q = nwg / 8, r = nwg % 8, xcd = orig % 8;
-    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + orig / 8;
-}
 
 
 // One launch covers up to two "groups" (the two directions of a pair batch: (f1 -> f2) and

@@ -37,11 +37,6 @@ constexpr int BW_LD_PER_THREAD = BW_KT * BW_D / 4 / BW_THREADS;  // 8 float4 per
 constexpr int BW_TILE_FLOATS = BW_KT * BW_LDK + 3 * BW_KT;       // rows + {norm, c2, coef}
 constexpr size_t BW_LDS_BYTES = ((size_t)2 * BW_TILE_FLOATS + BW_OB) * sizeof(float);
 
-__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
-    int q = nwg / 8, r = nwg % 8, xcd = orig % 8;
-    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + orig / 8;
-}
 
 // "outer" rows live in registers (32 per wave), "inner" rows stream through LDS.  The softmax row statistics
 // (c2 = smax*log2e, coef = -neg_alpha*G/l) belong to f1's rows: they sit on the outer side in the df1 pass

@@ -24,11 +24,6 @@ constexpr float HB_ERR = 2.5e-5f;  // |d2_passA - d2_chain| <= HB_ERR (|q|^2 + |
                                    // (2 x 7.7e-6) + the dropped split terms (1.4e-6) + the second form's 4 key bits that
                                    // carry the register number (2^-19 of d2 <= 2 (|q|^2 + |k|^2): 3.8e-6), see DESIGN.md
 
-__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
-    int q = nwg / 8, r = nwg % 8, xcd = orig % 8;
-    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + orig / 8;
-}
 
 // power of two s with max|x| * s in [2^11, 2^12): well inside fp16's range, the m-plane of every element within 2^-8 of
 // the largest stays a normal fp16 number (smaller ones keep an absolute error of 2^-25 in scaled units: far below the

@@ -225,6 +225,13 @@ __global__ __launch_bounds__(HB_THREADS) void softcorr_sweep2_kernel(const H2Arg
                                              (__attribute__((address_space(3))) void *)(knf0 + buf * HB_KT * 32 + wave * 1024), 16, 0, 0);
     };
 
+    // Workgroup barrier for LDS-DMA data: every wave first waits for ITS OWN pieces (vmcnt), then joins the barrier — the
+    // compiler places its own vmcnt wait only in front of the wave's next LDS read, which orders nothing for the rows the
+    // OTHER waves were to deliver (seen as a timing-dependent failure of the M = 5 edge case when it ran first in a process).
+    auto dma_barrier = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
     auto key_d2 = [&](unsigned key) __attribute__((always_inline)) {   // key -> squared distance
         return fmaxf(__uint_as_float((key >> 4) + H2_KBASE) - rowc, 0.f) * cf;
     };
@@ -377,7 +384,7 @@ __global__ __launch_bounds__(HB_THREADS) void softcorr_sweep2_kernel(const H2Arg
         }
     };
     stage(0, 0);
-    __syncthreads();  // (drains the DMA: vmcnt(0))
+    dma_barrier();  // (drains the DMA: vmcnt(0))
     if (PIPE == 0) {
         auto tile = [&](int t, int buf) __attribute__((always_inline)) {
             stage(t + 1, buf ^ 1);
@@ -390,7 +397,7 @@ __global__ __launch_bounds__(HB_THREADS) void softcorr_sweep2_kernel(const H2Arg
             stamp_after(1, __float_as_int(a1[0]));
             if (pads) epilogue(a1, 2 * t + 1, true); else epilogue(a1, 2 * t + 1, false);
             if ((t & 3) == 3 || t < 8) update_bound();   // (the cut moves slowly once the lists have filled)
-            __syncthreads();
+            dma_barrier();
             stamp(5);
             T[7] += 2;
         };
@@ -406,7 +413,7 @@ __global__ __launch_bounds__(HB_THREADS) void softcorr_sweep2_kernel(const H2Arg
             stamp(0);
             const f32x16 a1 = chain(buf, 1);
             if (last && ragged) epilogue(a0, 2 * t, true); else epilogue(a0, 2 * t, false, PIPE == 2);
-            __syncthreads();
+            dma_barrier();
             stamp(5);
             if (!last) a0 = chain(buf ^ 1, 0);
             if (last && ragged) epilogue(a1, 2 * t + 1, true); else epilogue(a1, 2 * t + 1, false, PIPE == 2 && !last);

@@ -78,6 +78,22 @@ def test_softcorr_ragged_shapes(ops, shape):
             check_softcorr(ops, f1[b], f2[b], 25.0, variant)
 
 
+def test_softcorr_writes_every_output_slot(ops):
+    """Fewer columns than topk (M = 5 < 10): the unused positions of every row are defined outputs (value 0, column 0, like
+    the oracle's).  The output tensors are handed out by the caching allocator uninitialised, so blocks of exactly their
+    sizes are poisoned and released first — a position the kernels leave unwritten then shows as garbage (found when the
+    M = 5 case ran first in a process: all empty candidate slots shared one rank and wrote one position)."""
+    g = np.random.default_rng(77)
+    N, M = 150, 5
+    f1, f2 = g.standard_normal((N, 128)).astype(np.float32), g.standard_normal((M, 128)).astype(np.float32)
+    for variant in (3, 2, 1):
+        junk = [torch.full((1, N, 10), float("nan"), device="cuda"), torch.full((1, N, 10), 0x7f7f7f7f, dtype=torch.int32, device="cuda"),
+                torch.full((1, N), float("nan"), device="cuda"), torch.full((1, N), float("nan"), device="cuda")]
+        torch.cuda.synchronize()
+        del junk
+        check_softcorr(ops, f1, f2, 40.0, variant)
+
+
 def test_softcorr_duplicate_rows(ops):
     """exact ties (duplicated target features): lowest column first, like the oracle."""
     g = torch.Generator().manual_seed(5)
