@@ -63,9 +63,7 @@ __global__ void pack_weights_f16_kernel(const float *__restrict__ W, int O, int 
 
 // acc[t][node][out] += sum_k act_t[node][k] W[out][k] over `steps` k-steps, for NT 32-node tiles sharing the weight
 // fragments.  a0: this lane's row of tile 0 (+ 16*hh); tile t is 32 rows further.  The weight fragments come straight
-// from L2 (every workgroup streams the same 1.2 MB): MH_AHEAD k-steps are requested ahead of their matrix instructions —
-// with two ahead (6 - 12 matrix instructions = 200 - 400 cycles) the counters showed the waves parked on s_waitcnt for
-// 59 % of their cycles, the L2 latency under load being longer than that.
+// from L2 (every workgroup streams the same 1.2 MB), MH_AHEAD k-steps ahead of their matrix instructions.
 template <int NT, int MH_AHEAD>
 __device__ __forceinline__ void mma_tiles(const char *__restrict__ a0, int row_stride, int plane_bytes,
                                           const _Float16 *__restrict__ wp /* (otile, first step) base + lane*8 */, int steps,
@@ -238,9 +236,11 @@ int *launch_mlp_rows_f16(const float *z, int rows, const float *W0, const float 
     pack(W1, 256, 512, 8, MH_K1 / 16, Wp1);
     pack(W2, 128, 256, 4, MH_K2 / 16, Wp2);
     pack(W3, 9, 128, 1, MH_K3 / 16, Wp3);
-    static const int ahead = [] {   // weight k-steps requested ahead of their matrix instructions (A/B: DVM_MLP_AHEAD = 2 | 4 | 8)
+    // weight k-steps requested ahead of their matrix instructions: 2 / 4 / 8 measured alike (2.74 / 2.83 / 2.82 ms per launch
+    // at 512 pairs) — the waves' 59 % parked cycles (SQ_WAIT_ANY) are not the L2 latency of the weights (DVM_MLP_AHEAD = A/B)
+    static const int ahead = [] {
         const char *e = getenv("DVM_MLP_AHEAD");
-        return e ? atoi(e) : 4;
+        return e ? atoi(e) : 2;
     }();
     prof_begin(s, DVM_PROF_MLP);
     const dim3 grid((rows + MH_NODES - 1) / MH_NODES), block(MH_THREADS);
