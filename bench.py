@@ -347,7 +347,7 @@ def run_pair(args):
             # it runs on (dense f16 peak) — the utilisation figure.  `algorithmic` is SURVEY §8d's accounting: 2*N*M*d per
             # pair, the distance tile counted once, over the same launch time, against the fp32 matrix peak §8d prescribes
             # (a formulation-independent number: it can exceed what an fp32-MFMA kernel could ever reach).
-            "roofline": {"bound": "mfma", "kernel": "softcorr_sweep_f16_kernel (K1 pass A, fp16x2-split sweep)",
+            "roofline": {"bound": "mfma", "kernel": "softcorr_sweep2_kernel (K1 pass A, fp16x2-split sweep, second form; the probe routes flat-row inputs to softcorr_sweep_f16_kernel)",
                          "achieved": 6.0 * tf(k1_ms), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": 6.0 * tf(k1_ms) / PEAK_F16_MFMA_TFLOPS, "pipe": "f16 matrix (v_mfma_f32_32x32x16_f16)",
                          "traffic": traffic, "launch_ms": k1_ms, "launches_timed": k1_launches,

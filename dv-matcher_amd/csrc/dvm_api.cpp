@@ -184,7 +184,7 @@ DVM_EXPORT int dvm_profile_read_kernel(int kernel, double *total_ms, int *launch
 
 DVM_EXPORT const char *dvm_profile_kernel_name(int kernel) {
     static const char *const names[DVM_PROF_COUNT] = {
-        "softcorr_sweep_f16_kernel", "softcorr_refine_kernel", "mlp_f16x2_kernel", "grid_chamfer_kernel", "pool_kernel",
+        "softcorr_sweep2_kernel",    "softcorr_refine_kernel", "mlp_f16x2_kernel", "grid_chamfer_kernel", "pool_kernel",
         "grid_knn_self_kernel",      "fps_kernel",             "assemble_pooled_kernel"};
     return (kernel >= 0 && kernel < DVM_PROF_COUNT) ? names[kernel] : "";
 }

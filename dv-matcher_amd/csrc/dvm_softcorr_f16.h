@@ -99,7 +99,13 @@ struct HBArgs {
     HBGroup g[2];
     int blocks0;
     float neg_alpha, cutw;
+    const int *route;        // per (group, batch entry): which kernel sweeps it (K1_ROUTE_*), or nullptr = this launch takes all
+    int nb;                  // batch entries per group
 };
+// Which pass-A kernel sweeps a (direction, pair): set per launch by k1_probe_kernel from the pair's own distance statistics
+constexpr int K1_ROUTE_FULL = 0;     // first form, every softmax term (flat rows: nearly every column lies within the cut)
+constexpr int K1_ROUTE_LEAN = 1;     // first form, lean
+constexpr int K1_ROUTE_SECOND = 2;   // second form (lean)
 
 
 // second form of pass A (dvm_softcorr_sweep2.hip); form = sweep_form() of the caller: 1 plain, 2 pipelined, 3 pipelined + paced

@@ -90,6 +90,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void softcorr_sweep_f16_kernel(const
     const HBGroup &G = args.g[grp];
     const int N = G.N, M = G.M;
     const int b = lid / G.tiles, qt = lid % G.tiles;
+    if (args.route && args.route[grp * args.nb + b] != (LEAN ? K1_ROUTE_LEAN : K1_ROUTE_FULL)) return;   // another kernel's pair
     const float neg_alpha = args.neg_alpha;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r32 = lane & 31, h = lane >> 5;
@@ -292,6 +293,115 @@ __global__ void common_absmax_kernel(const int *__restrict__ in, int *__restrict
     const int m = max(in[0], in[1]);
     out[0] = m;
     out[1] = m;
+}
+
+// ---------------------------------------------------------------- routing probe
+// Which pass-A kernel suits a (direction, pair) depends on how many columns of a row lie within the softmax cut
+// (d <= d_min + 20 / alpha): a handful on wide-spread features at large alpha (the second form: nothing per entry, sub-tiles
+// with a third candidate re-done at the end), a few dozen (first form, lean: per-entry loop, terms only for what leaves a
+// list), or most of the row (flat rows, small alpha x small spread: the lean bookkeeping only costs — first form, every term).
+// The alpha >= 32 rule alone got this wrong on clustered features (profiles/r3_bench_alpha.txt: 12.7 ms lean vs 10.4 ms full
+// per 256 pairs at alpha 33 on the "trained-like" set; the second form 16.0 ms there), so each pair is measured: K1P_ROWS query
+// rows x K1P_COLS key columns (evenly spaced) of exact fp32 distances per (direction, pair).  A row's minimum over ALL columns
+// is estimated as min(sample minimum, mean - z(M) sigma), z(M) the normal quantile of 1/M; p = fraction of the sampled
+// distances within the cut of that minimum, averaged over the rows, then over the pairs of the launch (k1_route_kernel).  2 K distances per group: 0.1 % of the sweep's work.
+// Thresholds from profiles/r3_route_calib.txt: the second form wins up to a mean fraction of 0.4 % (measured points: 0.06 - 0.40 %),
+// the lean first form at 1.2 %, the full first form from 4 % on.
+constexpr int K1P_ROWS = 8, K1P_COLS = 256;
+struct K1ProbeArgs {
+    const float *f[2], *n[2];   // features [B][rows][128] and squared norms of side 0 / 1
+    int rows[2];
+    float cutw, p_second, p_lean;
+    int have_second;
+    int *route;                 // [dirs][B]
+    float *frac;                // [dirs][B]
+};
+__global__ __launch_bounds__(256) void k1_probe_kernel(const K1ProbeArgs a) {
+    __shared__ float q[K1P_ROWS][HB_D];
+    __shared__ float psum[4];
+    const int b = blockIdx.x, dir = blockIdx.y, B = gridDim.x;
+    const int N = a.rows[dir], M = a.rows[dir ^ 1];
+    const float *fq = a.f[dir] + (size_t)b * N * HB_D, *fk = a.f[dir ^ 1] + (size_t)b * M * HB_D;
+    const float *nq = a.n[dir] + (size_t)b * N, *nk = a.n[dir ^ 1] + (size_t)b * M;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < K1P_ROWS * HB_D; i += 256) {
+        const int r = i / HB_D;
+        q[r][i % HB_D] = fq[(size_t)((long)r * N / K1P_ROWS) * HB_D + i % HB_D];
+    }
+    __syncthreads();
+    const int C = M < K1P_COLS ? M : K1P_COLS;
+    constexpr int PER = K1P_COLS / 64, RW = K1P_ROWS / 4;   // columns per lane, rows per wave
+    float d[RW][PER];
+#pragma unroll
+    for (int c = 0; c < PER; ++c) {
+        const int j = lane + 64 * c;
+        const int col = j < C ? (int)((long)j * M / C) : 0;
+        float dot[RW];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) dot[r] = 0.f;
+        const float4 *kr = (const float4 *)(fk + (size_t)col * HB_D);
+#pragma unroll 8
+        for (int k = 0; k < HB_D / 4; ++k) {
+            const float4 kv = kr[k];
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const float4 qv = *(const float4 *)&q[wave * RW + r][4 * k];
+                dot[r] = fmaf(kv.x, qv.x, fmaf(kv.y, qv.y, fmaf(kv.z, qv.z, fmaf(kv.w, qv.w, dot[r]))));
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const float nqr = nq[(long)(wave * RW + r) * N / K1P_ROWS];
+            d[r][c] = j < C ? sqrtf(fmaxf(nqr + nk[col] - 2.f * dot[r], 0.f)) : -1.f;   // -1: no sample
+        }
+    }
+    const float z = 1.1f + 0.2f * log2f((float)M);   // 2.9 / 3.3 / 3.7 at M = 512 / 2048 / 8192
+    float pw = 0.f;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        float s1 = 0.f, s2 = 0.f, mn = INFINITY;
+#pragma unroll
+        for (int c = 0; c < PER; ++c) {
+            const bool on = d[r][c] >= 0.f;
+            s1 += on ? d[r][c] : 0.f;
+            s2 += on ? d[r][c] * d[r][c] : 0.f;
+            mn = on ? fminf(mn, d[r][c]) : mn;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s1 += __shfl_xor(s1, o, 64);
+            s2 += __shfl_xor(s2, o, 64);
+            mn = fminf(mn, __shfl_xor(mn, o, 64));
+        }
+        const float mu = s1 / C, sg = sqrtf(fmaxf(s2 / C - mu * mu, 0.f));
+        const float thr = fminf(mn, mu - z * sg) + a.cutw;
+        float cnt = 0.f;
+#pragma unroll
+        for (int c = 0; c < PER; ++c) cnt += (d[r][c] >= 0.f && d[r][c] <= thr) ? 1.f : 0.f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+        pw += cnt / C;
+    }
+    if (lane == 0) psum[wave] = pw;
+    __syncthreads();
+    if (tid == 0) a.frac[dir * B + b] = (psum[0] + psum[1] + psum[2] + psum[3]) / K1P_ROWS;
+}
+// One route per direction of the launch, from the mean fraction over its pairs.  (Routing every pair by its own fraction was
+// measured first: near a threshold the batch splits between two kernels, each runs with half the workgroups, and the launch
+// is slower than either kernel alone — 9.47 vs 9.11 / 9.31 ms per 256 pairs on random features at alpha 33.)
+__global__ __launch_bounds__(256) void k1_route_kernel(const K1ProbeArgs a, int B) {
+    __shared__ float part[4];
+    const int dir = blockIdx.x, tid = threadIdx.x;
+    float sum = 0.f;
+    for (int i = tid; i < B; i += 256) sum += a.frac[dir * B + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if ((tid & 63) == 0) part[tid >> 6] = sum;
+    __syncthreads();
+    const float p = (part[0] + part[1] + part[2] + part[3]) / B;
+    int route = p <= a.p_second ? K1_ROUTE_SECOND : p <= a.p_lean ? K1_ROUTE_LEAN : K1_ROUTE_FULL;
+    if (route == K1_ROUTE_SECOND && !a.have_second) route = K1_ROUTE_LEAN;
+    for (int i = tid; i < B; i += 256) a.route[dir * B + i] = route;
 }
 
 // the reference's squared distance: k-ordered fp32 fma chain of (-2 q) . k, then + |q|^2, + |k|^2
@@ -654,12 +764,47 @@ static int sweep_form() {
     return form;
 }
 
+// routing thresholds of the probe (fractions of a row within the cut), env DVM_K1_ROUTE_P="p_second,p_lean"; DVM_K1_ROUTE
+// forces one route, DVM_K1_ROUTE_DEBUG prints the routes of every launch (synchronous)
+struct RoutePolicy {
+    int forced;
+    float p_second, p_lean;
+    bool debug;
+};
+static const RoutePolicy &route_policy() {
+    static const RoutePolicy pol = [] {
+        RoutePolicy r{-1, 0.006f, 0.02f, getenv("DVM_K1_ROUTE_DEBUG") != nullptr};
+        if (const char *e = getenv("DVM_K1_ROUTE")) r.forced = atoi(e);
+        if (const char *e = getenv("DVM_K1_ROUTE_P")) (void)sscanf(e, "%f,%f", &r.p_second, &r.p_lean);
+        return r;
+    }();
+    return pol;
+}
+static void report_routes(const int *route, const float *frac, int n, hipStream_t s) {   // diagnostic
+    std::vector<int> r(n);
+    std::vector<float> p(n);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(r.data(), route, n * sizeof(int), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(p.data(), frac, n * sizeof(float), hipMemcpyDeviceToHost);
+    int cnt[3] = {0, 0, 0};
+    double ps = 0, pmin = 1, pmax = 0;
+    for (int i = 0; i < n; ++i) {
+        ++cnt[r[i] < 0 || r[i] > 2 ? 0 : r[i]];
+        ps += p[i];
+        pmin = p[i] < pmin ? p[i] : pmin;
+        pmax = p[i] > pmax ? p[i] : pmax;
+    }
+    fprintf(stderr, "K1 routes: %d full, %d lean, %d second form; fraction within the cut: mean %.4f%% (min %.4f%%, max %.4f%%)\n", cnt[0],
+            cnt[1], cnt[2], 100 * ps / n, 100 * pmin, 100 * pmax);
+}
+
 // workspace of the fp16 path for (B, N, M): planes of both sides, candidates of both directions, flags
 size_t softcorr_f16_ws_bytes(int B, int N, int M, bool both) {
     const size_t Np = (size_t)(N + HB_KT - 1) / HB_KT * HB_KT, Mp = (size_t)(M + HB_KT - 1) / HB_KT * HB_KT;
     size_t n = align_up((size_t)B * N * HB_ROWB) + align_up((size_t)B * M * HB_ROWB) + 2 * align_up((size_t)B * sizeof(float)) +
                align_up(2 * sizeof(int)) + align_up(B * Np * sizeof(float)) + align_up(B * Mp * sizeof(float)) +
-               align_up(B * Np * 32) + align_up(B * Mp * 32);   // (norm fragments of the second sweep form)
+               align_up(B * Np * 32) + align_up(B * Mp * 32) +   // (norm fragments of the second sweep form)
+               align_up(2 * (size_t)B * sizeof(int)) + align_up(2 * (size_t)B * sizeof(float));   // routes + probe fractions
     const int dirs = both ? 2 : 1;
     for (int d = 0; d < dirs; ++d) {
         const size_t R = (size_t)B * (d == 0 ? N : M);
@@ -683,6 +828,8 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
     const int Np = (N + HB_KT - 1) / HB_KT * HB_KT, Mp = (M + HB_KT - 1) / HB_KT * HB_KT;
     float *n1p = ar.take<float>((size_t)B * Np), *n2p = ar.take<float>((size_t)B * Mp);
     char *nf1 = ar.take<char>((size_t)B * Np * 32), *nf2 = ar.take<char>((size_t)B * Mp * 32);
+    int *route = ar.take<int>(2 * (size_t)B);
+    float *pfrac = ar.take<float>(2 * (size_t)B);
     int32_t *cidx[2] = {nullptr, nullptr}, *flag[2] = {nullptr, nullptr};
     float *cd2[2] = {nullptr, nullptr}, *lsum[2] = {nullptr, nullptr};
     for (int d = 0; d < (both ? 2 : 1); ++d) {
@@ -708,12 +855,31 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
     hipLaunchKernelGGL(norm_max_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, n1, N, nmax1);
     hipLaunchKernelGGL(norm_max_kernel, dim3((M + 255) / 256, B), dim3(256), 0, s, n2, M, nmax2);
     for (int d = 0; d < (both ? 2 : 1); ++d) (void)hipMemsetAsync(flag[d], 0, sizeof(int32_t), s);
+    // alpha < 32: every softmax term counts, the first form in full.  From 32 on each (direction, pair) is routed by the
+    // probe; DVM_K1_ROUTE = 0 / 1 / 2 forces one kernel for all of them (A/B measurements), DVM_K1_SWEEP=0 takes the second
+    // form out of the choice.
     const bool lean = -neg_alpha >= 32.f;
-    const bool form2 = lean && sweep_form() != 0;
-    if (form2) {
+    const RoutePolicy &pol = route_policy();
+    const bool have2 = sweep_form() != 0;
+    const bool routed = lean && pol.forced < 0;
+    const int fixed = !lean ? K1_ROUTE_FULL : pol.forced < 0 ? -1 : (pol.forced == K1_ROUTE_SECOND && !have2) ? K1_ROUTE_LEAN : pol.forced;
+    if (routed) {
+        K1ProbeArgs pa;
+        pa.f[0] = f1, pa.f[1] = f2, pa.n[0] = n1, pa.n[1] = n2;
+        pa.rows[0] = N, pa.rows[1] = M;
+        pa.cutw = 20.f / -neg_alpha;
+        pa.p_second = pol.p_second, pa.p_lean = pol.p_lean;
+        pa.have_second = have2;
+        pa.route = route, pa.frac = pfrac;
+        hipLaunchKernelGGL(k1_probe_kernel, dim3(B, both ? 2 : 1), dim3(256), 0, s, pa);
+        hipLaunchKernelGGL(k1_route_kernel, dim3(both ? 2 : 1), dim3(256), 0, s, pa, B);
+        if (pol.debug) report_routes(route, pfrac, B * (both ? 2 : 1), s);
+    }
+    if (routed ? have2 : fixed == K1_ROUTE_SECOND) {
         launch_norm_frags(n2, B, M, Mp, amax, nf2, s);
         if (both) launch_norm_frags(n1, B, N, Np, amax, nf1, s);
-    } else {
+    }
+    if (routed || fixed != K1_ROUTE_SECOND) {
         hipLaunchKernelGGL(pad_norms_kernel, dim3((Mp + 255) / 256, B), dim3(256), 0, s, n2, M, Mp, n2p);
         if (both) hipLaunchKernelGGL(pad_norms_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, s, n1, N, Np, n1p);
     }
@@ -725,13 +891,16 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
     a.neg_alpha = neg_alpha;
     a.cutw = 20.f / -neg_alpha;
     const int blocks = a.blocks0 + (both ? B * a.g[1].tiles : 0);
+    a.route = routed ? route : nullptr;
+    a.nb = B;
     prof_begin(s);
-    if (form2) {
-        launch_sweep2(a, nf2, nf1, amax, blocks, sweep_form(), s);
-    } else if (lean) {
+    // (routed: all three kernels are launched and a workgroup whose pair belongs to another one returns at once)
+    if (routed ? have2 : fixed == K1_ROUTE_SECOND) launch_sweep2(a, nf2, nf1, amax, blocks, sweep_form(), s);
+    if (routed || fixed == K1_ROUTE_LEAN) {
         ensure_dyn_lds((const void *)softcorr_sweep_f16_kernel<true>, (int)HB_LDS_BYTES);
         hipLaunchKernelGGL(softcorr_sweep_f16_kernel<true>, dim3(blocks), dim3(HB_THREADS), HB_LDS_BYTES, s, a);
-    } else {
+    }
+    if (routed || fixed == K1_ROUTE_FULL) {
         ensure_dyn_lds((const void *)softcorr_sweep_f16_kernel<false>, (int)HB_LDS_BYTES);
         hipLaunchKernelGGL(softcorr_sweep_f16_kernel<false>, dim3(blocks), dim3(HB_THREADS), HB_LDS_BYTES, s, a);
     }
@@ -814,6 +983,8 @@ int launch_argmin_f16(const float *f1, const float *f2, int B, int N, int M, int
     a.blocks0 = B * a.g[0].tiles;
     a.neg_alpha = -100.f;  // only the candidate lists are used; the lean sweep keeps them exactly as the full one does
     a.cutw = 0.f;
+    a.route = nullptr;   // (no softmax sum here: nothing to route, the second form serves every pair)
+    a.nb = B;
     const int blocks = a.blocks0 + (both ? B * a.g[1].tiles : 0);
     if (form2) {
         launch_sweep2(a, nf2, nf1, amax, blocks, sweep_form(), s);

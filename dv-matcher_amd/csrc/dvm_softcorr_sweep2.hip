@@ -37,7 +37,7 @@ namespace {
 // of the two smallest of its sub-tile, or its sub-tile is re-done), the softmax sum covers every column outside the final
 // list that lies within the cut (the cut never exceeds the bound).
 constexpr int H2_NREC = 64;                                          // third-key records per lane
-constexpr int H2_LDS_BYTES = 2 * HB_KT * HB_ROWB + 2 * HB_KT * 32 + HB_THREADS * H2_NREC * 2;   // key tiles + norm fragments + records
+constexpr int H2_LDS_BYTES = 2 * HB_KT * HB_ROWB + 2 * HB_KT * 32 + 1024 + HB_THREADS * H2_NREC * 2;   // key tiles + norm fragments + DMA dump + records
 constexpr unsigned H2_REMOVED = 0xffc00000u;   // keys >= this: removed / invalid (as a list entry: hi word 0x7fe00000, a finite double)
 constexpr unsigned H2_KBASE = 129u << 23;      // bits(4.0f): bottom of the key window
 constexpr float H2_FLOOR = 4.5f;               // added to every accumulator through the norm instruction
@@ -55,6 +55,8 @@ struct H2Args {
     const int *amax;          // bit pattern of max |x| over BOTH sides (the common scale)
     int blocks0;
     float neg_alpha, cutw;
+    const int *route;         // see HBArgs
+    int nb;
     unsigned long long *stamps;   // diagnostic build only (DVM_K1_STAMPS): [block][wave][8] cycle totals per phase
 };
 
@@ -144,7 +146,8 @@ __global__ __launch_bounds__(HB_THREADS) void softcorr_sweep2_kernel(const H2Arg
     };
     char *const ktile0 = smem_b;                                         // [2][HB_KT][512], 16-B chunks XOR-swizzled
     char *const knf0 = smem_b + (size_t)2 * HB_KT * HB_ROWB;             // [2][HB_KT][32]
-    unsigned short *const rec0 = (unsigned short *)(knf0 + 2 * HB_KT * 32);   // [wave][H2_NREC][64 lanes]
+    char *const dump0 = knf0 + 2 * HB_KT * 32;                            // 1 KiB nobody reads (see stage_tile)
+    unsigned short *const rec0 = (unsigned short *)(dump0 + 1024);        // [wave][H2_NREC][64 lanes]
 
     int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int grp = lid >= args.blocks0 ? 1 : 0;
@@ -152,6 +155,7 @@ __global__ __launch_bounds__(HB_THREADS) void softcorr_sweep2_kernel(const H2Arg
     const H2Group &G = args.g[grp];
     const int N = G.N, M = G.M;
     const int b = lid / G.tiles, qt = lid % G.tiles;
+    if (args.route && args.route[grp * args.nb + b] != K1_ROUTE_SECOND) return;   // this pair goes through the first form
     const float neg_alpha = args.neg_alpha;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave: a scalar register)
     const int r32 = lane & 31, h = lane >> 5;
@@ -208,21 +212,22 @@ __global__ __launch_bounds__(HB_THREADS) void softcorr_sweep2_kernel(const H2Arg
         int lane;   // (a volatile statement: otherwise the offsets are hoisted out of the loop as invariants — and spilled)
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
         const int r32 = lane & 31, h = lane >> 5;
-        const unsigned nfoff = wave * 1024 + lane * 16;
         const int j0 = t * HB_KT;
         const char *tb = kbase + (size_t)j0 * HB_ROWB;   // wave-uniform
         char *kt = ktile0 + (size_t)buf * HB_KT * HB_ROWB;
 #pragma unroll
         for (int e = 0; e < HB_GLDS_PER_WAVE; ++e) {
             const int piece = wave * HB_GLDS_PER_WAVE + e;
-            const int r = 2 * piece + h, rc = (!clamp || j0 + r < M) ? r : M - 1 - j0;
+            const int r = 2 * piece + h, rc = clamp ? min(r, M - 1 - j0) : r;
             const unsigned off = rc * HB_ROWB + ((r32 ^ (r & 15)) << 4);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tb + off),
                                              (__attribute__((address_space(3))) void *)(kt + piece * 1024), 16, 0, 0);
         }
-        if (wave < 2)   // 64 keys x 32 B of norm fragments = two 1-KiB pieces
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(nfbase + (size_t)j0 * 32 + nfoff),
-                                             (__attribute__((address_space(3))) void *)(knf0 + buf * HB_KT * 32 + wave * 1024), 16, 0, 0);
+        // 64 keys x 32 B of norm fragments = two 1-KiB pieces, brought by waves 0 and 1; the other six waves issue the same
+        // instruction into a 1-KiB dump area (destination chosen by a scalar select): every wave issues five pieces per tile, and
+        // there is no branch here that would cut the scheduling region (an execution-masked DMA is branched around as well).
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(nfbase + (size_t)j0 * 32 + (wave & 1) * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void *)(wave < 2 ? knf0 + buf * HB_KT * 32 + wave * 1024 : dump0), 16, 0, 0);
     };
 
     // Workgroup barrier for LDS-DMA data: every wave first waits for ITS OWN pieces (vmcnt), then joins the barrier — the
@@ -352,6 +357,10 @@ __global__ __launch_bounds__(HB_THREADS) void softcorr_sweep2_kernel(const H2Arg
         rec[(s / rgrp) * 64] = (unsigned short)(urec >> 16);
         if (paced) pace();
         stamp_after(2, (int)(w.s2 ^ (unsigned)__double2hiint(kb.e[0])));
+        // (Finishing a sub-tile right here when a lane's third key lies within the cut — the clustered regime, where most
+        // sub-tiles end up re-done — was measured: 14.6 instead of 16.0 ms per 256 pairs on the "trained-like" set at alpha 33,
+        // but 4.26 instead of 3.61 ms per launch on random features: the loop's registers and code sit in the hot epilogue.
+        // Such inputs are routed to the first form instead, per pair, by the probe: see k1_probe_kernel.)
         terms2(o0, o1);
         stamp_after(3, __double2hiint(kb.e[0]));
     };
@@ -383,8 +392,10 @@ __global__ __launch_bounds__(HB_THREADS) void softcorr_sweep2_kernel(const H2Arg
             if (ragged && t + 1 == ntiles) stage_tile(t, buf, true); else stage_tile(t, buf, false);
         }
     };
-    stage(0, 0);
-    dma_barrier();  // (drains the DMA: vmcnt(0))
+    if (PIPE != 3) {
+        stage(0, 0);
+        dma_barrier();  // (drains the DMA: vmcnt(0))
+    }
     if (PIPE == 0) {
         auto tile = [&](int t, int buf) __attribute__((always_inline)) {
             stage(t + 1, buf ^ 1);
@@ -404,6 +415,43 @@ __global__ __launch_bounds__(HB_THREADS) void softcorr_sweep2_kernel(const H2Arg
         for (int t = 0; t < ntiles; t += 2) {
             tile(t, 0);
             if (t + 1 < ntiles) tile(t + 1, 1);
+        }
+    } else if (PIPE == 3) {
+        // As PIPE 1, but tile t + 2 is requested in the SECOND half of tile t, behind the matrix chain of that half and in front
+        // of the epilogue's vector tail (the barriers around it let vector and scalar instructions cross, matrix instructions
+        // and LDS reads not): the DMA instructions then issue while no fragment reads compete for the LDS path, and a tile has
+        // a tile and a half to land.  Branch-free: the tile index and the rows are clamped (a tile past the end re-stages the
+        // last tile into a buffer nobody reads any more).
+        stage(0, 0);
+        stage(1, 1);
+        dma_barrier();
+        f32x16 a0 = chain(0, 0);
+        auto tile = [&](int t, int buf, bool last) __attribute__((always_inline)) {   // buf, last: literals after inlining
+            const f32x16 a1 = chain(buf, 1);
+            if (last && ragged) epilogue(a0, 2 * t, true); else epilogue(a0, 2 * t, false);
+            dma_barrier();
+            stamp(5);
+            if (!last) {
+                a0 = chain(buf ^ 1, 0);
+                __builtin_amdgcn_sched_barrier(0x006);
+                stage_tile(min(t + 2, ntiles - 1), buf, true);
+                __builtin_amdgcn_sched_barrier(0x006);
+            }
+            stamp(0);
+            if (last && ragged) epilogue(a1, 2 * t + 1, true); else epilogue(a1, 2 * t + 1, false);
+            if ((t & 3) == 3 || t < 8) update_bound();
+            T[7] += 2;
+        };
+        int t = 0;
+        for (; t + 2 < ntiles; t += 2) {
+            tile(t, 0, false);
+            tile(t + 1, 1, false);
+        }
+        if (t + 1 < ntiles) {
+            tile(t, 0, false);
+            tile(t + 1, 1, true);
+        } else {
+            tile(t, 0, true);
         }
     } else {
         // software pipeline: the matrix chain of the next sub-tile is issued ahead of the epilogue of the current one
@@ -533,6 +581,8 @@ void launch_sweep2(const HBArgs &a, const char *knf0, const char *knf1, const in
     b.blocks0 = a.blocks0;
     b.neg_alpha = a.neg_alpha;
     b.cutw = a.cutw;
+    b.route = a.route;
+    b.nb = a.nb;
     b.stamps = nullptr;
     static const bool stamps_on = getenv("DVM_K1_STAMPS") != nullptr;
     if (stamps_on) {   // diagnostic: synchronous, allocates — never taken in production
@@ -543,6 +593,9 @@ void launch_sweep2(const HBArgs &a, const char *knf0, const char *knf1, const in
         if (form == 1) {
             ensure_dyn_lds((const void *)softcorr_sweep2_kernel<0, true>, H2_LDS_BYTES);
             hipLaunchKernelGGL((softcorr_sweep2_kernel<0, true>), dim3(blocks), dim3(HB_THREADS), H2_LDS_BYTES, s, b);
+        } else if (form == 4) {
+            ensure_dyn_lds((const void *)softcorr_sweep2_kernel<3, true>, H2_LDS_BYTES);
+            hipLaunchKernelGGL((softcorr_sweep2_kernel<3, true>), dim3(blocks), dim3(HB_THREADS), H2_LDS_BYTES, s, b);
         } else {
             ensure_dyn_lds((const void *)softcorr_sweep2_kernel<1, true>, H2_LDS_BYTES);
             hipLaunchKernelGGL((softcorr_sweep2_kernel<1, true>), dim3(blocks), dim3(HB_THREADS), H2_LDS_BYTES, s, b);
@@ -573,6 +626,9 @@ void launch_sweep2(const HBArgs &a, const char *knf0, const char *knf1, const in
     } else if (form == 3) {
         ensure_dyn_lds((const void *)softcorr_sweep2_kernel<2>, H2_LDS_BYTES);
         hipLaunchKernelGGL((softcorr_sweep2_kernel<2>), dim3(blocks), dim3(HB_THREADS), H2_LDS_BYTES, s, b);
+    } else if (form == 4) {
+        ensure_dyn_lds((const void *)softcorr_sweep2_kernel<3>, H2_LDS_BYTES);
+        hipLaunchKernelGGL((softcorr_sweep2_kernel<3>), dim3(blocks), dim3(HB_THREADS), H2_LDS_BYTES, s, b);
     } else {
         ensure_dyn_lds((const void *)softcorr_sweep2_kernel<1>, H2_LDS_BYTES);
         hipLaunchKernelGGL((softcorr_sweep2_kernel<1>), dim3(blocks), dim3(HB_THREADS), H2_LDS_BYTES, s, b);

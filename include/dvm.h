@@ -53,7 +53,7 @@ int dvm_device_count(void);
  * kernel time and bracket count of one slot (dvm_profile_read = slot DVM_PROF_K1_SWEEP); disable
  * closes the window.  dvm_profile_select chooses which slots record (bit k = slot k; default:
  * the sweep only, so the timed region of bench.py carries two event records per step). */
-#define DVM_PROF_K1_SWEEP 0   /* softcorr_sweep_f16_kernel (pass A of K1) */
+#define DVM_PROF_K1_SWEEP 0   /* pass A of K1: softcorr_sweep2_kernel, or softcorr_sweep_f16_kernel where the probe routes */
 #define DVM_PROF_K1_REFINE 1  /* softcorr_refine_kernel (pass B: exact re-evaluation) */
 #define DVM_PROF_MLP 2        /* mlp_f16x2_kernel (Deformer MLP) */
 #define DVM_PROF_CHAMFER 3    /* grid_chamfer_kernel */

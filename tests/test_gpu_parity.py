@@ -7,6 +7,8 @@ most of them far tighter.
 import glob
 import zlib
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -16,6 +18,7 @@ from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def names(prefix):
@@ -92,6 +95,44 @@ def test_softcorr_writes_every_output_slot(ops):
         torch.cuda.synchronize()
         del junk
         check_softcorr(ops, f1, f2, 40.0, variant)
+
+
+@pytest.mark.parametrize("alpha", [33.0, 100.0, 150.0])
+def test_softcorr_routed_sweeps_vs_oracle(ops, alpha):
+    """Pass A is chosen per launch by the probe (dvm_softcorr_f16.hip::k1_probe_kernel): on the "trained-like" feature set
+    (0.3 relu(N(0,1)): tight distance spread) the three alphas below take the three kernels (full / lean first form, second
+    form — profiles/r3_route_calib.txt).  Whatever the route, the result is the oracle's: columns exact, values to 5e-5.
+    (Which route runs is checked by test_softcorr_probe_routes below; here the results are compared.)"""
+    rng = np.random.default_rng(int(alpha))
+    f1 = (0.3 * np.maximum(rng.standard_normal((2048, 128)), 0)).astype(np.float32)
+    f2 = (0.3 * np.maximum(rng.standard_normal((2048, 128)), 0)).astype(np.float32)
+    check_softcorr(ops, f1, f2, alpha, 3)
+
+
+def test_softcorr_probe_routes():
+    """The probe's choice on the two synthetic feature sets of SURVEY 8d, read from the DVM_K1_ROUTE_DEBUG report of a child
+    process (the policy is read once per process): random features -> second form at every alpha >= 32; trained-like
+    features -> full first form at alpha 33, lean first form at 100, second form at 150."""
+    code = (
+        "import os, sys, torch\n"
+        "sys.path.insert(0, os.path.join(%r, 'dv-matcher_amd'))\n"
+        "from dvm import ops\n"
+        "g = torch.Generator().manual_seed(3)\n"
+        "for kind in ('randn', 'trained'):\n"
+        "    f1, f2 = torch.randn(8, 2048, 128, generator=g).cuda(), torch.randn(8, 2048, 128, generator=g).cuda()\n"
+        "    if kind == 'trained': f1, f2 = 0.3 * torch.relu(f1), 0.3 * torch.relu(f2)\n"
+        "    for alpha in (33.0, 100.0, 150.0):\n"
+        "        ops.softcorr(f1, f2, alpha, topk=10, variant=3)\n"
+        "torch.cuda.synchronize()\n" % ROOT)
+    env = dict(os.environ, DVM_K1_ROUTE_DEBUG="1")
+    env.pop("DVM_K1_ROUTE", None), env.pop("DVM_K1_SWEEP", None), env.pop("DVM_K1_ROUTE_P", None)
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stderr.splitlines() if ln.startswith("K1 routes:")]
+    assert len(lines) == 6, res.stderr[-2000:]
+    want = ["0 full, 0 lean, 8 second"] * 3 + ["8 full, 0 lean, 0 second", "0 full, 8 lean, 0 second", "0 full, 0 lean, 8 second"]
+    for ln, w in zip(lines, want):
+        assert w in ln, (ln, w)
 
 
 def test_softcorr_duplicate_rows(ops):
