@@ -15,6 +15,7 @@
 // Integer outputs (top-k columns, arg-max map) are thus bit-exact by construction, not by luck.
 // (reference: models/loss.py:110-114, 1339-1347, 1404-1407)
 #include <stdlib.h>
+#include <type_traits>
 
 #include "dvm_softcorr_f16.h"
 
@@ -440,32 +441,98 @@ struct HRArgs {
     int topk;
 };
 
-__global__ __launch_bounds__(256) void softcorr_refine_kernel(const HRArgs args) {
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E) (DPP controls must be constants)
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+// Three forms of the exact evaluation (FORM; DVM_K1_REFINE selects; measurements: profiles/r3_refine_pmc.txt, 512 pairs x 2):
+// 0  (shipped) every lane streams its own candidate row (32 x 16 B): 2.18 ms.  The wave gathers 48 rows x 512 B; the launch
+//    moves 12.9 GB from L2 to the CUs = 5.9 TB/s, the rate MI355X_MICROARCH.md measures for random whole rows of a buffer far
+//    larger than the Infinity Cache (5.5 - 5.8 TB/s).  A load instruction touches 48 rows: 1 900 64-B L1 accesses per wave,
+//    TA_BUSY 88 - 100 %.
+// 2  the 16 lanes of a row as a systolic chain (below): contiguous 512-B rows per load, no LDS, bit-identical chains: 2.20 ms
+//    with eight steps of rows in flight per lane (3.15 ms as the scheduler orders the loads).  32 B per lane at a 32-B stride
+//    still costs two 64-B accesses per four lanes and the chain's fill and drain steps load as well: 2 180 L1 accesses per
+//    wave, TA_BUSY 80 %, L1 misses 1.71e8 -> 1.08e8 (no line is fetched twice).
+// 1  persistent waves, rows through LDS: the wave's 4 x 12 candidate rows and 4 query rows come by LDS-DMA, two whole rows per
+//    instruction (16 full 64-B accesses each, 416 per wave), the 16-B chunks of a row XOR-swizzled with its slot number on
+//    the source address; each lane then runs the chain over ITS row from LDS (conflict-free: 16 slots spread over the 8 chunk
+//    positions of a bank row).  26 KiB of LDS per wave = 6 waves per CU: 2.87 ms with one quad per wave (three dependent
+//    memory round trips per wave), 2.58 ms with persistent waves that request the NEXT quad's lists, norms and partial sums
+//    together with the DMA of the current one, 2.46 ms with every XCD walking its own contiguous eighth of the rows (a
+//    pair's 1 MiB of key rows then stays in that XCD's L2).  7 us per quad and wave: 156 KB in flight per CU do not cover
+//    the round trip at this rate.
+// All three give bit-identical results; none beats the plain form, which is at the gather rate of the memory system: the
+// way to make pass B cheaper is fewer gathered bytes, not a different access shape.
+constexpr int HR_AHEAD = 8;                                              // systolic form: steps of rows in flight per lane
+constexpr int HR_SLOTS = 4 * HB_KC;                                      // candidate rows of a wave
+constexpr int HR_LDS_BYTES = (HR_SLOTS + 4) * HB_D * (int)sizeof(float);   // + the 4 query rows
+struct HRRow {     // what a lane needs of its row before the candidate rows can be requested
+    long row;      // within the group
+    int grp, jc;
+    bool rvalid;
+    float va, na, nkm, ls0, ls1;
+};
+template <int FORM>
+__global__ __launch_bounds__(FORM == 1 ? 64 : 256) void softcorr_refine_kernel(const HRArgs args) {
+    __shared__ __attribute__((aligned(16))) char hr_lds[FORM == 1 ? HR_LDS_BYTES : 16];
     const int lane = threadIdx.x & 63, l16 = lane & 15, base = lane & 48;
+    const float neg_alpha = args.neg_alpha;
+    const int topk = args.topk;
+    const bool cand = l16 < HB_KC;
     // (XCD-aware block numbering — a pair's rows on one XCD, so that its 2048 key rows stay in one L2 — was measured neutral,
     // 2.15 vs 2.19 ms: what the other seven L2s miss is served by the Infinity Cache)
-    long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const bool rvalid = row < args.rows_total;
-    if (!rvalid) row = args.rows_total - 1;
-    const int grp = row >= args.rows0 ? 1 : 0;
-    row -= grp ? args.rows0 : 0;
-    const HRGroup &G = args.g[grp];
-    const int N = G.N, M = G.M;
-    const int b = (int)(row / N);
-    const float neg_alpha = args.neg_alpha;
-    const bool cand = l16 < HB_KC;
-    const int jc = cand ? G.cidx[row * HB_KC + l16] : 0x7fffffff;
+    auto fetch = [&](long grow) __attribute__((always_inline)) {   // grow: row number over both groups
+        HRRow p;
+        p.rvalid = grow < args.rows_total;
+        if (!p.rvalid) grow = args.rows_total - 1;
+        p.grp = grow >= args.rows0 ? 1 : 0;
+        p.row = grow - (p.grp ? args.rows0 : 0);
+        const HRGroup &G = args.g[p.grp];
+        p.jc = cand ? G.cidx[p.row * HB_KC + l16] : 0x7fffffff;
+        p.va = cand ? G.cd2[p.row * HB_KC + l16] : INFINITY;
+        p.na = G.nq[p.row];
+        p.nkm = G.nkmax[p.row / G.N];
+        p.ls0 = G.lsum[p.row * 2];
+        p.ls1 = G.lsum[p.row * 2 + 1];
+        return p;
+    };
+    const long nquads = (args.rows_total + 3) / 4;
+    // Form 1: workgroup i runs on XCD i % 8; every XCD walks ITS contiguous eighth of the quads, its waves side by side — so the
+    // 192 waves of an XCD are inside one pair's rows at any time and that pair's 1 MiB of key rows stays in the XCD's L2.
+    long quad, qend, qstep;
+    if (FORM == 1) {
+        const long per = (nquads + 7) / 8, x = blockIdx.x & 7;
+        quad = x * per + (blockIdx.x >> 3);
+        qend = (x + 1) * per < nquads ? (x + 1) * per : nquads;
+        qstep = gridDim.x >> 3;
+    } else {   // one quad per wave
+        quad = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+        qend = nquads;
+        qstep = nquads;
+    }
+    if (quad >= qend) return;
+    HRRow cur = fetch(quad * 4 + (lane >> 4));
+    for (; quad < qend; quad += qstep) {
+    const HRRow p = cur;
+    const HRGroup &G = args.g[p.grp];
+    const long row = p.row;
+    const int M = G.M;
+    const int b = (int)(row / G.N);
+    const int jc = p.jc;
     const bool valid = cand && jc >= 0 && jc < M;
     // (empty slots — fewer than 12 columns, M < 12 — rank behind every column and among themselves by slot, so that every
     // output position below topk is written: with one shared "no column" value they would all take the same rank)
     const int j = valid ? jc : (0x7fffff00 | l16);
-    const float na = G.nq[row];
-    // (bandwidth-bound on the 12 x 512 B gathered rows per query — 3.2 GB per 256 pairs; staging them through LDS
-    // as whole 128-B segments was measured slower than each lane streaming its own row)
-    const int topk = args.topk;
+    const float na = p.na;
     const int need = topk < M ? topk : M;        // entries that must be exact
-    const float delta = HB_ERR * (na + G.nkmax[b]);
-    const float va = valid ? G.cd2[row * HB_KC + l16] : INFINITY;
+    const float delta = HB_ERR * (na + p.nkm);
+    const float va = valid ? p.va : INFINITY;
     // Candidates beyond the `need`-th whose approximate distance exceeds the need-th's by more than the error band
     // cannot rank among the first `need` (their exact value is above every one of those): their rows are not fetched
     // (usually the two margin candidates: 1/6 of the gather) and they keep their approximate softmax term.
@@ -473,7 +540,105 @@ __global__ __launch_bounds__(256) void softcorr_refine_kernel(const HRArgs args)
     const bool skip = valid && l16 >= need && va > va_need + 2.f * delta;
     const bool eval = valid && !skip;
     float v = INFINITY;
-    if (eval) v = exact_d2(G.q + (size_t)row * HB_D, G.k + ((size_t)b * M + j) * HB_D, na, G.nk[(size_t)b * M + j]);
+    if (FORM == 0) {
+        if (eval) v = exact_d2(G.q + (size_t)row * HB_D, G.k + ((size_t)b * M + j) * HB_D, na, G.nk[(size_t)b * M + j]);
+    } else if (FORM == 2) {
+        // The 16 lanes of a row as a systolic chain: lane l holds dims [8 l, 8 l + 8) of the query (times -2) and, at step t,
+        // the same dims of candidate t - l; it continues that candidate's fma chain (the accumulator arrives from lane l - 1
+        // by a DPP shift) and hands it on.  Candidate c leaves lane 15 after step c + 15 with the reference's k-ordered chain
+        // — bit for bit what one lane computes alone.
+        constexpr int ROW_SHR1 = 0x111, ROW_SHARE0 = 0x150;
+        const float *const kbat = G.k + (size_t)b * M * HB_D + 8 * l16, *const qpc = G.q + (size_t)row * HB_D + 8 * l16;
+        const f32x4 qa = *(const f32x4 *)qpc, qb = *(const f32x4 *)(qpc + 4);
+        const float qs[8] = {-2.f * qa.x, -2.f * qa.y, -2.f * qa.z, -2.f * qa.w, -2.f * qb.x, -2.f * qb.y, -2.f * qb.z, -2.f * qb.w};
+        const int jj = eval ? j : -1;   // (a candidate that is not evaluated reads the query piece instead: a line already here)
+        // The piece of step t + HR_AHEAD is requested at step t (the column numbers run ahead of the chain; scheduling barriers
+        // keep the requests where they are written: left alone, the scheduler holds two or three steps in flight — 3.15 ms).
+        constexpr int NS = HB_KC + 15;
+        int J = -1;
+        float acc = 0.f;
+        f32x4 ka[NS], kb4[NS];
+        auto request = [&](auto tc) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc)::value;
+            const int inj = t < HB_KC ? __builtin_amdgcn_update_dpp(0, jj, ROW_SHARE0 + (t < HB_KC ? t : 0), 0xf, 0xf, false) : -1;
+            J = __builtin_amdgcn_update_dpp(inj, J, ROW_SHR1, 0xf, 0xf, false);   // lane 0 takes the new candidate, lane l lane l - 1's
+            const float *src = J >= 0 ? kbat + (size_t)J * HB_D : qpc;
+            ka[t] = *(const f32x4 *)src;
+            kb4[t] = *(const f32x4 *)(src + 4);
+        };
+        static_for<0, HR_AHEAD>(request);
+        static_for<0, NS>([&](auto tc) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc)::value;
+            if constexpr (t + HR_AHEAD < NS) request(std::integral_constant<int, t + HR_AHEAD>{});
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), ROW_SHR1, 0xf, 0xf, false));   // lane 0 starts at 0
+            acc = fmaf(qs[0], ka[t].x, acc);
+            acc = fmaf(qs[1], ka[t].y, acc);
+            acc = fmaf(qs[2], ka[t].z, acc);
+            acc = fmaf(qs[3], ka[t].w, acc);
+            acc = fmaf(qs[4], kb4[t].x, acc);
+            acc = fmaf(qs[5], kb4[t].y, acc);
+            acc = fmaf(qs[6], kb4[t].z, acc);
+            acc = fmaf(qs[7], kb4[t].w, acc);
+            if (t >= 15) {
+                const float fin = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), ROW_SHARE0 + 15, 0xf, 0xf, false));
+                v = l16 == t - 15 ? fin : v;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (eval) {
+            const float d2 = (v + na) + G.nk[(size_t)b * M + j];
+            v = d2 > 0.f ? d2 : 0.f;
+        } else {
+            v = INFINITY;
+        }
+    } else {   // FORM == 1
+        const int h = lane >> 5, r32 = lane & 31;
+        const float *const kptr = eval ? G.k + ((size_t)b * M + j) * HB_D : nullptr;   // nullptr: the row is not fetched
+        const float *const qptr = G.q + (size_t)row * HB_D;
+        const unsigned klo = (unsigned)(uintptr_t)kptr, khi = (unsigned)((uintptr_t)kptr >> 32);
+        const unsigned qlo = (unsigned)(uintptr_t)qptr, qhi = (unsigned)((uintptr_t)qptr >> 32);
+        // slot s = 12 g + c holds candidate c of the wave's row g; instruction i brings slots 2 i (lanes 0-31) and 2 i + 1
+#pragma unroll
+        for (int i = 0; i < HR_SLOTS / 2; ++i) {
+            const int sa = 2 * i, sb = 2 * i + 1;
+            const int la = (sa / HB_KC) * 16 + sa % HB_KC, lb = (sb / HB_KC) * 16 + sb % HB_KC;   // the lanes that own them
+            const unsigned alo = __builtin_amdgcn_readlane(klo, la), ahi = __builtin_amdgcn_readlane(khi, la);
+            const unsigned blo = __builtin_amdgcn_readlane(klo, lb), bhi = __builtin_amdgcn_readlane(khi, lb);
+            const char *src = (const char *)(((uintptr_t)(h ? bhi : ahi) << 32) | (h ? blo : alo));
+            const int slot = 2 * i + h;
+            if (src)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + ((r32 ^ (slot & 31)) << 4)),
+                                                 (__attribute__((address_space(3))) void *)(hr_lds + i * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {   // query rows of the row groups 2 i and 2 i + 1, chunk p of group g at position p ^ g
+            const unsigned alo = __builtin_amdgcn_readlane(qlo, 32 * i), ahi = __builtin_amdgcn_readlane(qhi, 32 * i);
+            const unsigned blo = __builtin_amdgcn_readlane(qlo, 32 * i + 16), bhi = __builtin_amdgcn_readlane(qhi, 32 * i + 16);
+            const char *src = (const char *)(((uintptr_t)(h ? bhi : ahi) << 32) | (h ? blo : alo));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + ((r32 ^ (2 * i + h)) << 4)),
+                                             (__attribute__((address_space(3))) void *)(hr_lds + (HR_SLOTS / 2 + i) * 1024), 16, 0, 0);
+        }
+        const float nb = eval ? G.nk[(size_t)b * M + j] : 0.f;
+        if (quad + qstep < qend) cur = fetch((quad + qstep) * 4 + (lane >> 4));   // the next quad's lists ride on this round trip
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wave's own pieces have landed (one wave per workgroup: no barrier)
+        if (eval) {
+            const int g = lane >> 4, slot = g * HB_KC + l16;
+            const char *krow = hr_lds + slot * (HB_D * 4), *qrow = hr_lds + (HR_SLOTS + g) * (HB_D * 4);
+            const int ks = slot & 31;
+            float acc = 0.f;
+#pragma unroll 8
+            for (int c = 0; c < HB_D / 4; ++c) {
+                const f32x4 qv = *(const f32x4 *)(qrow + ((c ^ g) << 4)), kv = *(const f32x4 *)(krow + ((c ^ ks) << 4));
+                acc = fmaf(-2.f * qv.x, kv.x, acc);
+                acc = fmaf(-2.f * qv.y, kv.y, acc);
+                acc = fmaf(-2.f * qv.z, kv.z, acc);
+                acc = fmaf(-2.f * qv.w, kv.w, acc);
+            }
+            const float d2 = (acc + na) + nb;
+            v = d2 > 0.f ? d2 : 0.f;
+        }
+    }
     const float de = eval ? sqrt_rn(v) : INFINITY;
     int rank = 0;
 #pragma unroll
@@ -492,7 +657,7 @@ __global__ __launch_bounds__(256) void softcorr_refine_kernel(const HRArgs args)
     float esum = ex;
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) esum += __shfl_xor(esum, o, 64);
-    const float lsm = G.lsum[row * 2] * exp2f((G.lsum[row * 2 + 1] - smax) * LOG2E) + esum;
+    const float lsm = p.ls0 * exp2f((p.ls1 - smax) * LOG2E) + esum;
     // certification: every column that was not evaluated exactly — outside the list, or skipped — has approximate
     // d2 >= theta
     float vlast = (rank == need - 1) ? v : -INFINITY;  // exact d2 of the last needed entry
@@ -506,18 +671,18 @@ __global__ __launch_bounds__(256) void softcorr_refine_kernel(const HRArgs args)
     }
     const float theta = fminf(tmax, tskip);
     const bool certain = (M <= HB_KC) || (vlast < theta - 2.f * delta);
-    if (!rvalid) return;
-    if (!certain) {
-        if (l16 == 0) G.flagged[atomicAdd(G.nflagged, 1)] = (int32_t)row;
-        return;  // the exact kernel writes this row
+    if (p.rvalid && !certain) {
+        if (l16 == 0) G.flagged[atomicAdd(G.nflagged, 1)] = (int32_t)row;   // the exact kernel writes this row
+    } else if (p.rvalid) {
+        if (cand && rank < topk && !skip) {
+            G.val[row * topk + rank] = valid ? ex / lsm : 0.f;
+            G.idx[row * topk + rank] = valid ? j : 0;
+        }
+        if (l16 == 0) {
+            if (G.smax) G.smax[row] = smax;
+            if (G.sum) G.sum[row] = lsm;
+        }
     }
-    if (cand && rank < topk && !skip) {
-        G.val[row * topk + rank] = valid ? ex / lsm : 0.f;
-        G.idx[row * topk + rank] = valid ? j : 0;
-    }
-    if (l16 == 0) {
-        if (G.smax) G.smax[row] = smax;
-        if (G.sum) G.sum[row] = lsm;
     }
 }
 
@@ -915,7 +1080,20 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
     r.neg_alpha = neg_alpha;
     r.topk = topk;
     prof_begin(s, DVM_PROF_K1_REFINE);
-    hipLaunchKernelGGL(softcorr_refine_kernel, dim3((unsigned)((r.rows_total * 16 + 255) / 256)), dim3(256), 0, s, r);
+    static const int rform = [] { const char *e = getenv("DVM_K1_REFINE"); return e ? atoi(e) : 0; }();   // (A/B measurements)
+    static const int refine_waves = [] {   // persistent form: 6 single-wave workgroups of 26 KiB LDS fit a CU
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return cus * 6;
+    }();
+    const long nquads = (r.rows_total + 3) / 4;
+    if (rform == 1)
+        hipLaunchKernelGGL(softcorr_refine_kernel<1>, dim3((unsigned)refine_waves), dim3(64), 0, s, r);   // (a multiple of 8)
+    else if (rform == 0)
+        hipLaunchKernelGGL(softcorr_refine_kernel<0>, dim3((unsigned)((r.rows_total * 16 + 255) / 256)), dim3(256), 0, s, r);
+    else
+        hipLaunchKernelGGL(softcorr_refine_kernel<2>, dim3((unsigned)((r.rows_total * 16 + 255) / 256)), dim3(256), 0, s, r);
     prof_end(s, DVM_PROF_K1_REFINE);
 
     HXArgs x;
