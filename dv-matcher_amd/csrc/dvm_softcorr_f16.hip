@@ -439,6 +439,7 @@ struct HRArgs {
     long rows_total;
     float neg_alpha;
     int topk;
+    int remap;        // forms 0 and 2: XCD-aware block numbering (measurement switch)
 };
 
 // compile-time loop: f(std::integral_constant<int, I>) for I in [B, E) (DPP controls must be constants)
@@ -512,7 +513,7 @@ __global__ __launch_bounds__(FORM == 1 ? 64 : 256) void softcorr_refine_kernel(c
         qend = (x + 1) * per < nquads ? (x + 1) * per : nquads;
         qstep = gridDim.x >> 3;
     } else {   // one quad per wave
-        quad = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+        quad = ((long)(args.remap ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
         qend = nquads;
         qstep = nquads;
     }
@@ -1088,9 +1089,10 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
         return cus * 6;
     }();
     const long nquads = (r.rows_total + 3) / 4;
+    r.remap = rform >= 10;
     if (rform == 1)
         hipLaunchKernelGGL(softcorr_refine_kernel<1>, dim3((unsigned)refine_waves), dim3(64), 0, s, r);   // (a multiple of 8)
-    else if (rform == 0)
+    else if (rform % 10 == 0)
         hipLaunchKernelGGL(softcorr_refine_kernel<0>, dim3((unsigned)((r.rows_total * 16 + 255) / 256)), dim3(256), 0, s, r);
     else
         hipLaunchKernelGGL(softcorr_refine_kernel<2>, dim3((unsigned)((r.rows_total * 16 + 255) / 256)), dim3(256), 0, s, r);
