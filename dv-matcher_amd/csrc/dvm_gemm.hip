@@ -65,10 +65,18 @@ static int gemm_kblocks(int K, int *starts) {
     return n;
 }
 
-template <bool CM, int WM, int WN, int TM, int TN>
+// DMA (point-major only, every K-block a multiple of the k-step, no row prefix): both operand tiles go global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, no ds_write, the next k-step lands while this one's matrix instructions
+// run), rows in their natural [row][32 k] layout, the 16-byte chunks of a row XOR-swizzled with the row number on the SOURCE
+// address; a lane reads its two operands of a chunk (k = 4 c + h and 4 c + 2 + h) with one ds_read2_b32 — the inner loop holds
+// matrix instructions and LDS reads only.
+template <bool CM, int WM, int WN, int TM, int TN, bool DMA = false>
 __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a) {
+    static_assert(!DMA || !CM, "the DMA staging is for K-contiguous operands");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int QSZ = CM ? GK * BN : BN * GLD;
+    constexpr int DMA_BUF = (BM + BN) * GK;          // floats of one buffer: [P rows | Q rows][32]
+    constexpr int DMA_NI = (BM + BN) / 8 / 4;          // 1-KiB pieces (8 rows) per wave and k-step
     constexpr int PL = BM / 32;                     // f32x4 chunks of P per thread and k-step
     constexpr int QL = CM ? (GK * BN / 4) / 256 : BN / 32;
     // two LDS buffers per operand: the next k-step is written while the current one is read, one barrier per step
@@ -169,6 +177,30 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a) {
             qfast[u] = Q + (size_t)j * K + 4 * c;
         }
     }
+    const float *dsrc[DMA ? DMA_NI : 1];   // DMA: this lane's source of piece e (row 8 (wave NI + e) + lane / 8 of [P rows | Q rows])
+    int roff[DMA ? 8 : 1];                 // DMA: byte offset of chunk c in this lane's operand rows: r32 * 128 + ((c ^ (r32 & 7)) << 4) + 4 h
+    if (DMA) {
+#pragma unroll
+        for (int e = 0; e < DMA_NI; ++e) {
+            const int gr = 8 * (wave * DMA_NI + e) + (lane >> 3), c = (lane & 7) ^ (lane >> 3);
+            if (gr < BM) {
+                const int i = i0 + gr < I ? i0 + gr : I - 1;
+                dsrc[e] = P + (size_t)i * a.ldp + 4 * c;
+            } else {
+                const int j = j0 + gr - BM < J ? j0 + gr - BM : J - 1;
+                dsrc[e] = Q + (size_t)j * K + 4 * c;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) roff[c] = r32 * 128 + ((c ^ (r32 & 7)) << 4) + 4 * h;
+    }
+    auto dma_issue = [&](int k0, int buf) {
+        char *dst = (char *)lds_gemm + (size_t)buf * DMA_BUF * 4 + wave * DMA_NI * 1024;
+#pragma unroll
+        for (int e = 0; e < (DMA ? DMA_NI : 0); ++e)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(dsrc[e] + k0),
+                                             (__attribute__((address_space(3))) void *)(dst + e * 1024), 16, 0, 0);
+    };
     const bool q_interior = !CM || (a.qvec && j0 + BN <= J);
     auto fetch_step = [&](int k0, int kend) {
         const int Cg = CM ? 0 : a.Cg;
@@ -216,6 +248,7 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
     float *__restrict__ Y = a.Y + (size_t)b * a.y_bs;
+    f32x16 tot[DMA ? TM : 1][DMA ? TN : 1];   // DMA: running total over the closed K-blocks
 
     // Flat walk over the k-steps of all K-blocks.  Step s+1's global loads are issued before step s's MFMAs and written to
     // the other LDS buffer after them; the single barrier at the end of a step both publishes that buffer and retires the
@@ -224,8 +257,13 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a) {
     // wait — two per k-step at the head of the loop in the first version; the current block's end and the next one's are
     // carried in registers and re-read only when a block closes)
     int blk = 0, k0 = a.kb[0], kend = a.kb[1], cur = 0;
-    fetch_step(k0, kend);
-    stage(0);
+    if (DMA) {
+        dma_issue(k0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave waits for ITS pieces, then the barrier publishes them
+    } else {
+        fetch_step(k0, kend);
+        stage(0);
+    }
     __syncthreads();
     while (blk < a.nkb) {
         int nblk = blk, nk = k0 + GK, nkend = kend;
@@ -235,8 +273,33 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a) {
             if (nblk < a.nkb) nkend = a.kb[nblk + 1];
         }
         const bool has_next = nblk < a.nkb;
-        if (has_next) fetch_step(nk, nkend);
-        {
+        if (has_next) {
+            if (DMA) dma_issue(nk, cur ^ 1); else fetch_step(nk, nkend);   // (the other buffer was last read before the previous barrier)
+        }
+        if (DMA) {
+            const char *const Pl = (const char *)lds_gemm + (size_t)cur * DMA_BUF * 4 + wm * TM * 32 * 128;
+            const char *const Ql = (const char *)lds_gemm + (size_t)cur * DMA_BUF * 4 + (BM + wn * TN * 32) * 128;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float av[TM][2], bv[TN][2];
+#pragma unroll
+                for (int x = 0; x < TM; ++x) {
+                    const float *ap = (const float *)(Pl + x * 32 * 128 + roff[c]);
+                    av[x][0] = ap[0], av[x][1] = ap[2];
+                }
+#pragma unroll
+                for (int y = 0; y < TN; ++y) {
+                    const float *bp = (const float *)(Ql + y * 32 * 128 + roff[c]);
+                    bv[y][0] = bp[0], bv[y][1] = bp[2];
+                }
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int x = 0; x < TM; ++x)
+#pragma unroll
+                        for (int y = 0; y < TN; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[y][e], av[x][e], acc[x][y], 0, 0, 0);
+            }
+        } else {
             const float *const Ps = Ps0 + cur * BM * GLD, *const Qs = Qs0 + cur * QSZ;
             // the inner loop is MFMA + ds_read only: on gfx950 the fp32 matrix instruction and the vector ALU share the
             // issue slot, so every VALU instruction in here would cost matrix time.  All fragments of the k-step are
@@ -282,7 +345,20 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a) {
                 }
             }
         }
-        if (a.nkb > 1 && nblk != blk) {
+        if (DMA && a.nkb > 1 && nblk != blk) {
+            // close the block: total += block, restart the chain at 0 — the DMA form has the registers for a second accumulator set
+            const bool last = blk == a.nkb - 1;
+#pragma unroll
+            for (int x = 0; x < TM; ++x)
+#pragma unroll
+                for (int y = 0; y < TN; ++y)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float t = blk ? tot[DMA ? x : 0][DMA ? y : 0][r] + acc[x][y][r] : acc[x][y][r];
+                        tot[DMA ? x : 0][DMA ? y : 0][r] = t;
+                        acc[x][y][r] = last ? t : 0.f;
+                    }
+        } else if (a.nkb > 1 && nblk != blk) {
             // close the block: total += block, restart the chain at 0.  The running total lives in the output buffer
             // between blocks (every lane re-reads exactly the words it wrote) instead of a second accumulator set — 16
             // registers per tile that the large tiles do not have; 2 extra passes over the output at K = 1152.
@@ -315,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a) {
                     }
                 }
         }
-        if (has_next) stage(cur ^ 1);
+        if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else if (has_next) stage(cur ^ 1);
         __syncthreads();
         cur ^= 1;
         blk = nblk;
@@ -391,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a) {
         }
 }
 
-template <bool CM, int WM, int WN, int TM, int TN>
+template <bool CM, int WM, int WN, int TM, int TN, bool DMA = false>
 static void launch_cfg(LinArgs &a, int B, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     a.tiles_i = (a.I + BM - 1) / BM;
@@ -400,9 +476,9 @@ static void launch_cfg(LinArgs &a, int B, hipStream_t s) {
                            (uintptr_t)a.beta | (uintptr_t)((size_t)a.y_bs * sizeof(float));
     a.yvec = (a.ldy % 4 == 0 && bits % 16 == 0) ? 1 : 0;
     constexpr int QSZ = CM ? GK * BN : BN * GLD;
-    constexpr size_t lds = (size_t)2 * (BM * GLD + QSZ) * sizeof(float);
-    ensure_dyn_lds((const void *)linear_mfma_kernel<CM, WM, WN, TM, TN>, (int)lds);
-    hipLaunchKernelGGL((linear_mfma_kernel<CM, WM, WN, TM, TN>), dim3((unsigned)(a.tiles_i * a.tiles_j), (unsigned)B), dim3(256), lds, s, a);
+    constexpr size_t lds = DMA ? (size_t)2 * (BM + BN) * GK * sizeof(float) : (size_t)2 * (BM * GLD + QSZ) * sizeof(float);
+    ensure_dyn_lds((const void *)linear_mfma_kernel<CM, WM, WN, TM, TN, DMA>, (int)lds);
+    hipLaunchKernelGGL((linear_mfma_kernel<CM, WM, WN, TM, TN, DMA>), dim3((unsigned)(a.tiles_i * a.tiles_j), (unsigned)B), dim3(256), lds, s, a);
 }
 
 // Tile choice (measured on MI355X at 16384 points, tools/bench_linear_cfg.py; us for conv 1152->384 / conv0 384->64 /
@@ -415,12 +491,18 @@ static void launch_cfg(LinArgs &a, int B, hipStream_t s) {
 struct TileCfg {
     int wm, wn, tm, tn;
 };
-static int pick_cfg(int n, long rows_out_narrow) {
+// Point-major with LDS-DMA staging (round 3, profiles/r3_linear_cfg.txt; same shapes, us, register staging 64x64 -> DMA 64x64 /
+// 128x64 / 64x128 / 128x128): conv 1152->384: 161 -> 133 / 131 / 129 / 163; conv1 256->512: 52 -> 47 / 53 / 51 / 46; qkv128: 27 -> 24;
+// conv6 512->128: 30 -> 28; the 64-wide layers unchanged (10 - 16 us: launch- and epilogue-bound).  What the DMA form removes: the
+// staging registers and their ds_write instructions (102 -> 61 VGPRs at 64x64), and the K-block totals' round trips through the
+// output buffer (they live in a second accumulator set).  Default: DMA 64x64, DMA 64x128 from K = 768 on.
+static int pick_cfg(int n, long rows_out_narrow, int K = 0) {
     if (const char *force = getenv("DVM_LINEAR_CFG")) {
         const int c = atoi(force);
         if (c >= 0 && c < n) return c;
     }
-    return rows_out_narrow <= 32 ? 0 : 1;
+    if (rows_out_narrow <= 32) return 0;
+    return n > 4 ? (K >= 768 ? 6 : 4) : 1;
 }
 
 void launch_linear(const float *x, const float *w, int B, int N, int K, int Co, int channel_major, const float *bias,
@@ -436,11 +518,19 @@ void launch_linear(const float *x, const float *w, int B, int N, int K, int Co, 
         if (a.kb[i] % 4) a.kvec = 0;
     if (!channel_major) {
         a.P = x, a.Q = w, a.I = B * N, a.J = Co, a.q_bs = 0, a.y_bs = 0, a.ldy = Co, a.qvec = 1;
-        switch (pick_cfg(4, Co)) {   // {4,1,1,1} 128x32, {2,2,1,1} 64x64, {2,2,1,2} 64x128, {2,2,2,2} 128x128
+        bool dma_ok = a.kvec && !a.G && ((uintptr_t)x | (uintptr_t)w) % 16 == 0;
+        for (int i = 0; i <= a.nkb; ++i) dma_ok = dma_ok && a.kb[i] % GK == 0;
+        int cfg = pick_cfg(8, Co, K);
+        if (cfg >= 4 && !dma_ok) cfg -= 4;
+        switch (cfg) {   // {4,1,1,1} 128x32, {2,2,1,1} 64x64, {2,2,1,2} 64x128, {2,2,2,2} 128x128; 4..7: LDS-DMA staging, 64x64 / 128x64 / 64x128 / 128x128
             case 0: launch_cfg<false, 4, 1, 1, 1>(a, 1, s); break;
             case 1: launch_cfg<false, 2, 2, 1, 1>(a, 1, s); break;
             case 2: launch_cfg<false, 2, 2, 1, 2>(a, 1, s); break;
-            default: launch_cfg<false, 2, 2, 2, 2>(a, 1, s); break;
+            case 3: launch_cfg<false, 2, 2, 2, 2>(a, 1, s); break;
+            case 4: launch_cfg<false, 2, 2, 1, 1, true>(a, 1, s); break;
+            case 5: launch_cfg<false, 2, 2, 2, 1, true>(a, 1, s); break;
+            case 6: launch_cfg<false, 2, 2, 1, 2, true>(a, 1, s); break;
+            default: launch_cfg<false, 2, 2, 2, 2, true>(a, 1, s); break;
         }
     } else {
         a.P = w, a.Q = x, a.I = Co, a.J = N, a.q_bs = (long)K * N, a.y_bs = (long)Co * N, a.ldy = N, a.qvec = (N % 4 == 0);
