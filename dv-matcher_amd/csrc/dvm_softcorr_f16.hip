@@ -1088,7 +1088,6 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         return cus * 6;
     }();
-    const long nquads = (r.rows_total + 3) / 4;
     r.remap = rform >= 10;
     if (rform == 1)
         hipLaunchKernelGGL(softcorr_refine_kernel<1>, dim3((unsigned)refine_waves), dim3(64), 0, s, r);   // (a multiple of 8)

@@ -56,6 +56,8 @@ SIGNATURES = {
     "dvm_sa_attention_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, c_size_t, _P]),
     "dvm_pair_set_overlap": (c_int, [c_int]),
     "dvm_pair_init": (c_int, [_P]),
+    "dvm_uni3fc_fwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dvm_uni3fc_fwd_f32": (c_int, [_P, _P, c_int, c_int, _P, c_int, c_int, _P, _P, _P, c_size_t, _P]),
     "dvm_pair_destroy": (c_int, []),
     "dvm_argmin_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "dvm_argmin_exact_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),

@@ -824,6 +824,44 @@ def dist_loss_bwd_weights(feat, dist, anchors, idx, gout):
     return W
 
 
+U3_NWEIGHTS = 101
+
+
+def uni3fc_weight_table(tensors):
+    """The host array of DVM_U3_NWEIGHTS device pointers dvm_uni3fc_fwd_f32 takes (order: include/dvm.h) from a list of
+    fp32 CUDA tensors; returns (kept-alive tensors, ctypes array)."""
+    import ctypes
+    ts = [_f(t) for t in tensors]
+    if len(ts) != U3_NWEIGHTS:
+        raise DvmError("uni3fc_weight_table: %d tensors, expected %d" % (len(ts), U3_NWEIGHTS))
+    _need_gpu(*ts)
+    return ts, (ctypes.c_void_p * U3_NWEIGHTS)(*[t.data_ptr() for t in ts])
+
+
+def uni3fc_forward(table, x, dino, k=40):
+    """LG-Net's eval-mode forward in ONE native call (dvm_uni3fc_fwd_f32): x (B,3,N), dino (B,N,1152) -> feat (B,N,128),
+    tmp (B,N,64).  `table` = uni3fc_weight_table(...)."""
+    import ctypes
+    _need_gpu(x, dino)
+    x, dino = _f(x), _f(dino)
+    B, _, N = x.shape
+    if tuple(dino.shape) != (B, N, 1152):
+        raise DvmError("uni3fc_forward: dino features %s, expected %s" % (tuple(dino.shape), (B, N, 1152)))
+    lib = _lib.load()
+    dev = x.device
+    feat = torch.empty(B, N, 128, dtype=torch.float32, device=dev)
+    tmp = torch.empty(B, N, 64, dtype=torch.float32, device=dev)
+    nb = lib.dvm_uni3fc_fwd_workspace_bytes(B, N, int(k))
+    ws = workspace(nb, dev, "uni3fc")
+    ctx = (dev.index, _stream())
+    if ctx not in _pair_ctx:   # helper stream / events for this (device, stream): made once, outside the compute call
+        check(lib.dvm_pair_init(_stream()), "dvm_pair_init")
+        _pair_ctx.add(ctx)
+    check(lib.dvm_uni3fc_fwd_f32(_p(x), _p(dino), B, N, ctypes.cast(table[1], ctypes.c_void_p), U3_NWEIGHTS, int(k), _p(feat), _p(tmp),
+                                 _p(ws), nb, _stream()), "dvm_uni3fc_fwd_f32")
+    return feat, tmp
+
+
 def pair_forward(wl, feat1, feat2, verts1, verts2, alpha, start1, start2, with_map=True, out=None):
     """Config-2 path for B pairs, BOTH directions in one call.
     Returns (out12, out21), each dict(warped, verts12, T12, losses[B,6])."""

@@ -393,6 +393,10 @@ class Uni3FC(nn.Module, _VisualProjection):
         neighbour rows are contiguous for the gather kernels, nothing is transposed between layers.  (Training keeps the
         reference's (B,C,N) layout: there MIOpen's BatchNorm kernels want it and the step is GEMM/launch-bound.)"""
         B, _, N = x.shape
+        if os.environ.get("DVM_NATIVE_FWD", "1") == "1" and x.is_cuda and not getattr(self, "sync_minmax", False):
+            # the same launches, enqueued by ONE native call (dvm_uni3fc_fwd_f32): no Python between the ~250 kernels
+            with torch.no_grad():
+                return ops.uni3fc_forward(self._native_table(), x, dino_feat.contiguous(), self.k)
         with torch.no_grad():
             blk = lambda seq, xt, **kw: _conv_bn_pm(seq[0], seq[1], xt, seq[2].negative_slope, **kw)  # noqa: E731
             f = blk(self.conv, dino_feat)
@@ -419,6 +423,28 @@ class Uni3FC(nn.Module, _VisualProjection):
             y4 = self.n2p_attention7.infer_pm(y3)
             out = blk(self.conv6, torch.cat((y1, y2, y3, y4), dim=-1))
             return out.contiguous().view(B, N, self.out), tmp
+
+    def _native_table(self):
+        """The weight table of dvm_uni3fc_fwd_f32 (order: include/dvm.h), rebuilt when a parameter or a BatchNorm statistic was
+        written: conv weights as they are, every eval-mode BatchNorm folded by _bn_affine, q | k | v stacked."""
+        convs = (self.conv, self.conv0, self.conv1, self.conv2, self.conv3, self.conv4, self.conv5, self.conv6)
+        sas = (self.sa1, self.sa2, self.sa3, self.sa4)
+        n2ps = (self.n2p_attention1, self.n2p_attention2, self.n2p_attention3, self.n2p_attention4, self.n2p_attention5,
+                self.n2p_attention6, self.n2p_attention7)
+
+        def build():
+            ts = []
+            for seq in convs:
+                ts += [seq[0].weight.reshape(seq[0].weight.shape[0], -1), *_bn_affine(seq[1])]
+            for sa in sas:
+                ts += [sa.k_conv.weight.reshape(16, 64), sa.v_conv.weight.reshape(64, 64), sa.v_conv.bias,
+                       sa.trans_conv.weight.reshape(64, 64), sa.trans_conv.bias, *_bn_affine(sa.after_norm)]
+            for m in n2ps:
+                C = m.q_conv.weight.shape[0]
+                ts += [torch.cat([m.q_conv.weight.reshape(C, C), m.k_conv.weight.reshape(C, C), m.v_conv.weight.reshape(C, C)], 0),
+                       *_bn_affine(m.bn1), m.ff[0].weight.reshape(4 * C, C), m.ff[2].weight.reshape(C, 4 * C), *_bn_affine(m.bn2)]
+            return ops.uni3fc_weight_table([t.detach() for t in ts])
+        return _folded(self, "native_table", [t for t in list(self.parameters()) + list(self.buffers())], build)
 
     def _forward_train_pm(self, x, dino_feat):
         """Autograd forward with activations kept point-major (B,N,C), the layout dino_feat arrives in and the kNN /

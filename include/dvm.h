@@ -420,6 +420,27 @@ int dvm_pair_fwd_f32(const float *feat1, const float *feat2, const float *verts1
                      float *verts12, int32_t *T12, float *losses12, float *warped21, float *verts21, int32_t *T21,
                      float *losses21, void *ws, size_t ws_bytes, void *stream);
 
+/* ---- LG-Net, the whole eval-mode forward in one call (reference models/model.py:680-761 `Uni3FC.forward` with
+ * torch.no_grad() / model.eval(); layers 506-529, N2P blocks 325-395, SA_Layer 97-123).  xyz [B][3][N] coordinates, dino
+ * [B][N][1152] per-point visual features -> feat [B][N][128], tmp [B][N][64] (the second return value of the reference's
+ * forward).  Every layer is one of this library's own launches, enqueued natively in the order of the reference's forward:
+ * the same kernels and operands as dv-matcher_amd/models/model.py::Uni3FC._forward_infer, ~250 launches without a Python call
+ * in between.  k = neighbours of the N2P blocks (the reference's 40).  With a context from dvm_pair_init(stream) the global
+ * (self-attention) chain runs on the context's helper stream next to the local (kNN attention) chain.
+ * `weights`: DVM_U3_NWEIGHTS device pointers, fp32, in this order (W = conv weight [Co][K]; alpha, beta = the eval-mode
+ * BatchNorm folded as ATen's CPU kernel evaluates it, y = fma(x, alpha, beta), alpha = w / sqrt(var + eps), beta =
+ * fma(-mean, alpha, b) — dv-matcher_amd/models/model.py::_bn_affine):
+ *   8 conv blocks {W, alpha, beta}: conv (1152->384), conv0 (384->64), conv1 (256->512), conv2 (256->512),
+ *     conv3 (768->128), conv4 (768->128), conv5 (256->128), conv6 (512->128)                                  [0 .. 23]
+ *   4 SA layers sa1..sa4 {k_conv W [16][64], v_conv W [64][64], v_conv bias, trans_conv W [64][64], trans_conv bias,
+ *     after_norm alpha, after_norm beta}                                                                      [24 .. 51]
+ *   7 N2P blocks n2p_attention1..7 (C = 64 x 4, 128 x 3) {stacked q|k|v W [3C][C], bn1 alpha, bn1 beta, ff[0] W [4C][C],
+ *     ff[2] W [C][4C], bn2 alpha, bn2 beta}                                                                   [52 .. 100] */
+#define DVM_U3_NWEIGHTS 101
+size_t dvm_uni3fc_fwd_workspace_bytes(int B, int N, int k);
+int dvm_uni3fc_fwd_f32(const float *xyz, const float *dino, int B, int N, const float *const *weights, int nweights, int k,
+                       float *feat, float *tmp, void *ws, size_t ws_bytes, void *stream);
+
 /* dvm_pair_fwd_f32 can run its coordinate-only chain (FPS, graph, xyz kNN: latency-bound) on helper streams, forked
  * from and joined back into `stream` by events, next to the feature-only soft-correspondence chain.  The helper streams
  * and events are NOT created by the compute call: dvm_pair_init(stream) makes them for (current device, `stream`) —

@@ -78,6 +78,7 @@ def test_uni3fc_teacher_forced(golden, monkeypatch, name, mode):
     net = _net(g, mode)
     tap = KnnTap(ops, forced=g["knn_idx"])
     monkeypatch.setattr(ops, "knn_neg", tap)
+    monkeypatch.setenv("DVM_NATIVE_FWD", "0")   # the tap sits on the Python-level op: take the layer-by-layer path (== the native call, bit for bit: test_native_forward_is_the_python_path)
     B, _, N = g["xyz"].shape
     with torch.no_grad():
         feat, cf = net(dev(g["xyz"]), dino_from_seed(int(g["dino_seed"]), B, N).cuda(), None)
@@ -109,6 +110,7 @@ def test_uni3fc_free_running_stable_regime(golden, monkeypatch):
     net = _net(g, "eval")
     tap = KnnTap(ops)
     monkeypatch.setattr(ops, "knn_neg", tap)
+    monkeypatch.setenv("DVM_NATIVE_FWD", "0")   # the tap sits on the Python-level op: take the layer-by-layer path (== the native call, bit for bit: test_native_forward_is_the_python_path)
     B, _, N = g["xyz"].shape
     with torch.no_grad():
         feat, cf = net(dev(g["xyz"]), dino_from_seed(int(g["dino_seed"]), B, N).cuda(), None)
@@ -191,6 +193,7 @@ def _train_step(golden, name, monkeypatch, forced):
                                      partial=False, w_deform=0.5, w_img=0, w_rank=0, w_self_rec=0.5, w_cd=0.1, w_arap=0.01, save_name="t")
     tap = KnnTap(ops, forced=g["knn_idx"] if forced else None)
     monkeypatch.setattr(ops, "knn_neg", tap)
+    monkeypatch.setenv("DVM_NATIVE_FWD", "0")   # the tap sits on the Python-level op: take the layer-by-layer path (== the native call, bit for bit: test_native_forward_is_the_python_path)
     v1, v2 = dev(g["verts1"]), dev(g["verts2"])
     B, N, _ = v1.shape
     random.seed(9001)
@@ -387,6 +390,7 @@ def test_uni3fc_full_size_against_the_oracle(monkeypatch, B, N):
         return idx
 
     monkeypatch.setattr(ops, "knn_neg", tap)
+    monkeypatch.setenv("DVM_NATIVE_FWD", "0")   # the tap sits on the Python-level op: take the layer-by-layer path (== the native call, bit for bit: test_native_forward_is_the_python_path)
     with torch.no_grad():
         feat, cf = net(x.cuda(), dino.cuda(), None)
     assert len(acts) == 7
@@ -402,6 +406,53 @@ def test_uni3fc_full_size_against_the_oracle(monkeypatch, B, N):
         ah = a[0].cpu().numpy()
         want = O.knn_neg(ah[rows], ah, 40)
         assert np.array_equal(idx[0].cpu().numpy()[rows], want), layer
+
+
+@pytest.mark.parametrize("B,N", [(2, 700), (8, 2048), (1, 4995), (3, 41)])
+def test_native_forward_is_the_python_path(monkeypatch, B, N):
+    """dvm_uni3fc_fwd_f32 — LG-Net's eval forward as ONE C-ABI call (the default) — enqueues the launches of
+    `Uni3FC._forward_infer`'s layer-by-layer Python path with the same operands: both outputs bit-identical, at the bench
+    shapes, a ragged one and one with N barely above k.  (The oracle comparisons of this file therefore hold for either.)"""
+    import models.model as mm
+    torch.manual_seed(B * 1000 + N)
+    net = reinit(mm.Uni3FC(k=40), salt=11).cuda().eval()
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(0, 0.3), m.running_var.uniform_(0.5, 1.5), m.weight.uniform_(0.7, 1.3), m.bias.normal_(0, 0.2)
+    x, dino = torch.rand(B, 3, N).cuda(), torch.randn(B, N, 1152).cuda()
+    monkeypatch.setenv("DVM_NATIVE_FWD", "0")
+    with torch.no_grad():
+        ref, rtmp = net(x, dino, None)
+    monkeypatch.setenv("DVM_NATIVE_FWD", "1")
+    with torch.no_grad():
+        out, otmp = net(x, dino, None)
+        assert torch.equal(otmp, rtmp) and torch.equal(out, ref)
+        # a parameter written in place reaches the native call's weight table
+        net.conv6[0].weight.mul_(0.5)
+        net.bn6.running_var.mul_(1.7)
+        out2, _ = net(x, dino, None)
+        monkeypatch.setenv("DVM_NATIVE_FWD", "0")
+        ref2, _ = net(x, dino, None)
+    assert torch.equal(out2, ref2) and not torch.equal(out2, out)
+
+
+def test_native_forward_errors_are_loud():
+    from dvm import ops, _lib
+    from dvm.ops import DvmError
+    x, dino = torch.rand(1, 3, 64).cuda(), torch.randn(1, 64, 1152).cuda()
+    with pytest.raises(DvmError):
+        ops.uni3fc_weight_table([torch.zeros(4).cuda()] * 7)
+    ts, arr = ops.uni3fc_weight_table([torch.zeros(4).cuda()] * ops.U3_NWEIGHTS)
+    with pytest.raises(DvmError):
+        ops.uni3fc_forward((ts, arr), x, dino[:, :32], 40)               # feature rows != points
+    lib = _lib.load()
+    import ctypes
+    rc = lib.dvm_uni3fc_fwd_f32(x.data_ptr(), dino.data_ptr(), 1, 64, ctypes.cast(arr, ctypes.c_void_p), ops.U3_NWEIGHTS, 40, dino.data_ptr(),
+                                dino.data_ptr(), None, 0, None)
+    assert rc != 0 and b"workspace" in lib.dvm_last_error()
+    rc = lib.dvm_uni3fc_fwd_f32(x.data_ptr(), dino.data_ptr(), 1, 64, ctypes.cast(arr, ctypes.c_void_p), 7, 40, dino.data_ptr(), dino.data_ptr(), None, 0, None)
+    assert rc != 0 and b"weight table" in lib.dvm_last_error()
 
 
 def test_folded_cache_invalidation():
