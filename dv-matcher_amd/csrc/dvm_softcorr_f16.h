@@ -94,6 +94,10 @@ struct HBGroup {
     int32_t *cidx;           // [B][N][HB_KC]
     float *cd2;              // [B][N][HB_KC] approximate squared distances, ascending
     float *lsum;             // [B][N][2] = (sum exp(s - cref), cref)
+    // second form only — key slices (the feature kNN, dvm_knn_f16.hip): the M keys of a batch entry are cut into `kslices`
+    // slices of Ms keys (Ms a multiple of the key tile; the last one may be shorter), each swept as its own launch entry with
+    // its own candidate lists: outputs [B][kslices][N][...], columns relative to the slice
+    int kslices = 1, Ms = 0;
 };
 struct HBArgs {
     HBGroup g[2];

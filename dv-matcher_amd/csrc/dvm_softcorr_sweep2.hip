@@ -49,6 +49,7 @@ struct H2Group {
     int N, M, Mpad, tiles;
     int32_t *cidx;
     float *cd2, *lsum;
+    int kslices, Ms;          // see HBGroup
 };
 struct H2Args {
     H2Group g[2];
@@ -153,15 +154,17 @@ __global__ __launch_bounds__(HB_THREADS) void softcorr_sweep2_kernel(const H2Arg
     const int grp = lid >= args.blocks0 ? 1 : 0;
     lid -= grp ? args.blocks0 : 0;
     const H2Group &G = args.g[grp];
-    const int N = G.N, M = G.M;
-    const int b = lid / G.tiles, qt = lid % G.tiles;
+    const int N = G.N;
+    const int bs = lid / G.tiles, qt = lid % G.tiles;                 // launch entry = (batch entry, key slice)
+    const int b = bs / G.kslices, sl = bs - b * G.kslices;            // (one slice: bs == b, sl == 0)
+    const int M = G.kslices > 1 ? min(G.Ms, G.M - sl * G.Ms) : G.M;   // keys swept by this workgroup
     if (args.route && args.route[grp * args.nb + b] != K1_ROUTE_SECOND) return;   // this pair goes through the first form
     const float neg_alpha = args.neg_alpha;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave: a scalar register)
     const int r32 = lane & 31, h = lane >> 5;
 
-    const char *kbase = G.kp + (size_t)b * M * HB_ROWB;
-    const char *nfbase = G.knf + (size_t)b * G.Mpad * 32;
+    const char *kbase = G.kp + ((size_t)b * G.M + (size_t)sl * G.Ms) * HB_ROWB;
+    const char *nfbase = G.knf + ((size_t)b * G.Mpad + (size_t)sl * G.Ms) * 32;
     const int qrow = qt * HB_QB + wave * 32 + r32;
     const int qrc = qrow < N ? qrow : N - 1;
     const char *qptr = G.qp + ((size_t)b * N + qrc) * HB_ROWB + 16 * h;
@@ -546,7 +549,7 @@ __global__ __launch_bounds__(HB_THREADS) void softcorr_sweep2_kernel(const H2Arg
         for (int t = 0; t < HB_KC; ++t) add_term(entry_key(kb.insert(other[t])));  // dropped from the union
     }
     if (h == 0 && qrow < N) {
-        const size_t row = (size_t)b * N + qrow;
+        const size_t row = (size_t)bs * N + qrow;
 #pragma unroll
         for (int t = 0; t < HB_KC; ++t) {
             const unsigned key = entry_key(kb.e[t]), r = key & 15;
@@ -575,7 +578,7 @@ void launch_sweep2(const HBArgs &a, const char *knf0, const char *knf1, const in
     H2Args b;
     for (int g = 0; g < 2; ++g) {
         const HBGroup &G = a.g[g];
-        b.g[g] = H2Group{G.qp, G.kp, g == 0 ? knf0 : knf1, G.nq, G.N, G.M, G.Mpad, G.tiles, G.cidx, G.cd2, G.lsum};
+        b.g[g] = H2Group{G.qp, G.kp, g == 0 ? knf0 : knf1, G.nq, G.N, G.M, G.Mpad, G.tiles, G.cidx, G.cd2, G.lsum, G.kslices, G.Ms};
     }
     b.amax = amaxc;
     b.blocks0 = a.blocks0;
