@@ -98,6 +98,105 @@ __global__ __launch_bounds__(KS_THREADS, 2) void knn_scores_mfma_kernel(const fl
     }
 }
 
+// The same scores with the key tiles brought by LDS-DMA (round 3; shipped for C = 128, the form above for C = 64):
+// two alternating buffers of 64 keys in their natural [key][D] layout, the 16-byte chunks of a row XOR-swizzled with the row
+// number on the SOURCE address, the next tile requested before this tile's matrix instructions; a lane reads its two operands
+// of a chunk (k = 4 c + h and 4 c + 2 + h) with one ds_read2_b32.  No staging registers, no ds_write, one barrier per tile.
+// Same k-ordered chain per (query, key), same bits.
+template <int D>
+__global__ __launch_bounds__(KS_THREADS, 2) void knn_scores_dma_kernel(const float *__restrict__ a, const float *__restrict__ bq,
+                                                                      const float *__restrict__ na, const float *__restrict__ nb,
+                                                                      int N, int M, int kchunk, float *__restrict__ S) {
+    constexpr int H = D / 2, ROWB = D * 4, TILEB = KS_KT * ROWB, NI = TILEB / 1024 / 4;   // 1-KiB pieces per wave and tile
+    constexpr int RPI = 1024 / ROWB, CPR = ROWB / 16;                                     // rows per piece, chunks per row
+    extern __shared__ __attribute__((aligned(16))) char ks_lds[];   // [2][64 keys][D] + [2][64] norms
+    float *const kn0 = (float *)(ks_lds + 2 * TILEB);
+    const int b = blockIdx.y, qt = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r32 = lane & 31, h = lane >> 5;
+    const int qrow = qt * KS_QB + wave * 32 + r32;
+    const int qrc = qrow < N ? qrow : N - 1;
+    const float *qp = a + ((size_t)b * N + qrc) * D;
+    float q[H];
+#pragma unroll
+    for (int c = 0; c < D / 4; ++c) {
+        f32x4 v = *(const f32x4 *)(qp + 4 * c);
+        q[2 * c] = h ? v.y : v.x;
+        q[2 * c + 1] = h ? v.w : v.z;
+    }
+    float nq[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int row = qt * KS_QB + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        nq[r] = na[(size_t)b * N + (row < N ? row : N - 1)];
+    }
+    const float *kb = bq + (size_t)b * M * D;
+    const float *nbb = nb + (size_t)b * M;
+    const int jbeg = blockIdx.z * kchunk, jend = jbeg + kchunk < M ? jbeg + kchunk : M;
+    // this lane's part of a piece: row lr of the piece, source chunk (position ^ row) — the row number's low bits are the
+    // same for every piece (a piece starts on a multiple of RPI rows, RPI | 8 ... only RPI <= 8 rows per piece)
+    const int lr = lane / CPR, lc = lane % CPR;
+    auto stage = [&](int j0, int buf) {
+        char *dst = ks_lds + buf * TILEB + wave * NI * 1024;
+#pragma unroll
+        for (int e = 0; e < NI; ++e) {
+            const int r = (wave * NI + e) * RPI + lr;                 // key row of the tile
+            const int j = j0 + r < M ? j0 + r : M - 1;                // (rows past the end: the last key again, never stored)
+            const float *src = kb + (size_t)j * D + 4 * (lc ^ (r & 7));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(dst + e * 1024), 16, 0, 0);
+        }
+        if (wave == 0) {
+            const int j = j0 + lane < M ? j0 + lane : M - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(nbb + j),
+                                             (__attribute__((address_space(3))) void *)(kn0 + buf * KS_KT), 4, 0, 0);
+        }
+    };
+    int roff[8];   // byte offset of chunk c (mod 8) in this lane's key row, first operand
+#pragma unroll
+    for (int c = 0; c < 8; ++c) roff[c] = ((c ^ (r32 & 7)) << 4) + 4 * h;
+    int cur = 0;
+    stage(jbeg, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int j0 = jbeg; j0 < jend; j0 += KS_KT) {
+        if (j0 + KS_KT < jend) stage(j0 + KS_KT, cur ^ 1);   // (the other buffer was last read before the previous barrier)
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const char *krow = ks_lds + cur * TILEB + (sub * 32 + r32) * ROWB;
+            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c0 = 0; c0 < D / 4; c0 += 8) {
+                float k0[8], k1[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float *p = (const float *)(krow + (c0 / 8) * 128 + roff[c]);
+                    k0[c] = p[0], k1[c] = p[2];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q[2 * (c0 + c)], k0[c], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q[2 * (c0 + c) + 1], k1[c], acc, 0, 0, 0);
+                }
+            }
+            const int j = j0 + sub * 32 + r32;
+            const float nbj = kn0[cur * KS_KT + sub * 32 + r32];
+            if (j < M) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int row = qt * KS_QB + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    float inner = -2.f * acc[r];
+                    float s = (-nq[r] - inner) - nbj;
+                    if (row < N) S[((size_t)b * N + row) * M + j] = s;
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
 // generic-C scalar scores (any C): thread per (query, key tile)
 __global__ __launch_bounds__(128) void knn_scores_scalar_kernel(const float *__restrict__ a, const float *__restrict__ bq,
                                                                 const float *__restrict__ na, const float *__restrict__ nb, int N,
@@ -1015,7 +1114,20 @@ int launch_knn_neg(const float *a, const float *bq, int B, int N, int M, int C, 
     while (B * qtiles * nz < 1024 && nz * 2 <= ktiles) nz *= 2;
     const int kchunk = ((ktiles + nz - 1) / nz) * KS_KT;
     nz = (M + kchunk - 1) / kchunk;
-    if (C == 128)
+    // measured at 8 x 2048 / 1 x 4995 points, scores + top-k per call: C = 128: 187 -> 171 us / 184 -> 163 us with the DMA form;
+    // C = 64: 130 -> 137 us (half the bytes per key: the register path already hides them) — so C = 128 only by default
+    // (DVM_KNN_SCORES_DMA = 0: never, 2: both widths)
+    static const int dma_mode = [] { const char *e = getenv("DVM_KNN_SCORES_DMA"); return e ? atoi(e) : 1; }();
+    const bool dma = dma_mode == 2 || (dma_mode == 1 && C == 128);
+    if (C == 128 && dma) {
+        constexpr int lds = 2 * KS_KT * 128 * 4 + 2 * KS_KT * 4;
+        ensure_dyn_lds((const void *)knn_scores_dma_kernel<128>, lds);
+        hipLaunchKernelGGL(knn_scores_dma_kernel<128>, dim3(qtiles, B, nz), dim3(KS_THREADS), lds, s, a, bq, na, nb, N, M, kchunk, S);
+    } else if (C == 64 && dma) {
+        constexpr int lds = 2 * KS_KT * 64 * 4 + 2 * KS_KT * 4;
+        ensure_dyn_lds((const void *)knn_scores_dma_kernel<64>, lds);
+        hipLaunchKernelGGL(knn_scores_dma_kernel<64>, dim3(qtiles, B, nz), dim3(KS_THREADS), lds, s, a, bq, na, nb, N, M, kchunk, S);
+    } else if (C == 128)
         hipLaunchKernelGGL(knn_scores_mfma_kernel<128>, dim3(qtiles, B, nz), dim3(KS_THREADS), 0, s, a, bq, na, nb, N, M, kchunk, S);
     else if (C == 64)
         hipLaunchKernelGGL(knn_scores_mfma_kernel<64>, dim3(qtiles, B, nz), dim3(KS_THREADS), 0, s, a, bq, na, nb, N, M, kchunk, S);
