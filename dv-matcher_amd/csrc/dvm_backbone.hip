@@ -378,10 +378,23 @@ __global__ __launch_bounds__(256) void topk_wave_kernel(const float *__restrict_
     const float *s = S + row * M;
     unsigned key[EPL];
     unsigned m1 = 0xffffffffu, m2 = 0xffffffffu;
+    // all EPL loads are requested before the first is used: the index is clamped instead of the load being predicated (a
+    // conditional load is a branch around a load + wait: the row arrived in 32 dependent round trips, 63 us per layer)
+    float sv[EPL];
+    if (M == EPL * 64) {   // (wave-uniform) full rows: one base register, immediate offsets, EPL loads back to back
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) sv[e] = s[e * 64 + lane];
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int j = e * 64 + lane;
+            sv[e] = s[j < M ? j : M - 1];
+        }
+    }
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
         const int j = e * 64 + lane;
-        const unsigned x = j < M ? desc_key(s[j]) : 0xffffffffu;
+        const unsigned x = j < M ? desc_key(sv[e]) : 0xffffffffu;
         key[e] = x;
         m2 = min(m2, max(m1, x));
         m1 = min(m1, x);
@@ -419,7 +432,7 @@ __global__ __launch_bounds__(256) void topk_wave_kernel(const float *__restrict_
                 const int e = __ffs(pm) - 1;
                 pm &= pm - 1;
                 const int j = e * 64 + lane;
-                const unsigned x = j < M ? desc_key(s[j]) : 0xffffffffu;  // re-read (L1 hit): no dynamic register index
+                const unsigned x = j < M ? desc_key(s[j < M ? j : M - 1]) : 0xffffffffu;  // re-read (L1 hit): no dynamic register index
                 cw[pos++] = ((unsigned long long)x << 32) | (unsigned)j;
             }
         }
@@ -466,10 +479,10 @@ __global__ __launch_bounds__(256) void topk_wave_stream_kernel(const float *__re
     const int E = (M + 63) / 64;
     const unsigned long long below = (1ull << lane) - 1ull;
     unsigned m1 = 0xffffffffu, m2 = 0xffffffffu;
-#pragma unroll 4
+#pragma unroll 8
     for (int e = 0; e < E; ++e) {
         const int j = e * 64 + lane;
-        const unsigned x = j < M ? desc_key(s[j]) : 0xffffffffu;
+        const unsigned x = j < M ? desc_key(s[j < M ? j : M - 1]) : 0xffffffffu;   // (clamped, not predicated: see topk_wave_kernel)
         m2 = min(m2, max(m1, x));
         m1 = min(m1, x);
     }
@@ -486,7 +499,7 @@ __global__ __launch_bounds__(256) void topk_wave_stream_kernel(const float *__re
 #pragma unroll 4
     for (int e = 0; e < E; ++e) {  // optimistic: at most 128 keys pass unless the row has heavy ties
         const int j = e * 64 + lane;
-        const unsigned x = j < M ? desc_key(s[j]) : 0xffffffffu;
+        const unsigned x = j < M ? desc_key(s[j < M ? j : M - 1]) : 0xffffffffu;   // (clamped, not predicated: see topk_wave_kernel)
         const bool take = x <= T && j < M;
         const unsigned long long mt = __ballot(take);
         const int pos = base + __popcll(mt & below);
@@ -500,7 +513,7 @@ __global__ __launch_bounds__(256) void topk_wave_stream_kernel(const float *__re
             int cnt = 0;
             for (int e = 0; e < E; ++e) {
                 const int j = e * 64 + lane;
-                const unsigned x = j < M ? desc_key(s[j]) : 0xffffffffu;
+                const unsigned x = j < M ? desc_key(s[j < M ? j : M - 1]) : 0xffffffffu;   // (clamped, not predicated: see topk_wave_kernel)
                 cnt += __popcll(__ballot(x < c));
             }
             if (cnt < k) T = c;
@@ -508,7 +521,7 @@ __global__ __launch_bounds__(256) void topk_wave_stream_kernel(const float *__re
         int lt = 0;
         for (int e = 0; e < E; ++e) {
             const int j = e * 64 + lane;
-            const unsigned x = j < M ? desc_key(s[j]) : 0xffffffffu;
+            const unsigned x = j < M ? desc_key(s[j < M ? j : M - 1]) : 0xffffffffu;   // (clamped, not predicated: see topk_wave_kernel)
             lt += __popcll(__ballot(x < T));
         }
         const int ties = k - lt;
@@ -518,7 +531,7 @@ __global__ __launch_bounds__(256) void topk_wave_stream_kernel(const float *__re
         int tbase = 0;
         for (int e = 0; e < E; ++e) {
             const int j = e * 64 + lane;
-            const unsigned x = j < M ? desc_key(s[j]) : 0xffffffffu;
+            const unsigned x = j < M ? desc_key(s[j < M ? j : M - 1]) : 0xffffffffu;   // (clamped, not predicated: see topk_wave_kernel)
             const bool eq = x == T && j < M;
             const unsigned long long meq = __ballot(eq);
             const int teq = tbase + __popcll(meq & below);
