@@ -577,14 +577,32 @@ __global__ __launch_bounds__(256) void map_term_nbr_kernel(const float *__restri
         const size_t row = (size_t)b * N + i;
         const float *nb2 = nbr2 + (size_t)b * M * k * 3 + 3 * s;
         float acc[3] = {0.f, 0.f, 0.f};
+        if (topk == TOPK) {   // (uniform) the usual case without predicates: columns and weights, then all gathers, then the chain
+            int col[TOPK];
+            float w[TOPK], px[TOPK], py[TOPK], pz[TOPK];
 #pragma unroll
-        for (int t = 0; t < TOPK; ++t) {
-            if (t < topk) {
-                const float *p = nb2 + (size_t)pi_idx[row * topk + t] * k * 3;
-                const float w = pi_val[row * topk + t];
-                acc[0] = fmaf(w, p[0], acc[0]);
-                acc[1] = fmaf(w, p[1], acc[1]);
-                acc[2] = fmaf(w, p[2], acc[2]);
+            for (int t = 0; t < TOPK; ++t) col[t] = pi_idx[row * TOPK + t], w[t] = pi_val[row * TOPK + t];
+#pragma unroll
+            for (int t = 0; t < TOPK; ++t) {
+                const float *p = nb2 + (size_t)col[t] * k * 3;
+                px[t] = p[0], py[t] = p[1], pz[t] = p[2];
+            }
+#pragma unroll
+            for (int t = 0; t < TOPK; ++t) {
+                acc[0] = fmaf(w[t], px[t], acc[0]);
+                acc[1] = fmaf(w[t], py[t], acc[1]);
+                acc[2] = fmaf(w[t], pz[t], acc[2]);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < TOPK; ++t) {
+                if (t < topk) {
+                    const float *p = nb2 + (size_t)pi_idx[row * topk + t] * k * 3;
+                    const float w = pi_val[row * topk + t];
+                    acc[0] = fmaf(w, p[0], acc[0]);
+                    acc[1] = fmaf(w, p[1], acc[1]);
+                    acc[2] = fmaf(w, p[2], acc[2]);
+                }
             }
         }
         const float *p12 = verts12 + ((size_t)b * N + idx11[row * k + s]) * 3;
