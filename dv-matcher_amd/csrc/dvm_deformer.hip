@@ -90,9 +90,12 @@ __global__ __launch_bounds__(256) void assemble_kernel(const float *__restrict__
     int pc[TOPK];
 #pragma unroll
     for (int t = 0; t < TOPK; ++t) {
-        bool live = t < topk;
-        pv[t] = live ? pi_val[row * topk + t] : 0.f;
-        pc[t] = live ? pi_idx[row * topk + t] : 0x7fffffff;
+        const bool live = t < topk;
+        const size_t o = row * topk + (live ? t : 0);   // (clamped, then selected: a predicated load is a branch and a wait)
+        const float pvt = pi_val[o];
+        const int pct = pi_idx[o];
+        pv[t] = live ? pvt : 0.f;
+        pc[t] = live ? pct : 0x7fffffff;
     }
     // insertion sort by column
 #pragma unroll
@@ -110,14 +113,27 @@ __global__ __launch_bounds__(256) void assemble_kernel(const float *__restrict__
     }
     const float *g2b = g2 + (size_t)b * M * DF_C;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (topk == TOPK) {   // (uniform) the usual case: all TOPK rows requested before the first is used (no predicated loads)
+        f32x4 f[TOPK];
 #pragma unroll
-    for (int t = 0; t < TOPK; ++t) {
-        if (t < topk) {
-            f32x4 f = *(const f32x4 *)(g2b + (size_t)pc[t] * DF_C + 4 * c4);
-            acc.x = fmaf(pv[t], f.x, acc.x);
-            acc.y = fmaf(pv[t], f.y, acc.y);
-            acc.z = fmaf(pv[t], f.z, acc.z);
-            acc.w = fmaf(pv[t], f.w, acc.w);
+        for (int t = 0; t < TOPK; ++t) f[t] = *(const f32x4 *)(g2b + (size_t)pc[t] * DF_C + 4 * c4);
+#pragma unroll
+        for (int t = 0; t < TOPK; ++t) {
+            acc.x = fmaf(pv[t], f[t].x, acc.x);
+            acc.y = fmaf(pv[t], f[t].y, acc.y);
+            acc.z = fmaf(pv[t], f[t].z, acc.z);
+            acc.w = fmaf(pv[t], f[t].w, acc.w);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < TOPK; ++t) {
+            if (t < topk) {
+                f32x4 f = *(const f32x4 *)(g2b + (size_t)pc[t] * DF_C + 4 * c4);
+                acc.x = fmaf(pv[t], f.x, acc.x);
+                acc.y = fmaf(pv[t], f.y, acc.y);
+                acc.z = fmaf(pv[t], f.z, acc.z);
+                acc.w = fmaf(pv[t], f.w, acc.w);
+            }
         }
     }
     float *zr = z + ((size_t)b * Nn + n) * DF_ZS;
@@ -149,9 +165,12 @@ __global__ __launch_bounds__(256) void assemble_pooled_kernel(const float *__res
     int pc[TOPK];
 #pragma unroll
     for (int t = 0; t < TOPK; ++t) {
-        bool live = t < topk;
-        pv[t] = live ? pi_val[row * topk + t] : 0.f;
-        pc[t] = live ? pi_idx[row * topk + t] : 0x7fffffff;
+        const bool live = t < topk;
+        const size_t o = row * topk + (live ? t : 0);   // (clamped, then selected: a predicated load is a branch and a wait)
+        const float pvt = pi_val[o];
+        const int pct = pi_idx[o];
+        pv[t] = live ? pvt : 0.f;
+        pc[t] = live ? pct : 0x7fffffff;
     }
 #pragma unroll
     for (int a = 1; a < TOPK; ++a) {
@@ -168,14 +187,27 @@ __global__ __launch_bounds__(256) void assemble_pooled_kernel(const float *__res
     }
     const float *gt = gtgt + (size_t)b * M * DF_C;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (topk == TOPK) {   // (uniform) the usual case: all TOPK rows requested before the first is used (no predicated loads)
+        f32x4 f[TOPK];
 #pragma unroll
-    for (int t = 0; t < TOPK; ++t) {
-        if (t < topk) {
-            f32x4 f = *(const f32x4 *)(gt + (size_t)pc[t] * DF_C + 4 * c4);
-            acc.x = fmaf(pv[t], f.x, acc.x);
-            acc.y = fmaf(pv[t], f.y, acc.y);
-            acc.z = fmaf(pv[t], f.z, acc.z);
-            acc.w = fmaf(pv[t], f.w, acc.w);
+        for (int t = 0; t < TOPK; ++t) f[t] = *(const f32x4 *)(gt + (size_t)pc[t] * DF_C + 4 * c4);
+#pragma unroll
+        for (int t = 0; t < TOPK; ++t) {
+            acc.x = fmaf(pv[t], f[t].x, acc.x);
+            acc.y = fmaf(pv[t], f[t].y, acc.y);
+            acc.z = fmaf(pv[t], f[t].z, acc.z);
+            acc.w = fmaf(pv[t], f[t].w, acc.w);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < TOPK; ++t) {
+            if (t < topk) {
+                f32x4 f = *(const f32x4 *)(gt + (size_t)pc[t] * DF_C + 4 * c4);
+                acc.x = fmaf(pv[t], f.x, acc.x);
+                acc.y = fmaf(pv[t], f.y, acc.y);
+                acc.z = fmaf(pv[t], f.z, acc.z);
+                acc.w = fmaf(pv[t], f.w, acc.w);
+            }
         }
     }
     float *zr = z + ((size_t)b * Nn + n) * DF_ZS;
