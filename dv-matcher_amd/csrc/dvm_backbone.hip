@@ -1011,11 +1011,18 @@ __device__ __forceinline__ void dist_rows128(const float *__restrict__ featb, co
                                              const int32_t *__restrict__ ix, int k, int lane, float (&xs)[8], float (&ys)[8]) {
     const int half = lane >> 5, l = lane & 31;
     const f32x4 q = *(const f32x4 *)(featb + (size_t)a * 128 + 4 * l);
+    int ixl[8];   // this lane's neighbour indices: j = lane + 64 u (clamped, not predicated: the loads go out together)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int j = lane + 64 * u;
+        ixl[u] = ix[j < k ? j : k - 1];
+    }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {   // the geodesic column entries: scattered 4-byte reads, all requested up front
         const int j = lane + 64 * u;
+        const float y = distb[(size_t)ixl[u] * N + a];
         xs[u] = 0.f;
-        ys[u] = j < k ? distb[(size_t)ix[j] * N + a] : 0.f;
+        ys[u] = j < k ? y : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -1024,7 +1031,10 @@ __device__ __forceinline__ void dist_rows128(const float *__restrict__ featb, co
         for (int jj = 0; jj < 64; jj += 2) {
             if (64 * u + jj >= k) break;
             const int j = 64 * u + jj + half;
-            const int v = ix[j < k ? j : k - 1];
+            // neighbour j's index from the lane that holds it (no load in the loop: the row gathers of an unrolled group are
+            // independent and go out together)
+            const int v0 = __builtin_amdgcn_readlane(ixl[u], jj), v1 = __builtin_amdgcn_readlane(ixl[u], jj + 1);
+            const int v = half ? v1 : v0;
             const f32x4 p = *(const f32x4 *)(featb + (size_t)v * 128 + 4 * l);
             const float d0 = p.x - q.x, d1 = p.y - q.y, d2 = p.z - q.z, d3 = p.w - q.w;
             float s2 = d0 * d0;
