@@ -131,10 +131,24 @@ __global__ __launch_bounds__(MH_THREADS) void mlp_f16x2_kernel(const float *__re
     int bad = 0;
 
     // stage z: scale, split into the two planes (columns 262..271 are zero)
-    for (int e = tid; e < MH_NODES * (MH_K0 / 4); e += MH_THREADS) {
+    // (all of a thread's 9 loads are requested before the first is used: row and column are clamped and the value selected —
+    // a predicated load is a branch around a load with a full wait in front of it, nine dependent round trips per workgroup)
+    constexpr int ZIT = (MH_NODES * (MH_K0 / 4) + MH_THREADS - 1) / MH_THREADS;
+    f32x4 zv[ZIT];
+#pragma unroll
+    for (int it = 0; it < ZIT; ++it) {
+        const int e = tid + it * MH_THREADS, ec = e < MH_NODES * (MH_K0 / 4) ? e : 0;
+        const int r = ec / (MH_K0 / 4), c = ec % (MH_K0 / 4);
+        const int rr = row0 + r < rows ? row0 + r : rows - 1, cc = 4 * c < MH_ZS ? 4 * c : MH_ZS - 4;
+        zv[it] = *(const f32x4 *)(z + (size_t)rr * MH_ZS + cc);
+    }
+#pragma unroll
+    for (int it = 0; it < ZIT; ++it) {
+        const int e = tid + it * MH_THREADS;
+        if (e >= MH_NODES * (MH_K0 / 4)) break;
         const int r = e / (MH_K0 / 4), c = e % (MH_K0 / 4);
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row0 + r < rows && 4 * c < MH_ZS) v = *(const f32x4 *)(z + (size_t)(row0 + r) * MH_ZS + 4 * c);
+        if (row0 + r < rows && 4 * c < MH_ZS) v = zv[it];
         char *p = bufZ + r * MH_SZ + 8 * c;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
