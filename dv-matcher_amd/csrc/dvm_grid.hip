@@ -51,15 +51,42 @@ __global__ __launch_bounds__(GRID_T) void grid_build_kernel(const float *__restr
     const int P = gb.P, G = gb.G, G3 = G * G * G;
     const float *p = xyz + (size_t)b * Nsrc * 3;
     const int32_t *sl = sel ? sel + (size_t)b * P : nullptr;
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int j = tid; j < P; j += GRID_T) {
-        int v = sl ? sl[j] : j;
-        for (int a = 0; a < 3; ++a) {
-            float c = p[3 * v + a];
-            mn[a] = fminf(mn[a], c);
-            mx[a] = fmaxf(mx[a], c);
+    // Up to GC points per thread (P <= 2048: every cloud and node set of the pair path) are read ONCE, all selections and then
+    // all coordinates in flight together; the three passes below (bounding box, cell counts, scatter) run on the registers.
+    // (As written first, each pass walked its points one dependent selection -> coordinate round trip at a time: ~48 round trips
+    // per workgroup, 46 us per call and 22 calls per step of the pair path.)
+    constexpr int GC = 8;
+    const bool cached = P <= GC * GRID_T;   // (uniform)
+    float px[GC], py[GC], pz[GC];
+    if (cached) {
+        int vs[GC];
+#pragma unroll
+        for (int q = 0; q < GC; ++q) {
+            const int j = tid + q * GRID_T, jc = j < P ? j : P - 1;
+            vs[q] = sl ? sl[jc] : jc;
         }
+#pragma unroll
+        for (int q = 0; q < GC; ++q) px[q] = p[3 * vs[q]], py[q] = p[3 * vs[q] + 1], pz[q] = p[3 * vs[q] + 2];
     }
+    auto each_point = [&](auto &&f) __attribute__((always_inline)) {   // f(j, x, y, z) for this thread's points j
+        if (cached) {
+#pragma unroll
+            for (int q = 0; q < GC; ++q) {
+                const int j = tid + q * GRID_T;
+                if (j < P) f(j, px[q], py[q], pz[q]);
+            }
+        } else {
+            for (int j = tid; j < P; j += GRID_T) {
+                const int v = sl ? sl[j] : j;
+                f(j, p[3 * v], p[3 * v + 1], p[3 * v + 2]);
+            }
+        }
+    };
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    each_point([&](int, float x, float y, float z) {
+        mn[0] = fminf(mn[0], x), mn[1] = fminf(mn[1], y), mn[2] = fminf(mn[2], z);
+        mx[0] = fmaxf(mx[0], x), mx[1] = fmaxf(mx[1], y), mx[2] = fmaxf(mx[2], z);
+    });
     for (int a = 0; a < 3; ++a) {
         for (int o = 32; o > 0; o >>= 1) {
             mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, 64));
@@ -94,10 +121,7 @@ __global__ __launch_bounds__(GRID_T) void grid_build_kernel(const float *__restr
         cz = cz < 0 ? 0 : (cz > G - 1 ? G - 1 : cz);
         return (cz * G + cy) * G + cx;
     };
-    for (int j = tid; j < P; j += GRID_T) {
-        int v = sl ? sl[j] : j;
-        atomicAdd(&lds[cell_of(p[3 * v], p[3 * v + 1], p[3 * v + 2])], 1);
-    }
+    each_point([&](int, float x, float y, float z) { atomicAdd(&lds[cell_of(x, y, z)], 1); });
     __syncthreads();
     // exclusive scan of G3 counts (each thread owns a contiguous chunk)
     const int chunk = (G3 + GRID_T - 1) / GRID_T;
@@ -127,13 +151,11 @@ __global__ __launch_bounds__(GRID_T) void grid_build_kernel(const float *__restr
     for (int c = tid; c <= G3; c += GRID_T) st[c] = lds[c];
     float4 *op = gb.pts + (size_t)b * P;
     int32_t *oi = gb.ids + (size_t)b * P;
-    for (int j = tid; j < P; j += GRID_T) {
-        int v = sl ? sl[j] : j;
-        float x = p[3 * v], y = p[3 * v + 1], z = p[3 * v + 2];
-        int pos = atomicAdd(&cursor[cell_of(x, y, z)], 1);
+    each_point([&](int j, float x, float y, float z) {
+        const int pos = atomicAdd(&cursor[cell_of(x, y, z)], 1);
         op[pos] = make_float4(x, y, z, sumsq3(x, y, z));
         oi[pos] = j;
-    }
+    });
 }
 
 __device__ __forceinline__ GridView grid_view(const GridBuf &gb, int b) {
