@@ -303,12 +303,14 @@ __global__ void common_absmax_kernel(const int *__restrict__ in, int *__restrict
 // list), or most of the row (flat rows, small alpha x small spread: the lean bookkeeping only costs — first form, every term).
 // The alpha >= 32 rule alone got this wrong on clustered features (profiles/r3_bench_alpha.txt: 12.7 ms lean vs 10.4 ms full
 // per 256 pairs at alpha 33 on the "trained-like" set; the second form 16.0 ms there), so each pair is measured: K1P_ROWS query
-// rows x K1P_COLS key columns (evenly spaced) of exact fp32 distances per (direction, pair).  A row's minimum over ALL columns
+// rows x K1P_COLS key columns (evenly spaced) of exact fp32 distances per (direction, pair) — 1024 distances per group: the
+// decision is taken on the mean over the launch's groups, so the sample per group can be small.  A row's minimum over ALL columns
 // is estimated as min(sample minimum, mean - z(M) sigma), z(M) the normal quantile of 1/M; p = fraction of the sampled
-// distances within the cut of that minimum, averaged over the rows, then over the pairs of the launch (k1_route_kernel).  2 K distances per group: 0.1 % of the sweep's work.
+// distances within the cut of that minimum, averaged over the rows, then over the pairs of the launch (k1_route_kernel).
 // Thresholds from profiles/r3_route_calib.txt: the second form wins up to a mean fraction of 0.4 % (measured points: 0.06 - 0.40 %),
 // the lean first form at 1.2 %, the full first form from 4 % on.
-constexpr int K1P_ROWS = 8, K1P_COLS = 256;
+constexpr int K1P_ROWS = 4, K1P_COLS = 256;   // (8 x 256 with a wave per row pair measured 122 us per launch of 1024 groups: every wave
+                                              // streamed the sampled key rows again, and that per-lane row streaming is L1-bound)
 struct K1ProbeArgs {
     const float *f[2], *n[2];   // features [B][rows][128] and squared norms of side 0 / 1
     int rows[2];
@@ -318,8 +320,9 @@ struct K1ProbeArgs {
     float *frac;                // [dirs][B]
 };
 __global__ __launch_bounds__(256) void k1_probe_kernel(const K1ProbeArgs a) {
+    // thread = one sampled key column, against all K1P_ROWS sampled query rows: every key row is read once per workgroup
     __shared__ float q[K1P_ROWS][HB_D];
-    __shared__ float psum[4];
+    __shared__ float part[4][K1P_ROWS][3], pcnt[4][K1P_ROWS];
     const int b = blockIdx.x, dir = blockIdx.y, B = gridDim.x;
     const int N = a.rows[dir], M = a.rows[dir ^ 1];
     const float *fq = a.f[dir] + (size_t)b * N * HB_D, *fk = a.f[dir ^ 1] + (size_t)b * M * HB_D;
@@ -331,61 +334,56 @@ __global__ __launch_bounds__(256) void k1_probe_kernel(const K1ProbeArgs a) {
     }
     __syncthreads();
     const int C = M < K1P_COLS ? M : K1P_COLS;
-    constexpr int PER = K1P_COLS / 64, RW = K1P_ROWS / 4;   // columns per lane, rows per wave
-    float d[RW][PER];
+    const bool on = tid < C;
+    const int col = on ? (int)((long)tid * M / C) : 0;
+    float dot[K1P_ROWS];
 #pragma unroll
-    for (int c = 0; c < PER; ++c) {
-        const int j = lane + 64 * c;
-        const int col = j < C ? (int)((long)j * M / C) : 0;
-        float dot[RW];
-#pragma unroll
-        for (int r = 0; r < RW; ++r) dot[r] = 0.f;
-        const float4 *kr = (const float4 *)(fk + (size_t)col * HB_D);
+    for (int r = 0; r < K1P_ROWS; ++r) dot[r] = 0.f;
+    const float4 *kr = (const float4 *)(fk + (size_t)col * HB_D);
 #pragma unroll 8
-        for (int k = 0; k < HB_D / 4; ++k) {
-            const float4 kv = kr[k];
+    for (int k = 0; k < HB_D / 4; ++k) {
+        const float4 kv = kr[k];
 #pragma unroll
-            for (int r = 0; r < RW; ++r) {
-                const float4 qv = *(const float4 *)&q[wave * RW + r][4 * k];
-                dot[r] = fmaf(kv.x, qv.x, fmaf(kv.y, qv.y, fmaf(kv.z, qv.z, fmaf(kv.w, qv.w, dot[r]))));
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < RW; ++r) {
-            const float nqr = nq[(long)(wave * RW + r) * N / K1P_ROWS];
-            d[r][c] = j < C ? sqrtf(fmaxf(nqr + nk[col] - 2.f * dot[r], 0.f)) : -1.f;   // -1: no sample
+        for (int r = 0; r < K1P_ROWS; ++r) {
+            const float4 qv = *(const float4 *)&q[r][4 * k];
+            dot[r] = fmaf(kv.x, qv.x, fmaf(kv.y, qv.y, fmaf(kv.z, qv.z, fmaf(kv.w, qv.w, dot[r]))));
         }
     }
-    const float z = 1.1f + 0.2f * log2f((float)M);   // 2.9 / 3.3 / 3.7 at M = 512 / 2048 / 8192
-    float pw = 0.f;
+    const float nkc = nk[col];
+    float d[K1P_ROWS];
 #pragma unroll
-    for (int r = 0; r < RW; ++r) {
-        float s1 = 0.f, s2 = 0.f, mn = INFINITY;
-#pragma unroll
-        for (int c = 0; c < PER; ++c) {
-            const bool on = d[r][c] >= 0.f;
-            s1 += on ? d[r][c] : 0.f;
-            s2 += on ? d[r][c] * d[r][c] : 0.f;
-            mn = on ? fminf(mn, d[r][c]) : mn;
-        }
+    for (int r = 0; r < K1P_ROWS; ++r) {
+        d[r] = sqrtf(fmaxf(nq[(long)r * N / K1P_ROWS] + nkc - 2.f * dot[r], 0.f));
+        float s1 = on ? d[r] : 0.f, s2 = on ? d[r] * d[r] : 0.f, mn = on ? d[r] : INFINITY;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             s1 += __shfl_xor(s1, o, 64);
             s2 += __shfl_xor(s2, o, 64);
             mn = fminf(mn, __shfl_xor(mn, o, 64));
         }
+        if (lane == 0) part[wave][r][0] = s1, part[wave][r][1] = s2, part[wave][r][2] = mn;
+    }
+    __syncthreads();
+    const float z = 1.1f + 0.2f * log2f((float)M);   // 2.9 / 3.3 / 3.7 at M = 512 / 2048 / 8192
+#pragma unroll
+    for (int r = 0; r < K1P_ROWS; ++r) {
+        const float s1 = (part[0][r][0] + part[1][r][0]) + (part[2][r][0] + part[3][r][0]);
+        const float s2 = (part[0][r][1] + part[1][r][1]) + (part[2][r][1] + part[3][r][1]);
+        const float mn = fminf(fminf(part[0][r][2], part[1][r][2]), fminf(part[2][r][2], part[3][r][2]));
         const float mu = s1 / C, sg = sqrtf(fmaxf(s2 / C - mu * mu, 0.f));
         const float thr = fminf(mn, mu - z * sg) + a.cutw;
-        float cnt = 0.f;
-#pragma unroll
-        for (int c = 0; c < PER; ++c) cnt += (d[r][c] >= 0.f && d[r][c] <= thr) ? 1.f : 0.f;
+        float cnt = (on && d[r] <= thr) ? 1.f : 0.f;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-        pw += cnt / C;
+        if (lane == 0) pcnt[wave][r] = cnt;
     }
-    if (lane == 0) psum[wave] = pw;
     __syncthreads();
-    if (tid == 0) a.frac[dir * B + b] = (psum[0] + psum[1] + psum[2] + psum[3]) / K1P_ROWS;
+    if (tid == 0) {
+        float p = 0.f;
+#pragma unroll
+        for (int r = 0; r < K1P_ROWS; ++r) p += ((pcnt[0][r] + pcnt[1][r]) + (pcnt[2][r] + pcnt[3][r])) / C;
+        a.frac[dir * B + b] = p / K1P_ROWS;
+    }
 }
 // One route per direction of the launch, from the mean fraction over its pairs.  (Routing every pair by its own fraction was
 // measured first: near a threshold the batch splits between two kernels, each runs with half the workgroups, and the launch
