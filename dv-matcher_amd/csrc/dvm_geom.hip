@@ -198,21 +198,30 @@ __global__ __launch_bounds__(256) void apply_kernel(const float *__restrict__ pi
     int c[TOPK];
 #pragma unroll
     for (int t = 0; t < TOPK; ++t) {
-        bool live = t < topk;
-        v[t] = live ? pi_val[row * topk + t] : 0.f;
-        c[t] = live ? pi_idx[row * topk + t] : 0x7fffffff;  // padding sorts last, contributes 0*V[0]
+        const bool live = t < topk;
+        const size_t o = row * topk + (live ? t : 0);   // (clamped, then selected: predicated loads go out one round trip at a time)
+        const float vt = pi_val[o];
+        const int ct = pi_idx[o];
+        v[t] = live ? vt : 0.f;
+        c[t] = live ? ct : 0x7fffffff;  // padding sorts last, contributes nothing
     }
     sort_by_col<TOPK>(v, c);
     const float *Vb = V + (size_t)b * M * C;
     const int c0 = cg * 4;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float vr[TOPK][4];   // all gathered values first (clamped addresses), then the chains in order
+#pragma unroll
+    for (int t = 0; t < TOPK; ++t) {
+        const float *p = Vb + (size_t)(t < topk ? c[t] : 0) * C;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vr[t][e] = p[c0 + e < C ? c0 + e : C - 1];
+    }
 #pragma unroll
     for (int t = 0; t < TOPK; ++t) {
         if (t < topk) {
-            const float *vr = Vb + (size_t)c[t] * C + c0;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (c0 + e < C) acc[e] = fmaf(v[t], vr[e], acc[e]);
+                if (c0 + e < C) acc[e] = fmaf(v[t], vr[t][e], acc[e]);
         }
     }
 #pragma unroll
