@@ -529,20 +529,30 @@ __global__ __launch_bounds__(256) void map_term_kernel(const float *__restrict__
         const int32_t *i22 = idx22 + (size_t)b * M * k;
         int nb[TOPK];
         float v[TOPK];
+        // three levels of dependent loads (weights / columns -> second-level indices -> coordinates), each level requested as a
+        // whole: the addresses are clamped and the values selected (a predicated load goes out alone, after a full wait)
+        int col[TOPK];
 #pragma unroll
         for (int t = 0; t < TOPK; ++t) {
-            const bool live = t < topk;
-            v[t] = live ? pi_val[row * topk + t] : 0.f;
-            nb[t] = live ? i22[(size_t)pi_idx[row * topk + t] * k + s] : 0;  // all second-level indices in flight
+            const size_t o = row * topk + (t < topk ? t : 0);
+            v[t] = pi_val[o];
+            col[t] = pi_idx[o];
+        }
+#pragma unroll
+        for (int t = 0; t < TOPK; ++t) nb[t] = i22[(size_t)col[t] * k + s];
+        float px[TOPK], py[TOPK], pz[TOPK];
+#pragma unroll
+        for (int t = 0; t < TOPK; ++t) {
+            const float *p = v2 + 3 * (size_t)nb[t];
+            px[t] = p[0], py[t] = p[1], pz[t] = p[2];
         }
         float acc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < TOPK; ++t) {
             if (t < topk) {
-                const float *p = v2 + 3 * (size_t)nb[t];
-                acc[0] = fmaf(v[t], p[0], acc[0]);
-                acc[1] = fmaf(v[t], p[1], acc[1]);
-                acc[2] = fmaf(v[t], p[2], acc[2]);
+                acc[0] = fmaf(v[t], px[t], acc[0]);
+                acc[1] = fmaf(v[t], py[t], acc[1]);
+                acc[2] = fmaf(v[t], pz[t], acc[2]);
             }
         }
         const float *p12 = verts12 + ((size_t)b * N + idx11[row * k + s]) * 3;
