@@ -64,16 +64,27 @@ __global__ void pack_weights_f16_kernel(const float *__restrict__ W, int O, int 
 // acc[t][node][out] += sum_k act_t[node][k] W[out][k] over `steps` k-steps, for NT 32-node tiles sharing the weight
 // fragments.  a0: this lane's row of tile 0 (+ 16*hh); tile t is 32 rows further.  The weight fragments come straight
 // from L2 (every workgroup streams the same 1.2 MB), MH_AHEAD k-steps ahead of their matrix instructions.
+// the first MH_AHEAD k-steps of a weight stream, requested AHEAD of the phase that uses them (before the activation stores and
+// the barrier of the previous phase: each of the six phases of a workgroup otherwise starts with an exposed L2 round trip)
+template <int MH_AHEAD>
+struct WFrag {
+    f16x8 h[MH_AHEAD], m[MH_AHEAD];
+    __device__ __forceinline__ void request(const _Float16 *__restrict__ wp, int steps) {
+#pragma unroll
+        for (int u = 0; u < MH_AHEAD; ++u) {
+            const _Float16 *w = wp + (size_t)(u < steps ? u : steps - 1) * 1024;
+            h[u] = *(const f16x8 *)(w), m[u] = *(const f16x8 *)(w + 512);
+        }
+    }
+};
+
 template <int NT, int MH_AHEAD>
 __device__ __forceinline__ void mma_tiles(const char *__restrict__ a0, int row_stride, int plane_bytes,
                                           const _Float16 *__restrict__ wp /* (otile, first step) base + lane*8 */, int steps,
-                                          f32x16 (&acc)[NT]) {
+                                          f32x16 (&acc)[NT], const WFrag<MH_AHEAD> &first) {
     f16x8 wh[MH_AHEAD], wm[MH_AHEAD];
 #pragma unroll
-    for (int u = 0; u < MH_AHEAD; ++u) {
-        const _Float16 *w = wp + (size_t)(u < steps ? u : steps - 1) * 1024;
-        wh[u] = *(const f16x8 *)(w), wm[u] = *(const f16x8 *)(w + 512);
-    }
+    for (int u = 0; u < MH_AHEAD; ++u) wh[u] = first.h[u], wm[u] = first.m[u];
     for (int s0 = 0; s0 < steps; s0 += MH_AHEAD) {
 #pragma unroll
         for (int u = 0; u < MH_AHEAD; ++u) {
@@ -129,6 +140,12 @@ __global__ __launch_bounds__(MH_THREADS) void mlp_f16x2_kernel(const float *__re
     const int r32 = lane & 31, hh = lane >> 5;
     const int row0 = blockIdx.x * MH_NODES;
     int bad = 0;
+    // this wave's five biases and the first weight fragments of layer 0: requested before anything else, in flight while the z
+    // rows are staged (each bias load used to sit between a phase's last matrix instruction and its activation stores)
+    const float bias0a = b0[wave * 32 + r32], bias0b = b0[(8 + wave) * 32 + r32], bias1 = b1[wave * 32 + r32];
+    const float bias2 = b2[(wave & 3) * 32 + r32], bias3 = r32 < 9 ? b3[r32] : 0.f;
+    WFrag<AHEAD> wfirst;
+    wfirst.request(Wp0 + (size_t)wave * (MH_K0 / 16) * 1024 + lane * 8, MH_K0 / 16);
 
     // stage z: scale, split into the two planes (columns 262..271 are zero)
     // (all of a thread's 9 loads are requested before the first is used: row and column are clamped and the value selected —
@@ -163,11 +180,16 @@ __global__ __launch_bounds__(MH_THREADS) void mlp_f16x2_kernel(const float *__re
     __syncthreads();
 
     // layer 0 in two halves of 256 outputs; layer 1 consumes each half at once (split-K, accumulators in registers)
+    const _Float16 *const w0p[2] = {Wp0 + (size_t)wave * (MH_K0 / 16) * 1024 + lane * 8, Wp0 + (size_t)(8 + wave) * (MH_K0 / 16) * 1024 + lane * 8};
+    const _Float16 *const w1p[2] = {Wp1 + ((size_t)wave * (MH_K1 / 16)) * 1024 + lane * 8, Wp1 + ((size_t)wave * (MH_K1 / 16) + 16) * 1024 + lane * 8};
+    const _Float16 *const w2p = Wp2 + (size_t)(wave & 3) * (MH_K2 / 16) * 1024 + lane * 8;
+    const _Float16 *const w3p = Wp3 + lane * 8;
     f32x16 acc1[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc1[t][r] = 0.f;
+    WFrag<AHEAD> wa = wfirst, wb;   // (wfirst: layer 0, first half — requested before the z rows were staged)
     for (int hlf = 0; hlf < 2; ++hlf) {
         {
             const int ot = 8 * hlf + wave;  // of 16 output tiles
@@ -176,22 +198,21 @@ __global__ __launch_bounds__(MH_THREADS) void mlp_f16x2_kernel(const float *__re
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc0[t][r] = 0.f;
-            mma_tiles<2, AHEAD>(bufZ + r32 * MH_SZ + 16 * hh, MH_SZ, 2 * MH_K0, Wp0 + (size_t)ot * (MH_K0 / 16) * 1024 + lane * 8, MH_K0 / 16,
-                         acc0);
-            const float bv = b0[ot * 32 + r32];
+            mma_tiles<2, AHEAD>(bufZ + r32 * MH_SZ + 16 * hh, MH_SZ, 2 * MH_K0, w0p[hlf], MH_K0 / 16, acc0, wa);
+            wb.request(w1p[hlf], 16);   // layer 1's first fragments travel while this half's activations are stored
+            const float bv = hlf ? bias0b : bias0a;
 #pragma unroll
             for (int t = 0; t < 2; ++t) store_act(acc0[t], bv, wave * 32 + r32, bufH + t * 32 * MH_SH, MH_SH, 2 * 256, hh, bad);
         }
         __syncthreads();
         // layer 1, K-half hlf: out tile = wave (8 tiles = 256 outputs), k-steps 16*hlf .. 16*hlf+15
-        mma_tiles<2, AHEAD>(bufH + r32 * MH_SH + 16 * hh, MH_SH, 2 * 256, Wp1 + ((size_t)wave * (MH_K1 / 16) + 16 * hlf) * 1024 + lane * 8, 16,
-                     acc1);
+        mma_tiles<2, AHEAD>(bufH + r32 * MH_SH + 16 * hh, MH_SH, 2 * 256, w1p[hlf], 16, acc1, wb);
+        if (hlf == 0) wa.request(w0p[1], MH_K0 / 16); else wa.request(w2p, MH_K2 / 16);   // the next phase's, across the barrier
         __syncthreads();
     }
     {   // h1 -> bufZ (z is dead)
-        const float bv = b1[wave * 32 + r32];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) store_act(acc1[t], bv, wave * 32 + r32, bufZ + t * 32 * MH_SZ, MH_SZ, 2 * MH_K2, hh, bad);
+        for (int t = 0; t < 2; ++t) store_act(acc1[t], bias1, wave * 32 + r32, bufZ + t * 32 * MH_SZ, MH_SZ, 2 * MH_K2, hh, bad);
     }
     __syncthreads();
     // layer 2: 256 -> 128 : 4 output tiles x 2 node tiles, one pair per wave
@@ -200,9 +221,9 @@ __global__ __launch_bounds__(MH_THREADS) void mlp_f16x2_kernel(const float *__re
         f32x16 acc2[1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[0][r] = 0.f;
-        mma_tiles<1, AHEAD>(bufZ + (nt * 32 + r32) * MH_SZ + 16 * hh, MH_SZ, 2 * MH_K2, Wp2 + (size_t)ot * (MH_K2 / 16) * 1024 + lane * 8,
-                     MH_K2 / 16, acc2);
-        store_act(acc2[0], b2[ot * 32 + r32], ot * 32 + r32, bufH + nt * 32 * MH_SH, MH_SH, 2 * MH_K3, hh, bad);
+        mma_tiles<1, AHEAD>(bufZ + (nt * 32 + r32) * MH_SZ + 16 * hh, MH_SZ, 2 * MH_K2, w2p, MH_K2 / 16, acc2, wa);
+        if (wave < 2) wb.request(w3p, MH_K3 / 16);
+        store_act(acc2[0], bias2, ot * 32 + r32, bufH + nt * 32 * MH_SH, MH_SH, 2 * MH_K3, hh, bad);
     }
     __syncthreads();
     // layer 3: 128 -> 9 : one output tile per node tile, straight to HBM
@@ -210,9 +231,9 @@ __global__ __launch_bounds__(MH_THREADS) void mlp_f16x2_kernel(const float *__re
         f32x16 acc3[1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc3[0][r] = 0.f;
-        mma_tiles<1, AHEAD>(bufH + (wave * 32 + r32) * MH_SH + 16 * hh, MH_SH, 2 * MH_K3, Wp3 + lane * 8, MH_K3 / 16, acc3);
+        mma_tiles<1, AHEAD>(bufH + (wave * 32 + r32) * MH_SH + 16 * hh, MH_SH, 2 * MH_K3, w3p, MH_K3 / 16, acc3, wb);
         const int o = r32;
-        const float bv = o < 9 ? b3[o] : 0.f;
+        const float bv = bias3;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int node = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
