@@ -97,9 +97,12 @@ __device__ __forceinline__ void mma_tiles(const char *__restrict__ a0, int row_s
                 for (int t = 0; t < NT; ++t) {
                     const char *ar = a0 + t * 32 * row_stride + 32 * s;
                     const f16x8 ah = *(const f16x8 *)(ar), am = *(const f16x8 *)(ar + plane_bytes);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, bh, acc[t], 0, 0, 0);  // small terms first
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bm, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+                    // weights as the A operand, activations as B: the accumulator tile is [out][node] — a lane owns ONE node (its
+                    // r32) and 4 x 4 consecutive outputs, so the activation stores below are 8-byte ones (the fragments of the
+                    // two operands have the same register layout: swapping them transposes the tile and nothing else)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, am, acc[t], 0, 0, 0);  // small terms first
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bm, ah, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[t], 0, 0, 0);
                 }
             }
         }
@@ -110,19 +113,32 @@ __device__ __forceinline__ float elu_fast(float x) {
     return x > 0.f ? x : __builtin_amdgcn_exp2f(x * 1.4426950408889634f) - 1.f;
 }
 
-// bias + ELU on the un-scaled accumulator, then scale, split and store the two planes of this lane's 16 (node, out) values
-__device__ __forceinline__ void store_act(const f32x16 &acc, float bv, int col, char *dst /* tile's first row */, int stride,
-                                          int plane_bytes, int hh, int &bad) {
+// bias + ELU on the un-scaled accumulator, then scale, split and store the two planes of this lane's 16 (out, node) values:
+// register r = 4 g + e holds output ocol0 + 8 g + e of the lane's node — four 8-byte stores per plane
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+struct Bias16 {
+    f32x4 v[4];
+    __device__ __forceinline__ void request(const float *__restrict__ b, int ocol0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int node = (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const float a = elu_fast(acc[r] * MH_INV + bv) * MH_SA;
-        bad |= !(fabsf(a) <= MH_LIMIT);
-        _Float16 h, m;
-        split2(a, h, m);
-        char *p = dst + node * stride + 2 * col;
-        *(_Float16 *)(p) = h;
-        *(_Float16 *)(p + plane_bytes) = m;
+        for (int g = 0; g < 4; ++g) v[g] = *(const f32x4 *)(b + ocol0 + 8 * g);
+    }
+};
+__device__ __forceinline__ void store_act(const f32x16 &acc, const Bias16 &bv, int ocol0, char *dst /* this lane's node row */, int plane_bytes,
+                                          int &bad) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f16x4 h4, m4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = elu_fast(acc[4 * g + e] * MH_INV + bv.v[g][e]) * MH_SA;
+            bad |= !(fabsf(a) <= MH_LIMIT);
+            _Float16 h, m;
+            split2(a, h, m);
+            h4[e] = h, m4[e] = m;
+        }
+        char *p = dst + 2 * (ocol0 + 8 * g);
+        *(f16x4 *)(p) = h4;
+        *(f16x4 *)(p + plane_bytes) = m4;
     }
 }
 
@@ -142,8 +158,7 @@ __global__ __launch_bounds__(MH_THREADS) void mlp_f16x2_kernel(const float *__re
     int bad = 0;
     // this wave's five biases and the first weight fragments of layer 0: requested before anything else, in flight while the z
     // rows are staged (each bias load used to sit between a phase's last matrix instruction and its activation stores)
-    const float bias0a = b0[wave * 32 + r32], bias0b = b0[(8 + wave) * 32 + r32], bias1 = b1[wave * 32 + r32];
-    const float bias2 = b2[(wave & 3) * 32 + r32], bias3 = r32 < 9 ? b3[r32] : 0.f;
+    // (the biases of a phase — 16 per lane — are requested at the head of the phase: they land under its matrix instructions)
     WFrag<AHEAD> wfirst;
     wfirst.request(Wp0 + (size_t)wave * (MH_K0 / 16) * 1024 + lane * 8, MH_K0 / 16);
 
@@ -190,6 +205,7 @@ __global__ __launch_bounds__(MH_THREADS) void mlp_f16x2_kernel(const float *__re
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc1[t][r] = 0.f;
     WFrag<AHEAD> wa = wfirst, wb;   // (wfirst: layer 0, first half — requested before the z rows were staged)
+    Bias16 bias1;
     for (int hlf = 0; hlf < 2; ++hlf) {
         {
             const int ot = 8 * hlf + wave;  // of 16 output tiles
@@ -198,21 +214,23 @@ __global__ __launch_bounds__(MH_THREADS) void mlp_f16x2_kernel(const float *__re
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc0[t][r] = 0.f;
+            Bias16 bv;
+            bv.request(b0, ot * 32 + 4 * hh);
             mma_tiles<2, AHEAD>(bufZ + r32 * MH_SZ + 16 * hh, MH_SZ, 2 * MH_K0, w0p[hlf], MH_K0 / 16, acc0, wa);
             wb.request(w1p[hlf], 16);   // layer 1's first fragments travel while this half's activations are stored
-            const float bv = hlf ? bias0b : bias0a;
 #pragma unroll
-            for (int t = 0; t < 2; ++t) store_act(acc0[t], bv, wave * 32 + r32, bufH + t * 32 * MH_SH, MH_SH, 2 * 256, hh, bad);
+            for (int t = 0; t < 2; ++t) store_act(acc0[t], bv, wave * 32 + 4 * hh, bufH + (t * 32 + r32) * MH_SH, 2 * 256, bad);
         }
         __syncthreads();
         // layer 1, K-half hlf: out tile = wave (8 tiles = 256 outputs), k-steps 16*hlf .. 16*hlf+15
+        if (hlf == 1) bias1.request(b1, wave * 32 + 4 * hh);
         mma_tiles<2, AHEAD>(bufH + r32 * MH_SH + 16 * hh, MH_SH, 2 * 256, w1p[hlf], 16, acc1, wb);
         if (hlf == 0) wa.request(w0p[1], MH_K0 / 16); else wa.request(w2p, MH_K2 / 16);   // the next phase's, across the barrier
         __syncthreads();
     }
     {   // h1 -> bufZ (z is dead)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) store_act(acc1[t], bias1, wave * 32 + r32, bufZ + t * 32 * MH_SZ, MH_SZ, 2 * MH_K2, hh, bad);
+        for (int t = 0; t < 2; ++t) store_act(acc1[t], bias1, wave * 32 + 4 * hh, bufZ + (t * 32 + r32) * MH_SZ, 2 * MH_K2, bad);
     }
     __syncthreads();
     // layer 2: 256 -> 128 : 4 output tiles x 2 node tiles, one pair per wave
@@ -221,9 +239,11 @@ __global__ __launch_bounds__(MH_THREADS) void mlp_f16x2_kernel(const float *__re
         f32x16 acc2[1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[0][r] = 0.f;
+        Bias16 bias2;
+        bias2.request(b2, ot * 32 + 4 * hh);
         mma_tiles<1, AHEAD>(bufZ + (nt * 32 + r32) * MH_SZ + 16 * hh, MH_SZ, 2 * MH_K2, w2p, MH_K2 / 16, acc2, wa);
         if (wave < 2) wb.request(w3p, MH_K3 / 16);
-        store_act(acc2[0], bias2, ot * 32 + r32, bufH + nt * 32 * MH_SH, MH_SH, 2 * MH_K3, hh, bad);
+        store_act(acc2[0], bias2, ot * 32 + 4 * hh, bufH + (nt * 32 + r32) * MH_SH, 2 * MH_K3, bad);
     }
     __syncthreads();
     // layer 3: 128 -> 9 : one output tile per node tile, straight to HBM
@@ -232,12 +252,11 @@ __global__ __launch_bounds__(MH_THREADS) void mlp_f16x2_kernel(const float *__re
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc3[0][r] = 0.f;
         mma_tiles<1, AHEAD>(bufH + (wave * 32 + r32) * MH_SH + 16 * hh, MH_SH, 2 * MH_K3, w3p, MH_K3 / 16, acc3, wb);
-        const int o = r32;
-        const float bv = bias3;
+        const int node = wave * 32 + r32;   // (transposed tile: the lane's node, outputs (r & 3) + 8 (r >> 2) + 4 hh — r < 5 reaches 0..8)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int node = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            if (o < 9 && row0 + node < rows) out[(size_t)(row0 + node) * 9 + o] = acc3[0][r] * MH_INV + bv;
+        for (int r = 0; r < 5; ++r) {
+            const int o = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (o < 9 && row0 + node < rows) out[(size_t)(row0 + node) * 9 + o] = acc3[0][r] * MH_INV + b3[o];
         }
     }
     if (__any(bad) && lane == 0) atomicOr(flag, 1);
