@@ -366,18 +366,24 @@ struct ChGridArgs {
     ChGridGroup g[8];
     int scan_min;   // uncertified lanes in a wave from which the whole target is scanned instead of walked
 };
+typedef float f32x16_g __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(128) void grid_chamfer_kernel(const ChGridArgs args) {
     const ChGridGroup &G = args.g[blockIdx.z];
     const int b = blockIdx.y;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int Na = G.gq.P;
-    if (t >= Na) return;
+    // (lanes past the end stay in the kernel, with the last query and nothing to write: the matrix-core scan below needs whole waves)
+    const bool inrange = t < Na;
     GridView g = grid_view(G.gb, b);
     GridView q = grid_view(G.gq, b);
-    const float4 qp = q.pts[t];
-    const int i = q.ids[t];
+    const int tq = inrange ? t : Na - 1;
+    const float4 qp = q.pts[tq];
+    const int i = q.ids[tq];
     MetricDiff met;
     met.set(qp.x, qp.y, qp.z);
+    const float q2 = sumsq3(qp.x, qp.y, qp.z);
+    const float margin = 64.f * 1.1920929e-7f * (g.scale2 + q2) + 1e-30f;
+    bool done = !inrange;
     // K = 1 fast path: the radius-1 cube is 9 contiguous (z, y) rows.  All 18 range bounds are requested together
     // (the generic walk chases start -> pts -> ids one row at a time: a dependent-load chain per row), only the
     // coordinates are read per candidate, the original index once at the end (and on exact ties).
@@ -396,7 +402,10 @@ __global__ __launch_bounds__(128) void grid_chamfer_kernel(const ChGridArgs args
             const bool in = z >= 0 && z < Gd && y >= 0 && y < Gd;
             const int rowbase = ((in ? z : cz) * Gd + (in ? y : cy)) * Gd;
             rs[r] = g.start[rowbase + x0];
-            re[r] = in ? g.start[rowbase + x1 + 1] : rs[r];
+            // (loaded unconditionally — the row is clamped above — and selected: a predicated load is a branch around a load, and
+            // the compiler waits for rs[r] in front of it: the 18 bounds arrived in nine dependent round trips)
+            const int rend = g.start[rowbase + x1 + 1];
+            re[r] = in ? rend : rs[r];
         }
         float best = INFINITY;
         int bs = -1;
@@ -418,8 +427,6 @@ __global__ __launch_bounds__(128) void grid_chamfer_kernel(const ChGridArgs args
                 }
             }
         // certification of the radius-1 cube (same bound as grid_search)
-        const float q2 = sumsq3(qp.x, qp.y, qp.z);
-        const float margin = 64.f * 1.1920929e-7f * (g.scale2 + q2) + 1e-30f;
         const float ext = (float)Gd * g.h;
         const float ex = fmaxf(0.f, fmaxf(g.ox - qp.x, qp.x - (g.ox + ext)));
         const float ey = fmaxf(0.f, fmaxf(g.oy - qp.y, qp.y - (g.oy + ext)));
@@ -433,32 +440,28 @@ __global__ __launch_bounds__(128) void grid_chamfer_kernel(const ChGridArgs args
         if (cy + 1 < Gd - 1) face((g.oy + (float)(cy + 2) * g.h) - qp.y, exx + ezz);
         if (cz - 1 >= 1) face(qp.z - (g.oz + (float)(cz - 1) * g.h), exx + eyy);
         if (cz + 1 < Gd - 1) face((g.oz + (float)(cz + 2) * g.h) - qp.z, exx + eyy);
-        if (bs >= 0 && (bound2 == INFINITY || best < bound2 * 0.9999f - margin)) {
+        if (!done && bs >= 0 && (bound2 == INFINITY || best < bound2 * 0.9999f - margin)) {
             G.dout[(size_t)b * Na + i] = best;
             if (G.iout) G.iout[(size_t)b * Na + i] = g.ids[bs];
-            return;
+            done = true;
         }
     }
     // not certified within the radius-1 cube.  (Deferring these queries to a compacted second launch made the first one
     // 2.5x faster but the incoherent retry launch cost more than it saved — queries far outside the target's box, as the
     // bench's untrained warps produce, need most of the grid either way.)
-    // When many lanes of the wave are in that position — a query cloud far from, or much larger than, the target: a
-    // COLLAPSED correspondence image (flat soft-max rows at small alpha) makes every query of the other cloud such a one
-    // and cost 10.7 ms per call with the walk — the wave scans the whole target in storage order instead: every lane reads
-    // the same address (one broadcast transaction per point, no per-lane cell ranges), same minimum, same tie rule.
-    const int nfall = __popcll(__ballot(1));   // lanes still here
-    if (nfall >= args.scan_min) {
-        float best = INFINITY;
-        int bs = 0;
-        const int P = G.gb.P;
-        for (int s0 = 0; s0 < P; s0 += 4) {
+    const int nfall = __popcll(__ballot(!done));   // (wave-uniform)
+    if (nfall == 0) return;
+    const int P = G.gb.P;
+    // the whole target in storage order with the reference's arithmetic (difference form, lower original index on exact ties)
+    auto exact_scan = [&](int s_begin, int s_end, float &best, int &bs) __attribute__((always_inline)) {
+        for (int s0 = s_begin; s0 < s_end; s0 += 4) {
             float4 pc[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) pc[u] = g.pts[s0 + u < P ? s0 + u : P - 1];
+            for (int u = 0; u < 4; ++u) pc[u] = g.pts[s0 + u < s_end ? s0 + u : s_end - 1];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int sidx = s0 + u;
-                const float d = sidx < P ? met(pc[u]) : INFINITY;
+                const float d = sidx < s_end ? met(pc[u]) : INFINITY;
                 if (d < best) {
                     best = d, bs = sidx;
                 } else if (d == best && d < INFINITY && g.ids[sidx] < g.ids[bs]) {  // exact tie: lower original index
@@ -466,10 +469,77 @@ __global__ __launch_bounds__(128) void grid_chamfer_kernel(const ChGridArgs args
                 }
             }
         }
-        G.dout[(size_t)b * Na + i] = best;
-        if (G.iout) G.iout[(size_t)b * Na + i] = g.ids[bs];
+    };
+    // When many lanes of the wave are in that position — a query cloud far from, or much larger than, the target: a COLLAPSED
+    // correspondence image (flat soft-max rows at small alpha) makes every query of the other cloud such a one — the wave goes
+    // through the WHOLE target instead of walking cells.  Round 3: that scan is screened on the matrix cores.  Per 32 target
+    // points, three v_mfma_f32_32x32x2_f32 per half of the wave's queries give |p|^2 + |q|^2 - 2 p.q for 32 x 32 pairs (rows
+    // [-2 px, -2 py, -2 pz, |p|^2, 1, 0] against columns [qx, qy, qz, 1, |q|^2, 0]); a lane keeps, per query, the smallest value
+    // it has seen, the tile it came from and the smallest value of any OTHER tile.  At the end the best tile's 32 points are
+    // evaluated with the reference's difference form (ties by original index), and the result stands if every other tile's
+    // minimum lies more than twice the screening's error bound above the best — otherwise that query is scanned exactly.
+    // (The vector form of this scan was 12 instructions per pair and the whole of the kernel's time in the bench's regime:
+    // 2.57 ms per launch of 4 x 512 clouds.)
+    if (nfall >= args.scan_min) {
+        const int lane = threadIdx.x & 63, j32 = lane & 31, hh = lane >> 5;
+        float bq[2][3];
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+            const int src = j32 + 32 * tl;
+            const float x = __shfl(qp.x, src, 64), y = __shfl(qp.y, src, 64), z = __shfl(qp.z, src, 64), n = __shfl(q2, src, 64);
+            bq[tl][0] = hh ? y : x;
+            bq[tl][1] = hh ? 1.f : z;
+            bq[tl][2] = hh ? 0.f : n;
+        }
+        float tb[2] = {INFINITY, INFINITY}, ts[2] = {INFINITY, INFINITY};
+        int tt[2] = {0, 0};
+        for (int s0 = 0; s0 < P; s0 += 32) {
+            const int pi = s0 + j32;
+            const float4 pc = g.pts[pi < P ? pi : P - 1];
+            const float pn = pi < P ? pc.w : INFINITY;   // (rows past the end: +inf, never the minimum)
+            const float a0 = hh ? -2.f * pc.y : -2.f * pc.x, a1 = hh ? pn : -2.f * pc.z, a2 = hh ? 0.f : 1.f;
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) {
+                f32x16_g acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bq[tl][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bq[tl][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, bq[tl][2], acc, 0, 0, 0);
+                float m = fminf(fminf(fminf(acc[0], acc[1]), fminf(acc[2], acc[3])), fminf(fminf(acc[4], acc[5]), fminf(acc[6], acc[7])));
+                m = fminf(m, fminf(fminf(fminf(acc[8], acc[9]), fminf(acc[10], acc[11])), fminf(fminf(acc[12], acc[13]), fminf(acc[14], acc[15]))));
+                const bool better = m < tb[tl];
+                ts[tl] = better ? tb[tl] : fminf(ts[tl], m);
+                tt[tl] = better ? s0 : tt[tl];
+                tb[tl] = better ? m : tb[tl];
+            }
+        }
+        // a query's 32 points per tile sit in two lanes (its own and lane ^ 32): merge the halves at the query's own lane
+        const float mb = hh ? tb[1] : tb[0], ms = hh ? ts[1] : ts[0];
+        const int mt = hh ? tt[1] : tt[0];
+        const float ob = __shfl_xor(hh ? tb[0] : tb[1], 32, 64), os = __shfl_xor(hh ? ts[0] : ts[1], 32, 64);
+        const int ot = __shfl_xor(hh ? tt[0] : tt[1], 32, 64);
+        const float sbest = fminf(mb, ob);
+        const int stile = ob < mb ? ot : mt;
+        const float sother = fminf(fminf(ms, os), mt == ot ? INFINITY : fmaxf(mb, ob));
+        float best = INFINITY;
+        int bs = 0;
+        bool cert = false;
+        if (!done) {
+            exact_scan(stile, stile + 32 < P ? stile + 32 : P, best, bs);
+            cert = sother - sbest > 2.f * margin;
+        }
+        if (__ballot(!done && !cert) != 0) {   // (rare: a near-tie between tiles, within the screening's error)
+            if (!done && !cert) {
+                best = INFINITY, bs = 0;
+                exact_scan(0, P, best, bs);
+            }
+        }
+        if (!done) {
+            G.dout[(size_t)b * Na + i] = best;
+            if (G.iout) G.iout[(size_t)b * Na + i] = g.ids[bs];
+        }
         return;
     }
+    if (done) return;
     KBest<1, float> kb;
     kb.init(INFINITY);
     grid_search<1, MetricDiff>(g, qp.x, qp.y, qp.z, met, kb);
