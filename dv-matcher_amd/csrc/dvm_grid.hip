@@ -217,7 +217,7 @@ struct MetricDiff {  // chamfer: (dx^2 + dy^2) + dz^2 in fp32, no contraction
 // outside can rank before the current K-th.
 template <int K, class Metric>
 __device__ __forceinline__ void grid_search(const GridView &g, float qx, float qy, float qz, Metric &met,
-                                            KBest<K, typename Metric::key_t> &kb) {
+                                            KBest<K, typename Metric::key_t> &kb, int R0 = 1 /* cubes below R0: already in kb */) {
     const int G = g.G;
     const float inv = 1.0f / g.h;
     int cx = (int)((qx - g.ox) * inv), cy = (int)((qy - g.oy) * inv), cz = (int)((qz - g.oz) * inv);
@@ -226,12 +226,12 @@ __device__ __forceinline__ void grid_search(const GridView &g, float qx, float q
     cz = cz < 0 ? 0 : (cz > G - 1 ? G - 1 : cz);
     const float q2 = sumsq3(qx, qy, qz);
     const float margin = 64.f * 1.1920929e-7f * (g.scale2 + q2) + 1e-30f;
-    int Rprev = -1;
+    int Rprev = R0 > 1 ? R0 - 1 : -1;
     // (Measured, round 3: the first cube with all 18 row bounds requested together and the candidates four to a round trip —
     // the shape of grid_chamfer_kernel's fast path — made the xyz kNN SLOWER, 1.30 -> 1.48 ms per launch of 1024 clouds, and
     // left the ring / influence searches where they were: with 16+ waves per SIMD the dependent loads are already covered, and
     // the extra registers and list insertions behind predicates cost more than the round trips they save.)
-    for (int R = 1; R <= G; ++R) {
+    for (int R = R0; R <= G; ++R) {
         const int x0 = cx - R < 0 ? 0 : cx - R, x1 = cx + R > G - 1 ? G - 1 : cx + R;
         const int y0 = cy - R < 0 ? 0 : cy - R, y1 = cy + R > G - 1 ? G - 1 : cy + R;
         const int z0 = cz - R < 0 ? 0 : cz - R, z1 = cz + R > G - 1 ? G - 1 : cz + R;
@@ -384,6 +384,8 @@ __global__ __launch_bounds__(128) void grid_chamfer_kernel(const ChGridArgs args
     const float q2 = sumsq3(qp.x, qp.y, qp.z);
     const float margin = 64.f * 1.1920929e-7f * (g.scale2 + q2) + 1e-30f;
     bool done = !inrange;
+    float fbest = INFINITY;   // the radius-1 cube's result, kept for the walk below
+    int fid = 0x7fffffff;
     // K = 1 fast path: the radius-1 cube is 9 contiguous (z, y) rows.  All 18 range bounds are requested together
     // (the generic walk chases start -> pts -> ids one row at a time: a dependent-load chain per row), only the
     // coordinates are read per candidate, the original index once at the end (and on exact ties).
@@ -440,9 +442,10 @@ __global__ __launch_bounds__(128) void grid_chamfer_kernel(const ChGridArgs args
         if (cy + 1 < Gd - 1) face((g.oy + (float)(cy + 2) * g.h) - qp.y, exx + ezz);
         if (cz - 1 >= 1) face(qp.z - (g.oz + (float)(cz - 1) * g.h), exx + eyy);
         if (cz + 1 < Gd - 1) face((g.oz + (float)(cz + 2) * g.h) - qp.z, exx + eyy);
+        if (bs >= 0) fbest = best, fid = g.ids[bs];
         if (!done && bs >= 0 && (bound2 == INFINITY || best < bound2 * 0.9999f - margin)) {
             G.dout[(size_t)b * Na + i] = best;
-            if (G.iout) G.iout[(size_t)b * Na + i] = g.ids[bs];
+            if (G.iout) G.iout[(size_t)b * Na + i] = fid;
             done = true;
         }
     }
@@ -540,9 +543,9 @@ __global__ __launch_bounds__(128) void grid_chamfer_kernel(const ChGridArgs args
         return;
     }
     if (done) return;
-    KBest<1, float> kb;
-    kb.init(INFINITY);
-    grid_search<1, MetricDiff>(g, qp.x, qp.y, qp.z, met, kb);
+    KBest<1, float> kb;   // the walk continues from the radius-1 cube (already visited above: its best seeds the list)
+    kb.key[0] = fbest, kb.idx[0] = fid;
+    grid_search<1, MetricDiff>(g, qp.x, qp.y, qp.z, met, kb, 2);
     G.dout[(size_t)b * Na + i] = kb.key[0];
     // (non-finite coordinates leave the list empty: keep the index a valid row, the backward pass gathers through it)
     if (G.iout) G.iout[(size_t)b * Na + i] = (unsigned)kb.idx[0] < (unsigned)G.gb.P ? kb.idx[0] : 0;
@@ -605,7 +608,7 @@ void launch_grid_chamfer(const GridBuf *gq, const GridBuf *gb, float *const *dou
     }
     static const int scan_min = [] {
         const char *e = getenv("DVM_CHAMFER_SCAN_MIN");   // tuning knob; 65 = never
-        return e ? atoi(e) : 32;   // (measured 8 .. 65 on the alpha sweep: 32 - 48 best on every case)
+        return e ? atoi(e) : 24;   // (round 3, matrix-core scan + seeded walk, bench regime: 8 / 16 / 24 / 32 / never = 2.75 / 2.32 / 2.22 / 2.30 / 2.81 ms)
     }();
     args.scan_min = scan_min;
     prof_begin(s, DVM_PROF_CHAMFER);

@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-for t in 32 1 16 48 65; do
+for t in ${SCANS:-32 8 16 24 65}; do
 DVM_CHAMFER_SCAN_MIN=$t python bench.py --steps 6 --warmup 2 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=[x for x in d['roofline']['kernels'] if 'chamfer' in x['kernel']][0]
