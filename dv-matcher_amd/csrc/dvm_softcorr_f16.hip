@@ -722,6 +722,10 @@ __global__ __launch_bounds__(256) void softcorr_exact_rows_kernel(const HXArgs a
             KBest<10, float> kb;
             kb.init(INFINITY);
             float m = -INFINITY, l = 0.f;
+            // (Round 3: the same distances as 16 systolic streams — the form of softcorr_refine_kernel<2>: whole 512-byte key rows per
+            // load, finished chains parked one per lane and processed 16 at a time — was built and is bit-identical, and the kernel
+            // took the same 150 us per launch: with ~420 flagged rows of 2 M (DVM_K1_FLAG_DEBUG prints the count) every workgroup has
+            // at most one row per direction, and the launch lasts as long as one row's dependent chain, whichever way it is fed.)
             for (int j0 = wave * 64 + lane; j0 < M; j0 += 1024) {  // four independent chains per lane in flight
                 float acc[4] = {0.f, 0.f, 0.f, 0.f};
                 const float *kr[4];
@@ -1101,6 +1105,14 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
                   : HXGroup{nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     x.neg_alpha = neg_alpha;
     x.topk = topk;
+    static const bool flag_debug = getenv("DVM_K1_FLAG_DEBUG") != nullptr;   // diagnostic (synchronous): rows pass B could not certify
+    if (flag_debug) {
+        int n[2] = {0, 0};
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(&n[0], flag[0], sizeof(int), hipMemcpyDeviceToHost);
+        if (both) (void)hipMemcpy(&n[1], flag[1], sizeof(int), hipMemcpyDeviceToHost);
+        fprintf(stderr, "K1 pass B: %d + %d of %ld rows go through the exact-rows kernel\n", n[0], n[1], r.rows_total);
+    }
     hipLaunchKernelGGL(softcorr_exact_rows_kernel, dim3(512), dim3(256), 0, s, x);
     return DVM_OK;
 }
