@@ -215,9 +215,9 @@ struct MetricDiff {  // chamfer: (dx^2 + dy^2) + dz^2 in fp32, no contraction
 // every unvisited point is at least `face` away (true distance), the reference-rounded squared
 // distance of such a point is >= face^2 - margin, so once kth_d2 < face^2*(1-1e-4) - margin nothing
 // outside can rank before the current K-th.
-template <int K, class Metric>
-__device__ __forceinline__ void grid_search(const GridView &g, float qx, float qy, float qz, Metric &met,
-                                            KBest<K, typename Metric::key_t> &kb, int R0 = 1 /* cubes below R0: already in kb */) {
+template <int K, class Metric, class List>
+__device__ __forceinline__ void grid_search(const GridView &g, float qx, float qy, float qz, Metric &met, List &kb,
+                                            int R0 = 1 /* cubes below R0: already in kb */) {
     const int G = g.G;
     const float inv = 1.0f / g.h;
     int cx = (int)((qx - g.ox) * inv), cy = (int)((qy - g.oy) * inv), cz = (int)((qz - g.oz) * inv);
@@ -275,7 +275,7 @@ __device__ __forceinline__ void grid_search(const GridView &g, float qx, float q
         if (cz - R >= 1) face_z(qz - (g.oz + (float)(cz - R) * g.h));
         if (cz + R < G - 1) face_z((g.oz + (float)(cz + R + 1) * g.h) - qz);
         if (bound2 == INFINITY) break;  // the cube covers the whole grid
-        const float kth = Metric::to_d2(kb.key[K - 1]);
+        const float kth = Metric::to_d2(kb.worst());
         if (kth < bound2 * 0.9999f - margin) break;
         Rprev = R;
     }
@@ -293,12 +293,12 @@ __global__ __launch_bounds__(128) void grid_knn_self_kernel(GridBuf gb, int k, i
     const float4 qp = g.pts[t];
     MetricMMQueryRow met;
     met.set(qp.x, qp.y, qp.z);
-    KBest<K, float> kb;
+    KBestPacked<K> kb;   // (keys: matmul-form squared distances clamped at 0)
     kb.init(INFINITY);
     grid_search<K, MetricMMQueryRow>(g, qp.x, qp.y, qp.z, met, kb);
     int32_t *o = idx + ((size_t)b * P + g.ids[t]) * k;
     for (int q = 0; q < K; ++q)
-        if (q < k) o[q] = q < P ? kb.idx[q] : 0;
+        if (q < k) o[q] = q < P ? kb.idx_at(q) : 0;
 }
 
 // node ring: 9-NN among nodes in fp64 (grid over the nodes, queries = nodes in cell order)
@@ -334,13 +334,13 @@ __global__ __launch_bounds__(128) void grid_infl_kernel(const float *__restrict_
         GridView gn = grid_view(gnodes, b);
         MetricMMCandRow met;
         met.set(qp.x, qp.y, qp.z);
-        KBest<3, float> kb;
+        KBestPacked<3> kb;
         kb.init(INFINITY);
         grid_search<3, MetricMMCandRow>(gn, qp.x, qp.y, qp.z, met, kb);
         const size_t row = (size_t)b * N + i;
         for (int q = 0; q < 3; ++q) {
-            infl[row * 3 + q] = q < gnodes.P ? kb.idx[q] : 0;
-            dists[row * 3 + q] = kb.key[q];
+            infl[row * 3 + q] = q < gnodes.P ? kb.idx_at(q) : 0;
+            dists[row * 3 + q] = kb.key_at(q);
         }
     }
     {
