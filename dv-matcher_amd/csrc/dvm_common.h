@@ -172,7 +172,7 @@ struct KBest {
 // instead of two compares, their combination and four selects (the idiom of the soft-correspondence sweeps).  insert_lex below
 // costs 2 K instructions where KBest's costs 9 K: the xyz kNN executed 16 600 vector instructions per wave, most of them these.
 // Keys must be >= +0 (a -0 is turned into +0), finite or +inf.
-template <int K>
+template <int K, int W = K - 1 /* the entry worst() reports: the K-best search certifies against it */>
 struct KBestPacked {
     double e[K];
     static __device__ __forceinline__ double mn(double a, double b) {
@@ -191,7 +191,7 @@ struct KBestPacked {
     }
     __device__ __forceinline__ float key_at(int q) const { return __int_as_float(__double2hiint(e[q])); }
     __device__ __forceinline__ int idx_at(int q) const { return __double2loint(e[q]); }
-    __device__ __forceinline__ float worst() const { return key_at(K - 1); }
+    __device__ __forceinline__ float worst() const { return key_at(W); }
     __device__ __forceinline__ void insert_lex(float v, int j) {
         const double x = __hiloint2double(__float_as_int(v + 0.f), j);
         if (!(x < e[K - 1])) return;

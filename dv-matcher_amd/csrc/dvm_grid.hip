@@ -203,6 +203,13 @@ struct MetricF64 {  // scipy KDTree: exact fp64 squared distance of the fp32 coo
     }
     __device__ __forceinline__ static float to_d2(double k) { return (float)k; }
 };
+struct MetricF64Rounded {  // the same distance rounded to fp32: a screening key (weakly monotone in the fp64 value)
+    typedef float key_t;
+    MetricF64 m;
+    __device__ __forceinline__ void set(float x, float y, float z) { m.set(x, y, z); }
+    __device__ __forceinline__ float operator()(const float4 &c) const { return (float)m(c); }
+    __device__ __forceinline__ static float to_d2(float k) { return k; }
+};
 struct MetricDiff {  // chamfer: (dx^2 + dy^2) + dz^2 in fp32, no contraction
     typedef float key_t;
     float qx, qy, qz;
@@ -309,13 +316,29 @@ __global__ __launch_bounds__(128) void grid_ring_kernel(GridBuf gb, int32_t *__r
     if (t >= P) return;
     GridView g = grid_view(gb, b);
     const float4 qp = g.pts[t];
+    // Screened: the search runs on the fp64 distance ROUNDED to fp32, packed with the index (KBestPacked: two instructions per
+    // compare-swap instead of the fourteen of a (double, index) pair), on a list of 10 certified against its 9th entry.  Rounding
+    // keeps the order except between values it merges: if two neighbours of the first ten share their fp32 key (a relative gap
+    // below 6e-8: about one node in 10^5) the node is searched again with the fp64 keys themselves.  Same rings, bit for bit.
+    const int a = g.ids[t];
+    int32_t *o = ring + ((size_t)b * P + a) * 9;
+    MetricF64Rounded mr;
+    mr.set(qp.x, qp.y, qp.z);
+    KBestPacked<10, 8> ks;
+    ks.init(INFINITY);
+    grid_search<9, MetricF64Rounded>(g, qp.x, qp.y, qp.z, mr, ks);
+    bool ambiguous = false;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) ambiguous = ambiguous || (ks.key_at(q) == ks.key_at(q + 1) && ks.key_at(q) < INFINITY);
+    if (!ambiguous) {
+        for (int q = 0; q < 9; ++q) o[q] = q < P ? ks.idx_at(q) : a;
+        return;
+    }
     MetricF64 met;
     met.set(qp.x, qp.y, qp.z);
     KBest<9, double> kb;
     kb.init((double)INFINITY);
     grid_search<9, MetricF64>(g, qp.x, qp.y, qp.z, met, kb);
-    const int a = g.ids[t];
-    int32_t *o = ring + ((size_t)b * P + a) * 9;
     for (int q = 0; q < 9; ++q) o[q] = q < P ? kb.idx[q] : a;
 }
 
