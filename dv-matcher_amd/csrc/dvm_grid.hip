@@ -499,8 +499,9 @@ __global__ __launch_bounds__(128) void grid_chamfer_kernel(const ChGridArgs args
     // When many lanes of the wave are in that position — a query cloud far from, or much larger than, the target: a COLLAPSED
     // correspondence image (flat soft-max rows at small alpha) makes every query of the other cloud such a one — the wave goes
     // through the WHOLE target instead of walking cells.  Round 3: that scan is screened on the matrix cores.  Per 32 target
-    // points, three v_mfma_f32_32x32x2_f32 per half of the wave's queries give |p|^2 + |q|^2 - 2 p.q for 32 x 32 pairs (rows
-    // [-2 px, -2 py, -2 pz, |p|^2, 1, 0] against columns [qx, qy, qz, 1, |q|^2, 0]); a lane keeps, per query, the smallest value
+    // points, two v_mfma_f32_32x32x2_f32 per half of the wave's queries give |p|^2 - 2 p.q — the squared distance less the
+    // query's own |q|^2, which does not move a query's minimum — for 32 x 32 pairs (rows [-2 px, -2 py, -2 pz, |p|^2] against
+    // columns [qx, qy, qz, 1]); a lane keeps, per query, the smallest value
     // it has seen, the tile it came from and the smallest value of any OTHER tile.  At the end the best tile's 32 points are
     // evaluated with the reference's difference form (ties by original index), and the result stands if every other tile's
     // minimum lies more than twice the screening's error bound above the best — otherwise that query is scanned exactly.
@@ -508,14 +509,13 @@ __global__ __launch_bounds__(128) void grid_chamfer_kernel(const ChGridArgs args
     // 2.57 ms per launch of 4 x 512 clouds.)
     if (nfall >= args.scan_min) {
         const int lane = threadIdx.x & 63, j32 = lane & 31, hh = lane >> 5;
-        float bq[2][3];
+        float bq[2][2];
 #pragma unroll
         for (int tl = 0; tl < 2; ++tl) {
             const int src = j32 + 32 * tl;
-            const float x = __shfl(qp.x, src, 64), y = __shfl(qp.y, src, 64), z = __shfl(qp.z, src, 64), n = __shfl(q2, src, 64);
+            const float x = __shfl(qp.x, src, 64), y = __shfl(qp.y, src, 64), z = __shfl(qp.z, src, 64);
             bq[tl][0] = hh ? y : x;
             bq[tl][1] = hh ? 1.f : z;
-            bq[tl][2] = hh ? 0.f : n;
         }
         float tb[2] = {INFINITY, INFINITY}, ts[2] = {INFINITY, INFINITY};
         int tt[2] = {0, 0};
@@ -523,13 +523,12 @@ __global__ __launch_bounds__(128) void grid_chamfer_kernel(const ChGridArgs args
             const int pi = s0 + j32;
             const float4 pc = g.pts[pi < P ? pi : P - 1];
             const float pn = pi < P ? pc.w : INFINITY;   // (rows past the end: +inf, never the minimum)
-            const float a0 = hh ? -2.f * pc.y : -2.f * pc.x, a1 = hh ? pn : -2.f * pc.z, a2 = hh ? 0.f : 1.f;
+            const float a0 = hh ? -2.f * pc.y : -2.f * pc.x, a1 = hh ? pn : -2.f * pc.z;
 #pragma unroll
             for (int tl = 0; tl < 2; ++tl) {
                 f32x16_g acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bq[tl][0], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bq[tl][1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, bq[tl][2], acc, 0, 0, 0);
                 float m = fminf(fminf(fminf(acc[0], acc[1]), fminf(acc[2], acc[3])), fminf(fminf(acc[4], acc[5]), fminf(acc[6], acc[7])));
                 m = fminf(m, fminf(fminf(fminf(acc[8], acc[9]), fminf(acc[10], acc[11])), fminf(fminf(acc[12], acc[13]), fminf(acc[14], acc[15]))));
                 const bool better = m < tb[tl];
