@@ -222,9 +222,10 @@ struct MetricDiff {  // chamfer: (dx^2 + dy^2) + dz^2 in fp32, no contraction
 // every unvisited point is at least `face` away (true distance), the reference-rounded squared
 // distance of such a point is >= face^2 - margin, so once kth_d2 < face^2*(1-1e-4) - margin nothing
 // outside can rank before the current K-th.
+// Returns true once the list is certified (always, unless Rmax stops the walk first).
 template <int K, class Metric, class List>
-__device__ __forceinline__ void grid_search(const GridView &g, float qx, float qy, float qz, Metric &met, List &kb,
-                                            int R0 = 1 /* cubes below R0: already in kb */) {
+__device__ __forceinline__ bool grid_search(const GridView &g, float qx, float qy, float qz, Metric &met, List &kb,
+                                            int R0 = 1 /* cubes below R0: already in kb */, int Rmax = 1 << 30) {
     const int G = g.G;
     const float inv = 1.0f / g.h;
     int cx = (int)((qx - g.ox) * inv), cy = (int)((qy - g.oy) * inv), cz = (int)((qz - g.oz) * inv);
@@ -238,7 +239,7 @@ __device__ __forceinline__ void grid_search(const GridView &g, float qx, float q
     // the shape of grid_chamfer_kernel's fast path — made the xyz kNN SLOWER, 1.30 -> 1.48 ms per launch of 1024 clouds, and
     // left the ring / influence searches where they were: with 16+ waves per SIMD the dependent loads are already covered, and
     // the extra registers and list insertions behind predicates cost more than the round trips they save.)
-    for (int R = R0; R <= G; ++R) {
+    for (int R = R0; R <= G && R <= Rmax; ++R) {
         const int x0 = cx - R < 0 ? 0 : cx - R, x1 = cx + R > G - 1 ? G - 1 : cx + R;
         const int y0 = cy - R < 0 ? 0 : cy - R, y1 = cy + R > G - 1 ? G - 1 : cy + R;
         const int z0 = cz - R < 0 ? 0 : cz - R, z1 = cz + R > G - 1 ? G - 1 : cz + R;
@@ -281,11 +282,12 @@ __device__ __forceinline__ void grid_search(const GridView &g, float qx, float q
         if (cy + R < G - 1) face_y((g.oy + (float)(cy + R + 1) * g.h) - qy);
         if (cz - R >= 1) face_z(qz - (g.oz + (float)(cz - R) * g.h));
         if (cz + R < G - 1) face_z((g.oz + (float)(cz + R + 1) * g.h) - qz);
-        if (bound2 == INFINITY) break;  // the cube covers the whole grid
+        if (bound2 == INFINITY) return true;  // the cube covers the whole grid
         const float kth = Metric::to_d2(kb.worst());
-        if (kth < bound2 * 0.9999f - margin) break;
+        if (kth < bound2 * 0.9999f - margin) return true;
         Rprev = R;
     }
+    return Rmax >= G;   // (walked the whole grid: certified by exhaustion)
 }
 
 // ---------------------------------------------------------------- kernels on top of grid_search
@@ -507,7 +509,25 @@ __global__ __launch_bounds__(128) void grid_chamfer_kernel(const ChGridArgs args
     // minimum lies more than twice the screening's error bound above the best — otherwise that query is scanned exactly.
     // (The vector form of this scan was 12 instructions per pair and the whole of the kernel's time in the bench's regime:
     // 2.57 ms per launch of 4 x 512 clouds.)
-    if (nfall >= args.scan_min) {
+    bool scan = nfall >= args.scan_min;   // (wave-uniform)
+    if (!scan) {
+        // few open lanes: they walk on from the radius-1 cube (seeded with its best) — but only two more shells: a lane still
+        // open after radius 3 is a FAR query, for which the walk would visit most of the grid one dependent cell row at a
+        // time (tens of thousands of instructions for the whole wave); the wave scans the target for it instead
+        if (!done) {
+            KBest<1, float> kb;
+            kb.key[0] = fbest, kb.idx[0] = fid;
+            if (grid_search<1, MetricDiff>(g, qp.x, qp.y, qp.z, met, kb, 2, 3)) {
+                G.dout[(size_t)b * Na + i] = kb.key[0];
+                // (non-finite coordinates leave the list empty: keep the index a valid row, the backward pass gathers through it)
+                if (G.iout) G.iout[(size_t)b * Na + i] = (unsigned)kb.idx[0] < (unsigned)G.gb.P ? kb.idx[0] : 0;
+                done = true;
+            }
+        }
+        scan = __ballot(!done) != 0;
+        if (!scan) return;
+    }
+    {
         const int lane = threadIdx.x & 63, j32 = lane & 31, hh = lane >> 5;
         float bq[2][2];
 #pragma unroll
@@ -564,13 +584,6 @@ __global__ __launch_bounds__(128) void grid_chamfer_kernel(const ChGridArgs args
         }
         return;
     }
-    if (done) return;
-    KBest<1, float> kb;   // the walk continues from the radius-1 cube (already visited above: its best seeds the list)
-    kb.key[0] = fbest, kb.idx[0] = fid;
-    grid_search<1, MetricDiff>(g, qp.x, qp.y, qp.z, met, kb, 2);
-    G.dout[(size_t)b * Na + i] = kb.key[0];
-    // (non-finite coordinates leave the list empty: keep the index a valid row, the backward pass gathers through it)
-    if (G.iout) G.iout[(size_t)b * Na + i] = (unsigned)kb.idx[0] < (unsigned)G.gb.P ? kb.idx[0] : 0;
 }
 
 // ---------------------------------------------------------------- host side
