@@ -390,6 +390,8 @@ struct ChGridGroup {
 struct ChGridArgs {
     ChGridGroup g[8];
     int scan_min;   // uncertified lanes in a wave from which the whole target is scanned instead of walked
+    unsigned long long *stats;   // diagnostic (DVM_CHAMFER_STATS): per group [8]: queries, radius-1 candidates, certified at radius 1,
+                                 // walked, certified by the walk, waves that scanned, lanes served by a scan, exact fallback lanes
 };
 typedef float f32x16_g __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(128) void grid_chamfer_kernel(const ChGridArgs args) {
@@ -467,11 +469,19 @@ __global__ __launch_bounds__(128) void grid_chamfer_kernel(const ChGridArgs args
         if (cy + 1 < Gd - 1) face((g.oy + (float)(cy + 2) * g.h) - qp.y, exx + ezz);
         if (cz - 1 >= 1) face(qp.z - (g.oz + (float)(cz - 1) * g.h), exx + eyy);
         if (cz + 1 < Gd - 1) face((g.oz + (float)(cz + 2) * g.h) - qp.z, exx + eyy);
+        if (args.stats && inrange) {
+            int ncand = 0;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) ncand += re[r] - rs[r];
+            atomicAdd(args.stats + blockIdx.z * 8 + 0, 1ull);
+            atomicAdd(args.stats + blockIdx.z * 8 + 1, (unsigned long long)ncand);
+        }
         if (bs >= 0) fbest = best, fid = g.ids[bs];
         if (!done && bs >= 0 && (bound2 == INFINITY || best < bound2 * 0.9999f - margin)) {
             G.dout[(size_t)b * Na + i] = best;
             if (G.iout) G.iout[(size_t)b * Na + i] = fid;
             done = true;
+            if (args.stats) atomicAdd(args.stats + blockIdx.z * 8 + 2, 1ull);
         }
     }
     // not certified within the radius-1 cube.  (Deferring these queries to a compacted second launch made the first one
@@ -515,9 +525,11 @@ __global__ __launch_bounds__(128) void grid_chamfer_kernel(const ChGridArgs args
         // open after radius 3 is a FAR query, for which the walk would visit most of the grid one dependent cell row at a
         // time (tens of thousands of instructions for the whole wave); the wave scans the target for it instead
         if (!done) {
+            if (args.stats) atomicAdd(args.stats + blockIdx.z * 8 + 3, 1ull);
             KBest<1, float> kb;
             kb.key[0] = fbest, kb.idx[0] = fid;
             if (grid_search<1, MetricDiff>(g, qp.x, qp.y, qp.z, met, kb, 2, 3)) {
+                if (args.stats) atomicAdd(args.stats + blockIdx.z * 8 + 4, 1ull);
                 G.dout[(size_t)b * Na + i] = kb.key[0];
                 // (non-finite coordinates leave the list empty: keep the index a valid row, the backward pass gathers through it)
                 if (G.iout) G.iout[(size_t)b * Na + i] = (unsigned)kb.idx[0] < (unsigned)G.gb.P ? kb.idx[0] : 0;
@@ -529,6 +541,10 @@ __global__ __launch_bounds__(128) void grid_chamfer_kernel(const ChGridArgs args
     }
     {
         const int lane = threadIdx.x & 63, j32 = lane & 31, hh = lane >> 5;
+        if (args.stats) {
+            if (lane == 0) atomicAdd(args.stats + blockIdx.z * 8 + 5, 1ull);
+            if (!done) atomicAdd(args.stats + blockIdx.z * 8 + 6, 1ull);
+        }
         float bq[2][2];
 #pragma unroll
         for (int tl = 0; tl < 2; ++tl) {
@@ -574,6 +590,7 @@ __global__ __launch_bounds__(128) void grid_chamfer_kernel(const ChGridArgs args
         }
         if (__ballot(!done && !cert) != 0) {   // (rare: a near-tie between tiles, within the screening's error)
             if (!done && !cert) {
+                if (args.stats) atomicAdd(args.stats + blockIdx.z * 8 + 7, 1ull);
                 best = INFINITY, bs = 0;
                 exact_scan(0, P, best, bs);
             }
@@ -646,9 +663,24 @@ void launch_grid_chamfer(const GridBuf *gq, const GridBuf *gb, float *const *dou
         return e ? atoi(e) : 24;   // (round 3, matrix-core scan + seeded walk, bench regime: 8 / 16 / 24 / 32 / never = 2.75 / 2.32 / 2.22 / 2.30 / 2.81 ms)
     }();
     args.scan_min = scan_min;
+    args.stats = nullptr;
+    static const bool stats_on = getenv("DVM_CHAMFER_STATS") != nullptr;   // diagnostic: synchronous, allocates
+    if (stats_on && hipMalloc(&args.stats, 64 * sizeof(unsigned long long)) == hipSuccess)
+        (void)hipMemsetAsync(args.stats, 0, 64 * sizeof(unsigned long long), s);
     prof_begin(s, DVM_PROF_CHAMFER);
     hipLaunchKernelGGL(grid_chamfer_kernel, dim3((maxN + 127) / 128, B, ngroups), dim3(128), 0, s, args);
     prof_end(s, DVM_PROF_CHAMFER);
+    if (args.stats) {
+        unsigned long long h[64];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h, args.stats, sizeof(h), hipMemcpyDeviceToHost);
+        for (int q = 0; q < ngroups; ++q)
+            fprintf(stderr, "chamfer group %d: %llu queries, %.1f radius-1 candidates each, %.1f%% certified there, %.1f%% walked (%.1f%% certified by the walk), "
+                            "%llu waves scanned for %llu lanes, %llu exact fallbacks\n", q, h[q * 8], (double)h[q * 8 + 1] / (double)(h[q * 8] ? h[q * 8] : 1),
+                    100.0 * h[q * 8 + 2] / (h[q * 8] ? h[q * 8] : 1), 100.0 * h[q * 8 + 3] / (h[q * 8] ? h[q * 8] : 1),
+                    100.0 * h[q * 8 + 4] / (h[q * 8] ? h[q * 8] : 1), h[q * 8 + 5], h[q * 8 + 6], h[q * 8 + 7]);
+        (void)hipFree(args.stats);
+    }
 }
 
 }  // namespace dvm
