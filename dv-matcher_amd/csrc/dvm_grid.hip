@@ -245,8 +245,18 @@ __device__ __forceinline__ bool grid_search(const GridView &g, float qx, float q
         const int z0 = cz - R < 0 ? 0 : cz - R, z1 = cz + R > G - 1 ? G - 1 : cz + R;
         // cells that are adjacent in x are adjacent in memory: each (z, y) row of the cube is one
         // contiguous candidate range (two when the row crosses the already visited inner cube)
-        for (int z = z0; z <= z1; ++z)
+        // A (z, y) row of cells whose slab lies farther from the query than the list's current worst entry cannot contribute (the
+        // same inequality, with the same margins, as the certification below): it is skipped without a load.  The first cube
+        // of an empty list skips nothing; from the second shell on — and in walks that start from a seeded list — most rows go.
+        // (DVM_CHAMFER_STATS: 6 - 8 % of the bench's Chamfer queries need a second shell, and a wave with one such lane used to
+        // walk all 98 cells of it.)
+        for (int z = z0; z <= z1; ++z) {
+            const float zlo = g.oz + (float)z * g.h;
+            const float dz = fmaxf(0.f, fmaxf(zlo - qz, qz - (zlo + g.h)));
             for (int y = y0; y <= y1; ++y) {
+                const float ylo = g.oy + (float)y * g.h;
+                const float dy = fmaxf(0.f, fmaxf(ylo - qy, qy - (ylo + g.h)));
+                if (Metric::to_d2(kb.worst()) < (dy * dy + dz * dz) * 0.9999f - margin) continue;
                 const int rowbase = (z * G + y) * G;
                 const bool inner_zy = (abs(z - cz) <= Rprev) && (abs(y - cy) <= Rprev);
                 int sa0, sa1, sb0 = 0, sb1 = 0;
@@ -264,6 +274,7 @@ __device__ __forceinline__ bool grid_search(const GridView &g, float qx, float q
                 for (int s = sa0; s < sa1; ++s) kb.insert_lex(met(g.pts[s]), g.ids[s]);
                 for (int s = sb0; s < sb1; ++s) kb.insert_lex(met(g.pts[s]), g.ids[s]);
             }
+        }
         // certification.  An unvisited point lies inside the grid's box but beyond one of the cube's
         // (unclipped) faces, say along axis a:  |p - q|^2 >= f_a^2 + sum_{b != a} e_b^2, with f_a the
         // distance from q to that face and e_b the distance from q to the box along axis b (0 inside).
