@@ -449,8 +449,18 @@ __global__ __launch_bounds__(128) void grid_chamfer_kernel(const ChGridArgs args
         }
         float best = INFINITY;
         int bs = -1;
+        // the query's own row first, then the four rows beside it, then the corners: a row whose slab lies beyond the best found
+        // so far (the inequality and margins of the certification) is skipped
+        const float dlo[2] = {fmaxf(0.f, qp.y - (g.oy + (float)cy * g.h)), fmaxf(0.f, qp.z - (g.oz + (float)cz * g.h))};
+        const float dhi[2] = {fmaxf(0.f, (g.oy + (float)(cy + 1) * g.h) - qp.y), fmaxf(0.f, (g.oz + (float)(cz + 1) * g.h) - qp.z)};
+        constexpr int order[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};
 #pragma unroll
-        for (int r = 0; r < 9; ++r)
+        for (int ri = 0; ri < 9; ++ri) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int r = order[ri];
+            const float dyr = r % 3 == 1 ? 0.f : (r % 3 == 0 ? dlo[0] : dhi[0]), dzr = r / 3 == 1 ? 0.f : (r / 3 == 0 ? dlo[1] : dhi[1]);
+            if (best < (dyr * dyr + dzr * dzr) * 0.9999f - margin) continue;
             for (int s0 = rs[r]; s0 < re[r]; s0 += 4) {  // four candidates in flight (each iteration otherwise waits a full load)
                 float4 pc[4];
 #pragma unroll
@@ -466,6 +476,7 @@ __global__ __launch_bounds__(128) void grid_chamfer_kernel(const ChGridArgs args
                     }
                 }
             }
+        }
         // certification of the radius-1 cube (same bound as grid_search)
         const float ext = (float)Gd * g.h;
         const float ex = fmaxf(0.f, fmaxf(g.ox - qp.x, qp.x - (g.ox + ext)));
