@@ -42,22 +42,22 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x
 
 __global__ __launch_bounds__(256) void split_planes_kernel(const float *__restrict__ x, long rows, const int *__restrict__ maxbits,
                                                            char *__restrict__ planes) {
-    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 per thread
-    if (g >= rows * (HB_D / 4)) return;
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;  // eight columns per thread: two 16-byte loads, two 16-byte stores
+    if (g >= rows * (HB_D / 8)) return;
     const float sc = pow2i(scale_exp(*maxbits));
-    const long row = g / (HB_D / 4);
-    const int c = (int)(g % (HB_D / 4));
-    const f32x4 v = *(const f32x4 *)(x + row * HB_D + 4 * c);
-    f16x4 h, m;
+    const long row = g / (HB_D / 8);
+    const int c = (int)(g % (HB_D / 8));
+    const f32x4 v0 = *(const f32x4 *)(x + row * HB_D + 8 * c), v1 = *(const f32x4 *)(x + row * HB_D + 8 * c + 4);
+    f16x8 h, m;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float xv = v[e] * sc;            // exact
-        const _Float16 hh = (_Float16)xv;      // round to nearest even
+    for (int e = 0; e < 8; ++e) {
+        const float xv = (e < 4 ? v0[e & 3] : v1[e & 3]) * sc;   // exact
+        const _Float16 hh = (_Float16)xv;                        // round to nearest even
         h[e] = hh, m[e] = (_Float16)(xv - (float)hh);
     }
-    char *p = planes + row * HB_ROWB + 8 * c;
-    *(f16x4 *)(p) = h;
-    *(f16x4 *)(p + 256) = m;
+    char *p = planes + row * HB_ROWB + 16 * c;
+    *(f16x8 *)(p) = h;
+    *(f16x8 *)(p + 256) = m;
 }
 
 // norms padded to whole key tiles with +inf: out [B][Mpad]
@@ -1018,8 +1018,8 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
         hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, s, f2, r2 * 32, amax_own + 1);
     }
     hipLaunchKernelGGL(common_absmax_kernel, dim3(1), dim3(1), 0, s, amax_in ? amax_in : amax_own, amax_own);
-    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((r1 * 32 + 255) / 256)), dim3(256), 0, s, f1, r1, amax, p1);
-    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((r2 * 32 + 255) / 256)), dim3(256), 0, s, f2, r2, amax + 1, p2);
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((r1 * 16 + 255) / 256)), dim3(256), 0, s, f1, r1, amax, p1);
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((r2 * 16 + 255) / 256)), dim3(256), 0, s, f2, r2, amax + 1, p2);
     hipLaunchKernelGGL(norm_max_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, n1, N, nmax1);
     hipLaunchKernelGGL(norm_max_kernel, dim3((M + 255) / 256, B), dim3(256), 0, s, n2, M, nmax2);
     for (int d = 0; d < (both ? 2 : 1); ++d) (void)hipMemsetAsync(flag[d], 0, sizeof(int32_t), s);
@@ -1153,8 +1153,8 @@ int launch_argmin_f16(const float *f1, const float *f2, int B, int N, int M, int
     hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, s, f1, r1 * 32, amax);
     hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, s, f2, r2 * 32, amax + 1);
     hipLaunchKernelGGL(common_absmax_kernel, dim3(1), dim3(1), 0, s, amax, amax);
-    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((r1 * 32 + 255) / 256)), dim3(256), 0, s, f1, r1, amax, p1);
-    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((r2 * 32 + 255) / 256)), dim3(256), 0, s, f2, r2, amax + 1, p2);
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((r1 * 16 + 255) / 256)), dim3(256), 0, s, f1, r1, amax, p1);
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((r2 * 16 + 255) / 256)), dim3(256), 0, s, f2, r2, amax + 1, p2);
     hipLaunchKernelGGL(norm_max_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, n1, N, nmax1);
     hipLaunchKernelGGL(norm_max_kernel, dim3((M + 255) / 256, B), dim3(256), 0, s, n2, M, nmax2);
     for (int d = 0; d < (both ? 2 : 1); ++d) (void)hipMemsetAsync(flag[d], 0, sizeof(int32_t), s);
