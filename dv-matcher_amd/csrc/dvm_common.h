@@ -171,7 +171,9 @@ struct KBest {
 // low word the index: such doubles order like (key, index) pairs, so a compare-swap of the insertion is v_min_f64 + v_max_f64
 // instead of two compares, their combination and four selects (the idiom of the soft-correspondence sweeps).  insert_lex below
 // costs 2 K instructions where KBest's costs 9 K: the xyz kNN executed 16 600 vector instructions per wave, most of them these.
-// Keys must be >= +0 (a -0 is turned into +0), finite or +inf.
+// Keys must be >= +0 (a -0 is turned into +0), finite or +inf.  The key's bit pattern is biased by 2^20 in the high word, so that
+// even a key of 0 packs into a NORMAL double (the order of the patterns is unchanged; +inf and NaN patterns stay finite doubles):
+// the comparison does not depend on the fp64 denormal mode.
 template <int K, int W = K - 1 /* the entry worst() reports: the K-best search certifies against it */>
 struct KBestPacked {
     double e[K];
@@ -187,13 +189,14 @@ struct KBestPacked {
     }
     __device__ __forceinline__ void init(float inf) {
 #pragma unroll
-        for (int t = 0; t < K; ++t) e[t] = __hiloint2double(__float_as_int(inf), 0x7fffffff);
+        for (int t = 0; t < K; ++t) e[t] = __hiloint2double(__float_as_int(inf) + KBIAS, 0x7fffffff);
     }
-    __device__ __forceinline__ float key_at(int q) const { return __int_as_float(__double2hiint(e[q])); }
+    static constexpr int KBIAS = 1 << 20;
+    __device__ __forceinline__ float key_at(int q) const { return __int_as_float(__double2hiint(e[q]) - KBIAS); }
     __device__ __forceinline__ int idx_at(int q) const { return __double2loint(e[q]); }
     __device__ __forceinline__ float worst() const { return key_at(W); }
     __device__ __forceinline__ void insert_lex(float v, int j) {
-        const double x = __hiloint2double(__float_as_int(v + 0.f), j);
+        const double x = __hiloint2double(__float_as_int(v + 0.f) + KBIAS, j);
         if (!(x < e[K - 1])) return;
         e[K - 1] = x;
 #pragma unroll
