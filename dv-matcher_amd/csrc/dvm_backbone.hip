@@ -479,12 +479,20 @@ __global__ __launch_bounds__(256) void topk_wave_stream_kernel(const float *__re
     const int E = (M + 63) / 64;
     const unsigned long long below = (1ull << lane) - 1ull;
     unsigned m1 = 0xffffffffu, m2 = 0xffffffffu;
-#pragma unroll 8
-    for (int e = 0; e < E; ++e) {
-        const int j = e * 64 + lane;
-        const unsigned x = j < M ? desc_key(s[j < M ? j : M - 1]) : 0xffffffffu;   // (clamped, not predicated: see topk_wave_kernel)
-        m2 = min(m2, max(m1, x));
-        m1 = min(m1, x);
+    for (int e0 = 0; e0 < E; e0 += 8) {   // eight loads in flight (clamped, not predicated: see topk_wave_kernel)
+        float sv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = (e0 + u) * 64 + lane;
+            sv[u] = s[j < M ? j : M - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = (e0 + u) * 64 + lane;
+            const unsigned x = j < M ? desc_key(sv[u]) : 0xffffffffu;
+            m2 = min(m2, max(m1, x));
+            m1 = min(m1, x);
+        }
     }
     unsigned T = 0;
     for (int bit = 31; bit >= 0; --bit) {  // largest T with count(minima < T) < k  ==  their k-th smallest
@@ -496,15 +504,23 @@ __global__ __launch_bounds__(256) void topk_wave_stream_kernel(const float *__re
     cw[lane] = ~0ull;
     cw[lane + 64] = ~0ull;
     int base = 0;
-#pragma unroll 4
-    for (int e = 0; e < E; ++e) {  // optimistic: at most 128 keys pass unless the row has heavy ties
-        const int j = e * 64 + lane;
-        const unsigned x = j < M ? desc_key(s[j < M ? j : M - 1]) : 0xffffffffu;   // (clamped, not predicated: see topk_wave_kernel)
-        const bool take = x <= T && j < M;
-        const unsigned long long mt = __ballot(take);
-        const int pos = base + __popcll(mt & below);
-        if (take && pos < 128) cw[pos] = ((unsigned long long)x << 32) | (unsigned)j;
-        base += __popcll(mt);
+    for (int e0 = 0; e0 < E; e0 += 8) {  // optimistic: at most 128 keys pass unless the row has heavy ties
+        float sv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = (e0 + u) * 64 + lane;
+            sv[u] = s[j < M ? j : M - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = (e0 + u) * 64 + lane;
+            const unsigned x = j < M ? desc_key(sv[u]) : 0xffffffffu;
+            const bool take = x <= T && j < M;
+            const unsigned long long mt = __ballot(take);
+            const int pos = base + __popcll(mt & below);
+            if (take && pos < 128) cw[pos] = ((unsigned long long)x << 32) | (unsigned)j;
+            base += __popcll(mt);
+        }
     }
     if (base > 128) {  // heavy ties: the exact k-th key over all keys, then only the winners (ties in column order)
         T = 0;
