@@ -449,8 +449,11 @@ __device__ __forceinline__ void static_for(F &&f) {
     }
 }
 
-// Three forms of the exact evaluation (FORM; DVM_K1_REFINE selects; measurements: profiles/r3_refine_pmc.txt, 512 pairs x 2):
-// 0  (shipped) every lane streams its own candidate row (32 x 16 B): 2.18 ms.  The wave gathers 48 rows x 512 B; the launch
+// Four forms of the exact evaluation (FORM; DVM_K1_REFINE selects; measurements: profiles/r3_refine_pmc.txt, 512 pairs x 2):
+// 3  (shipped) form 0 with the query row shared by DPP instead of streamed by every lane: half the load instructions, the same
+//    gathered rows: 2.14 - 2.16 ms against 2.19 - 2.21 ms in the same run.  That halving the instructions buys 2 % says what
+//    TA_BUSY counts here: the 48 distinct lines of a candidate-row instruction, not the instruction.
+// 0  every lane streams its own candidate row and the query row (32 x 16 B): 2.18 ms.  The wave gathers 48 rows x 512 B; the launch
 //    moves 12.9 GB from L2 to the CUs = 5.9 TB/s, the rate MI355X_MICROARCH.md measures for random whole rows of a buffer far
 //    larger than the Infinity Cache (5.5 - 5.8 TB/s).  A load instruction touches 48 rows: 1 900 64-B L1 accesses per wave,
 //    TA_BUSY 88 - 100 %.
@@ -466,7 +469,7 @@ __device__ __forceinline__ void static_for(F &&f) {
 //    together with the DMA of the current one, 2.46 ms with every XCD walking its own contiguous eighth of the rows (a
 //    pair's 1 MiB of key rows then stays in that XCD's L2).  7 us per quad and wave: 156 KB in flight per CU do not cover
 //    the round trip at this rate.
-// All three give bit-identical results; none beats the plain form, which is at the gather rate of the memory system: the
+// All four give bit-identical results; none beats the plain forms (0, 3), which is at the gather rate of the memory system: the
 // way to make pass B cheaper is fewer gathered bytes, not a different access shape.
 constexpr int HR_AHEAD = 8;                                              // systolic form: steps of rows in flight per lane
 constexpr int HR_SLOTS = 4 * HB_KC;                                      // candidate rows of a wave
@@ -541,6 +544,34 @@ __global__ __launch_bounds__(FORM == 1 ? 64 : 256) void softcorr_refine_kernel(c
     float v = INFINITY;
     if (FORM == 0) {
         if (eval) v = exact_d2(G.q + (size_t)row * HB_D, G.k + ((size_t)b * M + j) * HB_D, na, G.nk[(size_t)b * M + j]);
+    } else if (FORM == 3) {
+        // As form 0, but the QUERY row is not streamed by every lane: the 16 lanes of a row each load 32 bytes of it once (times
+        // -2), and the chain takes q_k from the lane that holds it through a DPP row_share move (which replaces the multiply by
+        // -2: the same number of vector instructions).  Half of form 0's load instructions were these 16-fold redundant query
+        // loads, and the kernel is bound by the texture-address unit (TA_BUSY 88 - 100 %).  All 16 lanes run the chain (the
+        // lanes without a candidate on the query row itself: a line already there), the result is kept where `eval`.
+        constexpr int ROW_SHARE0 = 0x150;
+        const float *qpc = G.q + (size_t)row * HB_D + 8 * l16;
+        const f32x4 qa = *(const f32x4 *)qpc, qb = *(const f32x4 *)(qpc + 4);
+        const float qs[8] = {-2.f * qa.x, -2.f * qa.y, -2.f * qa.z, -2.f * qa.w, -2.f * qb.x, -2.f * qb.y, -2.f * qb.z, -2.f * qb.w};
+        const float *kr = eval ? G.k + ((size_t)b * M + j) * HB_D : G.q + (size_t)row * HB_D;
+        const float nb = eval ? G.nk[(size_t)b * M + j] : 0.f;
+        float acc = 0.f;
+        f32x4 kv[HB_D / 4];
+#pragma unroll
+        for (int c = 0; c < HB_D / 4; ++c) kv[c] = *(const f32x4 *)(kr + 4 * c);
+        static_for<0, HB_D / 4>([&](auto cc) __attribute__((always_inline)) {
+            constexpr int c = decltype(cc)::value;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(qs[4 * (c & 1) + e]), ROW_SHARE0 + c / 2, 0xf, 0xf, false));
+                acc = fmaf(t, kv[c][e], acc);
+            }
+        });
+        if (eval) {
+            const float d2 = (acc + na) + nb;
+            v = d2 > 0.f ? d2 : 0.f;
+        }
     } else if (FORM == 2) {
         // The 16 lanes of a row as a systolic chain: lane l holds dims [8 l, 8 l + 8) of the query (times -2) and, at step t,
         // the same dims of candidate t - l; it continues that candidate's fma chain (the accumulator arrives from lane l - 1
@@ -1083,7 +1114,7 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
     r.neg_alpha = neg_alpha;
     r.topk = topk;
     prof_begin(s, DVM_PROF_K1_REFINE);
-    static const int rform = [] { const char *e = getenv("DVM_K1_REFINE"); return e ? atoi(e) : 0; }();   // (A/B measurements)
+    static const int rform = [] { const char *e = getenv("DVM_K1_REFINE"); return e ? atoi(e) : 3; }();   // (A/B measurements)
     static const int refine_waves = [] {   // persistent form: 6 single-wave workgroups of 26 KiB LDS fit a CU
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
@@ -1093,6 +1124,8 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
     r.remap = rform >= 10;
     if (rform == 1)
         hipLaunchKernelGGL(softcorr_refine_kernel<1>, dim3((unsigned)refine_waves), dim3(64), 0, s, r);   // (a multiple of 8)
+    else if (rform == 3)
+        hipLaunchKernelGGL(softcorr_refine_kernel<3>, dim3((unsigned)((r.rows_total * 16 + 255) / 256)), dim3(256), 0, s, r);
     else if (rform % 10 == 0)
         hipLaunchKernelGGL(softcorr_refine_kernel<0>, dim3((unsigned)((r.rows_total * 16 + 255) / 256)), dim3(256), 0, s, r);
     else
