@@ -449,10 +449,16 @@ __device__ __forceinline__ void static_for(F &&f) {
     }
 }
 
-// Four forms of the exact evaluation (FORM; DVM_K1_REFINE selects; measurements: profiles/r3_refine_pmc.txt, 512 pairs x 2):
-// 3  (shipped) form 0 with the query row shared by DPP instead of streamed by every lane: half the load instructions, the same
-//    gathered rows: 2.14 - 2.16 ms against 2.19 - 2.21 ms in the same run.  That halving the instructions buys 2 % says what
-//    TA_BUSY counts here: the 48 distinct lines of a candidate-row instruction, not the instruction.
+// Five forms of the exact evaluation (FORM; DVM_K1_REFINE selects; measurements: profiles/r3_refine_pmc.txt, 512 pairs x 2):
+// 4  (shipped, as 14 = with XCD-aware block numbering) four lanes load a whole 64-byte piece of a candidate row, the lane <-> row
+//    transpose goes through LDS, the chain is one v_fmac_f32_dpp per dimension (query values by row_share): 1.04 ms.  A quarter
+//    of form 0's L1 accesses (652 per wave), no line fetched twice, TA_BUSY 43 %; what then set the time was how long a wave
+//    lives (two dependent round trips + the chain) times how many fit: 2.07 ms at 171 VGPRs (whole row in flight), 1.60 with a
+//    rolling window of 4 pieces and the fused DPP fma, 1.29 at 2 pieces (118 VGPRs = 4 waves per SIMD), 1.04 with the group
+//    wave-uniform (pointers in scalar registers) and 3 pieces; XCD-aware numbering is worth 5 % here (neutral on forms 0 - 2).
+// 3  form 0 with the query row shared by DPP instead of streamed by every lane: half the load instructions, the same
+//    gathered rows: 2.14 - 2.16 ms against 2.19 - 2.21 ms in the same run (with update_dpp + fma; 2.69 ms with the fused
+//    instruction, whose fixed order makes the compiler hold the whole row: 190 VGPRs).
 // 0  every lane streams its own candidate row and the query row (32 x 16 B): 2.18 ms.  The wave gathers 48 rows x 512 B; the launch
 //    moves 12.9 GB from L2 to the CUs = 5.9 TB/s, the rate MI355X_MICROARCH.md measures for random whole rows of a buffer far
 //    larger than the Infinity Cache (5.5 - 5.8 TB/s).  A load instruction touches 48 rows: 1 900 64-B L1 accesses per wave,
@@ -469,8 +475,15 @@ __device__ __forceinline__ void static_for(F &&f) {
 //    together with the DMA of the current one, 2.46 ms with every XCD walking its own contiguous eighth of the rows (a
 //    pair's 1 MiB of key rows then stays in that XCD's L2).  7 us per quad and wave: 156 KB in flight per CU do not cover
 //    the round trip at this rate.
-// All four give bit-identical results; none beats the plain forms (0, 3), which is at the gather rate of the memory system: the
-// way to make pass B cheaper is fewer gathered bytes, not a different access shape.
+// All five give bit-identical results.  Forms 0 - 3 end at 2.1 - 2.2 ms for three different reasons (L1 accesses; chain fill and
+// drain; occupancy) - which looked like the gather rate of the memory system until form 4 removed all three.
+// acc = fma(x of lane L of the 16-lane row, y, acc) in ONE instruction (the compiler keeps update_dpp + v_fma apart, with a
+// v_mov 0 for the DPP's `old` operand: three instructions).  x must have been written at least two instructions earlier (the DPP
+// read-after-write hazard is not tracked through inline assembly): here the scaled query values, written before the row loads.
+template <int L>
+__device__ __forceinline__ void fma_row_share(float &acc, float x, float y) {
+    asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(L));
+}
 constexpr int HR_AHEAD = 8;                                              // systolic form: steps of rows in flight per lane
 constexpr int HR_SLOTS = 4 * HB_KC;                                      // candidate rows of a wave
 constexpr int HR_LDS_BYTES = (HR_SLOTS + 4) * HB_D * (int)sizeof(float);   // + the 4 query rows
@@ -480,21 +493,27 @@ struct HRRow {     // what a lane needs of its row before the candidate rows can
     bool rvalid;
     float va, na, nkm, ls0, ls1;
 };
-template <int FORM>
+static inline long hr_quads(const HRArgs &r) { return (r.rows0 + 3) / 4 + (r.rows_total - r.rows0 + 3) / 4; }
+template <int FORM, int HR4W = 4>
 __global__ __launch_bounds__(FORM == 1 ? 64 : 256) void softcorr_refine_kernel(const HRArgs args) {
-    __shared__ __attribute__((aligned(16))) char hr_lds[FORM == 1 ? HR_LDS_BYTES : 16];
+    __shared__ __attribute__((aligned(16))) char hr_lds[FORM == 1 ? HR_LDS_BYTES : FORM == 4 ? 4 * 2 * HR_SLOTS * 64 : 16];
     const int lane = threadIdx.x & 63, l16 = lane & 15, base = lane & 48;
     const float neg_alpha = args.neg_alpha;
     const int topk = args.topk;
     const bool cand = l16 < HB_KC;
     // (XCD-aware block numbering — a pair's rows on one XCD, so that its 2048 key rows stay in one L2 — was measured neutral,
     // 2.15 vs 2.19 ms: what the other seven L2s miss is served by the Infinity Cache)
-    auto fetch = [&](long grow) __attribute__((always_inline)) {   // grow: row number over both groups
+    // A quad (the 4 rows of a wave) never straddles the two groups, so the group - and with it every pointer of HRGroup - is
+    // wave-uniform and lives in scalar registers (per-lane groups cost ~20 VGPRs, which is a wave per SIMD in form 4).
+    const long nq0 = (args.rows0 + 3) / 4, nquads = nq0 + (args.rows_total - args.rows0 + 3) / 4;
+    auto fetch = [&](long quad_) __attribute__((always_inline)) {
         HRRow p;
-        p.rvalid = grow < args.rows_total;
-        if (!p.rvalid) grow = args.rows_total - 1;
-        p.grp = grow >= args.rows0 ? 1 : 0;
-        p.row = grow - (p.grp ? args.rows0 : 0);
+        const int qd = __builtin_amdgcn_readfirstlane((int)quad_);
+        p.grp = qd >= nq0 ? 1 : 0;
+        const long rows = p.grp ? args.rows_total - args.rows0 : args.rows0;
+        p.row = (long)(qd - (p.grp ? (int)nq0 : 0)) * 4 + (lane >> 4);
+        p.rvalid = p.row < rows;
+        if (!p.rvalid) p.row = rows - 1;
         const HRGroup &G = args.g[p.grp];
         p.jc = cand ? G.cidx[p.row * HB_KC + l16] : 0x7fffffff;
         p.va = cand ? G.cd2[p.row * HB_KC + l16] : INFINITY;
@@ -504,7 +523,6 @@ __global__ __launch_bounds__(FORM == 1 ? 64 : 256) void softcorr_refine_kernel(c
         p.ls1 = G.lsum[p.row * 2 + 1];
         return p;
     };
-    const long nquads = (args.rows_total + 3) / 4;
     // Form 1: workgroup i runs on XCD i % 8; every XCD walks ITS contiguous eighth of the quads, its waves side by side — so the
     // 192 waves of an XCD are inside one pair's rows at any time and that pair's 1 MiB of key rows stays in the XCD's L2.
     long quad, qend, qstep;
@@ -519,7 +537,7 @@ __global__ __launch_bounds__(FORM == 1 ? 64 : 256) void softcorr_refine_kernel(c
         qstep = nquads;
     }
     if (quad >= qend) return;
-    HRRow cur = fetch(quad * 4 + (lane >> 4));
+    HRRow cur = fetch(quad);
     for (; quad < qend; quad += qstep) {
     const HRRow p = cur;
     const HRGroup &G = args.g[p.grp];
@@ -564,9 +582,68 @@ __global__ __launch_bounds__(FORM == 1 ? 64 : 256) void softcorr_refine_kernel(c
             constexpr int c = decltype(cc)::value;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float t = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(qs[4 * (c & 1) + e]), ROW_SHARE0 + c / 2, 0xf, 0xf, false));
-                acc = fmaf(t, kv[c][e], acc);
+                fma_row_share<c / 2>(acc, qs[4 * (c & 1) + e], kv[c][e]);
             }
+        });
+        if (eval) {
+            const float d2 = (acc + na) + nb;
+            v = d2 > 0.f ? d2 : 0.f;
+        }
+    } else if (FORM == 4) {
+        // Whole 64-byte pieces per four lanes, the lane <-> row transpose through LDS.  Forms 0 and 3 touch 48 different lines
+        // with every load instruction (16 bytes of each) - 1 536 L1 accesses per wave for 384 accesses' worth of bytes.  Here
+        // lane L loads chunk L % 4 of the 64-byte piece p of candidate row L / 4 + 16 i (i = 0..2): 16 full accesses per
+        // instruction, 384 per wave; the 24 loads of the 8 pieces are requested at once, and piece by piece the registers go
+        // to LDS (chunk c of slot s at position c ^ (s / 4 % 4): conflict-free both ways) from where each candidate lane reads
+        // ITS row's piece and continues its k-ordered chain.  Two 3-KiB piece buffers per wave; the LDS pipe serves a wave's
+        // instructions in order, so the write of piece p + 2 cannot overtake the reads of piece p.
+        constexpr int ROW_SHARE0 = 0x150;
+        const float *qrow = G.q + (size_t)row * HB_D;
+        const f32x4 qa = *(const f32x4 *)(qrow + 8 * l16), qb = *(const f32x4 *)(qrow + 8 * l16 + 4);
+        const float qs[8] = {-2.f * qa.x, -2.f * qa.y, -2.f * qa.z, -2.f * qa.w, -2.f * qb.x, -2.f * qb.y, -2.f * qb.z, -2.f * qb.w};
+        const float *const kptr = eval ? G.k + ((size_t)b * M + j) * HB_D : qrow;   // (a row that is not needed: the query row)
+        const float nb = eval ? G.nk[(size_t)b * M + j] : 0.f;
+        const unsigned klo = (unsigned)(uintptr_t)kptr, khi = (unsigned)((uintptr_t)kptr >> 32);
+        char *const wl = hr_lds + (threadIdx.x >> 6) * (2 * HR_SLOTS * 64);
+        const int ck = lane & 3, s0 = lane >> 2;
+        typedef const __attribute__((address_space(1))) float gfloat;   // (an address rebuilt from integers is a flat one otherwise,
+        gfloat *src[3];                                                  // and flat loads count on the LDS counter as well)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int sl = s0 + 16 * i, owner = (sl / HB_KC) * 16 + sl % HB_KC;
+            const unsigned lo = (unsigned)__shfl((int)klo, owner, 64), hi = (unsigned)__shfl((int)khi, owner, 64);
+            src[i] = (gfloat *)(((uintptr_t)hi << 32) | lo) + 4 * ck;
+        }
+        constexpr int WIN = HR4W;   // pieces in flight per lane (x 3 loads): 8 = the whole row (171 VGPRs, 2 waves per SIMD)
+        f32x4 kv[WIN][3];
+#pragma unroll
+        for (int pc = 0; pc < WIN; ++pc)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) kv[pc][i] = *(const __attribute__((address_space(1))) f32x4 *)(src[i] + 16 * pc);
+        const int myslot = (lane >> 4) * HB_KC + (cand ? l16 : 0);
+        const int wsw = (s0 >> 2) & 3, rsw = (myslot >> 2) & 3;   // (s0 + 16 i) / 4 % 4 does not depend on i
+        float acc = 0.f;
+        static_for<0, 8>([&](auto pcc) __attribute__((always_inline)) {
+            constexpr int pc = decltype(pcc)::value;
+            char *const buf = wl + (pc & 1) * (HR_SLOTS * 64);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) *(f32x4 *)(buf + (s0 + 16 * i) * 64 + ((ck ^ wsw) << 4)) = kv[pc % WIN][i];
+            if constexpr (pc + WIN < 8) {   // the registers just stored take the piece WIN further on
+#pragma unroll
+                for (int i = 0; i < 3; ++i) kv[pc % WIN][i] = *(const __attribute__((address_space(1))) f32x4 *)(src[i] + 16 * (pc + WIN));
+            }
+            __builtin_amdgcn_wave_barrier();
+            f32x4 kc[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) kc[c] = *(const f32x4 *)(buf + myslot * 64 + ((c ^ rsw) << 4));
+            __builtin_amdgcn_wave_barrier();
+            static_for<0, 4>([&](auto cc) __attribute__((always_inline)) {
+                constexpr int c = decltype(cc)::value;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    fma_row_share<2 * pc + c / 2>(acc, qs[4 * (c & 1) + e], kc[c][e]);
+                }
+            });
         });
         if (eval) {
             const float d2 = (acc + na) + nb;
@@ -650,7 +727,7 @@ __global__ __launch_bounds__(FORM == 1 ? 64 : 256) void softcorr_refine_kernel(c
                                              (__attribute__((address_space(3))) void *)(hr_lds + (HR_SLOTS / 2 + i) * 1024), 16, 0, 0);
         }
         const float nb = eval ? G.nk[(size_t)b * M + j] : 0.f;
-        if (quad + qstep < qend) cur = fetch((quad + qstep) * 4 + (lane >> 4));   // the next quad's lists ride on this round trip
+        if (quad + qstep < qend) cur = fetch(quad + qstep);   // the next quad's lists ride on this round trip
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wave's own pieces have landed (one wave per workgroup: no barrier)
         if (eval) {
             const int g = lane >> 4, slot = g * HB_KC + l16;
@@ -1114,7 +1191,7 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
     r.neg_alpha = neg_alpha;
     r.topk = topk;
     prof_begin(s, DVM_PROF_K1_REFINE);
-    static const int rform = [] { const char *e = getenv("DVM_K1_REFINE"); return e ? atoi(e) : 3; }();   // (A/B measurements)
+    static const int rform = [] { const char *e = getenv("DVM_K1_REFINE"); return e ? atoi(e) : 14; }();   // (A/B measurements)
     static const int refine_waves = [] {   // persistent form: 6 single-wave workgroups of 26 KiB LDS fit a CU
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
@@ -1124,12 +1201,21 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
     r.remap = rform >= 10;
     if (rform == 1)
         hipLaunchKernelGGL(softcorr_refine_kernel<1>, dim3((unsigned)refine_waves), dim3(64), 0, s, r);   // (a multiple of 8)
-    else if (rform == 3)
-        hipLaunchKernelGGL(softcorr_refine_kernel<3>, dim3((unsigned)((r.rows_total * 16 + 255) / 256)), dim3(256), 0, s, r);
+    else if (rform % 10 == 4) {
+        static const int win = [] { const char *e = getenv("DVM_K1_REFINE_WIN"); return e ? atoi(e) : 3; }();
+        const dim3 grid((unsigned)((hr_quads(r) * 64 + 255) / 256));
+        if (win == 1) hipLaunchKernelGGL((softcorr_refine_kernel<4, 1>), grid, dim3(256), 0, s, r);
+        else if (win == 2) hipLaunchKernelGGL((softcorr_refine_kernel<4, 2>), grid, dim3(256), 0, s, r);
+        else if (win == 3) hipLaunchKernelGGL((softcorr_refine_kernel<4, 3>), grid, dim3(256), 0, s, r);
+        else if (win == 8) hipLaunchKernelGGL((softcorr_refine_kernel<4, 8>), grid, dim3(256), 0, s, r);
+        else hipLaunchKernelGGL((softcorr_refine_kernel<4, 4>), grid, dim3(256), 0, s, r);
+    }
+    else if (rform % 10 == 3)
+        hipLaunchKernelGGL(softcorr_refine_kernel<3>, dim3((unsigned)((hr_quads(r) * 64 + 255) / 256)), dim3(256), 0, s, r);
     else if (rform % 10 == 0)
-        hipLaunchKernelGGL(softcorr_refine_kernel<0>, dim3((unsigned)((r.rows_total * 16 + 255) / 256)), dim3(256), 0, s, r);
+        hipLaunchKernelGGL(softcorr_refine_kernel<0>, dim3((unsigned)((hr_quads(r) * 64 + 255) / 256)), dim3(256), 0, s, r);
     else
-        hipLaunchKernelGGL(softcorr_refine_kernel<2>, dim3((unsigned)((r.rows_total * 16 + 255) / 256)), dim3(256), 0, s, r);
+        hipLaunchKernelGGL(softcorr_refine_kernel<2>, dim3((unsigned)((hr_quads(r) * 64 + 255) / 256)), dim3(256), 0, s, r);
     prof_end(s, DVM_PROF_K1_REFINE);
 
     HXArgs x;

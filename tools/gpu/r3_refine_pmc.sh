@@ -10,6 +10,6 @@ timeout 200 rocprofv3 --kernel-trace --pmc TCP_PENDING_STALL_CYCLES_sum TCP_TCC_
 timeout 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INST_CYCLES_VMEM -d $O/f$f/sq --output-format csv -- $B > $O/f${f}_sq.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE TCC_HIT_sum TCC_MISS_sum -d $O/f$f/tcc --output-format csv -- $B > $O/f${f}_tcc.log 2>&1
 echo "== DVM_K1_REFINE=$f"; cd $R; python tools/pmc_summary.py $O/f$f softcorr_refine; cd /tmp
-done > $O/summary_f2.txt 2>&1
+done > $O/summary.txt 2>&1
 find $O -name "*.csv" -size +2M -delete
-cat $O/summary_f2.txt
+cat $O/summary.txt
