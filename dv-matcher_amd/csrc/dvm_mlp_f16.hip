@@ -78,34 +78,49 @@ struct WFrag {
     }
 };
 
-template <int NT, int MH_AHEAD>
+// One k-loop of a phase, software-pipelined BY HAND: at step s the weight fragments of step s + MH_AHEAD and the activation
+// fragments of step s + 1 are requested, then step s's matrix instructions run - with scheduling barriers in between, because
+// left alone the compiler sinks every load to just above its first use to save registers (ISA: `global_load` / `s_waitcnt
+// vmcnt(0)` / `v_mfma` - a whole L2 round trip exposed per k-step - and `ds_read` x 2 / `s_waitcnt lgkmcnt(1)` / `v_mfma`).
+template <int NT, int MH_AHEAD, int STEPS, int ABL = 0>
 __device__ __forceinline__ void mma_tiles(const char *__restrict__ a0, int row_stride, int plane_bytes,
-                                          const _Float16 *__restrict__ wp /* (otile, first step) base + lane*8 */, int steps,
+                                          const _Float16 *__restrict__ wp /* (otile, first step) base + lane*8 */,
                                           f32x16 (&acc)[NT], const WFrag<MH_AHEAD> &first) {
     f16x8 wh[MH_AHEAD], wm[MH_AHEAD];
 #pragma unroll
     for (int u = 0; u < MH_AHEAD; ++u) wh[u] = first.h[u], wm[u] = first.m[u];
-    for (int s0 = 0; s0 < steps; s0 += MH_AHEAD) {
+    f16x8 ah[2][NT], am[2][NT];
 #pragma unroll
-        for (int u = 0; u < MH_AHEAD; ++u) {
-            const int s = s0 + u;
-            if (s < steps) {   // (wave-uniform)
-                const f16x8 bh = wh[u], bm = wm[u];
-                const _Float16 *wn = wp + (size_t)(s + MH_AHEAD < steps ? s + MH_AHEAD : steps - 1) * 1024;
-                wh[u] = *(const f16x8 *)(wn), wm[u] = *(const f16x8 *)(wn + 512);
+    for (int t = 0; t < NT; ++t) {
+        const char *ar = a0 + t * 32 * row_stride;
+        ah[0][t] = *(const f16x8 *)(ar), am[0][t] = *(const f16x8 *)(ar + plane_bytes);
+    }
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const char *ar = a0 + t * 32 * row_stride + 32 * s;
-                    const f16x8 ah = *(const f16x8 *)(ar), am = *(const f16x8 *)(ar + plane_bytes);
-                    // weights as the A operand, activations as B: the accumulator tile is [out][node] — a lane owns ONE node (its
-                    // r32) and 4 x 4 consecutive outputs, so the activation stores below are 8-byte ones (the fragments of the
-                    // two operands have the same register layout: swapping them transposes the tile and nothing else)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, am, acc[t], 0, 0, 0);  // small terms first
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bm, ah, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[t], 0, 0, 0);
-                }
+    for (int s = 0; s < STEPS; ++s) {
+        const int u = s % MH_AHEAD, cur = s & 1;
+        const f16x8 bh = wh[u], bm = wm[u];
+        if (!(ABL & 1) && s + MH_AHEAD < STEPS) {
+            const _Float16 *wn = wp + (size_t)(s + MH_AHEAD) * 1024;
+            wh[u] = *(const f16x8 *)(wn), wm[u] = *(const f16x8 *)(wn + 512);
+        }
+        if (s + 1 < STEPS) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const char *ar = a0 + t * 32 * row_stride + ((ABL & 2) ? 0 : 32 * (s + 1));
+                ah[cur ^ 1][t] = *(const f16x8 *)(ar), am[cur ^ 1][t] = *(const f16x8 *)(ar + plane_bytes);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            // weights as the A operand, activations as B: the accumulator tile is [out][node] - a lane owns ONE node (its
+            // r32) and 4 x 4 consecutive outputs, so the activation stores below are 8-byte ones (the fragments of the
+            // two operands have the same register layout: swapping them transposes the tile and nothing else)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, am[cur][t], acc[t], 0, 0, 0);  // small terms first
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bm, ah[cur][t], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah[cur][t], acc[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -113,9 +128,22 @@ __device__ __forceinline__ float elu_fast(float x) {
     return x > 0.f ? x : __builtin_amdgcn_exp2f(x * 1.4426950408889634f) - 1.f;
 }
 
-// bias + ELU on the un-scaled accumulator, then scale, split and store the two planes of this lane's 16 (out, node) values:
-// register r = 4 g + e holds output ocol0 + 8 g + e of the lane's node — four 8-byte stores per plane
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+// Two values -> their packed fp16 planes: h = rn16(a), m = rn16(a - h) (a - h is exact in fp32), three instructions per pair:
+// the packed round-to-nearest conversion (gfx950) and one v_fma_mix per value, which reads the fp16 h directly and writes its
+// half of m.  (The compiler's form of split2 is convert, convert back, subtract, convert, pack: 4.5 per value.)
+__device__ __forceinline__ void split2x2(float a0, float a1, unsigned &h, unsigned &m) {
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(a0), "v"(a1));
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(m) : "v"(a0), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(m) : "v"(a1), "v"(h));
+}
+
+// bias + ELU + scale + split of this lane's 16 (out, node) values, then four 8-byte stores per plane: register r = 4 g + e holds
+// output ocol0 + 8 g + e of the lane's node.  Everything runs in the SCALED domain (xs = S_a x: the scales are powers of two,
+// so every rounding is the one of the unscaled formula): xs = fma(acc, S_a / (S_a S_w), S_a b); S_a elu(x) = xs > 0 ? xs :
+// fma(exp2(xs log2e / S_a), S_a, -S_a).  The range guard is a running max of |a| (one instruction; compared once per kernel).
+// These epilogues are vector work that no matrix instruction overlaps (all eight waves reach them together): at 14.5
+// instructions per value they were 6.5 of a workgroup's 31 us.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 struct Bias16 {
     f32x4 v[4];
     __device__ __forceinline__ void request(const float *__restrict__ b, int ocol0) {
@@ -124,25 +152,28 @@ struct Bias16 {
     }
 };
 __device__ __forceinline__ void store_act(const f32x16 &acc, const Bias16 &bv, int ocol0, char *dst /* this lane's node row */, int plane_bytes,
-                                          int &bad) {
+                                          float &amax) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        f16x4 h4, m4;
+        float a[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float a = elu_fast(acc[4 * g + e] * MH_INV + bv.v[g][e]) * MH_SA;
-            bad |= !(fabsf(a) <= MH_LIMIT);
-            _Float16 h, m;
-            split2(a, h, m);
-            h4[e] = h, m4[e] = m;
+            const float xs = fmaf(acc[4 * g + e], MH_INV * MH_SA, bv.v[g][e] * MH_SA);
+            const float ex = fmaf(__builtin_amdgcn_exp2f(xs * (1.4426950408889634f / MH_SA)), MH_SA, -MH_SA);
+            a[e] = xs > 0.f ? xs : ex;
+            amax = fmaxf(amax, fabsf(a[e]));
         }
+        unsigned h0, m0, h1, m1;
+        split2x2(a[0], a[1], h0, m0);
+        split2x2(a[2], a[3], h1, m1);
+        const u32x2 h = {h0, h1}, m = {m0, m1};
         char *p = dst + 2 * (ocol0 + 8 * g);
-        *(f16x4 *)(p) = h4;
-        *(f16x4 *)(p + plane_bytes) = m4;
+        *(u32x2 *)(p) = h;
+        *(u32x2 *)(p + plane_bytes) = m;
     }
 }
 
-template <int AHEAD>
+template <int AHEAD, int ABL = 0>
 __global__ __launch_bounds__(MH_THREADS) void mlp_f16x2_kernel(const float *__restrict__ z, int rows,
                                                                const _Float16 *__restrict__ Wp0, const float *__restrict__ b0,
                                                                const _Float16 *__restrict__ Wp1, const float *__restrict__ b1,
@@ -155,7 +186,7 @@ __global__ __launch_bounds__(MH_THREADS) void mlp_f16x2_kernel(const float *__re
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r32 = lane & 31, hh = lane >> 5;
     const int row0 = blockIdx.x * MH_NODES;
-    int bad = 0;
+    float amax = 0.f;   // largest |activation| of this lane (scaled): beyond fp16's range -> the flag (inf included; a NaN is a NaN in the result either way)
     // this wave's five biases and the first weight fragments of layer 0: requested before anything else, in flight while the z
     // rows are staged (each bias load used to sit between a phase's last matrix instruction and its activation stores)
     // (the biases of a phase — 16 per lane — are requested at the head of the phase: they land under its matrix instructions)
@@ -182,15 +213,18 @@ __global__ __launch_bounds__(MH_THREADS) void mlp_f16x2_kernel(const float *__re
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (row0 + r < rows && 4 * c < MH_ZS) v = zv[it];
         char *p = bufZ + r * MH_SZ + 8 * c;
+        float a[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float a = (4 * c + q < 262 ? v[q] : 0.f) * MH_SA;
-            bad |= !(fabsf(a) <= MH_LIMIT);
-            _Float16 h, m;
-            split2(a, h, m);
-            *(_Float16 *)(p + 2 * q) = h;
-            *(_Float16 *)(p + 2 * MH_K0 + 2 * q) = m;
+            a[q] = (4 * c + q < 262 ? v[q] : 0.f) * MH_SA;
+            amax = fmaxf(amax, fabsf(a[q]));
         }
+        unsigned h0, m0, h1, m1;
+        split2x2(a[0], a[1], h0, m0);
+        split2x2(a[2], a[3], h1, m1);
+        const u32x2 h = {h0, h1}, m = {m0, m1};
+        *(u32x2 *)(p) = h;
+        *(u32x2 *)(p + 2 * MH_K0) = m;
     }
     __syncthreads();
 
@@ -216,21 +250,21 @@ __global__ __launch_bounds__(MH_THREADS) void mlp_f16x2_kernel(const float *__re
                 for (int r = 0; r < 16; ++r) acc0[t][r] = 0.f;
             Bias16 bv;
             bv.request(b0, ot * 32 + 4 * hh);
-            mma_tiles<2, AHEAD>(bufZ + r32 * MH_SZ + 16 * hh, MH_SZ, 2 * MH_K0, w0p[hlf], MH_K0 / 16, acc0, wa);
+            mma_tiles<2, AHEAD, MH_K0 / 16, ABL>(bufZ + r32 * MH_SZ + 16 * hh, MH_SZ, 2 * MH_K0, w0p[hlf], acc0, wa);
             wb.request(w1p[hlf], 16);   // layer 1's first fragments travel while this half's activations are stored
 #pragma unroll
-            for (int t = 0; t < 2; ++t) store_act(acc0[t], bv, wave * 32 + 4 * hh, bufH + (t * 32 + r32) * MH_SH, 2 * 256, bad);
+            for (int t = 0; t < 2; ++t) store_act(acc0[t], bv, wave * 32 + 4 * hh, bufH + (t * 32 + r32) * MH_SH, 2 * 256, amax);
         }
         __syncthreads();
         // layer 1, K-half hlf: out tile = wave (8 tiles = 256 outputs), k-steps 16*hlf .. 16*hlf+15
         if (hlf == 1) bias1.request(b1, wave * 32 + 4 * hh);
-        mma_tiles<2, AHEAD>(bufH + r32 * MH_SH + 16 * hh, MH_SH, 2 * 256, w1p[hlf], 16, acc1, wb);
+        mma_tiles<2, AHEAD, 16, ABL>(bufH + r32 * MH_SH + 16 * hh, MH_SH, 2 * 256, w1p[hlf], acc1, wb);
         if (hlf == 0) wa.request(w0p[1], MH_K0 / 16); else wa.request(w2p, MH_K2 / 16);   // the next phase's, across the barrier
         __syncthreads();
     }
     {   // h1 -> bufZ (z is dead)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) store_act(acc1[t], bias1, wave * 32 + 4 * hh, bufZ + (t * 32 + r32) * MH_SZ, 2 * MH_K2, bad);
+        for (int t = 0; t < 2; ++t) store_act(acc1[t], bias1, wave * 32 + 4 * hh, bufZ + (t * 32 + r32) * MH_SZ, 2 * MH_K2, amax);
     }
     __syncthreads();
     // layer 2: 256 -> 128 : 4 output tiles x 2 node tiles, one pair per wave
@@ -241,9 +275,9 @@ __global__ __launch_bounds__(MH_THREADS) void mlp_f16x2_kernel(const float *__re
         for (int r = 0; r < 16; ++r) acc2[0][r] = 0.f;
         Bias16 bias2;
         bias2.request(b2, ot * 32 + 4 * hh);
-        mma_tiles<1, AHEAD>(bufZ + (nt * 32 + r32) * MH_SZ + 16 * hh, MH_SZ, 2 * MH_K2, w2p, MH_K2 / 16, acc2, wa);
+        mma_tiles<1, AHEAD, MH_K2 / 16, ABL>(bufZ + (nt * 32 + r32) * MH_SZ + 16 * hh, MH_SZ, 2 * MH_K2, w2p, acc2, wa);
         if (wave < 2) wb.request(w3p, MH_K3 / 16);
-        store_act(acc2[0], bias2, ot * 32 + 4 * hh, bufH + (nt * 32 + r32) * MH_SH, 2 * MH_K3, bad);
+        store_act(acc2[0], bias2, ot * 32 + 4 * hh, bufH + (nt * 32 + r32) * MH_SH, 2 * MH_K3, amax);
     }
     __syncthreads();
     // layer 3: 128 -> 9 : one output tile per node tile, straight to HBM
@@ -251,7 +285,7 @@ __global__ __launch_bounds__(MH_THREADS) void mlp_f16x2_kernel(const float *__re
         f32x16 acc3[1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc3[0][r] = 0.f;
-        mma_tiles<1, AHEAD>(bufH + (wave * 32 + r32) * MH_SH + 16 * hh, MH_SH, 2 * MH_K3, w3p, MH_K3 / 16, acc3, wb);
+        mma_tiles<1, AHEAD, MH_K3 / 16, ABL>(bufH + (wave * 32 + r32) * MH_SH + 16 * hh, MH_SH, 2 * MH_K3, w3p, acc3, wb);
         const int node = wave * 32 + r32;   // (transposed tile: the lane's node, outputs (r & 3) + 8 (r >> 2) + 4 hh — r < 5 reaches 0..8)
 #pragma unroll
         for (int r = 0; r < 5; ++r) {
@@ -259,7 +293,7 @@ __global__ __launch_bounds__(MH_THREADS) void mlp_f16x2_kernel(const float *__re
             if (o < 9 && row0 + node < rows) out[(size_t)(row0 + node) * 9 + o] = acc3[0][r] * MH_INV + b3[o];
         }
     }
-    if (__any(bad) && lane == 0) atomicOr(flag, 1);
+    if (__any(!(amax <= MH_LIMIT)) && lane == 0) atomicOr(flag, 1);
 }
 
 }  // namespace
@@ -294,11 +328,18 @@ int *launch_mlp_rows_f16(const float *z, int rows, const float *W0, const float 
     // at 512 pairs) — the waves' 59 % parked cycles (SQ_WAIT_ANY) are not the L2 latency of the weights (DVM_MLP_AHEAD = A/B)
     static const int ahead = [] {
         const char *e = getenv("DVM_MLP_AHEAD");
-        return e ? atoi(e) : 2;
+        return e ? atoi(e) : 4;
     }();
     prof_begin(s, DVM_PROF_MLP);
     const dim3 grid((rows + MH_NODES - 1) / MH_NODES), block(MH_THREADS);
-    if (ahead <= 2) {
+    // (ablation, WRONG results: 1 = the weight fragments are not re-loaded in the k-loops, 2 = the activation fragments are read
+    // from one LDS address, 3 = both: what is left is the matrix instructions, the activation stores and the barriers)
+    static const int abl = [] { const char *e = getenv("DVM_MLP_ABLATE"); return e ? atoi(e) : 0; }();
+    if (abl == 1 || abl == 2 || abl == 3) {
+        auto k = abl == 1 ? mlp_f16x2_kernel<2, 1> : abl == 2 ? mlp_f16x2_kernel<2, 2> : mlp_f16x2_kernel<2, 3>;
+        ensure_dyn_lds((const void *)k, (int)MH_LDS_BYTES);
+        hipLaunchKernelGGL(k, grid, block, MH_LDS_BYTES, s, z, rows, Wp0, b0, Wp1, b1, Wp2, b2, Wp3, b3, out, flag);
+    } else if (ahead <= 2) {
         ensure_dyn_lds((const void *)mlp_f16x2_kernel<2>, (int)MH_LDS_BYTES);
         hipLaunchKernelGGL(mlp_f16x2_kernel<2>, grid, block, MH_LDS_BYTES, s, z, rows, Wp0, b0, Wp1, b1, Wp2, b2, Wp3, b3, out, flag);
     } else if (ahead <= 4) {
