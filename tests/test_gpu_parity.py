@@ -135,6 +135,44 @@ def test_softcorr_probe_routes():
         assert w in ln, (ln, w)
 
 
+def test_softcorr_refine_forms_agree(tmp_path):
+    """Pass B of the soft correspondence exists in five access shapes (DVM_K1_REFINE, read once per process: dvm_softcorr_f16.hip);
+    the product runs form 14.  Every form — and every window of the shipped one — must give the shipped form's bits: columns,
+    values, maxima and sums, on random features with duplicated rows (ties -> the exact-rows kernel), square and ragged (a row count that is
+    not a multiple of the four rows of a wave).  (Both directions in ONE launch: the pair-forward tests, shipped form.)"""
+    code = (
+        "import os, sys, numpy as np, torch\n"
+        "sys.path.insert(0, os.path.join(%r, 'dv-matcher_amd'))\n"
+        "from dvm import ops\n"
+        "g = torch.Generator().manual_seed(11)\n"
+        "out = {}\n"
+        "for name, (B, N, M) in {'sq': (3, 2048, 2048), 'ragged': (3, 1021, 777)}.items():\n"
+        "    f1, f2 = torch.randn(B, N, 128, generator=g), torch.randn(B, M, 128, generator=g)\n"
+        "    f2[:, 5] = f2[:, 3]; f2[:, 100:110] = f2[:, 99:100]\n"
+        "    r = tuple(ops.softcorr(f1.cuda(), f2.cuda(), 100.0, topk=10, variant=3))\n"
+        "    r += tuple(ops.softcorr(f2.cuda(), f1.cuda(), 100.0, topk=10, variant=3))\n"
+        "    for i, t in enumerate(r):\n"
+        "        if torch.is_tensor(t): out['%%s_%%d' %% (name, i)] = t.cpu().numpy()\n"
+        "torch.cuda.synchronize()\n"
+        "np.savez(sys.argv[1], **out)\n" % ROOT)
+    def run(form, win=None):
+        env = dict(os.environ, DVM_K1_REFINE=str(form))
+        env.pop("DVM_K1_REFINE_WIN", None)
+        if win is not None:
+            env["DVM_K1_REFINE_WIN"] = str(win)
+        path = str(tmp_path / ("f%s_%s.npz" % (form, win)))
+        res = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr[-2000:]
+        return dict(np.load(path))
+    ref = run(14)
+    assert len(ref) >= 8
+    for form, win in ((0, None), (1, None), (2, None), (3, None), (4, None), (10, None), (14, 1), (14, 2), (14, 4), (14, 8)):
+        got = run(form, win)
+        assert got.keys() == ref.keys()
+        for k in ref:
+            assert np.array_equal(ref[k], got[k]), (form, win, k)
+
+
 def test_softcorr_duplicate_rows(ops):
     """exact ties (duplicated target features): lowest column first, like the oracle."""
     g = torch.Generator().manual_seed(5)
