@@ -11,14 +11,23 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(name):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", name)], capture_output=True, text=True, timeout=900)
+def _run(name, **env):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", name)], capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, **env))
     assert out.returncode == 0, out.stderr[-2000:]
     return out.stdout
 
 
 def test_grid_searches_on_degenerate_clouds():
     text = _run("stress_geometry.py")
+    assert "mismatches: 0" in text, text
+    assert len(re.findall(r"chamfer True  knn True  graph True", text)) == 8, text
+
+
+def test_grid_chamfer_deferred_form_on_degenerate_clouds():
+    """DVM_CHAMFER_DEFER=1: the queries the radius-1 cube does not certify are marked and gathered into full waves by a second
+    kernel (grid_chamfer_retry_kernel) instead of being walked / scanned by the wave that found them — same answers."""
+    text = _run("stress_geometry.py", DVM_CHAMFER_DEFER="1")
     assert "mismatches: 0" in text, text
     assert len(re.findall(r"chamfer True  knn True  graph True", text)) == 8, text
 
