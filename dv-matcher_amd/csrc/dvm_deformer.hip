@@ -67,7 +67,12 @@ __global__ __launch_bounds__(256) void pool_kernel(const float *__restrict__ fea
     }
     const float bias = cb[0];
     float *o = out + ((size_t)b * nrows + r) * out_stride + out_off + 4 * c4;
-    o[0] = acc.x + bias, o[1] = acc.y + bias, o[2] = acc.z + bias, o[3] = acc.w + bias;
+    if (((out_stride | out_off) & 3) == 0) {   // (kernel-uniform) one 16-byte store per lane: the row goes out as whole lines
+        const f32x4 v = {acc.x + bias, acc.y + bias, acc.z + bias, acc.w + bias};
+        *(f32x4 *)o = v;
+    } else {   // the Deformer's z rows (offset 3): four 4-byte stores at a 16-byte stride
+        o[0] = acc.x + bias, o[1] = acc.y + bias, o[2] = acc.z + bias, o[3] = acc.w + bias;
+    }
 }
 
 // z[n, 0:3] = verts1[v]; z[n,131:134] = verts12[v]; z[n,134:262] = sum_t P[v,t] g2[pidx[v,t],:]
