@@ -166,29 +166,32 @@ __global__ __launch_bounds__(256) void assemble_pooled_kernel(const float *__res
     const int n = (int)(g / (DF_C / 4)), c4 = (int)(g % (DF_C / 4));
     const int v = fps[(size_t)b * Nn + n];
     const size_t row = (size_t)b * N + v;
+    // The correspondences of a node in ascending column order (the reference's sparse sum runs over the columns).  The 32 lanes of
+    // a node used to sort the ten (column, weight) pairs each for itself - 45 compare-swaps of five instructions, 225 of the
+    // kernel's ~300 vector instructions per lane.  Now lane t holds pair t, ranks it against the others (ten shuffles and
+    // compares), sends it to the lane of its rank (ds_permute), and every lane reads the sorted pairs from there.
+    const int lane = threadIdx.x & 63, base = lane & 32, l32 = lane & 31;
+    const bool live = l32 < topk;
+    const size_t o = row * topk + (live ? l32 : 0);   // (clamped, then selected: a predicated load is a branch and a wait)
+    const float pvt = pi_val[o];
+    const int pct = pi_idx[o];
+    const float my_pv = live ? pvt : 0.f;
+    const int my_pc = live ? pct : 0x7fffffff;
+    int rank = 0;
+#pragma unroll
+    for (int u = 0; u < TOPK; ++u) {
+        const int pcu = __shfl(my_pc, base + u, 64);
+        rank += (pcu < my_pc || (pcu == my_pc && u < l32)) ? 1 : 0;   // (unused slots share one key: their order is their position)
+    }
+    const int dst = l32 < TOPK ? base + rank : lane;   // (ranks of lanes 0 .. TOPK-1 are a permutation of 0 .. TOPK-1)
+    const int spc = __builtin_amdgcn_ds_permute(dst << 2, my_pc);
+    const float spv = __int_as_float(__builtin_amdgcn_ds_permute(dst << 2, __float_as_int(my_pv)));
     float pv[TOPK];
     int pc[TOPK];
 #pragma unroll
     for (int t = 0; t < TOPK; ++t) {
-        const bool live = t < topk;
-        const size_t o = row * topk + (live ? t : 0);   // (clamped, then selected: a predicated load is a branch and a wait)
-        const float pvt = pi_val[o];
-        const int pct = pi_idx[o];
-        pv[t] = live ? pvt : 0.f;
-        pc[t] = live ? pct : 0x7fffffff;
-    }
-#pragma unroll
-    for (int a = 1; a < TOPK; ++a) {
-#pragma unroll
-        for (int p = a; p > 0; --p) {
-            bool sw = pc[p] < pc[p - 1];
-            int c0 = pc[p - 1], c1 = pc[p];
-            float v0 = pv[p - 1], v1 = pv[p];
-            pc[p - 1] = sw ? c1 : c0;
-            pc[p] = sw ? c0 : c1;
-            pv[p - 1] = sw ? v1 : v0;
-            pv[p] = sw ? v0 : v1;
-        }
+        pc[t] = __shfl(spc, base + t, 64);
+        pv[t] = __shfl(spv, base + t, 64);
     }
     const float *gt = gtgt + (size_t)b * M * DF_C;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
