@@ -571,7 +571,10 @@ __global__ __launch_bounds__(FORM == 1 ? 64 : 256) void softcorr_refine_kernel(c
         constexpr int ROW_SHARE0 = 0x150;
         const float *qpc = G.q + (size_t)row * HB_D + 8 * l16;
         const f32x4 qa = *(const f32x4 *)qpc, qb = *(const f32x4 *)(qpc + 4);
-        const float qs[8] = {-2.f * qa.x, -2.f * qa.y, -2.f * qa.z, -2.f * qa.w, -2.f * qb.x, -2.f * qb.y, -2.f * qb.z, -2.f * qb.w};
+        float qs[8] = {-2.f * qa.x, -2.f * qa.y, -2.f * qa.z, -2.f * qa.w, -2.f * qb.x, -2.f * qb.y, -2.f * qb.z, -2.f * qb.w};
+        // (fma_row_share reads these through DPP from inline assembly: the two wait states a DPP read needs after the write of its
+        // source are not tracked there - pin the writes in front of an explicit s_nop, wherever the scheduler moves things)
+        asm volatile("s_nop 1" : "+v"(qs[0]), "+v"(qs[1]), "+v"(qs[2]), "+v"(qs[3]), "+v"(qs[4]), "+v"(qs[5]), "+v"(qs[6]), "+v"(qs[7]));
         const float *kr = eval ? G.k + ((size_t)b * M + j) * HB_D : G.q + (size_t)row * HB_D;
         const float nb = eval ? G.nk[(size_t)b * M + j] : 0.f;
         float acc = 0.f;
@@ -600,7 +603,10 @@ __global__ __launch_bounds__(FORM == 1 ? 64 : 256) void softcorr_refine_kernel(c
         constexpr int ROW_SHARE0 = 0x150;
         const float *qrow = G.q + (size_t)row * HB_D;
         const f32x4 qa = *(const f32x4 *)(qrow + 8 * l16), qb = *(const f32x4 *)(qrow + 8 * l16 + 4);
-        const float qs[8] = {-2.f * qa.x, -2.f * qa.y, -2.f * qa.z, -2.f * qa.w, -2.f * qb.x, -2.f * qb.y, -2.f * qb.z, -2.f * qb.w};
+        float qs[8] = {-2.f * qa.x, -2.f * qa.y, -2.f * qa.z, -2.f * qa.w, -2.f * qb.x, -2.f * qb.y, -2.f * qb.z, -2.f * qb.w};
+        // (fma_row_share reads these through DPP from inline assembly: the two wait states a DPP read needs after the write of its
+        // source are not tracked there - pin the writes in front of an explicit s_nop, wherever the scheduler moves things)
+        asm volatile("s_nop 1" : "+v"(qs[0]), "+v"(qs[1]), "+v"(qs[2]), "+v"(qs[3]), "+v"(qs[4]), "+v"(qs[5]), "+v"(qs[6]), "+v"(qs[7]));
         const float *const kptr = eval ? G.k + ((size_t)b * M + j) * HB_D : qrow;   // (a row that is not needed: the query row)
         const float nb = eval ? G.nk[(size_t)b * M + j] : 0.f;
         const unsigned klo = (unsigned)(uintptr_t)kptr, khi = (unsigned)((uintptr_t)kptr >> 32);
