@@ -675,6 +675,28 @@ __global__ void mean_kernel(const float *__restrict__ in, int n, float scale, fl
     }
 }
 
+// the same for up to eight inputs in one launch (blockIdx.y = input): the pair path reduces its eight Chamfer terms at once
+struct MeanGroups {
+    const float *in[8];
+    float *out[8];
+    int n[8], off[8];
+};
+__global__ void mean_grouped_kernel(const MeanGroups g, float scale, int out_stride) {
+    const int b = blockIdx.x, q8 = blockIdx.y;
+    const float *in = g.in[q8];
+    const int n = g.n[q8];
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int q = threadIdx.x; q < n; q += blockDim.x) s += (double)in[(size_t)b * n + q];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) g.out[q8][(size_t)b * out_stride + g.off[q8]] = (float)(red[0] / (double)n * (double)scale);
+}
+
 }  // namespace dvm
 
 using namespace dvm;
@@ -911,6 +933,16 @@ DVM_EXPORT int dvm_map_term_f32(const float *verts12, const float *verts2, const
 namespace dvm {
 int launch_mean(const float *in, int B, int n, float scale, float *out, int stride, int off, int accumulate, hipStream_t s) {
     hipLaunchKernelGGL(mean_kernel, dim3(B), dim3(256), 0, s, in, n, scale, out, stride, off, accumulate);
+    return DVM_OK;
+}
+int launch_mean_grouped(const float *const *in, const int *n, float *const *out, const int *off, int ngroups, int B, float scale,
+                        int stride, hipStream_t s) {
+    MeanGroups g;
+    for (int q = 0; q < 8; ++q) {
+        const int r = q < ngroups ? q : 0;
+        g.in[q] = in[r], g.out[q] = out[r], g.n[q] = n[r], g.off[q] = off[r];
+    }
+    hipLaunchKernelGGL(mean_grouped_kernel, dim3(B, ngroups), dim3(256), 0, s, g, scale, stride);
     return DVM_OK;
 }
 int launch_reduce_partials(const double *partial, int B, int nparts, float scale, float *out, int stride, int off,

@@ -8,6 +8,8 @@
 namespace dvm {
 // dvm_softcorr.hip / dvm_geom.hip / dvm_graph.hip / dvm_deformer.hip
 int launch_mean(const float *in, int B, int n, float scale, float *out, int stride, int off, int accumulate, hipStream_t s);
+int launch_mean_grouped(const float *const *in, const int *n, float *const *out, const int *off, int ngroups, int B, float scale,
+                        int stride, hipStream_t s);
 int launch_reduce_partials(const double *partial, int B, int nparts, float scale, float *out, int stride, int off, hipStream_t s);
 int map_term_blocks(int N, int k);
 void launch_gather_nbr_xyz(const float *verts, const int32_t *idx, int B, int M, int k, float *nbr, hipStream_t s);
@@ -377,9 +379,9 @@ DVM_EXPORT int dvm_pair_fwd_f32(const float *feat1, const float *feat2, const fl
         const GridBuf tg[8] = {w.gv[1], w.gw[0], w.gv[1], w.gc[0], w.gv[0], w.gw[1], w.gv[0], w.gc[1]};
         const int Na[8] = {N, M, N, M, M, N, M, N};
         launch_grid_chamfer(qg, tg, w.cd, nullptr, 8, B, s);
-        float *L[2] = {losses12, losses21};
-        const int off[4] = {0, 1, 3, 4};
-        for (int q = 0; q < 8; ++q) launch_mean(w.cd[q], B, Na[q], 1.f, L[q / 4], 6, off[q % 4], 0, s);
+        float *const L[8] = {losses12, losses12, losses12, losses12, losses21, losses21, losses21, losses21};
+        const int off[8] = {0, 1, 3, 4, 0, 1, 3, 4};
+        launch_mean_grouped(w.cd, Na, L, off, 8, B, 1.f, 6, s);   // (one launch for the eight means)
     }
     // ---- map terms (losses[:,5])
     if (with_map) {
