@@ -596,7 +596,7 @@ int launch_softcorr_both(const float *f1, const float *f2, const float *n1, cons
 size_t softcorr_f16_ws_bytes(int B, int N, int M, bool both);
 int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const float *n2, int B, int N, int M, float neg_alpha,
                          int topk, float *val12, int32_t *idx12, float *smax12, float *sum12, float *val21, int32_t *idx21,
-                         float *smax21, float *sum21, const int *amax, void *ws, size_t ws_bytes, hipStream_t s);
+                         float *smax21, float *sum21, const int *amax, void *ws, size_t ws_bytes, hipStream_t s, int *fuse_slots = nullptr);
 
 // K == 128 only: also maxes the bit pattern of max |x| into the 256 slots of `absmax_slots` (zero them first);
 // launch_absmax_finalize folds nt x 256 slots into nt values
@@ -638,12 +638,9 @@ int launch_softcorr_pair(const float *f1, const float *f2, float *n1, float *n2,
         set_error("softcorr (pair): workspace too small (%zu < %zu)", ws_bytes, ar.off);
         return DVM_ENOSPACE;
     }
-    (void)hipMemsetAsync(slots, 0, 512 * sizeof(int), s);
-    launch_rownorm2_absmax(f1, B * N, n1, slots, s);
-    launch_rownorm2_absmax(f2, B * M, n2, slots + 256, s);
-    launch_absmax_finalize(slots, 2, amax, s);
+    // (row norms, absmax and the fp16 planes come out of ONE pass over the features inside launch_softcorr_f16: `slots`)
     return launch_softcorr_f16(f1, f2, n1, n2, B, N, M, neg_alpha, 10, val12, idx12, nullptr, nullptr, val21, idx21, nullptr, nullptr,
-                                amax, bws, ws_bytes - ar.off, s);
+                                amax, bws, ws_bytes - ar.off, s, slots);
 }
 
 void launch_rownorm2(const float *x, int rows, int K, float *out, hipStream_t s) {

@@ -22,6 +22,8 @@
 namespace dvm {
 
 void launch_rownorm2(const float *x, int rows, int K, float *out, hipStream_t s);
+void launch_rownorm2_absmax(const float *x, int rows, float *out, int *absmax_slots, hipStream_t s);
+void launch_absmax_finalize(const int *slots, int nt, int *out, hipStream_t s);
 
 namespace {
 
@@ -58,6 +60,121 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float *__restri
     char *p = planes + row * HB_ROWB + 16 * c;
     *(f16x8 *)(p) = h;
     *(f16x8 *)(p + 256) = m;
+}
+
+// ---- the pair path's preparation in ONE pass over the features (instead of row norms + absmax, then the split: the 2 x 537 MB of
+// the bench were read twice).  The split needs the tensor's absmax (its exponent fixes the scale) before the first element can
+// be written, so the pass runs with a PROVISIONAL scale from a 1/64 sample of the rows; the true absmax comes out of the same
+// pass, and only if its exponent differs from the sample's (spec[1]) are the planes written again by the gated split below -
+// the result is the two-pass result either way.
+__global__ __launch_bounds__(256) void sample_absmax_kernel(const float *__restrict__ x1, long rows1, const float *__restrict__ x2, long rows2,
+                                                            int *__restrict__ spec) {
+    float m = 0.f;
+    const long n1 = (rows1 + 63) / 64 * 32, n2 = (rows2 + 63) / 64 * 32;   // float4s of every 64th row
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += (long)gridDim.x * blockDim.x) {
+        const bool second = i >= n1;
+        const long j = second ? i - n1 : i;
+        const float *x = second ? x2 : x1;
+        const f32x4 v = *(const f32x4 *)(x + (j / 32) * 64 * HB_D + 4 * (j % 32));
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && __float_as_int(m) > __atomic_load_n(spec, __ATOMIC_RELAXED)) atomicMax(spec, __float_as_int(m));
+}
+
+// 16 lanes per row, 8 consecutive columns each (two 16-byte loads, two 16-byte stores).  The row norm in ATen's summation order
+// (rownorm2_k128_kernel, dvm_softcorr.hip: s_l = ((x_l^2 + x_{l+32}^2) + x_{l+64}^2) + x_{l+96}^2, r_j = ((s_j + s_{j+8}) + s_{j+16})
+// + s_{j+24}, then r_0 .. r_7 left to right): column l = 8 a + b sits in lane a, slot b, so s_l gathers slot b of lanes a, a + 4,
+// a + 8, a + 12 (DPP row_shl 4 / 8 / 12, valid in lanes 0 - 3) and r_j slot j of lanes 0 - 3 (row_shl 1 / 2 / 3, valid in lane 0).
+constexpr int RS_ROWS = 4;   // rows per 16-lane group requested before the first is used
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__global__ __launch_bounds__(256) void rownorm_split_kernel(const float *__restrict__ x, long rows, float *__restrict__ nrm,
+                                                            int *__restrict__ absmax_slots, const int *__restrict__ spec,
+                                                            char *__restrict__ planes) {
+    const int lane = threadIdx.x & 63, l16 = lane & 15;
+    const long grp = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const float sc = pow2i(scale_exp(*spec));
+    f32x4 v0[RS_ROWS], v1[RS_ROWS];
+#pragma unroll
+    for (int q = 0; q < RS_ROWS; ++q) {
+        const long row0 = grp * RS_ROWS + q, row = row0 < rows ? row0 : rows - 1;
+        const float *p = x + row * HB_D + 8 * l16;
+        v0[q] = *(const f32x4 *)p, v1[q] = *(const f32x4 *)(p + 4);
+    }
+    float am = 0.f;
+#pragma unroll
+    for (int q = 0; q < RS_ROWS; ++q) {
+        const long row0 = grp * RS_ROWS + q;
+        float r[8];
+        f16x8 h, m;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xe = e < 4 ? v0[q][e & 3] : v1[q][e & 3];
+            am = fmaxf(am, fabsf(xe));
+            const float xv = xe * sc;                                // exact
+            const _Float16 hh = (_Float16)xv;                        // round to nearest even
+            h[e] = hh, m[e] = (_Float16)(xv - (float)hh);
+            const float sq = xe * xe;
+            const float s = ((sq + dpp_f<0x104>(sq)) + dpp_f<0x108>(sq)) + dpp_f<0x10c>(sq);   // lanes 0 - 3: s_{8 a + e}
+            r[e] = ((s + dpp_f<0x101>(s)) + dpp_f<0x102>(s)) + dpp_f<0x103>(s);                 // lane 0: r_e
+        }
+        if (row0 < rows) {
+            char *p = planes + row0 * HB_ROWB + 16 * l16;
+            *(f16x8 *)(p) = h;
+            *(f16x8 *)(p + 256) = m;
+            if (l16 == 0) nrm[row0] = ((((((r[0] + r[1]) + r[2]) + r[3]) + r[4]) + r[5]) + r[6]) + r[7];
+        }
+    }
+    int mb = __float_as_int(am);   // non-negative floats order like their bit patterns
+    mb = max(mb, __builtin_amdgcn_update_dpp(0, mb, 0x111, 0xf, 0xf, false));  // row_shr:1
+    mb = max(mb, __builtin_amdgcn_update_dpp(0, mb, 0x112, 0xf, 0xf, false));  // row_shr:2
+    mb = max(mb, __builtin_amdgcn_update_dpp(0, mb, 0x114, 0xf, 0xf, false));  // row_shr:4
+    mb = max(mb, __builtin_amdgcn_update_dpp(0, mb, 0x118, 0xf, 0xf, false));  // row_shr:8
+    mb = max(mb, __builtin_amdgcn_update_dpp(0, mb, 0x142, 0xa, 0xf, false));  // row_bcast:15
+    mb = max(mb, __builtin_amdgcn_update_dpp(0, mb, 0x143, 0xc, 0xf, false));  // row_bcast:31 -> lane 63 = the wave's max
+    int *slot = absmax_slots + (blockIdx.x & 255);
+    if (lane == 63 && mb > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, mb);
+}
+// slots -> the two absmax values, their common maximum (ONE scale for both sides), and whether the provisional scale was wrong
+__global__ void spec_finalize_kernel(const int *__restrict__ slots, int *__restrict__ amax_pair, int *__restrict__ amax_common,
+                                     int *__restrict__ spec) {
+    int v = 0;
+    for (int i = threadIdx.x & 63; i < 256; i += 64) v = max(v, slots[(threadIdx.x >> 6) * 256 + i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    __shared__ int two[2];
+    if ((threadIdx.x & 63) == 0) two[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int c = max(two[0], two[1]);
+        amax_pair[0] = two[0], amax_pair[1] = two[1];
+        amax_common[0] = c, amax_common[1] = c;
+        spec[1] = scale_exp(spec[0]) != scale_exp(c) ? 1 : 0;
+    }
+}
+__global__ __launch_bounds__(256) void split_planes_gated_kernel(const float *__restrict__ x, long rows, const int *__restrict__ maxbits,
+                                                                 const int *__restrict__ spec, char *__restrict__ planes) {
+    if (spec[1] == 0) return;   // (the usual case: the provisional scale was the right one)
+    const float sc = pow2i(scale_exp(*maxbits));
+    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < rows * (HB_D / 8); g += (long)gridDim.x * blockDim.x) {
+        const long row = g / (HB_D / 8);
+        const int c = (int)(g % (HB_D / 8));
+        const f32x4 v0 = *(const f32x4 *)(x + row * HB_D + 8 * c), v1 = *(const f32x4 *)(x + row * HB_D + 8 * c + 4);
+        f16x8 h, m;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xv = (e < 4 ? v0[e & 3] : v1[e & 3]) * sc;
+            const _Float16 hh = (_Float16)xv;
+            h[e] = hh, m[e] = (_Float16)(xv - (float)hh);
+        }
+        char *p = planes + row * HB_ROWB + 16 * c;
+        *(f16x8 *)(p) = h;
+        *(f16x8 *)(p + 256) = m;
+    }
 }
 
 // norms padded to whole key tiles with +inf: out [B][Mpad]
@@ -568,7 +685,6 @@ __global__ __launch_bounds__(FORM == 1 ? 64 : 256) void softcorr_refine_kernel(c
         // -2: the same number of vector instructions).  Half of form 0's load instructions were these 16-fold redundant query
         // loads, and the kernel is bound by the texture-address unit (TA_BUSY 88 - 100 %).  All 16 lanes run the chain (the
         // lanes without a candidate on the query row itself: a line already there), the result is kept where `eval`.
-        constexpr int ROW_SHARE0 = 0x150;
         const float *qpc = G.q + (size_t)row * HB_D + 8 * l16;
         const f32x4 qa = *(const f32x4 *)qpc, qb = *(const f32x4 *)(qpc + 4);
         float qs[8] = {-2.f * qa.x, -2.f * qa.y, -2.f * qa.z, -2.f * qa.w, -2.f * qb.x, -2.f * qb.y, -2.f * qb.z, -2.f * qb.w};
@@ -600,7 +716,6 @@ __global__ __launch_bounds__(FORM == 1 ? 64 : 256) void softcorr_refine_kernel(c
         // to LDS (chunk c of slot s at position c ^ (s / 4 % 4): conflict-free both ways) from where each candidate lane reads
         // ITS row's piece and continues its k-ordered chain.  Two 3-KiB piece buffers per wave; the LDS pipe serves a wave's
         // instructions in order, so the write of piece p + 2 cannot overtake the reads of piece p.
-        constexpr int ROW_SHARE0 = 0x150;
         const float *qrow = G.q + (size_t)row * HB_D;
         const f32x4 qa = *(const f32x4 *)(qrow + 8 * l16), qb = *(const f32x4 *)(qrow + 8 * l16 + 4);
         float qs[8] = {-2.f * qa.x, -2.f * qa.y, -2.f * qa.z, -2.f * qa.w, -2.f * qb.x, -2.f * qb.y, -2.f * qb.z, -2.f * qb.w};
@@ -1084,7 +1199,7 @@ static void report_routes(const int *route, const float *frac, int n, hipStream_
 size_t softcorr_f16_ws_bytes(int B, int N, int M, bool both) {
     const size_t Np = (size_t)(N + HB_KT - 1) / HB_KT * HB_KT, Mp = (size_t)(M + HB_KT - 1) / HB_KT * HB_KT;
     size_t n = align_up((size_t)B * N * HB_ROWB) + align_up((size_t)B * M * HB_ROWB) + 2 * align_up((size_t)B * sizeof(float)) +
-               align_up(2 * sizeof(int)) + align_up(B * Np * sizeof(float)) + align_up(B * Mp * sizeof(float)) +
+               2 * align_up(2 * sizeof(int)) + align_up(B * Np * sizeof(float)) + align_up(B * Mp * sizeof(float)) +
                align_up(B * Np * 32) + align_up(B * Mp * 32) +   // (norm fragments of the second sweep form)
                align_up(2 * (size_t)B * sizeof(int)) + align_up(2 * (size_t)B * sizeof(float));   // routes + probe fractions
     const int dirs = both ? 2 : 1;
@@ -1100,12 +1215,15 @@ size_t softcorr_f16_ws_bytes(int B, int N, int M, bool both) {
 // reverse.  Outputs as the fp32 kernel: top-`topk` values/columns (topk <= 10), optional row stats.
 int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const float *n2, int B, int N, int M, float neg_alpha,
                          int topk, float *val12, int32_t *idx12, float *smax12, float *sum12, float *val21, int32_t *idx21,
-                         float *smax21, float *sum21, const int *amax_in, void *ws, size_t ws_bytes, hipStream_t s) {
+                         float *smax21, float *sum21, const int *amax_in, void *ws, size_t ws_bytes, hipStream_t s, int *fuse_slots) {
+    // fuse_slots != nullptr (the pair path): n1 / n2 and the absmax values at amax_in are NOT computed yet - this call makes them
+    // in the same pass that writes the fp16 planes (rownorm_split_kernel); fuse_slots = 512 ints of scratch
     const bool both = val21 != nullptr;
     Arena ar(ws, ws_bytes);
     char *p1 = ar.take<char>((size_t)B * N * HB_ROWB), *p2 = ar.take<char>((size_t)B * M * HB_ROWB);
     float *nmax1 = ar.take<float>(B), *nmax2 = ar.take<float>(B);
     int *amax_own = ar.take<int>(2);  // bit patterns of max|f1|, max|f2| when the caller did not fuse them into the norms
+    int *spec = ar.take<int>(2);      // fused preparation: [0] absmax of the sampled rows (provisional scale), [1] planes must be re-made
     const int *amax = amax_own;   // ONE scale for both sides (the larger absmax), see common_absmax_kernel
     const int Np = (N + HB_KT - 1) / HB_KT * HB_KT, Mp = (M + HB_KT - 1) / HB_KT * HB_KT;
     float *n1p = ar.take<float>((size_t)B * Np), *n2p = ar.take<float>((size_t)B * Mp);
@@ -1127,13 +1245,33 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
     }
     const long r1 = (long)B * N, r2 = (long)B * M;
     (void)hipMemsetAsync(nmax1, 0, 2 * align_up((size_t)B * sizeof(float)) + 2 * sizeof(int), s);
-    if (!amax_in) {
-        hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, s, f1, r1 * 32, amax_own);
-        hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, s, f2, r2 * 32, amax_own + 1);
+    static const bool fuse_ok = [] { const char *e = getenv("DVM_K1_FUSED_PREP"); return !(e && atoi(e) == 0); }();
+    if (fuse_slots && fuse_ok) {
+        (void)hipMemsetAsync(fuse_slots, 0, 512 * sizeof(int), s);
+        (void)hipMemsetAsync(spec, 0, 2 * sizeof(int), s);
+        hipLaunchKernelGGL(sample_absmax_kernel, dim3(256), dim3(256), 0, s, f1, r1, f2, r2, spec);
+        hipLaunchKernelGGL(rownorm_split_kernel, dim3((unsigned)(((r1 + RS_ROWS - 1) / RS_ROWS * 16 + 255) / 256)), dim3(256), 0, s, f1, r1,
+                           (float *)n1, fuse_slots, spec, p1);
+        hipLaunchKernelGGL(rownorm_split_kernel, dim3((unsigned)(((r2 + RS_ROWS - 1) / RS_ROWS * 16 + 255) / 256)), dim3(256), 0, s, f2, r2,
+                           (float *)n2, fuse_slots + 256, spec, p2);
+        hipLaunchKernelGGL(spec_finalize_kernel, dim3(1), dim3(128), 0, s, fuse_slots, (int *)amax_in, amax_own, spec);
+        hipLaunchKernelGGL(split_planes_gated_kernel, dim3(2048), dim3(256), 0, s, f1, r1, amax, spec, p1);
+        hipLaunchKernelGGL(split_planes_gated_kernel, dim3(2048), dim3(256), 0, s, f2, r2, amax + 1, spec, p2);
+    } else {
+        if (fuse_slots) {   // (DVM_K1_FUSED_PREP=0: the two-pass preparation, for A/B)
+            (void)hipMemsetAsync(fuse_slots, 0, 512 * sizeof(int), s);
+            launch_rownorm2_absmax(f1, (int)r1, (float *)n1, fuse_slots, s);
+            launch_rownorm2_absmax(f2, (int)r2, (float *)n2, fuse_slots + 256, s);
+            launch_absmax_finalize(fuse_slots, 2, (int *)amax_in, s);
+        }
+        if (!amax_in) {
+            hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, s, f1, r1 * 32, amax_own);
+            hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, s, f2, r2 * 32, amax_own + 1);
+        }
+        hipLaunchKernelGGL(common_absmax_kernel, dim3(1), dim3(1), 0, s, amax_in ? amax_in : amax_own, amax_own);
+        hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((r1 * 16 + 255) / 256)), dim3(256), 0, s, f1, r1, amax, p1);
+        hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((r2 * 16 + 255) / 256)), dim3(256), 0, s, f2, r2, amax + 1, p2);
     }
-    hipLaunchKernelGGL(common_absmax_kernel, dim3(1), dim3(1), 0, s, amax_in ? amax_in : amax_own, amax_own);
-    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((r1 * 16 + 255) / 256)), dim3(256), 0, s, f1, r1, amax, p1);
-    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((r2 * 16 + 255) / 256)), dim3(256), 0, s, f2, r2, amax + 1, p2);
     hipLaunchKernelGGL(norm_max_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, n1, N, nmax1);
     hipLaunchKernelGGL(norm_max_kernel, dim3((M + 255) / 256, B), dim3(256), 0, s, n2, M, nmax2);
     for (int d = 0; d < (both ? 2 : 1); ++d) (void)hipMemsetAsync(flag[d], 0, sizeof(int32_t), s);

@@ -173,6 +173,42 @@ def test_softcorr_refine_forms_agree(tmp_path):
             assert np.array_equal(ref[k], got[k]), (form, win, k)
 
 
+def test_pair_forward_fused_preparation_equals_two_pass(tmp_path):
+    """The pair path makes the row norms, the absmax and the fp16 planes of the features in ONE pass (rownorm_split_kernel,
+    dvm_softcorr_f16.hip) with a provisional scale from a 1/64 sample of the rows, and re-makes the planes only when the true
+    absmax has another exponent.  Every output must be the two-pass path's (DVM_K1_FUSED_PREP=0), bit for bit: on random
+    features (the sample is right), with one large value in a row the sample does not see (the planes are re-made), at a
+    shape whose row counts are no multiples of anything, and for all-zero features."""
+    code = (
+        "import os, sys, numpy as np, torch\n"
+        "sys.path.insert(0, os.path.join(%r, 'dv-matcher_amd'))\n"
+        "from dvm import ops\n"
+        "wl = ops.deformer_weight_list(dict(np.load(os.path.join(%r, 'tests', 'golden', 'deformer_scape_r_weights.npz'))), 'cuda')\n"
+        "g = torch.Generator().manual_seed(21)\n"
+        "out = {}\n"
+        "for name, (B, N, M, mode) in {'sq': (3, 2048, 2048, 0), 'spike': (3, 2048, 2048, 1), 'ragged': (2, 1021, 777, 0), 'zero': (1, 256, 256, 2)}.items():\n"
+        "    f1, f2 = torch.randn(B, N, 128, generator=g), torch.randn(B, M, 128, generator=g)\n"
+        "    if mode == 1: f2[1, 33, 7] = 300.0\n"
+        "    if mode == 2: f1, f2 = f1 * 0, f2 * 0\n"
+        "    v1, v2 = torch.rand(B, N, 3, generator=g), torch.rand(B, M, 3, generator=g)\n"
+        "    s1 = torch.zeros(B, dtype=torch.int32)\n"
+        "    o = ops.pair_forward(wl, f1.cuda(), f2.cuda(), v1.cuda(), v2.cuda(), 100.0, s1.cuda(), s1.cuda())\n"
+        "    for d, od in enumerate(o):\n"
+        "        for k, t in od.items(): out['%%s_%%d_%%s' %% (name, d, k)] = t.cpu().numpy()\n"
+        "torch.cuda.synchronize()\n"
+        "np.savez(sys.argv[1], **out)\n" % (ROOT, ROOT))
+    res = {}
+    for mode in ("1", "0"):
+        path = str(tmp_path / ("prep%s.npz" % mode))
+        r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, DVM_K1_FUSED_PREP=mode), capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[mode] = dict(np.load(path))
+    assert res["1"].keys() == res["0"].keys() and len(res["1"]) == 32
+    for k in res["1"]:
+        assert np.array_equal(res["1"][k], res["0"][k], equal_nan=True), k
+
+
 def test_softcorr_duplicate_rows(ops):
     """exact ties (duplicated target features): lowest column first, like the oracle."""
     g = torch.Generator().manual_seed(5)
