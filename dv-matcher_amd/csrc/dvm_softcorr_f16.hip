@@ -42,6 +42,28 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x
     if ((threadIdx.x & 63) == 0 && __float_as_int(m) > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, __float_as_int(m));
 }
 
+// Two scaled values -> their packed fp16 planes: h = rn16(a), m = rn16(a - h) (a - h is exact in fp32): the packed round-to-nearest
+// conversion and one v_fma_mix per value (it reads the fp16 h directly).  Every kernel that writes planes goes through this, so the
+// one-pass and the two-pass preparation leave the same bytes (checked against a host computation: tools/check_planes.py).
+__device__ __forceinline__ void split2x2_f16(float a0, float a1, unsigned &h, unsigned &m) {
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(a0), "v"(a1));
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(m) : "v"(a0), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(m) : "v"(a1), "v"(h));
+}
+typedef unsigned u32x4_rs __attribute__((ext_vector_type(4)));
+// 8 columns (two float4s) of a row, scaled by sc, to the row's planes at p (h) and p + 256 (m)
+__device__ __forceinline__ void split8_store(const f32x4 &v0, const f32x4 &v1, float sc, char *p) {
+    unsigned hh[4], mm[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float a0 = (e < 2 ? v0[2 * e] : v1[2 * e - 4]) * sc, a1 = (e < 2 ? v0[2 * e + 1] : v1[2 * e - 3]) * sc;   // exact
+        split2x2_f16(a0, a1, hh[e], mm[e]);
+    }
+    const u32x4_rs h = {hh[0], hh[1], hh[2], hh[3]}, m = {mm[0], mm[1], mm[2], mm[3]};
+    *(u32x4_rs *)(p) = h;
+    *(u32x4_rs *)(p + 256) = m;
+}
+
 __global__ __launch_bounds__(256) void split_planes_kernel(const float *__restrict__ x, long rows, const int *__restrict__ maxbits,
                                                            char *__restrict__ planes) {
     const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;  // eight columns per thread: two 16-byte loads, two 16-byte stores
@@ -50,16 +72,7 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float *__restri
     const long row = g / (HB_D / 8);
     const int c = (int)(g % (HB_D / 8));
     const f32x4 v0 = *(const f32x4 *)(x + row * HB_D + 8 * c), v1 = *(const f32x4 *)(x + row * HB_D + 8 * c + 4);
-    f16x8 h, m;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float xv = (e < 4 ? v0[e & 3] : v1[e & 3]) * sc;   // exact
-        const _Float16 hh = (_Float16)xv;                        // round to nearest even
-        h[e] = hh, m[e] = (_Float16)(xv - (float)hh);
-    }
-    char *p = planes + row * HB_ROWB + 16 * c;
-    *(f16x8 *)(p) = h;
-    *(f16x8 *)(p + 256) = m;
+    split8_store(v0, v1, sc, planes + row * HB_ROWB + 16 * c);
 }
 
 // ---- the pair path's preparation in ONE pass over the features (instead of row norms + absmax, then the split: the 2 x 537 MB of
@@ -83,51 +96,68 @@ __global__ __launch_bounds__(256) void sample_absmax_kernel(const float *__restr
     if ((threadIdx.x & 63) == 0 && __float_as_int(m) > __atomic_load_n(spec, __ATOMIC_RELAXED)) atomicMax(spec, __float_as_int(m));
 }
 
-// 16 lanes per row, 8 consecutive columns each (two 16-byte loads, two 16-byte stores).  The row norm in ATen's summation order
-// (rownorm2_k128_kernel, dvm_softcorr.hip: s_l = ((x_l^2 + x_{l+32}^2) + x_{l+64}^2) + x_{l+96}^2, r_j = ((s_j + s_{j+8}) + s_{j+16})
-// + s_{j+24}, then r_0 .. r_7 left to right): column l = 8 a + b sits in lane a, slot b, so s_l gathers slot b of lanes a, a + 4,
-// a + 8, a + 12 (DPP row_shl 4 / 8 / 12, valid in lanes 0 - 3) and r_j slot j of lanes 0 - 3 (row_shl 1 / 2 / 3, valid in lane 0).
-constexpr int RS_ROWS = 4;   // rows per 16-lane group requested before the first is used
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
+// Loads and stores: 16 lanes per row, 8 consecutive columns each (two 16-byte loads, two 16-byte stores); 16 rows per wave and trip.
+// The row norm needs ATen's summation order (rownorm2_k128_kernel, dvm_softcorr.hip: lane l of 32 adds x_l^2, x_{l+32}^2, x_{l+64}^2,
+// x_{l+96}^2 in that order, then ((s_j + s_{j+8}) + s_{j+16}) + s_{j+24}, then r_0 .. r_7 left to right), which is cheap with 32
+// lanes per row and column l + 32 i in lane l - so the wave's 16 rows go through LDS once (rows 640 B apart: the two rows a wave
+// reduces at a time then sit in different banks) and are reduced with that kernel's DPP / v_permlane16_swap steps: ~25 vector
+// instructions per row pair.  (The same order on the 8-columns-per-lane layout costs 48 DPP additions per row and lane: built
+// first, 355 us per launch.)
+constexpr int RS_ROWS = 4;            // rows per 16-lane group and trip (all requested before the first is used)
+constexpr int RS_LROW = 160;          // floats between rows in LDS
 __global__ __launch_bounds__(256) void rownorm_split_kernel(const float *__restrict__ x, long rows, float *__restrict__ nrm,
                                                             int *__restrict__ absmax_slots, const int *__restrict__ spec,
                                                             char *__restrict__ planes) {
-    const int lane = threadIdx.x & 63, l16 = lane & 15;
-    const long grp = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    __shared__ __attribute__((aligned(16))) float xs_all[4][4 * RS_ROWS * RS_LROW];
+    const int lane = threadIdx.x & 63, l16 = lane & 15, g4 = lane >> 4;
+    float *xs = xs_all[threadIdx.x >> 6];
+    const long wave_row0 = (((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * (4 * RS_ROWS);   // this wave's 16 rows
     const float sc = pow2i(scale_exp(*spec));
     f32x4 v0[RS_ROWS], v1[RS_ROWS];
 #pragma unroll
-    for (int q = 0; q < RS_ROWS; ++q) {
-        const long row0 = grp * RS_ROWS + q, row = row0 < rows ? row0 : rows - 1;
+    for (int q = 0; q < RS_ROWS; ++q) {   // local row 4 q + g4
+        const long row0 = wave_row0 + 4 * q + g4, row = row0 < rows ? row0 : rows - 1;
         const float *p = x + row * HB_D + 8 * l16;
         v0[q] = *(const f32x4 *)p, v1[q] = *(const f32x4 *)(p + 4);
     }
     float am = 0.f;
 #pragma unroll
     for (int q = 0; q < RS_ROWS; ++q) {
-        const long row0 = grp * RS_ROWS + q;
-        float r[8];
-        f16x8 h, m;
+        const long row0 = wave_row0 + 4 * q + g4;
+        float *lp = xs + (4 * q + g4) * RS_LROW + 8 * l16;
+        *(f32x4 *)lp = v0[q];
+        *(f32x4 *)(lp + 4) = v1[q];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float xe = e < 4 ? v0[q][e & 3] : v1[q][e & 3];
-            am = fmaxf(am, fabsf(xe));
-            const float xv = xe * sc;                                // exact
-            const _Float16 hh = (_Float16)xv;                        // round to nearest even
-            h[e] = hh, m[e] = (_Float16)(xv - (float)hh);
-            const float sq = xe * xe;
-            const float s = ((sq + dpp_f<0x104>(sq)) + dpp_f<0x108>(sq)) + dpp_f<0x10c>(sq);   // lanes 0 - 3: s_{8 a + e}
-            r[e] = ((s + dpp_f<0x101>(s)) + dpp_f<0x102>(s)) + dpp_f<0x103>(s);                 // lane 0: r_e
-        }
-        if (row0 < rows) {
-            char *p = planes + row0 * HB_ROWB + 16 * l16;
-            *(f16x8 *)(p) = h;
-            *(f16x8 *)(p + 256) = m;
-            if (l16 == 0) nrm[row0] = ((((((r[0] + r[1]) + r[2]) + r[3]) + r[4]) + r[5]) + r[6]) + r[7];
-        }
+        for (int e = 0; e < 8; ++e) am = fmaxf(am, fabsf(e < 4 ? v0[q][e & 3] : v1[q][e & 3]));
+        if (row0 < rows) split8_store(v0[q], v1[q], sc, planes + row0 * HB_ROWB + 16 * l16);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's rows are in LDS (one wave per region: no barrier)
+    __builtin_amdgcn_wave_barrier();
+    const int l32 = lane & 31, half = lane >> 5;
+    float vv[2 * RS_ROWS][4];
+#pragma unroll
+    for (int pr = 0; pr < 2 * RS_ROWS; ++pr) {   // local rows 2 pr + half
+        const float *lp = xs + (2 * pr + half) * RS_LROW + l32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vv[pr][i] = lp[32 * i];
+    }
+#pragma unroll
+    for (int pr = 0; pr < 2 * RS_ROWS; ++pr) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s = s + vv[pr][i] * vv[pr][i];
+        // lanes 8 k + l of a 32-lane half: k = 1 is 8 lanes up in the same 16-lane row, k = 2, 3 sit in the next row
+        const unsigned su = __float_as_uint(s);
+        const auto sw = __builtin_amdgcn_permlane16_swap(su, su, false, false);   // sw[1]: even rows <- the odd row above them
+        const float up = __uint_as_float(sw[1]);
+        const float ror_s = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x128, 0xf, 0xf, false));
+        const float ror_up = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(up), 0x128, 0xf, 0xf, false));
+        const float r = ((s + ror_s) + up) + ror_up;  // valid in lanes l32 < 8 (k = 0)
+        float u = r;   // u_j <- u_{j-1} + r_j seven times leaves (((r0 + r1) + r2) ... + r7) in lane 7 of the half
+#pragma unroll
+        for (int st = 0; st < 7; ++st) u = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(u), 0x111, 0xf, 0xf, false)) + r;
+        const long row0 = wave_row0 + 2 * pr + half;
+        if (l32 == 7 && row0 < rows) nrm[row0] = u;
     }
     int mb = __float_as_int(am);   // non-negative floats order like their bit patterns
     mb = max(mb, __builtin_amdgcn_update_dpp(0, mb, 0x111, 0xf, 0xf, false));  // row_shr:1
@@ -164,16 +194,7 @@ __global__ __launch_bounds__(256) void split_planes_gated_kernel(const float *__
         const long row = g / (HB_D / 8);
         const int c = (int)(g % (HB_D / 8));
         const f32x4 v0 = *(const f32x4 *)(x + row * HB_D + 8 * c), v1 = *(const f32x4 *)(x + row * HB_D + 8 * c + 4);
-        f16x8 h, m;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float xv = (e < 4 ? v0[e & 3] : v1[e & 3]) * sc;
-            const _Float16 hh = (_Float16)xv;
-            h[e] = hh, m[e] = (_Float16)(xv - (float)hh);
-        }
-        char *p = planes + row * HB_ROWB + 16 * c;
-        *(f16x8 *)(p) = h;
-        *(f16x8 *)(p + 256) = m;
+        split8_store(v0, v1, sc, planes + row * HB_ROWB + 16 * c);
     }
 }
 
@@ -1250,9 +1271,9 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
         (void)hipMemsetAsync(fuse_slots, 0, 512 * sizeof(int), s);
         (void)hipMemsetAsync(spec, 0, 2 * sizeof(int), s);
         hipLaunchKernelGGL(sample_absmax_kernel, dim3(256), dim3(256), 0, s, f1, r1, f2, r2, spec);
-        hipLaunchKernelGGL(rownorm_split_kernel, dim3((unsigned)(((r1 + RS_ROWS - 1) / RS_ROWS * 16 + 255) / 256)), dim3(256), 0, s, f1, r1,
+        hipLaunchKernelGGL(rownorm_split_kernel, dim3((unsigned)((r1 + 16 * RS_ROWS - 1) / (16 * RS_ROWS))), dim3(256), 0, s, f1, r1,
                            (float *)n1, fuse_slots, spec, p1);
-        hipLaunchKernelGGL(rownorm_split_kernel, dim3((unsigned)(((r2 + RS_ROWS - 1) / RS_ROWS * 16 + 255) / 256)), dim3(256), 0, s, f2, r2,
+        hipLaunchKernelGGL(rownorm_split_kernel, dim3((unsigned)((r2 + 16 * RS_ROWS - 1) / (16 * RS_ROWS))), dim3(256), 0, s, f2, r2,
                            (float *)n2, fuse_slots + 256, spec, p2);
         hipLaunchKernelGGL(spec_finalize_kernel, dim3(1), dim3(128), 0, s, fuse_slots, (int *)amax_in, amax_own, spec);
         hipLaunchKernelGGL(split_planes_gated_kernel, dim3(2048), dim3(256), 0, s, f1, r1, amax, spec, p1);
