@@ -103,8 +103,8 @@ __global__ __launch_bounds__(256) void sample_absmax_kernel(const float *__restr
 // reduces at a time then sit in different banks) and are reduced with that kernel's DPP / v_permlane16_swap steps: ~25 vector
 // instructions per row pair.  (The same order on the 8-columns-per-lane layout costs 48 DPP additions per row and lane: built
 // first, 355 us per launch.)
-constexpr int RS_ROWS = 4;            // rows per 16-lane group and trip (all requested before the first is used)
 constexpr int RS_LROW = 160;          // floats between rows in LDS
+template <int RS_ROWS>   // rows per 16-lane group and trip (all requested before the first is used): DVM_PREP_ROWS = 1 | 2 | 4
 __global__ __launch_bounds__(256) void rownorm_split_kernel(const float *__restrict__ x, long rows, float *__restrict__ nrm,
                                                             int *__restrict__ absmax_slots, const int *__restrict__ spec,
                                                             char *__restrict__ planes) {
@@ -1271,10 +1271,15 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
         (void)hipMemsetAsync(fuse_slots, 0, 512 * sizeof(int), s);
         (void)hipMemsetAsync(spec, 0, 2 * sizeof(int), s);
         hipLaunchKernelGGL(sample_absmax_kernel, dim3(256), dim3(256), 0, s, f1, r1, f2, r2, spec);
-        hipLaunchKernelGGL(rownorm_split_kernel, dim3((unsigned)((r1 + 16 * RS_ROWS - 1) / (16 * RS_ROWS))), dim3(256), 0, s, f1, r1,
-                           (float *)n1, fuse_slots, spec, p1);
-        hipLaunchKernelGGL(rownorm_split_kernel, dim3((unsigned)((r2 + 16 * RS_ROWS - 1) / (16 * RS_ROWS))), dim3(256), 0, s, f2, r2,
-                           (float *)n2, fuse_slots + 256, spec, p2);
+        static const int prep_rows = [] { const char *e = getenv("DVM_PREP_ROWS"); const int v = e ? atoi(e) : 2; return v == 1 || v == 4 ? v : 2; }();
+        auto prep = [&](const float *f, long r, float *nn, int *slots, char *pp) {
+            const auto grid = [&](int rr) { return dim3((unsigned)((r + 16 * rr - 1) / (16 * rr))); };
+            if (prep_rows == 1) hipLaunchKernelGGL(rownorm_split_kernel<1>, grid(1), dim3(256), 0, s, f, r, nn, slots, spec, pp);
+            else if (prep_rows == 4) hipLaunchKernelGGL(rownorm_split_kernel<4>, grid(4), dim3(256), 0, s, f, r, nn, slots, spec, pp);
+            else hipLaunchKernelGGL(rownorm_split_kernel<2>, grid(2), dim3(256), 0, s, f, r, nn, slots, spec, pp);
+        };
+        prep(f1, r1, (float *)n1, fuse_slots, p1);
+        prep(f2, r2, (float *)n2, fuse_slots + 256, p2);
         hipLaunchKernelGGL(spec_finalize_kernel, dim3(1), dim3(128), 0, s, fuse_slots, (int *)amax_in, amax_own, spec);
         hipLaunchKernelGGL(split_planes_gated_kernel, dim3(2048), dim3(256), 0, s, f1, r1, amax, spec, p1);
         hipLaunchKernelGGL(split_planes_gated_kernel, dim3(2048), dim3(256), 0, s, f2, r2, amax + 1, spec, p2);
