@@ -25,8 +25,8 @@ Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the soft-
 of K1), its launch time measured with HIP events on the launch stream inside the timed region; `frac` =
 flops performed on the f16 matrix pipe / its dense peak, `algorithmic` = SURVEY §8d's flops against the fp32
 matrix peak; `roofline.kernels` = the other kernels of the step, event-timed the same way over 3 extra steps
-after the timed region.  `checked_pairs`: after the timed region 4 pairs of the very batch that was timed
-are recomputed by the CPU oracle and compared (arg-max maps bit-exact, coordinates <= 1e-4, losses rtol
+after the timed region.  `checked_pairs`: after the timed region 4 seeded-random pairs of the very batch that was
+timed are recomputed by the CPU oracle and compared (arg-max maps bit-exact, coordinates <= 1e-4, losses rtol
 1e-3); `cpu_baseline` is the same oracle ("port": a C/OpenMP restatement of the reference's algorithm)
 timed on a bounded sample of pairs of that same batch.
 """
@@ -66,7 +66,8 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo for the "
                     "two-ranks-on-one-GPU test of this script)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
-                    help="per-launch HBM bytes of the dominant kernel from the PMC passes (default: profiles/r3_k1_traffic.json)")
+                    help="per-launch HBM bytes of the dominant kernel from the PMC passes (default: profiles/r4_k1_traffic.json, "
+                         "used only if it was taken on this kernel source, for the kernel the timed launches ran, at this --pairs)")
     return ap.parse_args(argv)
 
 
@@ -90,11 +91,16 @@ def free_port():
         return s.getsockname()[1]
 
 
-def rank_environment(rank, world, port, base=None):
+def rank_environment(rank, world, port, base=None, cpus=None):
+    """Environment of rank `rank` of `world` on this node: rendezvous variables, and the rank's share of the host — a
+    contiguous `cores // world` slice of the launcher's cores (DVM_RANK_CPUS, applied by the child before it imports torch)
+    with OMP / MKL pools of that size, so that 8 ranks do not start 8 x all-cores threads (dvm/hostenv.py)."""
+    from dvm import hostenv   # torch-free
     env = dict(os.environ if base is None else base)
     env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
                MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this pool
+    env.update(hostenv.rank_host_env(rank, world, cpus=cpus, base=env))
     return env
 
 
@@ -152,27 +158,39 @@ def load_weights():
     return dict(np.load(path))  # the reference's shipped Deformer checkpoint (ckpt/dvmatcher_scape_r), as data
 
 
+def checked_pair_ids(P, n, seed=20260):
+    """`n` pairs of a batch of P chosen by a seeded draw ("checked on 4 random pairs per run")."""
+    import random
+    return sorted(random.Random(seed + P).sample(range(P), min(n, P)))
+
+
 def oracle_legs(batch, out12, out21, sample_pairs, check_pairs):
-    """The CPU oracle (oracle/dvm_oracle.c, test infrastructure) on the first pairs of the batch that was timed:
-    the first `check_pairs` are compared with the GPU outputs, the first `sample_pairs` are the cpu_baseline."""
+    """The CPU oracle (oracle/dvm_oracle.c, test infrastructure) on pairs of the batch that was timed: `check_pairs`
+    seeded-random pairs are compared with the GPU outputs; the cpu_baseline is timed on those plus the first pairs of the
+    batch up to `sample_pairs` in all."""
     import numpy as np
     from oracle import oracle as O
     O.lib()
     w = load_weights()
-    npairs = max(sample_pairs, check_pairs)
-    f1, f2, v1, v2, s1, s2 = [t[:npairs].cpu().numpy() for t in batch]
-    O.pair_direction(w, f1[0][:256], f2[0][:256], v1[0][:256], v2[0][:256], ALPHA, 0)  # warm the thread pool
-    check = {"T_exact": True, "max_abs_warped": 0.0, "max_abs_verts12": 0.0, "max_rel_losses": 0.0}
+    P = batch[0].shape[0]
+    ids = checked_pair_ids(P, check_pairs) if check_pairs > 0 else []
+    ids += [p for p in range(P) if p not in ids][:max(0, sample_pairs - len(ids))]
+    host = {p: [t[p].cpu().numpy() for t in batch] for p in ids}
+    f1, f2, v1, v2, _, _ = host[ids[0]]
+    O.pair_direction(w, f1[:256], f2[:256], v1[:256], v2[:256], ALPHA, 0)  # warm the thread pool
+    check = {"T_exact": True, "max_abs_warped": 0.0, "max_abs_verts12": 0.0, "max_rel_losses": 0.0, "pairs": ids[:check_pairs]}
     kept = []
+    dt = None
     t0 = time.perf_counter()
-    for p in range(npairs):
-        o12 = O.pair_direction(w, f1[p], f2[p], v1[p], v2[p], ALPHA, int(s1[p]))
-        o21 = O.pair_direction(w, f2[p], f1[p], v2[p], v1[p], ALPHA, int(s2[p]))
-        if p == sample_pairs - 1:
+    for n, p in enumerate(ids):
+        f1, f2, v1, v2, s1, s2 = host[p]
+        o12 = O.pair_direction(w, f1, f2, v1, v2, ALPHA, int(s1))
+        o21 = O.pair_direction(w, f2, f1, v2, v1, ALPHA, int(s2))
+        if n == sample_pairs - 1:
             dt = time.perf_counter() - t0
-        if p < check_pairs:
-            kept.append((o12, o21))
-    for p, (o12, o21) in enumerate(kept):
+        if n < check_pairs:
+            kept.append((p, o12, o21))
+    for p, o12, o21 in kept:
         for o, g in ((o12, out12), (o21, out21)):
             check["T_exact"] = check["T_exact"] and bool(np.array_equal(g["T12"][p].cpu().numpy(), o["T12"]))
             check["max_abs_warped"] = max(check["max_abs_warped"], float(np.abs(g["warped"][p].cpu().numpy() - o["warped"]).max()))
@@ -182,13 +200,45 @@ def oracle_legs(batch, out12, out21, sample_pairs, check_pairs):
     ok = check["T_exact"] and check["max_abs_warped"] <= 1e-4 and check["max_abs_verts12"] <= 1e-4 and check["max_rel_losses"] <= 1e-3
     check["ok"] = bool(ok) if check_pairs > 0 else None
     cpu = None
-    if sample_pairs > 0:
+    if sample_pairs > 0 and dt is not None:
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         omp = int(os.environ.get("OMP_NUM_THREADS", cores))
         cpu = {"value": sample_pairs / dt, "unit": "pairs/s", "cores": min(cores, omp), "kind": "port",
-               "sample": "the first %d pairs of the timed batch (N=M=%d, d=%d, both directions), C oracle with OpenMP (%.1f s)"
-                         % (sample_pairs, N_PTS, DIM, dt)}
+               "sample": "%d pairs of the timed batch (the %d checked ones + the first %d; N=M=%d, d=%d, both directions), C oracle "
+                         "with OpenMP (%.1f s)" % (sample_pairs, min(check_pairs, sample_pairs), max(0, sample_pairs - check_pairs),
+                                                   N_PTS, DIM, dt)}
     return check, cpu
+
+
+def k1_sources_sha16():
+    """Identity of the dominant kernel's source: sha256 over the files that define pass A of K1.  The PMC traffic file
+    records it when it is measured (tools/k1_traffic.py); bench.py reports `traffic` only from a file taken on THIS source
+    and for the kernel the timed launches actually ran."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("dvm_softcorr_sweep2.hip", "dvm_softcorr_f16.hip", "dvm_softcorr_f16.h"):
+        with open(os.path.join(ROOT, "dv-matcher_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def load_traffic(P, kernel_name):
+    """(bytes per launch or None, provenance dict) from profiles/r4_k1_traffic.json."""
+    tpath = os.path.join(ROOT, "profiles", "r4_k1_traffic.json")
+    if not os.path.exists(tpath):
+        return None, {"file": None, "why_null": "no traffic file for this round"}
+    tj = json.load(open(tpath))
+    prov = {"file": "profiles/r4_k1_traffic.json", "kernel": tj.get("kernel_slot_name"), "source_sha16": tj.get("source_sha16"),
+            "pairs": tj.get("pairs")}
+    if tj.get("pairs") != P:
+        prov["why_null"] = "measured at --pairs %s, this run is --pairs %d" % (tj.get("pairs"), P)
+    elif tj.get("kernel_slot_name") != kernel_name:
+        prov["why_null"] = "measured for %r, the timed launches ran %r" % (tj.get("kernel_slot_name"), kernel_name)
+    elif tj.get("source_sha16") != k1_sources_sha16():
+        prov["why_null"] = "measured on another version of the kernel source (%s, now %s)" % (tj.get("source_sha16"), k1_sources_sha16())
+    else:
+        return tj.get("bytes_per_launch"), prov
+    return None, prov
 
 
 def kernel_models(P):
@@ -227,12 +277,16 @@ def run_pair(args):
     local = local % torch.cuda.device_count()  # (more ranks than devices only happens in the gloo test)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # DVM_DIST_ALWAYS=1: initialise the process group (and run the barriers / the MAX all-reduce) even at world size 1, so
+    # that the RCCL branch of this script executes on a 1-GPU box (tests/test_gpu_ddp.py) and not first on the 8-GPU node
+    dist_on = world > 1 or os.environ.get("DVM_DIST_ALWAYS", "0") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     lib = _lib.load()
 
     strong = args.pairs_total is not None
@@ -259,19 +313,27 @@ def run_pair(args):
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     ops.check(lib.dvm_profile_enable(args.steps + 4), "dvm_profile_enable")   # slot 0 (the sweep) only
+    # per-step durations for the median: one event between steps on the caller's stream (pair_forward joins its helper
+    # streams back into it before returning, so consecutive events bracket whole steps)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     k1_total_ms, k1_launches = read_slot(0)
+    k1_name = lib.dvm_profile_kernel_name(0).decode()     # what the timed launches actually ran (the probe / alpha routes pass A)
     lib.dvm_profile_disable()
     # the other kernels of the step, bracketed the same way, over 3 extra steps (outside the timed region: 16 more event
     # records per step)
@@ -294,7 +356,7 @@ def run_pair(args):
     lib.dvm_profile_disable()
     lib.dvm_pair_set_overlap(1)
     local_dt = dt
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -304,15 +366,9 @@ def run_pair(args):
 
     if rank == 0:
         value = pairs_per_step * args.steps / dt
-        traffic = args.traffic_bytes
+        traffic, traffic_src = args.traffic_bytes, {"file": None, "why": "--traffic-bytes"}
         if traffic is None:
-            for name in ("r3_k1_traffic.json", "k1_traffic.json"):   # measured for one exact launch shape
-                tpath = os.path.join(ROOT, "profiles", name)
-                if os.path.exists(tpath):
-                    tj = json.load(open(tpath))
-                    if tj.get("pairs") == P:
-                        traffic = tj.get("bytes_per_launch")
-                    break
+            traffic, traffic_src = load_traffic(P, k1_name)
         k1_ms = k1_total_ms / max(k1_launches, 1)
         k1_alone = alone_ms / max(alone_n, 1)
         flops_launch = P * (2.0 * N_PTS * M_PTS * DIM)   # the distance tile counted once per pair
@@ -334,23 +390,26 @@ def run_pair(args):
                             "ms_per_step": per_step, "algorithmic_per_launch": work, "note": m["note"]})
         res = {
             "metric": "point-cloud pairs/sec (N=2048, d=128)", "value": value, "unit": "pairs/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "median_ms_per_step": median_ms,
+            "higher_is_better": True,
             "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: synthetic random pairs N=M=2048 d=128, correspondence+deform "
                                    "forward, both directions", "pairs_per_gpu_per_step": P, "pairs_per_step": pairs_per_step,
                        "alpha": ALPHA, "deformer_weights": "reference ckpt/dvmatcher_scape_r (fixture)", "fps_start": 0,
                        "parallelism": "pairs sharded over %d GPU(s), no collective" % world},
             "per_gpu": {"pairs_per_s": value / world, "rank0_ms_per_step": local_dt / args.steps * 1e3},
+            "process_group": (dist.get_backend() if dist_on else None),
             # The dominant kernel runs the N x M contraction on the 16-bit matrix pipe: 3 exact fp16 partial products
             # (2-way split of the scaled features, fp32 accumulate) per direction.  `achieved` / `peak` / `frac` price the
             # flops it PERFORMS (6 x the algorithmic count: 3 products x 2 directions of one distance tile) against the pipe
             # it runs on (dense f16 peak) — the utilisation figure.  `algorithmic` is SURVEY §8d's accounting: 2*N*M*d per
             # pair, the distance tile counted once, over the same launch time, against the fp32 matrix peak §8d prescribes
             # (a formulation-independent number: it can exceed what an fp32-MFMA kernel could ever reach).
-            "roofline": {"bound": "mfma", "kernel": "softcorr_sweep2_kernel (K1 pass A, fp16x2-split sweep, second form; the probe routes flat-row inputs to softcorr_sweep_f16_kernel)",
+            "roofline": {"bound": "mfma", "kernel": k1_name + " (K1 pass A: the N x M sweep on the f16 matrix pipe over an exact 2-way fp16 split; "
+                                                             "named by the library from what the timed launches ran)",
                          "achieved": 6.0 * tf(k1_ms), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": 6.0 * tf(k1_ms) / PEAK_F16_MFMA_TFLOPS, "pipe": "f16 matrix (v_mfma_f32_32x32x16_f16)",
-                         "traffic": traffic, "launch_ms": k1_ms, "launches_timed": k1_launches,
+                         "traffic": traffic, "traffic_source": traffic_src, "launch_ms": k1_ms, "launches_timed": k1_launches,
                          "flops_per_launch": 6.0 * flops_launch,
                          "algorithmic": {"flops_per_launch": flops_launch, "achieved": tf(k1_ms), "peak": PEAK_F32_MFMA_TFLOPS,
                                          "frac": tf(k1_ms) / PEAK_F32_MFMA_TFLOPS, "peak_name": "fp32 matrix"},
@@ -376,10 +435,10 @@ def run_pair(args):
         print(json.dumps(res))
         if res["check"] is not None and not res["check"]["ok"]:
             print("bench.py: the GPU outputs of the timed batch differ from the oracle: %s" % res["check"], file=sys.stderr)
-            if world > 1:
+            if dist_on:
                 dist.destroy_process_group()
             return 3
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
     return 0
 
@@ -411,6 +470,7 @@ def run_train(args):
                           "parallelism": "data parallel over %d GPU(s), one flat 8.5 MB gradient all-reduce" % world,
                           "alpha": tr["alpha"], "criterion": tr["criterion"]},
                "host_enqueue_ms_per_step": tr["host_enqueue_ms_per_step"], "roofline": tr["roofline"], "cpu_baseline": None,
+               "process_group": tr.get("process_group"),
                "first_losses": tr["first_losses"], "last_losses": tr["last_losses"]}
         print(json.dumps(res))
     return rc
@@ -421,6 +481,8 @@ def main(argv=None):
     args = parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(argv, args.gpus)      # parent: spawns the ranks, imports no torch
+    from dvm import hostenv
+    hostenv.apply_rank_host_limits()              # a rank pins itself and sizes its thread pools BEFORE torch is imported
     return run_pair(args) if args.workload == "pair" else run_train(args)
 
 

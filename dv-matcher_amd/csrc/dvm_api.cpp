@@ -106,35 +106,67 @@ DVM_EXPORT int dvm_pair_destroy(void) {
 // launched on (bench.py's roofline legs).  Slot 0 (DVM_PROF_K1_SWEEP) is the soft-correspondence sweep; the other
 // slots (include/dvm.h, DVM_PROF_*) are the remaining kernels of one step.  Off by default; when off the launch path
 // records nothing.  Only slots selected by dvm_profile_select() record (default: slot 0 only).
+// The registry is shared by every host thread that launches through the library (the ABI allows one thread per
+// stream): ONE mutex guards the event pool, the bracket list, the window flag and the slot names; a bracket's two
+// events are reserved under the lock when it opens and belong to the opening thread until it closes (thread-local).
+#include <string.h>
+
 #include <vector>
 namespace dvm {
 struct ProfRec {
     int id;
     hipEvent_t e0, e1;
 };
+static std::mutex g_prof_mu;
 static std::vector<hipEvent_t> g_ev;      // pool, 2 per bracket
-static std::vector<ProfRec> g_rec;        // brackets of the current window
+static std::vector<ProfRec> g_rec;        // closed brackets of the current window
 static int g_ev_used = 0;
 static bool g_prof_on = false;
 static unsigned g_prof_mask = 1u;
-static thread_local int g_open_id = -1;   // (a bracket is opened and closed by the same host thread)
+static unsigned g_prof_window = 0;        // bumped by enable / disable: a bracket opened in an earlier window is dropped
+static char g_slot_name[DVM_PROF_COUNT][96] = {"softcorr_sweep2_kernel", "softcorr_refine_kernel", "mlp_f16x2_kernel", "grid_chamfer_kernel",
+                                               "pool_kernel",            "grid_knn_self_kernel",   "fps_kernel",       "assemble_pooled_kernel"};
+struct ProfOpen {
+    int id = -1;
+    unsigned window = 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+};
+static thread_local ProfOpen g_open;      // (a bracket is opened and closed by the same host thread)
 void prof_begin(hipStream_t s, int id) {
-    if (!g_prof_on || !((g_prof_mask >> id) & 1u) || g_ev_used + 2 > (int)g_ev.size()) return;
-    (void)hipEventRecord(g_ev[g_ev_used], s);
-    g_open_id = id;
+    hipEvent_t e0;
+    {
+        std::lock_guard<std::mutex> lock(g_prof_mu);
+        if (!g_prof_on || !((g_prof_mask >> id) & 1u) || g_ev_used + 2 > (int)g_ev.size()) return;
+        e0 = g_ev[g_ev_used];
+        g_open.id = id, g_open.window = g_prof_window, g_open.e0 = e0, g_open.e1 = g_ev[g_ev_used + 1];
+        g_ev_used += 2;
+    }
+    (void)hipEventRecord(e0, s);
 }
 void prof_end(hipStream_t s, int id) {
-    if (!g_prof_on || g_open_id != id || g_ev_used + 2 > (int)g_ev.size()) return;
-    (void)hipEventRecord(g_ev[g_ev_used + 1], s);
-    g_rec.push_back(ProfRec{id, g_ev[g_ev_used], g_ev[g_ev_used + 1]});
-    g_ev_used += 2;
-    g_open_id = -1;
+    if (g_open.id != id) return;
+    g_open.id = -1;
+    (void)hipEventRecord(g_open.e1, s);
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    if (g_prof_on && g_open.window == g_prof_window) g_rec.push_back(ProfRec{id, g_open.e0, g_open.e1});
+}
+// the kernel(s) a slot's bracket actually enclosed at its last launch (slot 0: whichever pass-A kernel the probe / alpha routed to)
+void prof_note(int id, const char *name) {
+    if (id < 0 || id >= DVM_PROF_COUNT) return;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    if (!g_prof_on) return;
+    strncpy(g_slot_name[id], name, sizeof(g_slot_name[id]) - 1);
 }
 static int prof_read(int id, double *total_ms, int *launches) {
+    std::vector<ProfRec> recs;
+    {
+        std::lock_guard<std::mutex> lock(g_prof_mu);
+        for (const ProfRec &r : g_rec)
+            if (r.id == id) recs.push_back(r);
+    }
     double tot = 0.0;
     int n = 0;
-    for (const ProfRec &r : g_rec) {
-        if (r.id != id) continue;
+    for (const ProfRec &r : recs) {   // (synchronises outside the lock: launches on other threads go on recording)
         float ms = 0.f;
         if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) {
             set_error("dvm_profile_read: bracket %d of kernel slot %d not readable", n, id);
@@ -151,6 +183,7 @@ static int prof_read(int id, double *total_ms, int *launches) {
 
 DVM_EXPORT int dvm_profile_enable(int max_launches) {
     DVM_REQUIRE(max_launches >= 1 && max_launches <= (1 << 20), "dvm_profile_enable: bad max_launches %d", max_launches);
+    std::lock_guard<std::mutex> lock(dvm::g_prof_mu);
     while ((int)dvm::g_ev.size() < 2 * max_launches) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) {
@@ -161,12 +194,14 @@ DVM_EXPORT int dvm_profile_enable(int max_launches) {
     }
     dvm::g_ev_used = 0;
     dvm::g_rec.clear();
+    ++dvm::g_prof_window;
     dvm::g_prof_on = true;
     return DVM_OK;
 }
 
 DVM_EXPORT int dvm_profile_select(unsigned kernel_mask) {
     DVM_REQUIRE(kernel_mask != 0 && kernel_mask < (1u << DVM_PROF_COUNT), "dvm_profile_select: bad mask 0x%x", kernel_mask);
+    std::lock_guard<std::mutex> lock(dvm::g_prof_mu);
     dvm::g_prof_mask = kernel_mask;
     return DVM_OK;
 }
@@ -183,16 +218,19 @@ DVM_EXPORT int dvm_profile_read_kernel(int kernel, double *total_ms, int *launch
 }
 
 DVM_EXPORT const char *dvm_profile_kernel_name(int kernel) {
-    static const char *const names[DVM_PROF_COUNT] = {
-        "softcorr_sweep2_kernel",    "softcorr_refine_kernel", "mlp_f16x2_kernel", "grid_chamfer_kernel", "pool_kernel",
-        "grid_knn_self_kernel",      "fps_kernel",             "assemble_pooled_kernel"};
-    return (kernel >= 0 && kernel < DVM_PROF_COUNT) ? names[kernel] : "";
+    static thread_local char out[96];
+    if (kernel < 0 || kernel >= DVM_PROF_COUNT) return "";
+    std::lock_guard<std::mutex> lock(dvm::g_prof_mu);
+    memcpy(out, dvm::g_slot_name[kernel], sizeof(out));
+    return out;
 }
 
 DVM_EXPORT int dvm_profile_disable(void) {
+    std::lock_guard<std::mutex> lock(dvm::g_prof_mu);
     dvm::g_prof_on = false;
     dvm::g_ev_used = 0;
     dvm::g_rec.clear();
+    ++dvm::g_prof_window;
     dvm::g_prof_mask = 1u;
     return DVM_OK;
 }

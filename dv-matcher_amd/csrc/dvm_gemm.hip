@@ -521,7 +521,10 @@ void launch_linear(const float *x, const float *w, int B, int N, int K, int Co, 
         bool dma_ok = a.kvec && !a.G && ((uintptr_t)x | (uintptr_t)w) % 16 == 0;
         for (int i = 0; i <= a.nkb; ++i) dma_ok = dma_ok && a.kb[i] % GK == 0;
         int cfg = pick_cfg(8, Co, K);
-        if (cfg >= 4 && !dma_ok) cfg -= 4;
+        if (cfg >= 4 && !dma_ok) {   // register-staged twin of the DMA tile: 64x64 -> 64x64, 128x64 -> 64x64, 64x128 -> 64x128, 128x128 -> 128x128
+            static const int twin[4] = {1, 1, 2, 3};
+            cfg = twin[cfg - 4];
+        }
         switch (cfg) {   // {4,1,1,1} 128x32, {2,2,1,1} 64x64, {2,2,1,2} 64x128, {2,2,2,2} 128x128; 4..7: LDS-DMA staging, 64x64 / 128x64 / 64x128 / 128x128
             case 0: launch_cfg<false, 4, 1, 1, 1>(a, 1, s); break;
             case 1: launch_cfg<false, 2, 2, 1, 1>(a, 1, s); break;

@@ -601,14 +601,14 @@ __global__ __launch_bounds__(128) void grid_chamfer_kernel(const ChGridArgs args
                     asm volatile("" : "+v"(dm));   // (evaluated for every lane, then selected: no branch around eight instructions)
                     const bool inb = s < rend;
                     const float d = inb ? dm : INFINITY;
-                    const bool lt = d < best, eq = d == best && inb;   // (an infinite distance equal to an infinite best: resolved below)
+                    const bool lt = d < best, eq = d == best && inb && d < INFINITY;   // (inf == inf while bs is still -1 is NOT a tie: there is no candidate to resolve)
                     tie = lt ? false : (tie || eq);
                     bs = lt ? s : bs;
                     best = lt ? d : best;
                 }
             }
         }
-        if (tie) {   // exact ties (duplicated target points): the lowest original index among the candidates at the best distance
+        if (tie && bs >= 0) {   // exact ties (duplicated target points): the lowest original index among the candidates at the best distance
             int bid = g.ids[bs];
 #pragma unroll 1
             for (int r = 0; r < 9; ++r) {
@@ -823,8 +823,16 @@ void launch_grid_chamfer(const GridBuf *gq, const GridBuf *gb, float *const *dou
     // 2.5 G pair distances per launch - not by how full the scanning waves are.  Opt-in.)
     static const int defer = [] { const char *e = getenv("DVM_CHAMFER_DEFER"); return e ? atoi(e) : 0; }();
     args.defer = defer;
-    static const int ablate = [] { const char *e = getenv("DVM_CHAMFER_ABLATE"); return e ? atoi(e) : 0; }();
+    args.ablate = 0;
+#ifdef DVM_ABLATE   // `make ABLATE=1` only: WRONG results, timing experiments
+    static const int ablate = [] {
+        const char *e = getenv("DVM_CHAMFER_ABLATE");
+        const int v = e ? atoi(e) : 0;
+        if (v) fprintf(stderr, "libdvm_hip: DVM_CHAMFER_ABLATE=%d: Chamfer returns WRONG results (timing experiment)\n", v);
+        return v;
+    }();
     args.ablate = ablate;
+#endif
     prof_begin(s, DVM_PROF_CHAMFER);
     hipLaunchKernelGGL(grid_chamfer_kernel, dim3((maxN + 127) / 128, B, ngroups), dim3(128), 0, s, args);
     if (defer) hipLaunchKernelGGL(grid_chamfer_retry_kernel, dim3(B, ngroups), dim3(256), 0, s, args);

@@ -334,12 +334,18 @@ int *launch_mlp_rows_f16(const float *z, int rows, const float *W0, const float 
     const dim3 grid((rows + MH_NODES - 1) / MH_NODES), block(MH_THREADS);
     // (ablation, WRONG results: 1 = the weight fragments are not re-loaded in the k-loops, 2 = the activation fragments are read
     // from one LDS address, 3 = both: what is left is the matrix instructions, the activation stores and the barriers)
+    // compiled in only with `make ABLATE=1` (-DDVM_ABLATE): a stray environment variable must not be able to corrupt a production run
+#ifdef DVM_ABLATE
     static const int abl = [] { const char *e = getenv("DVM_MLP_ABLATE"); return e ? atoi(e) : 0; }();
     if (abl == 1 || abl == 2 || abl == 3) {
+        static bool warned = false;
+        if (!warned) warned = true, fprintf(stderr, "libdvm_hip: DVM_MLP_ABLATE=%d: the Deformer MLP returns WRONG results (timing experiment)\n", abl);
         auto k = abl == 1 ? mlp_f16x2_kernel<2, 1> : abl == 2 ? mlp_f16x2_kernel<2, 2> : mlp_f16x2_kernel<2, 3>;
         ensure_dyn_lds((const void *)k, (int)MH_LDS_BYTES);
         hipLaunchKernelGGL(k, grid, block, MH_LDS_BYTES, s, z, rows, Wp0, b0, Wp1, b1, Wp2, b2, Wp3, b3, out, flag);
-    } else if (ahead <= 2) {
+    } else
+#endif
+    if (ahead <= 2) {
         ensure_dyn_lds((const void *)mlp_f16x2_kernel<2>, (int)MH_LDS_BYTES);
         hipLaunchKernelGGL(mlp_f16x2_kernel<2>, grid, block, MH_LDS_BYTES, s, z, rows, Wp0, b0, Wp1, b1, Wp2, b2, Wp3, b3, out, flag);
     } else if (ahead <= 4) {

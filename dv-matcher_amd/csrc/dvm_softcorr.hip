@@ -586,6 +586,7 @@ int launch_softcorr_both(const float *f1, const float *f2, const float *n1, cons
     a.blocks0 = B * a.g[0].tiles;
     a.neg_alpha = neg_alpha;
     a.topk = 10;
+    prof_note(DVM_PROF_K1_SWEEP, "softcorr_mfma_kernel");
     prof_begin(s);
     launch_softcorr_mfma<10>(a, a.blocks0 + B * a.g[1].tiles, s);
     prof_end(s);
@@ -715,6 +716,7 @@ DVM_EXPORT int dvm_softcorr_fwd_f32(const float *f1, const float *f2, int B, int
     launch_rownorm2(f1, B * N, d, n1, s);
     launch_rownorm2(f2, B * M, d, n2, s);
     bool mfma = (variant == 2) || (variant == 0 && d == MF_D);
+    prof_note(DVM_PROF_K1_SWEEP, mfma ? "softcorr_mfma_kernel" : "softcorr_scalar_kernel");
     prof_begin(s);
     if (mfma) {
         SCArgs a;

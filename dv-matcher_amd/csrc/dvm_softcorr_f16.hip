@@ -1339,6 +1339,11 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
     const int blocks = a.blocks0 + (both ? B * a.g[1].tiles : 0);
     a.route = routed ? route : nullptr;
     a.nb = B;
+    prof_note(DVM_PROF_K1_SWEEP, routed ? (have2 ? "routed: softcorr_sweep2_kernel | softcorr_sweep_f16_kernel<lean> | softcorr_sweep_f16_kernel<full>"
+                                                 : "routed: softcorr_sweep_f16_kernel<lean> | softcorr_sweep_f16_kernel<full>")
+                                        : fixed == K1_ROUTE_SECOND ? "softcorr_sweep2_kernel"
+                                        : fixed == K1_ROUTE_LEAN   ? "softcorr_sweep_f16_kernel<lean>"
+                                                                   : "softcorr_sweep_f16_kernel<full>");
     prof_begin(s);
     // (routed: all three kernels are launched and a workgroup whose pair belongs to another one returns at once)
     if (routed ? have2 : fixed == K1_ROUTE_SECOND) launch_sweep2(a, nf2, nf1, amax, blocks, sweep_form(), s);

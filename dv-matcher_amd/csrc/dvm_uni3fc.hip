@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void add_affine_kernel(const f32x4 *__restrict
 // out[b][c] = max over n of x[b][n][c]: rows split over blockIdx.z, partial maxima combined with an ordered-integer atomic
 // (out pre-set to -inf); the maximum does not depend on the order
 __device__ __forceinline__ void atomic_max_float(float *addr, float v) {
-    if (v >= 0.f)
+    if (!(__float_as_uint(v) >> 31))   // by the SIGN BIT: -0.0f belongs to the negative branch (as an int it is INT_MIN and would never win)
         atomicMax((int *)addr, __float_as_int(v));
     else
         atomicMin((unsigned *)addr, __float_as_uint(v));

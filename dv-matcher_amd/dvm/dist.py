@@ -70,13 +70,13 @@ class FlatGradBucket:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
             self.flat.div_(world)
 
-    def all_reduce_sum(self, group=None, async_op=False):
+    def all_reduce_sum(self, group=None, async_op=False, always=False):
         """grad <- sum over ranks of grad, one collective.  With every rank back-propagating
         `criterion.data_parallel_loss(B_shard / B_global)` this is the single-process gradient of the global batch
         (the criterion mixes per-batch sums and means, so a plain mean would shrink its sum-type terms by 1/world).
         async_op=True returns the work handle (wait() before the optimizer step)."""
         self._gather_foreign()
-        if dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.is_initialized() and (always or dist.get_world_size(group) > 1):   # always: also a one-rank group (the collective runs)
             return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
         return None
 

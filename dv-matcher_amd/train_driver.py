@@ -36,13 +36,15 @@ import random
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 HERE = os.path.dirname(os.path.abspath(__file__))
 if HERE not in sys.path:
     sys.path.insert(0, HERE)
+from dvm import hostenv  # noqa: E402  (torch-free)
+hostenv.apply_rank_host_limits()   # one of several ranks: pin to this rank's cores, size the thread pools — BEFORE torch loads
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 from dvm.dist import FlatGradBucket, shard_range  # noqa: E402
 from models.loss import GraphDeformLoss_Neural, GraphDeformLoss_Neural_Partial  # noqa: E402
@@ -235,9 +237,17 @@ def main(argv=None):
     local = pick_device(local, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # DVM_DIST_ALWAYS=1: the process group, the flat-bucket all-reduce and the barriers also at world size 1 — the RCCL branch
+    # of this driver then runs on a 1-GPU box (tests/test_gpu_ddp.py) instead of first on the 8-GPU node
+    dist_on = world > 1 or os.environ.get("DVM_DIST_ALWAYS", "0") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(args.backend, **({"device_id": dev} if args.backend == "nccl" else {}))
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        dist.init_process_group(args.backend, rank=rank, world_size=world, **({"device_id": dev} if args.backend == "nccl" else {}))
     Bg = args.batch or int(cfg["training"]["batch_size"])
     if Bg < world:
         raise SystemExit("global batch %d < world size %d: every rank needs at least one pair" % (Bg, world))
@@ -258,7 +268,7 @@ def main(argv=None):
     # exchange and lets autograd hand Adam its gradient tensors directly — unless the step is captured into a graph, whose
     # gradient tensors must keep their addresses.  (DVM_FLAT_GRADS=1 forces the flat buffer on a single rank: the fused
     # gradient accumulation then covers the first network call of a step as well; measured neutral, 27.7 vs 27.9 ms.)
-    attach = world > 1 or use_graph or os.environ.get("DVM_FLAT_GRADS", "0") == "1"
+    attach = dist_on or use_graph or os.environ.get("DVM_FLAT_GRADS", "0") == "1"
     bucket = FlatGradBucket(params, attach=attach)
     random.seed(seed_py)
     torch.manual_seed(seed_torch)
@@ -339,10 +349,10 @@ def main(argv=None):
         t = mark(0, t)
         out = crit(f1, f2, dist1, dist2, v1, v2, alpha, dfm, geometry=join_geometry(geo))
         t = mark(1, t)
-        if world > 1:
+        if dist_on:
             crit.data_parallel_loss(frac).backward()
             join_side_streams(dev)                           # gradients written from the helper-stream chain are complete
-            work = bucket.all_reduce_sum(async_op=True)      # one 8.5 MB collective on RCCL's stream ...
+            work = bucket.all_reduce_sum(async_op=True, always=True)   # one 8.5 MB collective on RCCL's stream ...
         else:
             out[0].backward()
             join_side_streams(dev)
@@ -414,7 +424,7 @@ def main(argv=None):
         for i in range(args.warmup):
             train_step(feed[i % len(feed)], alpha)
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         if host_marks is not None:
             host_marks[:] = [0.0, 0.0, 0.0, 0.0, 0]
@@ -423,11 +433,11 @@ def main(argv=None):
             losses.append(train_step(feed[i % len(feed)], alpha))
         t_host = time.perf_counter() - t0          # all steps enqueued; the rest of dt is the GPU catching up
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         dt = time.perf_counter() - t0
         losses = [l if isinstance(l, list) else l.tolist() for l in losses]
-        if world > 1:
+        if dist_on:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t)
@@ -445,9 +455,9 @@ def main(argv=None):
                                            "note": "algorithmic matrix flops of the whole step per GPU over the step time; the step is "
                                                    "~1800 small launches, host- and latency-bound, not matrix-bound"},
                               "points": N, "points_target": M, "criterion": type(crit).__name__, "alpha": float(alpha),
-                              "hip_graph": use_graph,
+                              "hip_graph": use_graph, "process_group": (dist.get_backend() if dist_on else None),
                               "grad_bucket_floats": bucket.numel, "first_losses": losses[0], "last_losses": losses[-1]}))
-        if world > 1:
+        if dist_on:
             dist.destroy_process_group()
         return 0
 
@@ -480,7 +490,7 @@ def main(argv=None):
                 f1, f2 = forward_pair(v1, d1, v2, d2)
                 vsum += crit(f1, f2, dist1, dist2, v1, v2, alpha, dfm)[0].detach().float()
                 viters += 1
-        if world > 1:    # the validation loss that decides 'val_best' is the mean over all shards
+        if dist_on:    # the validation loss that decides 'val_best' is the mean over all shards
             dist.all_reduce(vsum, op=dist.ReduceOp.SUM)
             vsum /= world
         val = float(vsum) / max(viters, 1)
@@ -497,7 +507,7 @@ def main(argv=None):
     if rank == 0:
         print(json.dumps({"epochs": epochs, "history": history, "best_val": best_val, "criterion": type(crit).__name__,
                           "ckpt": list(ckpt_paths(args.ckpt_dir, cfg["expname"], "val_best"))}))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
     return 0
 

@@ -207,3 +207,76 @@ def test_bench_strong_scaling_shards():
     assert [bench.shard_pairs(10, r, 4) for r in range(4)] == [3, 3, 2, 2]
     a = bench.parse_args(["--gpus", "8", "--pairs-total", "4096"])
     assert a.pairs_total == 4096 and a.workload == "pair"
+
+
+def test_rank_host_limits_partition_the_cores(monkeypatch):
+    """Launcher side of VERDICT r3 'weak 8': every rank gets a disjoint contiguous share of the launcher's cores and thread
+    pools of that size; a rank applies them before torch is imported (checked in a child process)."""
+    import json
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "dv-matcher_amd"))
+    from dvm import hostenv
+    cpus = list(range(100, 164))                                   # a 64-core launcher mask
+    shares = [hostenv.rank_cpu_share(r, 8, cpus) for r in range(8)]
+    assert all(len(sh) == 8 for sh in shares) and sorted(sum(shares, [])) == cpus
+    assert hostenv.rank_cpu_share(5, 8, [3, 4]) in ([3], [4])      # more ranks than cores: one core each, wrapped
+    env = hostenv.rank_host_env(2, 8, cpus, base={})
+    assert env == {"DVM_RANK_CPUS": ",".join(str(c) for c in range(116, 124)), "OMP_NUM_THREADS": "8", "MKL_NUM_THREADS": "8"}
+    assert "OMP_NUM_THREADS" not in hostenv.rank_host_env(2, 8, cpus, base={"OMP_NUM_THREADS": "3"})   # the user's choice stays
+    assert hostenv.apply_rank_host_limits({}) is None               # a process on its own is left alone
+    mine = sorted(os.sched_getaffinity(0))
+    if len(mine) < 2:
+        pytest.skip("one core: nothing to partition")
+    code = ("import os, sys, json; sys.path.insert(0, %r); from dvm import hostenv; sh = hostenv.apply_rank_host_limits(); "
+            "assert 'torch' not in sys.modules; import torch; "
+            "print(json.dumps({'share': sh, 'aff': sorted(os.sched_getaffinity(0)), 'omp': os.environ['OMP_NUM_THREADS'], 'threads': torch.get_num_threads()}))"
+            % os.path.join(ROOT, "dv-matcher_amd"))
+    env = {k: v for k, v in os.environ.items() if k not in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "DVM_RANK_CPUS")}
+    env.update(LOCAL_RANK="1", LOCAL_WORLD_SIZE="2", WORLD_SIZE="2", RANK="1")      # external launcher: no DVM_RANK_CPUS
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    info = json.loads(out.stdout.strip().splitlines()[-1])
+    half = len(mine) // 2
+    assert info["aff"] == mine[half:2 * half] == info["share"] and info["omp"] == str(half) and info["threads"] == half
+
+
+def test_bench_gpus8_train_dry_run_builds_rank_environments():
+    """`bench.py --gpus 8 --workload train` on CPU with the process creation replaced: 8 children with rendezvous variables,
+    disjoint core lists and thread-pool sizes, the training workload's arguments passed through, no torch in the parent."""
+    import json
+    import subprocess
+    code = r"""
+import json, os, sys
+sys.path.insert(0, %r)
+import subprocess
+import bench
+seen = []
+class FakeProc:
+    def __init__(self, cmd, env=None, stdout=None, **kw):
+        assert 'torch' not in sys.modules and not any(m.startswith('torch.') for m in sys.modules), 'parent imported torch'
+        seen.append({k: env.get(k) for k in ('RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'DVM_RANK_CPUS', 'OMP_NUM_THREADS', 'MKL_NUM_THREADS')})
+        seen[-1]['cmd'] = cmd[2:]
+        self.returncode = 0
+        import io
+        self.stdout = io.StringIO('{"n_gpus": 8}\n') if stdout is not None else None
+    def poll(self): return 0
+    def wait(self): return 0
+    def kill(self): pass
+subprocess.Popen = FakeProc
+for k in ('WORLD_SIZE', 'OMP_NUM_THREADS', 'MKL_NUM_THREADS', 'DVM_RANK_CPUS'):
+    os.environ.pop(k, None)
+rc = bench.main(['--gpus', '8', '--workload', 'train', '--steps', '3', '--warmup', '1'])
+print(json.dumps({'rc': rc, 'seen': seen, 'cpus': sorted(os.sched_getaffinity(0))}), file=sys.stderr)
+""" % ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    info = json.loads(out.stderr.strip().splitlines()[-1])
+    assert info["rc"] == 0 and len(info["seen"]) == 8
+    per = max(1, len(info["cpus"]) // 8)
+    lists = [[int(c) for c in e["DVM_RANK_CPUS"].split(",")] for e in info["seen"]]
+    assert all(len(l) == per for l in lists) and all(e["OMP_NUM_THREADS"] == str(per) == e["MKL_NUM_THREADS"] for e in info["seen"])
+    if len(info["cpus"]) >= 8:
+        assert len({c for l in lists for c in l}) == 8 * per       # disjoint
+    assert all(e["WORLD_SIZE"] == "8" == e["LOCAL_WORLD_SIZE"] for e in info["seen"])
+    assert all(e["cmd"] == ["--gpus", "8", "--workload", "train", "--steps", "3", "--warmup", "1"] for e in info["seen"])

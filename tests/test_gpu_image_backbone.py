@@ -112,3 +112,37 @@ def test_uni3fc_forward_without_precomputed_features():
     assert feat.shape == (2, 1024, 128) and dino.shape == (2, 1024, 1152) and bool(torch.isfinite(feat).all())
     assert torch.equal(feat, feat2)
     np.testing.assert_allclose(dino.norm(dim=-1).cpu().numpy(), np.sqrt(3.0), rtol=1e-4)   # three L2-normalised 384-d blocks
+
+
+def test_uni3fc_config5_full_size_properties():
+    """BASELINE configs[4] at its contract size — N = 4096 points per shape, B = 2 — through Uni3FC.forward(x, None,
+    upsampler) (models/model.py:683-710): size-independent properties, since neither the reference nor the oracle can run
+    the image backbone here (parity unpinned: SURVEY 8f-1).  (1) end-to-end == explicit visual features, bit for bit;
+    (2) deterministic; (3) batch independence of the VISUAL features (rendering and back-projection are per shape; LG-Net's
+    positional encoding is not — models/model.py:548 normalises with the batch-global min/max — so the features of a shape
+    are compared inside one and the same batch only); (4) every point carries three L2-normalised 384-d blocks;
+    (5) a permutation of the points permutes the visual features (the splat is a sum, the back-projection a per-point
+    lookup), up to the fixed-point splat being order-independent: bit-exact."""
+    import models.model as mm
+    from models.image_backbone import load_upsampler
+    up = load_upsampler(seed=5)
+    net = mm.Uni3FC(k=40).cuda().eval()
+    g = torch.Generator().manual_seed(4096)
+    B, N = 2, 4096
+    x = (torch.rand(B, 3, N, generator=g) - 0.5).cuda()
+    with torch.no_grad():
+        feat, cf = net(x, None, up)
+        dino = net.visual_features(x, up)
+        feat2, cf2 = net(x, dino, None)
+        again, _ = net(x, None, up)
+        solo = net.visual_features(x[1:2], up)
+        perm = torch.randperm(N, generator=g).cuda()
+        dperm = net.visual_features(x[:, :, perm], up)
+    assert feat.shape == (B, N, 128) and cf.shape == (B, N, 64) and dino.shape == (B, N, 1152)
+    assert bool(torch.isfinite(feat).all()) and bool(torch.isfinite(dino).all())
+    assert torch.equal(feat, feat2) and torch.equal(cf, cf2)                      # (1)
+    assert torch.equal(feat, again)                                               # (2)
+    assert float((solo[0] - dino[1]).abs().max()) < 2e-3                          # (3) (GEMM tile choices differ with the image batch)
+    for c in range(3):                                                            # (4)
+        np.testing.assert_allclose(dino[..., c * 384:(c + 1) * 384].norm(dim=-1).cpu().numpy(), 1.0, rtol=1e-4)
+    assert torch.equal(dperm, dino[:, perm])                                      # (5)
