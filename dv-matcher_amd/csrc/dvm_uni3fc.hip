@@ -12,101 +12,15 @@
 //
 // Weight table: DVM_U3_NWEIGHTS device pointers, order documented in include/dvm.h (dvm_uni3fc_fwd_f32); the eval-mode
 // BatchNorms arrive folded to (alpha, beta) exactly as models/model.py::_bn_affine folds them on the host.
-#include "dvm_common.h"
+#include "dvm_uni3fc_kernels.h"
 
 namespace dvm {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 void launch_linear(const float *x, const float *w, int B, int N, int K, int Co, int channel_major, const float *bias,
                    const float *res, const float *alpha, const float *beta, float slope, float *y, hipStream_t s, const float *xg,
                    int Cg, const float *post_res, float post_scale);   // dvm_gemm.hip
 
 namespace {
-
-// out[b][n][c] += pe[b][c][n]   (f is point-major, the position encoding channel-major: 32 x 32 tiles through LDS)
-__global__ __launch_bounds__(256) void add_transposed_kernel(float *__restrict__ f, const float *__restrict__ pe, int N, int C) {
-    __shared__ float tile[32][33];
-    const int b = blockIdx.z, n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 8 rows per pass
-#pragma unroll
-    for (int r = ty; r < 32; r += 8) {
-        const int c = c0 + r, n = n0 + tx;
-        tile[r][tx] = (c < C && n < N) ? pe[((size_t)b * C + c) * N + n] : 0.f;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = ty; r < 32; r += 8) {
-        const int n = n0 + r, c = c0 + tx;
-        if (n < N && c < C) {
-            const size_t o = ((size_t)b * N + n) * C + c;
-            f[o] = f[o] + tile[tx][r];
-        }
-    }
-}
-
-// out = a - b
-__global__ __launch_bounds__(256) void sub_kernel(const f32x4 *__restrict__ a, const f32x4 *__restrict__ b, long n4, f32x4 *__restrict__ out) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) out[i] = a[i] - b[i];
-}
-
-// out[r][c] = t[c] + (x[r][c] + a[r][c]) * s[c], product and sum rounded separately   (the eval-mode BatchNorm of the attention
-// residual as models/model.py::_N2P.infer_pm evaluates it with torch.addcmul: the two paths agree bit for bit; C % 4 == 0)
-__global__ __launch_bounds__(256) void add_affine_kernel(const f32x4 *__restrict__ x, const f32x4 *__restrict__ a, const f32x4 *__restrict__ s,
-                                                         const f32x4 *__restrict__ t, long n4, int c4, f32x4 *__restrict__ out) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % c4);
-        const f32x4 v = x[i] + a[i], sv = s[c], tv = t[c];
-        f32x4 o;
-        o.x = __fadd_rn(tv.x, __fmul_rn(v.x, sv.x)), o.y = __fadd_rn(tv.y, __fmul_rn(v.y, sv.y)), o.z = __fadd_rn(tv.z, __fmul_rn(v.z, sv.z)), o.w = __fadd_rn(tv.w, __fmul_rn(v.w, sv.w));
-        out[i] = o;
-    }
-}
-
-// out[b][c] = max over n of x[b][n][c]: rows split over blockIdx.z, partial maxima combined with an ordered-integer atomic
-// (out pre-set to -inf); the maximum does not depend on the order
-__device__ __forceinline__ void atomic_max_float(float *addr, float v) {
-    if (!(__float_as_uint(v) >> 31))   // by the SIGN BIT: -0.0f belongs to the negative branch (as an int it is INT_MIN and would never win)
-        atomicMax((int *)addr, __float_as_int(v));
-    else
-        atomicMin((unsigned *)addr, __float_as_uint(v));
-}
-__global__ __launch_bounds__(256) void colmax_kernel(const float *__restrict__ x, int N, int C, int rows_per, float *__restrict__ out) {
-    __shared__ float part[4][64];
-    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
-    const int n0 = blockIdx.z * rows_per, n1 = min(N, n0 + rows_per);
-    float m = -INFINITY;
-    if (c < C)
-        for (int n = n0 + g; n < n1; n += 4) m = fmaxf(m, x[((size_t)b * N + n) * C + c]);
-    part[g][threadIdx.x & 63] = m;
-    __syncthreads();
-    if (g == 0 && c < C) {
-        m = fmaxf(fmaxf(part[0][threadIdx.x], part[1][threadIdx.x]), fmaxf(part[2][threadIdx.x], part[3][threadIdx.x]));
-        atomic_max_float(out + (size_t)b * C + c, m);
-    }
-}
-__global__ void fill_kernel(float *__restrict__ p, long n, float v) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
-}
-
-// out[r] = [s0[r] | s1[r] | s2[r] | s3[r]]   (ns sources of C floats each, C % 4 == 0)
-struct CatArgs {
-    const f32x4 *src[4];
-    int ns, c4;
-    long rows;
-    f32x4 *out;
-};
-__global__ __launch_bounds__(256) void concat_kernel(const CatArgs a) {
-    const long total = a.rows * a.ns * a.c4;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int w = a.ns * a.c4, col = (int)(i % w);
-        const long r = i / w;
-        a.out[i] = a.src[col / a.c4][r * a.c4 + col % a.c4];
-    }
-}
-
-inline unsigned blocks_for(long n, int cap = 4096) { return (unsigned)((n + 255) / 256 < cap ? (n + 255) / 256 : cap); }
 
 // indices into the weight table (include/dvm.h)
 enum { CB_W = 0, CB_A, CB_B, CB_N };                                   // conv block: weight, BN alpha, BN beta
