@@ -182,55 +182,69 @@ __global__ __launch_bounds__(256) void cat_prefix_kernel(const unsigned long lon
     }
 }
 // Backward of the two steps above for the Cg prefix columns of dcat [R][ld]: dmax[b][c] = sum_n dcat[b][n][c] (the broadcast),
-// then dwide[b][n][c] = (n == arg[b][c]) ? dmax[b][c] : 0 (the max).  Sums run in a fixed order (rows strided by 4 per
-// thread, four partials combined in order).
-__global__ __launch_bounds__(256) void prefix_colsum_kernel(const float *__restrict__ dcat, int N, int ld, int Cg, float *__restrict__ dmax) {
+// then dwide[b][n][c] = (n == arg[b][c]) ? dmax[b][c] : 0 (the max).  The column sums are formed in a fixed order: S row
+// slices per shape (partial [S][B][Cg]; inside a slice rows strided by 4 per thread, the four partials combined in order),
+// and the S slices are added in order by the one thread of max_bwd_kernel that owns the arg-max row.
+__global__ __launch_bounds__(256) void prefix_colsum_kernel(const float *__restrict__ dcat, int N, int ld, int Cg, int rows_per, float *__restrict__ partial) {
     __shared__ float part[4][64];
     const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const int n0 = blockIdx.z * rows_per, n1 = min(N, n0 + rows_per);
     float s = 0.f;
     if (c < Cg)
-        for (int n = g; n < N; n += 4) s += dcat[((size_t)b * N + n) * ld + c];
+        for (int n = n0 + g; n < n1; n += 4) s += dcat[((size_t)b * N + n) * ld + c];
     part[g][threadIdx.x & 63] = s;
     __syncthreads();
-    if (g == 0 && c < Cg) dmax[(size_t)b * Cg + c] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+    if (g == 0 && c < Cg)
+        partial[((size_t)blockIdx.z * gridDim.y + b) * Cg + c] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
 }
-__global__ __launch_bounds__(256) void max_bwd_kernel(const float *__restrict__ dmax, const int32_t *__restrict__ arg, int N, int C, float *__restrict__ dwide) {
-    const int b = blockIdx.y, c4n = C / 4;
+__global__ __launch_bounds__(256) void max_bwd_kernel(const float *__restrict__ partial, int S, const int32_t *__restrict__ arg, int N, int C,
+                                                      float *__restrict__ dwide) {
+    const int b = blockIdx.y, B = gridDim.y, c4n = C / 4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)N * c4n; i += (long)gridDim.x * blockDim.x) {
         const int n = (int)(i / c4n), c = 4 * (int)(i % c4n);
-        const float *dm = dmax + (size_t)b * C + c;
         const int32_t *ag = arg + (size_t)b * C + c;
+        float e[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            e[q] = 0.f;
+            if (ag[q] == n)
+                for (int s = 0; s < S; ++s) e[q] += partial[((size_t)s * B + b) * C + c + q];
+        }
         f32x4 v;
-        v.x = ag[0] == n ? dm[0] : 0.f, v.y = ag[1] == n ? dm[1] : 0.f, v.z = ag[2] == n ? dm[2] : 0.f, v.w = ag[3] == n ? dm[3] : 0.f;
+        v.x = e[0], v.y = e[1], v.z = e[2], v.w = e[3];
         *(f32x4 *)(dwide + ((size_t)b * N + n) * C + c) = v;
     }
 }
-// out[c] += sum_r g[r][c]  (bias gradients), deterministic in ONE launch: every block writes the column sums of its row chunk,
-// the block that finishes last (device-scope counter, reset by it for the next call) adds the chunks in order.  C <= 128.
-__global__ __launch_bounds__(256) void colsum_accum_kernel(const float *__restrict__ g, long R, int C, long rows_per, float *__restrict__ partial,
-                                                           unsigned *__restrict__ counter, float *__restrict__ out) {
-    __shared__ float part[2][128];
-    __shared__ bool last;
-    const int c = threadIdx.x & 127, h = threadIdx.x >> 7;
+// out[c] += sum_r g[r][c]  (bias gradients) in a fixed order, two launches: column sums per row chunk (rows strided over the
+// 256 / C thread groups, group partials combined in order), then ONE block adds the chunks in order.  (A one-launch form —
+// the block that finishes last adds the chunks, found through a device-scope counter — was measured at 39 - 46 us per call:
+// the device-scope release in front of the counter writes back the L2 on this eight-XCD part.)  C in {32, 64, 128}.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ g, long R, int C, long rows_per, float *__restrict__ partial) {
+    __shared__ float part[8][128];
+    const int groups = 256 / C, c = threadIdx.x % C, h = threadIdx.x / C;
     const long r0 = (long)blockIdx.x * rows_per, r1 = r0 + rows_per < R ? r0 + rows_per : R;
     float s = 0.f;
-    if (c < C)
-        for (long r = r0 + h; r < r1; r += 2) s += g[r * C + c];
+    for (long r = r0 + h; r < r1; r += groups) s += g[r * C + c];
     part[h][c] = s;
     __syncthreads();
-    if (h == 0 && c < C) partial[(size_t)blockIdx.x * C + c] = part[0][c] + part[1][c];
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(counter, 1u) == gridDim.x - 1;
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    if (h == 0 && c < C) {
-        float t = 0.f;
-        for (unsigned k = 0; k < gridDim.x; ++k) t += __builtin_nontemporal_load(partial + (size_t)k * C + c);
-        out[c] += t;
+    if (h == 0) {
+        float t = part[0][c];
+        for (int k = 1; k < groups; ++k) t += part[k][c];
+        partial[(size_t)blockIdx.x * C + c] = t;
     }
-    if (threadIdx.x == 0) *counter = 0u;
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float *__restrict__ partial, int chunks, int C, float *__restrict__ out) {
+    __shared__ float part[8][128];
+    const int groups = 256 / C, c = threadIdx.x % C, h = threadIdx.x / C;
+    float t = 0.f;
+    for (int k = h; k < chunks; k += groups) t += partial[(size_t)k * C + c];
+    part[h][c] = t;
+    __syncthreads();
+    if (h == 0) {
+        float tot = part[0][c];
+        for (int k = 1; k < groups; ++k) tot += part[k][c];
+        out[c] += tot;
+    }
 }
 // The three C x C projection weights of the N2P blocks stacked as [q | k | v] (3C x C per block): packed copies for the forward /
 // input-gradient GEMMs, and the reverse step for the weight gradient — grads[j] += stacked[j].

@@ -94,7 +94,7 @@ void carve_chain(Arena &ar, int B, int N, int K, ChainScratch &c, bool local) {
     c.sabws = c.sab_bytes ? (void *)ar.take<char>(c.sab_bytes) : nullptr;
     c.npb_bytes = local ? dvm_n2p_core_bwd_workspace_bytes(B, N, K) : 0;
     c.npbws = local ? (void *)ar.take<char>(c.npb_bytes) : nullptr;
-    c.colpart = ar.take<float>(512 * 128);
+    c.colpart = ar.take<float>(1024 * 128);
     c.counter = ar.take<unsigned>(64);
     c.g768 = ar.take<float>(R * 768);
     c.g512a = ar.take<float>(R * 512);
@@ -109,7 +109,7 @@ void carve_chain(Arena &ar, int B, int N, int K, ChainScratch &c, bool local) {
     c.dqkv = local ? ar.take<float>(R * 384) : nullptr;
     c.dh = local ? ar.take<float>(R * 512) : nullptr;
     c.dp = local ? nullptr : ar.take<float>(R * 16);
-    c.dmax = ar.take<float>((size_t)B * 512);
+    c.dmax = ar.take<float>((size_t)16 * B * 512);   // per-slice column sums of the max prefix
 }
 
 void carve(Arena &ar, int B, int N, int K, TrainWs &w) {
@@ -176,6 +176,8 @@ void carve(Arena &ar, int B, int N, int K, TrainWs &w) {
 struct Net {
     const float *const *P;   // parameters
     float *const *G;         // gradients (backward; entries of running statistics unused)
+    const int32_t *const *knn_forced = nullptr;   // per N2P block: neighbour sets to use instead of the library's own (tests)
+    int32_t *const *knn_log = nullptr;            // per N2P block: receives the library's own sets (tests)
     int B, N, K;
     long R;
     float eps, momentum;
@@ -204,6 +206,9 @@ int n2p_fwd(const Net &n, int l, const float *xin, const ChainScratch &c, hipStr
     const int C = NP_C[l];
     const float *wqkv = stacked(p[TN_WQ], p[TN_WK], p[TN_WV], C) ? p[TN_WQ] : n.w.wqkv[l];
     T_TRY(dvm_knn_neg_f32(xin, xin, n.B, n.N, n.N, C, n.K, sv.idx, c.knnws, c.knn_bytes, s));
+    const size_t idx_bytes = (size_t)n.R * n.K * sizeof(int32_t);
+    if (n.knn_log && n.knn_log[l]) (void)hipMemcpyAsync(n.knn_log[l], sv.idx, idx_bytes, hipMemcpyDeviceToDevice, s);
+    if (n.knn_forced && n.knn_forced[l]) (void)hipMemcpyAsync(sv.idx, n.knn_forced[l], idx_bytes, hipMemcpyDeviceToDevice, s);
     T_TRY(dvm_linear_f32(xin, wqkv, n.B, n.N, C, 3 * C, 0, nullptr, nullptr, nullptr, nullptr, 1.f, sv.qkv, s));
     T_TRY(dvm_n2p_core_fwd_f32(sv.qkv, sv.idx, n.B, n.N, C, n.K, 4, sv.att, sv.attn, s));
     T_TRY(bn_fwd(n, xin, sv.att, p[TN_G1], p[TN_B1], (float *)p[TN_RM1], (float *)p[TN_RV1], C, 1.f, sv.x1, sv.bn1, c, s));
@@ -255,11 +260,12 @@ int wgrad(const Net &n, const float *dy, const float *x, int Co, int K, float *d
     return dvm_linear_wgrad_f32(dy, x, n.R, Co, K, dW, s);
 }
 void colsum_accum(const Net &n, const float *g, int C, float *out, const ChainScratch &c, hipStream_t s) {
-    long chunks = (n.R + 255) / 256;
-    if (chunks > 512) chunks = 512;
+    long chunks = (n.R + 63) / 64;          // (C in {64, 128}: checked by the callers' layer table)
+    if (chunks > 1024) chunks = 1024;
     const long rows_per = (n.R + chunks - 1) / chunks;
     chunks = (n.R + rows_per - 1) / rows_per;
-    hipLaunchKernelGGL(colsum_accum_kernel, dim3((unsigned)chunks), dim3(256), 0, s, g, n.R, C, rows_per, c.colpart, c.counter, out);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)chunks), dim3(256), 0, s, g, n.R, C, rows_per, c.colpart);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(256), 0, s, c.colpart, (int)chunks, C, out);
 }
 void slice_add(const float *src, int ld, int off, const float *add, long rows, int C, float *dst, hipStream_t s) {
     hipLaunchKernelGGL(slice_add_kernel, dim3(blocks_for(rows * C / 4)), dim3(256), 0, s, src, ld, off, (const f32x4 *)add, rows, C / 4, (f32x4 *)dst);
@@ -322,8 +328,9 @@ int sa_bwd(const Net &n, int l, const float *xin, const float *g_out, float *dx,
 
 // backward of [max-prefix | x] -> conv_hi, conv_lo(x) -> wide: given dcat (R,768) returns the gradient of x (R,256) in dx256
 int prefix_bwd(const Net &n, int conv_wide, const float *dcat, const float *x256, const int32_t *arg, float *dx256, const ChainScratch &c, hipStream_t s) {
-    hipLaunchKernelGGL(prefix_colsum_kernel, dim3(512 / 64, n.B), dim3(256), 0, s, dcat, n.N, 768, 512, c.dmax);
-    hipLaunchKernelGGL(max_bwd_kernel, dim3(blocks_for((long)n.N * 128, 1024), n.B), dim3(256), 0, s, c.dmax, arg, n.N, 512, c.g512a);
+    const int S = n.N >= 512 ? 16 : 1, rows_per = (n.N + S - 1) / S;
+    hipLaunchKernelGGL(prefix_colsum_kernel, dim3(512 / 64, n.B, S), dim3(256), 0, s, dcat, n.N, 768, 512, rows_per, c.dmax);
+    hipLaunchKernelGGL(max_bwd_kernel, dim3(blocks_for((long)n.N * 128, 1024), n.B), dim3(256), 0, s, c.dmax, S, arg, n.N, 512, c.g512a);
     slice_add(dcat, 768, 512, nullptr, n.R, 256, c.g256a, s);
     // wide = blk(conv_wide, x256):  d x256 = dz W + (the slice above)
     return conv_bwd(n, conv_wide, c.g512a, n.w.cv[conv_wide].y, x256, c.g512b, c.g256a, dx256, c, s);
@@ -370,11 +377,13 @@ DVM_EXPORT size_t dvm_uni3fc_train_workspace_bytes(int B, int N, int k) {
 }
 
 DVM_EXPORT int dvm_uni3fc_train_fwd_f32(const float *xyz, const float *dino, int B, int N, const float *const *params, int nparams, int k, float eps,
-                                        float momentum, float *feat, float *tmp, void *arena, size_t arena_bytes, void *stream) {
+                                        float momentum, const int32_t *const *knn_forced, int32_t *const *knn_log, float *feat, float *tmp,
+                                        void *arena, size_t arena_bytes, void *stream) {
     DVM_REQUIRE(xyz && dino && params && feat && tmp, "dvm_uni3fc_train_fwd_f32: null pointer");
     T_TRY(check_args("dvm_uni3fc_train_fwd_f32", B, N, k, nparams, (const void *const *)params, false));
     Net n;
     n.P = params, n.G = nullptr, n.B = B, n.N = N, n.K = k, n.R = (long)B * N, n.eps = eps, n.momentum = momentum;
+    n.knn_forced = knn_forced, n.knn_log = knn_log;
     Arena ar(arena, arena_bytes);
     carve(ar, B, N, k, n.w);
     if (!ar.ok()) {

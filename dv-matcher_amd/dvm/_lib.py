@@ -58,6 +58,9 @@ SIGNATURES = {
     "dvm_pair_init": (c_int, [_P]),
     "dvm_uni3fc_fwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dvm_uni3fc_fwd_f32": (c_int, [_P, _P, c_int, c_int, _P, c_int, c_int, _P, _P, _P, c_size_t, _P]),
+    "dvm_uni3fc_train_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dvm_uni3fc_train_fwd_f32": (c_int, [_P, _P, c_int, c_int, _P, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "dvm_uni3fc_train_bwd_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P, c_int, c_int, _P, c_size_t, _P]),
     "dvm_pair_destroy": (c_int, []),
     "dvm_argmin_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "dvm_argmin_exact_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),

@@ -180,6 +180,54 @@ def bn_act_pm(bn, x, res=None, slope=1.0):
                           bn.momentum, bn.eps, slope)
 
 
+class _Uni3FCTrain(torch.autograd.Function):
+    """LG-Net's whole training-mode forward / backward as ONE autograd node over two native calls (dvm_uni3fc_train_{fwd,bwd}_f32:
+    the launches of Uni3FC._forward_train_pm and of the graph autograd records for it, enqueued without Python in between).
+    Inputs after (x, dino): the trainable tensors of the parameter table, in table order, so that autograd routes their
+    gradients; `meta` = (table tensors, positions of the trainable ones, k, eps, momentum)."""
+
+    @staticmethod
+    def forward(ctx, meta, x, dino, *trainable):
+        table, where, k, eps, momentum = meta
+        feat, tmp, arena = ops.uni3fc_train_forward(table, x, dino, k, eps, momentum)
+        ctx.set_materialize_grads(False)
+        ctx.meta, ctx.arena, ctx.dino = meta, arena, dino
+        ctx.trainable = trainable
+        ctx.save_for_backward(feat, tmp)
+        return feat, tmp
+
+    @staticmethod
+    def backward(ctx, g_feat, g_tmp):
+        table, where, k, _, _ = ctx.meta
+        feat, tmp = ctx.saved_tensors
+        trainable = ctx.trainable
+        if g_feat is None:
+            g_feat = torch.zeros_like(feat)
+        bufs = [_grad_buffer(p) if ctx.needs_input_grad[3 + i] else None for i, p in enumerate(trainable)]
+        fused = all(b is not None for b, need in zip(bufs, ctx.needs_input_grad[3:]) if need) and all(ctx.needs_input_grad[3:])
+        grads = [None] * len(table)
+        if fused:       # the kernels add into the parameters' existing .grad buffers; autograd gets None
+            for pos, b in zip(where, bufs):
+                grads[pos] = b
+            out = [None] * len(trainable)
+        else:           # one zeroed flat buffer; autograd accumulates its views into .grad
+            sizes = [p.numel() for p in trainable]
+            flat = torch.zeros(sum(sizes), dtype=torch.float32, device=feat.device)
+            out, off = [], 0
+            for pos, p, n in zip(where, trainable, sizes):
+                grads[pos] = flat[off:off + n]
+                out.append(flat[off:off + n].view_as(p))
+                off += n
+            out = [g if need else None for g, need in zip(out, ctx.needs_input_grad[3:])]
+        ops.uni3fc_train_backward(table, grads, ctx.dino, feat, tmp, ctx.arena, g_feat.contiguous(), None if g_tmp is None else g_tmp.contiguous(), k)
+        ctx.arena = None
+        return (None, None, None) + tuple(out)
+
+
+def uni3fc_train(meta, x, dino, trainable):
+    return _Uni3FCTrain.apply(meta, x, dino, *trainable)
+
+
 def sa_attention_pm(xt, w_qk, w_v, b_v):
     """SA_Layer's x_r on point-major xt (B,N,64) with autograd: ONE projection GEMM (q/k and v stacked), the fused attention
     core both ways."""

@@ -862,6 +862,86 @@ def uni3fc_forward(table, x, dino, k=40):
     return feat, tmp
 
 
+U3_TRAIN_NPARAMS = 167   # DVM_U3_TRAIN_NPARAMS (include/dvm.h)
+
+
+def _ptr_table(tensors, n):
+    if len(tensors) != n:
+        raise DvmError("pointer table: %d tensors, expected %d" % (len(tensors), n))
+    return (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+def _ensure_pair_ctx(dev):
+    ctx = (dev.index, _stream())
+    if ctx not in _pair_ctx:   # helper stream / events for this (device, stream): made once, outside the compute call
+        check(_lib.load().dvm_pair_init(_stream()), "dvm_pair_init")
+        _pair_ctx.add(ctx)
+
+
+def knn_tap():
+    """Test handle on the feature-space kNN layers.  tests/test_gpu_network.py replaces `ops.knn_neg` by a callable object with
+    the attributes `forced` (None, or per-layer index arrays (B,N,k) to use INSTEAD of our own sets: teacher forcing with the
+    reference's neighbours), `log` (list that receives our own sets, layer by layer) and `i` (cursor into `forced`).  The
+    layer-by-layer Python path goes through that object call by call; a native whole-network call has no Python between its
+    layers, so it hands the same object's `forced` entries to the library and appends the library's own sets to `log`
+    (dvm_uni3fc_train_fwd_f32's knn_forced / knn_log).  Returns the object, or None when knn_neg is the plain function."""
+    import inspect
+    fn = globals()["knn_neg"]
+    return None if inspect.isfunction(fn) else (fn if hasattr(fn, "log") and hasattr(fn, "forced") else None)
+
+
+def uni3fc_train_forward(params, x, dino, k, eps, momentum):
+    """LG-Net's training-mode forward in ONE native call (dvm_uni3fc_train_fwd_f32).  params: the U3_TRAIN_NPARAMS tensors of
+    include/dvm.h's table (raw parameters + BatchNorm running statistics, updated in place); x (B,3,N), dino (B,N,1152)
+    -> feat (B,N,128), tmp (B,N,64), arena (uint8 tensor holding what dvm_uni3fc_train_bwd_f32 needs)."""
+    _need_gpu(x, dino)
+    x, dino = _f(x), _f(dino)
+    B, _, N = x.shape
+    if tuple(dino.shape) != (B, N, 1152):
+        raise DvmError("uni3fc_train_forward: dino features %s, expected %s" % (tuple(dino.shape), (B, N, 1152)))
+    lib = _lib.load()
+    dev = x.device
+    feat = torch.empty(B, N, 128, dtype=torch.float32, device=dev)
+    tmp = torch.empty(B, N, 64, dtype=torch.float32, device=dev)
+    nb = lib.dvm_uni3fc_train_workspace_bytes(B, N, int(k))
+    arena = torch.empty(nb, dtype=torch.uint8, device=dev)
+    _ensure_pair_ctx(dev)
+    table = _ptr_table(params, U3_TRAIN_NPARAMS)
+    tap = knn_tap()
+    forced = logs = ftab = ltab = None
+    if tap is not None:
+        logs = [torch.empty(B, N, int(k), dtype=torch.int32, device=dev) for _ in range(7)]
+        ltab = ctypes.cast(_ptr_table(logs, 7), ctypes.c_void_p)
+        if tap.forced is not None:
+            import numpy as np
+            forced = [torch.from_numpy(np.ascontiguousarray(tap.forced[tap.i + l]).astype(np.int32)).to(dev) for l in range(7)]
+            if any(tuple(f.shape) != (B, N, int(k)) for f in forced):
+                raise DvmError("uni3fc_train_forward: forced neighbour sets must be (B, N, k)")
+            ftab = ctypes.cast(_ptr_table(forced, 7), ctypes.c_void_p)
+    check(lib.dvm_uni3fc_train_fwd_f32(_p(x), _p(dino), B, N, ctypes.cast(table, ctypes.c_void_p), U3_TRAIN_NPARAMS, int(k), float(eps),
+                                       float(momentum), ftab, ltab, _p(feat), _p(tmp), _p(arena), nb, _stream()), "dvm_uni3fc_train_fwd_f32")
+    if tap is not None:
+        tap.log.extend(logs)
+        if forced is not None:
+            tap.i += 7
+    return feat, tmp, arena
+
+
+def uni3fc_train_backward(params, grads, dino, feat, tmp, arena, g_feat, g_tmp, k):
+    """dvm_uni3fc_train_bwd_f32: ADDS the parameter gradients into `grads` (tensors aligned with `params`; None for the
+    running statistics)."""
+    _need_gpu(g_feat, dino)
+    B, N, _ = feat.shape
+    lib = _lib.load()
+    _ensure_pair_ctx(feat.device)
+    g_feat = _f(g_feat)
+    g_tmp = None if g_tmp is None else _f(g_tmp)
+    ptab, gtab = _ptr_table(params, U3_TRAIN_NPARAMS), _ptr_table(grads, U3_TRAIN_NPARAMS)
+    check(lib.dvm_uni3fc_train_bwd_f32(_p(g_feat), _p(g_tmp), _p(dino), _p(feat), _p(tmp), B, N, ctypes.cast(ptab, ctypes.c_void_p),
+                                       ctypes.cast(gtab, ctypes.c_void_p), U3_TRAIN_NPARAMS, int(k), _p(arena), arena.numel(), _stream()),
+          "dvm_uni3fc_train_bwd_f32")
+
+
 def pair_forward(wl, feat1, feat2, verts1, verts2, alpha, start1, start2, with_map=True, out=None):
     """Config-2 path for B pairs, BOTH directions in one call.
     Returns (out12, out21), each dict(warped, verts12, T12, losses[B,6])."""

@@ -446,6 +446,48 @@ class Uni3FC(nn.Module, _VisualProjection):
             return ops.uni3fc_weight_table([t.detach() for t in ts])
         return _folded(self, "native_table", [t for t in list(self.parameters()) + list(self.buffers())], build)
 
+    def _train_table(self):
+        """(tensors of dvm_uni3fc_train_fwd_f32's parameter table in include/dvm.h's order, positions of the trainable ones,
+        the trainable ones, BatchNorm modules whose batch counter a forward bumps)."""
+        convs = (self.conv, self.conv0, self.conv1, self.conv2, self.conv3, self.conv4, self.conv5, self.conv6)
+        sas = (self.sa1, self.sa2, self.sa3, self.sa4)
+        n2ps = (self.n2p_attention1, self.n2p_attention2, self.n2p_attention3, self.n2p_attention4, self.n2p_attention5,
+                self.n2p_attention6, self.n2p_attention7)
+        ts, bns = [], []
+
+        def bn(m):
+            bns.append(m)
+            return [m.weight, m.bias, m.running_mean, m.running_var]
+        for seq in convs:
+            ts += [seq[0].weight] + bn(seq[1])
+        for sa in sas:
+            ts += [sa.k_conv.weight, sa.v_conv.weight, sa.v_conv.bias, sa.trans_conv.weight, sa.trans_conv.bias] + bn(sa.after_norm)
+        for m in n2ps:
+            ts += [m.q_conv.weight, m.k_conv.weight, m.v_conv.weight] + bn(m.bn1) + [m.ff[0].weight, m.ff[2].weight] + bn(m.bn2)
+        where = [i for i, t in enumerate(ts) if isinstance(t, nn.Parameter)]
+        return ts, where, [ts[i] for i in where], bns
+
+    def _native_train_ok(self, x, dino_feat):
+        """The native training path takes plain data tensors (no gradient w.r.t. x / dino_feat), fp32 contiguous parameters and
+        one (eps, momentum) for all BatchNorms; anything else goes through the autograd path below."""
+        if os.environ.get("DVM_NATIVE_TRAIN", "1") != "1" or not x.is_cuda or getattr(self, "sync_minmax", False):
+            return False
+        if x.requires_grad or dino_feat.requires_grad or x.dtype != torch.float32 or dino_feat.dtype != torch.float32:
+            return False
+        ts, _, _, bns = self._train_table()
+        if any(t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda for t in ts):
+            return False
+        return len({(m.eps, m.momentum) for m in bns}) == 1 and bns[0].momentum is not None and all(m.track_running_stats for m in bns)
+
+    def _forward_train_native(self, x, dino_feat):
+        """Training forward + backward as ONE autograd node over dvm_uni3fc_train_{fwd,bwd}_f32 (csrc/dvm_uni3fc_train.hip): the
+        launches of _forward_train_pm and of its autograd graph without the ~1500 Python / autograd hops per call."""
+        ts, where, trainable, bns = self._train_table()
+        with torch.no_grad():
+            torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
+        meta = ([t.detach() for t in ts], where, self.k, bns[0].eps, bns[0].momentum)
+        return nn_ops.uni3fc_train(meta, x.contiguous(), dino_feat.contiguous(), trainable)
+
     def _forward_train_pm(self, x, dino_feat):
         """Autograd forward with activations kept point-major (B,N,C), the layout dino_feat arrives in and the kNN /
         attention cores work in: the convs are dvm_linear_f32 GEMMs forward, dvm_linear_f32 / dvm_linear_wgrad_f32
@@ -496,6 +538,8 @@ class Uni3FC(nn.Module, _VisualProjection):
             return self._forward_infer(x, dino_feat)
         if self.training and os.environ.get("DVM_TRAIN_LAYOUT", "pm") == "pm" and \
                 all(type(m) is nn.BatchNorm1d for m in self.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)):
+            if self._native_train_ok(x, dino_feat):
+                return self._forward_train_native(x, dino_feat)
             return self._forward_train_pm(x, dino_feat.contiguous())
         # channel-major fallback (eval-mode fine-tuning, SyncBatchNorm): the reference's own layout.
         # conv -> BatchNorm -> LeakyReLU blocks: the GEMM, then ONE fused statistics + normalise + activation pass

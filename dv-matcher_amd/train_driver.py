@@ -262,8 +262,11 @@ def main(argv=None):
         net.sync_minmax = True
     params = list(net.parameters()) + list(dfm.parameters())
     use_graph = bool(args.graph) and world == 1 and args.epochs <= 0
+    # one fused multi-tensor Adam launch per step (same update as the reference's torch.optim.Adam, train.py:44-45; the default
+    # foreach form costs the host ~1.5 ms per step in ~10 launches over 151 tensors); DVM_FUSED_ADAM=0 = the foreach form
+    fused_adam = os.environ.get("DVM_FUSED_ADAM", "1") == "1" and not use_graph
     opt = torch.optim.Adam(params, lr=float(cfg["optimizer"]["lr"]), betas=(cfg["optimizer"]["b1"], cfg["optimizer"]["b2"]),
-                           capturable=use_graph)
+                           **({"fused": True} if fused_adam else {"capturable": use_graph}))
     # world > 1: every p.grad is a view into one flat buffer (one all-reduce, no pack/unpack); a single rank has nothing to
     # exchange and lets autograd hand Adam its gradient tensors directly — unless the step is captured into a graph, whose
     # gradient tensors must keep their addresses.  (DVM_FLAT_GRADS=1 forces the flat buffer on a single rank: the fused

@@ -441,6 +441,39 @@ size_t dvm_uni3fc_fwd_workspace_bytes(int B, int N, int k);
 int dvm_uni3fc_fwd_f32(const float *xyz, const float *dino, int B, int N, const float *const *weights, int nweights, int k,
                        float *feat, float *tmp, void *ws, size_t ws_bytes, void *stream);
 
+/* ---- LG-Net, the TRAINING forward and backward in two calls (reference `Uni3FC.forward` in train mode under autograd,
+ * models/model.py:680-761 — conv blocks 506-529 with batch-statistics BatchNorm, N2PAttention[_DIM] 325-395, SA_Layer
+ * 97-123 — and the part of `loss.backward()`, train.py:110, that runs through it).  Same launches as
+ * dv-matcher_amd/models/model.py::Uni3FC._forward_train_pm and the autograd graph it records, enqueued natively.
+ * fwd: xyz [B][3][N], dino [B][N][1152] -> feat [B][N][128], tmp [B][N][64]; every activation the backward needs is
+ *      written into `arena` (dvm_uni3fc_train_workspace_bytes(B, N, k) bytes, caller-owned, must stay untouched until
+ *      the matching bwd); running_mean / running_var get PyTorch's momentum update (unbiased variance); the
+ *      num_batches_tracked counters are the caller's business.  knn_forced / knn_log (each NULL or 7 device pointers
+ *      [B][N][k] int32, entries may be NULL) are the parity tests' handles on the 7 feature-space kNN layers: the
+ *      library's own neighbour sets are copied to knn_log[l], and knn_forced[l], when given, is what the layer and
+ *      its backward then use (teacher forcing: the discrete sets of the reference, tests/test_gpu_network.py).
+ * bwd: g_feat [B][N][128], g_tmp [B][N][64] (may be NULL = zero), the forward's dino / feat / tmp and arena ->
+ *      parameter gradients ADDED into grads[i] (same indexing as params; entries of running statistics ignored, may
+ *      be NULL).  Inputs carry no gradient (the reference feeds data tensors).  Weight gradients are combined with
+ *      fp32 atomics over row chunks (dvm_linear_wgrad_f32); bias / BatchNorm gradients in a fixed order.
+ * With a context from dvm_pair_init(stream) the global (self-attention) chain runs on the helper stream in both passes.
+ * `params`: DVM_U3_TRAIN_NPARAMS device pointers, fp32, in this order:
+ *   8 conv blocks {W [Co][K], bn gamma, bn beta, running_mean, running_var}: conv, conv0 .. conv6            [0 .. 39]
+ *   4 SA layers sa1..sa4 {k_conv W [16][64] (tied with q_conv), v_conv W [64][64], v_conv bias, trans_conv W [64][64],
+ *     trans_conv bias, after_norm gamma, beta, running_mean, running_var}                                     [40 .. 75]
+ *   7 N2P blocks n2p_attention1..7 (C = 64 x 4, 128 x 3) {q_conv W [C][C], k_conv W, v_conv W, bn1 gamma, beta,
+ *     running_mean, running_var, ff[0] W [4C][C], ff[2] W [C][4C], bn2 gamma, beta, running_mean, running_var} [76 .. 166]
+ * (q / k / v weights — and their gradient buffers — that lie back to back in memory are used as one stacked [3C][C]
+ * matrix in place; otherwise a packed copy is made per call.) */
+#define DVM_U3_TRAIN_NPARAMS 167
+size_t dvm_uni3fc_train_workspace_bytes(int B, int N, int k);
+int dvm_uni3fc_train_fwd_f32(const float *xyz, const float *dino, int B, int N, const float *const *params, int nparams, int k,
+                             float eps, float momentum, const int32_t *const *knn_forced, int32_t *const *knn_log, float *feat,
+                             float *tmp, void *arena, size_t arena_bytes, void *stream);
+int dvm_uni3fc_train_bwd_f32(const float *g_feat, const float *g_tmp, const float *dino, const float *feat, const float *tmp,
+                             int B, int N, const float *const *params, float *const *grads, int nparams, int k, void *arena,
+                             size_t arena_bytes, void *stream);
+
 /* dvm_pair_fwd_f32 can run its coordinate-only chain (FPS, graph, xyz kNN: latency-bound) on helper streams, forked
  * from and joined back into `stream` by events, next to the feature-only soft-correspondence chain.  The helper streams
  * and events are NOT created by the compute call: dvm_pair_init(stream) makes them for (current device, `stream`) —
