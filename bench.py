@@ -355,6 +355,26 @@ def run_pair(args):
     alone_ms, alone_n = read_slot(0)
     lib.dvm_profile_disable()
     lib.dvm_pair_set_overlap(1)
+    # "graph build reported with and without caching".  The timed region above rebuilds both clouds' deformation graphs
+    # every step, as the reference does (models/loss.py:1325-1337); here the same steps reuse the graphs / grids / xyz kNN of a
+    # first call through the opt-in per-shape cache (dvm_pair_fwd_cached_f32: bit-identical outputs, checked below)
+    gcache = ops.GeometryCache()
+    ref12 = {k: v.clone() for k, v in out12.items()}
+    couts = ops.pair_forward(wl, f1, f2, v1, v2, ALPHA, s1, s2, with_map=True, cache=gcache, key="bench-batch")   # builds
+    for _ in range(max(1, args.warmup)):
+        couts = ops.pair_forward(wl, f1, f2, v1, v2, ALPHA, s1, s2, with_map=True, out=couts, cache=gcache, key="bench-batch")
+    torch.cuda.synchronize()
+    tc0 = time.perf_counter()
+    for _ in range(args.steps):
+        couts = ops.pair_forward(wl, f1, f2, v1, v2, ALPHA, s1, s2, with_map=True, out=couts, cache=gcache, key="bench-batch")
+    torch.cuda.synchronize()
+    dtc = time.perf_counter() - tc0
+    cached_same = all(torch.equal(couts[0][k], ref12[k]) for k in ref12)
+    if dist_on:
+        t = torch.tensor([dtc], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dtc = float(t.item())
+    del gcache
     local_dt = dt
     if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -398,6 +418,11 @@ def run_pair(args):
                        "alpha": ALPHA, "deformer_weights": "reference ckpt/dvmatcher_scape_r (fixture)", "fps_start": 0,
                        "parallelism": "pairs sharded over %d GPU(s), no collective" % world},
             "per_gpu": {"pairs_per_s": value / world, "rank0_ms_per_step": local_dt / args.steps * 1e3},
+            # the same steps with the per-shape graph cache on (opt-in; NOT `value`: the reference rebuilds the graphs per call)
+            "graph_cached": {"value": pairs_per_step * args.steps / dtc, "unit": "pairs/s", "ms_per_step": dtc / args.steps * 1e3,
+                             "hits": args.steps, "bit_identical_to_uncached": bool(cached_same),
+                             "what": "graphs (FPS nodes, rings, skinning), uniform grids and xyz kNN of both clouds reused from a first "
+                                     "call (dvm_pair_fwd_cached_f32); everything feature-dependent recomputed"},
             "process_group": (dist.get_backend() if dist_on else None),
             # The dominant kernel runs the N x M contraction on the 16-bit matrix pipe: 3 exact fp16 partial products
             # (2-way split of the scaled features, fp32 accumulate) per direction.  `achieved` / `peak` / `frac` price the

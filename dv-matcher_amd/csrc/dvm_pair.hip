@@ -264,12 +264,16 @@ DVM_EXPORT int dvm_pair_set_overlap(int on) {
     return prev;
 }
 
-DVM_EXPORT int dvm_pair_fwd_f32(const float *feat1, const float *feat2, const float *verts1, const float *verts2, int B, int N,
-                                int M, float neg_alpha, const int32_t *start1, const int32_t *start2, const float *conv_w,
-                                const float *conv_b, const float *W0, const float *b0, const float *W1, const float *b1,
-                                const float *W2, const float *b2, const float *W3, const float *b3, int with_map, float *warped12,
-                                float *verts12, int32_t *T12, float *losses12, float *warped21, float *verts21, int32_t *T21,
-                                float *losses21, void *ws, size_t ws_bytes, void *stream) {
+// reuse_geometry != 0: the coordinate-only products of an earlier call on the SAME workspace with the SAME coordinates and FPS
+// starts — both clouds' deformation graphs (nodes, rings, skinning), their uniform grids, the xyz kNN and the neighbours'
+// coordinates of the map term — are still in `ws` and are used as they are (the per-shape graph cache of SURVEY 8f-2 / 8d;
+// the reference rebuilds them on every call, models/loss.py:1325-1337); everything that depends on the features runs as always
+static int pair_fwd_impl(const float *feat1, const float *feat2, const float *verts1, const float *verts2, int B, int N, int M,
+                         float neg_alpha, const int32_t *start1, const int32_t *start2, const float *conv_w, const float *conv_b,
+                         const float *W0, const float *b0, const float *W1, const float *b1, const float *W2, const float *b2,
+                         const float *W3, const float *b3, int with_map, float *warped12, float *verts12, int32_t *T12, float *losses12,
+                         float *warped21, float *verts21, int32_t *T21, float *losses21, void *ws, size_t ws_bytes, void *stream,
+                         int reuse_geometry) {
     DVM_REQUIRE(feat1 && feat2 && verts1 && verts2 && start1 && start2, "dvm_pair_fwd_f32: null input pointer");
     DVM_REQUIRE(warped12 && verts12 && T12 && losses12 && warped21 && verts21 && T21 && losses21,
                 "dvm_pair_fwd_f32: null output pointer");
@@ -303,7 +307,9 @@ DVM_EXPORT int dvm_pair_fwd_f32(const float *feat1, const float *feat2, const fl
         (void)hipStreamWaitEvent(cx->side, cx->ev_fork, 0);
         s = cx->side;
     }
-    if (both) {
+    if (reuse_geometry) {
+        // graphs, grids and xyz kNN of both clouds are in the workspace already
+    } else if (both) {
         (void)hipMemcpyAsync(w.vcat, verts1, (size_t)B * N * 3 * sizeof(float), hipMemcpyDeviceToDevice, s);
         (void)hipMemcpyAsync(w.vcat + (size_t)B * N * 3, verts2, (size_t)B * N * 3 * sizeof(float), hipMemcpyDeviceToDevice, s);
         (void)hipMemcpyAsync(w.startcat, start1, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
@@ -331,7 +337,7 @@ DVM_EXPORT int dvm_pair_fwd_f32(const float *feat1, const float *feat2, const fl
     // gathers run next to the ALU-bound sweep instead of after it
     launch_pool_all(feat1, w.idxk[0], B, N, 10, conv_w, conv_b, w.gall[0], s, w.gv[0].ids);
     launch_pool_all(feat2, w.idxk[1], B, M, 10, conv_w, conv_b, w.gall[1], s, w.gv[1].ids);
-    if (with_map) {
+    if (with_map && !reuse_geometry) {
         launch_gather_nbr_xyz(verts2, w.idxk[1], B, M, 10, w.nbrxyz[1], s);
         launch_gather_nbr_xyz(verts1, w.idxk[0], B, N, 10, w.nbrxyz[0], s);
     }
@@ -395,4 +401,26 @@ DVM_EXPORT int dvm_pair_fwd_f32(const float *feat1, const float *feat2, const fl
     }
     DVM_CHECK_LAUNCH("pair_fwd");
     return DVM_OK;
+}
+
+DVM_EXPORT int dvm_pair_fwd_f32(const float *feat1, const float *feat2, const float *verts1, const float *verts2, int B, int N,
+                                int M, float neg_alpha, const int32_t *start1, const int32_t *start2, const float *conv_w,
+                                const float *conv_b, const float *W0, const float *b0, const float *W1, const float *b1,
+                                const float *W2, const float *b2, const float *W3, const float *b3, int with_map, float *warped12,
+                                float *verts12, int32_t *T12, float *losses12, float *warped21, float *verts21, int32_t *T21,
+                                float *losses21, void *ws, size_t ws_bytes, void *stream) {
+    return pair_fwd_impl(feat1, feat2, verts1, verts2, B, N, M, neg_alpha, start1, start2, conv_w, conv_b, W0, b0, W1, b1, W2, b2, W3, b3,
+                         with_map, warped12, verts12, T12, losses12, warped21, verts21, T21, losses21, ws, ws_bytes, stream, 0);
+}
+
+DVM_EXPORT int dvm_pair_fwd_cached_f32(const float *feat1, const float *feat2, const float *verts1, const float *verts2, int B, int N,
+                                       int M, float neg_alpha, const int32_t *start1, const int32_t *start2, const float *conv_w,
+                                       const float *conv_b, const float *W0, const float *b0, const float *W1, const float *b1,
+                                       const float *W2, const float *b2, const float *W3, const float *b3, int with_map,
+                                       float *warped12, float *verts12, int32_t *T12, float *losses12, float *warped21,
+                                       float *verts21, int32_t *T21, float *losses21, void *ws, size_t ws_bytes, int reuse_geometry,
+                                       void *stream) {
+    return pair_fwd_impl(feat1, feat2, verts1, verts2, B, N, M, neg_alpha, start1, start2, conv_w, conv_b, W0, b0, W1, b1, W2, b2, W3, b3,
+                         with_map, warped12, verts12, T12, losses12, warped21, verts21, T21, losses21, ws, ws_bytes, stream,
+                         reuse_geometry ? 1 : 0);
 }

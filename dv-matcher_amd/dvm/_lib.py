@@ -111,6 +111,8 @@ SIGNATURES = {
     "dvm_pair_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dvm_pair_fwd_f32": (c_int, [_P] * 4 + [c_int] * 3 + [c_float, _P, _P] + [_P] * 10 + [c_int] + [_P] * 8 +
                          [_P, c_size_t, _P]),
+    "dvm_pair_fwd_cached_f32": (c_int, [_P] * 4 + [c_int] * 3 + [c_float, _P, _P] + [_P] * 10 + [c_int] + [_P] * 8 +
+                                [_P, c_size_t, c_int, _P]),
 }
 
 

@@ -942,9 +942,40 @@ def uni3fc_train_backward(params, grads, dino, feat, tmp, arena, g_feat, g_tmp, 
           "dvm_uni3fc_train_bwd_f32")
 
 
-def pair_forward(wl, feat1, feat2, verts1, verts2, alpha, start1, start2, with_map=True, out=None):
+class GeometryCache:
+    """Opt-in per-shape graph cache of the pair forward (the reference rebuilds both deformation graphs on every
+    call, models/loss.py:1325-1337).  An entry is a DEDICATED workspace in which a dvm_pair_fwd_cached_f32 call left the
+    coordinate-only products of a batch (graphs, grids, xyz kNN); it is keyed by whatever identifies the batch's geometry —
+    the caller's shape ids AND FPS start indices (a different start gives a different graph) — plus the sizes.  A hit skips the
+    geometry chain; outputs are bit-identical.  Least-recently-used entries are dropped beyond `max_entries`."""
+
+    def __init__(self, max_entries=16):
+        import collections
+        self.max_entries, self.entries, self.hits, self.misses = max_entries, collections.OrderedDict(), 0, 0
+
+    def lookup(self, key, nbytes, device):
+        """-> (workspace, reuse flag)"""
+        ent = self.entries.get(key)
+        if ent is not None and ent.numel() >= nbytes and ent.device == device:
+            self.entries.move_to_end(key)
+            self.hits += 1
+            return ent, 1
+        ent = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        self.entries[key] = ent
+        self.misses += 1
+        while len(self.entries) > self.max_entries:
+            self.entries.popitem(last=False)
+        return ent, 0
+
+    def clear(self):
+        self.entries.clear()
+
+
+def pair_forward(wl, feat1, feat2, verts1, verts2, alpha, start1, start2, with_map=True, out=None, cache=None, key=None):
     """Config-2 path for B pairs, BOTH directions in one call.
-    Returns (out12, out21), each dict(warped, verts12, T12, losses[B,6])."""
+    Returns (out12, out21), each dict(warped, verts12, T12, losses[B,6]).
+    cache / key: a GeometryCache and the hashable identity of this batch's geometry (shape ids + FPS starts): on a hit the
+    graphs / grids / xyz kNN of the cached call are reused (same bits, no geometry chain)."""
     _need_gpu(feat1, feat2, verts1, verts2, start1, start2, *wl)
     feat1, feat2, verts1, verts2 = _f(feat1), _f(feat2), _f(verts1), _f(verts2)
     start1, start2 = _i(start1), _i(start2)
@@ -960,11 +991,20 @@ def pair_forward(wl, feat1, feat2, verts1, verts2, alpha, start1, start2, with_m
                     losses=torch.empty(B, 6, dtype=torch.float32, device=dev))
     o12, o21 = out if out is not None else (alloc(N), alloc(M))
     nb = lib.dvm_pair_workspace_bytes(B, N, M)
-    ws = workspace(nb, dev, "pair2")
     ctx = (dev.index, _stream())
     if ctx not in _pair_ctx:   # helper streams / events for this (device, stream): made once, outside the compute call
         check(lib.dvm_pair_init(_stream()), "dvm_pair_init")
         _pair_ctx.add(ctx)
+    if cache is not None:
+        if key is None:
+            raise DvmError("pair_forward: a GeometryCache needs the key of this batch's geometry (shape ids + FPS starts)")
+        ws, reuse = cache.lookup((key, B, N, M, bool(with_map), ctx), nb, dev)
+        check(lib.dvm_pair_fwd_cached_f32(_p(feat1), _p(feat2), _p(verts1), _p(verts2), B, N, M, neg_alpha_f32(alpha), _p(start1),
+                                          _p(start2), *[_p(w) for w in wl], int(with_map), _p(o12["warped"]), _p(o12["verts12"]),
+                                          _p(o12["T12"]), _p(o12["losses"]), _p(o21["warped"]), _p(o21["verts12"]), _p(o21["T12"]),
+                                          _p(o21["losses"]), _p(ws), nb, reuse, _stream()), "dvm_pair_fwd_cached_f32")
+        return o12, o21
+    ws = workspace(nb, dev, "pair2")
     check(lib.dvm_pair_fwd_f32(_p(feat1), _p(feat2), _p(verts1), _p(verts2), B, N, M, neg_alpha_f32(alpha), _p(start1),
                                _p(start2), *[_p(w) for w in wl], int(with_map), _p(o12["warped"]), _p(o12["verts12"]),
                                _p(o12["T12"]), _p(o12["losses"]), _p(o21["warped"]), _p(o21["verts12"]), _p(o21["T12"]),

@@ -110,8 +110,11 @@ class GraphDeformLoss_Neural(nn.Module):
     partial_variant = False
 
     def __init__(self, k_deform=10, w_dist=1, w_map=1, k_dist=1000, N_dist=1000, partial=False, w_deform=1, w_img=1,
-                 w_rank=1, w_self_rec=1, w_cd=1, w_arap=1, save_name=None, dump=False):
+                 w_rank=1, w_self_rec=1, w_cd=1, w_arap=1, save_name=None, dump=False, graph_cache=None):
         super().__init__()
+        # opt-in per-shape graph cache: a dict filled by geometry(..., shape_ids=...); the reference rebuilds
+        # every graph on every call (models/loss.py:1325-1337).  Entries are keyed by (shape id, FPS start, point count)
+        self.graph_cache = graph_cache
         self.device = 'cuda:0'
         self.w_dist, self.w_map, self.w_deform, self.w_self_rec = w_dist, w_map, w_deform, w_self_rec
         self.w_cd, self.w_arap, self.w_rank, self.w_img = w_cd, w_arap, w_rank, w_img
@@ -210,7 +213,27 @@ class GraphDeformLoss_Neural(nn.Module):
             save_off_file(path + '/' + name + n + '.off', t.detach().cpu().numpy())
 
     # ---- forward ------------------------------------------------------------------------------
-    def geometry(self, verts1, verts2, fps_starts=None):
+    def _cached_side(self, verts, starts, ids):
+        """Graph + xyz kNN of a batch of shapes assembled from per-shape cache entries; shapes not yet seen are built in ONE
+        batched call and stored.  Bit-identical to building the batch (every kernel of the build works per shape)."""
+        B, N, _ = verts.shape
+        keys = [(ids[b], int(starts[b]), N) for b in range(B)]
+        miss = [b for b in range(B) if keys[b] not in self.graph_cache]
+        if miss:
+            sel = torch.as_tensor(miss, device=verts.device)
+            sub = verts.index_select(0, sel).contiguous()
+            st = torch.as_tensor([int(starts[b]) for b in miss], dtype=torch.int32)
+            g = ops.dg_build(sub, _host_draw_to_device(st, verts.device))
+            idx = ops.knn_cdist(sub, sub, self.k_deform)
+            for j, b in enumerate(miss):
+                ent = {name: t[j].clone() for name, t in g.items()}
+                ent["_idx"] = idx[j].clone()
+                self.graph_cache[keys[b]] = ent
+        ents = [self.graph_cache[k] for k in keys]
+        g = {name: torch.stack([e[name] for e in ents]) for name in ents[0] if name != "_idx"}
+        return g, torch.stack([e["_idx"] for e in ents])
+
+    def geometry(self, verts1, verts2, fps_starts=None, shape_ids=None):
         """The part of the criterion that depends on the COORDINATES only — both shapes' deformation graphs (FPS nodes, node
         rings, skinning) and their xyz kNN — as (g1, g2, idx11, idx22).  forward() calls it itself; a driver may call it
         earlier, on another stream, while the network is still computing the features (FPS is a chain of N/2 dependent
@@ -220,6 +243,16 @@ class GraphDeformLoss_Neural(nn.Module):
         M = verts2.shape[1]
         s1, s2 = fps_starts if fps_starts is not None else (None, None)
         k = self.k_deform
+        if self.graph_cache is not None and shape_ids is not None and not self.dump:
+            # the cache needs the start index of every shape on the host: drawn here in the reference's order when not given
+            if s1 is None:
+                s1 = torch.cat([torch.randint(0, N, (1,), dtype=torch.long) for _ in range(B)])
+            if s2 is None:
+                s2 = torch.cat([torch.randint(0, M, (1,), dtype=torch.long) for _ in range(B)])
+            if not any(torch.is_tensor(t) and t.is_cuda for t in (s1, s2)):
+                g1, idx11 = self._cached_side(verts1, list(torch.as_tensor(s1).reshape(-1).tolist()), list(shape_ids[0]))
+                g2, idx22 = self._cached_side(verts2, list(torch.as_tensor(s2).reshape(-1).tolist()), list(shape_ids[1]))
+                return g1, g2, idx11, idx22
         if verts1.shape == verts2.shape and not self.dump:
             # both shapes' graphs and xyz-kNN in ONE batched call each (FPS is a sequential 1-workgroup-per-shape
             # kernel: 2B shapes cost what B do); the start indices are drawn in the reference's order
@@ -239,10 +272,12 @@ class GraphDeformLoss_Neural(nn.Module):
             idx11, idx22 = ops.knn_cdist(verts1, verts1, k), ops.knn_cdist(verts2, verts2, k)
         return g1, g2, idx11, idx22
 
-    def forward(self, feat1, feat2, dist1, dist2, verts1, verts2, alpha_i, deformer, fps_starts=None, anchors=None, geometry=None):
+    def forward(self, feat1, feat2, dist1, dist2, verts1, verts2, alpha_i, deformer, fps_starts=None, anchors=None, geometry=None,
+                shape_ids=None):
         """-> (loss, dist_loss, deform_loss, map_loss, self_rec_loss), like the reference.
         fps_starts=(s1 (B,), s2 (B,)) and anchors=(a1, a2) pin the draws the reference makes at random; geometry = what
-        self.geometry(verts1, verts2, fps_starts) returned, when the caller made it ahead of time."""
+        self.geometry(verts1, verts2, fps_starts) returned, when the caller made it ahead of time; shape_ids = (ids of the B
+        source shapes, ids of the B target shapes) lets a criterion built with graph_cache={} reuse per-shape graphs."""
         loss = 0
         self._sum_part = self._mean_part = 0
         B, N, _ = verts1.shape
@@ -260,7 +295,7 @@ class GraphDeformLoss_Neural(nn.Module):
             loss = loss + self.dist_loss
             self._sum_part = self._sum_part + self.dist_loss
         if self.w_deform > 0 or not self.partial_variant:
-            g1, g2, idx11, idx22 = geometry if geometry is not None else self.geometry(verts1, verts2, fps_starts)
+            g1, g2, idx11, idx22 = geometry if geometry is not None else self.geometry(verts1, verts2, fps_starts, shape_ids)
             m12, c12, a12, s12, ex12 = direction(feat1, feat2, verts1, verts2, alpha_i, g1, deformer, idx11, idx22)
             n12 = str(random.randint(0, 10))
             m21, c21, a21, s21, ex21 = direction(feat2, feat1, verts2, verts1, alpha_i, g2, deformer, idx22, idx11)

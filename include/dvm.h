@@ -420,6 +420,20 @@ int dvm_pair_fwd_f32(const float *feat1, const float *feat2, const float *verts1
                      float *verts12, int32_t *T12, float *losses12, float *warped21, float *verts21, int32_t *T21,
                      float *losses21, void *ws, size_t ws_bytes, void *stream);
 
+/* dvm_pair_fwd_f32 with the per-shape graph cache of SURVEY 8f-2: the coordinate-only products of a call — both clouds'
+ * deformation graphs (FPS nodes, node rings, skinning weights: lib/deformation_graph_point.py:177-201 via
+ * models/loss.py:1325-1337), their uniform grids, the xyz kNN (models/loss.py:97-101) and the neighbour coordinates of the map
+ * term — stay in the caller's workspace.  reuse_geometry = 0 builds them (identical to dvm_pair_fwd_f32); reuse_geometry != 0
+ * uses what an earlier call left in THIS workspace: valid iff that call had the same B, N, M, coordinates and FPS starts and
+ * nothing else wrote the workspace since (the caller keeps one workspace per cache key).  Outputs are bit-identical to the
+ * uncached call.  The reference rebuilds the graphs on every call; the cache is the caller's opt-in. */
+int dvm_pair_fwd_cached_f32(const float *feat1, const float *feat2, const float *verts1, const float *verts2, int B, int N,
+                            int M, float neg_alpha, const int32_t *start1, const int32_t *start2, const float *conv_w,
+                            const float *conv_b, const float *W0, const float *b0, const float *W1, const float *b1,
+                            const float *W2, const float *b2, const float *W3, const float *b3, int with_map, float *warped12,
+                            float *verts12, int32_t *T12, float *losses12, float *warped21, float *verts21, int32_t *T21,
+                            float *losses21, void *ws, size_t ws_bytes, int reuse_geometry, void *stream);
+
 /* ---- LG-Net, the whole eval-mode forward in one call (reference models/model.py:680-761 `Uni3FC.forward` with
  * torch.no_grad() / model.eval(); layers 506-529, N2P blocks 325-395, SA_Layer 97-123).  xyz [B][3][N] coordinates, dino
  * [B][N][1152] per-point visual features -> feat [B][N][128], tmp [B][N][64] (the second return value of the reference's

@@ -349,3 +349,30 @@ def test_geodesic_eval_uses_the_exact_map(ops):
     To, _ = O.argmin_exact(noisy, phi)
     assert np.array_equal(T, To)
     assert eg.mean_geodesic_error(noisy, phi, lm, lm, M) == float(eg.geodesic_errors(To, lm, lm, M).mean())
+
+
+def test_criterion_graph_cache_equals_rebuild(golden):
+    """The criterion's opt-in per-shape graph cache (GraphDeformLoss_Neural(graph_cache={}), forward(..., shape_ids=...)):
+    batches assembled from cached per-shape graphs give the 5-tuple of the criterion that rebuilds them
+    (models/loss.py:1325-1337), bit for bit, across batches that share some shapes; entries are per (shape, FPS start)."""
+    import models.loss as ml
+    import models.model as mm
+    w = golden("deformer_scape_r_weights")
+    d = mm.Deformer(10)
+    d.load_state_dict({k.replace("__", "."): torch.from_numpy(v) for k, v in w.items()})
+    d = d.cuda().eval()
+    kw = dict(k_deform=10, w_dist=0.02, w_map=0.005, k_dist=40, N_dist=60, partial=False, w_deform=0.5, w_img=0, w_rank=0,
+              w_self_rec=0.5, w_cd=0.1, w_arap=0.01, save_name="t")
+    plain, cached = ml.GraphDeformLoss_Neural(**kw), ml.GraphDeformLoss_Neural(graph_cache={}, **kw)
+    g = torch.Generator().manual_seed(21)
+    shapes = torch.rand(5, 300, 3, generator=g).cuda()                     # a "dataset" of 5 shapes
+    feats = (0.3 * torch.relu(torch.randn(5, 300, 128, generator=g))).cuda()
+    anchors = (list(range(0, 120, 2)), list(range(1, 121, 2)))
+    for ids1, ids2 in (([0, 1], [2, 3]), ([1, 4], [0, 2]), ([0, 1], [2, 3])):
+        v1, v2, f1, f2 = shapes[ids1], shapes[ids2], feats[ids1], feats[ids2]
+        starts = (torch.tensor([7 * i % 300 for i in ids1]), torch.tensor([11 * i % 300 for i in ids2]))
+        with torch.no_grad():
+            a = plain(f1, f2, torch.cdist(v1, v1), torch.cdist(v2, v2), v1, v2, 50.0, d, fps_starts=starts, anchors=anchors)
+            b = cached(f1, f2, torch.cdist(v1, v1), torch.cdist(v2, v2), v1, v2, 50.0, d, fps_starts=starts, anchors=anchors, shape_ids=(ids1, ids2))
+        assert [float(x) for x in a] == [float(x) for x in b]
+    assert len(cached.graph_cache) == 5            # (shape, start): (0,0) (1,7) (2,22) (3,33) (4,28); every other lookup was a hit

@@ -684,3 +684,36 @@ def test_partial_criterion_contract_size_vs_oracle(ops, golden):
                  float(TR.dist_loss_term(f2.double(), dist2.double(), torch.tensor(anchors[1]), 300).sum()))
     want = [dl + deform + self_rec, dl, deform, 0.0, self_rec]
     np.testing.assert_allclose(got, want, rtol=2e-4, atol=1e-12)
+
+
+def test_pair_forward_graph_cache_is_bit_identical(ops, golden):
+    """SURVEY 8f-2 / 8d, the opt-in per-shape graph cache: a hit (dvm_pair_fwd_cached_f32 with reuse_geometry = 1 on the
+    workspace of an earlier call with the same coordinates and FPS starts) gives the bits of the uncached call for NEW
+    features; another key, other starts or other sizes miss and rebuild; N == M and N != M layouts."""
+    w = golden("deformer_scape_r_weights")
+    wl = ops.deformer_weight_list(w, "cuda")
+    for B, N, M in ((3, 512, 512), (2, 330, 170)):
+        f1, f2, v1, v2, start = _pair_inputs(B, N, M, 9 + N)
+        g = torch.Generator().manual_seed(N)
+        f1b, f2b = torch.randn(B, N, 128, generator=g), torch.randn(B, M, 128, generator=g)
+        d = [t.cuda() for t in (v1, v2)]
+        s1, s2 = start.cuda(), (start % M).int().cuda()
+        cache = ops.GeometryCache()
+        first = ops.pair_forward(wl, f1.cuda(), f2.cuda(), *d, 60.0, s1, s2, cache=cache, key=("a", N))
+        plain1 = ops.pair_forward(wl, f1.cuda(), f2.cuda(), *d, 60.0, s1, s2)
+        hit = ops.pair_forward(wl, f1b.cuda(), f2b.cuda(), *d, 60.0, s1, s2, cache=cache, key=("a", N))      # new features, cached geometry
+        plain2 = ops.pair_forward(wl, f1b.cuda(), f2b.cuda(), *d, 60.0, s1, s2)
+        assert (cache.hits, cache.misses) == (1, 1)
+        for got, want in ((first, plain1), (hit, plain2)):
+            for a, b in zip(got, want):
+                for k in a:
+                    assert torch.equal(a[k], b[k]), (B, N, M, k)
+        # other starts under another key: a miss, and the result is that of the uncached call with those starts
+        s1b = ((start + 5) % N).int().cuda()
+        other = ops.pair_forward(wl, f1.cuda(), f2.cuda(), *d, 60.0, s1b, s2, cache=cache, key=("b", N))
+        plain3 = ops.pair_forward(wl, f1.cuda(), f2.cuda(), *d, 60.0, s1b, s2)
+        assert cache.misses == 2
+        for a, b in zip(other, plain3):
+            for k in a:
+                assert torch.equal(a[k], b[k]), k
+        assert not torch.equal(other[0]["warped"], first[0]["warped"])
