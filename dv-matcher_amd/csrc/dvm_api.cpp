@@ -21,6 +21,22 @@ DVM_EXPORT int dvm_device_count(void) {
     return n;
 }
 
+// ---------------------------------------------------------------- deterministic gradient sums
+// LG-Net's backward combines partial sums of different workgroups with fp32 atomics in three places (row chunks of the weight
+// gradient, the split inner loop of the SA backward, the order of a point's in-edges in the N2P gather): fastest, but the
+// summation order — hence the low bits of the gradients — changes from run to run.  dvm_set_deterministic(1) (or
+// DVM_DETERMINISTIC=1) fixes the order in all three: per-chunk partial tiles added in chunk order, no split, in-edge lists sorted.
+#include <atomic>
+#include <stdlib.h>
+namespace dvm {
+static std::atomic<int> g_deterministic{[] {
+    const char *e = getenv("DVM_DETERMINISTIC");
+    return (e && atoi(e) != 0) ? 1 : 0;
+}()};
+bool deterministic() { return g_deterministic.load(std::memory_order_relaxed) != 0; }
+}  // namespace dvm
+DVM_EXPORT int dvm_set_deterministic(int on) { return dvm::g_deterministic.exchange(on ? 1 : 0); }
+
 // ---------------------------------------------------------------- per-device kernel attributes
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device's copy of a kernel: it has to be made
 // per (device, kernel), not once per process, and it has to GROW when a later launch of the same kernel needs more

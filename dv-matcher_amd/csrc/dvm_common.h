@@ -17,6 +17,7 @@ namespace dvm {
 void set_error(const char *fmt, ...);
 void prof_begin(hipStream_t s, int id = 0);  // dvm_api.cpp: optional event bracket around a launch (slot DVM_PROF_*)
 void prof_end(hipStream_t s, int id = 0);
+bool deterministic();   // dvm_api.cpp: dvm_set_deterministic / DVM_DETERMINISTIC — gradient sums in a fixed order (no float atomics between workgroups)
 void prof_note(int id, const char *name);   // which kernel(s) the slot's bracket enclosed (reported by dvm_profile_kernel_name)
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (current device, kernel) — dvm_api.cpp
 void ensure_dyn_lds(const void *kernel, int bytes);

@@ -553,7 +553,10 @@ void launch_linear(const float *x, const float *w, int B, int N, int K, int Co, 
 // from x.  (rocBLAS runs this shape — reduction length 16384, outputs 64..1152 wide, K-strided operands — at ~1 TFLOP/s.)
 // A workgroup = 4 waves = a 64 x 64 tile of dW over one chunk of rows; chunks are combined with fp32 atomics (dW zeroed
 // by the caller).  Gradient sums carry no ordering contract.
+// DET (dvm_set_deterministic): every row chunk writes its tile to its own slice of a scratch buffer and a second kernel adds
+// the slices to dW in chunk order — the same sums, one fixed order, bit-reproducible from run to run.
 constexpr int WG_ROWS = 32;   // rows staged per step
+template <bool DET>
 __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(const float *__restrict__ gy, const float *__restrict__ x, long R, int Co, int K,
                                                               long rchunk, float *__restrict__ dW) {
     __shared__ __attribute__((aligned(16))) float gs[2][WG_ROWS * 64], xs[2][WG_ROWS * 64];
@@ -632,8 +635,21 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(const float *__res
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int co = co0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (co < Co && k < K) atomicAdd(dW + (size_t)co * K + k, acc[r]);
+        if (co < Co && k < K) {
+            if (DET)
+                dW[((size_t)blockIdx.y * Co + co) * K + k] = acc[r];   // dW = the scratch: [chunk][Co][K]
+            else
+                atomicAdd(dW + (size_t)co * K + k, acc[r]);
+        }
     }
+}
+// dW[i] += part[0][i] + part[1][i] + ... in chunk order
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int chunks, long n, float *__restrict__ dW) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float t = part[i];
+    for (int c = 1; c < chunks; ++c) t += part[(size_t)c * n + i];
+    dW[i] += t;
 }
 
 }  // namespace dvm
@@ -681,20 +697,52 @@ DVM_EXPORT int dvm_linear_scaled_residual_f32(const float *x, const float *w, in
     return DVM_OK;
 }
 
-DVM_EXPORT int dvm_linear_wgrad_f32(const float *gy, const float *x, long R, int Co, int K, float *dW, void *stream) {
-    DVM_REQUIRE(gy && x && dW, "dvm_linear_wgrad_f32: null pointer");
-    DVM_REQUIRE(R >= 1 && Co >= 1 && K >= 1, "dvm_linear_wgrad_f32: empty input (R=%ld Co=%d K=%d)", R, Co, K);
+namespace dvm {
+static long wgrad_chunks(long R, int Co, int K, long &rchunk) {
     const int tiles = ((Co + 63) / 64) * ((K + 63) / 64);
     // row chunks until ~1024 workgroups, each at least 256 rows (measured at R = 16384: 64 chunks of 256 rows beat 256
     // chunks of 64 on the one-tile layers, 10.7 vs 13.6 us — four times the atomics — and 16 chunks beat 8 on the
     // 108-tile conv, 152 vs 172 us)
     long chunks = 1;
     while (tiles * chunks < 1024 && R / (chunks * 2) >= 256) chunks *= 2;
-    long rchunk = (R + chunks - 1) / chunks;
+    rchunk = (R + chunks - 1) / chunks;
     rchunk = (rchunk + WG_ROWS - 1) / WG_ROWS * WG_ROWS;
-    chunks = (R + rchunk - 1) / rchunk;
+    return (R + rchunk - 1) / rchunk;
+}
+}  // namespace dvm
+
+DVM_EXPORT size_t dvm_linear_wgrad_workspace_bytes(long R, int Co, int K) {
+    if (R < 1 || Co < 1 || K < 1) return 0;
+    long rchunk;
+    return align_up((size_t)wgrad_chunks(R, Co, K, rchunk) * Co * K * sizeof(float));
+}
+
+// ws == NULL or the deterministic mode off: row chunks combined with fp32 atomics; with a workspace AND dvm_set_deterministic(1):
+// per-chunk partial tiles added in chunk order
+DVM_EXPORT int dvm_linear_wgrad_ws_f32(const float *gy, const float *x, long R, int Co, int K, float *dW, void *ws, size_t ws_bytes, void *stream) {
+    DVM_REQUIRE(gy && x && dW, "dvm_linear_wgrad_f32: null pointer");
+    DVM_REQUIRE(R >= 1 && Co >= 1 && K >= 1, "dvm_linear_wgrad_f32: empty input (R=%ld Co=%d K=%d)", R, Co, K);
+    const int tiles = ((Co + 63) / 64) * ((K + 63) / 64);
+    long rchunk;
+    const long chunks = wgrad_chunks(R, Co, K, rchunk);
     DVM_REQUIRE(chunks <= 65535, "dvm_linear_wgrad_f32: too many row chunks");
-    hipLaunchKernelGGL(linear_wgrad_kernel, dim3((unsigned)tiles, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, gy, x, R, Co, K, rchunk, dW);
+    hipStream_t s = (hipStream_t)stream;
+    if (ws && deterministic()) {
+        const size_t need = (size_t)chunks * Co * K * sizeof(float);
+        if (ws_bytes < need) {
+            set_error("dvm_linear_wgrad_ws_f32: workspace too small (%zu < %zu)", ws_bytes, need);
+            return DVM_ENOSPACE;
+        }
+        hipLaunchKernelGGL(linear_wgrad_kernel<true>, dim3((unsigned)tiles, (unsigned)chunks), dim3(256), 0, s, gy, x, R, Co, K, rchunk, (float *)ws);
+        const long n = (long)Co * K;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float *)ws, (int)chunks, n, dW);
+    } else {
+        hipLaunchKernelGGL(linear_wgrad_kernel<false>, dim3((unsigned)tiles, (unsigned)chunks), dim3(256), 0, s, gy, x, R, Co, K, rchunk, dW);
+    }
     DVM_CHECK_LAUNCH("linear_wgrad");
     return DVM_OK;
+}
+
+DVM_EXPORT int dvm_linear_wgrad_f32(const float *gy, const float *x, long R, int Co, int K, float *dW, void *stream) {
+    return dvm_linear_wgrad_ws_f32(gy, x, R, Co, K, dW, nullptr, 0, stream);
 }

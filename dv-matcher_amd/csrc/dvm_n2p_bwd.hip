@@ -265,6 +265,69 @@ __global__ __launch_bounds__(1024) void csr_build_lds_kernel(const int32_t *__re
     }
 }
 
+// Deterministic mode (dvm_set_deterministic): the reversed lists in ASCENDING EDGE ORDER without atomics between threads.
+// The edges of a cloud are cut into DET_CHUNKS contiguous chunks: (1) a histogram of targets per chunk (LDS counters, integer
+// atomics inside one workgroup: order-free), (2) per target an exclusive scan over the chunks on top of the exclusive scan
+// over the targets (= offs), (3) every chunk placed by ONE thread walking its edges in order from those bases.
+constexpr int DET_CHUNKS = 64;
+__global__ __launch_bounds__(256) void csr_det_hist_kernel(const int32_t *__restrict__ idx, int N, int K, int32_t *__restrict__ hist) {
+    extern __shared__ int csr_lds[];   // cnt[N]
+    const int b = blockIdx.y, ch = blockIdx.x;
+    const int E = N * K, per = (E + DET_CHUNKS - 1) / DET_CHUNKS, e0 = ch * per, e1 = min(E, e0 + per);
+    for (int i = threadIdx.x; i < N; i += blockDim.x) csr_lds[i] = 0;
+    __syncthreads();
+    const int32_t *ib = idx + (size_t)b * E;
+    for (int e = e0 + threadIdx.x; e < e1; e += blockDim.x) atomicAdd(&csr_lds[ib[e]], 1);
+    __syncthreads();
+    int32_t *h = hist + ((size_t)b * DET_CHUNKS + ch) * N;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) h[i] = csr_lds[i];
+}
+// hist[b][ch][t] -> base position of chunk ch's first edge into target t; offs[b][0..N]
+__global__ __launch_bounds__(1024) void csr_det_scan_kernel(int32_t *__restrict__ hist, int N, int32_t *__restrict__ offs) {
+    __shared__ int part[1024];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int32_t *h = hist + (size_t)b * DET_CHUNKS * N;
+    const int per = (N + 1023) / 1024, lo = min(N, tid * per), hi = min(N, lo + per);
+    int s = 0;
+    for (int t = lo; t < hi; ++t)
+        for (int ch = 0; ch < DET_CHUNKS; ++ch) s += h[(size_t)ch * N + t];
+    part[tid] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - s;
+    int32_t *ob = offs + (size_t)b * (N + 1);
+    for (int t = lo; t < hi; ++t) {
+        ob[t] = run;
+        for (int ch = 0; ch < DET_CHUNKS; ++ch) {
+            const int v = h[(size_t)ch * N + t];
+            h[(size_t)ch * N + t] = run;
+            run += v;
+        }
+    }
+    if (tid == 1023) ob[N] = part[1023];
+}
+__global__ __launch_bounds__(256) void csr_det_fill_kernel(const int32_t *__restrict__ idx, int N, int K, const int32_t *__restrict__ hist,
+                                                           int2 *__restrict__ edges) {
+    extern __shared__ int csr_lds[];   // cursor[N]
+    const int b = blockIdx.y, ch = blockIdx.x;
+    const int E = N * K, per = (E + DET_CHUNKS - 1) / DET_CHUNKS, e0 = ch * per, e1 = min(E, e0 + per);
+    const int32_t *h = hist + ((size_t)b * DET_CHUNKS + ch) * N;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) csr_lds[i] = h[i];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const int32_t *ib = idx + (size_t)b * E;
+    int2 *eb = edges + (size_t)b * E;
+    for (int e = e0; e < e1; ++e) {
+        const int pos = csr_lds[ib[e]]++;
+        eb[pos] = make_int2(e, e / K);
+    }
+}
+
 template <int C>
 __global__ __launch_bounds__(256) void n2p_bwd_gather_kernel(const float *__restrict__ qkv, const float *__restrict__ attn,
                                                              const float *__restrict__ de_buf, const float *__restrict__ gout,
@@ -332,7 +395,8 @@ DVM_EXPORT int dvm_n2p_core_fwd_f32(const float *qkv, const int32_t *idx, int B,
 
 DVM_EXPORT size_t dvm_n2p_core_bwd_workspace_bytes(int B, int N, int K) {
     return align_up((size_t)B * N * K * NP_H * sizeof(float)) + align_up((size_t)B * (N + 1) * sizeof(int32_t)) +
-           align_up((size_t)B * N * sizeof(int32_t)) + align_up((size_t)B * N * K * sizeof(int2));
+           align_up((size_t)B * N * sizeof(int32_t)) + align_up((size_t)B * N * K * sizeof(int2)) +
+           align_up((size_t)B * DET_CHUNKS * N * sizeof(int32_t));   // (last: per-chunk histograms of the deterministic list build)
 }
 
 DVM_EXPORT int dvm_n2p_core_bwd_f32(const float *qkv, const int32_t *idx, const float *attn, const float *g_out, int B, int N, int C,
@@ -347,6 +411,7 @@ DVM_EXPORT int dvm_n2p_core_bwd_f32(const float *qkv, const int32_t *idx, const 
     int32_t *offs = ar.take<int32_t>((size_t)B * (N + 1));
     int32_t *cursor = ar.take<int32_t>((size_t)B * N);
     int2 *edges = ar.take<int2>((size_t)B * N * K);
+    int32_t *hist = ar.take<int32_t>((size_t)B * DET_CHUNKS * N);
     if (!ar.ok()) {
         set_error("dvm_n2p_core_bwd_f32: workspace too small (%zu < %zu)", ws_bytes, ar.off);
         return DVM_ENOSPACE;
@@ -355,7 +420,13 @@ DVM_EXPORT int dvm_n2p_core_bwd_f32(const float *qkv, const int32_t *idx, const 
     dim3 grid((N + 3) / 4, B), egrid((unsigned)(((long)N * K + 255) / 256), B);
     const size_t csr_lds = (size_t)(2 * N + 1) * sizeof(int);
     // (one workgroup per cloud: from 4 clouds on; fewer, larger clouds keep the chip busier with the three-kernel form)
-    if (B >= 4 && csr_lds <= 96 * 1024 && (long)N * K < (1L << 31)) {
+    if (deterministic() && (size_t)N * sizeof(int) <= 96 * 1024) {
+        ensure_dyn_lds((const void *)csr_det_hist_kernel, (int)(N * sizeof(int)));
+        ensure_dyn_lds((const void *)csr_det_fill_kernel, (int)(N * sizeof(int)));
+        hipLaunchKernelGGL(csr_det_hist_kernel, dim3(DET_CHUNKS, B), dim3(256), (size_t)N * sizeof(int), s, idx, N, K, hist);
+        hipLaunchKernelGGL(csr_det_scan_kernel, dim3(B), dim3(1024), 0, s, hist, N, offs);
+        hipLaunchKernelGGL(csr_det_fill_kernel, dim3(DET_CHUNKS, B), dim3(256), (size_t)N * sizeof(int), s, idx, N, K, hist, edges);
+    } else if (B >= 4 && csr_lds <= 96 * 1024 && (long)N * K < (1L << 31)) {
         ensure_dyn_lds((const void *)csr_build_lds_kernel, (int)csr_lds);
         hipLaunchKernelGGL(csr_build_lds_kernel, dim3(B), dim3(1024), csr_lds, s, idx, N, K, offs, edges);
     } else {

@@ -280,7 +280,8 @@ DVM_EXPORT int dvm_sa_attention_bwd_f32(const float *p, const float *v, const fl
     SaBwdArgs a{p, v, g_xr, stats, cinv, t, u, u, d_v, d_p, N, 1};
     const int ot = (N + SB_ROWS - 1) / SB_ROWS, ntiles = (N + 31) / 32;
     int split = 1;
-    while (B * ot * split < 512 && split < 16 && ntiles / (2 * split) >= 4) split *= 2;
+    if (!deterministic())   // (the split's partial sums meet in fp32 atomics: order not fixed)
+        while (B * ot * split < 512 && split < 16 && ntiles / (2 * split) >= 4) split *= 2;
     a.split = split;
     dim3 grid(ot * split, B);
     hipLaunchKernelGGL(sa_bwd_rows_kernel, grid, dim3(256), 0, s, a);

@@ -56,8 +56,8 @@ struct SaSave {
     BnSave bn;
 };
 struct ChainScratch {   // per stream: library workspaces + gradient ping-pong buffers of the backward
-    void *bnws, *knnws, *saws, *sabws, *npbws;
-    size_t bn_bytes, knn_bytes, sa_bytes, sab_bytes, npb_bytes;
+    void *bnws, *knnws, *saws, *sabws, *npbws, *wgws;
+    size_t bn_bytes, knn_bytes, sa_bytes, sab_bytes, npb_bytes, wg_bytes;
     float *colpart;        // colsum_accum partials
     unsigned *counter;
     float *g768, *g512a, *g512b, *g256a, *g256b, *ga, *gb, *gc, *gd, *ge, *dqkv, *dh, *dp;   // gradient scratch (backward)
@@ -94,6 +94,16 @@ void carve_chain(Arena &ar, int B, int N, int K, ChainScratch &c, bool local) {
     c.sabws = c.sab_bytes ? (void *)ar.take<char>(c.sab_bytes) : nullptr;
     c.npb_bytes = local ? dvm_n2p_core_bwd_workspace_bytes(B, N, K) : 0;
     c.npbws = local ? (void *)ar.take<char>(c.npb_bytes) : nullptr;
+    c.wg_bytes = 0;   // per-chunk partial tiles of the weight gradient (deterministic mode): the largest layer of the chain
+    for (int i = 0; i < 8; ++i) {
+        const size_t nb = dvm_linear_wgrad_workspace_bytes((long)R, CONV_CO[i], CONV_K[i]);
+        c.wg_bytes = nb > c.wg_bytes ? nb : c.wg_bytes;
+    }
+    for (int C : {64, 128})
+        for (size_t nb : {dvm_linear_wgrad_workspace_bytes((long)R, 3 * C, C), dvm_linear_wgrad_workspace_bytes((long)R, 4 * C, C),
+                          dvm_linear_wgrad_workspace_bytes((long)R, C, 4 * C)})
+            c.wg_bytes = nb > c.wg_bytes ? nb : c.wg_bytes;
+    c.wgws = ar.take<char>(c.wg_bytes);
     c.colpart = ar.take<float>(1024 * 128);
     c.counter = ar.take<unsigned>(64);
     c.g768 = ar.take<float>(R * 768);
@@ -256,8 +266,8 @@ int bn_bwd(const Net &n, const float *dy, const float *y, const float *x, const 
 int dgrad(const Net &n, const float *dy, const float *W, int Co, int K, const float *res, float *dx, hipStream_t s) {
     return dvm_linear_f32(W, dy, 1, K, Co, (int)n.R, 1, nullptr, res, nullptr, nullptr, 1.f, dx, s);
 }
-int wgrad(const Net &n, const float *dy, const float *x, int Co, int K, float *dW, hipStream_t s) {
-    return dvm_linear_wgrad_f32(dy, x, n.R, Co, K, dW, s);
+int wgrad(const Net &n, const float *dy, const float *x, int Co, int K, float *dW, const ChainScratch &c, hipStream_t s) {
+    return dvm_linear_wgrad_ws_f32(dy, x, n.R, Co, K, dW, c.wgws, c.wg_bytes, s);   // (the workspace is used in deterministic mode only)
 }
 void colsum_accum(const Net &n, const float *g, int C, float *out, const ChainScratch &c, hipStream_t s) {
     long chunks = (n.R + 63) / 64;          // (C in {64, 128}: checked by the callers' layer table)
@@ -278,7 +288,7 @@ int conv_bwd(const Net &n, int i, const float *dy, const float *y, const float *
     float *const *g = n.G + T_CONV0 + i * TC_N;
     const ConvSave &cv = n.w.cv[i];
     T_TRY(bn_bwd(n, dy, y, cv.z, nullptr, p[TC_G], cv.bn, CONV_CO[i], 0.2f, dz, g[TC_G], g[TC_B], c, s));
-    T_TRY(wgrad(n, dz, x, CONV_CO[i], CONV_K[i], g[TC_W], s));
+    T_TRY(wgrad(n, dz, x, CONV_CO[i], CONV_K[i], g[TC_W], c, s));
     if (dx) T_TRY(dgrad(n, dz, p[TC_W], CONV_CO[i], CONV_K[i], dx_res, dx, s));
     return DVM_OK;
 }
@@ -291,15 +301,15 @@ int n2p_bwd(const Net &n, int l, const float *xin, const float *g_out, float *dx
     const int C = NP_C[l];
     float *dz = c.gc, *dx1 = c.gd, *din = c.ge;
     T_TRY(bn_bwd(n, g_out, sv.out, sv.x1, sv.ffo, p[TN_G2], sv.bn2, C, 1.f, dz, g[TN_G2], g[TN_B2], c, s));
-    T_TRY(wgrad(n, dz, sv.h, C, 4 * C, g[TN_FF2], s));
+    T_TRY(wgrad(n, dz, sv.h, C, 4 * C, g[TN_FF2], c, s));
     T_TRY(dgrad(n, dz, p[TN_FF2], C, 4 * C, nullptr, c.dh, s));
     hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks_for(n.R * C)), dim3(256), 0, s, (f32x4 *)c.dh, (const f32x4 *)sv.h, n.R * C, 0.2f);
-    T_TRY(wgrad(n, c.dh, sv.x1, 4 * C, C, g[TN_FF0], s));
+    T_TRY(wgrad(n, c.dh, sv.x1, 4 * C, C, g[TN_FF0], c, s));
     T_TRY(dgrad(n, c.dh, p[TN_FF0], 4 * C, C, dz, dx1, s));                       // d x1 = dh W0 + dz (the residual path)
     T_TRY(bn_bwd(n, dx1, sv.x1, xin, sv.att, p[TN_G1], sv.bn1, C, 1.f, din, g[TN_G1], g[TN_B1], c, s));
     T_TRY(dvm_n2p_core_bwd_f32(sv.qkv, sv.idx, sv.attn, din, n.B, n.N, C, n.K, 4, c.dqkv, c.npbws, c.npb_bytes, s));
     const bool st = stacked(p[TN_WQ], p[TN_WK], p[TN_WV], C), gst = stacked(g[TN_WQ], g[TN_WK], g[TN_WV], C);
-    T_TRY(wgrad(n, c.dqkv, xin, 3 * C, C, gst ? g[TN_WQ] : n.w.dwqkv[l], s));
+    T_TRY(wgrad(n, c.dqkv, xin, 3 * C, C, gst ? g[TN_WQ] : n.w.dwqkv[l], c, s));
     T_TRY(dgrad(n, c.dqkv, st ? p[TN_WQ] : n.w.wqkv[l], 3 * C, C, din, dx, s));   // d xin = dqkv Wqkv + din (the residual path)
     return DVM_OK;
 }
@@ -312,14 +322,14 @@ int sa_bwd(const Net &n, int l, const float *xin, const float *g_out, float *dx,
     const long n4 = n.R * 16;
     float *dt = c.gc, *dd = c.gd, *ssum = c.ge, *ngx = c.gc;   // dt is dead once dd, dWt, dbt are formed
     T_TRY(bn_bwd(n, g_out, sv.y, sv.t, nullptr, p[TS_G], sv.bn, 64, 0.f, dt, g[TS_G], g[TS_B], c, s));
-    T_TRY(wgrad(n, dt, sv.d, 64, 64, g[TS_WT], s));
+    T_TRY(wgrad(n, dt, sv.d, 64, 64, g[TS_WT], c, s));
     colsum_accum(n, dt, 64, g[TS_BT], c, s);
     T_TRY(dgrad(n, dt, p[TS_WT], 64, 64, nullptr, dd, s));
     hipLaunchKernelGGL(add_neg_kernel, dim3(blocks_for(n4)), dim3(256), 0, s, (const f32x4 *)g_out, (const f32x4 *)dd, n4, (f32x4 *)ssum, (f32x4 *)ngx);
     float *dv = dd;   // dd is dead after add_neg
     T_TRY(dvm_sa_attention_bwd_f32(sv.p, sv.v, sv.xr, sv.stats, sv.cinv, ngx, n.B, n.N, c.dp, dv, c.sabws, c.sab_bytes, s));
-    T_TRY(wgrad(n, c.dp, xin, 16, 64, g[TS_WK], s));
-    T_TRY(wgrad(n, dv, xin, 64, 64, g[TS_WV], s));
+    T_TRY(wgrad(n, c.dp, xin, 16, 64, g[TS_WK], c, s));
+    T_TRY(wgrad(n, dv, xin, 64, 64, g[TS_WV], c, s));
     colsum_accum(n, dv, 64, g[TS_BV], c, s);
     T_TRY(dgrad(n, c.dp, p[TS_WK], 16, 64, ssum, ngx, s));      // ngx is dead after the attention backward: reused as the partial sum
     T_TRY(dgrad(n, dv, p[TS_WV], 64, 64, ngx, dx, s));

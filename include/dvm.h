@@ -108,6 +108,18 @@ int dvm_linear_scaled_residual_f32(const float *x, const float *w, int B, int N,
  * ZEROED by the caller (row chunks are combined with fp32 atomics: summation order not fixed).  The input gradient of the
  * same layer needs no entry point of its own: dX = gy W is dvm_linear_f32(x := W as [1, Co, K], w := gy, channel_major = 1). */
 int dvm_linear_wgrad_f32(const float *gy, const float *x, long R, int Co, int K, float *dW, void *stream);
+/* The same weight gradient with an optional workspace (dvm_linear_wgrad_workspace_bytes): in the deterministic mode (below) every
+ * row chunk writes its partial tile there and the tiles are added to dW in chunk order — bit-reproducible from run to run;
+ * otherwise (or with ws == NULL) identical to dvm_linear_wgrad_f32. */
+size_t dvm_linear_wgrad_workspace_bytes(long R, int Co, int K);
+int dvm_linear_wgrad_ws_f32(const float *gy, const float *x, long R, int Co, int K, float *dW, void *ws, size_t ws_bytes, void *stream);
+
+/* Deterministic gradient sums for LG-Net's backward (the reference's `loss.backward()`, train.py:110, sums in whatever order
+ * its CUDA kernels' atomics land): on = 1 fixes the summation order of the three places that combine partial sums of different
+ * workgroups with fp32 atomics — the row chunks of dvm_linear_wgrad_ws_f32, the split inner loop of dvm_sa_attention_bwd_f32, the
+ * in-edge order of dvm_n2p_core_bwd_f32 — so that dvm_uni3fc_train_bwd_f32 returns the same bits on every run (measured:
+ * LG-Net forward + backward, 2 x 8 x 2048 points, 18.5 ms instead of 14.3 ms).  Returns the previous setting; environment default DVM_DETERMINISTIC=1.  Process-wide. */
+int dvm_set_deterministic(int on);
 
 /* knnsearch_t_grad + topk_pi (+ the argmax map)  —  models/loss.py:110-114,
  * 1339-1347, 1404-1407.   D = cdist(f1,f2) (matmul form, bit-identical squared

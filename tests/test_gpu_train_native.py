@@ -153,3 +153,32 @@ def test_native_training_is_the_default_and_falls_back():
     assert torch.equal(feat.detach(), feat2.detach())
     feat2.sum().backward()
     assert dino2.grad is not None and bool(torch.isfinite(dino2.grad).all())
+
+
+@pytest.mark.parametrize("native", [True, False], ids=["native", "autograd"])
+def test_deterministic_switch_gives_bit_reproducible_gradients(native):
+    """with dvm_set_deterministic(1) the three places of LG-Net's backward that combine partial sums of different
+    workgroups with fp32 atomics (row chunks of the weight gradient, the split of the SA backward, the in-edge order of the N2P
+    gather) sum in a fixed order: two runs of the same step give the SAME BITS in every parameter gradient, on the native node
+    and on the autograd path; against the default (atomic) mode the gradients agree to summation-order noise."""
+    from dvm import ops
+    x, dino = _inputs(4, 1024, 5)
+    g = torch.Generator().manual_seed(6)
+    gf, gt = torch.randn(4, 1024, 128, generator=g).cuda(), torch.randn(4, 1024, 64, generator=g).cuda()
+
+    def grads():
+        a, _ = _nets(40, seed=3, gain=0.5)
+        _run(a, x, dino, native, True, gf, gt)
+        return a, [p.grad.clone() for p in a.parameters() if p.grad is not None]
+
+    prev = ops.set_deterministic(True)
+    try:
+        _, g1 = grads()
+        _, g2 = grads()
+        _, g3 = grads()
+    finally:
+        ops.set_deterministic(prev)
+    assert all(torch.equal(u, v) for u, v in zip(g1, g2)) and all(torch.equal(u, v) for u, v in zip(g1, g3))
+    ref, g0 = grads()                                   # default mode
+    worst = max(float((u - v).abs().max()) / (float(v.abs().max()) + 1e-30) for u, v in zip(g1, g0) if float(v.abs().max()) > 1e-3)
+    assert worst < 1e-3, worst
