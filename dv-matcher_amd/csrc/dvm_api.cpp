@@ -140,7 +140,7 @@ static int g_ev_used = 0;
 static bool g_prof_on = false;
 static unsigned g_prof_mask = 1u;
 static unsigned g_prof_window = 0;        // bumped by enable / disable: a bracket opened in an earlier window is dropped
-static char g_slot_name[DVM_PROF_COUNT][96] = {"softcorr_sweep2_kernel", "softcorr_refine_kernel", "mlp_f16x2_kernel", "grid_chamfer_kernel",
+static char g_slot_name[DVM_PROF_COUNT][160] = {"softcorr_sweep2_kernel", "softcorr_refine_kernel", "mlp_f16x2_kernel", "grid_chamfer_kernel",
                                                "pool_kernel",            "grid_knn_self_kernel",   "fps_kernel",       "assemble_pooled_kernel"};
 struct ProfOpen {
     int id = -1;
@@ -234,7 +234,7 @@ DVM_EXPORT int dvm_profile_read_kernel(int kernel, double *total_ms, int *launch
 }
 
 DVM_EXPORT const char *dvm_profile_kernel_name(int kernel) {
-    static thread_local char out[96];
+    static thread_local char out[160];
     if (kernel < 0 || kernel >= DVM_PROF_COUNT) return "";
     std::lock_guard<std::mutex> lock(dvm::g_prof_mu);
     memcpy(out, dvm::g_slot_name[kernel], sizeof(out));

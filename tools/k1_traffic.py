@@ -27,7 +27,9 @@ res = {
     "config": "bench.py --pairs %d (N=M=2048, d=128)" % P,
     "FETCH_SIZE_KB": per.get("FETCH_SIZE"), "WRITE_SIZE_KB": per.get("WRITE_SIZE"),
     "fetch_bytes_corrected_x2": fetch, "write_bytes": write, "bytes_per_launch": fetch + write,
-    "algorithmic_bytes_per_launch": P * (4 * 2048 * 512 + 2 * 2048 * 12 * 8),   # fp16 planes of both clouds read once + 12 candidates (column, distance) per row written
+    # per pair, as in rounds 1-3: the fp16 planes of both clouds read once (2 x 2048 x 512 B) + per row and direction 12 candidate
+    # (column, distance) pairs, the two partial softmax sums and the norm fragments (2 x 2048 x 144 B)
+    "algorithmic_bytes_per_launch": P * (2 * 2048 * 512 + 2 * 2048 * 144),
     "l2_hit_rate": (per["TCC_HIT_sum"] / (per["TCC_HIT_sum"] + per["TCC_MISS_sum"])) if "TCC_HIT_sum" in per and "TCC_MISS_sum" in per else None,
     "SQ": {k: v for k, v in sorted(per.items()) if k.startswith("SQ_")},
     "kernels_in_bracket": sorted({k for ks in acc.values() for k in ks}),
