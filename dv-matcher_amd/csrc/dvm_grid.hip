@@ -301,15 +301,37 @@ __device__ __forceinline__ bool grid_search(const GridView &g, float qx, float q
     return Rmax >= G;   // (walked the whole grid: certified by exhaustion)
 }
 
+// The workgroup copies a grid's sorted points and cell table into LDS and repoints the view at the copy: every candidate and
+// range-bound read of a search is then an LDS read instead of an L2 round trip (the original indices stay in global memory).
+// Returns the bytes used.  All threads of the workgroup must call it; the caller synchronises afterwards.
+__device__ __forceinline__ size_t grid_stage_lds(GridView &g, int P, char *lds, int threads) {
+    const int G3 = g.G * g.G * g.G;
+    float4 *lp = (float4 *)lds;
+    int32_t *ls = (int32_t *)(lds + (size_t)P * sizeof(float4));
+    for (int i = threadIdx.x; i < P; i += threads) lp[i] = g.pts[i];
+    for (int i = threadIdx.x; i <= G3; i += threads) ls[i] = g.start[i];
+    g.pts = lp;
+    g.start = ls;
+    return ((size_t)P * sizeof(float4) + (size_t)(G3 + 1) * sizeof(int32_t) + 15) / 16 * 16;
+}
+static size_t grid_lds_bytes(const GridBuf &gb) {
+    return ((size_t)gb.P * sizeof(float4) + ((size_t)gb.G * gb.G * gb.G + 1) * sizeof(int32_t) + 15) / 16 * 16;
+}
+
 // ---------------------------------------------------------------- kernels on top of grid_search
 // xyz kNN of a cloud against itself (knn_grad): thread t handles the t-th point in cell order.
-template <int K>
-__global__ __launch_bounds__(128) void grid_knn_self_kernel(GridBuf gb, int k, int32_t *__restrict__ idx) {
+template <int K, int THREADS = 128, bool LDS_GRID = false>
+__global__ __launch_bounds__(THREADS) void grid_knn_self_kernel(GridBuf gb, int k, int32_t *__restrict__ idx) {
+    extern __shared__ __attribute__((aligned(16))) char kn_lds[];
     const int b = blockIdx.y;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int P = gb.P;
-    if (t >= P) return;
     GridView g = grid_view(gb, b);
+    if (LDS_GRID) {
+        grid_stage_lds(g, P, kn_lds, THREADS);
+        __syncthreads();
+    }
+    if (t >= P) return;
     const float4 qp = g.pts[t];
     MetricMMQueryRow met;
     met.set(qp.x, qp.y, qp.z);
@@ -322,12 +344,18 @@ __global__ __launch_bounds__(128) void grid_knn_self_kernel(GridBuf gb, int k, i
 }
 
 // node ring: 9-NN among nodes in fp64 (grid over the nodes, queries = nodes in cell order)
-__global__ __launch_bounds__(128) void grid_ring_kernel(GridBuf gb, int32_t *__restrict__ ring) {
+template <int THREADS = 128, bool LDS_GRID = false>
+__global__ __launch_bounds__(THREADS) void grid_ring_kernel(GridBuf gb, int32_t *__restrict__ ring) {
+    extern __shared__ __attribute__((aligned(16))) char rg_lds[];
     const int b = blockIdx.y;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int P = gb.P;
-    if (t >= P) return;
     GridView g = grid_view(gb, b);
+    if (LDS_GRID) {
+        grid_stage_lds(g, P, rg_lds, THREADS);
+        __syncthreads();
+    }
+    if (t >= P) return;
     const float4 qp = g.pts[t];
     // Screened: the search runs on the fp64 distance ROUNDED to fp32, packed with the index (KBestPacked: two instructions per
     // compare-swap instead of the fourteen of a (double, index) pair), on a list of 10 certified against its 9th entry.  Rounding
@@ -357,17 +385,25 @@ __global__ __launch_bounds__(128) void grid_ring_kernel(GridBuf gb, int32_t *__r
 
 // influence nodes (3 nearest nodes, matmul form with the node as row operand) on the node grid, and
 // the fp64 distance to the nearest other vertex on the vertex grid
-__global__ __launch_bounds__(128) void grid_infl_kernel(const float *__restrict__ xyz, int N, GridBuf gnodes, GridBuf gverts,
-                                                        int32_t *__restrict__ infl, float *__restrict__ dists,
-                                                        double *__restrict__ nnd) {
+template <int THREADS = 128, int LDS_GRID = 0>   // LDS_GRID: bit 0 = the node grid, bit 1 = the vertex grid staged in LDS
+__global__ __launch_bounds__(THREADS) void grid_infl_kernel(const float *__restrict__ xyz, int N, GridBuf gnodes, GridBuf gverts,
+                                                            int32_t *__restrict__ infl, float *__restrict__ dists,
+                                                            double *__restrict__ nnd) {
+    extern __shared__ __attribute__((aligned(16))) char in_lds[];
     const int b = blockIdx.y;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= N) return;
     GridView gv = grid_view(gverts, b);
+    GridView gn = grid_view(gnodes, b);
+    if (LDS_GRID) {   // the nodes' grid (three nearest nodes) and / or the vertices' (nearest other vertex)
+        size_t used = 0;
+        if (LDS_GRID & 2) used = grid_stage_lds(gv, gverts.P, in_lds, THREADS);
+        if (LDS_GRID & 1) grid_stage_lds(gn, gnodes.P, in_lds + used, THREADS);
+        __syncthreads();
+    }
+    if (t >= N) return;
     const float4 qp = gv.pts[t];  // vertices in cell order (coherent waves)
     const int i = gv.ids[t];
     {
-        GridView gn = grid_view(gnodes, b);
         MetricMMCandRow met;
         met.set(qp.x, qp.y, qp.z);
         KBestPacked<3> kb;
@@ -526,7 +562,13 @@ __device__ __forceinline__ void chamfer_scan_wave(const ChGridGroup &G, const Gr
     }
 }
 
-__global__ __launch_bounds__(128) void grid_chamfer_kernel(const ChGridArgs args) {
+// LDS_TARGET (round 4): the workgroup first copies the TARGET cloud's sorted points and cell table into LDS (32 KB + 7 KB at 2048
+// points) and every candidate / range-bound read of the searches below is an LDS read instead of an L2 round trip — the kernel
+// spent 58 % of its wave cycles parked on those (profiles/r3_pmc_summary.txt, r4_pmc_grid.txt).  Same arithmetic, same order,
+// same results; the original indices (one read per query, more on exact ties) stay in global memory.
+template <int THREADS, bool LDS_TARGET>
+__global__ __launch_bounds__(THREADS) void grid_chamfer_kernel(const ChGridArgs args) {
+    extern __shared__ __attribute__((aligned(16))) char ch_lds[];
     const ChGridGroup &G = args.g[blockIdx.z];
     const int b = blockIdx.y;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -534,6 +576,16 @@ __global__ __launch_bounds__(128) void grid_chamfer_kernel(const ChGridArgs args
     // (lanes past the end stay in the kernel, with the last query and nothing to write: the matrix-core scan below needs whole waves)
     const bool inrange = t < Na;
     GridView g = grid_view(G.gb, b);
+    if (LDS_TARGET) {
+        const int P = G.gb.P, G3 = G.gb.G * G.gb.G * G.gb.G;
+        float4 *lp = (float4 *)ch_lds;
+        int32_t *ls = (int32_t *)(ch_lds + (size_t)P * sizeof(float4));
+        for (int i = threadIdx.x; i < P; i += THREADS) lp[i] = g.pts[i];
+        for (int i = threadIdx.x; i <= G3; i += THREADS) ls[i] = g.start[i];
+        __syncthreads();
+        g.pts = lp;
+        g.start = ls;
+    }
     GridView q = grid_view(G.gq, b);
     const int tq = inrange ? t : Na - 1;
     const float4 qp = q.pts[tq];
@@ -780,25 +832,89 @@ void launch_grid_build(const float *xyz, int B, int Nsrc, const int32_t *sel, co
     hipLaunchKernelGGL(grid_build_kernel, dim3(B), dim3(GRID_T), lds, s, xyz, Nsrc, sel, gb);
 }
 
+// LDS-resident grids for the searches (round 4): DVM_GRID_LDS=0 off, 1 (default) on where the grid fits 64 KB; threads per
+// workgroup of the LDS forms: DVM_GRID_LDS_T (256 / 512 / 1024)
+static int grid_lds_mode() {
+    static const int m = [] { const char *e = getenv("DVM_GRID_LDS"); return e ? atoi(e) : 1; }();
+    return m;
+}
+static int grid_lds_threads() {
+    static const int t = [] { const char *e = getenv("DVM_GRID_LDS_T"); return e ? atoi(e) : 512; }();
+    return t;
+}
+
+template <int K>
+static void launch_knn_self_k(const GridBuf &gb, int B, int k, int32_t *idx, hipStream_t s) {
+    const size_t lds = grid_lds_bytes(gb);
+    const int T = grid_lds_threads();
+    if (grid_lds_mode() && lds <= 64 * 1024) {
+        if (T >= 1024) {
+            ensure_dyn_lds((const void *)grid_knn_self_kernel<K, 1024, true>, (int)lds);
+            hipLaunchKernelGGL((grid_knn_self_kernel<K, 1024, true>), dim3((gb.P + 1023) / 1024, B), dim3(1024), lds, s, gb, k, idx);
+        } else if (T >= 512) {
+            ensure_dyn_lds((const void *)grid_knn_self_kernel<K, 512, true>, (int)lds);
+            hipLaunchKernelGGL((grid_knn_self_kernel<K, 512, true>), dim3((gb.P + 511) / 512, B), dim3(512), lds, s, gb, k, idx);
+        } else {
+            ensure_dyn_lds((const void *)grid_knn_self_kernel<K, 256, true>, (int)lds);
+            hipLaunchKernelGGL((grid_knn_self_kernel<K, 256, true>), dim3((gb.P + 255) / 256, B), dim3(256), lds, s, gb, k, idx);
+        }
+    } else {
+        hipLaunchKernelGGL((grid_knn_self_kernel<K, 128, false>), dim3((gb.P + 127) / 128, B), dim3(128), 0, s, gb, k, idx);
+    }
+}
+
 void launch_grid_knn_self(const GridBuf &gb, int B, int k, int32_t *idx, hipStream_t s) {
-    dim3 grid((gb.P + 127) / 128, B);
     prof_begin(s, DVM_PROF_KNN_XYZ);
     if (k <= 3)
-        hipLaunchKernelGGL(grid_knn_self_kernel<3>, grid, dim3(128), 0, s, gb, k, idx);
+        launch_knn_self_k<3>(gb, B, k, idx, s);
     else if (k <= 10)
-        hipLaunchKernelGGL(grid_knn_self_kernel<10>, grid, dim3(128), 0, s, gb, k, idx);
+        launch_knn_self_k<10>(gb, B, k, idx, s);
     else
-        hipLaunchKernelGGL(grid_knn_self_kernel<16>, grid, dim3(128), 0, s, gb, k, idx);
+        launch_knn_self_k<16>(gb, B, k, idx, s);
     prof_end(s, DVM_PROF_KNN_XYZ);
 }
 
 void launch_grid_ring(const GridBuf &gnodes, int B, int32_t *ring, hipStream_t s) {
-    hipLaunchKernelGGL(grid_ring_kernel, dim3((gnodes.P + 127) / 128, B), dim3(128), 0, s, gnodes, ring);
+    const size_t lds = grid_lds_bytes(gnodes);
+    const int T = grid_lds_threads();
+    if (grid_lds_mode() && lds <= 64 * 1024) {
+        if (T >= 512) {
+            ensure_dyn_lds((const void *)grid_ring_kernel<512, true>, (int)lds);
+            hipLaunchKernelGGL((grid_ring_kernel<512, true>), dim3((gnodes.P + 511) / 512, B), dim3(512), lds, s, gnodes, ring);
+        } else {
+            ensure_dyn_lds((const void *)grid_ring_kernel<256, true>, (int)lds);
+            hipLaunchKernelGGL((grid_ring_kernel<256, true>), dim3((gnodes.P + 255) / 256, B), dim3(256), lds, s, gnodes, ring);
+        }
+    } else {
+        hipLaunchKernelGGL((grid_ring_kernel<128, false>), dim3((gnodes.P + 127) / 128, B), dim3(128), 0, s, gnodes, ring);
+    }
 }
 
+template <int T, int MODE>
+static void launch_infl_t(const float *xyz, int B, int N, const GridBuf &gnodes, const GridBuf &gverts, int32_t *infl, float *dists, double *nnd,
+                          size_t lds, hipStream_t s) {
+    ensure_dyn_lds((const void *)grid_infl_kernel<T, MODE>, (int)lds);
+    hipLaunchKernelGGL((grid_infl_kernel<T, MODE>), dim3((N + T - 1) / T, B), dim3(T), lds, s, xyz, N, gnodes, gverts, infl, dists, nnd);
+}
 void launch_grid_infl(const float *xyz, int B, int N, const GridBuf &gnodes, const GridBuf &gverts, int32_t *infl, float *dists,
                       double *nnd, hipStream_t s) {
-    hipLaunchKernelGGL(grid_infl_kernel, dim3((N + 127) / 128, B), dim3(128), 0, s, xyz, N, gnodes, gverts, infl, dists, nnd);
+    static const int mode = [] { const char *e = getenv("DVM_INFL_LDS"); return e ? atoi(e) : 1; }();   // 0 none, 1 node grid, 2 vertex grid, 3 both
+    const size_t lds = ((mode & 1) ? grid_lds_bytes(gnodes) : 0) + ((mode & 2) ? grid_lds_bytes(gverts) : 0);
+    const int T = grid_lds_threads();
+    if (grid_lds_mode() && mode >= 1 && mode <= 3 && lds <= 64 * 1024) {
+        if (mode == 1) {
+            if (T >= 512) launch_infl_t<512, 1>(xyz, B, N, gnodes, gverts, infl, dists, nnd, lds, s);
+            else launch_infl_t<256, 1>(xyz, B, N, gnodes, gverts, infl, dists, nnd, lds, s);
+        } else if (mode == 2) {
+            if (T >= 512) launch_infl_t<512, 2>(xyz, B, N, gnodes, gverts, infl, dists, nnd, lds, s);
+            else launch_infl_t<256, 2>(xyz, B, N, gnodes, gverts, infl, dists, nnd, lds, s);
+        } else {
+            if (T >= 512) launch_infl_t<512, 3>(xyz, B, N, gnodes, gverts, infl, dists, nnd, lds, s);
+            else launch_infl_t<256, 3>(xyz, B, N, gnodes, gverts, infl, dists, nnd, lds, s);
+        }
+    } else {
+        hipLaunchKernelGGL((grid_infl_kernel<128, 0>), dim3((N + 127) / 128, B), dim3(128), 0, s, xyz, N, gnodes, gverts, infl, dists, nnd);
+    }
 }
 
 void launch_grid_chamfer(const GridBuf *gq, const GridBuf *gb, float *const *dout, int32_t *const *iout, int ngroups, int B,
@@ -833,8 +949,31 @@ void launch_grid_chamfer(const GridBuf *gq, const GridBuf *gb, float *const *dou
     }();
     args.ablate = ablate;
 #endif
+    // LDS-resident target (DVM_CHAMFER_LDS=0: off; =128 / 256 / 512: threads per workgroup): every group's target must fit
+    static const int lds_threads = [] { const char *e = getenv("DVM_CHAMFER_LDS"); return e ? atoi(e) : 512; }();
+    size_t lds_bytes = 0;
+    for (int q = 0; q < ngroups; ++q) {
+        const size_t nb = (size_t)gb[q].P * sizeof(float4) + ((size_t)gb[q].G * gb[q].G * gb[q].G + 1) * sizeof(int32_t);
+        lds_bytes = nb > lds_bytes ? nb : lds_bytes;
+    }
+    lds_bytes = (lds_bytes + 15) / 16 * 16;
     prof_begin(s, DVM_PROF_CHAMFER);
-    hipLaunchKernelGGL(grid_chamfer_kernel, dim3((maxN + 127) / 128, B, ngroups), dim3(128), 0, s, args);
+    if (lds_threads >= 128 && lds_bytes <= 64 * 1024 && !defer) {
+        if (lds_threads >= 1024) {
+            ensure_dyn_lds((const void *)grid_chamfer_kernel<1024, true>, (int)lds_bytes);
+            hipLaunchKernelGGL((grid_chamfer_kernel<1024, true>), dim3((maxN + 1023) / 1024, B, ngroups), dim3(1024), lds_bytes, s, args);
+        } else if (lds_threads >= 512) {
+            ensure_dyn_lds((const void *)grid_chamfer_kernel<512, true>, (int)lds_bytes);
+            hipLaunchKernelGGL((grid_chamfer_kernel<512, true>), dim3((maxN + 511) / 512, B, ngroups), dim3(512), lds_bytes, s, args);
+        } else if (lds_threads >= 256) {
+            ensure_dyn_lds((const void *)grid_chamfer_kernel<256, true>, (int)lds_bytes);
+            hipLaunchKernelGGL((grid_chamfer_kernel<256, true>), dim3((maxN + 255) / 256, B, ngroups), dim3(256), lds_bytes, s, args);
+        } else {
+            ensure_dyn_lds((const void *)grid_chamfer_kernel<128, true>, (int)lds_bytes);
+            hipLaunchKernelGGL((grid_chamfer_kernel<128, true>), dim3((maxN + 127) / 128, B, ngroups), dim3(128), lds_bytes, s, args);
+        }
+    } else
+        hipLaunchKernelGGL((grid_chamfer_kernel<128, false>), dim3((maxN + 127) / 128, B, ngroups), dim3(128), 0, s, args);
     if (defer) hipLaunchKernelGGL(grid_chamfer_retry_kernel, dim3(B, ngroups), dim3(256), 0, s, args);
     prof_end(s, DVM_PROF_CHAMFER);
     if (args.stats) {
