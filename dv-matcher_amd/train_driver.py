@@ -218,6 +218,9 @@ def main(argv=None):
                     "Adam) into ONE HIP graph and replay it — ~2000 kernel launches per step become one graph launch")
     ap.add_argument("--sync-stats", action="store_true", help="DDP: BatchNorm statistics and the positional encoding's min/max "
                     "over the GLOBAL batch (SyncBatchNorm + two scalar all-reduces)")
+    ap.add_argument("--graph-cache", action="store_true", help="opt-in per-shape deformation-graph cache (SURVEY 8f-2): every shape gets ONE "
+                    "fixed FPS start index (from its id) instead of the reference's fresh random start per call (models/loss.py:1325-1337), and its "
+                    "graph / xyz kNN are built once and reused whenever the shape comes up again")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--data-root", default=None, help="dataset directory (shapes_train/, shapes_test/, feat/, cache_*.pt); default: synthetic")
     ap.add_argument("--data-name", default=None)
@@ -291,6 +294,8 @@ def main(argv=None):
         train_set = SyntheticPairs(n_train, N, M, seed_data if timing else 1000, dev)   # full loop: every rank holds the same pairs
         val_set = train_set if timing else SyntheticPairs(args.val_pairs or Bg, N, M, 2000, dev)
     crit = build_criterion(cfg, partial, min(N, M))
+    if args.graph_cache:
+        crit.graph_cache = {}
     frac = (hi - lo) / Bg
     sync_each = os.environ.get("DVM_SYNC_EACH_STEP", "0") == "1"   # train.py logs loss.item() every iteration
 
@@ -325,12 +330,20 @@ def main(argv=None):
     # enqueued on its own stream BEFORE the network forward and joined in front of the criterion
     geo_stream = torch.cuda.Stream() if os.environ.get("DVM_PREFETCH_GEOMETRY", "1") == "1" else None
 
-    def prefetch_geometry(v1, v2, starts=None):
+    def cached_keys(idx, n1, n2):
+        """--graph-cache: (fixed FPS starts, shape ids) of the pairs `idx` — a shape's start is a hash of its id, so the same shape
+        always gets the same graph (the key of the cache is (id, start, point count))."""
+        ids1, ids2 = [("s", int(i)) for i in idx], [("t", int(i)) for i in idx]
+        s1 = torch.tensor([(int(i) * 2654435761 + 12345) % n1 for i in idx], dtype=torch.long)
+        s2 = torch.tensor([(int(i) * 2246822519 + 54321) % n2 for i in idx], dtype=torch.long)
+        return (s1, s2), (ids1, ids2)
+
+    def prefetch_geometry(v1, v2, starts=None, shape_ids=None):
         if geo_stream is None:
             return None
         geo_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(geo_stream), torch.no_grad():
-            return crit.geometry(v1, v2, starts)
+            return crit.geometry(v1, v2, starts, shape_ids)
 
     def join_geometry(geo):
         if geo is None:
@@ -343,14 +356,15 @@ def main(argv=None):
                     t.record_stream(cur)
         return geo
 
-    def train_step(batch, alpha):
+    def train_step(batch, alpha, pair_ids=None):
         v1, v2, d1, d2, dist1, dist2 = batch
         fit_criterion(crit, cfg, min(v1.shape[1], v2.shape[1]))
         t = time.perf_counter()
-        geo = prefetch_geometry(v1, v2)
+        starts, shape_ids = cached_keys(pair_ids, v1.shape[1], v2.shape[1]) if (args.graph_cache and pair_ids is not None) else (None, None)
+        geo = prefetch_geometry(v1, v2, starts, shape_ids)
         f1, f2 = forward_pair(v1, d1, v2, d2)
         t = mark(0, t)
-        out = crit(f1, f2, dist1, dist2, v1, v2, alpha, dfm, geometry=join_geometry(geo))
+        out = crit(f1, f2, dist1, dist2, v1, v2, alpha, dfm, fps_starts=starts, geometry=join_geometry(geo), shape_ids=shape_ids)
         t = mark(1, t)
         if dist_on:
             crit.data_parallel_loss(frac).backward()
@@ -386,9 +400,10 @@ def main(argv=None):
         net.train()
         dfm.train()
         if args.data_root:
-            feed = [train_set.batch(shard(b)) for b in global_batches(train_set.pairs, Bg)[:max(1, args.steps)]]
+            feed_ids = [shard(b) for b in global_batches(train_set.pairs, Bg)[:max(1, args.steps)]]
         else:   # every rank owns its own Bg/world pairs (weak-scaling shape of the forward bench)
-            feed = [train_set.batch(list(range(lo, hi)) if train_set.pairs >= Bg else list(range(hi - lo)))]
+            feed_ids = [list(range(lo, hi)) if train_set.pairs >= Bg else list(range(hi - lo))]
+        feed = [train_set.batch(ix) for ix in feed_ids]
         losses = []
         if use_graph:
             # every draw the criterion makes on the host (dist-loss anchors, FPS starts) becomes a device-resident input of
@@ -421,11 +436,11 @@ def main(argv=None):
             with torch.cuda.graph(graph):
                 static_vals = graph_step()
 
-            def train_step(_batch, _alpha):   # noqa: F811  (the replay stands in for the eager step)
+            def train_step(_batch, _alpha, _ids=None):   # noqa: F811  (the replay stands in for the eager step)
                 graph.replay()
                 return static_vals.clone()
         for i in range(args.warmup):
-            train_step(feed[i % len(feed)], alpha)
+            train_step(feed[i % len(feed)], alpha, feed_ids[i % len(feed)])
         torch.cuda.synchronize()
         if dist_on:
             dist.barrier()
@@ -433,7 +448,7 @@ def main(argv=None):
             host_marks[:] = [0.0, 0.0, 0.0, 0.0, 0]
         t0 = time.perf_counter()
         for i in range(args.steps):
-            losses.append(train_step(feed[i % len(feed)], alpha))
+            losses.append(train_step(feed[i % len(feed)], alpha, feed_ids[i % len(feed)]))
         t_host = time.perf_counter() - t0          # all steps enqueued; the rest of dt is the GPU catching up
         torch.cuda.synchronize()
         if dist_on:
@@ -458,7 +473,7 @@ def main(argv=None):
                                            "note": "algorithmic matrix flops of the whole step per GPU over the step time; the step is "
                                                    "~1800 small launches, host- and latency-bound, not matrix-bound"},
                               "points": N, "points_target": M, "criterion": type(crit).__name__, "alpha": float(alpha),
-                              "hip_graph": use_graph, "process_group": (dist.get_backend() if dist_on else None),
+                              "hip_graph": use_graph, "graph_cache": bool(args.graph_cache), "process_group": (dist.get_backend() if dist_on else None),
                               "grad_bucket_floats": bucket.numel, "first_losses": losses[0], "last_losses": losses[-1]}))
         if dist_on:
             dist.destroy_process_group()
@@ -478,7 +493,8 @@ def main(argv=None):
         dfm.train()
         sums, iters = torch.zeros(5, device=dev), 0
         for b in global_batches(train_set.pairs, Bg, shuffle_seed=1000 * epoch, keep_tail=(world == 1)):   # the same order on every rank
-            sums += torch.as_tensor(train_step(train_set.batch(shard(b) if len(b) == Bg else b), alpha), device=dev)
+            ix = shard(b) if len(b) == Bg else b
+            sums += torch.as_tensor(train_step(train_set.batch(ix), alpha, ix), device=dev)
             iters += 1
             if rank == 0 and iters % int(cfg["misc"]["log_interval"]) == 0:    # per-epoch count, (i + 1) % log_interval (train.py:120-126)
                 save_ckpt(net, dfm, args.ckpt_dir, cfg["expname"], "train_best")

@@ -311,3 +311,17 @@ def test_rccl_branch_runs_at_world_size_one():
         if bucket and "grad_bucket_floats" in res:
             assert res["grad_bucket_floats"] == bucket
             assert all(v == v and abs(v) < 1e9 for v in res["first_losses"] + res["last_losses"])
+
+
+def test_training_driver_graph_cache_flag():
+    """`--graph-cache`: per-shape graphs with a fixed FPS start per shape, built once and reused; the step runs, the losses stay
+    finite and move, and (timing mode: one resident batch) every step after the first is served from the cache."""
+    import json
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "dv-matcher_amd", "train_driver.py"), "--steps", "4", "--warmup", "1", "--batch", "2", "--points", "256",
+           "--graph-cache"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert res["graph_cache"] is True
+    assert all(v == v and abs(v) < 1e9 for v in res["first_losses"] + res["last_losses"]) and res["first_losses"] != res["last_losses"]
