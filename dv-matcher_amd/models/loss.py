@@ -73,6 +73,16 @@ def _host_draw_to_device(values, device):
     return t.pin_memory().to(device, non_blocking=True)
 
 
+_crit_side = {}
+
+
+def _crit_streams(device, cur):
+    key = (device, cur.cuda_stream)
+    if key not in _crit_side:
+        _crit_side[key] = (torch.cuda.Stream(device), torch.cuda.Stream(device))
+    return _crit_side[key]
+
+
 class SparsePi:
     """Top-k rows of the soft correspondence: val/idx (B,N,k); stands in for the dense (B,N,M) Pi."""
 
@@ -286,20 +296,47 @@ class GraphDeformLoss_Neural(nn.Module):
                                              any(p.requires_grad for p in deformer.parameters()))
         dist_term = self._dist_term_train if train else self._dist_term
         direction = self._direction_train if train else self._direction
+        # The dist term and the two directions of the deformation part are independent of each other: on a GPU they run on
+        # three streams (forked from / joined into the caller's stream; autograd replays each branch's backward on the stream its
+        # forward ran on).  At 8 pairs their kernels fill a fraction of the chip each.  DVM_CRIT_STREAMS=0: one stream.
+        par = feat1.is_cuda and os.environ.get("DVM_CRIT_STREAMS", "1") == "1" and not self.dump
+        cur = torch.cuda.current_stream(feat1.device) if par else None
+        side = _crit_streams(feat1.device, cur) if par else None
+
+        def on(k, fn):
+            if not par:
+                return fn()
+            st = side[k]
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                return fn()
+
+        def joined(k, out):
+            if par:
+                cur.wait_stream(side[k])
+                for t in (out if isinstance(out, (tuple, list)) else (out,)):
+                    for u in (t.values() if isinstance(t, dict) else (t,)):
+                        if torch.is_tensor(u) and u.is_cuda:
+                            u.record_stream(cur)
+            return out
         if self.w_dist > 0:
             if anchors is None:
                 anchors = (random.sample(range(dist1.shape[1]), self.N_dist), random.sample(range(dist2.shape[1]), self.N_dist))
             # (device tensors pass through untouched: no host-to-device copy inside a captured step)
             a1, a2 = _host_draw_to_device(anchors[0], feat1.device), _host_draw_to_device(anchors[1], feat2.device)
-            self.dist_loss = (dist_term(feat1, dist1, a1) + dist_term(feat2, dist2, a2)) * self.w_dist
+            dterm = on(0, lambda: (dist_term(feat1, dist1, a1) + dist_term(feat2, dist2, a2)) * self.w_dist)
+        if self.w_deform > 0 or not self.partial_variant:
+            g1, g2, idx11, idx22 = geometry if geometry is not None else self.geometry(verts1, verts2, fps_starts, shape_ids)
+            r21 = on(1, lambda: direction(feat2, feat1, verts2, verts1, alpha_i, g2, deformer, idx22, idx11))
+            m12, c12, a12, s12, ex12 = direction(feat1, feat2, verts1, verts2, alpha_i, g1, deformer, idx11, idx22)
+            n12 = str(random.randint(0, 10))
+            m21, c21, a21, s21, ex21 = joined(1, r21)
+            n21 = str(random.randint(0, 10))
+        if self.w_dist > 0:
+            self.dist_loss = joined(0, dterm)
             loss = loss + self.dist_loss
             self._sum_part = self._sum_part + self.dist_loss
         if self.w_deform > 0 or not self.partial_variant:
-            g1, g2, idx11, idx22 = geometry if geometry is not None else self.geometry(verts1, verts2, fps_starts, shape_ids)
-            m12, c12, a12, s12, ex12 = direction(feat1, feat2, verts1, verts2, alpha_i, g1, deformer, idx11, idx22)
-            n12 = str(random.randint(0, 10))
-            m21, c21, a21, s21, ex21 = direction(feat2, feat1, verts2, verts1, alpha_i, g2, deformer, idx22, idx11)
-            n21 = str(random.randint(0, 10))
             cross12 = c12 * self.w_cd + a12 * self.w_arap
             cross21 = c21 * self.w_cd + a21 * self.w_arap
             if self.dump:
