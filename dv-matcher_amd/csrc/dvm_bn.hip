@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void bn_pm_finalize_fwd_kernel(const double *_
                                                                  const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
                                                                  float momentum, float *__restrict__ fin, float *__restrict__ mean_out,
                                                                  float *__restrict__ invstd_out, float *__restrict__ running_mean,
-                                                                 float *__restrict__ running_var) {
+                                                                 float *__restrict__ running_var, float *__restrict__ unb_out) {
     const int cl = threadIdx.x & (PM_CG - 1), sl = threadIdx.x / PM_CG, c = blockIdx.x * PM_CG + cl;
     double ta, tq;
     if (!pm_sum_partials(partial, S, C, c, cl, sl, ta, tq)) return;
@@ -267,8 +267,9 @@ __global__ __launch_bounds__(256) void bn_pm_finalize_fwd_kernel(const double *_
     const float invstd = (float)(1.0 / sqrt(var + (double)eps)), mf = (float)mean;
     mean_out[c] = mf;
     invstd_out[c] = invstd;
+    const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
+    if (unb_out) unb_out[c] = (float)unb;   // for a deferred running-statistics update (dvm_bn_running_update_f32): the same float
     if (running_mean) {
-        const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
         running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mf;
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
     }
@@ -285,8 +286,16 @@ __global__ __launch_bounds__(256) void bn_pm_finalize_bwd_kernel(const double *_
     const int cl = threadIdx.x & (PM_CG - 1), sl = threadIdx.x / PM_CG, c = blockIdx.x * PM_CG + cl;
     double ta, tq;
     if (!pm_sum_partials(partial, S, C, c, cl, sl, ta, tq)) return;
-    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)tq;
-    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)ta;
+    // accumulate: an atomic add — two network calls whose backward passes run side by side on two streams add into the same buffers
+    // (a zeroed buffer plus two addends gives the same bits in either order)
+    if (dgamma) {
+        if (accumulate) atomicAdd(dgamma + c, (float)tq);
+        else dgamma[c] = (float)tq;
+    }
+    if (dbeta) {
+        if (accumulate) atomicAdd(dbeta + c, (float)ta);
+        else dbeta[c] = (float)ta;
+    }
     fin[c * 4] = (float)(ta / (double)R);
     fin[c * 4 + 1] = (float)(tq / (double)R);
     fin[c * 4 + 2] = (gamma ? gamma[c] : 1.f) * invstd[c];
@@ -407,6 +416,14 @@ DVM_EXPORT size_t dvm_bn_pm_workspace_bytes(long R, int C) {
 DVM_EXPORT int dvm_bn_act_train_fwd_pm_f32(const float *x, const float *res, const float *gamma, const float *beta, long R, int C, float eps,
                                            float slope, float momentum, float *y, float *save_mean, float *save_invstd,
                                            float *running_mean, float *running_var, void *ws, size_t ws_bytes, void *stream) {
+    return dvm_bn_act_train_fwd_pm_var_f32(x, res, gamma, beta, R, C, eps, slope, momentum, y, save_mean, save_invstd, nullptr, running_mean,
+                                           running_var, ws, ws_bytes, stream);
+}
+
+DVM_EXPORT int dvm_bn_act_train_fwd_pm_var_f32(const float *x, const float *res, const float *gamma, const float *beta, long R, int C, float eps,
+                                               float slope, float momentum, float *y, float *save_mean, float *save_invstd,
+                                               float *save_var_unbiased, float *running_mean, float *running_var, void *ws, size_t ws_bytes,
+                                               void *stream) {
     DVM_REQUIRE(x && y && save_mean && save_invstd, "dvm_bn_act_train_fwd_pm_f32: null pointer");
     DVM_REQUIRE(R >= 1 && C >= 4 && C % 4 == 0 && C <= 1024, "dvm_bn_act_train_fwd_pm_f32: need R >= 1 and C a multiple of 4, at most 1024 (R=%ld C=%d)", R, C);
     DVM_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "dvm_bn_act_train_fwd_pm_f32: running_mean/var go together");
@@ -423,7 +440,7 @@ DVM_EXPORT int dvm_bn_act_train_fwd_pm_f32(const float *x, const float *res, con
     hipLaunchKernelGGL(bn_pm_reduce_kernel<false>, dim3(S, C / CG), dim3(256), 0, s, x, res, nullptr, nullptr, nullptr, nullptr, R, C, CG,
                        pm_chunk_for(R, C), slope, partial);
     hipLaunchKernelGGL(bn_pm_finalize_fwd_kernel, dim3((C + PM_CG - 1) / PM_CG), dim3(256), 0, s, partial, S, R, C, gamma, beta, eps, momentum, fin,
-                       save_mean, save_invstd, running_mean, running_var);
+                       save_mean, save_invstd, running_mean, running_var, save_var_unbiased);
     hipLaunchKernelGGL(bn_pm_apply_kernel<false>, dim3((unsigned)((R * C / 4 + 255) / 256)), dim3(256), 0, s, x, res, nullptr, nullptr, fin,
                        nullptr, nullptr, R, C, slope, y);
     DVM_CHECK_LAUNCH("bn_act_train_fwd_pm");
@@ -454,3 +471,34 @@ DVM_EXPORT int dvm_bn_act_train_bwd_pm_f32(const float *dy, const float *y, cons
     DVM_CHECK_LAUNCH("bn_act_train_bwd_pm");
     return DVM_OK;
 }
+
+// Deferred running-statistics update of up to 32 BatchNorms in one launch: running = (1 - momentum) running + momentum batch, the
+// expression (and roundings) of the fused forward kernel — for callers that ran the forward with running_mean == NULL (two network
+// calls side by side on two streams share every BatchNorm: their updates are applied afterwards, in the reference's call order).
+namespace dvm {
+namespace {
+struct RunUpd {
+    float *rm[32], *rv[32];
+    const float *mean[32], *var[32];
+    int C[32], count;
+};
+__global__ __launch_bounds__(256) void bn_running_update_kernel(const RunUpd u, float momentum) {
+    const int k = blockIdx.y;
+    if (k >= u.count) return;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < u.C[k]; c += gridDim.x * blockDim.x) {
+        u.rm[k][c] = (1.f - momentum) * u.rm[k][c] + momentum * u.mean[k][c];
+        u.rv[k][c] = (1.f - momentum) * u.rv[k][c] + momentum * u.var[k][c];
+    }
+}
+}  // namespace
+int launch_bn_running_update(float *const *rm, float *const *rv, const float *const *mean, const float *const *var, const int *C, int count,
+                             float momentum, hipStream_t s) {
+    for (int k0 = 0; k0 < count; k0 += 32) {
+        RunUpd u;
+        u.count = count - k0 < 32 ? count - k0 : 32;
+        for (int k = 0; k < u.count; ++k) u.rm[k] = rm[k0 + k], u.rv[k] = rv[k0 + k], u.mean[k] = mean[k0 + k], u.var[k] = var[k0 + k], u.C[k] = C[k0 + k];
+        hipLaunchKernelGGL(bn_running_update_kernel, dim3(2, u.count), dim3(256), 0, s, u, momentum);
+    }
+    return DVM_OK;
+}
+}  // namespace dvm

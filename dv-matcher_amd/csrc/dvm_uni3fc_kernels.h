@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float *__restri
     if (h == 0) {
         float tot = part[0][c];
         for (int k = 1; k < groups; ++k) tot += part[k][c];
-        out[c] += tot;
+        atomicAdd(out + c, tot);   // (atomic: see bn_pm_finalize_bwd_kernel — two calls' backward passes may run side by side)
     }
 }
 // The three C x C projection weights of the N2P blocks stacked as [q | k | v] (3C x C per block): packed copies for the forward /
@@ -259,7 +259,15 @@ __global__ __launch_bounds__(256) void stack_copy_kernel(const StackArgs a, int 
     if (m >= a.count) return;
     const f32x4 *s = (const f32x4 *)a.src[m];
     f32x4 *d = (f32x4 *)a.dst[m];
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n[m] / 4; i += gridDim.x * blockDim.x) d[i] = accumulate ? d[i] + s[i] : s[i];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n[m] / 4; i += gridDim.x * blockDim.x) {
+        if (accumulate) {
+            const f32x4 v = s[i];
+            float *o = (float *)(d + i);
+            atomicAdd(o, v.x), atomicAdd(o + 1, v.y), atomicAdd(o + 2, v.z), atomicAdd(o + 3, v.w);
+        } else {
+            d[i] = s[i];
+        }
+    }
 }
 
 inline unsigned blocks_for(long n, int cap = 4096) { return (unsigned)((n + 255) / 256 < cap ? (n + 255) / 256 : cap); }

@@ -23,6 +23,10 @@ void launch_linear(const float *x, const float *w, int B, int N, int K, int Co, 
                    const float *res, const float *alpha, const float *beta, float slope, float *y, hipStream_t s, const float *xg,
                    int Cg, const float *post_res, float post_scale);   // dvm_gemm.hip
 
+// dvm_bn.hip
+int launch_bn_running_update(float *const *rm, float *const *rv, const float *const *mean, const float *const *var, const int *C, int count,
+                             float momentum, hipStream_t s);
+
 namespace {
 
 // ---- parameter table (include/dvm.h, dvm_uni3fc_train_fwd_f32): raw trainable tensors + BatchNorm running statistics
@@ -40,7 +44,7 @@ constexpr int CONV_CO[8] = {384, 64, 512, 512, 128, 128, 128, 128};
 constexpr int NP_C[7] = {64, 64, 64, 64, 128, 128, 128};
 
 struct BnSave {
-    float *mean, *invstd;
+    float *mean, *invstd, *var;   // var: unbiased batch variance (for a deferred running-statistics update)
 };
 struct ConvSave {   // y = act(bn(z)), z = x W^T
     float *z, *y;
@@ -132,6 +136,7 @@ void carve(Arena &ar, int B, int N, int K, TrainWs &w) {
         w.cv[i].y = (i == 1 || i == 7) ? nullptr : ar.take<float>(R * CONV_CO[i]);   // tmp / feat live in the caller's tensors
         w.cv[i].bn.mean = ar.take<float>(CONV_CO[i]);
         w.cv[i].bn.invstd = ar.take<float>(CONV_CO[i]);
+        w.cv[i].bn.var = ar.take<float>(CONV_CO[i]);
     }
     for (int l = 0; l < 7; ++l) {
         const int C = NP_C[l];
@@ -144,8 +149,8 @@ void carve(Arena &ar, int B, int N, int K, TrainWs &w) {
         n.h = ar.take<float>(R * 4 * C);
         n.ffo = ar.take<float>(R * C);
         n.out = ar.take<float>(R * C);
-        n.bn1.mean = ar.take<float>(C), n.bn1.invstd = ar.take<float>(C);
-        n.bn2.mean = ar.take<float>(C), n.bn2.invstd = ar.take<float>(C);
+        n.bn1.mean = ar.take<float>(C), n.bn1.invstd = ar.take<float>(C), n.bn1.var = ar.take<float>(C);
+        n.bn2.mean = ar.take<float>(C), n.bn2.invstd = ar.take<float>(C), n.bn2.var = ar.take<float>(C);
         w.wqkv[l] = ar.take<float>((size_t)3 * C * C);
     }
     w.dwqkv_off = ar.off;
@@ -162,7 +167,7 @@ void carve(Arena &ar, int B, int N, int K, TrainWs &w) {
         a.t = ar.take<float>(R * 64);
         a.y = ar.take<float>(R * 64);
         a.out = ar.take<float>(R * 64);
-        a.bn.mean = ar.take<float>(64), a.bn.invstd = ar.take<float>(64);
+        a.bn.mean = ar.take<float>(64), a.bn.invstd = ar.take<float>(64), a.bn.var = ar.take<float>(64);
     }
     w.loc = ar.take<float>(R * 256);
     w.catL = ar.take<float>(R * 768);
@@ -191,13 +196,15 @@ struct Net {
     int B, N, K;
     long R;
     float eps, momentum;
+    bool defer_stats = false;   // leave the running statistics alone (dvm_uni3fc_train_running_stats_f32 applies the updates later)
     TrainWs w;
 };
 
 // ---------------------------------------------------------------- forward pieces
 int bn_fwd(const Net &n, const float *x, const float *res, const float *g, const float *b, float *rm, float *rv, int C, float slope, float *y,
            const BnSave &sv, const ChainScratch &c, hipStream_t s) {
-    return dvm_bn_act_train_fwd_pm_f32(x, res, g, b, n.R, C, n.eps, slope, n.momentum, y, sv.mean, sv.invstd, rm, rv, c.bnws, c.bn_bytes, s);
+    return dvm_bn_act_train_fwd_pm_var_f32(x, res, g, b, n.R, C, n.eps, slope, n.momentum, y, sv.mean, sv.invstd, sv.var, n.defer_stats ? nullptr : rm,
+                                           n.defer_stats ? nullptr : rv, c.bnws, c.bn_bytes, s);
 }
 
 // conv block i: y = leaky_0.2(bn(x W^T))
@@ -387,13 +394,14 @@ DVM_EXPORT size_t dvm_uni3fc_train_workspace_bytes(int B, int N, int k) {
 }
 
 DVM_EXPORT int dvm_uni3fc_train_fwd_f32(const float *xyz, const float *dino, int B, int N, const float *const *params, int nparams, int k, float eps,
-                                        float momentum, const int32_t *const *knn_forced, int32_t *const *knn_log, float *feat, float *tmp,
-                                        void *arena, size_t arena_bytes, void *stream) {
+                                        float momentum, int defer_running_stats, const int32_t *const *knn_forced, int32_t *const *knn_log,
+                                        float *feat, float *tmp, void *arena, size_t arena_bytes, void *stream) {
     DVM_REQUIRE(xyz && dino && params && feat && tmp, "dvm_uni3fc_train_fwd_f32: null pointer");
     T_TRY(check_args("dvm_uni3fc_train_fwd_f32", B, N, k, nparams, (const void *const *)params, false));
     Net n;
     n.P = params, n.G = nullptr, n.B = B, n.N = N, n.K = k, n.R = (long)B * N, n.eps = eps, n.momentum = momentum;
     n.knn_forced = knn_forced, n.knn_log = knn_log;
+    n.defer_stats = defer_running_stats != 0;
     Arena ar(arena, arena_bytes);
     carve(ar, B, N, k, n.w);
     if (!ar.ok()) {
@@ -572,5 +580,34 @@ DVM_EXPORT int dvm_uni3fc_train_bwd_f32(const float *g_feat, const float *g_tmp,
         hipLaunchKernelGGL(stack_copy_kernel, dim3(16, a.count), dim3(256), 0, s, a, 1);
     }
     DVM_CHECK_LAUNCH("uni3fc_train_bwd");
+    return DVM_OK;
+}
+
+// The running-statistics updates of one network call whose forward ran with defer_running_stats: 26 BatchNorms, one launch
+DVM_EXPORT int dvm_uni3fc_train_running_stats_f32(const float *const *params, int nparams, int B, int N, int k, float momentum, void *arena,
+                                                  size_t arena_bytes, void *stream) {
+    DVM_REQUIRE(params && arena, "dvm_uni3fc_train_running_stats_f32: null pointer");
+    T_TRY(check_args("dvm_uni3fc_train_running_stats_f32", B, N, k, nparams, (const void *const *)params, false));
+    TrainWs w;
+    Arena ar(arena, arena_bytes);
+    carve(ar, B, N, k, w);
+    if (!ar.ok()) {
+        set_error("dvm_uni3fc_train_running_stats_f32: arena too small (%zu < %zu)", arena_bytes, ar.off);
+        return DVM_ENOSPACE;
+    }
+    float *rm[26], *rv[26];
+    const float *mean[26], *var[26];
+    int C[26], n = 0;
+    auto add = [&](const float *const *p, int irm, int irv, const BnSave &sv, int c) {
+        rm[n] = (float *)p[irm], rv[n] = (float *)p[irv], mean[n] = sv.mean, var[n] = sv.var, C[n] = c, ++n;
+    };
+    for (int i = 0; i < 8; ++i) add(params + T_CONV0 + i * TC_N, TC_RM, TC_RV, w.cv[i].bn, CONV_CO[i]);
+    for (int l = 0; l < 4; ++l) add(params + T_SA0 + l * TS_N, TS_RM, TS_RV, w.sa[l].bn, 64);
+    for (int l = 0; l < 7; ++l) {
+        add(params + T_NP0 + l * TN_N, TN_RM1, TN_RV1, w.np[l].bn1, NP_C[l]);
+        add(params + T_NP0 + l * TN_N, TN_RM2, TN_RV2, w.np[l].bn2, NP_C[l]);
+    }
+    launch_bn_running_update(rm, rv, mean, var, C, n, momentum, (hipStream_t)stream);
+    DVM_CHECK_LAUNCH("uni3fc_train_running_stats");
     return DVM_OK;
 }

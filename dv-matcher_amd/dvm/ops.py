@@ -157,6 +157,15 @@ def set_deterministic(on=True):
     return prev
 
 
+def is_deterministic():
+    if _deterministic[0] is None:   # the library's own default (DVM_DETERMINISTIC)
+        lib = _lib.load()
+        prev = lib.dvm_set_deterministic(0)
+        lib.dvm_set_deterministic(prev)
+        _deterministic[0] = bool(prev)
+    return _deterministic[0]
+
+
 def linear_wgrad(gy, x, out=None):
     """dW = gy^T x over the rows: gy (R,Co), x (R,K) -> (Co,K) (dvm_linear_wgrad_f32; fp32 atomics over row chunks).
     With `out` (Co,K) the product is ADDED to it in place."""
@@ -911,7 +920,7 @@ def knn_tap():
     return None if inspect.isfunction(fn) else (fn if hasattr(fn, "log") and hasattr(fn, "forced") else None)
 
 
-def uni3fc_train_forward(params, x, dino, k, eps, momentum):
+def uni3fc_train_forward(params, x, dino, k, eps, momentum, defer_stats=False):
     """LG-Net's training-mode forward in ONE native call (dvm_uni3fc_train_fwd_f32).  params: the U3_TRAIN_NPARAMS tensors of
     include/dvm.h's table (raw parameters + BatchNorm running statistics, updated in place); x (B,3,N), dino (B,N,1152)
     -> feat (B,N,128), tmp (B,N,64), arena (uint8 tensor holding what dvm_uni3fc_train_bwd_f32 needs)."""
@@ -940,12 +949,22 @@ def uni3fc_train_forward(params, x, dino, k, eps, momentum):
                 raise DvmError("uni3fc_train_forward: forced neighbour sets must be (B, N, k)")
             ftab = ctypes.cast(_ptr_table(forced, 7), ctypes.c_void_p)
     check(lib.dvm_uni3fc_train_fwd_f32(_p(x), _p(dino), B, N, ctypes.cast(table, ctypes.c_void_p), U3_TRAIN_NPARAMS, int(k), float(eps),
-                                       float(momentum), ftab, ltab, _p(feat), _p(tmp), _p(arena), nb, _stream()), "dvm_uni3fc_train_fwd_f32")
+                                       float(momentum), 1 if defer_stats else 0, ftab, ltab, _p(feat), _p(tmp), _p(arena), nb, _stream()),
+          "dvm_uni3fc_train_fwd_f32")
     if tap is not None:
         tap.log.extend(logs)
         if forced is not None:
             tap.i += 7
     return feat, tmp, arena
+
+
+def uni3fc_train_running_stats(params, arena, B, N, k, momentum):
+    """The 26 running-statistics updates of a forward that ran with defer_stats=True (dvm_uni3fc_train_running_stats_f32), on the
+    current stream."""
+    lib = _lib.load()
+    table = _ptr_table(params, U3_TRAIN_NPARAMS)
+    check(lib.dvm_uni3fc_train_running_stats_f32(ctypes.cast(table, ctypes.c_void_p), U3_TRAIN_NPARAMS, int(B), int(N), int(k), float(momentum),
+                                                 _p(arena), arena.numel(), _stream()), "dvm_uni3fc_train_running_stats_f32")
 
 
 def uni3fc_train_backward(params, grads, dino, feat, tmp, arena, g_feat, g_tmp, k):

@@ -333,6 +333,11 @@ def _two_branches(x, main, side):
 
 
 def join_side_streams(device=None):
+    nn_ops.join_pair_streams(device)
+    _join_branch_streams(device)
+
+
+def _join_branch_streams(device=None):
     """Make the current stream wait for every helper stream `_two_branches` has used on `device`.  With the fused gradient
     accumulation (dvm.nn_ops.fuse_grad_accumulation) the weight-gradient kernels of the helper-stream chain write straight
     into `p.grad` during backward; autograd orders the caller's stream after them only through its leaf-stream
@@ -487,6 +492,28 @@ class Uni3FC(nn.Module, _VisualProjection):
             torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
         meta = ([t.detach() for t in ts], where, self.k, bns[0].eps, bns[0].momentum)
         return nn_ops.uni3fc_train(meta, x.contiguous(), dino_feat.contiguous(), trainable)
+
+    def forward_pair(self, x1, dino1, x2, dino2, upsampler=None):
+        """The two network calls of a training step (train.py:100-101: `Uni3FC(verts1^T, dino1)`, `Uni3FC(verts2^T, dino2)`) — same
+        results as calling forward twice.  In train mode on the native path the two calls run SIDE BY SIDE on two streams (forward
+        and, through autograd, backward), with the shared BatchNorms' running statistics updated afterwards in the reference's
+        call order; otherwise simply two calls.  -> ((feat1, cfeats1), (feat2, cfeats2)).
+        The side-by-side form is OPT-IN (DVM_PAIR_CALLS=1): measured on one MI355X it takes LG-Net's forward + backward alone from
+        14.2 to 13.1 ms at 2 x 8 x 2048 points, but the whole training step from 21.3 to 23.2 ms (with the criterion's three streams
+        and the geometry stream the process then drives ~10 streams through the runtime's 4 hardware queues)."""
+        native = (self.training and x1.is_cuda and dino1 is not None and dino2 is not None and os.environ.get("DVM_PAIR_CALLS", "0") == "1"
+                  and os.environ.get("DVM_TRAIN_LAYOUT", "pm") == "pm" and torch.is_grad_enabled()
+                  and all(type(m) is nn.BatchNorm1d for m in self.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm))
+                  and self._native_train_ok(x1, dino1) and self._native_train_ok(x2, dino2) and ops.knn_tap() is None
+                  and not ops.is_deterministic()    # (deterministic mode adds the ordered weight-gradient partials non-atomically)
+                  and not torch.cuda.is_current_stream_capturing())
+        if not native:
+            return self.forward(x1, dino1, upsampler), self.forward(x2, dino2, upsampler)
+        ts, where, trainable, bns = self._train_table()
+        with torch.no_grad():
+            torch._foreach_add_([m.num_batches_tracked for m in bns], 2)
+        meta = ([t.detach() for t in ts], where, self.k, bns[0].eps, bns[0].momentum)
+        return nn_ops.uni3fc_train_pair(meta, x1.contiguous(), dino1.contiguous(), x2.contiguous(), dino2.contiguous(), trainable)
 
     def _forward_train_pm(self, x, dino_feat):
         """Autograd forward with activations kept point-major (B,N,C), the layout dino_feat arrives in and the kNN /

@@ -317,6 +317,9 @@ def main(argv=None):
         # global chains already run on two streams (models/model.py:_two_branches)
         if (d1 is None or d2 is None) and upsampler is None:
             raise RuntimeError("the batch carries no visual features and no image backbone was built (use --random-feat for noise)")
+        if d1 is not None and d2 is not None and hasattr(net, "forward_pair"):   # (SyncBatchNorm-converted nets keep the method: it falls back itself)
+            (f1, _), (f2, _) = net.forward_pair(v1.permute(0, 2, 1), d1, v2.permute(0, 2, 1), d2, upsampler)
+            return f1, f2
         return net(v1.permute(0, 2, 1), d1, upsampler)[0], net(v2.permute(0, 2, 1), d2, upsampler)[0]
 
     host_marks = [0.0, 0.0, 0.0, 0.0, 0] if os.environ.get("DVM_STEP_BREAKDOWN", "0") == "1" else None   # host seconds per phase

@@ -291,6 +291,13 @@ size_t dvm_bn_pm_workspace_bytes(long R, int C);
 int dvm_bn_act_train_fwd_pm_f32(const float *x, const float *res, const float *gamma, const float *beta, long R, int C, float eps,
                                 float slope, float momentum, float *y, float *save_mean, float *save_invstd, float *running_mean,
                                 float *running_var, void *ws, size_t ws_bytes, void *stream);
+/* The same forward that also returns the UNBIASED batch variance (save_var_unbiased [C], may be NULL): with running_mean ==
+ * running_var == NULL the running statistics are left alone and can be updated later from (save_mean, save_var_unbiased) with
+ * exactly the fused kernel's expression — dvm_uni3fc_train_running_stats_f32 does so for a whole network call. */
+int dvm_bn_act_train_fwd_pm_var_f32(const float *x, const float *res, const float *gamma, const float *beta, long R, int C, float eps,
+                                    float slope, float momentum, float *y, float *save_mean, float *save_invstd,
+                                    float *save_var_unbiased, float *running_mean, float *running_var, void *ws, size_t ws_bytes,
+                                    void *stream);
 int dvm_bn_act_train_bwd_pm_f32(const float *dy, const float *y, const float *x, const float *res, const float *gamma,
                                 const float *save_mean, const float *save_invstd, long R, int C, float slope, float *dx,
                                 float *dgamma, float *dbeta, int accumulate, void *ws, size_t ws_bytes, void *stream);
@@ -473,8 +480,11 @@ int dvm_uni3fc_fwd_f32(const float *xyz, const float *dino, int B, int N, const 
  * dv-matcher_amd/models/model.py::Uni3FC._forward_train_pm and the autograd graph it records, enqueued natively.
  * fwd: xyz [B][3][N], dino [B][N][1152] -> feat [B][N][128], tmp [B][N][64]; every activation the backward needs is
  *      written into `arena` (dvm_uni3fc_train_workspace_bytes(B, N, k) bytes, caller-owned, must stay untouched until
- *      the matching bwd); running_mean / running_var get PyTorch's momentum update (unbiased variance); the
- *      num_batches_tracked counters are the caller's business.  knn_forced / knn_log (each NULL or 7 device pointers
+ *      the matching bwd); running_mean / running_var get PyTorch's momentum update (unbiased variance) — or, with
+ *      defer_running_stats != 0, are left alone: the batch statistics stay in the arena and
+ *      dvm_uni3fc_train_running_stats_f32(params, arena) applies the 26 updates later in one launch (two network calls
+ *      that run side by side on two streams share every BatchNorm; their updates are applied afterwards in the
+ *      reference's call order, train.py:100-101); the num_batches_tracked counters are the caller's business.  knn_forced / knn_log (each NULL or 7 device pointers
  *      [B][N][k] int32, entries may be NULL) are the parity tests' handles on the 7 feature-space kNN layers: the
  *      library's own neighbour sets are copied to knn_log[l], and knn_forced[l], when given, is what the layer and
  *      its backward then use (teacher forcing: the discrete sets of the reference, tests/test_gpu_network.py).
@@ -494,8 +504,10 @@ int dvm_uni3fc_fwd_f32(const float *xyz, const float *dino, int B, int N, const 
 #define DVM_U3_TRAIN_NPARAMS 167
 size_t dvm_uni3fc_train_workspace_bytes(int B, int N, int k);
 int dvm_uni3fc_train_fwd_f32(const float *xyz, const float *dino, int B, int N, const float *const *params, int nparams, int k,
-                             float eps, float momentum, const int32_t *const *knn_forced, int32_t *const *knn_log, float *feat,
-                             float *tmp, void *arena, size_t arena_bytes, void *stream);
+                             float eps, float momentum, int defer_running_stats, const int32_t *const *knn_forced,
+                             int32_t *const *knn_log, float *feat, float *tmp, void *arena, size_t arena_bytes, void *stream);
+int dvm_uni3fc_train_running_stats_f32(const float *const *params, int nparams, int B, int N, int k, float momentum, void *arena,
+                                       size_t arena_bytes, void *stream);
 int dvm_uni3fc_train_bwd_f32(const float *g_feat, const float *g_tmp, const float *dino, const float *feat, const float *tmp,
                              int B, int N, const float *const *params, float *const *grads, int nparams, int k, void *arena,
                              size_t arena_bytes, void *stream);

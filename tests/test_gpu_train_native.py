@@ -182,3 +182,43 @@ def test_deterministic_switch_gives_bit_reproducible_gradients(native):
     ref, g0 = grads()                                   # default mode
     worst = max(float((u - v).abs().max()) / (float(v.abs().max()) + 1e-30) for u, v in zip(g1, g0) if float(v.abs().max()) > 1e-3)
     assert worst < 1e-3, worst
+
+
+def test_forward_pair_equals_two_calls():
+    """Uni3FC.forward_pair — the step's two network calls side by side on two streams, running statistics deferred and applied in
+    call order — against two sequential forward() calls on an identical copy: features, second outputs, running statistics
+    and batch counters bit-identical; parameter gradients (both backward passes adding into one flat bucket, concurrently) to
+    summation-order noise."""
+    from dvm import nn_ops
+    from dvm.dist import FlatGradBucket
+    import models.model as mm
+    a, b = _nets(40, seed=7, gain=0.5)
+    x1, d1 = _inputs(4, 1024, 31)
+    x2, d2 = _inputs(4, 1024, 32)
+    g = torch.Generator().manual_seed(9)
+    gf1, gf2 = torch.randn(4, 1024, 128, generator=g).cuda(), torch.randn(4, 1024, 128, generator=g).cuda()
+    ba, bb = FlatGradBucket(list(a.parameters()), attach=True), FlatGradBucket(list(b.parameters()), attach=True)
+    prev = nn_ops.fuse_grad_accumulation(True)
+    try:
+        for _ in range(2):   # twice: the second round reuses the pair streams and the caching allocator's blocks
+            ba.zero(), bb.zero()
+            os.environ["DVM_PAIR_CALLS"] = "1"      # (opt-in: see Uni3FC.forward_pair)
+            try:
+                (f1, t1), (f2, t2) = a.forward_pair(x1, d1, x2, d2)
+            finally:
+                os.environ.pop("DVM_PAIR_CALLS", None)
+            assert type(f1.grad_fn).__name__ == "_Uni3FCTrainBackward"
+            ((f1 * gf1).sum() + (f2 * gf2).sum() + t1.sum()).backward()
+            mm.join_side_streams(torch.device("cuda", 0))
+            os.environ["DVM_PAIR_CALLS"] = "0"
+            try:
+                (g1, u1), (g2, u2) = b.forward_pair(x1, d1, x2, d2)
+                ((g1 * gf1).sum() + (g2 * gf2).sum() + u1.sum()).backward()
+                mm.join_side_streams(torch.device("cuda", 0))
+            finally:
+                os.environ.pop("DVM_PAIR_CALLS", None)
+            torch.cuda.synchronize()
+            assert torch.equal(f1, g1) and torch.equal(f2, g2) and torch.equal(t1, u1) and torch.equal(t2, u2)
+            _compare(a, b, 2e-4)
+    finally:
+        nn_ops.fuse_grad_accumulation(prev)
