@@ -43,6 +43,7 @@ constexpr int CONV_K[8] = {1152, 384, 256, 256, 768, 768, 256, 512};
 constexpr int CONV_CO[8] = {384, 64, 512, 512, 128, 128, 128, 128};
 constexpr int NP_C[7] = {64, 64, 64, 64, 128, 128, 128};
 
+constexpr int MAXG = 2;   // groups (merged network calls) per native call
 struct BnSave {
     float *mean, *invstd, *var;   // var: unbiased batch variance (for a deferred running-statistics update)
 };
@@ -85,10 +86,11 @@ struct TrainWs {
 void carve_chain(Arena &ar, int B, int N, int K, ChainScratch &c, bool local) {
     const size_t R = (size_t)B * N;
     c.bn_bytes = 0;
-    for (int C : {64, 128, 384, 512}) {
-        const size_t b = dvm_bn_pm_workspace_bytes((long)R, C);
-        c.bn_bytes = b > c.bn_bytes ? b : c.bn_bytes;
-    }
+    for (int C : {64, 128, 384, 512})
+        for (long rows : {(long)R, (long)R / MAXG}) {   // (a group of a merged call has its own, shorter reduction)
+            const size_t b = dvm_bn_pm_workspace_bytes(rows > 0 ? rows : 1, C);
+            c.bn_bytes = b > c.bn_bytes ? b : c.bn_bytes;
+        }
     c.bnws = ar.take<char>(c.bn_bytes);
     c.knn_bytes = local ? dvm_knn_neg_workspace_bytes(B, N, N, 128, K) : 0;
     c.knnws = local ? (void *)ar.take<char>(c.knn_bytes) : nullptr;
@@ -134,9 +136,9 @@ void carve(Arena &ar, int B, int N, int K, TrainWs &w) {
     for (int i = 0; i < 8; ++i) {
         w.cv[i].z = ar.take<float>(R * CONV_CO[i]);
         w.cv[i].y = (i == 1 || i == 7) ? nullptr : ar.take<float>(R * CONV_CO[i]);   // tmp / feat live in the caller's tensors
-        w.cv[i].bn.mean = ar.take<float>(CONV_CO[i]);
-        w.cv[i].bn.invstd = ar.take<float>(CONV_CO[i]);
-        w.cv[i].bn.var = ar.take<float>(CONV_CO[i]);
+        w.cv[i].bn.mean = ar.take<float>(MAXG * CONV_CO[i]);
+        w.cv[i].bn.invstd = ar.take<float>(MAXG * CONV_CO[i]);
+        w.cv[i].bn.var = ar.take<float>(MAXG * CONV_CO[i]);
     }
     for (int l = 0; l < 7; ++l) {
         const int C = NP_C[l];
@@ -149,8 +151,8 @@ void carve(Arena &ar, int B, int N, int K, TrainWs &w) {
         n.h = ar.take<float>(R * 4 * C);
         n.ffo = ar.take<float>(R * C);
         n.out = ar.take<float>(R * C);
-        n.bn1.mean = ar.take<float>(C), n.bn1.invstd = ar.take<float>(C), n.bn1.var = ar.take<float>(C);
-        n.bn2.mean = ar.take<float>(C), n.bn2.invstd = ar.take<float>(C), n.bn2.var = ar.take<float>(C);
+        n.bn1.mean = ar.take<float>(MAXG * C), n.bn1.invstd = ar.take<float>(MAXG * C), n.bn1.var = ar.take<float>(MAXG * C);
+        n.bn2.mean = ar.take<float>(MAXG * C), n.bn2.invstd = ar.take<float>(MAXG * C), n.bn2.var = ar.take<float>(MAXG * C);
         w.wqkv[l] = ar.take<float>((size_t)3 * C * C);
     }
     w.dwqkv_off = ar.off;
@@ -167,7 +169,7 @@ void carve(Arena &ar, int B, int N, int K, TrainWs &w) {
         a.t = ar.take<float>(R * 64);
         a.y = ar.take<float>(R * 64);
         a.out = ar.take<float>(R * 64);
-        a.bn.mean = ar.take<float>(64), a.bn.invstd = ar.take<float>(64), a.bn.var = ar.take<float>(64);
+        a.bn.mean = ar.take<float>(MAXG * 64), a.bn.invstd = ar.take<float>(MAXG * 64), a.bn.var = ar.take<float>(MAXG * 64);
     }
     w.loc = ar.take<float>(R * 256);
     w.catL = ar.take<float>(R * 768);
@@ -190,11 +192,13 @@ void carve(Arena &ar, int B, int N, int K, TrainWs &w) {
 
 struct Net {
     const float *const *P;   // parameters
-    float *const *G;         // gradients (backward; entries of running statistics unused)
+    float *const *GR;        // gradients (backward; entries of running statistics unused)
     const int32_t *const *knn_forced = nullptr;   // per N2P block: neighbour sets to use instead of the library's own (tests)
     int32_t *const *knn_log = nullptr;            // per N2P block: receives the library's own sets (tests)
-    int B, N, K;
-    long R;
+    int B, N, K;   // B: ALL shapes of the call (groups x shapes per group)
+    int G = 1;     // groups: network calls of the reference merged into this one (each with its own BatchNorm statistics and
+                   // position-encoding range, exactly as if it had been a call of its own); rows of group g: [g Rg, (g + 1) Rg)
+    long R, Rg;
     float eps, momentum;
     bool defer_stats = false;   // leave the running statistics alone (dvm_uni3fc_train_running_stats_f32 applies the updates later)
     TrainWs w;
@@ -203,8 +207,13 @@ struct Net {
 // ---------------------------------------------------------------- forward pieces
 int bn_fwd(const Net &n, const float *x, const float *res, const float *g, const float *b, float *rm, float *rv, int C, float slope, float *y,
            const BnSave &sv, const ChainScratch &c, hipStream_t s) {
-    return dvm_bn_act_train_fwd_pm_var_f32(x, res, g, b, n.R, C, n.eps, slope, n.momentum, y, sv.mean, sv.invstd, sv.var, n.defer_stats ? nullptr : rm,
-                                           n.defer_stats ? nullptr : rv, c.bnws, c.bn_bytes, s);
+    for (int q = 0; q < n.G; ++q) {   // per group: its own batch statistics; the running statistics take the groups' updates in order
+        const size_t o = (size_t)q * n.Rg * C;
+        T_TRY(dvm_bn_act_train_fwd_pm_var_f32(x + o, res ? res + o : nullptr, g, b, n.Rg, C, n.eps, slope, n.momentum, y + o, sv.mean + q * C,
+                                              sv.invstd + q * C, sv.var + q * C, n.defer_stats ? nullptr : rm, n.defer_stats ? nullptr : rv, c.bnws,
+                                              c.bn_bytes, s));
+    }
+    return DVM_OK;
 }
 
 // conv block i: y = leaky_0.2(bn(x W^T))
@@ -267,7 +276,12 @@ void max_prefix(const Net &n, const float *wide, const float *x, unsigned long l
 // ---------------------------------------------------------------- backward pieces
 int bn_bwd(const Net &n, const float *dy, const float *y, const float *x, const float *res, const float *g, const BnSave &sv, int C, float slope,
            float *dx, float *dg, float *db, const ChainScratch &c, hipStream_t s) {
-    return dvm_bn_act_train_bwd_pm_f32(dy, y, x, res, g, sv.mean, sv.invstd, n.R, C, slope, dx, dg, db, 1, c.bnws, c.bn_bytes, s);
+    for (int q = 0; q < n.G; ++q) {
+        const size_t o = (size_t)q * n.Rg * C;
+        T_TRY(dvm_bn_act_train_bwd_pm_f32(dy + o, y + o, x + o, res ? res + o : nullptr, g, sv.mean + q * C, sv.invstd + q * C, n.Rg, C, slope, dx + o, dg,
+                                          db, 1, c.bnws, c.bn_bytes, s));
+    }
+    return DVM_OK;
 }
 // dX [R][K] = dY [R][Co] W [Co][K]  (+ res): dvm_linear_f32 with the operands' roles swapped
 int dgrad(const Net &n, const float *dy, const float *W, int Co, int K, const float *res, float *dx, hipStream_t s) {
@@ -292,7 +306,7 @@ void slice_add(const float *src, int ld, int off, const float *add, long rows, i
 int conv_bwd(const Net &n, int i, const float *dy, const float *y, const float *x, float *dz, const float *dx_res, float *dx, const ChainScratch &c,
              hipStream_t s) {
     const float *const *p = n.P + T_CONV0 + i * TC_N;
-    float *const *g = n.G + T_CONV0 + i * TC_N;
+    float *const *g = n.GR + T_CONV0 + i * TC_N;
     const ConvSave &cv = n.w.cv[i];
     T_TRY(bn_bwd(n, dy, y, cv.z, nullptr, p[TC_G], cv.bn, CONV_CO[i], 0.2f, dz, g[TC_G], g[TC_B], c, s));
     T_TRY(wgrad(n, dz, x, CONV_CO[i], CONV_K[i], g[TC_W], c, s));
@@ -303,7 +317,7 @@ int conv_bwd(const Net &n, int i, const float *dy, const float *y, const float *
 // N2P block l backward: g_out (R,C) -> dx (R,C) (gradient w.r.t. the block's input); g_out may alias nothing of the scratch used here
 int n2p_bwd(const Net &n, int l, const float *xin, const float *g_out, float *dx, const ChainScratch &c, hipStream_t s) {
     const float *const *p = n.P + T_NP0 + l * TN_N;
-    float *const *g = n.G + T_NP0 + l * TN_N;
+    float *const *g = n.GR + T_NP0 + l * TN_N;
     const NpSave &sv = n.w.np[l];
     const int C = NP_C[l];
     float *dz = c.gc, *dx1 = c.gd, *din = c.ge;
@@ -324,7 +338,7 @@ int n2p_bwd(const Net &n, int l, const float *xin, const float *g_out, float *dx
 // SA_Layer l backward: g_out (R,64) -> dx (R,64)
 int sa_bwd(const Net &n, int l, const float *xin, const float *g_out, float *dx, const ChainScratch &c, hipStream_t s) {
     const float *const *p = n.P + T_SA0 + l * TS_N;
-    float *const *g = n.G + T_SA0 + l * TS_N;
+    float *const *g = n.GR + T_SA0 + l * TS_N;
     const SaSave &sv = n.w.sa[l];
     const long n4 = n.R * 16;
     float *dt = c.gc, *dd = c.gd, *ssum = c.ge, *ngx = c.gc;   // dt is dead once dd, dWt, dbt are formed
@@ -364,6 +378,10 @@ struct Fork {
     }
 };
 
+int check_groups(const char *who, int B, int groups) {
+    DVM_REQUIRE(groups >= 1 && groups <= MAXG && B % groups == 0, "%s: %d shapes cannot be split into %d groups (1..%d)", who, B, groups, MAXG);
+    return DVM_OK;
+}
 int check_args(const char *who, int B, int N, int k, int nparams, const void *const *tab, bool grads) {
     DVM_REQUIRE(nparams == DVM_U3_TRAIN_NPARAMS, "%s: the table has %d entries, expected %d", who, nparams, DVM_U3_TRAIN_NPARAMS);
     DVM_REQUIRE(B >= 1 && N >= 1 && k >= 1 && k <= 64 && k <= N, "%s: bad sizes (B=%d N=%d k=%d)", who, B, N, k);
@@ -394,12 +412,14 @@ DVM_EXPORT size_t dvm_uni3fc_train_workspace_bytes(int B, int N, int k) {
 }
 
 DVM_EXPORT int dvm_uni3fc_train_fwd_f32(const float *xyz, const float *dino, int B, int N, const float *const *params, int nparams, int k, float eps,
-                                        float momentum, int defer_running_stats, const int32_t *const *knn_forced, int32_t *const *knn_log,
-                                        float *feat, float *tmp, void *arena, size_t arena_bytes, void *stream) {
+                                        float momentum, int groups, int defer_running_stats, const int32_t *const *knn_forced,
+                                        int32_t *const *knn_log, float *feat, float *tmp, void *arena, size_t arena_bytes, void *stream) {
     DVM_REQUIRE(xyz && dino && params && feat && tmp, "dvm_uni3fc_train_fwd_f32: null pointer");
     T_TRY(check_args("dvm_uni3fc_train_fwd_f32", B, N, k, nparams, (const void *const *)params, false));
     Net n;
-    n.P = params, n.G = nullptr, n.B = B, n.N = N, n.K = k, n.R = (long)B * N, n.eps = eps, n.momentum = momentum;
+    T_TRY(check_groups("dvm_uni3fc_train_fwd_f32", B, groups));
+    n.P = params, n.GR = nullptr, n.B = B, n.N = N, n.K = k, n.R = (long)B * N, n.eps = eps, n.momentum = momentum;
+    n.G = groups, n.Rg = n.R / groups;
     n.knn_forced = knn_forced, n.knn_log = knn_log;
     n.defer_stats = defer_running_stats != 0;
     Arena ar(arena, arena_bytes);
@@ -430,7 +450,9 @@ DVM_EXPORT int dvm_uni3fc_train_fwd_f32(const float *xyz, const float *dino, int
     }
     // f = blk(conv, dino); tmp = blk(conv0, f + pos_encoding(x)^T)
     T_TRY(conv_fwd(n, 0, dino, w.cv[0].y, c0, s));
-    T_TRY(dvm_pos_encoding_f32(xyz, B, N, w.pe, w.pews, dvm_pos_encoding_workspace_bytes(), s));
+    for (int q = 0; q < n.G; ++q)   // the encoding normalises with the min / max over ONE call's tensor (models/model.py:548)
+        T_TRY(dvm_pos_encoding_f32(xyz + (size_t)q * (B / n.G) * 3 * N, B / n.G, N, w.pe + (size_t)q * n.Rg * 384, w.pews,
+                                   dvm_pos_encoding_workspace_bytes(), s));
     (void)hipMemcpyAsync(w.fpe, w.cv[0].y, (size_t)R * 384 * sizeof(float), hipMemcpyDeviceToDevice, s);
     hipLaunchKernelGGL(add_transposed_kernel, dim3((N + 31) / 32, 384 / 32, B), dim3(256), 0, s, w.fpe, w.pe, N, 384);
     T_TRY(conv_fwd(n, 1, w.fpe, tmp, c0, s));
@@ -482,13 +504,15 @@ DVM_EXPORT int dvm_uni3fc_train_fwd_f32(const float *xyz, const float *dino, int
 }
 
 DVM_EXPORT int dvm_uni3fc_train_bwd_f32(const float *g_feat, const float *g_tmp, const float *dino, const float *feat, const float *tmp, int B, int N,
-                                        const float *const *params, float *const *grads, int nparams, int k, void *arena, size_t arena_bytes,
-                                        void *stream) {
+                                        const float *const *params, float *const *grads, int nparams, int k, int groups, void *arena,
+                                        size_t arena_bytes, void *stream) {
     DVM_REQUIRE(g_feat && dino && feat && tmp && params && grads, "dvm_uni3fc_train_bwd_f32: null pointer");
     T_TRY(check_args("dvm_uni3fc_train_bwd_f32", B, N, k, nparams, (const void *const *)params, false));
     T_TRY(check_args("dvm_uni3fc_train_bwd_f32 (gradients)", B, N, k, nparams, (const void *const *)grads, true));
     Net n;
-    n.P = params, n.G = grads, n.B = B, n.N = N, n.K = k, n.R = (long)B * N, n.eps = 0.f, n.momentum = 0.f;
+    T_TRY(check_groups("dvm_uni3fc_train_bwd_f32", B, groups));
+    n.P = params, n.GR = grads, n.B = B, n.N = N, n.K = k, n.R = (long)B * N, n.eps = 0.f, n.momentum = 0.f;
+    n.G = groups, n.Rg = n.R / groups;
     Arena ar(arena, arena_bytes);
     carve(ar, B, N, k, n.w);
     if (!ar.ok()) {
@@ -584,9 +608,10 @@ DVM_EXPORT int dvm_uni3fc_train_bwd_f32(const float *g_feat, const float *g_tmp,
 }
 
 // The running-statistics updates of one network call whose forward ran with defer_running_stats: 26 BatchNorms, one launch
-DVM_EXPORT int dvm_uni3fc_train_running_stats_f32(const float *const *params, int nparams, int B, int N, int k, float momentum, void *arena,
-                                                  size_t arena_bytes, void *stream) {
+DVM_EXPORT int dvm_uni3fc_train_running_stats_f32(const float *const *params, int nparams, int B, int N, int k, int groups, float momentum,
+                                                  void *arena, size_t arena_bytes, void *stream) {
     DVM_REQUIRE(params && arena, "dvm_uni3fc_train_running_stats_f32: null pointer");
+    T_TRY(check_groups("dvm_uni3fc_train_running_stats_f32", B, groups));
     T_TRY(check_args("dvm_uni3fc_train_running_stats_f32", B, N, k, nparams, (const void *const *)params, false));
     TrainWs w;
     Arena ar(arena, arena_bytes);
@@ -607,7 +632,11 @@ DVM_EXPORT int dvm_uni3fc_train_running_stats_f32(const float *const *params, in
         add(params + T_NP0 + l * TN_N, TN_RM1, TN_RV1, w.np[l].bn1, NP_C[l]);
         add(params + T_NP0 + l * TN_N, TN_RM2, TN_RV2, w.np[l].bn2, NP_C[l]);
     }
-    launch_bn_running_update(rm, rv, mean, var, C, n, momentum, (hipStream_t)stream);
+    for (int q = 0; q < groups; ++q) {   // one launch per group, in order: the second group's update builds on the first's
+        const float *mq[26], *vq[26];
+        for (int i = 0; i < n; ++i) mq[i] = mean[i] + q * C[i], vq[i] = var[i] + q * C[i];
+        launch_bn_running_update(rm, rv, mq, vq, C, n, momentum, (hipStream_t)stream);
+    }
     DVM_CHECK_LAUNCH("uni3fc_train_running_stats");
     return DVM_OK;
 }

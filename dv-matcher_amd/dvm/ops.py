@@ -920,7 +920,7 @@ def knn_tap():
     return None if inspect.isfunction(fn) else (fn if hasattr(fn, "log") and hasattr(fn, "forced") else None)
 
 
-def uni3fc_train_forward(params, x, dino, k, eps, momentum, defer_stats=False):
+def uni3fc_train_forward(params, x, dino, k, eps, momentum, defer_stats=False, groups=1):
     """LG-Net's training-mode forward in ONE native call (dvm_uni3fc_train_fwd_f32).  params: the U3_TRAIN_NPARAMS tensors of
     include/dvm.h's table (raw parameters + BatchNorm running statistics, updated in place); x (B,3,N), dino (B,N,1152)
     -> feat (B,N,128), tmp (B,N,64), arena (uint8 tensor holding what dvm_uni3fc_train_bwd_f32 needs)."""
@@ -949,7 +949,7 @@ def uni3fc_train_forward(params, x, dino, k, eps, momentum, defer_stats=False):
                 raise DvmError("uni3fc_train_forward: forced neighbour sets must be (B, N, k)")
             ftab = ctypes.cast(_ptr_table(forced, 7), ctypes.c_void_p)
     check(lib.dvm_uni3fc_train_fwd_f32(_p(x), _p(dino), B, N, ctypes.cast(table, ctypes.c_void_p), U3_TRAIN_NPARAMS, int(k), float(eps),
-                                       float(momentum), 1 if defer_stats else 0, ftab, ltab, _p(feat), _p(tmp), _p(arena), nb, _stream()),
+                                       float(momentum), int(groups), 1 if defer_stats else 0, ftab, ltab, _p(feat), _p(tmp), _p(arena), nb, _stream()),
           "dvm_uni3fc_train_fwd_f32")
     if tap is not None:
         tap.log.extend(logs)
@@ -958,16 +958,16 @@ def uni3fc_train_forward(params, x, dino, k, eps, momentum, defer_stats=False):
     return feat, tmp, arena
 
 
-def uni3fc_train_running_stats(params, arena, B, N, k, momentum):
+def uni3fc_train_running_stats(params, arena, B, N, k, momentum, groups=1):
     """The 26 running-statistics updates of a forward that ran with defer_stats=True (dvm_uni3fc_train_running_stats_f32), on the
     current stream."""
     lib = _lib.load()
     table = _ptr_table(params, U3_TRAIN_NPARAMS)
-    check(lib.dvm_uni3fc_train_running_stats_f32(ctypes.cast(table, ctypes.c_void_p), U3_TRAIN_NPARAMS, int(B), int(N), int(k), float(momentum),
+    check(lib.dvm_uni3fc_train_running_stats_f32(ctypes.cast(table, ctypes.c_void_p), U3_TRAIN_NPARAMS, int(B), int(N), int(k), int(groups), float(momentum),
                                                  _p(arena), arena.numel(), _stream()), "dvm_uni3fc_train_running_stats_f32")
 
 
-def uni3fc_train_backward(params, grads, dino, feat, tmp, arena, g_feat, g_tmp, k):
+def uni3fc_train_backward(params, grads, dino, feat, tmp, arena, g_feat, g_tmp, k, groups=1):
     """dvm_uni3fc_train_bwd_f32: ADDS the parameter gradients into `grads` (tensors aligned with `params`; None for the
     running statistics)."""
     _need_gpu(g_feat, dino)
@@ -978,7 +978,7 @@ def uni3fc_train_backward(params, grads, dino, feat, tmp, arena, g_feat, g_tmp, 
     g_tmp = None if g_tmp is None else _f(g_tmp)
     ptab, gtab = _ptr_table(params, U3_TRAIN_NPARAMS), _ptr_table(grads, U3_TRAIN_NPARAMS)
     check(lib.dvm_uni3fc_train_bwd_f32(_p(g_feat), _p(g_tmp), _p(dino), _p(feat), _p(tmp), B, N, ctypes.cast(ptab, ctypes.c_void_p),
-                                       ctypes.cast(gtab, ctypes.c_void_p), U3_TRAIN_NPARAMS, int(k), _p(arena), arena.numel(), _stream()),
+                                       ctypes.cast(gtab, ctypes.c_void_p), U3_TRAIN_NPARAMS, int(k), int(groups), _p(arena), arena.numel(), _stream()),
           "dvm_uni3fc_train_bwd_f32")
 
 

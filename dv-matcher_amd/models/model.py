@@ -501,18 +501,25 @@ class Uni3FC(nn.Module, _VisualProjection):
         The side-by-side form is OPT-IN (DVM_PAIR_CALLS=1): measured on one MI355X it takes LG-Net's forward + backward alone from
         14.2 to 13.1 ms at 2 x 8 x 2048 points, but the whole training step from 21.3 to 23.2 ms (with the criterion's three streams
         and the geometry stream the process then drives ~10 streams through the runtime's 4 hardware queues)."""
-        native = (self.training and x1.is_cuda and dino1 is not None and dino2 is not None and os.environ.get("DVM_PAIR_CALLS", "0") == "1"
+        # DVM_PAIR_CALLS: "merged" (default where both shapes have the same point count) = ONE native call with two groups;
+        # "1" = two calls side by side on two streams (opt-in, below); "0" = two calls one after the other
+        mode = os.environ.get("DVM_PAIR_CALLS", "merged")
+        if mode == "merged" and (dino1 is None or dino2 is None or tuple(x1.shape) != tuple(x2.shape)):
+            mode = "0"
+        native = (self.training and x1.is_cuda and dino1 is not None and dino2 is not None and mode in ("1", "merged")
                   and os.environ.get("DVM_TRAIN_LAYOUT", "pm") == "pm" and torch.is_grad_enabled()
                   and all(type(m) is nn.BatchNorm1d for m in self.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm))
                   and self._native_train_ok(x1, dino1) and self._native_train_ok(x2, dino2) and ops.knn_tap() is None
-                  and not ops.is_deterministic()    # (deterministic mode adds the ordered weight-gradient partials non-atomically)
-                  and not torch.cuda.is_current_stream_capturing())
+                  and (mode == "merged" or (not ops.is_deterministic()    # (deterministic mode adds the ordered weight-gradient partials non-atomically)
+                                            and not torch.cuda.is_current_stream_capturing())))
         if not native:
             return self.forward(x1, dino1, upsampler), self.forward(x2, dino2, upsampler)
         ts, where, trainable, bns = self._train_table()
         with torch.no_grad():
             torch._foreach_add_([m.num_batches_tracked for m in bns], 2)
         meta = ([t.detach() for t in ts], where, self.k, bns[0].eps, bns[0].momentum)
+        if mode == "merged":
+            return nn_ops.uni3fc_train_merged(meta, x1, dino1, x2, dino2, trainable)
         return nn_ops.uni3fc_train_pair(meta, x1.contiguous(), dino1.contiguous(), x2.contiguous(), dino2.contiguous(), trainable)
 
     def _forward_train_pm(self, x, dino_feat):

@@ -492,6 +492,10 @@ int dvm_uni3fc_fwd_f32(const float *xyz, const float *dino, int B, int N, const 
  *      parameter gradients ADDED into grads[i] (same indexing as params; entries of running statistics ignored, may
  *      be NULL).  Inputs carry no gradient (the reference feeds data tensors).  Weight gradients are combined with
  *      fp32 atomics over row chunks (dvm_linear_wgrad_f32); bias / BatchNorm gradients in a fixed order.
+ * groups (1 or 2): SEVERAL network calls of the reference in one — the B shapes are `groups` consecutive blocks of B / groups
+ *      shapes, each with its own BatchNorm batch statistics and position-encoding range (and the running statistics updated
+ *      block after block), i.e. exactly the results of `groups` separate calls (the criterion calls the network once per shape
+ *      of a pair, train.py:100-101: same point count -> ONE call with groups = 2, every row-wise kernel over twice the rows).
  * With a context from dvm_pair_init(stream) the global (self-attention) chain runs on the helper stream in both passes.
  * `params`: DVM_U3_TRAIN_NPARAMS device pointers, fp32, in this order:
  *   8 conv blocks {W [Co][K], bn gamma, bn beta, running_mean, running_var}: conv, conv0 .. conv6            [0 .. 39]
@@ -504,13 +508,13 @@ int dvm_uni3fc_fwd_f32(const float *xyz, const float *dino, int B, int N, const 
 #define DVM_U3_TRAIN_NPARAMS 167
 size_t dvm_uni3fc_train_workspace_bytes(int B, int N, int k);
 int dvm_uni3fc_train_fwd_f32(const float *xyz, const float *dino, int B, int N, const float *const *params, int nparams, int k,
-                             float eps, float momentum, int defer_running_stats, const int32_t *const *knn_forced,
+                             float eps, float momentum, int groups, int defer_running_stats, const int32_t *const *knn_forced,
                              int32_t *const *knn_log, float *feat, float *tmp, void *arena, size_t arena_bytes, void *stream);
-int dvm_uni3fc_train_running_stats_f32(const float *const *params, int nparams, int B, int N, int k, float momentum, void *arena,
-                                       size_t arena_bytes, void *stream);
+int dvm_uni3fc_train_running_stats_f32(const float *const *params, int nparams, int B, int N, int k, int groups, float momentum,
+                                       void *arena, size_t arena_bytes, void *stream);
 int dvm_uni3fc_train_bwd_f32(const float *g_feat, const float *g_tmp, const float *dino, const float *feat, const float *tmp,
-                             int B, int N, const float *const *params, float *const *grads, int nparams, int k, void *arena,
-                             size_t arena_bytes, void *stream);
+                             int B, int N, const float *const *params, float *const *grads, int nparams, int k, int groups,
+                             void *arena, size_t arena_bytes, void *stream);
 
 /* dvm_pair_fwd_f32 can run its coordinate-only chain (FPS, graph, xyz kNN: latency-bound) on helper streams, forked
  * from and joined back into `stream` by events, next to the feature-only soft-correspondence chain.  The helper streams

@@ -184,11 +184,12 @@ def test_deterministic_switch_gives_bit_reproducible_gradients(native):
     assert worst < 1e-3, worst
 
 
-def test_forward_pair_equals_two_calls():
-    """Uni3FC.forward_pair — the step's two network calls side by side on two streams, running statistics deferred and applied in
-    call order — against two sequential forward() calls on an identical copy: features, second outputs, running statistics
-    and batch counters bit-identical; parameter gradients (both backward passes adding into one flat bucket, concurrently) to
-    summation-order noise."""
+@pytest.mark.parametrize("mode", ["merged", "1"])
+def test_forward_pair_equals_two_calls(mode):
+    """Uni3FC.forward_pair — the step's two network calls as ONE native call with two groups ("merged": BatchNorm statistics,
+    position-encoding range and running-statistics updates per call, in call order), or side by side on two streams with the
+    running statistics deferred ("1") — against two sequential forward() calls on an identical copy: features, second outputs,
+    running statistics and batch counters bit-identical; parameter gradients to summation-order noise."""
     from dvm import nn_ops
     from dvm.dist import FlatGradBucket
     import models.model as mm
@@ -202,12 +203,13 @@ def test_forward_pair_equals_two_calls():
     try:
         for _ in range(2):   # twice: the second round reuses the pair streams and the caching allocator's blocks
             ba.zero(), bb.zero()
-            os.environ["DVM_PAIR_CALLS"] = "1"      # (opt-in: see Uni3FC.forward_pair)
+            os.environ["DVM_PAIR_CALLS"] = mode
             try:
                 (f1, t1), (f2, t2) = a.forward_pair(x1, d1, x2, d2)
             finally:
                 os.environ.pop("DVM_PAIR_CALLS", None)
-            assert type(f1.grad_fn).__name__ == "_Uni3FCTrainBackward"
+            node = f1.grad_fn if mode == "1" else f1.grad_fn.next_functions[0][0]      # (merged: the outputs are row slices of ONE node's)
+            assert type(node).__name__ == "_Uni3FCTrainBackward"
             ((f1 * gf1).sum() + (f2 * gf2).sum() + t1.sum()).backward()
             mm.join_side_streams(torch.device("cuda", 0))
             os.environ["DVM_PAIR_CALLS"] = "0"
