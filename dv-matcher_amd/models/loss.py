@@ -180,8 +180,10 @@ class GraphDeformLoss_Neural(nn.Module):
         map_sum = ops.map_term(verts12, verts2, idx11, idx22, pval, pidx) if (self.w_map > 0 and not self.partial_variant) else None
         return map_sum, cd_warp, arap.sum(), cd_self, dict(warped=warped, verts12=verts12, pval=pval, pidx=pidx)
 
-    def _chamfer_train(self, a, b):
+    def _chamfer_train(self, a, b, per_pair=False):
         d1, d2 = nn_ops.chamfer_nn(a, b)
+        if per_pair:   # (B,2): the two sides' means of every pair (the batch mean of each column is torch.mean(d*))
+            return torch.stack([d1.mean(1), d2.mean(1)], 1)
         if self.partial_variant:
             return torch.mean(d1 if d1.shape[1] <= d2.shape[1] else d2)
         return torch.mean(d1) + torch.mean(d2)
@@ -190,8 +192,9 @@ class GraphDeformLoss_Neural(nn.Module):
         """dist-loss term with autograd (HIP forward, HIP weights + GEMM backward)."""
         return nn_ops.dist_loss(feat, dist, anchors, self.k_dist).sum()
 
-    def _direction_train(self, feat1, feat2, verts1, verts2, alpha, g1, deformer, idx11, idx22):
-        """deform() with autograd (models/loss.py:1228-1296)."""
+    def _direction_train(self, feat1, feat2, verts1, verts2, alpha, g1, deformer, idx11, idx22, per_pair=False):
+        """deform() with autograd (models/loss.py:1228-1296).  per_pair: Chamfer terms as (B,2) per-pair side means and ARAP as (B,)
+        instead of batch scalars (for a caller that has merged several calls into one batch)."""
         B, N, _ = verts1.shape
         pval, pidx = nn_ops.softcorr_topk(feat1, feat2, alpha, 10)
         verts12 = nn_ops.sparse_apply(pval, pidx, verts2)
@@ -204,15 +207,15 @@ class GraphDeformLoss_Neural(nn.Module):
         def9 = deformer.deformation_decoder_layer(z)
         R = nn_ops.rot6d(def9[..., 3:] + self._identity6(def9.device))
         warped, arap = nn_ops.dg_warp_arap(verts1, g1, R, def9[..., :3])
-        cd_warp = self._chamfer_train(warped, verts2)
-        cd_self = self._chamfer_train(verts12, verts2)
+        cd_warp = self._chamfer_train(warped, verts2, per_pair)
+        cd_self = self._chamfer_train(verts12, verts2, per_pair)
         map_sum = None
         if self.w_map > 0 and not self.partial_variant:
             lhs = nn_ops.gather_rows(verts12, idx11)                                   # (B,N,k,3)
             v2n = nn_ops.gather_rows(verts2, idx22).reshape(B, verts2.shape[1], -1)    # (B,M,k*3)
             rhs = nn_ops.sparse_apply(pval, pidx, v2n).view(B, N, -1, 3)
             map_sum = ((lhs - rhs) ** 2).sum(dim=(1, 2, 3))
-        return map_sum, cd_warp, arap.sum(), cd_self, dict(warped=warped, verts12=verts12, pval=pval, pidx=pidx)
+        return map_sum, cd_warp, (arap if per_pair else arap.sum()), cd_self, dict(warped=warped, verts12=verts12, pval=pval, pidx=pidx)
 
     def _dump(self, ex, verts1, verts2, n, cd, arap):
         print("Rand:%s, Deform_Result: cd_loss:%s, arap_loss:%s" % (n, cd, arap))
@@ -327,11 +330,32 @@ class GraphDeformLoss_Neural(nn.Module):
             dterm = on(0, lambda: (dist_term(feat1, dist1, a1) + dist_term(feat2, dist2, a2)) * self.w_dist)
         if self.w_deform > 0 or not self.partial_variant:
             g1, g2, idx11, idx22 = geometry if geometry is not None else self.geometry(verts1, verts2, fps_starts, shape_ids)
-            r21 = on(1, lambda: direction(feat2, feat1, verts2, verts1, alpha_i, g2, deformer, idx22, idx11))
-            m12, c12, a12, s12, ex12 = direction(feat1, feat2, verts1, verts2, alpha_i, g1, deformer, idx11, idx22)
-            n12 = str(random.randint(0, 10))
-            m21, c21, a21, s21, ex21 = joined(1, r21)
-            n21 = str(random.randint(0, 10))
+            merged = (train and N == M and not self.dump and not self.partial_variant and self.w_rank <= 0
+                      and os.environ.get("DVM_CRIT_MERGE", "1") == "1"
+                      and all(torch.is_tensor(g1[k]) for k in g1))
+            if merged:
+                # Both directions are the SAME function of (source, target): with equal point counts they run as ONE batch of 2B
+                # pairs — [(1 -> 2) x B | (2 -> 1) x B] — through every kernel of deform() and its backward: half the launches of two
+                # calls (which at 8 pairs fill a fraction of the chip each).  Chamfer / self-reconstruction are means over the batch
+                # and enter the loss as c12 + c21 = 2 mean over both; ARAP and the map term are sums.
+                cat = lambda u, v: torch.cat([u, v], 0)  # noqa: E731
+                gm = {k: cat(g1[k], g2[k]) for k in g1}
+                mm_, cm, am, sm, exm = direction(cat(feat1, feat2), cat(feat2, feat1), cat(verts1, verts2), cat(verts2, verts1), alpha_i, gm,
+                                                 deformer, cat(idx11, idx22), cat(idx22, idx11), per_pair=True)
+                m12, m21 = (mm_[:B], mm_[B:]) if mm_ is not None else (None, None)
+                c12, c21 = cm[:B].mean(0).sum(), cm[B:].mean(0).sum()
+                s12, s21 = sm[:B].mean(0).sum(), sm[B:].mean(0).sum()
+                a12, a21 = am[:B].sum(), am[B:].sum()
+                ex12 = {k: v[:B] for k, v in exm.items()}
+                ex21 = {k: v[B:] for k, v in exm.items()}
+                n12 = str(random.randint(0, 10))
+                n21 = str(random.randint(0, 10))
+            else:
+                r21 = on(1, lambda: direction(feat2, feat1, verts2, verts1, alpha_i, g2, deformer, idx22, idx11))
+                m12, c12, a12, s12, ex12 = direction(feat1, feat2, verts1, verts2, alpha_i, g1, deformer, idx11, idx22)
+                n12 = str(random.randint(0, 10))
+                m21, c21, a21, s21, ex21 = joined(1, r21)
+                n21 = str(random.randint(0, 10))
         if self.w_dist > 0:
             self.dist_loss = joined(0, dterm)
             loss = loss + self.dist_loss
