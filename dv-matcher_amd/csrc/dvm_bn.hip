@@ -185,6 +185,13 @@ __global__ __launch_bounds__(256) void bn_pm_reduce_kernel(const float *__restri
                                                            const float *__restrict__ mean, const float *__restrict__ invstd /* BWD */, long R,
                                                            int C, int CG, long chunk, float slope, double *__restrict__ partial) {
     __shared__ double sa[1024], sq[1024];     // [rl][c], RPP * CG <= 1024
+    {   // group blockIdx.z of a merged call: rows [z R, (z + 1) R), its own statistics and partials
+        const size_t go = (size_t)blockIdx.z * R * C;
+        x += go;
+        if (res) res += go;
+        if (BWD) dy += go, y += go, mean += (size_t)blockIdx.z * C, invstd += (size_t)blockIdx.z * C;
+        partial += (size_t)blockIdx.z * gridDim.x * C * 2;
+    }
     const int C4 = CG >> 2, RPP = 256 / C4;
     const int c4 = threadIdx.x % C4, rl = threadIdx.x / C4, cl = c4 * 4, c = blockIdx.y * CG + cl;
     const long lo = (long)blockIdx.x * chunk, hi = lo + chunk < R ? lo + chunk : R;
@@ -251,55 +258,72 @@ __device__ inline bool pm_sum_partials(const double *__restrict__ partial, int S
     return true;
 }
 
-// grid (ceil(C / 8)) x 256 threads: partials -> fin[c] = {mean, invstd, gamma * invstd, beta} (forward; + running
-// statistics) or {mean(dz), mean(dz xhat), gamma * invstd, -} (backward; + dgamma, dbeta)
+// grid (ceil(C / 8)) x 256 threads: partials -> fin[g][c] = {mean, invstd, gamma * invstd, beta} (forward; + running
+// statistics) or {mean(dz), mean(dz xhat), gamma * invstd, -} (backward; + dgamma, dbeta), for every group of a merged call
 __global__ __launch_bounds__(256) void bn_pm_finalize_fwd_kernel(const double *__restrict__ partial, int S, long R, int C,
                                                                  const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
                                                                  float momentum, float *__restrict__ fin, float *__restrict__ mean_out,
                                                                  float *__restrict__ invstd_out, float *__restrict__ running_mean,
-                                                                 float *__restrict__ running_var, float *__restrict__ unb_out) {
+                                                                 float *__restrict__ running_var, float *__restrict__ unb_out, int groups) {
     const int cl = threadIdx.x & (PM_CG - 1), sl = threadIdx.x / PM_CG, c = blockIdx.x * PM_CG + cl;
-    double ta, tq;
-    if (!pm_sum_partials(partial, S, C, c, cl, sl, ta, tq)) return;
-    const double mean = ta / (double)R;
-    double var = tq / (double)R - mean * mean;
-    var = var > 0.0 ? var : 0.0;
-    const float invstd = (float)(1.0 / sqrt(var + (double)eps)), mf = (float)mean;
-    mean_out[c] = mf;
-    invstd_out[c] = invstd;
-    const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
-    if (unb_out) unb_out[c] = (float)unb;   // for a deferred running-statistics update (dvm_bn_running_update_f32): the same float
-    if (running_mean) {
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mf;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    for (int g = 0; g < groups; ++g) {   // group after group: the running statistics take the groups' updates in order
+        double ta, tq;
+        const bool lead = pm_sum_partials(partial + (size_t)g * S * C * 2, S, C, c, cl, sl, ta, tq);
+        if (lead) {
+            const double mean = ta / (double)R;
+            double var = tq / (double)R - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)eps)), mf = (float)mean;
+            mean_out[(size_t)g * C + c] = mf;
+            invstd_out[(size_t)g * C + c] = invstd;
+            const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
+            if (unb_out) unb_out[(size_t)g * C + c] = (float)unb;   // for a deferred running-statistics update: the same float
+            if (running_mean) {
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mf;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+            }
+            float *f = fin + ((size_t)g * C + c) * 4;
+            f[0] = mf;
+            f[1] = invstd;
+            f[2] = (gamma ? gamma[c] : 1.f) * invstd;
+            f[3] = beta ? beta[c] : 0.f;
+        }
+        __syncthreads();   // (pm_sum_partials' shared arrays are reused by the next group)
     }
-    fin[c * 4] = mf;
-    fin[c * 4 + 1] = invstd;
-    fin[c * 4 + 2] = (gamma ? gamma[c] : 1.f) * invstd;
-    fin[c * 4 + 3] = beta ? beta[c] : 0.f;
 }
 
 __global__ __launch_bounds__(256) void bn_pm_finalize_bwd_kernel(const double *__restrict__ partial, int S, long R, int C,
                                                                  const float *__restrict__ gamma, const float *__restrict__ mean,
                                                                  const float *__restrict__ invstd, float *__restrict__ fin,
-                                                                 float *__restrict__ dgamma, float *__restrict__ dbeta, int accumulate) {
+                                                                 float *__restrict__ dgamma, float *__restrict__ dbeta, int accumulate, int groups) {
     const int cl = threadIdx.x & (PM_CG - 1), sl = threadIdx.x / PM_CG, c = blockIdx.x * PM_CG + cl;
-    double ta, tq;
-    if (!pm_sum_partials(partial, S, C, c, cl, sl, ta, tq)) return;
+    float sg = 0.f, sb = 0.f;   // the groups' parameter gradients, added in group order
+    bool any = false;
+    for (int g = 0; g < groups; ++g) {
+        double ta, tq;
+        const bool lead = pm_sum_partials(partial + (size_t)g * S * C * 2, S, C, c, cl, sl, ta, tq);
+        if (lead) {
+            any = true;
+            sg += (float)tq, sb += (float)ta;
+            float *f = fin + ((size_t)g * C + c) * 4;
+            f[0] = (float)(ta / (double)R);
+            f[1] = (float)(tq / (double)R);
+            f[2] = (gamma ? gamma[c] : 1.f) * invstd[(size_t)g * C + c];
+            f[3] = 0.f;
+        }
+        __syncthreads();
+    }
+    if (!any) return;
     // accumulate: an atomic add — two network calls whose backward passes run side by side on two streams add into the same buffers
     // (a zeroed buffer plus two addends gives the same bits in either order)
     if (dgamma) {
-        if (accumulate) atomicAdd(dgamma + c, (float)tq);
-        else dgamma[c] = (float)tq;
+        if (accumulate) atomicAdd(dgamma + c, sg);
+        else dgamma[c] = sg;
     }
     if (dbeta) {
-        if (accumulate) atomicAdd(dbeta + c, (float)ta);
-        else dbeta[c] = (float)ta;
+        if (accumulate) atomicAdd(dbeta + c, sb);
+        else dbeta[c] = sb;
     }
-    fin[c * 4] = (float)(ta / (double)R);
-    fin[c * 4 + 1] = (float)(tq / (double)R);
-    fin[c * 4 + 2] = (gamma ? gamma[c] : 1.f) * invstd[c];
-    fin[c * 4 + 3] = 0.f;
 }
 
 // elementwise pass, 4 consecutive channels per thread (C % 4 == 0)
@@ -308,10 +332,15 @@ __global__ __launch_bounds__(256) void bn_pm_apply_kernel(const float *__restric
                                                           const float *__restrict__ dy, const float *__restrict__ y_in,
                                                           const float *__restrict__ fin, const float *__restrict__ mean,
                                                           const float *__restrict__ invstd, long R, int C, float slope,
-                                                          float *__restrict__ out) {
+                                                          float *__restrict__ out, long Rg) {
     const long q0 = (long)blockIdx.x * 256 + threadIdx.x;   // float4 index
     const long e0 = q0 * 4;
     if (e0 >= R * C) return;
+    if (Rg < R) {   // merged call: the row's group selects the statistics (R = all rows, Rg = rows per group)
+        const long g = (e0 / C) / Rg;
+        fin += (size_t)g * C * 4;
+        if (BWD) mean += (size_t)g * C, invstd += (size_t)g * C;
+    }
     const int c = 4 * (q0 < (1L << 32) ? (int)((unsigned)q0 % (unsigned)(C >> 2)) : (int)(q0 % (C >> 2)));
     f32x4 v = *(const f32x4 *)(x + e0);
     if (res) v += *(const f32x4 *)(res + e0);
@@ -416,33 +445,40 @@ DVM_EXPORT size_t dvm_bn_pm_workspace_bytes(long R, int C) {
 DVM_EXPORT int dvm_bn_act_train_fwd_pm_f32(const float *x, const float *res, const float *gamma, const float *beta, long R, int C, float eps,
                                            float slope, float momentum, float *y, float *save_mean, float *save_invstd,
                                            float *running_mean, float *running_var, void *ws, size_t ws_bytes, void *stream) {
-    return dvm_bn_act_train_fwd_pm_var_f32(x, res, gamma, beta, R, C, eps, slope, momentum, y, save_mean, save_invstd, nullptr, running_mean,
+    return dvm_bn_act_train_fwd_pm_var_f32(x, res, gamma, beta, R, C, 1, eps, slope, momentum, y, save_mean, save_invstd, nullptr, running_mean,
                                            running_var, ws, ws_bytes, stream);
 }
 
-DVM_EXPORT int dvm_bn_act_train_fwd_pm_var_f32(const float *x, const float *res, const float *gamma, const float *beta, long R, int C, float eps,
-                                               float slope, float momentum, float *y, float *save_mean, float *save_invstd,
+DVM_EXPORT size_t dvm_bn_pm_groups_workspace_bytes(long R, int C, int groups) {
+    if (R < 1 || C < 4 || C % 4 != 0 || C > 1024 || groups < 1) return 0;
+    return align_up((size_t)groups * C * pm_splits_for(R, C) * 2 * sizeof(double)) + align_up((size_t)groups * C * 4 * sizeof(float));
+}
+
+DVM_EXPORT int dvm_bn_act_train_fwd_pm_var_f32(const float *x, const float *res, const float *gamma, const float *beta, long R, int C, int groups,
+                                               float eps, float slope, float momentum, float *y, float *save_mean, float *save_invstd,
                                                float *save_var_unbiased, float *running_mean, float *running_var, void *ws, size_t ws_bytes,
                                                void *stream) {
+    DVM_REQUIRE(groups >= 1 && groups <= 64, "dvm_bn_act_train_fwd_pm_var_f32: bad group count %d", groups);
     DVM_REQUIRE(x && y && save_mean && save_invstd, "dvm_bn_act_train_fwd_pm_f32: null pointer");
     DVM_REQUIRE(R >= 1 && C >= 4 && C % 4 == 0 && C <= 1024, "dvm_bn_act_train_fwd_pm_f32: need R >= 1 and C a multiple of 4, at most 1024 (R=%ld C=%d)", R, C);
     DVM_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "dvm_bn_act_train_fwd_pm_f32: running_mean/var go together");
     const int S = pm_splits_for(R, C);
     Arena ar(ws, ws_bytes);
-    double *partial = ar.take<double>((size_t)C * S * 2);
-    float *fin = ar.take<float>((size_t)C * 4);
+    double *partial = ar.take<double>((size_t)groups * C * S * 2);
+    float *fin = ar.take<float>((size_t)groups * C * 4);
     if (!ar.ok()) {
         set_error("dvm_bn_act_train_fwd_pm_f32: workspace too small (%zu < %zu)", ws_bytes, ar.off);
         return DVM_ENOSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
     const int CG = pm_group_for(C);
-    hipLaunchKernelGGL(bn_pm_reduce_kernel<false>, dim3(S, C / CG), dim3(256), 0, s, x, res, nullptr, nullptr, nullptr, nullptr, R, C, CG,
+    const long Rall = R * groups;   // R: rows PER GROUP
+    hipLaunchKernelGGL(bn_pm_reduce_kernel<false>, dim3(S, C / CG, groups), dim3(256), 0, s, x, res, nullptr, nullptr, nullptr, nullptr, R, C, CG,
                        pm_chunk_for(R, C), slope, partial);
     hipLaunchKernelGGL(bn_pm_finalize_fwd_kernel, dim3((C + PM_CG - 1) / PM_CG), dim3(256), 0, s, partial, S, R, C, gamma, beta, eps, momentum, fin,
-                       save_mean, save_invstd, running_mean, running_var, save_var_unbiased);
-    hipLaunchKernelGGL(bn_pm_apply_kernel<false>, dim3((unsigned)((R * C / 4 + 255) / 256)), dim3(256), 0, s, x, res, nullptr, nullptr, fin,
-                       nullptr, nullptr, R, C, slope, y);
+                       save_mean, save_invstd, running_mean, running_var, save_var_unbiased, groups);
+    hipLaunchKernelGGL(bn_pm_apply_kernel<false>, dim3((unsigned)((Rall * C / 4 + 255) / 256)), dim3(256), 0, s, x, res, nullptr, nullptr, fin,
+                       nullptr, nullptr, Rall, C, slope, y, R);
     DVM_CHECK_LAUNCH("bn_act_train_fwd_pm");
     return DVM_OK;
 }
@@ -450,24 +486,33 @@ DVM_EXPORT int dvm_bn_act_train_fwd_pm_var_f32(const float *x, const float *res,
 DVM_EXPORT int dvm_bn_act_train_bwd_pm_f32(const float *dy, const float *y, const float *x, const float *res, const float *gamma,
                                            const float *save_mean, const float *save_invstd, long R, int C, float slope, float *dx,
                                            float *dgamma, float *dbeta, int accumulate, void *ws, size_t ws_bytes, void *stream) {
+    return dvm_bn_act_train_bwd_pm_groups_f32(dy, y, x, res, gamma, save_mean, save_invstd, R, C, 1, slope, dx, dgamma, dbeta, accumulate, ws, ws_bytes,
+                                              stream);
+}
+
+DVM_EXPORT int dvm_bn_act_train_bwd_pm_groups_f32(const float *dy, const float *y, const float *x, const float *res, const float *gamma,
+                                                  const float *save_mean, const float *save_invstd, long R, int C, int groups, float slope,
+                                                  float *dx, float *dgamma, float *dbeta, int accumulate, void *ws, size_t ws_bytes, void *stream) {
     DVM_REQUIRE(dy && y && x && save_mean && save_invstd && dx, "dvm_bn_act_train_bwd_pm_f32: null pointer");
+    DVM_REQUIRE(groups >= 1 && groups <= 64, "dvm_bn_act_train_bwd_pm_groups_f32: bad group count %d", groups);
     DVM_REQUIRE(R >= 1 && C >= 4 && C % 4 == 0 && C <= 1024, "dvm_bn_act_train_bwd_pm_f32: need R >= 1 and C a multiple of 4, at most 1024 (R=%ld C=%d)", R, C);
     const int S = pm_splits_for(R, C);
     Arena ar(ws, ws_bytes);
-    double *partial = ar.take<double>((size_t)C * S * 2);
-    float *fin = ar.take<float>((size_t)C * 4);
+    double *partial = ar.take<double>((size_t)groups * C * S * 2);
+    float *fin = ar.take<float>((size_t)groups * C * 4);
     if (!ar.ok()) {
         set_error("dvm_bn_act_train_bwd_pm_f32: workspace too small (%zu < %zu)", ws_bytes, ar.off);
         return DVM_ENOSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
     const int CG = pm_group_for(C);
-    hipLaunchKernelGGL(bn_pm_reduce_kernel<true>, dim3(S, C / CG), dim3(256), 0, s, x, res, dy, y, save_mean, save_invstd, R, C, CG,
+    const long Rall = R * groups;   // R: rows PER GROUP
+    hipLaunchKernelGGL(bn_pm_reduce_kernel<true>, dim3(S, C / CG, groups), dim3(256), 0, s, x, res, dy, y, save_mean, save_invstd, R, C, CG,
                        pm_chunk_for(R, C), slope, partial);
     hipLaunchKernelGGL(bn_pm_finalize_bwd_kernel, dim3((C + PM_CG - 1) / PM_CG), dim3(256), 0, s, partial, S, R, C, gamma, save_mean, save_invstd, fin,
-                       dgamma, dbeta, accumulate);
-    hipLaunchKernelGGL(bn_pm_apply_kernel<true>, dim3((unsigned)((R * C / 4 + 255) / 256)), dim3(256), 0, s, x, res, dy, y, fin, save_mean,
-                       save_invstd, R, C, slope, dx);
+                       dgamma, dbeta, accumulate, groups);
+    hipLaunchKernelGGL(bn_pm_apply_kernel<true>, dim3((unsigned)((Rall * C / 4 + 255) / 256)), dim3(256), 0, s, x, res, dy, y, fin, save_mean,
+                       save_invstd, Rall, C, slope, dx, R);
     DVM_CHECK_LAUNCH("bn_act_train_bwd_pm");
     return DVM_OK;
 }

@@ -87,8 +87,8 @@ void carve_chain(Arena &ar, int B, int N, int K, ChainScratch &c, bool local) {
     const size_t R = (size_t)B * N;
     c.bn_bytes = 0;
     for (int C : {64, 128, 384, 512})
-        for (long rows : {(long)R, (long)R / MAXG}) {   // (a group of a merged call has its own, shorter reduction)
-            const size_t b = dvm_bn_pm_workspace_bytes(rows > 0 ? rows : 1, C);
+        for (int G : {1, MAXG}) {   // (a group of a merged call has its own, shorter reduction)
+            const size_t b = dvm_bn_pm_groups_workspace_bytes((long)R / G > 0 ? (long)R / G : 1, C, G);
             c.bn_bytes = b > c.bn_bytes ? b : c.bn_bytes;
         }
     c.bnws = ar.take<char>(c.bn_bytes);
@@ -207,13 +207,9 @@ struct Net {
 // ---------------------------------------------------------------- forward pieces
 int bn_fwd(const Net &n, const float *x, const float *res, const float *g, const float *b, float *rm, float *rv, int C, float slope, float *y,
            const BnSave &sv, const ChainScratch &c, hipStream_t s) {
-    for (int q = 0; q < n.G; ++q) {   // per group: its own batch statistics; the running statistics take the groups' updates in order
-        const size_t o = (size_t)q * n.Rg * C;
-        T_TRY(dvm_bn_act_train_fwd_pm_var_f32(x + o, res ? res + o : nullptr, g, b, n.Rg, C, n.eps, slope, n.momentum, y + o, sv.mean + q * C,
-                                              sv.invstd + q * C, sv.var + q * C, n.defer_stats ? nullptr : rm, n.defer_stats ? nullptr : rv, c.bnws,
-                                              c.bn_bytes, s));
-    }
-    return DVM_OK;
+    // per group its own batch statistics (one launch set for all groups); the running statistics take the groups' updates in order
+    return dvm_bn_act_train_fwd_pm_var_f32(x, res, g, b, n.Rg, C, n.G, n.eps, slope, n.momentum, y, sv.mean, sv.invstd, sv.var,
+                                           n.defer_stats ? nullptr : rm, n.defer_stats ? nullptr : rv, c.bnws, c.bn_bytes, s);
 }
 
 // conv block i: y = leaky_0.2(bn(x W^T))
@@ -276,12 +272,7 @@ void max_prefix(const Net &n, const float *wide, const float *x, unsigned long l
 // ---------------------------------------------------------------- backward pieces
 int bn_bwd(const Net &n, const float *dy, const float *y, const float *x, const float *res, const float *g, const BnSave &sv, int C, float slope,
            float *dx, float *dg, float *db, const ChainScratch &c, hipStream_t s) {
-    for (int q = 0; q < n.G; ++q) {
-        const size_t o = (size_t)q * n.Rg * C;
-        T_TRY(dvm_bn_act_train_bwd_pm_f32(dy + o, y + o, x + o, res ? res + o : nullptr, g, sv.mean + q * C, sv.invstd + q * C, n.Rg, C, slope, dx + o, dg,
-                                          db, 1, c.bnws, c.bn_bytes, s));
-    }
-    return DVM_OK;
+    return dvm_bn_act_train_bwd_pm_groups_f32(dy, y, x, res, g, sv.mean, sv.invstd, n.Rg, C, n.G, slope, dx, dg, db, 1, c.bnws, c.bn_bytes, s);
 }
 // dX [R][K] = dY [R][Co] W [Co][K]  (+ res): dvm_linear_f32 with the operands' roles swapped
 int dgrad(const Net &n, const float *dy, const float *W, int Co, int K, const float *res, float *dx, hipStream_t s) {

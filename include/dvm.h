@@ -294,10 +294,18 @@ int dvm_bn_act_train_fwd_pm_f32(const float *x, const float *res, const float *g
 /* The same forward that also returns the UNBIASED batch variance (save_var_unbiased [C], may be NULL): with running_mean ==
  * running_var == NULL the running statistics are left alone and can be updated later from (save_mean, save_var_unbiased) with
  * exactly the fused kernel's expression — dvm_uni3fc_train_running_stats_f32 does so for a whole network call. */
-int dvm_bn_act_train_fwd_pm_var_f32(const float *x, const float *res, const float *gamma, const float *beta, long R, int C, float eps,
-                                    float slope, float momentum, float *y, float *save_mean, float *save_invstd,
+int dvm_bn_act_train_fwd_pm_var_f32(const float *x, const float *res, const float *gamma, const float *beta, long R, int C, int groups,
+                                    float eps, float slope, float momentum, float *y, float *save_mean, float *save_invstd,
                                     float *save_var_unbiased, float *running_mean, float *running_var, void *ws, size_t ws_bytes,
                                     void *stream);
+/* groups > 1 (here and in dvm_bn_act_train_bwd_pm_groups_f32): x holds `groups` consecutive blocks of R rows, each normalised
+ * with ITS OWN batch statistics (several network calls merged into one batch: the reference normalises per call); save_* are
+ * [groups][C]; the running statistics take the groups' updates one after the other; dgamma / dbeta sum over the groups.
+ * Workspace: dvm_bn_pm_groups_workspace_bytes(R, C, groups). */
+size_t dvm_bn_pm_groups_workspace_bytes(long R, int C, int groups);
+int dvm_bn_act_train_bwd_pm_groups_f32(const float *dy, const float *y, const float *x, const float *res, const float *gamma,
+                                       const float *save_mean, const float *save_invstd, long R, int C, int groups, float slope,
+                                       float *dx, float *dgamma, float *dbeta, int accumulate, void *ws, size_t ws_bytes, void *stream);
 int dvm_bn_act_train_bwd_pm_f32(const float *dy, const float *y, const float *x, const float *res, const float *gamma,
                                 const float *save_mean, const float *save_invstd, long R, int C, float slope, float *dx,
                                 float *dgamma, float *dbeta, int accumulate, void *ws, size_t ws_bytes, void *stream);
