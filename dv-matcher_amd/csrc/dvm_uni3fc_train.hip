@@ -282,8 +282,8 @@ int wgrad(const Net &n, const float *dy, const float *x, int Co, int K, float *d
     return dvm_linear_wgrad_ws_f32(dy, x, n.R, Co, K, dW, c.wgws, c.wg_bytes, s);   // (the workspace is used in deterministic mode only)
 }
 void colsum_accum(const Net &n, const float *g, int C, float *out, const ChainScratch &c, hipStream_t s) {
-    long chunks = (n.R + 63) / 64;          // (C in {64, 128}: checked by the callers' layer table)
-    if (chunks > 1024) chunks = 1024;
+    long chunks = (n.R + 255) / 256;        // (C in {64, 128}: checked by the callers' layer table)
+    if (chunks > 128) chunks = 128;         // (the second launch is ONE workgroup walking the chunks: 512 of them cost it 37 us)
     const long rows_per = (n.R + chunks - 1) / chunks;
     chunks = (n.R + rows_per - 1) / rows_per;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)chunks), dim3(256), 0, s, g, n.R, C, rows_per, c.colpart);
