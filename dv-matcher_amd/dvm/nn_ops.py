@@ -481,7 +481,7 @@ class _DistLoss(torch.autograd.Function):
         feat, dist, anchors, idx = ctx.saved_tensors
         W = ops.dist_loss_bwd_weights(feat, dist, anchors, idx, gout.contiguous())   # (B,nA,N)
         a = anchors.long()
-        fa = feat[:, a]
+        fa = feat.index_select(1, a)    # (feat[:, a] runs ATen's general advanced-indexing kernel: 216 us for these 4 MB; index_select: ~10)
         dfeat = W.sum(1).unsqueeze(-1) * feat - torch.bmm(W.transpose(1, 2), fa)
         dfa = W.sum(2).unsqueeze(-1) * fa - torch.bmm(W, feat)
         dfeat.index_add_(1, a, dfa)
