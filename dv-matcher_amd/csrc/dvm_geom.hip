@@ -5,6 +5,7 @@
 // floating-point expression is written in the rounding order of the reference's CPU path
 // (see oracle/dvm_oracle.c) so that the integer outputs are bit-exact.
 #include "dvm_common.h"
+#include <stdlib.h>
 
 namespace dvm {
 
@@ -571,6 +572,67 @@ __global__ __launch_bounds__(256) void map_term_kernel(const float *__restrict__
     }
 }
 
+// Round 4: the map term with the TARGET side resident in LDS — one workgroup of 1024 threads per cloud stages verts2 (12 M bytes)
+// and idx22 (4 M k bytes: 24 + 80 KB at 2048 points, k = 10) once, and every (index -> coordinate) lookup of the 10 correspondences
+// of a (point, slot) thread is two LDS reads instead of L2 round trips; no [M][k][3] neighbour table is built (gather_nbr_xyz_kernel
+// and its 250 MB per launch disappear).  The workgroup walks the 256-thread blocks of map_term_kernel four at a time and writes
+// the SAME partial sums in the same slots (a wave's sum, then the block's four waves in order): bit-identical to both older forms.
+template <int TOPK>
+__global__ __launch_bounds__(1024) void map_term_lds_kernel(const float *__restrict__ verts12, const float *__restrict__ verts2,
+                                                            const int32_t *__restrict__ idx11, const int32_t *__restrict__ idx22,
+                                                            const float *__restrict__ pi_val, const int32_t *__restrict__ pi_idx, int N, int M,
+                                                            int k, int nblk, double *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char mt_lds[];
+    __shared__ double red[16];
+    float *v2 = (float *)mt_lds;                                   // [M][3]
+    int32_t *i22 = (int32_t *)(mt_lds + (((size_t)M * 3 * sizeof(float) + 15) / 16) * 16);   // [M][k]
+    const int b = blockIdx.x;
+    {
+        const float *gv = verts2 + (size_t)b * M * 3;
+        const int32_t *gi = idx22 + (size_t)b * M * k;
+        for (int e = threadIdx.x; e < M * 3; e += 1024) v2[e] = gv[e];
+        for (int e = threadIdx.x; e < M * k; e += 1024) i22[e] = gi[e];
+    }
+    __syncthreads();
+    const int sub = threadIdx.x >> 8, tl = threadIdx.x & 255;      // four virtual 256-thread blocks at a time
+    for (int vb0 = 0; vb0 < nblk; vb0 += 4) {
+        const int vb = vb0 + sub;
+        const long g = (long)vb * 256 + tl;
+        float e2 = 0.f;
+        if (vb < nblk && g < (long)N * k) {
+            const int i = (int)(g / k), s = (int)(g % k);
+            const size_t row = (size_t)b * N + i;
+            int col[TOPK];
+            float w[TOPK];
+#pragma unroll
+            for (int t = 0; t < TOPK; ++t) col[t] = pi_idx[row * TOPK + t], w[t] = pi_val[row * TOPK + t];
+            int nb[TOPK];
+#pragma unroll
+            for (int t = 0; t < TOPK; ++t) nb[t] = i22[col[t] * k + s];
+            float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < TOPK; ++t) {
+                const float *p = v2 + 3 * nb[t];
+                acc[0] = fmaf(w[t], p[0], acc[0]);
+                acc[1] = fmaf(w[t], p[1], acc[1]);
+                acc[2] = fmaf(w[t], p[2], acc[2]);
+            }
+            const float *p12 = verts12 + ((size_t)b * N + idx11[row * k + s]) * 3;
+            const float e0 = p12[0] - acc[0], e1 = p12[1] - acc[1], e2c = p12[2] - acc[2];
+            e2 = (e0 * e0 + e1 * e1) + e2c * e2c;
+        }
+        const double ws = wave_sum((double)e2);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ws;
+        __syncthreads();
+        if (tl == 0 && vb < nblk) {
+            double t = 0.0;
+            for (int q = 0; q < 4; ++q) t += red[sub * 4 + q];
+            partial[(size_t)b * nblk + vb] = t;
+        }
+        __syncthreads();
+    }
+}
+
 // Two-level gathers flattened (fused pair path): nbr[b][j][s][3] = verts[b][idx[b][j][s]] once per cloud, then the map
 // term reads ONE contiguous 12*k-byte row per correspondence instead of k (index, coordinate) pairs.
 __global__ void gather_nbr_xyz_kernel(const float *__restrict__ verts, const int32_t *__restrict__ idx, int M, int k,
@@ -972,6 +1034,21 @@ int launch_map_term_nbr(const float *verts12, const float *nbr2, const int32_t *
     hipLaunchKernelGGL(map_term_nbr_kernel<10>, dim3(nblk, B), dim3(256), 0, s, verts12, nbr2, idx11, pi_val, pi_idx, N, M, k, topk,
                        partial);
     return DVM_OK;
+}
+// -> true if the LDS form ran (topk == 10, the target side fits 150 KB of LDS); else the caller uses one of the older forms
+bool map_term_lds_applies(int M, int k) {
+    static const int on = [] { const char *e = getenv("DVM_MAP_LDS"); return e ? atoi(e) : 1; }();
+    return on && (((size_t)M * 3 * sizeof(float) + 15) / 16) * 16 + (size_t)M * k * sizeof(int32_t) <= 150 * 1024;
+}
+bool launch_map_term_lds(const float *verts12, const float *verts2, const int32_t *idx11, const int32_t *idx22, const float *pi_val,
+                         const int32_t *pi_idx, int B, int N, int M, int k, int topk, double *partial, hipStream_t s) {
+    static const int on = [] { const char *e = getenv("DVM_MAP_LDS"); return e ? atoi(e) : 1; }();
+    const size_t lds = (((size_t)M * 3 * sizeof(float) + 15) / 16) * 16 + (size_t)M * k * sizeof(int32_t);
+    if (!on || topk != 10 || lds > 150 * 1024) return false;
+    ensure_dyn_lds((const void *)map_term_lds_kernel<10>, (int)lds);
+    hipLaunchKernelGGL(map_term_lds_kernel<10>, dim3(B), dim3(1024), lds, s, verts12, verts2, idx11, idx22, pi_val, pi_idx, N, M, k,
+                       map_term_blocks(N, k), partial);
+    return true;
 }
 int launch_map_term(const float *verts12, const float *verts2, const int32_t *idx11, const int32_t *idx22,
                     const float *pi_val, const int32_t *pi_idx, int B, int N, int M, int k, int topk, double *partial,

@@ -17,6 +17,9 @@ int launch_map_term_nbr(const float *verts12, const float *nbr2, const int32_t *
                         int B, int N, int M, int k, int topk, double *partial, hipStream_t s);
 int launch_map_term(const float *verts12, const float *verts2, const int32_t *idx11, const int32_t *idx22, const float *pi_val,
                     const int32_t *pi_idx, int B, int N, int M, int k, int topk, double *partial, hipStream_t s);
+bool launch_map_term_lds(const float *verts12, const float *verts2, const int32_t *idx11, const int32_t *idx22, const float *pi_val,
+                         const int32_t *pi_idx, int B, int N, int M, int k, int topk, double *partial, hipStream_t s);
+bool map_term_lds_applies(int M, int k);
 int launch_dg_build(const float *xyz, int B, int N, const int32_t *start, int32_t *nodes_idx, int32_t *ring, int32_t *infl_idx,
                     float *dists, float *weights, double *sigma, double *nnd, const GridBuf &gverts, const GridBuf &gnodes,
                     bool build_gverts, hipStream_t s);
@@ -144,7 +147,8 @@ DVM_EXPORT int dvm_pair_direction_fwd_f32(const float *feat1, const float *feat2
         launch_mean(w.d2, B, M, 1.f, losses, 6, 4, 0, s);
     }
     if (with_map) {
-        launch_map_term(verts12, verts2, w.idx11, w.idx22, w.pval, w.pidx, B, N, M, k, topk, w.partial, s);
+        if (!launch_map_term_lds(verts12, verts2, w.idx11, w.idx22, w.pval, w.pidx, B, N, M, k, topk, w.partial, s))
+            launch_map_term(verts12, verts2, w.idx11, w.idx22, w.pval, w.pidx, B, N, M, k, topk, w.partial, s);
         launch_reduce_partials(w.partial, B, map_term_blocks(N, k), 1.f, losses, 6, 5, s);
     } else {
         // losses[:,5] = 0 — a strided fill through the mean kernel's overwrite path
@@ -337,7 +341,8 @@ static int pair_fwd_impl(const float *feat1, const float *feat2, const float *ve
     // gathers run next to the ALU-bound sweep instead of after it
     launch_pool_all(feat1, w.idxk[0], B, N, 10, conv_w, conv_b, w.gall[0], s, w.gv[0].ids);
     launch_pool_all(feat2, w.idxk[1], B, M, 10, conv_w, conv_b, w.gall[1], s, w.gv[1].ids);
-    if (with_map && !reuse_geometry) {
+    const bool map_lds = map_term_lds_applies(N, 10) && map_term_lds_applies(M, 10);   // (the target side in LDS: no neighbour tables)
+    if (with_map && !reuse_geometry && !map_lds) {
         launch_gather_nbr_xyz(verts2, w.idxk[1], B, M, 10, w.nbrxyz[1], s);
         launch_gather_nbr_xyz(verts1, w.idxk[0], B, N, 10, w.nbrxyz[0], s);
     }
@@ -391,9 +396,14 @@ static int pair_fwd_impl(const float *feat1, const float *feat2, const float *ve
     }
     // ---- map terms (losses[:,5])
     if (with_map) {
-        launch_map_term_nbr(verts12, w.nbrxyz[1], w.idxk[0], w.pval[0], w.pidx[0], B, N, M, 10, 10, w.partial[0], s);
+        if (map_lds) {
+            launch_map_term_lds(verts12, verts2, w.idxk[0], w.idxk[1], w.pval[0], w.pidx[0], B, N, M, 10, 10, w.partial[0], s);
+            launch_map_term_lds(verts21, verts1, w.idxk[1], w.idxk[0], w.pval[1], w.pidx[1], B, M, N, 10, 10, w.partial[1], s);
+        } else {
+            launch_map_term_nbr(verts12, w.nbrxyz[1], w.idxk[0], w.pval[0], w.pidx[0], B, N, M, 10, 10, w.partial[0], s);
+            launch_map_term_nbr(verts21, w.nbrxyz[0], w.idxk[1], w.pval[1], w.pidx[1], B, M, N, 10, 10, w.partial[1], s);
+        }
         launch_reduce_partials(w.partial[0], B, map_term_blocks(N, 10), 1.f, losses12, 6, 5, s);
-        launch_map_term_nbr(verts21, w.nbrxyz[0], w.idxk[1], w.pval[1], w.pidx[1], B, M, N, 10, 10, w.partial[1], s);
         launch_reduce_partials(w.partial[1], B, map_term_blocks(M, 10), 1.f, losses21, 6, 5, s);
     } else {
         launch_mean(w.cd[0], B, 1, 0.f, losses12, 6, 5, 0, s);
