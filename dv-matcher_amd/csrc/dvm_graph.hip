@@ -392,6 +392,78 @@ int launch_dg_build(const float *xyz, int B, int N, const int32_t *start, int32_
     return DVM_OK;
 }
 
+// Round 4: rot6d -> warp -> ARAP of one cloud in ONE workgroup with the node tables in LDS — node positions (p[nodes_idx]), R, T:
+// 15 floats per node, 60 KB at 1024 nodes.  The three kernels above chase nodes_idx -> coordinates and the R / T rows through L2
+// for every (vertex, influence node) and (node, ring neighbour) pair (62 + 105 us per launch of 1024 clouds, latency-bound: 256
+// threads per cloud in the ARAP kernel); here every such lookup is an LDS read.  Same expressions in the same order; the ARAP sum
+// keeps the 256-thread accumulation and reduction tree of dg_arap_kernel (thread t: nodes t, t + 256, ...), hence the same bits.
+__global__ __launch_bounds__(256) void dg_warp_arap_fused_kernel(const float *__restrict__ xyz, int N, int Nn, const int32_t *__restrict__ nodes_idx,
+                                                                 const int32_t *__restrict__ ring, const int32_t *__restrict__ infl,
+                                                                 const float *__restrict__ weights, const float *__restrict__ def9,
+                                                                 float *__restrict__ R, float *__restrict__ T, float *__restrict__ warped,
+                                                                 float *__restrict__ arap, int arap_stride) {
+    extern __shared__ __attribute__((aligned(16))) float wa_lds[];   // gpos [Nn][3] | R [Nn][9] | T [Nn][3]
+    __shared__ double red[256];
+    float *gp = wa_lds, *lr = wa_lds + (size_t)Nn * 3, *lt = lr + (size_t)Nn * 9;
+    const int b = blockIdx.x;
+    const float *p = xyz + (size_t)b * N * 3;
+    for (int a = threadIdx.x; a < Nn; a += 256) {
+        const size_t na = (size_t)b * Nn + a;
+        float r[9], t[3];
+        rot6d(def9 + na * 9, r, t);
+        const int va = nodes_idx[na];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) lr[a * 9 + c] = r[c], R[na * 9 + c] = r[c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) lt[a * 3 + c] = t[c], T[na * 3 + c] = t[c], gp[a * 3 + c] = p[3 * va + c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < N; i += 256) {   // v' = sum_s w_s (R_s (v - g_s) + g_s + t_s)
+        const size_t row = (size_t)b * N + i;
+        const float vx = p[3 * i], vy = p[3 * i + 1], vz = p[3 * i + 2];
+        float o[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int nb = infl[row * 3 + s];
+            const float *r = lr + nb * 9, *t = lt + nb * 3;
+            const float gx = gp[nb * 3], gy = gp[nb * 3 + 1], gz = gp[nb * 3 + 2];
+            const float dx = vx - gx, dy = vy - gy, dz = vz - gz;
+            const float w = weights[row * 3 + s];
+            const float g[3] = {gx, gy, gz};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float rv = (r[3 * c] * dx + r[3 * c + 1] * dy) + r[3 * c + 2] * dz;
+                o[c] = o[c] + ((rv + g[c]) + t[c]) * w;
+            }
+        }
+        warped[row * 3] = o[0], warped[row * 3 + 1] = o[1], warped[row * 3 + 2] = o[2];
+    }
+    double sa = 0.0;
+    for (int a = threadIdx.x; a < Nn; a += 256) {
+        const float *ra = lr + a * 9, *ta = lt + a * 3;
+        const float ga[3] = {gp[a * 3], gp[a * 3 + 1], gp[a * 3 + 2]};
+        for (int q = 0; q < 9; ++q) {
+            const int nb = ring[((size_t)b * Nn + a) * 9 + q];
+            const float *tb = lt + nb * 3;
+            const float gb[3] = {gp[nb * 3], gp[nb * 3 + 1], gp[nb * 3 + 2]};
+            const float dx = ga[0] - gb[0], dy = ga[1] - gb[1], dz = ga[2] - gb[2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float rv = (ra[3 * c] * dx + ra[3 * c + 1] * dy) + ra[3 * c + 2] * dz;
+                const float e = ((ga[c] + ta[c]) - (gb[c] + tb[c])) - rv;
+                sa += (double)(e * e);
+            }
+        }
+    }
+    red[threadIdx.x] = sa;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) arap[(size_t)b * arap_stride] = (float)(red[0] / (double)Nn);
+}
+
 int launch_dg_warp_rt(const float *xyz, int B, int N, const int32_t *nodes_idx, const int32_t *ring,
                       const int32_t *infl_idx, const float *weights, const float *R, const float *T, float *warped,
                       float *arap, int arap_stride, float *sr, hipStream_t s) {
@@ -406,6 +478,14 @@ int launch_dg_warp(const float *xyz, int B, int N, const int32_t *nodes_idx, con
                    const float *weights, const float *def9, float *R, float *T, float *warped, float *arap, int arap_stride,
                    float *sr, hipStream_t s) {
     const int Nn = N / 2;
+    static const int fused_on = [] { const char *e = getenv("DVM_WARP_FUSED"); return e ? atoi(e) : 1; }();
+    const size_t lds = (size_t)Nn * 15 * sizeof(float);
+    if (fused_on && !sr && lds <= 150 * 1024) {   // (sr — the unused smooth-rotation term — only through the separate kernels)
+        ensure_dyn_lds((const void *)dg_warp_arap_fused_kernel, (int)lds);
+        hipLaunchKernelGGL(dg_warp_arap_fused_kernel, dim3(B), dim3(256), lds, s, xyz, N, Nn, nodes_idx, ring, infl_idx, weights, def9, R, T,
+                           warped, arap, arap_stride);
+        return DVM_OK;
+    }
     hipLaunchKernelGGL(rot6d_kernel, dim3((B * Nn + 255) / 256), dim3(256), 0, s, def9, B * Nn, R, T);
     hipLaunchKernelGGL(dg_warp_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, xyz, N, Nn, nodes_idx, infl_idx, weights, R, T,
                        warped);
