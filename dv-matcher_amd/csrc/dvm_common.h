@@ -93,6 +93,7 @@ static inline GridBuf grid_slice(const GridBuf &g, int b0) {
 }
 GridBuf grid_carve(Arena &ar, int B, int P);
 void launch_grid_build(const float *xyz, int B, int Nsrc, const int32_t *sel, const GridBuf &gb, hipStream_t s);
+void launch_grid_build_sets(const float *const *xyz, const int *Nsrc, const GridBuf *gb, int nsets, int B, hipStream_t s);   // up to 4 cloud sets, one launch
 void launch_grid_knn_self(const GridBuf &gb, int B, int k, int32_t *idx, hipStream_t s);
 void launch_grid_ring(const GridBuf &gnodes, int B, int32_t *ring, hipStream_t s);
 void launch_grid_infl(const float *xyz, int B, int N, const GridBuf &gnodes, const GridBuf &gverts, int32_t *infl, float *dists,

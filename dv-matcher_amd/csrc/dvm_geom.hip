@@ -230,6 +230,44 @@ __global__ __launch_bounds__(256) void apply_kernel(const float *__restrict__ pi
         if (c0 + e < C) out[row * C + c0 + e] = acc[e];
 }
 
+// Pi~ @ verts (C = 3, top-10) of BOTH directions of a pair batch in one launch, with the arg-max maps: one workgroup per (cloud,
+// direction) stages the target coordinates (12 M bytes) in LDS, a thread takes rows i, i + 256, ...: T[i] = the row's first
+// column (the arg-max, before the sort), then apply_kernel's column-ordered fma chains — the same bits.  (Two apply_kernel and
+// two take_col0 launches before; their 10 coordinate gathers per row went through L2.)
+struct Apply3Pair {
+    const float *val[2], *V[2];
+    const int32_t *idx[2];
+    float *out[2];
+    int32_t *T[2];
+    int N[2], M[2];
+};
+__global__ __launch_bounds__(256) void apply3_pair_kernel(const Apply3Pair a) {
+    extern __shared__ __attribute__((aligned(16))) float ap_lds[];   // [M][3]
+    const int b = blockIdx.x, d = blockIdx.y;
+    const int N = a.N[d], M = a.M[d];
+    const float *Vb = a.V[d] + (size_t)b * M * 3;
+    for (int e = threadIdx.x; e < M * 3; e += 256) ap_lds[e] = Vb[e];
+    __syncthreads();
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const size_t row = (size_t)b * N + i;
+        float v[10];
+        int c[10];
+#pragma unroll
+        for (int t = 0; t < 10; ++t) v[t] = a.val[d][row * 10 + t], c[t] = a.idx[d][row * 10 + t];
+        a.T[d][row] = c[0];
+        sort_by_col<10>(v, c);
+        float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 10; ++t) {
+            const float *p = ap_lds + 3 * c[t];
+            acc[0] = fmaf(v[t], p[0], acc[0]);
+            acc[1] = fmaf(v[t], p[1], acc[1]);
+            acc[2] = fmaf(v[t], p[2], acc[2]);
+        }
+        a.out[d][row * 3] = acc[0], a.out[d][row * 3 + 1] = acc[1], a.out[d][row * 3 + 2] = acc[2];
+    }
+}
+
 // Backward of apply_kernel: out[i] = sum_t val[i,t] V[idx[i,t]]  =>  d_val[i,t] = g[i] . V[idx[i,t]],
 // d_V[idx[i,t]] += val[i,t] g[i] (fp32 atomics).  A row's ceil(C/4) channel groups sit in GP2 (power of two
 // >= groups, <= 64) consecutive lanes so the dot products reduce with shuffles.
@@ -1036,6 +1074,19 @@ int launch_map_term_nbr(const float *verts12, const float *nbr2, const int32_t *
     return DVM_OK;
 }
 // -> true if the LDS form ran (topk == 10, the target side fits 150 KB of LDS); else the caller uses one of the older forms
+// -> false if a target cloud does not fit LDS (the caller then uses apply_kernel + take_col0)
+bool launch_apply3_pair(const float *val12, const int32_t *idx12, const float *verts2, float *verts12, int32_t *T12, const float *val21,
+                        const int32_t *idx21, const float *verts1, float *verts21, int32_t *T21, int B, int N, int M, hipStream_t s) {
+    static const int on = [] { const char *e = getenv("DVM_APPLY_LDS"); return e ? atoi(e) : 1; }();
+    const size_t lds = (size_t)(N > M ? N : M) * 3 * sizeof(float);
+    if (!on || lds > 150 * 1024) return false;
+    Apply3Pair a;
+    a.val[0] = val12, a.idx[0] = idx12, a.V[0] = verts2, a.out[0] = verts12, a.T[0] = T12, a.N[0] = N, a.M[0] = M;
+    a.val[1] = val21, a.idx[1] = idx21, a.V[1] = verts1, a.out[1] = verts21, a.T[1] = T21, a.N[1] = M, a.M[1] = N;
+    ensure_dyn_lds((const void *)apply3_pair_kernel, (int)lds);
+    hipLaunchKernelGGL(apply3_pair_kernel, dim3(B, 2), dim3(256), lds, s, a);
+    return true;
+}
 bool map_term_lds_applies(int M, int k) {
     static const int on = [] { const char *e = getenv("DVM_MAP_LDS"); return e ? atoi(e) : 1; }();
     return on && (((size_t)M * 3 * sizeof(float) + 15) / 16) * 16 + (size_t)M * k * sizeof(int32_t) <= 150 * 1024;

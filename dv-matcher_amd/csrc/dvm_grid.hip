@@ -41,8 +41,25 @@ static int grid_dim_for(int P) {
 }
 
 // One workgroup per shape.  src points are xyz[sel[j]] (sel == nullptr: identity), j < P.
+// up to four (cloud set, grid) pairs built by ONE launch (blockIdx.y = set): the pair path builds the grids of its four Chamfer
+// clouds back to back on the main stream, one workgroup per cloud each — four launches of B workgroups were four launch gaps
+struct GridBuildSets {
+    const float *xyz[4];
+    int Nsrc[4];
+    GridBuf gb[4];
+};
+template <bool SETS>
+__device__ __forceinline__ void grid_build_body(const float *__restrict__ xyz, int Nsrc, const int32_t *__restrict__ sel, const GridBuf &gb);
+__global__ __launch_bounds__(GRID_T) void grid_build_sets_kernel(const GridBuildSets sets) {
+    const int q = blockIdx.y;
+    grid_build_body<true>(sets.xyz[q], sets.Nsrc[q], nullptr, sets.gb[q]);
+}
 __global__ __launch_bounds__(GRID_T) void grid_build_kernel(const float *__restrict__ xyz, int Nsrc,
                                                             const int32_t *__restrict__ sel, GridBuf gb) {
+    grid_build_body<false>(xyz, Nsrc, sel, gb);
+}
+template <bool SETS>
+__device__ __forceinline__ void grid_build_body(const float *__restrict__ xyz, int Nsrc, const int32_t *__restrict__ sel, const GridBuf &gb) {
     extern __shared__ int lds[];  // [G^3 + 1] counts/starts, then cursors [G^3]
     __shared__ float red[6][GRID_T / 64];
     __shared__ float par[8];
@@ -826,6 +843,18 @@ GridBuf grid_carve(Arena &ar, int B, int P) {
     return gb;
 }
 
+void launch_grid_build_sets(const float *const *xyz, const int *Nsrc, const GridBuf *gb, int nsets, int B, hipStream_t s) {
+    GridBuildSets sets;
+    size_t lds = 0;
+    for (int q = 0; q < 4; ++q) {
+        const int r = q < nsets ? q : 0;
+        sets.xyz[q] = xyz[r], sets.Nsrc[q] = Nsrc[r], sets.gb[q] = gb[r];
+        const int G3 = gb[r].G * gb[r].G * gb[r].G;
+        const size_t nb = (size_t)(2 * G3 + 1) * sizeof(int);
+        lds = nb > lds ? nb : lds;
+    }
+    hipLaunchKernelGGL(grid_build_sets_kernel, dim3(B, nsets), dim3(GRID_T), lds, s, sets);
+}
 void launch_grid_build(const float *xyz, int B, int Nsrc, const int32_t *sel, const GridBuf &gb, hipStream_t s) {
     const int G3 = gb.G * gb.G * gb.G;
     size_t lds = (size_t)(2 * G3 + 1) * sizeof(int);

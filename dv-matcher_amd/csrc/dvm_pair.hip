@@ -20,6 +20,8 @@ int launch_map_term(const float *verts12, const float *verts2, const int32_t *id
 bool launch_map_term_lds(const float *verts12, const float *verts2, const int32_t *idx11, const int32_t *idx22, const float *pi_val,
                          const int32_t *pi_idx, int B, int N, int M, int k, int topk, double *partial, hipStream_t s);
 bool map_term_lds_applies(int M, int k);
+bool launch_apply3_pair(const float *val12, const int32_t *idx12, const float *verts2, float *verts12, int32_t *T12, const float *val21,
+                        const int32_t *idx21, const float *verts1, float *verts21, int32_t *T21, int B, int N, int M, hipStream_t s);
 int launch_dg_build(const float *xyz, int B, int N, const int32_t *start, int32_t *nodes_idx, int32_t *ring, int32_t *infl_idx,
                     float *dists, float *weights, double *sigma, double *nnd, const GridBuf &gverts, const GridBuf &gnodes,
                     bool build_gverts, hipStream_t s);
@@ -360,12 +362,14 @@ static int pair_fwd_impl(const float *feat1, const float *feat2, const float *ve
     rc = launch_softcorr_pair(feat1, feat2, w.nrm[0], w.nrm[1], B, N, M, neg_alpha, w.pval[0], w.pidx[0], w.pval[1], w.pidx[1], w.k1ws,
                               w.k1ws_bytes, s);
     if (rc != DVM_OK) return fail(rc);
-    hipLaunchKernelGGL(take_col0_kernel, dim3((B * N + 255) / 256), dim3(256), 0, s, w.pidx[0], B * N, 10, T12);
-    hipLaunchKernelGGL(take_col0_kernel, dim3((B * M + 255) / 256), dim3(256), 0, s, w.pidx[1], B * M, 10, T21);
-    rc = dvm_softcorr_apply_f32(w.pval[0], w.pidx[0], verts2, B, N, M, 10, 3, verts12, s);
-    if (rc != DVM_OK) return fail(rc);
-    rc = dvm_softcorr_apply_f32(w.pval[1], w.pidx[1], verts1, B, M, N, 10, 3, verts21, s);
-    if (rc != DVM_OK) return fail(rc);
+    if (!launch_apply3_pair(w.pval[0], w.pidx[0], verts2, verts12, T12, w.pval[1], w.pidx[1], verts1, verts21, T21, B, N, M, s)) {
+        hipLaunchKernelGGL(take_col0_kernel, dim3((B * N + 255) / 256), dim3(256), 0, s, w.pidx[0], B * N, 10, T12);
+        hipLaunchKernelGGL(take_col0_kernel, dim3((B * M + 255) / 256), dim3(256), 0, s, w.pidx[1], B * M, 10, T21);
+        rc = dvm_softcorr_apply_f32(w.pval[0], w.pidx[0], verts2, B, N, M, 10, 3, verts12, s);
+        if (rc != DVM_OK) return fail(rc);
+        rc = dvm_softcorr_apply_f32(w.pval[1], w.pidx[1], verts1, B, M, N, 10, 3, verts21, s);
+        if (rc != DVM_OK) return fail(rc);
+    }
     if (overlap) (void)hipStreamWaitEvent(caller, cx->ev_join, 0);  // join: everything below needs the graphs / kNN
     // ---- Deformer: z for both directions from the pooled features (made above), one MLP launch
     const int Nn1 = N / 2, Nn2 = M / 2;
@@ -382,10 +386,12 @@ static int pair_fwd_impl(const float *feat1, const float *feat2, const float *ve
                    nullptr, s);
     // ---- the four Chamfer terms, both sides each, in one grouped launch
     {
-        launch_grid_build(warped12, B, N, nullptr, w.gw[0], s);
-        launch_grid_build(verts12, B, N, nullptr, w.gc[0], s);
-        launch_grid_build(warped21, B, M, nullptr, w.gw[1], s);
-        launch_grid_build(verts21, B, M, nullptr, w.gc[1], s);
+        {   // the grids of the four Chamfer clouds in one launch
+            const float *const gx[4] = {warped12, verts12, warped21, verts21};
+            const int gn[4] = {N, N, M, M};
+            const GridBuf gg[4] = {w.gw[0], w.gc[0], w.gw[1], w.gc[1]};
+            launch_grid_build_sets(gx, gn, gg, 4, B, s);
+        }
         const GridBuf qg[8] = {w.gw[0], w.gv[1], w.gc[0], w.gv[1], w.gw[1], w.gv[0], w.gc[1], w.gv[0]};
         const GridBuf tg[8] = {w.gv[1], w.gw[0], w.gv[1], w.gc[0], w.gv[0], w.gw[1], w.gv[0], w.gc[1]};
         const int Na[8] = {N, M, N, M, M, N, M, N};
