@@ -36,8 +36,20 @@ __device__ __forceinline__ void split3(float x, __bf16 &h, __bf16 &m, __bf16 &l)
 
 // Packed weights: Wp[otile][step][plane][lane][8] bf16 with element j of lane (o = lane&31, hh = lane>>5)
 // = plane(W[otile*32 + o][16*step + 8*hh + j])  (0 outside the matrix).
-__global__ void pack_weights_bf16_kernel(const float *__restrict__ W, int O, int I, int otiles, int steps,
-                                         __bf16 *__restrict__ Wp) {
+// the four layers in ONE launch (blockIdx.y = layer), gated like the kernel they serve: as the range-safe fallback of the fp16x2
+// MLP (gate != nullptr) nothing is packed unless the flag is set
+struct PackLayersBf16 {
+    const float *W[4];
+    int O[4], I[4], otiles[4], steps[4];
+    __bf16 *Wp[4];
+};
+__device__ __forceinline__ void pack_weights_bf16_body(const float *__restrict__ W, int O, int I, int otiles, int steps, __bf16 *__restrict__ Wp);
+__global__ void pack_layers_bf16_kernel(const PackLayersBf16 a, const int *__restrict__ gate) {
+    if (gate && *gate == 0) return;
+    const int q = blockIdx.y;
+    pack_weights_bf16_body(a.W[q], a.O[q], a.I[q], a.otiles[q], a.steps[q], a.Wp[q]);
+}
+__device__ __forceinline__ void pack_weights_bf16_body(const float *__restrict__ W, int O, int I, int otiles, int steps, __bf16 *__restrict__ Wp) {
     long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
     long total = (long)otiles * steps * 64 * 8;
     if (g >= total) return;
@@ -182,14 +194,20 @@ void launch_mlp_rows_bf16(const float *z, int rows, const float *W0, const float
     __bf16 *Wp1 = Wp0 + (size_t)16 * (MB_K0 / 16) * 1536;
     __bf16 *Wp2 = Wp1 + (size_t)8 * (MB_K1 / 16) * 1536;
     __bf16 *Wp3 = Wp2 + (size_t)4 * (MB_K2 / 16) * 1536;
-    auto pack = [&](const float *W, int O, int I, int otiles, int steps, __bf16 *Wp) {
-        long th = (long)otiles * steps * 512;
-        hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, W, O, I, otiles, steps, Wp);
-    };
-    pack(W0, 512, 262, 16, MB_K0 / 16, Wp0);
-    pack(W1, 256, 512, 8, MB_K1 / 16, Wp1);
-    pack(W2, 128, 256, 4, MB_K2 / 16, Wp2);
-    pack(W3, 9, 128, 1, MB_K3 / 16, Wp3);
+    {
+        PackLayersBf16 a;
+        long maxth = 0;
+        auto layer = [&](int q, const float *W, int O, int I, int otiles, int steps, __bf16 *Wp) {
+            a.W[q] = W, a.O[q] = O, a.I[q] = I, a.otiles[q] = otiles, a.steps[q] = steps, a.Wp[q] = Wp;
+            const long th = (long)otiles * steps * 512;
+            maxth = th > maxth ? th : maxth;
+        };
+        layer(0, W0, 512, 262, 16, MB_K0 / 16, Wp0);
+        layer(1, W1, 256, 512, 8, MB_K1 / 16, Wp1);
+        layer(2, W2, 128, 256, 4, MB_K2 / 16, Wp2);
+        layer(3, W3, 9, 128, 1, MB_K3 / 16, Wp3);
+        hipLaunchKernelGGL(pack_layers_bf16_kernel, dim3((unsigned)((maxth + 255) / 256), 4), dim3(256), 0, s, a, gate);
+    }
     ensure_dyn_lds((const void *)mlp_bf16x3_kernel, (int)MB_LDS_BYTES);
     hipLaunchKernelGGL(mlp_bf16x3_kernel, dim3((rows + MB_NODES - 1) / MB_NODES), dim3(MB_THREADS), MB_LDS_BYTES, s, z, rows, Wp0,
                        b0, Wp1, b1, Wp2, b2, Wp3, b3, out, gate);

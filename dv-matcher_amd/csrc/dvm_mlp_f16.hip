@@ -42,8 +42,20 @@ __device__ __forceinline__ void split2(float xs, _Float16 &h, _Float16 &m) {
 
 // Packed weights: Wp[otile][step][plane][lane][8] fp16, element j of lane (o = lane&31, hh = lane>>5)
 // = plane(S_w * W[otile*32 + o][16*step + 8*hh + j])  (0 outside the matrix)
-__global__ void pack_weights_f16_kernel(const float *__restrict__ W, int O, int I, int otiles, int steps, _Float16 *__restrict__ Wp,
-                                        int *__restrict__ flag) {
+// the four layers of the MLP in ONE launch (blockIdx.y = layer; four launches before: four gaps on the main stream in front of the MLP)
+struct PackLayersF16 {
+    const float *W[4];
+    int O[4], I[4], otiles[4], steps[4];
+    _Float16 *Wp[4];
+};
+__device__ __forceinline__ void pack_weights_f16_body(const float *__restrict__ W, int O, int I, int otiles, int steps, _Float16 *__restrict__ Wp,
+                                                      int *__restrict__ flag);
+__global__ void pack_layers_f16_kernel(const PackLayersF16 a, int *__restrict__ flag) {
+    const int q = blockIdx.y;
+    pack_weights_f16_body(a.W[q], a.O[q], a.I[q], a.otiles[q], a.steps[q], a.Wp[q], flag);
+}
+__device__ __forceinline__ void pack_weights_f16_body(const float *__restrict__ W, int O, int I, int otiles, int steps, _Float16 *__restrict__ Wp,
+                                                      int *__restrict__ flag) {
     long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
     long total = (long)otiles * steps * 64 * 8;
     if (g >= total) return;
@@ -315,15 +327,20 @@ int *launch_mlp_rows_f16(const float *z, int rows, const float *W0, const float 
     _Float16 *Wp3 = Wp2 + (size_t)4 * (MH_K2 / 16) * 1024;
     int *flag = (int *)((char *)scratch + mlp_f16_pack_bytes() - align_up(sizeof(int)));
     (void)hipMemsetAsync(flag, 0, sizeof(int), s);
-    auto pack = [&](const float *W, int O, int I, int otiles, int steps, _Float16 *Wp) {
-        long th = (long)otiles * steps * 512;
-        hipLaunchKernelGGL(pack_weights_f16_kernel, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, W, O, I, otiles, steps, Wp,
-                           flag);
-    };
-    pack(W0, 512, 262, 16, MH_K0 / 16, Wp0);
-    pack(W1, 256, 512, 8, MH_K1 / 16, Wp1);
-    pack(W2, 128, 256, 4, MH_K2 / 16, Wp2);
-    pack(W3, 9, 128, 1, MH_K3 / 16, Wp3);
+    {
+        PackLayersF16 a;
+        long maxth = 0;
+        auto layer = [&](int q, const float *W, int O, int I, int otiles, int steps, _Float16 *Wp) {
+            a.W[q] = W, a.O[q] = O, a.I[q] = I, a.otiles[q] = otiles, a.steps[q] = steps, a.Wp[q] = Wp;
+            const long th = (long)otiles * steps * 512;
+            maxth = th > maxth ? th : maxth;
+        };
+        layer(0, W0, 512, 262, 16, MH_K0 / 16, Wp0);
+        layer(1, W1, 256, 512, 8, MH_K1 / 16, Wp1);
+        layer(2, W2, 128, 256, 4, MH_K2 / 16, Wp2);
+        layer(3, W3, 9, 128, 1, MH_K3 / 16, Wp3);
+        hipLaunchKernelGGL(pack_layers_f16_kernel, dim3((unsigned)((maxth + 255) / 256), 4), dim3(256), 0, s, a, flag);
+    }
     // weight k-steps requested ahead of their matrix instructions: 2 / 4 / 8 measured alike (2.74 / 2.83 / 2.82 ms per launch
     // at 512 pairs) — the waves' 59 % parked cycles (SQ_WAIT_ANY) are not the L2 latency of the weights (DVM_MLP_AHEAD = A/B)
     static const int ahead = [] {

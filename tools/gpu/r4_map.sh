@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_abi_state.py tests/test_gpu_stress.py -m gpu -q --timeout 900 2>&1 | grep -v amdgpu | tail -3
-for m in 0 1 0 1; do echo "DVM_APPLY_LDS=$m"; DVM_APPLY_LDS=$m python bench.py --steps 20 --warmup 5 --cpu-sample 0 2>/dev/null | python -c "
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_backbone.py -m gpu -q --timeout 900 -k "deformer or mlp or pair or criterion" 2>&1 | grep -v amdgpu | tail -3
+for i in 1 2; do python bench.py --steps 20 --warmup 5 --cpu-sample 0 2>/dev/null | python -c "
 import json,sys
 j=json.loads(sys.stdin.read()); print(round(j['value']), round(j['ms_per_step'],3), j['check']['ok'], 'cached', round(j['graph_cached']['value']))"; done
