@@ -50,14 +50,20 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float *__restrict__ xy
     for (int it = 0; it < npoint; ++it) {
         if (tid == 0) o[it] = far;
         const float cx = cloud[3 * far], cy = cloud[3 * far + 1], cz = cloud[3 * far + 2];
-        ArgMax best = {-INFINITY, 0x7fffffff};
+        // the running minima (one v_min each: fminf keeps dist where dv is a NaN, as `dv < dist ? dv : dist` did), the thread's largest
+        // one (v_max), then ITS FIRST position from a descending pass of compare + select: 4 instructions per point instead of the 5
+        // of a (value, index) pair carried through the loop; same arg-max (largest value, lowest index)
+        float bv = -INFINITY;
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
-            float dv = d2_diff3(px[q], py[q], pz[q], cx, cy, cz);
-            dist[q] = (dv < dist[q]) ? dv : dist[q];
-            ArgMax c = {dist[q], tid + q * FPS_T};
-            best = (c.v > best.v) ? c : best;  // ascending index within the thread: strict keeps the first
+            const float dv = d2_diff3(px[q], py[q], pz[q], cx, cy, cz);
+            dist[q] = fminf(dist[q], dv);
+            bv = fmaxf(bv, dist[q]);
         }
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int q = PPT - 1; q >= 0; --q) bi = (dist[q] == bv) ? tid + q * FPS_T : bi;
+        ArgMax best = {bv, bi};
         // wave arg-max by two DPP reductions (distances are >= 0 or -inf: order-preserving as sign-flipped integers):
         // the largest value, then the lowest index among its holders — instead of six dependent (value, index)
         // shuffle pairs through the LDS crossbar, which dominated this latency-bound loop
