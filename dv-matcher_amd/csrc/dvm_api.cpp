@@ -56,6 +56,20 @@ void ensure_dyn_lds(const void *kernel, int bytes) {
     if (it != g_attr_bytes.end() && it->second >= bytes) return;
     if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess) g_attr_bytes[{dev, kernel}] = bytes;
 }
+// compute units of the current device (cached per device): the grid of the persistent kernels
+int device_cu_count() {
+    static std::mutex mu;
+    static std::map<int, int> cus;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cus.find(dev);
+    if (it != cus.end()) return it->second;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+    cus[dev] = n;
+    return n;
+}
 }  // namespace dvm
 
 // ---------------------------------------------------------------- helper streams of dvm_pair_fwd_f32

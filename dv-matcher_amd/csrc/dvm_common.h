@@ -21,6 +21,7 @@ bool deterministic();   // dvm_api.cpp: dvm_set_deterministic / DVM_DETERMINISTI
 void prof_note(int id, const char *name);   // which kernel(s) the slot's bracket enclosed (reported by dvm_profile_kernel_name)
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (current device, kernel) — dvm_api.cpp
 void ensure_dyn_lds(const void *kernel, int bytes);
+int device_cu_count();   // compute units of the current device (cached)
 // helper streams / events of dvm_pair_fwd_f32 for one (device, caller stream), made by dvm_pair_init — dvm_api.cpp
 struct PairCtx {
     int device = 0;

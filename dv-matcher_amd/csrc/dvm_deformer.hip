@@ -13,6 +13,7 @@
 // into the MFMA B-fragment order so each k-step is one coalesced 256-B load per wave.  The
 // accumulation is the same k-ordered fma chain as the oracle's (and torch's CPU addmm).
 #include "dvm_common.h"
+#include "dvm_mlp_f16.h"
 
 namespace dvm {
 
@@ -154,12 +155,16 @@ __global__ __launch_bounds__(256) void assemble_kernel(const float *__restrict__
 
 // z row from POOLED features of both clouds (used by the two-direction path, where g(feat, idx) is
 // computed once per cloud):  z[n] = [vsrc_v, gsrc[v,:], vcorr_v, sum_t P[v,t] gtgt[pidx[v,t],:]], v = fps[n]
-template <int TOPK>
+// PLANES: the row goes out in the plane form the persistent MLP kernel stages by LDS-DMA (dvm_mlp_f16.h: scaled by 32, split into
+// two fp16 planes, the two 128-wide blocks first) instead of as 264 floats; gate (fp32 form only): the launch does nothing unless
+// *gate != 0 — the fp32 rows are needed only by the range fallback of that kernel.
+template <int TOPK, bool PLANES = false>
 __global__ __launch_bounds__(256) void assemble_pooled_kernel(const float *__restrict__ vsrc, const float *__restrict__ vcorr,
                                                               const float *__restrict__ gsrc, const float *__restrict__ gtgt,
                                                               const float *__restrict__ pi_val, const int32_t *__restrict__ pi_idx,
                                                               const int32_t *__restrict__ fps, int N, int M, int Nn, int topk,
-                                                              float *__restrict__ z) {
+                                                              float *__restrict__ z, const int *__restrict__ gate) {
+    if (gate && *gate == 0) return;
     const int b = blockIdx.y;
     const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= (long)Nn * (DF_C / 4)) return;
@@ -218,8 +223,33 @@ __global__ __launch_bounds__(256) void assemble_pooled_kernel(const float *__res
             }
         }
     }
-    float *zr = z + ((size_t)b * Nn + n) * DF_ZS;
     f32x4 gs = *(const f32x4 *)(gsrc + row * DF_C + 4 * c4);
+    if (PLANES) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        char *zr = (char *)z + ((size_t)b * Nn + n) * MH_SZ;
+        unsigned h0, m0, h1, m1;
+        split2x2(gs.x * MH_SA, gs.y * MH_SA, h0, m0);
+        split2x2(gs.z * MH_SA, gs.w * MH_SA, h1, m1);
+        *(u32x2 *)(zr + 8 * c4) = u32x2{h0, h1};
+        *(u32x2 *)(zr + 2 * MH_K0 + 8 * c4) = u32x2{m0, m1};
+        split2x2(acc.x * MH_SA, acc.y * MH_SA, h0, m0);
+        split2x2(acc.z * MH_SA, acc.w * MH_SA, h1, m1);
+        *(u32x2 *)(zr + 256 + 8 * c4) = u32x2{h0, h1};
+        *(u32x2 *)(zr + 2 * MH_K0 + 256 + 8 * c4) = u32x2{m0, m1};
+        if (c4 == 0) {   // plane columns 256..261 = the two points, 262..271 = 0
+            unsigned h2, m2;
+            split2x2(vsrc[row * 3] * MH_SA, vsrc[row * 3 + 1] * MH_SA, h0, m0);
+            split2x2(vsrc[row * 3 + 2] * MH_SA, vcorr[row * 3] * MH_SA, h1, m1);
+            split2x2(vcorr[row * 3 + 1] * MH_SA, vcorr[row * 3 + 2] * MH_SA, h2, m2);
+            *(u32x4 *)(zr + 512) = u32x4{h0, h1, h2, 0u};
+            *(u32x4 *)(zr + 528) = u32x4{0u, 0u, 0u, 0u};
+            *(u32x4 *)(zr + 2 * MH_K0 + 512) = u32x4{m0, m1, m2, 0u};
+            *(u32x4 *)(zr + 2 * MH_K0 + 528) = u32x4{0u, 0u, 0u, 0u};
+        }
+        return;
+    }
+    float *zr = z + ((size_t)b * Nn + n) * DF_ZS;
     zr[3 + 4 * c4] = gs.x, zr[4 + 4 * c4] = gs.y, zr[5 + 4 * c4] = gs.z, zr[6 + 4 * c4] = gs.w;
     zr[134 + 4 * c4] = acc.x, zr[135 + 4 * c4] = acc.y, zr[136 + 4 * c4] = acc.z, zr[137 + 4 * c4] = acc.w;
     if (c4 == 0) {
@@ -384,11 +414,12 @@ __global__ __launch_bounds__(ML_THREADS) void mlp_mfma_kernel(const float *__res
 
 struct DeformerWs {
     float *g2, *z, *Wp0, *Wp1, *Wp2, *Wp3, *h0, *h1, *h2;
+    char *zp;   // the rows in the plane form (input of the persistent MLP kernel)
 };
 
 size_t mlp_pack_floats();
 void launch_mlp_rows(const float *z, int rows, const float *W0, const float *b0, const float *W1, const float *b1, const float *W2,
-                     const float *b2, const float *W3, const float *b3, float *wp, float *out, hipStream_t s, int variant);
+                     const float *b2, const float *W3, const float *b3, float *wp, float *out, hipStream_t s, int variant, void *zp);
 
 static size_t carve(Arena &ar, int B, int M, int Nn, DeformerWs &w) {
     w.g2 = ar.take<float>((size_t)B * M * DF_C);
@@ -400,6 +431,7 @@ static size_t carve(Arena &ar, int B, int M, int Nn, DeformerWs &w) {
     w.h0 = ar.take<float>((size_t)B * Nn * 512);
     w.h1 = ar.take<float>((size_t)B * Nn * 256);
     w.h2 = ar.take<float>((size_t)B * Nn * 128);
+    w.zp = ar.take<char>(mlp_zplane_bytes(B * Nn));
     return ar.off;
 }
 
@@ -438,7 +470,7 @@ int launch_deformer(const float *feat1, const float *feat2, const float *verts1,
         layer(w.h1, 256, W2, b2, 256, 128, 1, w.h2, 128);
         layer(w.h2, 128, W3, b3, 128, 9, 0, out, 9);
     } else {
-        launch_mlp_rows(w.z, rows, W0, b0, W1, b1, W2, b2, W3, b3, w.Wp0, out, s, variant);
+        launch_mlp_rows(w.z, rows, W0, b0, W1, b1, W2, b2, W3, b3, w.Wp0, out, s, variant, w.zp);
     }
     return DVM_OK;
 }
@@ -458,10 +490,18 @@ void launch_pool_all(const float *feat, const int32_t *idx, int B, int P, int k,
     prof_end(s, DVM_PROF_POOL);
 }
 void launch_assemble_pooled(const float *vsrc, const float *vcorr, const float *gsrc, const float *gtgt, const float *pi_val,
-                            const int32_t *pi_idx, const int32_t *fps, int B, int N, int M, int Nn, float *z, hipStream_t s) {
-    prof_begin(s, DVM_PROF_ASSEMBLE);
+                            const int32_t *pi_idx, const int32_t *fps, int B, int N, int M, int Nn, float *z, hipStream_t s, const int *gate) {
+    if (!gate) prof_begin(s, DVM_PROF_ASSEMBLE);
     hipLaunchKernelGGL(assemble_pooled_kernel<10>, dim3((unsigned)(((long)Nn * 32 + 255) / 256), B), dim3(256), 0, s, vsrc, vcorr,
-                       gsrc, gtgt, pi_val, pi_idx, fps, N, M, Nn, 10, z);
+                       gsrc, gtgt, pi_val, pi_idx, fps, N, M, Nn, 10, z, gate);
+    if (!gate) prof_end(s, DVM_PROF_ASSEMBLE);
+}
+// the rows in the plane form (zp: row (b, n) at ((b Nn + n) MH_SZ) bytes)
+void launch_assemble_pooled_planes(const float *vsrc, const float *vcorr, const float *gsrc, const float *gtgt, const float *pi_val,
+                                   const int32_t *pi_idx, const int32_t *fps, int B, int N, int M, int Nn, void *zp, hipStream_t s) {
+    prof_begin(s, DVM_PROF_ASSEMBLE);
+    hipLaunchKernelGGL((assemble_pooled_kernel<10, true>), dim3((unsigned)(((long)Nn * 32 + 255) / 256), B), dim3(256), 0, s, vsrc, vcorr,
+                       gsrc, gtgt, pi_val, pi_idx, fps, N, M, Nn, 10, (float *)zp, (const int *)nullptr);
     prof_end(s, DVM_PROF_ASSEMBLE);
 }
 size_t mlp_bf16_pack_bytes();
@@ -472,6 +512,27 @@ size_t mlp_f16_pack_bytes();
 int *launch_mlp_rows_f16(const float *z, int rows, const float *W0, const float *b0, const float *W1, const float *b1,
                          const float *W2, const float *b2, const float *W3, const float *b3, void *scratch, float *out,
                          hipStream_t s);
+void launch_split_rows(const float *z, int rows, int stride, void *zp, hipStream_t s);
+int *launch_mlp_planes_f16(const void *zp, int rows, const float *W0, const float *b0, const float *W1, const float *b1, const float *W2,
+                           const float *b2, const float *W3, const float *b3, void *scratch, float *out, hipStream_t s);
+// the persistent form of the fp16x2 kernel is the default (DVM_MLP_PERSIST=0: the one-workgroup-per-block kernel it replaced)
+bool mlp_persistent() {
+    static const bool on = [] {
+        const char *e = getenv("DVM_MLP_PERSIST");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+// variant 0 on rows that are in the plane form already; returns the range flag for launch_mlp_fallback
+const int *launch_mlp_planes(const void *zp, int rows, const float *W0, const float *b0, const float *W1, const float *b1, const float *W2,
+                             const float *b2, const float *W3, const float *b3, float *wp, float *out, hipStream_t s) {
+    return launch_mlp_planes_f16(zp, rows, W0, b0, W1, b1, W2, b2, W3, b3, wp, out, s);
+}
+// the bf16x3 kernel on the fp32 rows, gated on the flag
+void launch_mlp_fallback(const float *z, int rows, const float *W0, const float *b0, const float *W1, const float *b1, const float *W2,
+                         const float *b2, const float *W3, const float *b3, float *wp, float *out, hipStream_t s, const int *flag) {
+    launch_mlp_rows_bf16(z, rows, W0, b0, W1, b1, W2, b2, W3, b3, (char *)wp + mlp_f16_pack_bytes(), out, s, flag);
+}
 size_t mlp_pack_floats() {
     size_t f32 = (size_t)16 * 132 * 64 + (size_t)8 * 256 * 64 + (size_t)4 * 128 * 64 + (size_t)64 * 64;
     size_t h16 = (mlp_f16_pack_bytes() + mlp_bf16_pack_bytes() + 3) / 4;  // variant 0 keeps both packings
@@ -481,7 +542,13 @@ size_t mlp_pack_floats() {
 // variant 0: fp16x2-split matrix-core kernel, 64 nodes per workgroup (dvm_mlp_f16.hip), followed by the bf16x3 kernel
 //            gated on its out-of-range flag; 3: bf16x3-split kernel (dvm_mlp_bf16.hip); 2: fp32-MFMA kernel
 void launch_mlp_rows(const float *z, int rows, const float *W0, const float *b0, const float *W1, const float *b1, const float *W2,
-                     const float *b2, const float *W3, const float *b3, float *wp, float *out, hipStream_t s, int variant) {
+                     const float *b2, const float *W3, const float *b3, float *wp, float *out, hipStream_t s, int variant, void *zp) {
+    if (variant == 0 && zp && mlp_persistent()) {
+        launch_split_rows(z, rows, DF_ZS, zp, s);
+        const int *flag = launch_mlp_planes_f16(zp, rows, W0, b0, W1, b1, W2, b2, W3, b3, wp, out, s);
+        launch_mlp_rows_bf16(z, rows, W0, b0, W1, b1, W2, b2, W3, b3, (char *)wp + mlp_f16_pack_bytes(), out, s, flag);
+        return;
+    }
     if (variant == 0) {
         const int *flag = launch_mlp_rows_f16(z, rows, W0, b0, W1, b1, W2, b2, W3, b3, wp, out, s);
         launch_mlp_rows_bf16(z, rows, W0, b0, W1, b1, W2, b2, W3, b3, (char *)wp + mlp_f16_pack_bytes(), out, s, flag);
@@ -558,7 +625,7 @@ DVM_EXPORT int dvm_deformer_mlp_fwd_f32(const float *z, int rows, const float *W
     hipStream_t s = (hipStream_t)stream;
     long th = (long)rows * DF_ZS;
     hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, z, rows, DF_IN, DF_ZS, w.z);
-    launch_mlp_rows(w.z, rows, W0, b0, W1, b1, W2, b2, W3, b3, w.Wp0, out, s, 0);
+    launch_mlp_rows(w.z, rows, W0, b0, W1, b1, W2, b2, W3, b3, w.Wp0, out, s, 0, w.zp);
     DVM_CHECK_LAUNCH("deformer_mlp");
     return DVM_OK;
 }

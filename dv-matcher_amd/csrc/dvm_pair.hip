@@ -175,10 +175,18 @@ int launch_softcorr_pair(const float *f1, const float *f2, float *n1, float *n2,
 void launch_pool_all(const float *feat, const int32_t *idx, int B, int P, int k, const float *cw, const float *cb, float *out,
                      hipStream_t s, const int32_t *order = nullptr);
 void launch_assemble_pooled(const float *vsrc, const float *vcorr, const float *gsrc, const float *gtgt, const float *pi_val,
-                            const int32_t *pi_idx, const int32_t *fps, int B, int N, int M, int Nn, float *z, hipStream_t s);
+                            const int32_t *pi_idx, const int32_t *fps, int B, int N, int M, int Nn, float *z, hipStream_t s, const int *gate = nullptr);
+void launch_assemble_pooled_planes(const float *vsrc, const float *vcorr, const float *gsrc, const float *gtgt, const float *pi_val,
+                                   const int32_t *pi_idx, const int32_t *fps, int B, int N, int M, int Nn, void *zp, hipStream_t s);
 size_t mlp_pack_floats();
+size_t mlp_zplane_bytes(int rows);
+bool mlp_persistent();
 void launch_mlp_rows(const float *z, int rows, const float *W0, const float *b0, const float *W1, const float *b1, const float *W2,
-                     const float *b2, const float *W3, const float *b3, float *wp, float *out, hipStream_t s, int variant);
+                     const float *b2, const float *W3, const float *b3, float *wp, float *out, hipStream_t s, int variant, void *zp);
+const int *launch_mlp_planes(const void *zp, int rows, const float *W0, const float *b0, const float *W1, const float *b1, const float *W2,
+                             const float *b2, const float *W3, const float *b3, float *wp, float *out, hipStream_t s);
+void launch_mlp_fallback(const float *z, int rows, const float *W0, const float *b0, const float *W1, const float *b1, const float *W2,
+                         const float *b2, const float *W3, const float *b3, float *wp, float *out, hipStream_t s, const int *flag);
 int launch_chamfer_grouped(const float *const *a, const float *const *b, const int *Na, const int *Nb, float *const *dout,
                            int ngroups, int B, hipStream_t s);
 
@@ -189,6 +197,7 @@ struct Pair2Ws {
     float *dists[2], *weights[2], *pval[2], *nrm[2], *gall[2];
     double *nnd[2], *partial[2];
     float *z, *def9, *R, *T, *wp;
+    char *zp;          // the Deformer rows in the plane form (dvm_mlp_f16.h)
     float *nbrxyz[2];  // [B][P][10][3] coordinates of every point's xyz neighbours (map term)
     char *k1ws;  // soft-correspondence scratch (fp16 planes, candidates, flags)
     size_t k1ws_bytes;
@@ -216,6 +225,7 @@ static size_t carve_pair2(Arena &ar, int B, int N, int M, Pair2Ws &w) {
     for (int sd = 0; sd < 2; ++sd) w.partial[sd] = ar.take<double>((size_t)B * map_term_blocks(P[sd], 10));
     const size_t rows = (size_t)B * (N / 2) + (size_t)B * (M / 2);
     w.z = ar.take<float>(rows * 264);
+    w.zp = ar.take<char>(mlp_zplane_bytes((int)rows));
     w.def9 = ar.take<float>(rows * 9);
     w.R = ar.take<float>(rows * 9);
     w.T = ar.take<float>(rows * 3);
@@ -374,10 +384,22 @@ static int pair_fwd_impl(const float *feat1, const float *feat2, const float *ve
     // ---- Deformer: z for both directions from the pooled features (made above), one MLP launch
     const int Nn1 = N / 2, Nn2 = M / 2;
     float *z21 = w.z + (size_t)B * Nn1 * 264;
-    launch_assemble_pooled(verts1, verts12, w.gall[0], w.gall[1], w.pval[0], w.pidx[0], w.nodes[0], B, N, M, Nn1, w.z, s);
-    launch_assemble_pooled(verts2, verts21, w.gall[1], w.gall[0], w.pval[1], w.pidx[1], w.nodes[1], B, M, N, Nn2, z21, s);
     const int rows = B * (Nn1 + Nn2);
-    launch_mlp_rows(w.z, rows, W0, b0, W1, b1, W2, b2, W3, b3, w.wp, w.def9, s, 0);
+    if (mlp_persistent()) {
+        // the rows straight in the plane form the persistent MLP kernel stages by LDS-DMA; the fp32 rows are written (and the
+        // bf16x3 kernel runs) only if that kernel's range flag comes up: three gated launches that return at once otherwise
+        char *zp21 = w.zp + (size_t)B * Nn1 * 1104;
+        launch_assemble_pooled_planes(verts1, verts12, w.gall[0], w.gall[1], w.pval[0], w.pidx[0], w.nodes[0], B, N, M, Nn1, w.zp, s);
+        launch_assemble_pooled_planes(verts2, verts21, w.gall[1], w.gall[0], w.pval[1], w.pidx[1], w.nodes[1], B, M, N, Nn2, zp21, s);
+        const int *flag = launch_mlp_planes(w.zp, rows, W0, b0, W1, b1, W2, b2, W3, b3, w.wp, w.def9, s);
+        launch_assemble_pooled(verts1, verts12, w.gall[0], w.gall[1], w.pval[0], w.pidx[0], w.nodes[0], B, N, M, Nn1, w.z, s, flag);
+        launch_assemble_pooled(verts2, verts21, w.gall[1], w.gall[0], w.pval[1], w.pidx[1], w.nodes[1], B, M, N, Nn2, z21, s, flag);
+        launch_mlp_fallback(w.z, rows, W0, b0, W1, b1, W2, b2, W3, b3, w.wp, w.def9, s, flag);
+    } else {
+        launch_assemble_pooled(verts1, verts12, w.gall[0], w.gall[1], w.pval[0], w.pidx[0], w.nodes[0], B, N, M, Nn1, w.z, s);
+        launch_assemble_pooled(verts2, verts21, w.gall[1], w.gall[0], w.pval[1], w.pidx[1], w.nodes[1], B, M, N, Nn2, z21, s);
+        launch_mlp_rows(w.z, rows, W0, b0, W1, b1, W2, b2, W3, b3, w.wp, w.def9, s, 0, nullptr);
+    }
     // ---- ED warp + ARAP (losses[:,2])
     float *def21 = w.def9 + (size_t)B * Nn1 * 9, *R21 = w.R + (size_t)B * Nn1 * 9, *T21v = w.T + (size_t)B * Nn1 * 3;
     launch_dg_warp(verts1, B, N, w.nodes[0], w.ring[0], w.infl[0], w.weights[0], w.def9, w.R, w.T, warped12, losses12 + 2, 6,

@@ -528,6 +528,51 @@ def test_deformer_mlp_fp16_range_fallback(ops, golden):
     np.testing.assert_allclose(host(ref), x, rtol=2e-5, atol=2e-5 * np.abs(x).max())
 
 
+@pytest.mark.parametrize("rows", [1, 63, 64, 65, 200, 2 * 256 * 64 + 77])
+def test_deformer_mlp_persistent_form_row_counts(ops, golden, rows):
+    """Variant 0's persistent kernel walks 64-row blocks, the next block's fp16 planes arriving by LDS-DMA while the current one
+    is computed: row counts below / at / above a block, and more blocks than the chip has compute units (every workgroup walks
+    three), against the fp64 MLP on the host.  (reference models/model.py:433-452)"""
+    w = golden("deformer_scape_r_weights")
+    wl = ops.deformer_weight_list(dict(w), "cuda")
+    g = torch.Generator().manual_seed(rows)
+    z = torch.randn(1, rows, 262, generator=g)
+    z[..., :3] = torch.rand(1, rows, 3, generator=g)
+    got = host(ops.deformer_mlp(wl, z.cuda()))
+    W = [w["deformation_decoder_layer__linear__%d__weight" % i].astype(np.float64) for i in (0, 2, 4, 6)]
+    bb = [w["deformation_decoder_layer__linear__%d__bias" % i].astype(np.float64) for i in (0, 2, 4, 6)]
+    x = z.numpy().astype(np.float64)
+    for i in range(4):
+        x = x @ W[i].T + bb[i]
+        if i < 3:
+            x = np.where(x > 0, x, np.expm1(x))
+    assert got.shape == x.shape and np.isfinite(got).all()
+    np.testing.assert_allclose(got, x, rtol=2e-5, atol=2e-5 * np.abs(x).max())
+    again = host(ops.deformer_mlp(wl, z.cuda()))
+    assert np.array_equal(got, again)                      # fixed summation order: bit-reproducible
+
+
+def test_pair_forward_range_fallback_equals_two_directions(ops, golden):
+    """Coordinates far outside fp16's range (|32 v| > 65504): the persistent MLP kernel's outputs are NaN for those nodes, its flag
+    comes up, and the GATED launches behind it — the fp32 rows, then the bf16x3 kernel — deliver the result.  The fused entry
+    assembles its rows in the plane form and re-assembles them as floats under the gate; the one-direction entry keeps the float
+    rows: both must agree bit for bit, and be finite."""
+    B, N, M = 2, 330, 330
+    w = golden("deformer_scape_r_weights")
+    wl = ops.deformer_weight_list(w, "cuda")
+    f1, f2, v1, v2, s1 = _pair_inputs(B, N, M, 77)
+    v1, v2 = v1 * 3000.0, v2 * 3000.0
+    s2 = torch.arange(B, dtype=torch.int32) % M
+    d = [t.cuda() for t in (f1, f2, v1, v2)]
+    o12, o21 = ops.pair_forward(wl, *d, 33.0, s1.cuda(), s2.cuda())
+    r12 = ops.pair_direction(wl, d[0], d[1], d[2], d[3], 33.0, s1.cuda())
+    r21 = ops.pair_direction(wl, d[1], d[0], d[3], d[2], 33.0, s2.cuda())
+    for k in r12:
+        assert torch.equal(o12[k], r12[k]), ("12", k)
+        assert torch.equal(o21[k], r21[k]), ("21", k)
+    assert torch.isfinite(o12["warped"]).all() and torch.isfinite(o21["warped"]).all()
+
+
 @pytest.mark.parametrize("rows,K", [(1, 128), (7, 128), (4096 + 3, 128), (2 * 2048, 128), (513, 64), (300, 262), (64, 3)])
 def test_rownorm2_bit_exact(ops, rows, K):
     """|x|^2 per row in ATen's summation order (the norms cdist's matmul form adds to the products): the K = 128 kernel's

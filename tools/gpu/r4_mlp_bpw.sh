@@ -1,0 +1,9 @@
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/mlp
+run() { timeout 300 python bench.py --steps 20 --warmup 5 --cpu-sample 0 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=[x for x in d['roofline']['kernels'] if 'mlp' in x['kernel']][0]
+print('$1 mlp %.3f ms  step %.2f ms (median %.2f)  pairs/s %.0f cached %.0f check %s' % (k['launch_ms'], d['ms_per_step'], d['median_ms_per_step'], d['value'], d.get('graph_cached',{}).get('value',0), d.get('check',{}).get('ok')))" | tee -a gpurun_out/mlp/bpw.txt; }
+DVM_MLP_PERSIST=0 run old
+for b in 1 2 4 8 16 0; do DVM_MLP_BPW=$b run bpw$b; done
+DVM_MLP_PERSIST=0 run old
+DVM_MLP_BPW=4 run bpw4
