@@ -36,8 +36,13 @@ namespace {
 // guarantees: a column that belongs to a row's 12 smallest is never lost (an entry at or below the row's final bound is one
 // of the two smallest of its sub-tile, or its sub-tile is re-done), the softmax sum covers every column outside the final
 // list that lies within the cut (the cut never exceeds the bound).
-constexpr int H2_NREC = 64;                                          // third-key records per lane
-constexpr int H2_LDS_BYTES = 2 * HB_KT * HB_ROWB + 2 * HB_KT * 32 + 1024 + HB_THREADS * H2_NREC * 2;   // key tiles + norm fragments + DMA dump + records
+// WAVES = 8: one workgroup of 256 query rows per compute unit (133 KB of LDS).  WAVES = 4: 128 query rows, 16 records per lane
+// (one per FOUR sub-tiles at M = 2048), 77 KB — TWO workgroups per compute unit, so that the two waves of a SIMD belong to
+// different workgroups with their own barriers: one's LDS-DMA issue and barrier wait fall into the other's matrix chain instead
+// of both waves of a SIMD doing the same thing at the same time (DESIGN §8.1 b).  Price: every key tile serves half the rows —
+// twice the LDS-DMA pieces per wave — and a flagged record re-does four sub-tiles.
+template <int WAVES> constexpr int h2_nrec() { return WAVES == 8 ? 64 : 16; }                             // third-key records per lane
+template <int WAVES> constexpr int h2_lds_bytes() { return 2 * HB_KT * HB_ROWB + 2 * HB_KT * 32 + 1024 + 64 * WAVES * h2_nrec<WAVES>() * 2; }   // key tiles + norm fragments + DMA dump + records
 constexpr unsigned H2_REMOVED = 0xffc00000u;   // keys >= this: removed / invalid (as a list entry: hi word 0x7fe00000, a finite double)
 constexpr unsigned H2_KBASE = 129u << 23;      // bits(4.0f): bottom of the key window
 constexpr float H2_FLOOR = 4.5f;               // added to every accumulator through the norm instruction
@@ -126,8 +131,9 @@ __device__ __forceinline__ int entry_jb(double e) { return __double2loint(e) & 0
 // args.stamps; no output value depends on them.  Phases: 0 LDS-DMA issue, 1 matrix chain (fragment reads, waits, 25 matrix
 // instructions, until the accumulator is readable), 2 epilogue (selection + insertions), 3 softmax terms + re-done
 // sub-tiles, 4 bound update, 5 barrier (incl. the wait for the wave's own DMA pieces), 6 whole sweep, 7 sub-tiles.
-template <int PIPE, bool STAMP = false>
-__global__ __launch_bounds__(HB_THREADS) void softcorr_sweep2_kernel(const H2Args args) {
+template <int PIPE, bool STAMP = false, int WAVES = 8>
+__global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void softcorr_sweep2_kernel(const H2Args args) {
+    constexpr int H2_NREC = h2_nrec<WAVES>(), HB_QB = 32 * WAVES, HB_GLDS_PER_WAVE = HB_KT * HB_ROWB / 1024 / WAVES, HB_WAVES = WAVES;   // (shadow the 8-wave constants)
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
     unsigned long long T[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0, tstart = 0;
     if (STAMP) tstart = tlast = __builtin_amdgcn_s_memtime();
@@ -573,15 +579,39 @@ void launch_norm_frags(const float *nrm, int B, int M, int Mpad, const int *amax
     hipLaunchKernelGGL(norm_frags_kernel, dim3((Mpad + 255) / 256, B), dim3(256), 0, s, nrm, M, Mpad, amax, out);
 }
 
-// pass A for the groups in `a` (lean semantics), second form; knf = key-side norm fragments of either group
+template <int PIPE, bool STAMP, int WAVES>
+static void launch_form(const H2Args &b, int blocks, hipStream_t s) {
+    ensure_dyn_lds((const void *)softcorr_sweep2_kernel<PIPE, STAMP, WAVES>, h2_lds_bytes<WAVES>());
+    hipLaunchKernelGGL((softcorr_sweep2_kernel<PIPE, STAMP, WAVES>), dim3(blocks), dim3(64 * WAVES), h2_lds_bytes<WAVES>(), s, b);
+}
+
+// workgroup size of the second form: 8 waves (256 query rows, one workgroup per compute unit) or 4 (128 rows, two per compute unit)
+int sweep2_waves() {
+    static const int w = [] {
+        const char *e = getenv("DVM_K1_WAVES");
+        return e && atoi(e) == 4 ? 4 : 8;
+    }();
+    return w;
+}
+
+// pass A for the groups in `a` (lean semantics), second form; knf = key-side norm fragments of either group.  `a` and `blocks` are
+// laid out for 256-row workgroups (HB_QB); the 4-wave form re-derives its own tiling from them.
 void launch_sweep2(const HBArgs &a, const char *knf0, const char *knf1, const int *amaxc, int blocks, int form, hipStream_t s) {
     H2Args b;
+    const int waves = sweep2_waves();
     for (int g = 0; g < 2; ++g) {
         const HBGroup &G = a.g[g];
         b.g[g] = H2Group{G.qp, G.kp, g == 0 ? knf0 : knf1, G.nq, G.N, G.M, G.Mpad, G.tiles, G.cidx, G.cd2, G.lsum, G.kslices, G.Ms};
     }
-    b.amax = amaxc;
     b.blocks0 = a.blocks0;
+    if (waves == 4) {
+        const int e0 = a.blocks0 / a.g[0].tiles, e1 = blocks > a.blocks0 ? (blocks - a.blocks0) / a.g[1].tiles : 0;   // launch entries per group
+        b.g[0].tiles = (a.g[0].N + 127) / 128;
+        b.g[1].tiles = (a.g[1].N + 127) / 128;
+        b.blocks0 = e0 * b.g[0].tiles;
+        blocks = b.blocks0 + e1 * b.g[1].tiles;
+    }
+    b.amax = amaxc;
     b.neg_alpha = a.neg_alpha;
     b.cutw = a.cutw;
     b.route = a.route;
@@ -590,52 +620,38 @@ void launch_sweep2(const HBArgs &a, const char *knf0, const char *knf1, const in
     static const bool stamps_on = getenv("DVM_K1_STAMPS") != nullptr;
     if (stamps_on) {   // diagnostic: synchronous, allocates — never taken in production
         unsigned long long *dbuf = nullptr;
-        const size_t n = (size_t)blocks * HB_WAVES * 8;
+        const size_t n = (size_t)blocks * waves * 8;
         if (hipMalloc(&dbuf, n * sizeof(unsigned long long)) != hipSuccess) return;
         b.stamps = dbuf;
-        if (form == 1) {
-            ensure_dyn_lds((const void *)softcorr_sweep2_kernel<0, true>, H2_LDS_BYTES);
-            hipLaunchKernelGGL((softcorr_sweep2_kernel<0, true>), dim3(blocks), dim3(HB_THREADS), H2_LDS_BYTES, s, b);
-        } else if (form == 4) {
-            ensure_dyn_lds((const void *)softcorr_sweep2_kernel<3, true>, H2_LDS_BYTES);
-            hipLaunchKernelGGL((softcorr_sweep2_kernel<3, true>), dim3(blocks), dim3(HB_THREADS), H2_LDS_BYTES, s, b);
-        } else {
-            ensure_dyn_lds((const void *)softcorr_sweep2_kernel<1, true>, H2_LDS_BYTES);
-            hipLaunchKernelGGL((softcorr_sweep2_kernel<1, true>), dim3(blocks), dim3(HB_THREADS), H2_LDS_BYTES, s, b);
-        }
+        if (waves == 4) launch_form<1, true, 4>(b, blocks, s);
+        else if (form == 1) launch_form<0, true, 8>(b, blocks, s);
+        else if (form == 4) launch_form<3, true, 8>(b, blocks, s);
+        else launch_form<1, true, 8>(b, blocks, s);
         (void)hipStreamSynchronize(s);
         unsigned long long *hbuf = (unsigned long long *)malloc(n * sizeof(unsigned long long));
         (void)hipMemcpy(hbuf, dbuf, n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         double tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (size_t w = 0; w < (size_t)blocks * HB_WAVES; ++w)
+        for (size_t w = 0; w < (size_t)blocks * waves; ++w)
             for (int i = 0; i < 8; ++i) tot[i] += (double)hbuf[w * 8 + i];
         double redo = 0;
-        for (size_t w = 0; w < (size_t)blocks * HB_WAVES; ++w) {
+        for (size_t w = 0; w < (size_t)blocks * waves; ++w) {
             redo += (double)(hbuf[w * 8 + 7] >> 20);
             tot[7] -= (double)(hbuf[w * 8 + 7] >> 20 << 20);
         }
-        const double nw = (double)blocks * HB_WAVES, st = tot[7] / nw;
+        const double nw = (double)blocks * waves, st = tot[7] / nw;
         fprintf(stderr, "K1 stamps: %.2f re-done records per wave\n", redo / nw);
-        fprintf(stderr, "K1 stamps (form %d, %d blocks): per wave and sub-tile, cycles: dma %.0f  chain %.0f  epilogue %.0f  terms+redo %.0f  "
-                        "bound %.0f  barrier %.0f  | whole sweep %.0f per sub-tile (%.0f sub-tiles per wave)\n", form, blocks, tot[0] / nw / st,
+        fprintf(stderr, "K1 stamps (form %d, %d waves, %d blocks): per wave and sub-tile, cycles: dma %.0f  chain %.0f  epilogue %.0f  terms+redo %.0f  "
+                        "bound %.0f  barrier %.0f  | whole sweep %.0f per sub-tile (%.0f sub-tiles per wave)\n", form, waves, blocks, tot[0] / nw / st,
                 tot[1] / nw / st, tot[2] / nw / st, tot[3] / nw / st, tot[4] / nw / st, tot[5] / nw / st, tot[6] / nw / st, st);
         free(hbuf);
         (void)hipFree(dbuf);
         return;
     }
-    if (form == 1) {
-        ensure_dyn_lds((const void *)softcorr_sweep2_kernel<0>, H2_LDS_BYTES);
-        hipLaunchKernelGGL((softcorr_sweep2_kernel<0>), dim3(blocks), dim3(HB_THREADS), H2_LDS_BYTES, s, b);
-    } else if (form == 3) {
-        ensure_dyn_lds((const void *)softcorr_sweep2_kernel<2>, H2_LDS_BYTES);
-        hipLaunchKernelGGL((softcorr_sweep2_kernel<2>), dim3(blocks), dim3(HB_THREADS), H2_LDS_BYTES, s, b);
-    } else if (form == 4) {
-        ensure_dyn_lds((const void *)softcorr_sweep2_kernel<3>, H2_LDS_BYTES);
-        hipLaunchKernelGGL((softcorr_sweep2_kernel<3>), dim3(blocks), dim3(HB_THREADS), H2_LDS_BYTES, s, b);
-    } else {
-        ensure_dyn_lds((const void *)softcorr_sweep2_kernel<1>, H2_LDS_BYTES);
-        hipLaunchKernelGGL((softcorr_sweep2_kernel<1>), dim3(blocks), dim3(HB_THREADS), H2_LDS_BYTES, s, b);
-    }
+    if (waves == 4) launch_form<1, false, 4>(b, blocks, s);
+    else if (form == 1) launch_form<0, false, 8>(b, blocks, s);
+    else if (form == 3) launch_form<2, false, 8>(b, blocks, s);
+    else if (form == 4) launch_form<3, false, 8>(b, blocks, s);
+    else launch_form<1, false, 8>(b, blocks, s);
 }
 
 }  // namespace k1
