@@ -581,8 +581,12 @@ void launch_norm_frags(const float *nrm, int B, int M, int Mpad, const int *amax
 
 template <int PIPE, bool STAMP, int WAVES>
 static void launch_form(const H2Args &b, int blocks, hipStream_t s) {
-    ensure_dyn_lds((const void *)softcorr_sweep2_kernel<PIPE, STAMP, WAVES>, h2_lds_bytes<WAVES>());
-    hipLaunchKernelGGL((softcorr_sweep2_kernel<PIPE, STAMP, WAVES>), dim3(blocks), dim3(64 * WAVES), h2_lds_bytes<WAVES>(), s, b);
+    // DVM_K1_LDS_PAD (diagnostic): extra dynamic LDS per workgroup — 8192 keeps a second 4-wave workgroup off the compute unit, so
+    // that every wave has its SIMD to itself (what a wave costs when nothing runs beside it)
+    static const int pad = [] { const char *e = getenv("DVM_K1_LDS_PAD"); return e ? atoi(e) : 0; }();
+    const int lds = h2_lds_bytes<WAVES>() + pad;
+    ensure_dyn_lds((const void *)softcorr_sweep2_kernel<PIPE, STAMP, WAVES>, lds);
+    hipLaunchKernelGGL((softcorr_sweep2_kernel<PIPE, STAMP, WAVES>), dim3(blocks), dim3(64 * WAVES), lds, s, b);
 }
 
 // workgroup size of the second form: 8 waves (256 query rows, one workgroup per compute unit) or 4 (128 rows, two per compute unit)
