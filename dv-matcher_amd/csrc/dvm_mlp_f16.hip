@@ -662,6 +662,7 @@ int *launch_mlp_planes_f16(const void *zp, int rows, const float *W0, const floa
         (void)hipFree(dbuf);
         return flag;
     }
+    prof_note(DVM_PROF_MLP, "mlp_f16x2p_kernel");
     prof_begin(s, DVM_PROF_MLP);
     ensure_dyn_lds((const void *)mlp_f16x2p_kernel<4>, (int)MP_LDS_BYTES);
     hipLaunchKernelGGL((mlp_f16x2p_kernel<4>), grid, block, MP_LDS_BYTES, s, (const char *)zp, rows, nblocks, bpw, Wp0, b0, Wp1, b1, Wp2, b2, W3x, b3, out, flag,
@@ -724,6 +725,7 @@ int *launch_mlp_rows_f16(const float *z, int rows, const float *W0, const float 
         (void)hipFree(dbuf);
         return flag;
     }
+    prof_note(DVM_PROF_MLP, "mlp_f16x2_kernel");
     prof_begin(s, DVM_PROF_MLP);
     // (ablation, WRONG results: 1 = the weight fragments are not re-loaded in the k-loops, 2 = the activation fragments are read
     // from one LDS address, 3 = both: what is left is the matrix instructions, the activation stores and the barriers)
