@@ -472,6 +472,40 @@ class Uni3FC(nn.Module, _VisualProjection):
         where = [i for i, t in enumerate(ts) if isinstance(t, nn.Parameter)]
         return ts, where, [ts[i] for i in where], bns
 
+    def _train_state(self):
+        """_train_table() once per parameter set, not three times per step: (tensors, positions of the trainable ones, the
+        trainable ones, BatchNorm modules, detached aliases for the pointer table, parameters fit the native path).  The 167
+        attribute walks, `detach()`s and layout checks cost the host ~1 ms per step.  The entry is dropped whenever the module
+        is converted (`_apply`: .to / .cuda / .float), its mode changes or a state_dict is loaded, and it is re-validated on every
+        use against the first and last parameter objects and the first one's address; code that REPLACES a parameter object in
+        between (`net.conv6[0].weight = nn.Parameter(...)`) must call `invalidate_train_state()`."""
+        first, last = self.conv[0].weight, self.n2p_attention7.bn2.bias
+        c = self.__dict__.get("_tt_cache")
+        if c is not None and c[0] is first and c[1] is last and c[2] == first.data_ptr():
+            return c[3]
+        ts, where, trainable, bns = self._train_table()
+        ok = (not any(t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda for t in ts)
+              and len({(m.eps, m.momentum) for m in bns}) == 1 and bns[0].momentum is not None
+              and all(m.track_running_stats for m in bns))
+        state = (ts, where, trainable, bns, [t.detach() for t in ts], ok)
+        self.__dict__["_tt_cache"] = (first, last, first.data_ptr(), state)
+        return state
+
+    def invalidate_train_state(self):
+        self.__dict__.pop("_tt_cache", None)
+
+    def _apply(self, fn, *a, **kw):
+        self.invalidate_train_state()
+        return super()._apply(fn, *a, **kw)
+
+    def train(self, mode=True):
+        self.invalidate_train_state()
+        return super().train(mode)
+
+    def load_state_dict(self, *a, **kw):
+        self.invalidate_train_state()
+        return super().load_state_dict(*a, **kw)
+
     def _native_train_ok(self, x, dino_feat):
         """The native training path takes plain data tensors (no gradient w.r.t. x / dino_feat), fp32 contiguous parameters and
         one (eps, momentum) for all BatchNorms; anything else goes through the autograd path below."""
@@ -479,18 +513,15 @@ class Uni3FC(nn.Module, _VisualProjection):
             return False
         if x.requires_grad or dino_feat.requires_grad or x.dtype != torch.float32 or dino_feat.dtype != torch.float32:
             return False
-        ts, _, _, bns = self._train_table()
-        if any(t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda for t in ts):
-            return False
-        return len({(m.eps, m.momentum) for m in bns}) == 1 and bns[0].momentum is not None and all(m.track_running_stats for m in bns)
+        return self._train_state()[5]
 
     def _forward_train_native(self, x, dino_feat):
         """Training forward + backward as ONE autograd node over dvm_uni3fc_train_{fwd,bwd}_f32 (csrc/dvm_uni3fc_train.hip): the
         launches of _forward_train_pm and of its autograd graph without the ~1500 Python / autograd hops per call."""
-        ts, where, trainable, bns = self._train_table()
+        ts, where, trainable, bns, det, _ = self._train_state()
         with torch.no_grad():
             torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
-        meta = ([t.detach() for t in ts], where, self.k, bns[0].eps, bns[0].momentum)
+        meta = (det, where, self.k, bns[0].eps, bns[0].momentum)
         return nn_ops.uni3fc_train(meta, x.contiguous(), dino_feat.contiguous(), trainable)
 
     def forward_pair(self, x1, dino1, x2, dino2, upsampler=None):
@@ -514,10 +545,10 @@ class Uni3FC(nn.Module, _VisualProjection):
                                             and not torch.cuda.is_current_stream_capturing())))
         if not native:
             return self.forward(x1, dino1, upsampler), self.forward(x2, dino2, upsampler)
-        ts, where, trainable, bns = self._train_table()
+        ts, where, trainable, bns, det, _ = self._train_state()
         with torch.no_grad():
             torch._foreach_add_([m.num_batches_tracked for m in bns], 2)
-        meta = ([t.detach() for t in ts], where, self.k, bns[0].eps, bns[0].momentum)
+        meta = (det, where, self.k, bns[0].eps, bns[0].momentum)
         if mode == "merged":
             return nn_ops.uni3fc_train_merged(meta, x1, dino1, x2, dino2, trainable)
         return nn_ops.uni3fc_train_pair(meta, x1.contiguous(), dino1.contiguous(), x2.contiguous(), dino2.contiguous(), trainable)

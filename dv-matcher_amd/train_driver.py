@@ -474,7 +474,7 @@ def main(argv=None):
                                            "frac": step_flops(Bg, N, M) / (dt / args.steps) / 1e12 / world / 157.3,
                                            "flops_per_step": step_flops(Bg, N, M),
                                            "note": "algorithmic matrix flops of the whole step per GPU over the step time; the step is "
-                                                   "~1800 small launches, host- and latency-bound, not matrix-bound"},
+                                                   "~900 small launches, bound by the latency of its kernel chain (network forward -> criterion -> backward), not by the matrix pipe"},
                               "points": N, "points_target": M, "criterion": type(crit).__name__, "alpha": float(alpha),
                               "hip_graph": use_graph, "graph_cache": bool(args.graph_cache), "process_group": (dist.get_backend() if dist_on else None),
                               "grad_bucket_floats": bucket.numel, "first_losses": losses[0], "last_losses": losses[-1]}))

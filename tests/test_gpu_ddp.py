@@ -147,7 +147,8 @@ def test_bench_single_gpu_line_and_check():
     assert res["n_gpus"] == 1 and res["checked_pairs"] == 4 and res["check"]["ok"]
     assert res["cpu_baseline"]["kind"] == "port" and res["cpu_baseline"]["value"] > 0 and "timed batch" in res["cpu_baseline"]["sample"]
     names = [k["kernel"] for k in res["roofline"]["kernels"]]
-    assert "softcorr_refine_kernel" in names and "mlp_f16x2_kernel" in names and "grid_chamfer_kernel" in names
+    assert "softcorr_refine_kernel" in names and "grid_chamfer_kernel" in names
+    assert "mlp_f16x2p_kernel" in names or "mlp_f16x2_kernel" in names      # (the MLP slot reports the kernel the launch ran: DVM_MLP_PERSIST)
     assert all(k["launch_ms"] > 0 and 0 < k["frac"] < 1.5 for k in res["roofline"]["kernels"])
     assert 0 < res["roofline"]["whole_path"]["frac"] < 1
 
