@@ -201,8 +201,12 @@ class GraphDeformLoss_Neural(nn.Module):
         g1p = nn_ops.pool_rows(feat1, idx11, deformer.conv_layer.weight, deformer.conv_layer.bias)
         g2p = nn_ops.pool_rows(feat2, idx22, deformer.conv_layer.weight, deformer.conv_layer.bias)
         g2t = nn_ops.sparse_apply(pval, pidx, g2p)
-        fps = g1["nodes_idx"].long().unsqueeze(-1)
-        pick = lambda t: torch.gather(t, 1, fps.expand(-1, -1, t.shape[-1]))  # noqa: E731
+        # the rows at the graph nodes: index_select on the flattened batch (whole rows, ~10 us per call and for its index_add_
+        # backward) instead of torch.gather with an expanded index (element-wise: 50 - 90 us per call at 16 x 1024 x 128, and as
+        # much again for the scatter_add of its backward); the nodes of a shape are distinct, so the backward adds nothing twice
+        nodes = g1["nodes_idx"].long()
+        flat = (nodes + torch.arange(B, device=nodes.device).unsqueeze(1) * N).reshape(-1)
+        pick = lambda t: t.reshape(B * N, t.shape[-1]).index_select(0, flat).view(B, nodes.shape[1], t.shape[-1])  # noqa: E731
         z = torch.cat([pick(verts1), pick(g1p), pick(verts12), pick(g2t)], dim=-1)
         def9 = deformer.deformation_decoder_layer(z)
         R = nn_ops.rot6d(def9[..., 3:] + self._identity6(def9.device))
