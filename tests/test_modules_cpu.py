@@ -178,3 +178,29 @@ def test_grad_accumulation_switch_roundtrip():
         assert nn_ops._grad_buffer(p) is None
     finally:
         nn_ops.fuse_grad_accumulation(prev)
+
+
+def test_train_pointer_table_cache_follows_the_parameters():
+    """Uni3FC._train_state() caches the 167-entry parameter table of the native training node: same entry while the parameters
+    stay where they are (an in-place optimizer step, a state_dict load), a new one after a conversion (`_apply`), a mode change,
+    or invalidate_train_state(); on CPU parameters the table says the native path does not apply."""
+    from models.model import Uni3FC
+    net = Uni3FC(k=8)
+    st = net._train_state()
+    assert len(st[0]) == 167 and len(st[4]) == 167 and st[5] is False      # CPU parameters: not for the native path
+    assert net._train_state() is st
+    with torch.no_grad():
+        net.conv[0].weight.add_(1.0)                                        # in-place update: same storage, same entry
+    assert net._train_state() is st and st[4][0].data_ptr() == net.conv[0].weight.data_ptr()
+    assert torch.equal(st[4][0], net.conv[0].weight.detach())
+    net.load_state_dict(net.state_dict())
+    st2 = net._train_state()
+    assert st2 is not st and st2[4][0].data_ptr() == net.conv[0].weight.data_ptr()
+    net.double()
+    st3 = net._train_state()
+    assert st3 is not st2 and st3[4][0].dtype == torch.float64
+    net.eval()
+    assert net._train_state() is not st3
+    st4 = net._train_state()
+    net.invalidate_train_state()
+    assert net._train_state() is not st4
