@@ -573,6 +573,408 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void softcorr_sweep
     }
 }
 
+// ---------------------------------------------------------------- pass A, third form: split roles (round 4, DVM_K1_SWEEP=5)
+// Same tiles, keys, lists, records and guarantees as the second form; what changes is WHO does what.  Measured on the second form
+// (profiles/r4_k1_waves.txt): a wave alone on its SIMD needs 2 301 cycles per 32 x 32 sub-tile, two symmetric waves 3 140 each —
+// every phase of a wave stretches when its partner issues anything, and the LDS-DMA instructions (~200 cycles of the issuing
+// wave each) and the list bookkeeping stand in the same instruction stream as the matrix chain.  Here a SIMD holds
+//  * two PRODUCER waves (waves 0-7, 32 query rows each as before): fragments -> matrix chain -> keys -> sorted three smallest of
+//    16 -> 3 keys per lane and sub-tile into an LDS hand-off buffer, and nothing else;
+//  * one CONSUMER wave (waves 8-11, two row blocks each): ALL LDS-DMA pieces of the workgroup, the lists, third-key records,
+//    softmax terms and bounds, working one TILE behind the producers (hand-off buffers alternate with the key tiles; the one
+//    barrier per tile covers both), and, after the last tile, the re-done sub-tiles and the outputs.
+// 12 waves x <= 168 registers (a producer carries no lists, a consumer no query fragments until the end).  (64 rows per producer with
+// two chains per key fragment was tried first: 128 registers of query fragments + two accumulators + fragments in flight spill
+// into the matrix loop.)
+// STAMP (DVM_K1_STAMPS): per wave, cycles waiting at the barriers (slot 5), in the matrix chains / in the hand-off processing (1),
+// in the selection / the DMA issue (2), whole kernel (6), tiles (7): tells which role the workgroup waits for.
+constexpr int H3_THREADS = 768;
+constexpr int H3_HAND_WORDS = 2 * 2 * 8 * 3 * 64;                          // [buf][sub][row block][key][lane]
+constexpr int H3_LDS_BYTES = 2 * HB_KT * HB_ROWB + 2 * HB_KT * 32 + 1024 + H3_HAND_WORDS * 4 + 4 * 2 * 64 * 64 * 2;   // 160 768 B
+static_assert(H3_LDS_BYTES <= 160 * 1024, "third sweep form: LDS");
+
+struct H3Row {                       // a consumer lane's state for one of its two row blocks
+    PackedBest<HB_KC> kb;
+    float cref, l, rowc;
+    unsigned lim, cut_k, urec;
+};
+
+template <bool STAMP = false>
+__global__ __launch_bounds__(H3_THREADS) void softcorr_sweep3_kernel(const H2Args args) {
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+    unsigned long long T[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0, tstart = 0;
+    if (STAMP) tstart = tlast = __builtin_amdgcn_s_memtime();
+    auto stamp = [&](int slot) __attribute__((always_inline)) {
+        if (STAMP) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            T[slot] += now - tlast;
+            tlast = now;
+        }
+    };
+    char *const ktile0 = smem_b;                                         // [2][HB_KT][512], 16-B chunks XOR-swizzled
+    char *const knf0 = smem_b + (size_t)2 * HB_KT * HB_ROWB;             // [2][HB_KT][32]
+    char *const dump0 = knf0 + 2 * HB_KT * 32;                            // 1 KiB nobody reads
+    unsigned *const hand0 = (unsigned *)(dump0 + 1024);                   // hand-off: [buf][sub][row block][key][lane]
+    unsigned short *const rec0 = (unsigned short *)(hand0 + H3_HAND_WORDS);   // [consumer][rb][64 records][64 lanes]
+
+    int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int grp = lid >= args.blocks0 ? 1 : 0;
+    lid -= grp ? args.blocks0 : 0;
+    const H2Group &G = args.g[grp];
+    const int N = G.N;
+    const int bs = lid / G.tiles, qt = lid % G.tiles;
+    const int b = bs / G.kslices, sl = bs - b * G.kslices;
+    const int M = G.kslices > 1 ? min(G.Ms, G.M - sl * G.Ms) : G.M;
+    if (args.route && args.route[grp * args.nb + b] != K1_ROUTE_SECOND) return;
+    const float neg_alpha = args.neg_alpha;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r32 = lane & 31, h = lane >> 5;
+    const bool producer = wave < 8;
+    const int pw = wave & 7;      // producer: its row block; consumer (waves 8-11 -> 0-3): row blocks 2 pw and 2 pw + 1
+    const char *kbase = G.kp + ((size_t)b * G.M + (size_t)sl * G.Ms) * HB_ROWB;
+    const char *nfbase = G.knf + ((size_t)b * G.Mpad + (size_t)sl * G.Ms) * 32;
+    const int se = scale_exp(*args.amax);
+    const float cf = pow2i(1 - 2 * se), icf = pow2i(2 * se - 1);
+    const float cutw = args.cutw;
+    const int ntiles = (M + HB_KT - 1) / HB_KT, nsub = 2 * ntiles;
+    const int rgrp = (nsub + 63) / 64;
+    const bool ragged = (M & (HB_KT - 1)) != 0;
+    auto dma_barrier = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    // the hand-off slot of (buffer, sub-tile, row block, key) for this lane
+    auto hand = [&](int buf, int sub, int blk, int key) __attribute__((always_inline)) {
+        return hand0 + (((buf * 2 + sub) * 8 + blk) * 3 + key) * 64 + lane;
+    };
+    auto finish_stamps = [&]() __attribute__((always_inline)) {
+        if (STAMP) {
+            T[6] = __builtin_amdgcn_s_memtime() - tstart;
+            if (lane == 0 && args.stamps)
+                for (int i = 0; i < 8; ++i) args.stamps[((size_t)blockIdx.x * 12 + wave) * 8 + i] = T[i];
+        }
+    };
+
+    if (producer) {
+        // ---------------------------------------------------------------- producer
+        const int qrow = qt * HB_QB + pw * 32 + r32;
+        const int qrc = qrow < N ? qrow : N - 1;
+        const char *qptr = G.qp + ((size_t)b * N + qrc) * HB_ROWB + 16 * h;
+        f16x8 qh[8], qm[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            qh[s] = -*(const f16x8 *)(qptr + 32 * s);
+            qm[s] = -*(const f16x8 *)(qptr + 256 + 32 * s);
+        }
+        f16x8 qn = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (h == 0) {
+            const float nas = norm_scaled(G.nq[(size_t)b * N + qrc], se);
+            const float nasb = (nas + nas * 0x1p-13f) + H2_FLOOR;
+            _Float16 p1, p2, p3;
+            norm_pieces(nasb, p1, p2, p3);
+            qn[0] = (_Float16)0x1p+15f, qn[1] = (_Float16)0x1p+4f, qn[2] = (_Float16)0x1p-7f;
+            qn[3] = p1, qn[4] = p2, qn[5] = p3;
+        }
+        unsigned fadr[8];
+        {
+            const unsigned rowb = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)ktile0 + r32 * HB_ROWB;
+            const int tq = h ^ (r32 & 15);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                fadr[s] = rowb + (((2 * s) ^ tq) << 4);
+                asm volatile("" : "+v"(fadr[s]));
+            }
+        }
+        unsigned nadr = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)knf0 + r32 * 32 + 16 * h;
+        asm volatile("" : "+v"(nadr));
+        auto lds16 = [](unsigned adr, int off) __attribute__((always_inline)) {
+            return *(const f16x8 *)(const __attribute__((address_space(3))) char *)(size_t)(adr + off);
+        };
+        auto chain = [&](int buf, int sub) __attribute__((always_inline)) -> f32x16 {   // as the second form's
+            const int toff = buf * (HB_KT * HB_ROWB) + sub * (32 * HB_ROWB);
+            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            f16x8 ah[4][2], am[4][2];
+            auto reads = [&](int q) __attribute__((always_inline)) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    ah[q][u] = lds16(fadr[2 * q + u], toff);
+                    am[q][u] = lds16(fadr[2 * q + u], toff + 256);
+                }
+            };
+            auto products = [&](int q) __attribute__((always_inline)) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int s = 2 * q + u;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(am[q][u], qh[s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q][u], qm[s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q][u], qh[s], acc, 0, 0, 0);
+                }
+            };
+            reads(0);
+            reads(1);
+            const f16x8 an = lds16(nadr, buf * (HB_KT * 32) + sub * (32 * 32));
+            __builtin_amdgcn_sched_barrier(0x00E);
+            products(0);
+            reads(2);
+            __builtin_amdgcn_sched_barrier(0x00E);
+            products(1);
+            reads(3);
+            __builtin_amdgcn_sched_barrier(0x00E);
+            products(2);
+            products(3);
+            return __builtin_amdgcn_mfma_f32_32x32x16_f16(an, qn, acc, 0, 0, 0);
+        };
+        // keys of an accumulator, their sorted three smallest into the hand-off buffer
+        auto emit = [&](const f32x16 &acc, int t, int buf, int sub, bool pads) __attribute__((always_inline)) {
+            const int s = 2 * t + sub, jb = s * 32 + 4 * h;
+            unsigned v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                v[r] = (__float_as_uint(acc[r]) << 4) + ((unsigned)r - (H2_KBASE << 4));
+                if (pads) v[r] = jb + (r & 3) + 8 * (r >> 2) < M ? v[r] : (H2_REMOVED | r);
+            }
+            const Top3 w = top3_of_16(v);
+            *hand(buf, sub, pw, 0) = w.s0;
+            *hand(buf, sub, pw, 1) = w.s1;
+            *hand(buf, sub, pw, 2) = w.s2;
+        };
+        // (no software pipeline inside the wave: the selection is ~65 vector instructions, and the SIMD's other producer keeps the
+        // matrix pipe busy meanwhile; a second accumulator in flight does not fit 168 registers)
+        dma_barrier();                      // tile 0 has landed (staged by the consumers)
+        stamp(5);
+        auto tile = [&](int t, int buf) __attribute__((always_inline)) {   // buf: literal after inlining
+            const bool pads = ragged && t + 1 == ntiles;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const f32x16 a = chain(buf, sub);
+                if (STAMP) {
+                    const int x = __builtin_amdgcn_readfirstlane(__float_as_int(a[0]));
+                    asm volatile("" ::"s"(x));
+                    stamp(1);
+                }
+                if (pads) emit(a, t, buf, sub, true); else emit(a, t, buf, sub, false);
+                stamp(2);
+            }
+            dma_barrier();
+            stamp(5);
+            T[7] += 1;
+        };
+        for (int t = 0; t < ntiles; t += 2) {
+            tile(t, 0);
+            if (t + 1 < ntiles) tile(t + 1, 1);
+        }
+        finish_stamps();
+        return;
+    }
+
+    // ---------------------------------------------------------------- consumer
+    H3Row R[2];
+    int qrowv[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const int qrow = qt * HB_QB + (2 * pw + rb) * 32 + r32;
+        const int qrc = qrow < N ? qrow : N - 1;
+        qrowv[rb] = qrow;
+        const float nas = norm_scaled(G.nq[(size_t)b * N + qrc], se);
+        const float nasb = (nas + nas * 0x1p-13f) + H2_FLOOR;
+        R[rb].rowc = nasb - nas;
+#pragma unroll
+        for (int t = 0; t < HB_KC; ++t) R[rb].kb.e[t] = __hiloint2double((int)(H2_REMOVED >> 1), 0x7fffffff);
+        R[rb].cref = -INFINITY, R[rb].l = 0.f, R[rb].lim = 0xffffffffu, R[rb].cut_k = 0xffffffffu, R[rb].urec = 0xffffffffu;
+    }
+    auto key_d2 = [&](const H3Row &S, unsigned key) __attribute__((always_inline)) {
+        return fmaxf(__uint_as_float((key >> 4) + H2_KBASE) - S.rowc, 0.f) * cf;
+    };
+    auto add_term = [&](H3Row &S, unsigned key) __attribute__((always_inline)) {
+        const bool live = key < H2_REMOVED;
+        const float s = __builtin_amdgcn_sqrtf(key_d2(S, key)) * neg_alpha;
+        const float cnew = live ? fmaxf(S.cref, s) : S.cref;
+        const float sc = (cnew == S.cref) ? 1.f : __builtin_amdgcn_exp2f((S.cref - cnew) * LOG2E);
+        const float term = live ? __builtin_amdgcn_exp2f((s - cnew) * LOG2E) : 0.f;
+        S.l = S.l * sc + term;
+        S.cref = cnew;
+    };
+    auto terms2 = [&](H3Row &S, double o0, double o1) __attribute__((always_inline)) {
+        const unsigned k0 = entry_key(o0), k1 = entry_key(o1);
+        if (__builtin_amdgcn_ballot_w64(min(k0, k1) <= S.cut_k) != 0) {
+            add_term(S, k0 <= S.cut_k ? k0 : H2_REMOVED);
+            add_term(S, k1 <= S.cut_k ? k1 : H2_REMOVED);
+        }
+    };
+    auto update_bound = [&](H3Row &S) __attribute__((always_inline)) {
+        const unsigned wk = entry_key(S.kb.e[HB_KC - 1]), wm = entry_key(S.kb.e[HB_KC / 2 - 1]), w0 = entry_key(S.kb.e[0]);
+        const auto sk = __builtin_amdgcn_permlane32_swap(wk, wk, false, false);
+        const auto sm = __builtin_amdgcn_permlane32_swap(wm, wm, false, false);
+        const auto s0 = __builtin_amdgcn_permlane32_swap(w0, w0, false, false);
+        const unsigned pk = h ? sk[0] : sk[1], pm = h ? sm[0] : sm[1], p0 = h ? s0[0] : s0[1];
+        const unsigned thr = min(min(wk, pk), max(wm, pm));
+        const unsigned kmin = min(w0, p0);
+        const float dmin = kmin < H2_REMOVED ? __builtin_amdgcn_sqrtf(key_d2(S, kmin)) : INFINITY;
+        const float cut = dmin + cutw;
+        const float ca = fmaf((cut * cut) * 1.000001f, icf, S.rowc);
+        S.cut_k = ca < 0x1p+33f ? ((__float_as_uint(fmaxf(ca, 4.f)) - H2_KBASE) << 4) + 15u : 0xffffffffu;
+        S.lim = max(thr, S.cut_k);
+    };
+    unsigned short *const recw = rec0 + (size_t)pw * 2 * 64 * 64 + lane;     // + (rb * 64 + record) * 64
+    // all LDS-DMA pieces of a tile: 8 key pieces per consumer + the two norm-fragment pieces (consumers 0 and 1; 2 and 3 into the dump)
+    auto stage_tile = [&](int t, int buf, bool clamp) __attribute__((always_inline)) {
+        const int j0 = t * HB_KT;
+        const char *tb = kbase + (size_t)j0 * HB_ROWB;
+        char *kt = ktile0 + (size_t)buf * HB_KT * HB_ROWB;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int piece = pw * 8 + e;
+            const int r = 2 * piece + h, rc = clamp ? min(r, M - 1 - j0) : r;
+            const unsigned off = rc * HB_ROWB + ((r32 ^ (r & 15)) << 4);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tb + off),
+                                             (__attribute__((address_space(3))) void *)(kt + piece * 1024), 16, 0, 0);
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(nfbase + (size_t)j0 * 32 + (pw & 1) * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void *)(pw < 2 ? knf0 + buf * HB_KT * 32 + pw * 1024 : dump0), 16, 0, 0);
+    };
+    auto stage = [&](int t, int buf) __attribute__((always_inline)) {
+        if (t < ntiles) {
+            if (ragged && t + 1 == ntiles) stage_tile(t, buf, true); else stage_tile(t, buf, false);
+        }
+    };
+    // the hand-off of tile tt: two smallest keys of every (sub-tile, row block) into the lists, the third into the record
+    auto process = [&](int tt, int buf) __attribute__((always_inline)) {   // buf: literal after inlining
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int s = 2 * tt + sub, jb = s * 32 + 4 * h;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const unsigned s0 = *hand(buf, sub, 2 * pw + rb, 0), s1 = *hand(buf, sub, 2 * pw + rb, 1), s2 = *hand(buf, sub, 2 * pw + rb, 2);
+                const double o0 = R[rb].kb.insert(pack_entry(s0, jb));
+                const double o1 = R[rb].kb.insert(pack_entry(s1, jb));
+                R[rb].urec = (s % rgrp == 0) ? s2 : min(R[rb].urec, s2);
+                recw[(rb * 64 + s / rgrp) * 64] = (unsigned short)(R[rb].urec >> 16);
+                terms2(R[rb], o0, o1);
+            }
+        }
+        if ((tt & 3) == 3 || tt < 8) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) update_bound(R[rb]);
+        }
+    };
+    stage(0, 0);
+    dma_barrier();
+    stamp(5);
+    {
+        auto iter = [&](int t, int buf) __attribute__((always_inline)) {   // producers compute tile t from buffer buf meanwhile
+            stage(t + 1, buf ^ 1);
+            stamp(2);
+            if (t >= 1) process(t - 1, buf ^ 1);
+            if (STAMP) {
+                const int x = __builtin_amdgcn_readfirstlane(__double2hiint(R[0].kb.e[0]) ^ __double2hiint(R[1].kb.e[0]));
+                asm volatile("" ::"s"(x));
+                stamp(1);
+            }
+            dma_barrier();
+            stamp(5);
+            T[7] += 1;
+        };
+        for (int t = 0; t < ntiles; t += 2) {
+            iter(t, 0);
+            if (t + 1 < ntiles) iter(t + 1, 1);
+        }
+        if ((ntiles - 1) & 1) process(ntiles - 1, 1); else process(ntiles - 1, 0);
+    }
+
+    // ---- per row block: final bound, re-done sub-tiles, merge of the two half-lanes, outputs (as in the second form)
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        H3Row &S = R[rb];
+        update_bound(S);
+        const int qrow = qrowv[rb], qrc = qrow < N ? qrow : N - 1;
+        const char *qptr = G.qp + ((size_t)b * N + qrc) * HB_ROWB + 16 * h;
+        f16x8 qh[8], qm[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            qh[s] = -*(const f16x8 *)(qptr + 32 * s);
+            qm[s] = -*(const f16x8 *)(qptr + 256 + 32 * s);
+        }
+        f16x8 qn = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (h == 0) {
+            const float nas = norm_scaled(G.nq[(size_t)b * N + qrc], se);
+            const float nasb = (nas + nas * 0x1p-13f) + H2_FLOOR;
+            _Float16 p1, p2, p3;
+            norm_pieces(nasb, p1, p2, p3);
+            qn[0] = (_Float16)0x1p+15f, qn[1] = (_Float16)0x1p+4f, qn[2] = (_Float16)0x1p-7f;
+            qn[3] = p1, qn[4] = p2, qn[5] = p3;
+        }
+        const unsigned limr = S.lim >> 16;
+        const int nrec = (nsub + rgrp - 1) / rgrp;
+        unsigned long long todo = 0;
+#pragma unroll
+        for (int g = 0; g < 64; ++g)
+            if (g < nrec && __builtin_amdgcn_ballot_w64((unsigned)recw[(rb * 64 + g) * 64] <= limr) != 0) todo |= 1ull << g;
+        while (todo != 0) {
+            const int g = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            for (int s = g * rgrp; s < (g + 1) * rgrp && s < nsub; ++s) {
+                const int j = s * 32 + r32, jc = j < M ? j : M - 1;
+                const char *arow = kbase + (size_t)jc * HB_ROWB + 16 * h;
+                const f16x8 an = *(const f16x8 *)(nfbase + (size_t)j * 32 + 16 * h);
+                f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const f16x8 ah = *(const f16x8 *)(arow + 32 * u), am = *(const f16x8 *)(arow + 256 + 32 * u);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, qh[u], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qm[u], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[u], acc, 0, 0, 0);
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(an, qn, acc, 0, 0, 0);
+                const int jb = s * 32 + 4 * h;
+                unsigned v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    v[r] = (__float_as_uint(acc[r]) << 4) + ((unsigned)r - (H2_KBASE << 4));
+                    v[r] = jb + (r & 3) + 8 * (r >> 2) < M ? v[r] : (H2_REMOVED | r);
+                }
+                Top3 w = top3_of_16(v);
+                bool more = w.s2 <= S.lim && w.s2 < H2_REMOVED;
+                while (__builtin_amdgcn_ballot_w64(more) != 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = v[r] <= w.s1 ? (H2_REMOVED | r) : v[r];
+                    w = top3_of_16(v);
+                    const double o0 = S.kb.insert(pack_entry(w.s0, jb));
+                    const double o1 = S.kb.insert(pack_entry(w.s1, jb));
+                    terms2(S, o0, o1);
+                    more = w.s2 <= S.lim && w.s2 < H2_REMOVED;
+                }
+            }
+        }
+        {   // merge the two half-lanes that share a query (lane, lane^32)
+            const float co = __shfl_xor(S.cref, 32, 64), lo = __shfl_xor(S.l, 32, 64);
+            const float cm = fmaxf(S.cref, co);
+            const float a = (S.cref == -INFINITY) ? 0.f : S.l * exp2f((S.cref - cm) * LOG2E);
+            const float bb = (co == -INFINITY) ? 0.f : lo * exp2f((co - cm) * LOG2E);
+            S.l = a + bb;
+            S.cref = cm;
+            double other[HB_KC];
+#pragma unroll
+            for (int t = 0; t < HB_KC; ++t)
+                other[t] = __hiloint2double(__shfl_xor(__double2hiint(S.kb.e[t]), 32, 64), __shfl_xor(__double2loint(S.kb.e[t]), 32, 64));
+#pragma unroll
+            for (int t = 0; t < HB_KC; ++t) add_term(S, entry_key(S.kb.insert(other[t])));
+        }
+        if (h == 0 && qrow < N) {
+            const size_t row = (size_t)bs * N + qrow;
+#pragma unroll
+            for (int t = 0; t < HB_KC; ++t) {
+                const unsigned key = entry_key(S.kb.e[t]), r = key & 15;
+                const bool live = key < H2_REMOVED;
+                G.cidx[row * HB_KC + t] = live ? entry_jb(S.kb.e[t]) + (int)((r & 3) + 8 * (r >> 2)) : 0x7fffffff;
+                G.cd2[row * HB_KC + t] = live ? key_d2(S, key) : INFINITY;
+            }
+            G.lsum[row * 2] = S.l;
+            G.lsum[row * 2 + 1] = S.cref;
+        }
+    }
+    finish_stamps();
+}
+
 }  // namespace
 
 void launch_norm_frags(const float *nrm, int B, int M, int Mpad, const int *amax, char *out, hipStream_t s) {
@@ -622,6 +1024,39 @@ void launch_sweep2(const HBArgs &a, const char *knf0, const char *knf1, const in
     b.nb = a.nb;
     b.stamps = nullptr;
     static const bool stamps_on = getenv("DVM_K1_STAMPS") != nullptr;
+    if (form == 5 && waves == 8) {   // third form: split roles
+        if (stamps_on) {   // diagnostic: synchronous, allocates
+            unsigned long long *dbuf = nullptr;
+            const size_t n = (size_t)blocks * 12 * 8;
+            if (hipMalloc(&dbuf, n * sizeof(unsigned long long)) != hipSuccess) return;
+            (void)hipMemset(dbuf, 0, n * sizeof(unsigned long long));
+            b.stamps = dbuf;
+            ensure_dyn_lds((const void *)softcorr_sweep3_kernel<true>, H3_LDS_BYTES);
+            hipLaunchKernelGGL(softcorr_sweep3_kernel<true>, dim3(blocks), dim3(H3_THREADS), H3_LDS_BYTES, s, b);
+            (void)hipStreamSynchronize(s);
+            unsigned long long *hbuf = (unsigned long long *)malloc(n * sizeof(unsigned long long));
+            (void)hipMemcpy(hbuf, dbuf, n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            double tot[2][8] = {{0}}, cnt[2] = {0, 0};
+            for (size_t w = 0; w < (size_t)blocks * 12; ++w) {
+                if (hbuf[w * 8 + 6] == 0) continue;   // (workgroup routed elsewhere)
+                const int role = (w % 12) < 8 ? 0 : 1;
+                cnt[role] += 1;
+                for (int i = 0; i < 8; ++i) tot[role][i] += (double)hbuf[w * 8 + i];
+            }
+            for (int role = 0; role < 2; ++role) {
+                const double tiles = tot[role][7] > 0 ? tot[role][7] : 1;
+                fprintf(stderr, "K1 stamps (third form, %s): cycles per wave and TILE: %s %.0f  %s %.0f  barrier %.0f  | whole %.0f per tile\n",
+                        role ? "consumer" : "producer", role ? "hand-off processing" : "matrix chains", tot[role][1] / tiles,
+                        role ? "DMA issue" : "selection", tot[role][2] / tiles, tot[role][5] / tiles, tot[role][6] / tiles);
+            }
+            free(hbuf);
+            (void)hipFree(dbuf);
+            return;
+        }
+        ensure_dyn_lds((const void *)softcorr_sweep3_kernel<false>, H3_LDS_BYTES);
+        hipLaunchKernelGGL(softcorr_sweep3_kernel<false>, dim3(blocks), dim3(H3_THREADS), H3_LDS_BYTES, s, b);
+        return;
+    }
     if (stamps_on) {   // diagnostic: synchronous, allocates — never taken in production
         unsigned long long *dbuf = nullptr;
         const size_t n = (size_t)blocks * waves * 8;
