@@ -29,5 +29,6 @@ __device__ __forceinline__ void split2x2(float a0, float a1, unsigned &h, unsign
 }
 
 size_t mlp_zplane_bytes(int rows);   // bytes of the plane form of `rows` z rows (padded to whole 64-row blocks)
+size_t mlp_zplane_row_bytes();       // MH_SZ
 
 }  // namespace dvm

@@ -593,6 +593,7 @@ size_t mlp_f16_pack_bytes() {   // [Wp0 | Wp1 | Wp2 | Wp3 | W3x (persistent form
     return mlp_f16_w3x_offset() + align_up((size_t)4 * 2 * 1024 * sizeof(_Float16)) + align_up(sizeof(int));
 }
 size_t mlp_zplane_bytes(int rows) { return (size_t)((rows + MH_NODES - 1) / MH_NODES) * MP_ZBLOCK; }
+size_t mlp_zplane_row_bytes() { return MH_SZ; }
 
 void launch_split_rows(const float *z, int rows, int stride, void *zp, hipStream_t s) {
     const int rp = (rows + MH_NODES - 1) / MH_NODES * MH_NODES;

@@ -180,6 +180,7 @@ void launch_assemble_pooled_planes(const float *vsrc, const float *vcorr, const 
                                    const int32_t *pi_idx, const int32_t *fps, int B, int N, int M, int Nn, void *zp, hipStream_t s);
 size_t mlp_pack_floats();
 size_t mlp_zplane_bytes(int rows);
+size_t mlp_zplane_row_bytes();
 bool mlp_persistent();
 void launch_mlp_rows(const float *z, int rows, const float *W0, const float *b0, const float *W1, const float *b1, const float *W2,
                      const float *b2, const float *W3, const float *b3, float *wp, float *out, hipStream_t s, int variant, void *zp);
@@ -388,7 +389,7 @@ static int pair_fwd_impl(const float *feat1, const float *feat2, const float *ve
     if (mlp_persistent()) {
         // the rows straight in the plane form the persistent MLP kernel stages by LDS-DMA; the fp32 rows are written (and the
         // bf16x3 kernel runs) only if that kernel's range flag comes up: three gated launches that return at once otherwise
-        char *zp21 = w.zp + (size_t)B * Nn1 * 1104;
+        char *zp21 = w.zp + (size_t)B * Nn1 * mlp_zplane_row_bytes();
         launch_assemble_pooled_planes(verts1, verts12, w.gall[0], w.gall[1], w.pval[0], w.pidx[0], w.nodes[0], B, N, M, Nn1, w.zp, s);
         launch_assemble_pooled_planes(verts2, verts21, w.gall[1], w.gall[0], w.pval[1], w.pidx[1], w.nodes[1], B, M, N, Nn2, zp21, s);
         const int *flag = launch_mlp_planes(w.zp, rows, W0, b0, W1, b1, W2, b2, W3, b3, w.wp, w.def9, s);
