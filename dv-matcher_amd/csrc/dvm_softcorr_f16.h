@@ -110,6 +110,19 @@ struct HBArgs {
 constexpr int K1_ROUTE_FULL = 0;     // first form, every softmax term (flat rows: nearly every column lies within the cut)
 constexpr int K1_ROUTE_LEAN = 1;     // first form, lean
 constexpr int K1_ROUTE_SECOND = 2;   // second form (lean)
+constexpr int K1_ROUTE_COARSE = 3;   // coarse screen (one fp16 plane; dvm_softcorr_coarse.hip): no softmax term outside the certified list
+
+// ---------------------------------------------------------------- coarse screen (dvm_softcorr_coarse.hip)
+constexpr int K1_KC_COARSE = 16;     // candidates per row handed to pass B (the other forms: HB_KC)
+// |d2_coarse - d2_chain| <= HC_ERR (|q|^2 + |k|^2), d2_chain = the reference's fp32 chain (what pass B evaluates):
+//   one-plane product: x s = h + e, |e| <= u |x s|, u = 2^-11 (fp16 round to nearest; elements below 2^-14 of the largest keep an
+//     absolute error of 2^-25 in scaled units, as in the three-product forms): |q.k - qh.kh| <= (2 u + u^2) sum |q_i k_i|
+//     <= (2^-10 + 2^-22) |q||k|, twice that in d2, and |q||k| <= (|q|^2 + |k|^2) / 2:          9.77e-4
+//   the list entry keeps 19 bits of the accumulator (rounded down): 2^-14 (d2 + 2^-8 |q|^2), d2 <= 2 (|q|^2 + |k|^2):  1.23e-4
+//   fp32 accumulation of the matrix instructions and of the chain (gamma_130 of sum |2 q_i k_i| + the norms, both):   1.6e-5
+constexpr float HC_ERR = 1.12e-3f;
+bool coarse_supports(int N, int M);
+void launch_coarse(const HBArgs &a, const char *knf0, const char *knf1, const int *amaxc, int blocks, hipStream_t s);
 
 
 // second form of pass A (dvm_softcorr_sweep2.hip); form = sweep_form() of the caller: 1 plain, 2 pipelined, 3 pipelined + paced

@@ -452,8 +452,8 @@ constexpr int K1P_ROWS = 4, K1P_COLS = 256;   // (8 x 256 with a wave per row pa
 struct K1ProbeArgs {
     const float *f[2], *n[2];   // features [B][rows][128] and squared norms of side 0 / 1
     int rows[2];
-    float cutw, p_second, p_lean;
-    int have_second;
+    float cutw, p_coarse, p_second, p_lean;
+    int have_second, have_coarse;
     int *route;                 // [dirs][B]
     float *frac;                // [dirs][B]
 };
@@ -537,6 +537,7 @@ __global__ __launch_bounds__(256) void k1_route_kernel(const K1ProbeArgs a, int 
     __syncthreads();
     const float p = (part[0] + part[1] + part[2] + part[3]) / B;
     int route = p <= a.p_second ? K1_ROUTE_SECOND : p <= a.p_lean ? K1_ROUTE_LEAN : K1_ROUTE_FULL;
+    if (a.have_coarse && p <= a.p_coarse) route = K1_ROUTE_COARSE;
     if (route == K1_ROUTE_SECOND && !a.have_second) route = K1_ROUTE_LEAN;
     for (int i = tid; i < B; i += 256) a.route[dir * B + i] = route;
 }
@@ -573,9 +574,10 @@ struct HRArgs {
     HRGroup g[2];
     long rows0;       // B * g[0].N
     long rows_total;
-    float neg_alpha;
+    float neg_alpha, cutw;
     int topk;
-    int remap;        // forms 0 and 2: XCD-aware block numbering (measurement switch)
+    const int *route; // per (group, batch entry) as for pass A, or nullptr = this launch takes every row
+    int nb;
 };
 
 // compile-time loop: f(std::integral_constant<int, I>) for I in [B, E) (DPP controls must be constants)
@@ -587,34 +589,14 @@ __device__ __forceinline__ void static_for(F &&f) {
     }
 }
 
-// Five forms of the exact evaluation (FORM; DVM_K1_REFINE selects; measurements: profiles/r3_refine_pmc.txt, 512 pairs x 2):
-// 4  (shipped, as 14 = with XCD-aware block numbering) four lanes load a whole 64-byte piece of a candidate row, the lane <-> row
-//    transpose goes through LDS, the chain is one v_fmac_f32_dpp per dimension (query values by row_share): 1.04 ms.  A quarter
-//    of form 0's L1 accesses (652 per wave), no line fetched twice, TA_BUSY 43 %; what then set the time was how long a wave
-//    lives (two dependent round trips + the chain) times how many fit: 2.07 ms at 171 VGPRs (whole row in flight), 1.60 with a
-//    rolling window of 4 pieces and the fused DPP fma, 1.29 at 2 pieces (118 VGPRs = 4 waves per SIMD), 1.04 with the group
-//    wave-uniform (pointers in scalar registers) and 3 pieces; XCD-aware numbering is worth 5 % here (neutral on forms 0 - 2).
-// 3  form 0 with the query row shared by DPP instead of streamed by every lane: half the load instructions, the same
-//    gathered rows: 2.14 - 2.16 ms against 2.19 - 2.21 ms in the same run (with update_dpp + fma; 2.69 ms with the fused
-//    instruction, whose fixed order makes the compiler hold the whole row: 190 VGPRs).
-// 0  every lane streams its own candidate row and the query row (32 x 16 B): 2.18 ms.  The wave gathers 48 rows x 512 B; the launch
-//    moves 12.9 GB from L2 to the CUs = 5.9 TB/s, the rate MI355X_MICROARCH.md measures for random whole rows of a buffer far
-//    larger than the Infinity Cache (5.5 - 5.8 TB/s).  A load instruction touches 48 rows: 1 900 64-B L1 accesses per wave,
-//    TA_BUSY 88 - 100 %.
-// 2  the 16 lanes of a row as a systolic chain (below): contiguous 512-B rows per load, no LDS, bit-identical chains: 2.20 ms
-//    with eight steps of rows in flight per lane (3.15 ms as the scheduler orders the loads).  32 B per lane at a 32-B stride
-//    still costs two 64-B accesses per four lanes and the chain's fill and drain steps load as well: 2 180 L1 accesses per
-//    wave, TA_BUSY 80 %, L1 misses 1.71e8 -> 1.08e8 (no line is fetched twice).
-// 1  persistent waves, rows through LDS: the wave's 4 x 12 candidate rows and 4 query rows come by LDS-DMA, two whole rows per
-//    instruction (16 full 64-B accesses each, 416 per wave), the 16-B chunks of a row XOR-swizzled with its slot number on
-//    the source address; each lane then runs the chain over ITS row from LDS (conflict-free: 16 slots spread over the 8 chunk
-//    positions of a bank row).  26 KiB of LDS per wave = 6 waves per CU: 2.87 ms with one quad per wave (three dependent
-//    memory round trips per wave), 2.58 ms with persistent waves that request the NEXT quad's lists, norms and partial sums
-//    together with the DMA of the current one, 2.46 ms with every XCD walking its own contiguous eighth of the rows (a
-//    pair's 1 MiB of key rows then stays in that XCD's L2).  7 us per quad and wave: 156 KB in flight per CU do not cover
-//    the round trip at this rate.
-// All five give bit-identical results.  Forms 0 - 3 end at 2.1 - 2.2 ms for three different reasons (L1 accesses; chain fill and
-// drain; occupancy) - which looked like the gather rate of the memory system until form 4 removed all three.
+// The exact evaluation gathers KC candidate rows of 512 B per query row.  Four lanes load a whole 64-byte piece of a candidate
+// row, the lane <-> row transpose goes through LDS, the chain is one v_fmac_f32_dpp per dimension (query values by row_share):
+// 1.04 ms per launch of 512 pairs x 2 at KC = 12.  A quarter of the L1 accesses of "every lane streams its own row" (652 per wave),
+// no line fetched twice; what then sets the time is how long a wave lives (two dependent round trips + the chain) times how many
+// fit: a rolling window of HR4W pieces in flight (3: 126 VGPRs = 4 waves per SIMD), the group wave-uniform (pointers in scalar
+// registers), XCD-aware block numbering (a pair's key rows in one L2: 5 %).  Four other access shapes were measured in round 3
+// (per-lane streaming with and without a DPP-shared query row, a systolic chain over the 16 lanes of a row, persistent waves fed
+// by LDS-DMA: 2.1 - 2.9 ms, each bound by something of its own) and are gone: profiles/notes_k1.md.
 // acc = fma(x of lane L of the 16-lane row, y, acc) in ONE instruction (the compiler keeps update_dpp + v_fma apart, with a
 // v_mov 0 for the DPP's `old` operand: three instructions).  x must have been written at least two instructions earlier (the DPP
 // read-after-write hazard is not tracked through inline assembly): here the scaled query values, written before the row loads.
@@ -622,9 +604,6 @@ template <int L>
 __device__ __forceinline__ void fma_row_share(float &acc, float x, float y) {
     asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(L));
 }
-constexpr int HR_AHEAD = 8;                                              // systolic form: steps of rows in flight per lane
-constexpr int HR_SLOTS = 4 * HB_KC;                                      // candidate rows of a wave
-constexpr int HR_LDS_BYTES = (HR_SLOTS + 4) * HB_D * (int)sizeof(float);   // + the 4 query rows
 struct HRRow {     // what a lane needs of its row before the candidate rows can be requested
     long row;      // within the group
     int grp, jc;
@@ -632,111 +611,73 @@ struct HRRow {     // what a lane needs of its row before the candidate rows can
     float va, na, nkm, ls0, ls1;
 };
 static inline long hr_quads(const HRArgs &r) { return (r.rows0 + 3) / 4 + (r.rows_total - r.rows0 + 3) / 4; }
-template <int FORM, int HR4W = 4>
-__global__ __launch_bounds__(FORM == 1 ? 64 : 256) void softcorr_refine_kernel(const HRArgs args) {
-    __shared__ __attribute__((aligned(16))) char hr_lds[FORM == 1 ? HR_LDS_BYTES : FORM == 4 ? 4 * 2 * HR_SLOTS * 64 : 16];
+// KC: candidates per row in cidx / cd2 (HB_KC from the three-product sweeps, K1_KC_COARSE from the coarse screen).
+// COARSE: the list comes from the one-plane screen — error band HC_ERR instead of HB_ERR, pass A's partial sum is empty: every
+// entry that can rank among the first `need` OR lie within the softmax cut is evaluated exactly, the others owe no term, and the
+// row is certified only if no column outside the evaluated ones can do either.
+template <int KC, bool COARSE, int HR4W>
+__global__ __launch_bounds__(256) void softcorr_refine_kernel(const HRArgs args) {
+    constexpr int SLOTS = 4 * KC, NL = SLOTS / 16;     // candidate rows of a wave; loads per lane and 64-byte piece
+    __shared__ __attribute__((aligned(16))) char hr_lds[4 * 2 * SLOTS * 64];
     const int lane = threadIdx.x & 63, l16 = lane & 15, base = lane & 48;
     const float neg_alpha = args.neg_alpha;
     const int topk = args.topk;
-    const bool cand = l16 < HB_KC;
-    // (XCD-aware block numbering — a pair's rows on one XCD, so that its 2048 key rows stay in one L2 — was measured neutral,
-    // 2.15 vs 2.19 ms: what the other seven L2s miss is served by the Infinity Cache)
+    const bool cand = l16 < KC;
     // A quad (the 4 rows of a wave) never straddles the two groups, so the group - and with it every pointer of HRGroup - is
-    // wave-uniform and lives in scalar registers (per-lane groups cost ~20 VGPRs, which is a wave per SIMD in form 4).
+    // wave-uniform and lives in scalar registers (per-lane groups cost ~20 VGPRs, which is a wave per SIMD).
     const long nq0 = (args.rows0 + 3) / 4, nquads = nq0 + (args.rows_total - args.rows0 + 3) / 4;
-    auto fetch = [&](long quad_) __attribute__((always_inline)) {
-        HRRow p;
-        const int qd = __builtin_amdgcn_readfirstlane((int)quad_);
+    const long quad = ((long)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x) >> 6;   // one quad per wave
+    if (quad >= nquads) return;
+    HRRow p;
+    {
+        const int qd = __builtin_amdgcn_readfirstlane((int)quad);
         p.grp = qd >= nq0 ? 1 : 0;
+        // (one route per direction of a launch: k1_route_kernel)
+        if (args.route && (args.route[p.grp * args.nb] == K1_ROUTE_COARSE) != COARSE) return;
         const long rows = p.grp ? args.rows_total - args.rows0 : args.rows0;
         p.row = (long)(qd - (p.grp ? (int)nq0 : 0)) * 4 + (lane >> 4);
         p.rvalid = p.row < rows;
         if (!p.rvalid) p.row = rows - 1;
         const HRGroup &G = args.g[p.grp];
-        p.jc = cand ? G.cidx[p.row * HB_KC + l16] : 0x7fffffff;
-        p.va = cand ? G.cd2[p.row * HB_KC + l16] : INFINITY;
+        p.jc = cand ? G.cidx[p.row * KC + l16] : 0x7fffffff;
+        p.va = cand ? G.cd2[p.row * KC + l16] : INFINITY;
         p.na = G.nq[p.row];
         p.nkm = G.nkmax[p.row / G.N];
         p.ls0 = G.lsum[p.row * 2];
         p.ls1 = G.lsum[p.row * 2 + 1];
-        return p;
-    };
-    // Form 1: workgroup i runs on XCD i % 8; every XCD walks ITS contiguous eighth of the quads, its waves side by side — so the
-    // 192 waves of an XCD are inside one pair's rows at any time and that pair's 1 MiB of key rows stays in the XCD's L2.
-    long quad, qend, qstep;
-    if (FORM == 1) {
-        const long per = (nquads + 7) / 8, x = blockIdx.x & 7;
-        quad = x * per + (blockIdx.x >> 3);
-        qend = (x + 1) * per < nquads ? (x + 1) * per : nquads;
-        qstep = gridDim.x >> 3;
-    } else {   // one quad per wave
-        quad = ((long)(args.remap ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
-        qend = nquads;
-        qstep = nquads;
     }
-    if (quad >= qend) return;
-    HRRow cur = fetch(quad);
-    for (; quad < qend; quad += qstep) {
-    const HRRow p = cur;
     const HRGroup &G = args.g[p.grp];
     const long row = p.row;
     const int M = G.M;
     const int b = (int)(row / G.N);
     const int jc = p.jc;
     const bool valid = cand && jc >= 0 && jc < M;
-    // (empty slots — fewer than 12 columns, M < 12 — rank behind every column and among themselves by slot, so that every
-    // output position below topk is written: with one shared "no column" value they would all take the same rank)
+    // (empty slots — fewer than KC columns — rank behind every column and among themselves by slot, so that every output
+    // position below topk is written: with one shared "no column" value they would all take the same rank)
     const int j = valid ? jc : (0x7fffff00 | l16);
     const float na = p.na;
     const int need = topk < M ? topk : M;        // entries that must be exact
-    const float delta = HB_ERR * (na + p.nkm);
+    const float delta = (COARSE ? HC_ERR : HB_ERR) * (na + p.nkm);
     const float va = valid ? p.va : INFINITY;
-    // Candidates beyond the `need`-th whose approximate distance exceeds the need-th's by more than the error band
-    // cannot rank among the first `need` (their exact value is above every one of those): their rows are not fetched
-    // (usually the two margin candidates: 1/6 of the gather) and they keep their approximate softmax term.
+    // Candidates beyond the `need`-th whose approximate distance exceeds the need-th's by more than the error band cannot
+    // rank among the first `need` (their exact value is above every one of those): their rows are not fetched.  From the
+    // three-product sweeps they keep their approximate softmax term (usually the two margin candidates: 1/6 of the gather).
+    // From the coarse screen an approximate term is worth nothing, so an entry is also evaluated if it can lie within the
+    // cut — sqrt(va - delta) <= d_min + cutw with d_min <= sqrt(va_0 + delta) — and the others owe none.
     const float va_need = __shfl(va, base + need - 1, 64);
-    const bool skip = valid && l16 >= need && va > va_need + 2.f * delta;
+    bool skip = valid && l16 >= need && va > va_need + 2.f * delta;
+    if (COARSE) {
+        const float dcut = __builtin_amdgcn_sqrtf(__shfl(va, base, 64) + delta) * 1.000001f + args.cutw;
+        skip = skip && (va - delta) > (dcut * dcut) * 1.000001f;
+    }
     const bool eval = valid && !skip;
     float v = INFINITY;
-    if (FORM == 0) {
-        if (eval) v = exact_d2(G.q + (size_t)row * HB_D, G.k + ((size_t)b * M + j) * HB_D, na, G.nk[(size_t)b * M + j]);
-    } else if (FORM == 3) {
-        // As form 0, but the QUERY row is not streamed by every lane: the 16 lanes of a row each load 32 bytes of it once (times
-        // -2), and the chain takes q_k from the lane that holds it through a DPP row_share move (which replaces the multiply by
-        // -2: the same number of vector instructions).  Half of form 0's load instructions were these 16-fold redundant query
-        // loads, and the kernel is bound by the texture-address unit (TA_BUSY 88 - 100 %).  All 16 lanes run the chain (the
-        // lanes without a candidate on the query row itself: a line already there), the result is kept where `eval`.
-        const float *qpc = G.q + (size_t)row * HB_D + 8 * l16;
-        const f32x4 qa = *(const f32x4 *)qpc, qb = *(const f32x4 *)(qpc + 4);
-        float qs[8] = {-2.f * qa.x, -2.f * qa.y, -2.f * qa.z, -2.f * qa.w, -2.f * qb.x, -2.f * qb.y, -2.f * qb.z, -2.f * qb.w};
-        // (fma_row_share reads these through DPP from inline assembly: the two wait states a DPP read needs after the write of its
-        // source are not tracked there - pin the writes in front of an explicit s_nop, wherever the scheduler moves things)
-        asm volatile("s_nop 1" : "+v"(qs[0]), "+v"(qs[1]), "+v"(qs[2]), "+v"(qs[3]), "+v"(qs[4]), "+v"(qs[5]), "+v"(qs[6]), "+v"(qs[7]));
-        const float *kr = eval ? G.k + ((size_t)b * M + j) * HB_D : G.q + (size_t)row * HB_D;
-        const float nb = eval ? G.nk[(size_t)b * M + j] : 0.f;
-        float acc = 0.f;
-        f32x4 kv[HB_D / 4];
-#pragma unroll
-        for (int c = 0; c < HB_D / 4; ++c) kv[c] = *(const f32x4 *)(kr + 4 * c);
-        static_for<0, HB_D / 4>([&](auto cc) __attribute__((always_inline)) {
-            constexpr int c = decltype(cc)::value;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                fma_row_share<c / 2>(acc, qs[4 * (c & 1) + e], kv[c][e]);
-            }
-        });
-        if (eval) {
-            const float d2 = (acc + na) + nb;
-            v = d2 > 0.f ? d2 : 0.f;
-        }
-    } else if (FORM == 4) {
-        // Whole 64-byte pieces per four lanes, the lane <-> row transpose through LDS.  Forms 0 and 3 touch 48 different lines
-        // with every load instruction (16 bytes of each) - 1 536 L1 accesses per wave for 384 accesses' worth of bytes.  Here
-        // lane L loads chunk L % 4 of the 64-byte piece p of candidate row L / 4 + 16 i (i = 0..2): 16 full accesses per
-        // instruction, 384 per wave; the 24 loads of the 8 pieces are requested at once, and piece by piece the registers go
-        // to LDS (chunk c of slot s at position c ^ (s / 4 % 4): conflict-free both ways) from where each candidate lane reads
-        // ITS row's piece and continues its k-ordered chain.  Two 3-KiB piece buffers per wave; the LDS pipe serves a wave's
-        // instructions in order, so the write of piece p + 2 cannot overtake the reads of piece p.
+    {
+        // Lane L loads chunk L % 4 of the 64-byte piece p of candidate row L / 4 + 16 i (i < NL): 16 full accesses per
+        // instruction; piece by piece the registers go to LDS (chunk c of slot s at position c ^ (s / 4 % 4): conflict-free
+        // both ways) from where each candidate lane reads ITS row's piece and continues its k-ordered chain.  Two piece buffers
+        // per wave; the LDS pipe serves a wave's instructions in order, so the write of piece p + 2 cannot overtake the reads
+        // of piece p.
         const float *qrow = G.q + (size_t)row * HB_D;
         const f32x4 qa = *(const f32x4 *)(qrow + 8 * l16), qb = *(const f32x4 *)(qrow + 8 * l16 + 4);
         float qs[8] = {-2.f * qa.x, -2.f * qa.y, -2.f * qa.z, -2.f * qa.w, -2.f * qb.x, -2.f * qb.y, -2.f * qb.z, -2.f * qb.w};
@@ -746,33 +687,33 @@ __global__ __launch_bounds__(FORM == 1 ? 64 : 256) void softcorr_refine_kernel(c
         const float *const kptr = eval ? G.k + ((size_t)b * M + j) * HB_D : qrow;   // (a row that is not needed: the query row)
         const float nb = eval ? G.nk[(size_t)b * M + j] : 0.f;
         const unsigned klo = (unsigned)(uintptr_t)kptr, khi = (unsigned)((uintptr_t)kptr >> 32);
-        char *const wl = hr_lds + (threadIdx.x >> 6) * (2 * HR_SLOTS * 64);
+        char *const wl = hr_lds + (threadIdx.x >> 6) * (2 * SLOTS * 64);
         const int ck = lane & 3, s0 = lane >> 2;
         typedef const __attribute__((address_space(1))) float gfloat;   // (an address rebuilt from integers is a flat one otherwise,
-        gfloat *src[3];                                                  // and flat loads count on the LDS counter as well)
+        gfloat *src[NL];                                                 // and flat loads count on the LDS counter as well)
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int sl = s0 + 16 * i, owner = (sl / HB_KC) * 16 + sl % HB_KC;
+        for (int i = 0; i < NL; ++i) {
+            const int sl = s0 + 16 * i, owner = (sl / KC) * 16 + sl % KC;
             const unsigned lo = (unsigned)__shfl((int)klo, owner, 64), hi = (unsigned)__shfl((int)khi, owner, 64);
             src[i] = (gfloat *)(((uintptr_t)hi << 32) | lo) + 4 * ck;
         }
-        constexpr int WIN = HR4W;   // pieces in flight per lane (x 3 loads): 8 = the whole row (171 VGPRs, 2 waves per SIMD)
-        f32x4 kv[WIN][3];
+        constexpr int WIN = HR4W;   // pieces in flight per lane (x NL loads)
+        f32x4 kv[WIN][NL];
 #pragma unroll
         for (int pc = 0; pc < WIN; ++pc)
 #pragma unroll
-            for (int i = 0; i < 3; ++i) kv[pc][i] = *(const __attribute__((address_space(1))) f32x4 *)(src[i] + 16 * pc);
-        const int myslot = (lane >> 4) * HB_KC + (cand ? l16 : 0);
+            for (int i = 0; i < NL; ++i) kv[pc][i] = *(const __attribute__((address_space(1))) f32x4 *)(src[i] + 16 * pc);
+        const int myslot = (lane >> 4) * KC + (cand ? l16 : 0);
         const int wsw = (s0 >> 2) & 3, rsw = (myslot >> 2) & 3;   // (s0 + 16 i) / 4 % 4 does not depend on i
         float acc = 0.f;
         static_for<0, 8>([&](auto pcc) __attribute__((always_inline)) {
             constexpr int pc = decltype(pcc)::value;
-            char *const buf = wl + (pc & 1) * (HR_SLOTS * 64);
+            char *const buf = wl + (pc & 1) * (SLOTS * 64);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) *(f32x4 *)(buf + (s0 + 16 * i) * 64 + ((ck ^ wsw) << 4)) = kv[pc % WIN][i];
+            for (int i = 0; i < NL; ++i) *(f32x4 *)(buf + (s0 + 16 * i) * 64 + ((ck ^ wsw) << 4)) = kv[pc % WIN][i];
             if constexpr (pc + WIN < 8) {   // the registers just stored take the piece WIN further on
 #pragma unroll
-                for (int i = 0; i < 3; ++i) kv[pc % WIN][i] = *(const __attribute__((address_space(1))) f32x4 *)(src[i] + 16 * (pc + WIN));
+                for (int i = 0; i < NL; ++i) kv[pc % WIN][i] = *(const __attribute__((address_space(1))) f32x4 *)(src[i] + 16 * (pc + WIN));
             }
             __builtin_amdgcn_wave_barrier();
             f32x4 kc[4];
@@ -791,107 +732,11 @@ __global__ __launch_bounds__(FORM == 1 ? 64 : 256) void softcorr_refine_kernel(c
             const float d2 = (acc + na) + nb;
             v = d2 > 0.f ? d2 : 0.f;
         }
-    } else if (FORM == 2) {
-        // The 16 lanes of a row as a systolic chain: lane l holds dims [8 l, 8 l + 8) of the query (times -2) and, at step t,
-        // the same dims of candidate t - l; it continues that candidate's fma chain (the accumulator arrives from lane l - 1
-        // by a DPP shift) and hands it on.  Candidate c leaves lane 15 after step c + 15 with the reference's k-ordered chain
-        // — bit for bit what one lane computes alone.
-        constexpr int ROW_SHR1 = 0x111, ROW_SHARE0 = 0x150;
-        const float *const kbat = G.k + (size_t)b * M * HB_D + 8 * l16, *const qpc = G.q + (size_t)row * HB_D + 8 * l16;
-        const f32x4 qa = *(const f32x4 *)qpc, qb = *(const f32x4 *)(qpc + 4);
-        const float qs[8] = {-2.f * qa.x, -2.f * qa.y, -2.f * qa.z, -2.f * qa.w, -2.f * qb.x, -2.f * qb.y, -2.f * qb.z, -2.f * qb.w};
-        const int jj = eval ? j : -1;   // (a candidate that is not evaluated reads the query piece instead: a line already here)
-        // The piece of step t + HR_AHEAD is requested at step t (the column numbers run ahead of the chain; scheduling barriers
-        // keep the requests where they are written: left alone, the scheduler holds two or three steps in flight — 3.15 ms).
-        constexpr int NS = HB_KC + 15;
-        int J = -1;
-        float acc = 0.f;
-        f32x4 ka[NS], kb4[NS];
-        auto request = [&](auto tc) __attribute__((always_inline)) {
-            constexpr int t = decltype(tc)::value;
-            const int inj = t < HB_KC ? __builtin_amdgcn_update_dpp(0, jj, ROW_SHARE0 + (t < HB_KC ? t : 0), 0xf, 0xf, false) : -1;
-            J = __builtin_amdgcn_update_dpp(inj, J, ROW_SHR1, 0xf, 0xf, false);   // lane 0 takes the new candidate, lane l lane l - 1's
-            const float *src = J >= 0 ? kbat + (size_t)J * HB_D : qpc;
-            ka[t] = *(const f32x4 *)src;
-            kb4[t] = *(const f32x4 *)(src + 4);
-        };
-        static_for<0, HR_AHEAD>(request);
-        static_for<0, NS>([&](auto tc) __attribute__((always_inline)) {
-            constexpr int t = decltype(tc)::value;
-            if constexpr (t + HR_AHEAD < NS) request(std::integral_constant<int, t + HR_AHEAD>{});
-            __builtin_amdgcn_sched_barrier(0);
-            acc = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), ROW_SHR1, 0xf, 0xf, false));   // lane 0 starts at 0
-            acc = fmaf(qs[0], ka[t].x, acc);
-            acc = fmaf(qs[1], ka[t].y, acc);
-            acc = fmaf(qs[2], ka[t].z, acc);
-            acc = fmaf(qs[3], ka[t].w, acc);
-            acc = fmaf(qs[4], kb4[t].x, acc);
-            acc = fmaf(qs[5], kb4[t].y, acc);
-            acc = fmaf(qs[6], kb4[t].z, acc);
-            acc = fmaf(qs[7], kb4[t].w, acc);
-            if (t >= 15) {
-                const float fin = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), ROW_SHARE0 + 15, 0xf, 0xf, false));
-                v = l16 == t - 15 ? fin : v;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        if (eval) {
-            const float d2 = (v + na) + G.nk[(size_t)b * M + j];
-            v = d2 > 0.f ? d2 : 0.f;
-        } else {
-            v = INFINITY;
-        }
-    } else {   // FORM == 1
-        const int h = lane >> 5, r32 = lane & 31;
-        const float *const kptr = eval ? G.k + ((size_t)b * M + j) * HB_D : nullptr;   // nullptr: the row is not fetched
-        const float *const qptr = G.q + (size_t)row * HB_D;
-        const unsigned klo = (unsigned)(uintptr_t)kptr, khi = (unsigned)((uintptr_t)kptr >> 32);
-        const unsigned qlo = (unsigned)(uintptr_t)qptr, qhi = (unsigned)((uintptr_t)qptr >> 32);
-        // slot s = 12 g + c holds candidate c of the wave's row g; instruction i brings slots 2 i (lanes 0-31) and 2 i + 1
-#pragma unroll
-        for (int i = 0; i < HR_SLOTS / 2; ++i) {
-            const int sa = 2 * i, sb = 2 * i + 1;
-            const int la = (sa / HB_KC) * 16 + sa % HB_KC, lb = (sb / HB_KC) * 16 + sb % HB_KC;   // the lanes that own them
-            const unsigned alo = __builtin_amdgcn_readlane(klo, la), ahi = __builtin_amdgcn_readlane(khi, la);
-            const unsigned blo = __builtin_amdgcn_readlane(klo, lb), bhi = __builtin_amdgcn_readlane(khi, lb);
-            const char *src = (const char *)(((uintptr_t)(h ? bhi : ahi) << 32) | (h ? blo : alo));
-            const int slot = 2 * i + h;
-            if (src)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + ((r32 ^ (slot & 31)) << 4)),
-                                                 (__attribute__((address_space(3))) void *)(hr_lds + i * 1024), 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {   // query rows of the row groups 2 i and 2 i + 1, chunk p of group g at position p ^ g
-            const unsigned alo = __builtin_amdgcn_readlane(qlo, 32 * i), ahi = __builtin_amdgcn_readlane(qhi, 32 * i);
-            const unsigned blo = __builtin_amdgcn_readlane(qlo, 32 * i + 16), bhi = __builtin_amdgcn_readlane(qhi, 32 * i + 16);
-            const char *src = (const char *)(((uintptr_t)(h ? bhi : ahi) << 32) | (h ? blo : alo));
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + ((r32 ^ (2 * i + h)) << 4)),
-                                             (__attribute__((address_space(3))) void *)(hr_lds + (HR_SLOTS / 2 + i) * 1024), 16, 0, 0);
-        }
-        const float nb = eval ? G.nk[(size_t)b * M + j] : 0.f;
-        if (quad + qstep < qend) cur = fetch(quad + qstep);   // the next quad's lists ride on this round trip
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wave's own pieces have landed (one wave per workgroup: no barrier)
-        if (eval) {
-            const int g = lane >> 4, slot = g * HB_KC + l16;
-            const char *krow = hr_lds + slot * (HB_D * 4), *qrow = hr_lds + (HR_SLOTS + g) * (HB_D * 4);
-            const int ks = slot & 31;
-            float acc = 0.f;
-#pragma unroll 8
-            for (int c = 0; c < HB_D / 4; ++c) {
-                const f32x4 qv = *(const f32x4 *)(qrow + ((c ^ g) << 4)), kv = *(const f32x4 *)(krow + ((c ^ ks) << 4));
-                acc = fmaf(-2.f * qv.x, kv.x, acc);
-                acc = fmaf(-2.f * qv.y, kv.y, acc);
-                acc = fmaf(-2.f * qv.z, kv.z, acc);
-                acc = fmaf(-2.f * qv.w, kv.w, acc);
-            }
-            const float d2 = (acc + na) + nb;
-            v = d2 > 0.f ? d2 : 0.f;
-        }
     }
     const float de = eval ? sqrt_rn(v) : INFINITY;
     int rank = 0;
 #pragma unroll
-    for (int t = 0; t < HB_KC; ++t) {
+    for (int t = 0; t < KC; ++t) {
         const float dt = __shfl(de, base + t, 64);
         const int jt = __shfl(j, base + t, 64);
         rank += (dt < de || (dt == de && jt < j)) ? 1 : 0;
@@ -902,7 +747,7 @@ __global__ __launch_bounds__(FORM == 1 ? 64 : 256) void softcorr_refine_kernel(c
     for (int o = 1; o < 16; o <<= 1) dmin = fminf(dmin, __shfl_xor(dmin, o, 64));
     const float smax = dmin * neg_alpha;
     const float s = (eval ? de : __builtin_amdgcn_sqrtf(fmaxf(va, 0.f))) * neg_alpha;
-    const float ex = valid ? exp2f((s - smax) * LOG2E) : 0.f;
+    const float ex = (COARSE ? eval : valid) ? exp2f((s - smax) * LOG2E) : 0.f;
     float esum = ex;
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) esum += __shfl_xor(esum, o, 64);
@@ -919,7 +764,17 @@ __global__ __launch_bounds__(FORM == 1 ? 64 : 256) void softcorr_refine_kernel(c
         tskip = fminf(tskip, __shfl_xor(tskip, o, 64));
     }
     const float theta = fminf(tmax, tskip);
-    const bool certain = (M <= HB_KC) || (vlast < theta - 2.f * delta);
+    bool certain = (M <= KC) || (vlast < theta - 2.f * delta);
+    if (COARSE) {
+        // A skipped entry needs no test here: va > va_need + 2 delta puts its exact value above va_need + delta, which is
+        // at least the exact value of each of the first `need` entries, hence above vlast; and it lies outside the cut by the
+        // rule that skipped it.  (Testing it against theta as above would flag a row whenever the exact `need`-th value exceeds
+        // its approximation by more than the first skipped entry clears the band: 0.8 % of random rows at this error level.)
+        // What is left are the columns OUTSIDE the list, all at or above tmax: none of them ranks among the first `need`, and
+        // none lies within the cut of the EXACT minimum.
+        const float dcut = dmin * 1.000001f + args.cutw;
+        certain = (M <= KC) || (vlast < tmax - delta && (dcut * dcut) * 1.000001f < tmax - delta);
+    }
     if (p.rvalid && !certain) {
         if (l16 == 0) G.flagged[atomicAdd(G.nflagged, 1)] = (int32_t)row;   // the exact kernel writes this row
     } else if (p.rvalid) {
@@ -931,7 +786,6 @@ __global__ __launch_bounds__(FORM == 1 ? 64 : 256) void softcorr_refine_kernel(c
             if (G.smax) G.smax[row] = smax;
             if (G.sum) G.sum[row] = lsm;
         }
-    }
     }
 }
 
@@ -1186,14 +1040,15 @@ static int sweep_form() {
 // forces one route, DVM_K1_ROUTE_DEBUG prints the routes of every launch (synchronous)
 struct RoutePolicy {
     int forced;
-    float p_second, p_lean;
-    bool debug;
+    float p_coarse, p_second, p_lean;
+    bool debug, coarse;
 };
 static const RoutePolicy &route_policy() {
     static const RoutePolicy pol = [] {
-        RoutePolicy r{-1, 0.006f, 0.02f, getenv("DVM_K1_ROUTE_DEBUG") != nullptr};
+        RoutePolicy r{-1, 0.004f, 0.006f, 0.02f, getenv("DVM_K1_ROUTE_DEBUG") != nullptr, true};
         if (const char *e = getenv("DVM_K1_ROUTE")) r.forced = atoi(e);
-        if (const char *e = getenv("DVM_K1_ROUTE_P")) (void)sscanf(e, "%f,%f", &r.p_second, &r.p_lean);
+        if (const char *e = getenv("DVM_K1_ROUTE_P")) (void)sscanf(e, "%f,%f,%f", &r.p_second, &r.p_lean, &r.p_coarse);
+        if (const char *e = getenv("DVM_K1_COARSE")) r.coarse = atoi(e) != 0;
         return r;
     }();
     return pol;
@@ -1204,16 +1059,16 @@ static void report_routes(const int *route, const float *frac, int n, hipStream_
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(r.data(), route, n * sizeof(int), hipMemcpyDeviceToHost);
     (void)hipMemcpy(p.data(), frac, n * sizeof(float), hipMemcpyDeviceToHost);
-    int cnt[3] = {0, 0, 0};
+    int cnt[4] = {0, 0, 0, 0};
     double ps = 0, pmin = 1, pmax = 0;
     for (int i = 0; i < n; ++i) {
-        ++cnt[r[i] < 0 || r[i] > 2 ? 0 : r[i]];
+        ++cnt[r[i] < 0 || r[i] > 3 ? 0 : r[i]];
         ps += p[i];
         pmin = p[i] < pmin ? p[i] : pmin;
         pmax = p[i] > pmax ? p[i] : pmax;
     }
-    fprintf(stderr, "K1 routes: %d full, %d lean, %d second form; fraction within the cut: mean %.4f%% (min %.4f%%, max %.4f%%)\n", cnt[0],
-            cnt[1], cnt[2], 100 * ps / n, 100 * pmin, 100 * pmax);
+    fprintf(stderr, "K1 routes: %d full, %d lean, %d second form, %d coarse; fraction within the cut: mean %.4f%% (min %.4f%%, max %.4f%%)\n",
+            cnt[0], cnt[1], cnt[2], cnt[3], 100 * ps / n, 100 * pmin, 100 * pmax);
 }
 
 // workspace of the fp16 path for (B, N, M): planes of both sides, candidates of both directions, flags
@@ -1226,8 +1081,8 @@ size_t softcorr_f16_ws_bytes(int B, int N, int M, bool both) {
     const int dirs = both ? 2 : 1;
     for (int d = 0; d < dirs; ++d) {
         const size_t R = (size_t)B * (d == 0 ? N : M);
-        n += align_up(R * HB_KC * sizeof(int32_t)) + align_up(R * HB_KC * sizeof(float)) + align_up(R * 2 * sizeof(float)) +
-             align_up((R + 1) * sizeof(int32_t));
+        n += align_up(R * K1_KC_COARSE * sizeof(int32_t)) + align_up(R * K1_KC_COARSE * sizeof(float)) + align_up(R * 2 * sizeof(float)) +
+             align_up((R + 1) * sizeof(int32_t));   // (candidate lists sized for the longest form's)
     }
     return n;
 }
@@ -1255,8 +1110,8 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
     float *cd2[2] = {nullptr, nullptr}, *lsum[2] = {nullptr, nullptr};
     for (int d = 0; d < (both ? 2 : 1); ++d) {
         const size_t R = (size_t)B * (d == 0 ? N : M);
-        cidx[d] = ar.take<int32_t>(R * HB_KC);
-        cd2[d] = ar.take<float>(R * HB_KC);
+        cidx[d] = ar.take<int32_t>(R * K1_KC_COARSE);
+        cd2[d] = ar.take<float>(R * K1_KC_COARSE);
         lsum[d] = ar.take<float>(R * 2);
         flag[d] = ar.take<int32_t>(R + 1);  // [0] = counter, [1..] = rows
     }
@@ -1307,25 +1162,27 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
     const bool lean = -neg_alpha >= 32.f;
     const RoutePolicy &pol = route_policy();
     const bool have2 = sweep_form() != 0;
+    const bool havec = pol.coarse && coarse_supports(N, M);
     const bool routed = lean && pol.forced < 0;
-    const int fixed = !lean ? K1_ROUTE_FULL : pol.forced < 0 ? -1 : (pol.forced == K1_ROUTE_SECOND && !have2) ? K1_ROUTE_LEAN : pol.forced;
+    const int fixed = !lean ? K1_ROUTE_FULL : pol.forced < 0 ? -1 : (pol.forced == K1_ROUTE_SECOND && !have2) ? K1_ROUTE_LEAN
+                     : (pol.forced == K1_ROUTE_COARSE && !coarse_supports(N, M)) ? K1_ROUTE_LEAN : pol.forced;
     if (routed) {
         K1ProbeArgs pa;
         pa.f[0] = f1, pa.f[1] = f2, pa.n[0] = n1, pa.n[1] = n2;
         pa.rows[0] = N, pa.rows[1] = M;
         pa.cutw = 20.f / -neg_alpha;
-        pa.p_second = pol.p_second, pa.p_lean = pol.p_lean;
-        pa.have_second = have2;
+        pa.p_coarse = pol.p_coarse, pa.p_second = pol.p_second, pa.p_lean = pol.p_lean;
+        pa.have_second = have2, pa.have_coarse = havec;
         pa.route = route, pa.frac = pfrac;
         hipLaunchKernelGGL(k1_probe_kernel, dim3(B, both ? 2 : 1), dim3(256), 0, s, pa);
         hipLaunchKernelGGL(k1_route_kernel, dim3(both ? 2 : 1), dim3(256), 0, s, pa, B);
         if (pol.debug) report_routes(route, pfrac, B * (both ? 2 : 1), s);
     }
-    if (routed ? have2 : fixed == K1_ROUTE_SECOND) {
+    if (routed ? (have2 || havec) : (fixed == K1_ROUTE_SECOND || fixed == K1_ROUTE_COARSE)) {
         launch_norm_frags(n2, B, M, Mp, amax, nf2, s);
         if (both) launch_norm_frags(n1, B, N, Np, amax, nf1, s);
     }
-    if (routed || fixed != K1_ROUTE_SECOND) {
+    if (routed || (fixed != K1_ROUTE_SECOND && fixed != K1_ROUTE_COARSE)) {
         hipLaunchKernelGGL(pad_norms_kernel, dim3((Mp + 255) / 256, B), dim3(256), 0, s, n2, M, Mp, n2p);
         if (both) hipLaunchKernelGGL(pad_norms_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, s, n1, N, Np, n1p);
     }
@@ -1339,13 +1196,16 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
     const int blocks = a.blocks0 + (both ? B * a.g[1].tiles : 0);
     a.route = routed ? route : nullptr;
     a.nb = B;
-    prof_note(DVM_PROF_K1_SWEEP, routed ? (have2 ? "routed: softcorr_sweep2_kernel | softcorr_sweep_f16_kernel<lean> | softcorr_sweep_f16_kernel<full>"
+    prof_note(DVM_PROF_K1_SWEEP, routed ? (havec ? "routed: softcorr_coarse_kernel | softcorr_sweep2_kernel | softcorr_sweep_f16_kernel<lean> | softcorr_sweep_f16_kernel<full>"
+                                           : have2 ? "routed: softcorr_sweep2_kernel | softcorr_sweep_f16_kernel<lean> | softcorr_sweep_f16_kernel<full>"
                                                  : "routed: softcorr_sweep_f16_kernel<lean> | softcorr_sweep_f16_kernel<full>")
+                                        : fixed == K1_ROUTE_COARSE ? "softcorr_coarse_kernel"
                                         : fixed == K1_ROUTE_SECOND ? "softcorr_sweep2_kernel"
                                         : fixed == K1_ROUTE_LEAN   ? "softcorr_sweep_f16_kernel<lean>"
                                                                    : "softcorr_sweep_f16_kernel<full>");
     prof_begin(s);
     // (routed: all three kernels are launched and a workgroup whose pair belongs to another one returns at once)
+    if (routed ? havec : fixed == K1_ROUTE_COARSE) launch_coarse(a, nf2, nf1, amax, blocks, s);
     if (routed ? have2 : fixed == K1_ROUTE_SECOND) launch_sweep2(a, nf2, nf1, amax, blocks, sweep_form(), s);
     if (routed || fixed == K1_ROUTE_LEAN) {
         ensure_dyn_lds((const void *)softcorr_sweep_f16_kernel<true>, (int)HB_LDS_BYTES);
@@ -1364,33 +1224,17 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
     r.rows0 = r1;
     r.rows_total = r1 + (both ? r2 : 0);
     r.neg_alpha = neg_alpha;
+    r.cutw = 20.f / -neg_alpha;
     r.topk = topk;
+    r.route = routed ? route : nullptr;
+    r.nb = B;
     prof_begin(s, DVM_PROF_K1_REFINE);
-    static const int rform = [] { const char *e = getenv("DVM_K1_REFINE"); return e ? atoi(e) : 14; }();   // (A/B measurements)
-    static const int refine_waves = [] {   // persistent form: 6 single-wave workgroups of 26 KiB LDS fit a CU
-        int dev = 0, cus = 256;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        return cus * 6;
-    }();
-    r.remap = rform >= 10;
-    if (rform == 1)
-        hipLaunchKernelGGL(softcorr_refine_kernel<1>, dim3((unsigned)refine_waves), dim3(64), 0, s, r);   // (a multiple of 8)
-    else if (rform % 10 == 4) {
-        static const int win = [] { const char *e = getenv("DVM_K1_REFINE_WIN"); return e ? atoi(e) : 3; }();
+    {
+        // (routed: both list lengths are launched and a wave whose direction went through the other kind of screen returns at once)
         const dim3 grid((unsigned)((hr_quads(r) * 64 + 255) / 256));
-        if (win == 1) hipLaunchKernelGGL((softcorr_refine_kernel<4, 1>), grid, dim3(256), 0, s, r);
-        else if (win == 2) hipLaunchKernelGGL((softcorr_refine_kernel<4, 2>), grid, dim3(256), 0, s, r);
-        else if (win == 3) hipLaunchKernelGGL((softcorr_refine_kernel<4, 3>), grid, dim3(256), 0, s, r);
-        else if (win == 8) hipLaunchKernelGGL((softcorr_refine_kernel<4, 8>), grid, dim3(256), 0, s, r);
-        else hipLaunchKernelGGL((softcorr_refine_kernel<4, 4>), grid, dim3(256), 0, s, r);
+        if (routed ? havec : fixed == K1_ROUTE_COARSE) hipLaunchKernelGGL((softcorr_refine_kernel<K1_KC_COARSE, true, 2>), grid, dim3(256), 0, s, r);
+        if (routed || fixed != K1_ROUTE_COARSE) hipLaunchKernelGGL((softcorr_refine_kernel<HB_KC, false, 3>), grid, dim3(256), 0, s, r);
     }
-    else if (rform % 10 == 3)
-        hipLaunchKernelGGL(softcorr_refine_kernel<3>, dim3((unsigned)((hr_quads(r) * 64 + 255) / 256)), dim3(256), 0, s, r);
-    else if (rform % 10 == 0)
-        hipLaunchKernelGGL(softcorr_refine_kernel<0>, dim3((unsigned)((hr_quads(r) * 64 + 255) / 256)), dim3(256), 0, s, r);
-    else
-        hipLaunchKernelGGL(softcorr_refine_kernel<2>, dim3((unsigned)((hr_quads(r) * 64 + 255) / 256)), dim3(256), 0, s, r);
     prof_end(s, DVM_PROF_K1_REFINE);
 
     HXArgs x;
@@ -1431,8 +1275,8 @@ int launch_argmin_f16(const float *f1, const float *f2, int B, int N, int M, int
     float *cd2[2] = {nullptr, nullptr}, *lsum[2] = {nullptr, nullptr};
     for (int d = 0; d < (both ? 2 : 1); ++d) {
         const size_t R = (size_t)B * (d == 0 ? N : M);
-        cidx[d] = ar.take<int32_t>(R * HB_KC);
-        cd2[d] = ar.take<float>(R * HB_KC);
+        cidx[d] = ar.take<int32_t>(R * K1_KC_COARSE);
+        cd2[d] = ar.take<float>(R * K1_KC_COARSE);
         lsum[d] = ar.take<float>(R * 2);
         flag[d] = ar.take<int32_t>(R + 1);
     }
