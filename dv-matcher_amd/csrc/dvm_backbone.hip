@@ -1196,18 +1196,8 @@ int launch_knn_neg(const float *a, const float *bq, int B, int N, int M, int C, 
 
 using namespace dvm;
 
-namespace dvm {   // dvm_knn_f16.hip: the self-kNN of the N2P blocks without the N x N score matrix
-bool knn_f16_applies(int B, int N, int M, int C, int k, bool self);
-size_t knn_f16_ws_bytes(int B, int N);
-int launch_knn_f16(const float *x, int B, int N, int C, int k, int32_t *idx, void *ws, size_t ws_bytes, hipStream_t s);
-}  // namespace dvm
-
 DVM_EXPORT size_t dvm_knn_neg_workspace_bytes(int B, int N, int M, int C, int k) {
-    // (the caller does not say whether a == b: sized for either path)
-    const size_t dense = align_up((size_t)B * N * sizeof(float)) + align_up((size_t)B * M * sizeof(float)) +
-                         align_up((size_t)B * N * M * sizeof(float));
-    const size_t f16 = knn_f16_applies(B, N, M, C, k, true) ? knn_f16_ws_bytes(B, N) : 0;
-    return dense > f16 ? dense : f16;
+    return align_up((size_t)B * N * sizeof(float)) + align_up((size_t)B * M * sizeof(float)) + align_up((size_t)B * N * M * sizeof(float));
 }
 
 DVM_EXPORT int dvm_knn_neg_f32(const float *a, const float *b, int B, int N, int M, int C, int k, int32_t *idx, void *ws,
@@ -1216,12 +1206,6 @@ DVM_EXPORT int dvm_knn_neg_f32(const float *a, const float *b, int B, int N, int
     DVM_REQUIRE(B >= 1 && N >= 1 && M >= 1 && C >= 1, "dvm_knn_neg_f32: empty input (B=%d N=%d M=%d C=%d)", B, N, M, C);
     DVM_REQUIRE(k >= 1 && k <= 512 && k <= M, "dvm_knn_neg_f32: k=%d unsupported (1..min(512,M=%d))", k, M);
     DVM_REQUIRE(M <= 8192, "dvm_knn_neg_f32: M=%d exceeds 8192", M);
-    if (knn_f16_applies(B, N, M, C, k, a == b)) {
-        const int rc = launch_knn_f16(a, B, N, C, k, idx, ws, ws_bytes, (hipStream_t)stream);
-        if (rc != DVM_OK) return rc;
-        DVM_CHECK_LAUNCH("knn_neg (fp16 path)");
-        return DVM_OK;
-    }
     Arena ar(ws, ws_bytes);
     float *na = ar.take<float>((size_t)B * N);
     float *nb = ar.take<float>((size_t)B * M);

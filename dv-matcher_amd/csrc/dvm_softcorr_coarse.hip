@@ -13,7 +13,8 @@
 // row, both the top-10 and that no column outside the list can lie within the cut, and sends a row that fails either test
 // through the exact-rows kernel.  Integer outputs stay bit-exact by construction.
 //
-// Structure: the second form's (dvm_softcorr_sweep2.hip), with what the single plane allows:
+// Structure (the tile staging, the norm instruction, the exact keys and the selection network come from the three-product
+// "second form" of rounds 3 - 4, which this kernel replaced: profiles/notes_k1.md):
 //  * a wave owns QB = 2 blocks of 32 query rows (64 VGPRs of query fragments, as the two-plane form needs for one block): every
 //    key fragment read from LDS feeds two matrix instructions, and a workgroup of 8 waves covers 512 query rows, so a pair's key
 //    plane is staged 4 times instead of 8;
@@ -21,7 +22,7 @@
 //    with the row number: a 256-byte row is one full bank row, the swizzle spreads the 16 rows of a ds_read_b128 lane group over
 //    the 16 chunk positions;
 //  * norms on the matrix pipe (a 9th instruction per block), exact 32-bit keys (accumulator bits + register number), the fixed
-//    selection network for the sorted three smallest of a lane's 16 keys — all as in the second form;
+//    selection network for the sorted three smallest of a lane's 16 keys;
 //  * 32-bit list entries [key: 19 bits | sub-tile: 8 | half: 1 | register: 4]: a sorted insertion is ONE v_med3_u32 per slot
 //    (the packed doubles of the other forms take a v_min_f64 + v_max_f64 pair, at half rate).  19 key bits = 5 exponent bits +
 //    14 of the mantissa, rounded DOWN: 2^-14 of the accumulator, part of HC_ERR.  Lists of 12 per half-lane; the two smallest of
@@ -84,6 +85,24 @@ __device__ __forceinline__ void norm_pieces(float x, _Float16 &p1, _Float16 &p2,
 // |x|^2 in accumulator units: n s^2 / 2, formed as (n s) (s / 2) so that no intermediate leaves the fp32 range
 __device__ __forceinline__ float norm_scaled(float n, int se) { return (n * pow2i(se)) * pow2i(se - 1); }
 
+// key-side norm fragments, padded to whole key tiles (padding keys: zero norm; their entries are masked by column in the
+// sweep): out [B][Mpad][16 fp16] = {a1, a2, a3, 2^15, 2^4, 2^-7, 0, 0 | 0 x 8} — the A operand of the norm instruction
+__global__ void norm_frags_kernel(const float *__restrict__ nrm, int M, int Mpad, const int *__restrict__ amax, char *__restrict__ out) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Mpad) return;
+    f16x8 lo = {0, 0, 0, (_Float16)0x1p+15f, (_Float16)0x1p+4f, (_Float16)0x1p-7f, 0, 0};
+    const f16x8 hi = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (i < M) {
+        _Float16 p1, p2, p3;
+        norm_pieces(norm_scaled(nrm[(size_t)b * M + i], scale_exp(*amax)), p1, p2, p3);
+        lo[0] = p1, lo[1] = p2, lo[2] = p3;
+    }
+    char *p = out + ((size_t)b * Mpad + i) * 32;
+    *(f16x8 *)p = lo;
+    *(f16x8 *)(p + 16) = hi;
+}
+
 // sorted (s0 <= s1 <= s2) three smallest of 16 distinct keys: 46 three-input unsigned min / med / max instructions
 struct Top3 {
     unsigned s0, s1, s2;
@@ -129,7 +148,7 @@ __device__ __forceinline__ int entry_col(unsigned e) {
 // STAMP: diagnostic build — every wave adds up the shader cycles (s_memtime) it spends per phase; no output depends on them.
 // Phases: 0 LDS-DMA issue, 1 matrix chain (until the accumulators are readable), 2 epilogue, 3 re-done sub-tiles, 5 barrier
 // (incl. the wait for the wave's own DMA pieces), 6 whole kernel, 7 sub-tiles (re-done records counted in the high bits).
-template <int QB, bool STAMP = false>
+template <int QB, bool STAMP = false, bool PACE = true>
 __global__ __launch_bounds__(64 * HC_WAVES, 1) void softcorr_coarse_kernel(const HCArgs args) {
     constexpr int NREC = hc_nrec<QB>(), ROWS = 32 * QB * HC_WAVES;
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
@@ -181,7 +200,7 @@ __global__ __launch_bounds__(64 * HC_WAVES, 1) void softcorr_coarse_kernel(const
         // the query's norm, biased by 2^-8 of itself plus the floor, so that the accumulator stays >= 4 whatever the rounding: in
         // accumulator units the one-plane product is off by at most e |q||k| s^2, e = 2^-10, and with x = |k| / |q| the exact part
         // ((x - 1)^2 + bias) |q|^2 s^2 / 2 exceeds it for every x once bias >= 2 e + e^2; the rest of 2^-8 covers the fp32
-        // accumulation (2^-16 |q||k| s^2).  (The three-product forms need 2^-13.)
+        // accumulation (2^-16 |q||k| s^2).
         const float nas = norm_scaled(G.nq[(size_t)b * N + qrc], se);
         const float nasb = (nas + nas * 0x1p-8f) + HC_FLOOR;
         rowc[qb] = nasb - nas;
@@ -208,7 +227,7 @@ __global__ __launch_bounds__(64 * HC_WAVES, 1) void softcorr_coarse_kernel(const
     // Key tiles go global -> LDS by LDS-DMA, 1 KiB = 4 rows of 256 B per wave instruction, 2 per wave and tile.  Lane L of
     // piece p delivers position L & 15 of LDS row 4 p + (L >> 4), which holds chunk (L & 15) ^ (row & 15) of the key.  The
     // per-lane offsets are re-formed for every tile from the lane number (v_mbcnt): anything kept in a vector register across
-    // the tile for this is spilled (see the second form).
+    // the tile for this is spilled, and a scratch reload next to the DMA issue waits, through vmcnt, for every piece in flight.
     auto stage_tile = [&](int t, int buf, bool clamp) __attribute__((always_inline)) {
         int lane;   // (a volatile statement: otherwise the offsets are hoisted out of the loop as invariants — and spilled)
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
@@ -229,7 +248,8 @@ __global__ __launch_bounds__(64 * HC_WAVES, 1) void softcorr_coarse_kernel(const
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(nfbase + (size_t)j0 * 32 + (wave & 1) * 1024 + lane * 16),
                                          (__attribute__((address_space(3))) void *)(wave < 2 ? knf0 + buf * HC_KT * 32 + wave * 1024 : dump0), 16, 0, 0);
     };
-    // every wave first waits for ITS OWN pieces (vmcnt), then joins the barrier (see the second form)
+    // every wave first waits for ITS OWN pieces (vmcnt), then joins the barrier: the compiler places its own vmcnt wait only in
+    // front of the wave's next LDS read, which orders nothing for the rows the OTHER waves were to deliver
     auto dma_barrier = [&]() __attribute__((always_inline)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -277,13 +297,13 @@ __global__ __launch_bounds__(64 * HC_WAVES, 1) void softcorr_coarse_kernel(const
         reads(0);
         reads(1);
         const f16x8 an = lds16(nadr, buf * (HC_KT * 32) + sub * (32 * 32));
-        __builtin_amdgcn_sched_barrier(0x00E);   // (vector, scalar and matrix instructions may cross, LDS reads not)
+        if (!PACE) __builtin_amdgcn_sched_barrier(0x00E);   // (vector, scalar and matrix instructions may cross, LDS reads not)
         products(0);
         reads(2);
-        __builtin_amdgcn_sched_barrier(0x00E);
+        if (!PACE) __builtin_amdgcn_sched_barrier(0x00E);
         products(1);
         reads(3);
-        __builtin_amdgcn_sched_barrier(0x00E);
+        if (!PACE) __builtin_amdgcn_sched_barrier(0x00E);
         products(2);
         products(3);
         // the norms last: every partial sum before it has the magnitude of q.k
@@ -318,6 +338,24 @@ __global__ __launch_bounds__(64 * HC_WAVES, 1) void softcorr_coarse_kernel(const
         }
     };
 
+    // PACE: the scheduling region that ends here holds the matrix chain of the NEXT sub-tile (9 QB instructions, 9 LDS reads) and
+    // this sub-tile's selection + insertions (~105 QB vector instructions).  A wave issues in order: a run of matrix instructions
+    // parks it at the matrix pipe (32 cycles each) while its vector instructions wait, and the two waves of a SIMD, released by
+    // the same barrier, then do the same thing at the same time.  Ask for one matrix instruction per VPM vector instructions, the
+    // first five fragment reads up front and the other two pairs behind the 2 QB-th and the 4 QB-th matrix instruction.
+    auto pace = [&]() __attribute__((always_inline)) {
+        if (PACE) {
+            constexpr int NM = 9 * QB, VPM = 11;
+            __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i == 2 * QB - 1 || i == 4 * QB - 1) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+            }
+        }
+    };
     const bool ragged = (M & (HC_KT - 1)) != 0;   // the last tile holds padding keys
     auto stage = [&](int t, int buf) __attribute__((always_inline)) {
         if (t < ntiles) {
@@ -334,14 +372,14 @@ __global__ __launch_bounds__(64 * HC_WAVES, 1) void softcorr_coarse_kernel(const
             stamp(0);
             const Acc a1 = chain(buf, 1);
             stamp_after(1, __float_as_int(a1.a[QB - 1][0]));
-            if (last && ragged) epilogue(a0, 2 * t, true); else epilogue(a0, 2 * t, false);
+            if (last && ragged) epilogue(a0, 2 * t, true); else { epilogue(a0, 2 * t, false); pace(); }
             dma_barrier();
             stamp(5);
             if (!last) {
                 a0 = chain(buf ^ 1, 0);
                 stamp_after(1, __float_as_int(a0.a[QB - 1][0]));
             }
-            if (last && ragged) epilogue(a1, 2 * t + 1, true); else epilogue(a1, 2 * t + 1, false);
+            if (last && ragged) epilogue(a1, 2 * t + 1, true); else { epilogue(a1, 2 * t + 1, false); if (!last) pace(); }
             T[7] += 2;
         };
         // (the last tile is peeled off so that inside the loop the next chain is unconditional)
@@ -444,13 +482,23 @@ __global__ __launch_bounds__(64 * HC_WAVES, 1) void softcorr_coarse_kernel(const
 template <int QB, bool STAMP>
 static void launch_form(const HCArgs &a, int blocks, hipStream_t s) {
     const int lds = hc_lds_bytes<QB>();
-    ensure_dyn_lds((const void *)softcorr_coarse_kernel<QB, STAMP>, lds);
-    hipLaunchKernelGGL((softcorr_coarse_kernel<QB, STAMP>), dim3(blocks), dim3(64 * HC_WAVES), lds, s, a);
+    static const bool pace = [] { const char *e = getenv("DVM_K1_COARSE_PACE"); return !(e && atoi(e) == 0); }();   // (A/B measurements)
+    if (pace) {
+        ensure_dyn_lds((const void *)softcorr_coarse_kernel<QB, STAMP, true>, lds);
+        hipLaunchKernelGGL((softcorr_coarse_kernel<QB, STAMP, true>), dim3(blocks), dim3(64 * HC_WAVES), lds, s, a);
+    } else {
+        ensure_dyn_lds((const void *)softcorr_coarse_kernel<QB, STAMP, false>, lds);
+        hipLaunchKernelGGL((softcorr_coarse_kernel<QB, STAMP, false>), dim3(blocks), dim3(64 * HC_WAVES), lds, s, a);
+    }
 }
 
 }  // namespace
 
 bool coarse_supports(int N, int M) { return M <= HC_MAX_M && N <= HC_MAX_M; }
+
+void launch_norm_frags(const float *nrm, int B, int M, int Mpad, const int *amax, char *out, hipStream_t s) {
+    hipLaunchKernelGGL(norm_frags_kernel, dim3((Mpad + 255) / 256, B), dim3(256), 0, s, nrm, M, Mpad, amax, out);
+}
 
 // pass A for the groups in `a`, coarse screen; knf = key-side norm fragments of either group (launch_norm_frags).  `a` is laid
 // out for the 256-row workgroups of the other forms; this form re-derives its own tiling.

@@ -1,5 +1,5 @@
 // dvm_softcorr_f16.h — what the two translation units of the fp16-split soft-correspondence sweep share
-// (dvm_softcorr_f16.hip: splitting, first form of pass A, pass B, launchers; dvm_softcorr_sweep2.hip: second form of pass A).
+// (dvm_softcorr_f16.hip: splitting, first form of pass A, pass B, launchers; dvm_softcorr_coarse.hip: the one-plane screen).
 #pragma once
 #include "dvm_common.h"
 
@@ -21,8 +21,7 @@ constexpr int HB_STAGE = 16 * 64;       // floats per wave
 constexpr int HB_KC = 12;               // candidates kept per row (top-10 + 2 of margin)
 constexpr size_t HB_LDS_BYTES = (size_t)2 * HB_KT * HB_ROWB + 2 * HB_KT * sizeof(float) + (size_t)HB_WAVES * HB_STAGE * sizeof(float);
 constexpr float HB_ERR = 2.5e-5f;  // |d2_passA - d2_chain| <= HB_ERR (|q|^2 + |k|^2): gamma_128 of both fp32 accumulations
-                                   // (2 x 7.7e-6) + the dropped split terms (1.4e-6) + the second form's 4 key bits that
-                                   // carry the register number (2^-19 of d2 <= 2 (|q|^2 + |k|^2): 3.8e-6), see DESIGN.md
+                                   // (2 x 7.7e-6) + the dropped split terms (1.4e-6), with room to spare
 
 
 // power of two s with max|x| * s in [2^11, 2^12): well inside fp16's range, the m-plane of every element within 2^-8 of
@@ -42,12 +41,6 @@ __device__ __forceinline__ float pow2i(int k) { return __int_as_float((127 + k) 
 // v_min_f64 + v_max_f64 (instead of a compare and four selects) and ties break on the column for free.
 // Keys are squared distances: >= 0 up to rounding (a slightly negative key only reverses its own tie order).
 // (plain v_min_f64 / v_max_f64: the C fmin/fmax add a canonicalising v_max_f64 x, x per operand; no NaNs here)
-#ifdef DVM_K1_BUILTIN_MINMAX
-// (dvm_softcorr_sweep2.hip is built with -fno-honor-nans: fmin / fmax lower to the bare instructions there, and — unlike an
-// asm statement — stay visible to the instruction scheduler as vector instructions)
-__device__ __forceinline__ double min64(double a, double b) { return __builtin_fmin(a, b); }
-__device__ __forceinline__ double max64(double a, double b) { return __builtin_fmax(a, b); }
-#else
 __device__ __forceinline__ double min64(double a, double b) {
     double r;
     asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -58,7 +51,6 @@ __device__ __forceinline__ double max64(double a, double b) {
     asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-#endif
 
 template <int K>
 struct PackedBest {
@@ -94,10 +86,6 @@ struct HBGroup {
     int32_t *cidx;           // [B][N][HB_KC]
     float *cd2;              // [B][N][HB_KC] approximate squared distances, ascending
     float *lsum;             // [B][N][2] = (sum exp(s - cref), cref)
-    // second form only — key slices (the feature kNN, dvm_knn_f16.hip): the M keys of a batch entry are cut into `kslices`
-    // slices of Ms keys (Ms a multiple of the key tile; the last one may be shorter), each swept as its own launch entry with
-    // its own candidate lists: outputs [B][kslices][N][...], columns relative to the slice
-    int kslices = 1, Ms = 0;
 };
 struct HBArgs {
     HBGroup g[2];
@@ -109,7 +97,6 @@ struct HBArgs {
 // Which pass-A kernel sweeps a (direction, pair): set per launch by k1_probe_kernel from the pair's own distance statistics
 constexpr int K1_ROUTE_FULL = 0;     // first form, every softmax term (flat rows: nearly every column lies within the cut)
 constexpr int K1_ROUTE_LEAN = 1;     // first form, lean
-constexpr int K1_ROUTE_SECOND = 2;   // second form (lean)
 constexpr int K1_ROUTE_COARSE = 3;   // coarse screen (one fp16 plane; dvm_softcorr_coarse.hip): no softmax term outside the certified list
 
 // ---------------------------------------------------------------- coarse screen (dvm_softcorr_coarse.hip)
@@ -125,9 +112,8 @@ bool coarse_supports(int N, int M);
 void launch_coarse(const HBArgs &a, const char *knf0, const char *knf1, const int *amaxc, int blocks, hipStream_t s);
 
 
-// second form of pass A (dvm_softcorr_sweep2.hip); form = sweep_form() of the caller: 1 plain, 2 pipelined, 3 pipelined + paced
+// key-side norm fragments of the coarse screen [B][Mpad][32 B] (dvm_softcorr_coarse.hip)
 void launch_norm_frags(const float *nrm, int B, int M, int Mpad, const int *amax, char *out, hipStream_t s);
-void launch_sweep2(const HBArgs &a, const char *knf0, const char *knf1, const int *amaxc, int blocks, int form, hipStream_t s);
 
 }  // namespace k1
 }  // namespace dvm

@@ -436,24 +436,25 @@ __global__ void common_absmax_kernel(const int *__restrict__ in, int *__restrict
 
 // ---------------------------------------------------------------- routing probe
 // Which pass-A kernel suits a (direction, pair) depends on how many columns of a row lie within the softmax cut
-// (d <= d_min + 20 / alpha): a handful on wide-spread features at large alpha (the second form: nothing per entry, sub-tiles
-// with a third candidate re-done at the end), a few dozen (first form, lean: per-entry loop, terms only for what leaves a
-// list), or most of the row (flat rows, small alpha x small spread: the lean bookkeeping only costs — first form, every term).
-// The alpha >= 32 rule alone got this wrong on clustered features (profiles/r3_bench_alpha.txt: 12.7 ms lean vs 10.4 ms full
-// per 256 pairs at alpha 33 on the "trained-like" set; the second form 16.0 ms there), so each pair is measured: K1P_ROWS query
-// rows x K1P_COLS key columns (evenly spaced) of exact fp32 distances per (direction, pair) — 1024 distances per group: the
-// decision is taken on the mean over the launch's groups, so the sample per group can be small.  A row's minimum over ALL columns
-// is estimated as min(sample minimum, mean - z(M) sigma), z(M) the normal quantile of 1/M; p = fraction of the sampled
-// distances within the cut of that minimum, averaged over the rows, then over the pairs of the launch (k1_route_kernel).
-// Thresholds from profiles/r3_route_calib.txt: the second form wins up to a mean fraction of 0.4 % (measured points: 0.06 - 0.40 %),
-// the lean first form at 1.2 %, the full first form from 4 % on.
+// (d <= d_min + 20 / alpha): a handful on wide-spread features at large alpha (the coarse screen: one fp16 plane, lists of 16,
+// no softmax term owed outside the list — pass B certifies that per row), a few dozen (first form, lean: per-entry loop, terms
+// only for what leaves a list), or most of the row (flat rows, small alpha x small spread: the lean bookkeeping only costs —
+// first form, every term).  An alpha rule alone got this wrong on clustered features (profiles/r3_bench_alpha.txt), so each pair
+// is measured: K1P_ROWS query rows x K1P_COLS key columns (evenly spaced) of exact fp32 distances per (direction, pair) — 1024
+// distances per group: the decision is taken on the mean over the launch's groups, so the sample per group can be small.  A
+// row's minimum over ALL columns is estimated as min(sample minimum, mean - z(M) sigma), z(M) the normal quantile of 1 / M;
+// p = fraction of the sampled distances within the cut of that minimum, averaged over the rows, then over the pairs of the
+// launch (k1_route_kernel).  Thresholds: the coarse screen up to a mean fraction of 0.14 % (3 of 2048 columns within the cut:
+// measured on random features it beats the lean first form up to 0.11 % and loses from 0.16 % on, where 2 % of the rows have
+// more columns within the cut than its list of 16 can certify; profiles/notes_k1.md), the lean first form up to 2 %, the full
+// first form beyond.  k1_gate_kernel catches what the probe gets wrong.
 constexpr int K1P_ROWS = 4, K1P_COLS = 256;   // (8 x 256 with a wave per row pair measured 122 us per launch of 1024 groups: every wave
                                               // streamed the sampled key rows again, and that per-lane row streaming is L1-bound)
 struct K1ProbeArgs {
     const float *f[2], *n[2];   // features [B][rows][128] and squared norms of side 0 / 1
     int rows[2];
-    float cutw, p_coarse, p_second, p_lean;
-    int have_second, have_coarse;
+    float cutw, p_coarse, p_lean;
+    int have_coarse;
     int *route;                 // [dirs][B]
     float *frac;                // [dirs][B]
 };
@@ -536,9 +537,7 @@ __global__ __launch_bounds__(256) void k1_route_kernel(const K1ProbeArgs a, int 
     if ((tid & 63) == 0) part[tid >> 6] = sum;
     __syncthreads();
     const float p = (part[0] + part[1] + part[2] + part[3]) / B;
-    int route = p <= a.p_second ? K1_ROUTE_SECOND : p <= a.p_lean ? K1_ROUTE_LEAN : K1_ROUTE_FULL;
-    if (a.have_coarse && p <= a.p_coarse) route = K1_ROUTE_COARSE;
-    if (route == K1_ROUTE_SECOND && !a.have_second) route = K1_ROUTE_LEAN;
+    const int route = (a.have_coarse && p <= a.p_coarse) ? K1_ROUTE_COARSE : p <= a.p_lean ? K1_ROUTE_LEAN : K1_ROUTE_FULL;
     for (int i = tid; i < B; i += 256) a.route[dir * B + i] = route;
 }
 
@@ -615,7 +614,8 @@ static inline long hr_quads(const HRArgs &r) { return (r.rows0 + 3) / 4 + (r.row
 // COARSE: the list comes from the one-plane screen — error band HC_ERR instead of HB_ERR, pass A's partial sum is empty: every
 // entry that can rank among the first `need` OR lie within the softmax cut is evaluated exactly, the others owe no term, and the
 // row is certified only if no column outside the evaluated ones can do either.
-template <int KC, bool COARSE, int HR4W>
+// GATED: the second pass behind k1_gate_kernel — only the directions it sent back to the first form (route == K1_ROUTE_LEAN).
+template <int KC, bool COARSE, int HR4W, bool GATED = false>
 __global__ __launch_bounds__(256) void softcorr_refine_kernel(const HRArgs args) {
     constexpr int SLOTS = 4 * KC, NL = SLOTS / 16;     // candidate rows of a wave; loads per lane and 64-byte piece
     __shared__ __attribute__((aligned(16))) char hr_lds[4 * 2 * SLOTS * 64];
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(256) void softcorr_refine_kernel(const HRArgs args)
         const int qd = __builtin_amdgcn_readfirstlane((int)quad);
         p.grp = qd >= nq0 ? 1 : 0;
         // (one route per direction of a launch: k1_route_kernel)
-        if (args.route && (args.route[p.grp * args.nb] == K1_ROUTE_COARSE) != COARSE) return;
+        if (GATED ? args.route[p.grp * args.nb] != K1_ROUTE_LEAN : (args.route && (args.route[p.grp * args.nb] == K1_ROUTE_COARSE) != COARSE)) return;
         const long rows = p.grp ? args.rows_total - args.rows0 : args.rows0;
         p.row = (long)(qd - (p.grp ? (int)nq0 : 0)) * 4 + (lane >> 4);
         p.rvalid = p.row < rows;
@@ -789,6 +789,29 @@ __global__ __launch_bounds__(256) void softcorr_refine_kernel(const HRArgs args)
     }
 }
 
+// The coarse screen serves a direction well only while few of its rows fail pass B's certification: a flagged row costs the
+// exact-rows kernel a whole key side (1 MB at M = 2048, ~0.3 us), a row of the lean first form ~3 ns.  The probe keeps most
+// unsuitable launches away from it, but it sees 4 rows x 256 columns per pair, not the spacing of a row's 16 best.  So behind
+// the coarse pass a direction with more than 1 / 128 of its rows flagged is sent through the lean first form after all: this
+// kernel writes the second pass's routes (K1_ROUTE_LEAN for such a direction — its flag list emptied — and -1 for every other),
+// and the lean sweep + pass B launched behind it return at once unless their direction is marked.  Nothing is read back.
+struct K1GateArgs {
+    const int *route;         // first-pass routes [dirs][B], or nullptr = every direction took the coarse screen
+    int *route2;              // [dirs][B]
+    int32_t *nflagged[2];
+    long rows[2];
+    int dirs, nb;
+};
+__global__ void k1_gate_kernel(const K1GateArgs a) {
+    for (int d = 0; d < a.dirs; ++d) {
+        const bool coarse = !a.route || a.route[d * a.nb] == K1_ROUTE_COARSE;
+        const bool again = coarse && *a.nflagged[d] > (a.rows[d] >> 7);
+        __syncthreads();
+        if (again && threadIdx.x == 0) *a.nflagged[d] = 0;
+        for (int b = threadIdx.x; b < a.nb; b += blockDim.x) a.route2[d * a.nb + b] = again ? K1_ROUTE_LEAN : -1;
+    }
+}
+
 // ---------------------------------------------------------------- exact recompute of the uncertified rows
 // One workgroup per flagged row: every lane sweeps its share of the keys with the exact arithmetic, keeps its own
 // top-10 (ascending j, so ties keep the lower column) and online softmax; each wave's 64 lists are merged by
@@ -918,11 +941,13 @@ __global__ __launch_bounds__(256) void softcorr_exact_rows_kernel(const HXArgs a
 // T[i] = argmin_j sqrt(sum_c (q_c - k_c)^2) in the reference's exact-difference form (models/loss.py:91-95,
 // test.py:19-23): sequential sub / mul / add over the feature index, ties -> lowest j.  That form cannot run on the
 // matrix cores, but it only has to be evaluated for the columns that can still be the minimum: pass A's candidate
-// list holds the 12 smallest mm-form distances up to HB_ERR (na + nk); the exact-difference value differs from the
-// real distance by at most (d + 1) ulp-relative.  A column is examined when its approximate squared distance is within
-// 2 AM_ERR (na + nkmax) of the row's smallest; a row whose 12 candidates ALL fall inside that band (duplicate points)
-// is re-done by a full exact scan.
-constexpr float AM_ERR = HB_ERR + 2e-5f;
+// list holds the smallest mm-form distances up to its error bound E (na + nk) (coarse screen: 16 entries, HC_ERR; first form:
+// 12, HB_ERR); the exact-difference value differs from the real distance by at most (d + 1) ulp-relative.  A column is
+// examined when its approximate squared distance is within 2 (E + AM_DIFF) (na + nkmax) of the row's smallest; a row whose
+// band reaches past its list (duplicate points, tight clusters) is re-done by a full exact scan.  The coarse screen's band is
+// 40 x the first form's: if it sends more than 1 / 16 of a direction's rows to the full scan, that direction is swept again by
+// the first form (argmin_gate_kernel: the extra launches are gated on the device, nothing is read back).
+constexpr float AM_DIFF = 2e-5f;   // the exact-difference form against the real distance, relative to the norms
 
 __device__ __forceinline__ float diff_d2(const float *__restrict__ q, const float *__restrict__ k) {
     float acc = 0.f;
@@ -951,37 +976,58 @@ struct AMGroup {
 struct AMArgs {
     AMGroup g[2];
     long rows0, rows_total;
+    const int *route;   // per (group, batch entry): K1_ROUTE_LEAN = this direction was swept again by the first form; nullptr: no gate
+    int nb;
 };
 
+// KC / ERR: list length and error bound of the screen that made the lists.  GATED: the second pass (first-form lists) — only
+// the directions the gate sent back.
+template <int KC, bool COARSE, bool GATED>
 __global__ __launch_bounds__(256) void argmin_refine_kernel(const AMArgs args) {
     long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= args.rows_total) return;
     const int grp = row >= args.rows0 ? 1 : 0;
     row -= grp ? args.rows0 : 0;
+    if (GATED && args.route[grp * args.nb] != K1_ROUTE_LEAN) return;
     const AMGroup &G = args.g[grp];
     const int b = (int)(row / G.N);
     const float *q = G.q + (size_t)row * HB_D;
-    const float band = 2.f * AM_ERR * (G.nq[row] + G.nkmax[b]);
-    const float v0 = G.cd2[row * HB_KC];
+    const float band = 2.f * ((COARSE ? HC_ERR : HB_ERR) + AM_DIFF) * (G.nq[row] + G.nkmax[b]);
+    const float v0 = G.cd2[row * KC];
     float best = INFINITY;
     int bj = 0x7fffffff;
-    bool open = true;  // does the band reach past the list?
-    for (int t = 0; t < HB_KC; ++t) {
-        const float v = G.cd2[row * HB_KC + t];
-        const int j = G.cidx[row * HB_KC + t];
-        if (!(v <= v0 + band) || j < 0 || j >= G.M) {
+    // does the band reach past the list?  It does not once a listed column lies beyond it: every column outside the list is
+    // at or above the list's last valid entry.  (A list may hold fewer than KC valid entries: the coarse screen drops what
+    // lies above its completeness bound.)
+    bool open = true;
+    for (int t = 0; t < KC; ++t) {
+        const float v = G.cd2[row * KC + t];
+        const int j = G.cidx[row * KC + t];
+        if (j < 0 || j >= G.M) break;
+        if (!(v <= v0 + band)) {
             open = false;
             break;
         }
         const float dv = sqrt_rn(diff_d2(q, G.k + ((size_t)b * G.M + j) * HB_D));
         if (dv < best || (dv == best && j < bj)) best = dv, bj = j;
     }
-    if (open && G.M > HB_KC) {
+    if (open && G.M > KC) {
         G.flagged[atomicAdd(G.nflagged, 1)] = (int32_t)row;
         return;
     }
     G.T[row] = bj;
     if (G.dmin) G.dmin[row] = best;
+}
+
+// after the coarse pass: a direction with more than 1 / 16 of its rows flagged goes through the first form again (its flag list is
+// emptied; the gated launches behind this kernel return at once for the other direction)
+__global__ void argmin_gate_kernel(const AMArgs args, int dirs, int *route) {
+    const int d = threadIdx.x;
+    if (d >= dirs) return;
+    const long rows = d ? args.rows_total - args.rows0 : args.rows0;
+    const bool again = *args.g[d].nflagged > (rows >> 4);
+    if (again) *args.g[d].nflagged = 0;
+    for (int b = 0; b < args.nb; ++b) route[d * args.nb + b] = again ? K1_ROUTE_LEAN : K1_ROUTE_COARSE;
 }
 
 // full exact scan of the flagged rows, one workgroup per row
@@ -1024,31 +1070,18 @@ __global__ __launch_bounds__(256) void argmin_exact_rows_kernel(const AMArgs arg
 
 }  // namespace
 
-// which form of pass A runs when the lean sweep applies (alpha >= 32, and the hard-map screening): 0 = first form (per-entry
-// test + insertion loop), 1 = second form, 2 = second form with the next sub-tile's matrix chain issued ahead of the
-// epilogue, 3 = the same with the scheduler asked for one matrix instruction per five vector instructions.  env DVM_K1_SWEEP
-// overrides (A/B measurements).
-static int sweep_form() {
-    static const int form = [] {
-        const char *e = getenv("DVM_K1_SWEEP");
-        return e ? atoi(e) : 2;
-    }();
-    return form;
-}
-
-// routing thresholds of the probe (fractions of a row within the cut), env DVM_K1_ROUTE_P="p_second,p_lean"; DVM_K1_ROUTE
-// forces one route, DVM_K1_ROUTE_DEBUG prints the routes of every launch (synchronous)
+// routing thresholds of the probe (fractions of a row within the cut), env DVM_K1_ROUTE_P="p_coarse,p_lean"; DVM_K1_ROUTE
+// forces one route (K1_ROUTE_*: 0 full, 1 lean, 3 coarse), DVM_K1_ROUTE_DEBUG prints the routes of every launch (synchronous)
 struct RoutePolicy {
     int forced;
-    float p_coarse, p_second, p_lean;
-    bool debug, coarse;
+    float p_coarse, p_lean;
+    bool debug;
 };
 static const RoutePolicy &route_policy() {
     static const RoutePolicy pol = [] {
-        RoutePolicy r{-1, 0.004f, 0.006f, 0.02f, getenv("DVM_K1_ROUTE_DEBUG") != nullptr, true};
+        RoutePolicy r{-1, 0.0014f, 0.02f, getenv("DVM_K1_ROUTE_DEBUG") != nullptr};
         if (const char *e = getenv("DVM_K1_ROUTE")) r.forced = atoi(e);
-        if (const char *e = getenv("DVM_K1_ROUTE_P")) (void)sscanf(e, "%f,%f,%f", &r.p_second, &r.p_lean, &r.p_coarse);
-        if (const char *e = getenv("DVM_K1_COARSE")) r.coarse = atoi(e) != 0;
+        if (const char *e = getenv("DVM_K1_ROUTE_P")) (void)sscanf(e, "%f,%f", &r.p_coarse, &r.p_lean);
         return r;
     }();
     return pol;
@@ -1067,8 +1100,8 @@ static void report_routes(const int *route, const float *frac, int n, hipStream_
         pmin = p[i] < pmin ? p[i] : pmin;
         pmax = p[i] > pmax ? p[i] : pmax;
     }
-    fprintf(stderr, "K1 routes: %d full, %d lean, %d second form, %d coarse; fraction within the cut: mean %.4f%% (min %.4f%%, max %.4f%%)\n",
-            cnt[0], cnt[1], cnt[2], cnt[3], 100 * ps / n, 100 * pmin, 100 * pmax);
+    fprintf(stderr, "K1 routes: %d full, %d lean, %d coarse; fraction within the cut: mean %.4f%% (min %.4f%%, max %.4f%%)\n", cnt[0], cnt[1],
+            cnt[3], 100 * ps / n, 100 * pmin, 100 * pmax);
 }
 
 // workspace of the fp16 path for (B, N, M): planes of both sides, candidates of both directions, flags
@@ -1077,7 +1110,7 @@ size_t softcorr_f16_ws_bytes(int B, int N, int M, bool both) {
     size_t n = align_up((size_t)B * N * HB_ROWB) + align_up((size_t)B * M * HB_ROWB) + 2 * align_up((size_t)B * sizeof(float)) +
                2 * align_up(2 * sizeof(int)) + align_up(B * Np * sizeof(float)) + align_up(B * Mp * sizeof(float)) +
                align_up(B * Np * 32) + align_up(B * Mp * 32) +   // (norm fragments of the second sweep form)
-               align_up(2 * (size_t)B * sizeof(int)) + align_up(2 * (size_t)B * sizeof(float));   // routes + probe fractions
+               2 * align_up(2 * (size_t)B * sizeof(int)) + align_up(2 * (size_t)B * sizeof(float));   // routes (both passes) + probe fractions
     const int dirs = both ? 2 : 1;
     for (int d = 0; d < dirs; ++d) {
         const size_t R = (size_t)B * (d == 0 ? N : M);
@@ -1104,7 +1137,7 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
     const int Np = (N + HB_KT - 1) / HB_KT * HB_KT, Mp = (M + HB_KT - 1) / HB_KT * HB_KT;
     float *n1p = ar.take<float>((size_t)B * Np), *n2p = ar.take<float>((size_t)B * Mp);
     char *nf1 = ar.take<char>((size_t)B * Np * 32), *nf2 = ar.take<char>((size_t)B * Mp * 32);
-    int *route = ar.take<int>(2 * (size_t)B);
+    int *route = ar.take<int>(2 * (size_t)B), *route2 = ar.take<int>(2 * (size_t)B);
     float *pfrac = ar.take<float>(2 * (size_t)B);
     int32_t *cidx[2] = {nullptr, nullptr}, *flag[2] = {nullptr, nullptr};
     float *cd2[2] = {nullptr, nullptr}, *lsum[2] = {nullptr, nullptr};
@@ -1161,28 +1194,27 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
     // form out of the choice.
     const bool lean = -neg_alpha >= 32.f;
     const RoutePolicy &pol = route_policy();
-    const bool have2 = sweep_form() != 0;
-    const bool havec = pol.coarse && coarse_supports(N, M);
+    const bool havec = coarse_supports(N, M);
     const bool routed = lean && pol.forced < 0;
-    const int fixed = !lean ? K1_ROUTE_FULL : pol.forced < 0 ? -1 : (pol.forced == K1_ROUTE_SECOND && !have2) ? K1_ROUTE_LEAN
-                     : (pol.forced == K1_ROUTE_COARSE && !coarse_supports(N, M)) ? K1_ROUTE_LEAN : pol.forced;
+    const int fixed = !lean ? K1_ROUTE_FULL : pol.forced < 0 ? -1
+                     : (pol.forced == K1_ROUTE_COARSE && havec) ? K1_ROUTE_COARSE : pol.forced == K1_ROUTE_FULL ? K1_ROUTE_FULL : K1_ROUTE_LEAN;
     if (routed) {
         K1ProbeArgs pa;
         pa.f[0] = f1, pa.f[1] = f2, pa.n[0] = n1, pa.n[1] = n2;
         pa.rows[0] = N, pa.rows[1] = M;
         pa.cutw = 20.f / -neg_alpha;
-        pa.p_coarse = pol.p_coarse, pa.p_second = pol.p_second, pa.p_lean = pol.p_lean;
-        pa.have_second = have2, pa.have_coarse = havec;
+        pa.p_coarse = pol.p_coarse, pa.p_lean = pol.p_lean;
+        pa.have_coarse = havec;
         pa.route = route, pa.frac = pfrac;
         hipLaunchKernelGGL(k1_probe_kernel, dim3(B, both ? 2 : 1), dim3(256), 0, s, pa);
         hipLaunchKernelGGL(k1_route_kernel, dim3(both ? 2 : 1), dim3(256), 0, s, pa, B);
         if (pol.debug) report_routes(route, pfrac, B * (both ? 2 : 1), s);
     }
-    if (routed ? (have2 || havec) : (fixed == K1_ROUTE_SECOND || fixed == K1_ROUTE_COARSE)) {
+    if (routed ? havec : fixed == K1_ROUTE_COARSE) {
         launch_norm_frags(n2, B, M, Mp, amax, nf2, s);
         if (both) launch_norm_frags(n1, B, N, Np, amax, nf1, s);
     }
-    if (routed || (fixed != K1_ROUTE_SECOND && fixed != K1_ROUTE_COARSE)) {
+    {   // (the first form's padded norms: also behind the coarse screen, for the gate's second pass)
         hipLaunchKernelGGL(pad_norms_kernel, dim3((Mp + 255) / 256, B), dim3(256), 0, s, n2, M, Mp, n2p);
         if (both) hipLaunchKernelGGL(pad_norms_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, s, n1, N, Np, n1p);
     }
@@ -1196,17 +1228,14 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
     const int blocks = a.blocks0 + (both ? B * a.g[1].tiles : 0);
     a.route = routed ? route : nullptr;
     a.nb = B;
-    prof_note(DVM_PROF_K1_SWEEP, routed ? (havec ? "routed: softcorr_coarse_kernel | softcorr_sweep2_kernel | softcorr_sweep_f16_kernel<lean> | softcorr_sweep_f16_kernel<full>"
-                                           : have2 ? "routed: softcorr_sweep2_kernel | softcorr_sweep_f16_kernel<lean> | softcorr_sweep_f16_kernel<full>"
+    prof_note(DVM_PROF_K1_SWEEP, routed ? (havec ? "routed: softcorr_coarse_kernel | softcorr_sweep_f16_kernel<lean> | softcorr_sweep_f16_kernel<full>"
                                                  : "routed: softcorr_sweep_f16_kernel<lean> | softcorr_sweep_f16_kernel<full>")
                                         : fixed == K1_ROUTE_COARSE ? "softcorr_coarse_kernel"
-                                        : fixed == K1_ROUTE_SECOND ? "softcorr_sweep2_kernel"
                                         : fixed == K1_ROUTE_LEAN   ? "softcorr_sweep_f16_kernel<lean>"
                                                                    : "softcorr_sweep_f16_kernel<full>");
     prof_begin(s);
     // (routed: all three kernels are launched and a workgroup whose pair belongs to another one returns at once)
     if (routed ? havec : fixed == K1_ROUTE_COARSE) launch_coarse(a, nf2, nf1, amax, blocks, s);
-    if (routed ? have2 : fixed == K1_ROUTE_SECOND) launch_sweep2(a, nf2, nf1, amax, blocks, sweep_form(), s);
     if (routed || fixed == K1_ROUTE_LEAN) {
         ensure_dyn_lds((const void *)softcorr_sweep_f16_kernel<true>, (int)HB_LDS_BYTES);
         hipLaunchKernelGGL(softcorr_sweep_f16_kernel<true>, dim3(blocks), dim3(HB_THREADS), HB_LDS_BYTES, s, a);
@@ -1232,8 +1261,17 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
     {
         // (routed: both list lengths are launched and a wave whose direction went through the other kind of screen returns at once)
         const dim3 grid((unsigned)((hr_quads(r) * 64 + 255) / 256));
-        if (routed ? havec : fixed == K1_ROUTE_COARSE) hipLaunchKernelGGL((softcorr_refine_kernel<K1_KC_COARSE, true, 2>), grid, dim3(256), 0, s, r);
+        const bool coarse = routed ? havec : fixed == K1_ROUTE_COARSE;
+        if (coarse) hipLaunchKernelGGL((softcorr_refine_kernel<K1_KC_COARSE, true, 2>), grid, dim3(256), 0, s, r);
         if (routed || fixed != K1_ROUTE_COARSE) hipLaunchKernelGGL((softcorr_refine_kernel<HB_KC, false, 3>), grid, dim3(256), 0, s, r);
+        if (coarse) {   // the gate and its second pass (k1_gate_kernel)
+            K1GateArgs ga{routed ? route : nullptr, route2, {flag[0], both ? flag[1] : flag[0]}, {r1, r2}, both ? 2 : 1, B};
+            hipLaunchKernelGGL(k1_gate_kernel, dim3(1), dim3(256), 0, s, ga);
+            a.route = route2, r.route = route2;
+            ensure_dyn_lds((const void *)softcorr_sweep_f16_kernel<true>, (int)HB_LDS_BYTES);
+            hipLaunchKernelGGL(softcorr_sweep_f16_kernel<true>, dim3(blocks), dim3(HB_THREADS), HB_LDS_BYTES, s, a);
+            hipLaunchKernelGGL((softcorr_refine_kernel<HB_KC, false, 3, true>), grid, dim3(256), 0, s, r);
+        }
     }
     prof_end(s, DVM_PROF_K1_REFINE);
 
@@ -1296,36 +1334,47 @@ int launch_argmin_f16(const float *f1, const float *f2, int B, int N, int M, int
     hipLaunchKernelGGL(norm_max_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, n1, N, nmax1);
     hipLaunchKernelGGL(norm_max_kernel, dim3((M + 255) / 256, B), dim3(256), 0, s, n2, M, nmax2);
     for (int d = 0; d < (both ? 2 : 1); ++d) (void)hipMemsetAsync(flag[d], 0, sizeof(int32_t), s);
-    const bool form2 = sweep_form() != 0;
-    if (form2) {
+    // coarse screen first (lists of 16), the first form behind the device-side gate for directions it serves badly
+    const bool havec = coarse_supports(N, M);
+    int *route = ar.take<int>(2 * (size_t)B);
+    if (!ar.ok()) {
+        set_error("argmin (fp16 sweep): workspace too small (%zu < %zu)", ws_bytes, ar.off);
+        return DVM_ENOSPACE;
+    }
+    if (havec) {
         launch_norm_frags(n2, B, M, Mp, amax, nf2, s);
         if (both) launch_norm_frags(n1, B, N, Np, amax, nf1, s);
-    } else {
-        hipLaunchKernelGGL(pad_norms_kernel, dim3((Mp + 255) / 256, B), dim3(256), 0, s, n2, M, Mp, n2p);
-        if (both) hipLaunchKernelGGL(pad_norms_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, s, n1, N, Np, n1p);
     }
+    hipLaunchKernelGGL(pad_norms_kernel, dim3((Mp + 255) / 256, B), dim3(256), 0, s, n2, M, Mp, n2p);
+    if (both) hipLaunchKernelGGL(pad_norms_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, s, n1, N, Np, n1p);
     HBArgs a;
     a.g[0] = HBGroup{p1, p2, amax, amax + 1, n1, n2p, N, M, Mp, (N + HB_QB - 1) / HB_QB, cidx[0], cd2[0], lsum[0]};
     a.g[1] = both ? HBGroup{p2, p1, amax + 1, amax, n2, n1p, M, N, Np, (M + HB_QB - 1) / HB_QB, cidx[1], cd2[1], lsum[1]} : a.g[0];
     a.blocks0 = B * a.g[0].tiles;
     a.neg_alpha = -100.f;  // only the candidate lists are used; the lean sweep keeps them exactly as the full one does
     a.cutw = 0.f;
-    a.route = nullptr;   // (no softmax sum here: nothing to route, the second form serves every pair)
+    a.route = nullptr;
     a.nb = B;
     const int blocks = a.blocks0 + (both ? B * a.g[1].tiles : 0);
-    if (form2) {
-        launch_sweep2(a, nf2, nf1, amax, blocks, sweep_form(), s);
-    } else {
-        ensure_dyn_lds((const void *)softcorr_sweep_f16_kernel<true>, (int)HB_LDS_BYTES);
-        hipLaunchKernelGGL(softcorr_sweep_f16_kernel<true>, dim3(blocks), dim3(HB_THREADS), HB_LDS_BYTES, s, a);
-    }
     AMArgs r;
     r.g[0] = AMGroup{f1, f2, n1, nmax2, N, M, cidx[0], cd2[0], T12, dmin12, flag[0] + 1, flag[0]};
     r.g[1] = both ? AMGroup{f2, f1, n2, nmax1, M, N, cidx[1], cd2[1], T21, dmin21, flag[1] + 1, flag[1]}
                   : AMGroup{nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     r.rows0 = r1;
     r.rows_total = r1 + (both ? r2 : 0);
-    hipLaunchKernelGGL(argmin_refine_kernel, dim3((unsigned)((r.rows_total + 255) / 256)), dim3(256), 0, s, r);
+    r.route = nullptr;
+    r.nb = B;
+    const dim3 rgrid((unsigned)((r.rows_total + 255) / 256));
+    if (havec) {
+        launch_coarse(a, nf2, nf1, amax, blocks, s);
+        hipLaunchKernelGGL((argmin_refine_kernel<K1_KC_COARSE, true, false>), rgrid, dim3(256), 0, s, r);
+        hipLaunchKernelGGL(argmin_gate_kernel, dim3(1), dim3(64), 0, s, r, both ? 2 : 1, route);
+        a.route = route, r.route = route;
+    }
+    ensure_dyn_lds((const void *)softcorr_sweep_f16_kernel<true>, (int)HB_LDS_BYTES);
+    hipLaunchKernelGGL(softcorr_sweep_f16_kernel<true>, dim3(blocks), dim3(HB_THREADS), HB_LDS_BYTES, s, a);
+    if (havec) hipLaunchKernelGGL((argmin_refine_kernel<HB_KC, false, true>), rgrid, dim3(256), 0, s, r);
+    else hipLaunchKernelGGL((argmin_refine_kernel<HB_KC, false, false>), rgrid, dim3(256), 0, s, r);
     hipLaunchKernelGGL(argmin_exact_rows_kernel, dim3(512), dim3(256), 0, s, r);
     return DVM_OK;
 }

@@ -303,32 +303,6 @@ def test_knn_neg_heavy_ties(ops):
         assert np.array_equal(idx, O.knn_neg(a[0].numpy(), b[0].numpy(), k)), (N, M, C, k)
 
 
-def test_knn_f16_sweep_path_equals_dense_path():
-    """DVM_KNN_F16=1 (opt-in: dvm_knn_f16.hip — the self-kNN from the 16-bit matrix pipe's candidate sweep, exact fp32 scores
-    only where the approximate order is uncertain, no N x N matrix) returns the dense path's indices bit for bit: random,
-    half-zero, clustered features and every point duplicated (heavy ties -> the exact-rows kernel), C = 64 and 128, ragged N.
-    A child process: the switch is read once per process; the dense path is reached by passing a copy as the key side."""
-    import subprocess
-    code = (
-        "import os, sys, torch\n"
-        "sys.path.insert(0, os.path.join(%r, 'dv-matcher_amd'))\n"
-        "from dvm import ops\n"
-        "g = torch.Generator().manual_seed(5)\n"
-        "for kind in ('randn', 'relu', 'clustered', 'duplicates'):\n"
-        "    for (B, N, C) in ((2, 2048, 128), (3, 1500, 64), (1, 4995, 128), (2, 700, 64)):\n"
-        "        x = torch.randn(B, N, C, generator=g)\n"
-        "        if kind == 'relu': x = 0.3 * torch.relu(x)\n"
-        "        if kind == 'clustered': x = 0.02 * x + torch.randn(B, 1, C, generator=g)\n"
-        "        if kind == 'duplicates': x[:, N // 2:] = x[:, :N - N // 2].clone()\n"
-        "        x = x.cuda()\n"
-        "        a, b = ops.knn_neg(x, x, 40), ops.knn_neg(x, x.clone(), 40)\n"
-        "        assert torch.equal(a, b), (kind, B, N, C, int((a != b).any(-1).sum()))\n"
-        "print('ok')\n" % ROOT)
-    env = dict(os.environ, DVM_KNN_F16="1")
-    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert res.returncode == 0 and "ok" in res.stdout, res.stderr[-2000:]
-
-
 def test_geodesic_eval_uses_the_exact_map(ops):
     """SURVEY §8d 'geodesic error': identical features give error 0; the device map equals the oracle's, so the
     geodesic error of any feature pair equals the one computed from the oracle's map."""

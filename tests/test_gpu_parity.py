@@ -100,8 +100,9 @@ def test_softcorr_writes_every_output_slot(ops):
 @pytest.mark.parametrize("alpha", [33.0, 100.0, 150.0])
 def test_softcorr_routed_sweeps_vs_oracle(ops, alpha):
     """Pass A is chosen per launch by the probe (dvm_softcorr_f16.hip::k1_probe_kernel): on the "trained-like" feature set
-    (0.3 relu(N(0,1)): tight distance spread) the three alphas below take the three kernels (full / lean first form, second
-    form — profiles/r3_route_calib.txt).  Whatever the route, the result is the oracle's: columns exact, values to 5e-5.
+    (0.3 relu(N(0,1)): tight distance spread) the alphas below take the full and the lean first form; random features at alpha
+    100 take the coarse screen (test_pair_forward_full_size_vs_oracle, the bench).  Whatever the route, the result is the
+    oracle's: columns exact, values to 5e-5.
     (Which route runs is checked by test_softcorr_probe_routes below; here the results are compared.)"""
     rng = np.random.default_rng(int(alpha))
     f1 = (0.3 * np.maximum(rng.standard_normal((2048, 128)), 0)).astype(np.float32)
@@ -111,8 +112,9 @@ def test_softcorr_routed_sweeps_vs_oracle(ops, alpha):
 
 def test_softcorr_probe_routes():
     """The probe's choice on the two synthetic feature sets of SURVEY 8d, read from the DVM_K1_ROUTE_DEBUG report of a child
-    process (the policy is read once per process): random features -> second form at every alpha >= 32; trained-like
-    features -> full first form at alpha 33, lean first form at 100, second form at 150."""
+    process (the policy is read once per process): random features -> lean first form at alpha 33 (seven columns of a row within
+    the cut: more than the coarse screen's list certifies for every row), the coarse screen at 100 and 150; trained-like features
+    -> full first form at alpha 33, lean first form at 100 and 150."""
     code = (
         "import os, sys, torch\n"
         "sys.path.insert(0, os.path.join(%r, 'dv-matcher_amd'))\n"
@@ -125,52 +127,14 @@ def test_softcorr_probe_routes():
         "        ops.softcorr(f1, f2, alpha, topk=10, variant=3)\n"
         "torch.cuda.synchronize()\n" % ROOT)
     env = dict(os.environ, DVM_K1_ROUTE_DEBUG="1")
-    env.pop("DVM_K1_ROUTE", None), env.pop("DVM_K1_SWEEP", None), env.pop("DVM_K1_ROUTE_P", None)
+    env.pop("DVM_K1_ROUTE", None), env.pop("DVM_K1_ROUTE_P", None)
     res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stderr.splitlines() if ln.startswith("K1 routes:")]
     assert len(lines) == 6, res.stderr[-2000:]
-    want = ["0 full, 0 lean, 8 second"] * 3 + ["8 full, 0 lean, 0 second", "0 full, 8 lean, 0 second", "0 full, 0 lean, 8 second"]
+    want = ["0 full, 8 lean, 0 coarse"] + ["0 full, 0 lean, 8 coarse"] * 2 + ["8 full, 0 lean, 0 coarse"] + ["0 full, 8 lean, 0 coarse"] * 2
     for ln, w in zip(lines, want):
         assert w in ln, (ln, w)
-
-
-def test_softcorr_refine_forms_agree(tmp_path):
-    """Pass B of the soft correspondence exists in five access shapes (DVM_K1_REFINE, read once per process: dvm_softcorr_f16.hip);
-    the product runs form 14.  Every form — and every window of the shipped one — must give the shipped form's bits: columns,
-    values, maxima and sums, on random features with duplicated rows (ties -> the exact-rows kernel), square and ragged (a row count that is
-    not a multiple of the four rows of a wave).  (Both directions in ONE launch: the pair-forward tests, shipped form.)"""
-    code = (
-        "import os, sys, numpy as np, torch\n"
-        "sys.path.insert(0, os.path.join(%r, 'dv-matcher_amd'))\n"
-        "from dvm import ops\n"
-        "g = torch.Generator().manual_seed(11)\n"
-        "out = {}\n"
-        "for name, (B, N, M) in {'sq': (3, 2048, 2048), 'ragged': (3, 1021, 777)}.items():\n"
-        "    f1, f2 = torch.randn(B, N, 128, generator=g), torch.randn(B, M, 128, generator=g)\n"
-        "    f2[:, 5] = f2[:, 3]; f2[:, 100:110] = f2[:, 99:100]\n"
-        "    r = tuple(ops.softcorr(f1.cuda(), f2.cuda(), 100.0, topk=10, variant=3))\n"
-        "    r += tuple(ops.softcorr(f2.cuda(), f1.cuda(), 100.0, topk=10, variant=3))\n"
-        "    for i, t in enumerate(r):\n"
-        "        if torch.is_tensor(t): out['%%s_%%d' %% (name, i)] = t.cpu().numpy()\n"
-        "torch.cuda.synchronize()\n"
-        "np.savez(sys.argv[1], **out)\n" % ROOT)
-    def run(form, win=None):
-        env = dict(os.environ, DVM_K1_REFINE=str(form))
-        env.pop("DVM_K1_REFINE_WIN", None)
-        if win is not None:
-            env["DVM_K1_REFINE_WIN"] = str(win)
-        path = str(tmp_path / ("f%s_%s.npz" % (form, win)))
-        res = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=300)
-        assert res.returncode == 0, res.stderr[-2000:]
-        return dict(np.load(path))
-    ref = run(14)
-    assert len(ref) >= 8
-    for form, win in ((0, None), (1, None), (2, None), (3, None), (4, None), (10, None), (14, 1), (14, 2), (14, 4), (14, 8)):
-        got = run(form, win)
-        assert got.keys() == ref.keys()
-        for k in ref:
-            assert np.array_equal(ref[k], got[k]), (form, win, k)
 
 
 def test_pair_forward_fused_preparation_equals_two_pass(tmp_path):
@@ -660,7 +624,7 @@ def test_pair_forward_contract_size_low_alpha_vs_oracle(ops, golden, alpha, kind
 
 
 def test_softcorr_non_finite_features_keep_columns_in_range(ops):
-    """the second-form sweep is built with -fno-honor-nans ("no NaN is ever formed" holds for finite features).
+    """the coarse screen (as the second-form sweep it replaced) is built with -fno-honor-nans ("no NaN is ever formed" holds for finite features).
     A diverged training step can hand it NaN / Inf rows; whatever the values then are, every column index written must
     stay inside [0, M): the columns feed unchecked gathers (Pi @ V, the Deformer rows, the map term).  The finite rows of
     the same launch that do not see a non-finite key are still the oracle's."""
@@ -673,7 +637,7 @@ def test_softcorr_non_finite_features_keep_columns_in_range(ops):
     f1[0, 301, 9] = -np.inf
     f2[1, 11] = np.nan                                 # a non-finite KEY: every row of pair 1 sees it
     f2[1, 900, 3] = np.inf
-    for alpha in (10.0, 100.0):                        # first form in full / the routed second form
+    for alpha in (10.0, 100.0):                        # first form in full / the routed coarse screen
         for variant in (0, 3):
             junk = [torch.full((2, N, 10), 0x7f7f7f7f, dtype=torch.int32, device="cuda")]
             torch.cuda.synchronize()
