@@ -49,6 +49,15 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak F
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense f16 / bf16 matrix peak (same guide)
 PEAK_HBM_GBS = 8000.0          # HBM3E peak (same guide; 6.3 TB/s achievable)
 CHECK_PAIRS = 4
+TRAFFIC_FILE = "r5_k1_traffic.json"   # PMC passes of this round's dominant kernel (tools/k1_traffic.py)
+
+
+def k1_products(kernel_name):
+    """fp16 products of the N x M contraction that pass A PERFORMS per direction: the coarse screen runs the hh product alone, the
+    first form the three products hh + hm + mh of the exact 2-way split.  A routed launch prices the kernel the probe sends the
+    bench's inputs to (random features at alpha 100: the coarse screen — checked by tests/test_gpu_parity.py::test_softcorr_probe_routes);
+    the others return at once."""
+    return 1 if "softcorr_coarse_kernel" in kernel_name else 3
 
 
 def parse_args(argv=None):
@@ -66,7 +75,7 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo for the "
                     "two-ranks-on-one-GPU test of this script)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
-                    help="per-launch HBM bytes of the dominant kernel from the PMC passes (default: profiles/r4_k1_traffic.json, "
+                    help="per-launch HBM bytes of the dominant kernel from the PMC passes (default: profiles/r5_k1_traffic.json, "
                          "used only if it was taken on this kernel source, for the kernel the timed launches ran, at this --pairs)")
     return ap.parse_args(argv)
 
@@ -216,19 +225,19 @@ def k1_sources_sha16():
     and for the kernel the timed launches actually ran."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("dvm_softcorr_sweep2.hip", "dvm_softcorr_f16.hip", "dvm_softcorr_f16.h"):
+    for name in ("dvm_softcorr_coarse.hip", "dvm_softcorr_f16.hip", "dvm_softcorr_f16.h"):
         with open(os.path.join(ROOT, "dv-matcher_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
 
 
 def load_traffic(P, kernel_name):
-    """(bytes per launch or None, provenance dict) from profiles/r4_k1_traffic.json."""
-    tpath = os.path.join(ROOT, "profiles", "r4_k1_traffic.json")
+    """(bytes per launch or None, provenance dict) from profiles/r5_k1_traffic.json."""
+    tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
     if not os.path.exists(tpath):
         return None, {"file": None, "why_null": "no traffic file for this round"}
     tj = json.load(open(tpath))
-    prov = {"file": "profiles/r4_k1_traffic.json", "kernel": tj.get("kernel_slot_name"), "source_sha16": tj.get("source_sha16"),
+    prov = {"file": "profiles/" + TRAFFIC_FILE, "kernel": tj.get("kernel_slot_name"), "source_sha16": tj.get("source_sha16"),
             "pairs": tj.get("pairs")}
     if tj.get("pairs") != P:
         prov["why_null"] = "measured at --pairs %s, this run is --pairs %d" % (tj.get("pairs"), P)
@@ -249,8 +258,8 @@ def kernel_models(P):
     row = DIM * 4               # one feature row, bytes
     return {
         1: dict(bound="hbm", work=2 * R * row + R * 12 * 8 + R * 10 * 8,
-                note="pass B, one launch: every feature row once as a query and at least once as a candidate; the 12 candidate "
-                     "rows of 512 B gathered per query are served by L2 (6.5 x the unique bytes priced here)"),
+                note="pass B: every feature row once as a query and at least once as a candidate; the ~11 candidate rows of 512 B "
+                     "gathered per query (of a list of 16 from the coarse screen, 12 from the first form) are served by L2"),
         2: dict(bound="mfma", work=3 * 2.0 * 299136 * Rn, peak=PEAK_F16_MFMA_TFLOPS,
                 note="Deformer MLP 262-512-256-128-9 over all nodes on the f16 pipe, 3 partial products of the exact 2-way split"),
         3: dict(bound="hbm", work=8 * P * N_PTS * (16 + 16 + 4),
@@ -393,6 +402,7 @@ def run_pair(args):
         k1_alone = alone_ms / max(alone_n, 1)
         flops_launch = P * (2.0 * N_PTS * M_PTS * DIM)   # the distance tile counted once per pair
         tf = lambda ms_: flops_launch / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0  # noqa: E731
+        nprod = k1_products(k1_name)
         kernels = []
         for k, (ms_tot, n) in sorted(slots.items()):
             if n == 0:
@@ -424,26 +434,27 @@ def run_pair(args):
                              "what": "graphs (FPS nodes, rings, skinning), uniform grids and xyz kNN of both clouds reused from a first "
                                      "call (dvm_pair_fwd_cached_f32); everything feature-dependent recomputed"},
             "process_group": (dist.get_backend() if dist_on else None),
-            # The dominant kernel runs the N x M contraction on the 16-bit matrix pipe: 3 exact fp16 partial products
-            # (2-way split of the scaled features, fp32 accumulate) per direction.  `achieved` / `peak` / `frac` price the
-            # flops it PERFORMS (6 x the algorithmic count: 3 products x 2 directions of one distance tile) against the pipe
-            # it runs on (dense f16 peak) — the utilisation figure.  `algorithmic` is SURVEY §8d's accounting: 2*N*M*d per
-            # pair, the distance tile counted once, over the same launch time, against the fp32 matrix peak §8d prescribes
-            # (a formulation-independent number: it can exceed what an fp32-MFMA kernel could ever reach).
-            "roofline": {"bound": "mfma", "kernel": k1_name + " (K1 pass A: the N x M sweep on the f16 matrix pipe over an exact 2-way fp16 split; "
-                                                             "named by the library from what the timed launches ran)",
-                         "achieved": 6.0 * tf(k1_ms), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": 6.0 * tf(k1_ms) / PEAK_F16_MFMA_TFLOPS, "pipe": "f16 matrix (v_mfma_f32_32x32x16_f16)",
+            # The dominant kernel runs the N x M contraction on the 16-bit matrix pipe.  `achieved` / `peak` / `frac` price the
+            # flops it PERFORMS — `products` fp16 products per direction (coarse screen: hh alone; first form: hh + hm + mh of the
+            # exact 2-way split) x 2 directions of one distance tile, the norm instruction not counted — against the pipe it
+            # runs on (dense f16 peak): the utilisation figure.  `algorithmic` is SURVEY §8d's accounting: 2*N*M*d per pair, the
+            # distance tile counted once, over the same launch time, against the fp32 matrix peak §8d prescribes (a
+            # formulation-independent number: it exceeds what an fp32-MFMA kernel could ever reach).
+            "roofline": {"bound": "mfma", "kernel": k1_name + " (K1 pass A: the N x M sweep on the f16 matrix pipe; named by the library "
+                                                             "from what the timed launches ran)",
+                         "products_per_direction": nprod,
+                         "achieved": 2.0 * nprod * tf(k1_ms), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": 2.0 * nprod * tf(k1_ms) / PEAK_F16_MFMA_TFLOPS, "pipe": "f16 matrix (v_mfma_f32_32x32x16_f16)",
                          "traffic": traffic, "traffic_source": traffic_src, "launch_ms": k1_ms, "launches_timed": k1_launches,
-                         "flops_per_launch": 6.0 * flops_launch,
+                         "flops_per_launch": 2.0 * nprod * flops_launch,
                          "algorithmic": {"flops_per_launch": flops_launch, "achieved": tf(k1_ms), "peak": PEAK_F32_MFMA_TFLOPS,
                                          "frac": tf(k1_ms) / PEAK_F32_MFMA_TFLOPS, "peak_name": "fp32 matrix"},
                          "share_of_step": (k1_total_ms * 1e-3) / local_dt if local_dt > 0 else None,
                          # in the timed region the sweep shares the CUs with the geometry chain on the helper stream
                          # (FPS / graph / kNN / pooling), which stretches its launch; alone (overlap off, 3 launches after
                          # the timed region) it takes `launch_ms` below
-                         "standalone": {"launch_ms": k1_alone, "achieved": 6.0 * tf(k1_alone),
-                                        "frac": 6.0 * tf(k1_alone) / PEAK_F16_MFMA_TFLOPS,
+                         "standalone": {"launch_ms": k1_alone, "achieved": 2.0 * nprod * tf(k1_alone),
+                                        "frac": 2.0 * nprod * tf(k1_alone) / PEAK_F16_MFMA_TFLOPS,
                                         "algorithmic_frac": tf(k1_alone) / PEAK_F32_MFMA_TFLOPS},
                          "kernels": kernels,
                          # SURVEY §8d's whole-path count: 2.5 GFLOP of matrix work per pair (both directions' distance tiles,

@@ -1,4 +1,4 @@
-"""profiles/r4_k1_traffic.json from the PMC passes of tools/gpu/profiles_r4.sh: per-launch HBM bytes (and the SQ rows) of pass A of
+"""profiles/r5_k1_traffic.json from the PMC passes of tools/gpu/profiles_r5.sh: per-launch HBM bytes (and the SQ rows) of pass A of
 K1 as bench.py launches it, with the provenance bench.py checks before it reports `roofline.traffic`: the kernel name the library
 reports for the timed launches (dvm_profile_kernel_name(0), taken from the bench line measured in the same script) and the sha256
 of the kernel's source files.  FETCH_SIZE is doubled as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (128-byte
@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (torch-free at import)
 
 d, line, out = sys.argv[1], json.load(open(sys.argv[2])), sys.argv[3]
-SUBS = ("softcorr_sweep2_kernel", "softcorr_sweep_f16_kernel")   # everything the slot-0 bracket encloses
+SUBS = ("softcorr_coarse_kernel", "softcorr_sweep_f16_kernel")   # everything the slot-0 bracket encloses
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
@@ -27,14 +27,14 @@ res = {
     "config": "bench.py --pairs %d (N=M=2048, d=128)" % P,
     "FETCH_SIZE_KB": per.get("FETCH_SIZE"), "WRITE_SIZE_KB": per.get("WRITE_SIZE"),
     "fetch_bytes_corrected_x2": fetch, "write_bytes": write, "bytes_per_launch": fetch + write,
-    # per pair, as in rounds 1-3: the fp16 planes of both clouds read once (2 x 2048 x 512 B) + per row and direction 12 candidate
-    # (column, distance) pairs, the two partial softmax sums and the norm fragments (2 x 2048 x 144 B)
-    "algorithmic_bytes_per_launch": P * (2 * 2048 * 512 + 2 * 2048 * 144),
+    # per pair: the h plane of both clouds read once (2 x 2048 x 256 B; the first form reads both planes: 512 B) + per row and
+    # direction 16 candidate (column, distance) pairs, the two partial softmax sums and the norm fragments (2 x 2048 x 168 B)
+    "algorithmic_bytes_per_launch": P * (2 * 2048 * (256 if "softcorr_coarse_kernel" in line["roofline"]["kernel"] else 512) + 2 * 2048 * 168),
     "l2_hit_rate": (per["TCC_HIT_sum"] / (per["TCC_HIT_sum"] + per["TCC_MISS_sum"])) if "TCC_HIT_sum" in per and "TCC_MISS_sum" in per else None,
     "SQ": {k: v for k, v in sorted(per.items()) if k.startswith("SQ_")},
     "kernels_in_bracket": sorted({k for ks in acc.values() for k in ks}),
     "how": "rocprofv3 --kernel-trace --pmc <one group per pass> -- python3 bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-check "
-           "(tools/gpu/profiles_r4.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md; Infinity-Cache hits are counted in FETCH_SIZE",
+           "(tools/gpu/profiles_r5.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md; Infinity-Cache hits are counted in FETCH_SIZE",
 }
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps({k: res[k] for k in ("kernel_slot_name", "source_sha16", "pairs", "bytes_per_launch", "algorithmic_bytes_per_launch", "l2_hit_rate")}))
