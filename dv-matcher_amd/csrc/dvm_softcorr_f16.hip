@@ -689,45 +689,67 @@ __global__ __launch_bounds__(256) void softcorr_refine_kernel(const HRArgs args)
         const unsigned klo = (unsigned)(uintptr_t)kptr, khi = (unsigned)((uintptr_t)kptr >> 32);
         char *const wl = hr_lds + (threadIdx.x >> 6) * (2 * SLOTS * 64);
         const int ck = lane & 3, s0 = lane >> 2;
-        typedef const __attribute__((address_space(1))) float gfloat;   // (an address rebuilt from integers is a flat one otherwise,
-        gfloat *src[NL];                                                 // and flat loads count on the LDS counter as well)
-#pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            const int sl = s0 + 16 * i, owner = (sl / KC) * 16 + sl % KC;
-            const unsigned lo = (unsigned)__shfl((int)klo, owner, 64), hi = (unsigned)__shfl((int)khi, owner, 64);
-            src[i] = (gfloat *)(((uintptr_t)hi << 32) | lo) + 4 * ck;
+        // Slot of a candidate row in the wave's piece buffers.  Lists of 12: slot = 12 x (row of the quad) + entry, static.  Lists
+        // of 16 (coarse screen): only ~11 of a row's 16 entries are evaluated, so the evaluated ones of the four rows are
+        // COMPACTED — slot = number of evaluated lanes below this one — and 3 loads per lane and piece cover them (48 slots) in
+        // all but ~1e-3 of the waves, which take 4; ds_permute hands every slot's pointer to the lane of that number (the
+        // other lanes' query-row pointers fill the slots behind: a permutation, every lane receives one).
+        int myslot = (lane >> 4) * KC + (cand ? l16 : 0);
+        unsigned plo = klo, phi = khi;
+        int nslots = SLOTS;
+        if (COARSE) {
+            const unsigned long long em = __builtin_amdgcn_ballot_w64(eval);
+            const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(em >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)em, 0u));
+            nslots = __builtin_popcountll(em);
+            const int dest = eval ? below : nslots + (lane - below);
+            plo = (unsigned)__builtin_amdgcn_ds_permute(dest << 2, (int)klo);
+            phi = (unsigned)__builtin_amdgcn_ds_permute(dest << 2, (int)khi);
+            myslot = eval ? below : 0;
         }
-        constexpr int WIN = HR4W;   // pieces in flight per lane (x NL loads)
-        f32x4 kv[WIN][NL];
-#pragma unroll
-        for (int pc = 0; pc < WIN; ++pc)
-#pragma unroll
-            for (int i = 0; i < NL; ++i) kv[pc][i] = *(const __attribute__((address_space(1))) f32x4 *)(src[i] + 16 * pc);
-        const int myslot = (lane >> 4) * KC + (cand ? l16 : 0);
         const int wsw = (s0 >> 2) & 3, rsw = (myslot >> 2) & 3;   // (s0 + 16 i) / 4 % 4 does not depend on i
         float acc = 0.f;
-        static_for<0, 8>([&](auto pcc) __attribute__((always_inline)) {
-            constexpr int pc = decltype(pcc)::value;
-            char *const buf = wl + (pc & 1) * (SLOTS * 64);
+        typedef const __attribute__((address_space(1))) float gfloat;   // (an address rebuilt from integers is a flat one otherwise,
+                                                                         // and flat loads count on the LDS counter as well)
+        auto gather = [&](auto nlc) __attribute__((always_inline)) {
+            constexpr int NLR = decltype(nlc)::value;   // loads per lane and 64-byte piece: 16 NLR slots
+            gfloat *src[NLR];
 #pragma unroll
-            for (int i = 0; i < NL; ++i) *(f32x4 *)(buf + (s0 + 16 * i) * 64 + ((ck ^ wsw) << 4)) = kv[pc % WIN][i];
-            if constexpr (pc + WIN < 8) {   // the registers just stored take the piece WIN further on
-#pragma unroll
-                for (int i = 0; i < NL; ++i) kv[pc % WIN][i] = *(const __attribute__((address_space(1))) f32x4 *)(src[i] + 16 * (pc + WIN));
+            for (int i = 0; i < NLR; ++i) {
+                const int sl = s0 + 16 * i, owner = COARSE ? sl : (sl / KC) * 16 + sl % KC;
+                const unsigned lo = (unsigned)__shfl((int)plo, owner, 64), hi = (unsigned)__shfl((int)phi, owner, 64);
+                src[i] = (gfloat *)(((uintptr_t)hi << 32) | lo) + 4 * ck;
             }
-            __builtin_amdgcn_wave_barrier();
-            f32x4 kc[4];
+            constexpr int WIN = HR4W;   // pieces in flight per lane (x NLR loads)
+            f32x4 kv[WIN][NLR];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) kc[c] = *(const f32x4 *)(buf + myslot * 64 + ((c ^ rsw) << 4));
-            __builtin_amdgcn_wave_barrier();
-            static_for<0, 4>([&](auto cc) __attribute__((always_inline)) {
-                constexpr int c = decltype(cc)::value;
+            for (int pc = 0; pc < WIN; ++pc)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    fma_row_share<2 * pc + c / 2>(acc, qs[4 * (c & 1) + e], kc[c][e]);
+                for (int i = 0; i < NLR; ++i) kv[pc][i] = *(const __attribute__((address_space(1))) f32x4 *)(src[i] + 16 * pc);
+            static_for<0, 8>([&](auto pcc) __attribute__((always_inline)) {
+                constexpr int pc = decltype(pcc)::value;
+                char *const buf = wl + (pc & 1) * (SLOTS * 64);
+#pragma unroll
+                for (int i = 0; i < NLR; ++i) *(f32x4 *)(buf + (s0 + 16 * i) * 64 + ((ck ^ wsw) << 4)) = kv[pc % WIN][i];
+                if constexpr (pc + WIN < 8) {   // the registers just stored take the piece WIN further on
+#pragma unroll
+                    for (int i = 0; i < NLR; ++i) kv[pc % WIN][i] = *(const __attribute__((address_space(1))) f32x4 *)(src[i] + 16 * (pc + WIN));
                 }
+                __builtin_amdgcn_wave_barrier();
+                f32x4 kc[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) kc[c] = *(const f32x4 *)(buf + myslot * 64 + ((c ^ rsw) << 4));
+                __builtin_amdgcn_wave_barrier();
+                static_for<0, 4>([&](auto cc) __attribute__((always_inline)) {
+                    constexpr int c = decltype(cc)::value;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        fma_row_share<2 * pc + c / 2>(acc, qs[4 * (c & 1) + e], kc[c][e]);
+                    }
+                });
             });
-        });
+        };
+        if (COARSE && nslots <= 16 * (NL - 1)) gather(std::integral_constant<int, NL - 1>{});
+        else gather(std::integral_constant<int, NL>{});
         if (eval) {
             const float d2 = (acc + na) + nb;
             v = d2 > 0.f ? d2 : 0.f;
@@ -1262,7 +1284,8 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
         // (routed: both list lengths are launched and a wave whose direction went through the other kind of screen returns at once)
         const dim3 grid((unsigned)((hr_quads(r) * 64 + 255) / 256));
         const bool coarse = routed ? havec : fixed == K1_ROUTE_COARSE;
-        if (coarse) hipLaunchKernelGGL((softcorr_refine_kernel<K1_KC_COARSE, true, 2>), grid, dim3(256), 0, s, r);
+        // (window 3: 112 VGPRs, 4 waves per SIMD, 1.11 ms per launch of the bench; window 2: 96, 5 waves, 1.17 ms)
+        if (coarse) hipLaunchKernelGGL((softcorr_refine_kernel<K1_KC_COARSE, true, 3>), grid, dim3(256), 0, s, r);
         if (routed || fixed != K1_ROUTE_COARSE) hipLaunchKernelGGL((softcorr_refine_kernel<HB_KC, false, 3>), grid, dim3(256), 0, s, r);
         if (coarse) {   // the gate and its second pass (k1_gate_kernel)
             K1GateArgs ga{routed ? route : nullptr, route2, {flag[0], both ? flag[1] : flag[0]}, {r1, r2}, both ? 2 : 1, B};
