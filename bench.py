@@ -291,7 +291,12 @@ def run_pair(args):
     dist_on = world > 1 or os.environ.get("DVM_DIST_ALWAYS", "0") == "1"
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        if "MASTER_PORT" not in os.environ:
+            # (a port of its own only for the single-rank case: with more ranks each would pick a different one and hang)
+            if world > 1:
+                raise SystemExit("bench.py: WORLD_SIZE = %d but MASTER_PORT is not set (use `bench.py --gpus N`, which starts its own "
+                                 "ranks, or torch.distributed.run --master-port P)" % world)
+            os.environ["MASTER_PORT"] = str(free_port())
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:

@@ -36,6 +36,7 @@ static std::atomic<int> g_deterministic{[] {
 bool deterministic() { return g_deterministic.load(std::memory_order_relaxed) != 0; }
 }  // namespace dvm
 DVM_EXPORT int dvm_set_deterministic(int on) { return dvm::g_deterministic.exchange(on ? 1 : 0); }
+DVM_EXPORT int dvm_get_deterministic(void) { return dvm::g_deterministic.load(std::memory_order_relaxed); }
 
 // ---------------------------------------------------------------- per-device kernel attributes
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device's copy of a kernel: it has to be made

@@ -43,21 +43,21 @@ namespace {
 constexpr int HC_ROWB = 256;                   // bytes of a key row in LDS (h plane)
 constexpr int HC_KT = 64;                      // keys per LDS tile
 constexpr int HC_KL = 12;                      // list entries per half-lane
-constexpr int HC_WAVES = 8;
 constexpr unsigned HC_REMOVED = 0xffc00000u;   // keys / entries >= this: removed / invalid
 constexpr unsigned HC_KBASE = 129u << 23;      // bits(4.0f): bottom of the key window
 constexpr float HC_FLOOR = 4.5f;               // added to every accumulator through the norm instruction
 constexpr unsigned HC_EMASK = 0xffffe00fu;     // bits of a key that survive in a list entry (19 key bits + register number)
 constexpr int HC_MAX_M = 256 * 32;             // 8 bits of sub-tile number
 
-template <int QB> constexpr int hc_nrec() { return 64 / QB; }   // third-key records per lane and block
-template <int QB> constexpr int hc_lds_bytes() { return 2 * HC_KT * HC_ROWB + 2 * HC_KT * 32 + 1024 + HC_WAVES * QB * hc_nrec<QB>() * 64 * 2; }
+// W waves per workgroup (8: two per SIMD, software-pipelined; 16: four per SIMD, one sub-tile at a time), QB blocks of 32 query rows per wave
+template <int QB, int W> constexpr int hc_nrec() { return 512 / (QB * W); }   // third-key records per lane and block (64 KB of LDS in all)
+template <int QB, int W> constexpr int hc_lds_bytes() { return 2 * HC_KT * HC_ROWB + 2 * HC_KT * 32 + 1024 + W * QB * hc_nrec<QB, W>() * 64 * 2; }
 
 struct HCGroup {
     const char *qp, *kp;      // planes of the query / key side [B][rows][512]: h plane = the first 256 B of a row
     const char *knf;          // key-side norm fragments [B][Mpad][32 B] (launch_norm_frags)
     const float *nq;          // |q|^2 (ATen order)
-    int N, M, Mpad, tiles;    // tiles: workgroups per batch entry (32 QB HC_WAVES query rows each)
+    int N, M, Mpad, tiles;    // tiles: workgroups per batch entry (32 QB W query rows each)
     int32_t *cidx;            // [B][N][K1_KC_COARSE]
     float *cd2, *lsum;
 };
@@ -148,9 +148,10 @@ __device__ __forceinline__ int entry_col(unsigned e) {
 // STAMP: diagnostic build — every wave adds up the shader cycles (s_memtime) it spends per phase; no output depends on them.
 // Phases: 0 LDS-DMA issue, 1 matrix chain (until the accumulators are readable), 2 epilogue, 3 re-done sub-tiles, 5 barrier
 // (incl. the wait for the wave's own DMA pieces), 6 whole kernel, 7 sub-tiles (re-done records counted in the high bits).
-template <int QB, bool STAMP = false, bool PACE = true>
-__global__ __launch_bounds__(64 * HC_WAVES, 1) void softcorr_coarse_kernel(const HCArgs args) {
-    constexpr int NREC = hc_nrec<QB>(), ROWS = 32 * QB * HC_WAVES;
+template <int QB, bool STAMP = false, bool PACE = true, int W = 8>
+__global__ __launch_bounds__(64 * W, W / 4) void softcorr_coarse_kernel(const HCArgs args) {
+    constexpr int NREC = hc_nrec<QB, W>(), ROWS = 32 * QB * W;
+    constexpr bool PIPE = W == 8;   // two waves per SIMD: the next sub-tile's matrix chain is issued ahead of this one's epilogue
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
     unsigned long long T[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0, tstart = 0;
     if (STAMP) tstart = tlast = __builtin_amdgcn_s_memtime();
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(64 * HC_WAVES, 1) void softcorr_coarse_kernel(const
         const int j0 = t * HC_KT;
         const char *tb = kbase + (size_t)j0 * HB_ROWB;   // wave-uniform
         char *kt = ktile0 + (size_t)buf * HC_KT * HC_ROWB;
-        constexpr int PIECES = HC_KT * HC_ROWB / 1024 / HC_WAVES;
+        constexpr int PIECES = HC_KT * HC_ROWB / 1024 / W;
 #pragma unroll
         for (int e = 0; e < PIECES; ++e) {
             const int piece = wave * PIECES + e;
@@ -364,7 +365,28 @@ __global__ __launch_bounds__(64 * HC_WAVES, 1) void softcorr_coarse_kernel(const
     };
     stage(0, 0);
     dma_barrier();
-    {
+    if (!PIPE) {
+        // four waves per SIMD: a wave does one sub-tile at a time (chain, then epilogue); what overlaps its vector work with
+        // matrix work is the other three waves
+        auto tile = [&](int t, int buf) __attribute__((always_inline)) {   // buf: literal after inlining
+            stage(t + 1, buf ^ 1);   // (last read before the previous barrier)
+            stamp(0);
+            const bool pads = ragged && t + 1 == ntiles;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const Acc a = chain(buf, sub);
+                stamp_after(1, __float_as_int(a.a[QB - 1][0]));
+                if (pads) epilogue(a, 2 * t + sub, true); else epilogue(a, 2 * t + sub, false);
+            }
+            dma_barrier();
+            stamp(5);
+            T[7] += 2;
+        };
+        for (int t = 0; t < ntiles; t += 2) {
+            tile(t, 0);
+            if (t + 1 < ntiles) tile(t + 1, 1);
+        }
+    } else {
         // software pipeline: the matrix chain of the next sub-tile is issued ahead of the epilogue of the current one
         Acc a0 = chain(0, 0);
         auto tile = [&](int t, int buf, bool last) __attribute__((always_inline)) {   // buf, last: literals after inlining
@@ -415,9 +437,12 @@ __global__ __launch_bounds__(64 * HC_WAVES, 1) void softcorr_coarse_kernel(const
     for (int qb = 0; qb < QB; ++qb) {
         const unsigned limr = lim[qb] >> 16, limk = lim[qb] | ~HC_EMASK;   // (as a key: every key that shares the bound's 19 bits counts)
         unsigned long long todo = 0;   // wave-uniform: records with a lane at or below its bound
+        unsigned short rv[NREC];       // (all reads requested before the first is used: one LDS round trip, not NREC)
+#pragma unroll
+        for (int g = 0; g < NREC; ++g) rv[g] = rec[(qb * NREC + g) * 64];
 #pragma unroll
         for (int g = 0; g < NREC; ++g)
-            if (g < nrec && __builtin_amdgcn_ballot_w64((unsigned)rec[(qb * NREC + g) * 64] <= limr) != 0) todo |= 1ull << g;
+            if (g < nrec && __builtin_amdgcn_ballot_w64((unsigned)rv[g] <= limr) != 0) todo |= 1ull << g;
         while (todo != 0) {
             const int g = __builtin_ctzll(todo);
             todo &= todo - 1;
@@ -475,21 +500,15 @@ __global__ __launch_bounds__(64 * HC_WAVES, 1) void softcorr_coarse_kernel(const
     if (STAMP) {
         T[6] = __builtin_amdgcn_s_memtime() - tstart;
         if (lane == 0 && args.stamps)
-            for (int i = 0; i < 8; ++i) args.stamps[((size_t)blockIdx.x * HC_WAVES + wave) * 8 + i] = T[i];
+            for (int i = 0; i < 8; ++i) args.stamps[((size_t)blockIdx.x * W + wave) * 8 + i] = T[i];
     }
 }
 
-template <int QB, bool STAMP>
+template <int QB, bool STAMP, bool PACE, int W>
 static void launch_form(const HCArgs &a, int blocks, hipStream_t s) {
-    const int lds = hc_lds_bytes<QB>();
-    static const bool pace = [] { const char *e = getenv("DVM_K1_COARSE_PACE"); return !(e && atoi(e) == 0); }();   // (A/B measurements)
-    if (pace) {
-        ensure_dyn_lds((const void *)softcorr_coarse_kernel<QB, STAMP, true>, lds);
-        hipLaunchKernelGGL((softcorr_coarse_kernel<QB, STAMP, true>), dim3(blocks), dim3(64 * HC_WAVES), lds, s, a);
-    } else {
-        ensure_dyn_lds((const void *)softcorr_coarse_kernel<QB, STAMP, false>, lds);
-        hipLaunchKernelGGL((softcorr_coarse_kernel<QB, STAMP, false>), dim3(blocks), dim3(64 * HC_WAVES), lds, s, a);
-    }
+    const int lds = hc_lds_bytes<QB, W>();
+    ensure_dyn_lds((const void *)softcorr_coarse_kernel<QB, STAMP, PACE, W>, lds);
+    hipLaunchKernelGGL((softcorr_coarse_kernel<QB, STAMP, PACE, W>), dim3(blocks), dim3(64 * W), lds, s, a);
 }
 
 }  // namespace
@@ -503,9 +522,11 @@ void launch_norm_frags(const float *nrm, int B, int M, int Mpad, const int *amax
 // pass A for the groups in `a`, coarse screen; knf = key-side norm fragments of either group (launch_norm_frags).  `a` is laid
 // out for the 256-row workgroups of the other forms; this form re-derives its own tiling.
 void launch_coarse(const HBArgs &a, const char *knf0, const char *knf1, const int *amaxc, int blocks, hipStream_t s) {
-    static const int qb = [] { const char *e = getenv("DVM_K1_COARSE_QB"); return e && atoi(e) == 1 ? 1 : 2; }();   // (A/B measurements)
+    // (A/B measurements, temporary) DVM_K1_COARSE_FORM: 0 = 8 waves x 2 blocks, paced (default); 1 = unpaced; 2 = 8 waves x 1 block; 3 = 16 waves x 1 block
+    static const int form = [] { const char *e = getenv("DVM_K1_COARSE_FORM"); return e ? atoi(e) : 0; }();
+    const int qb = form >= 2 ? 1 : 2, W = form == 3 ? 16 : 8;
     HCArgs c;
-    const int rows = 32 * qb * HC_WAVES;
+    const int rows = 32 * qb * W;
     const int e0 = a.blocks0 / a.g[0].tiles, e1 = blocks > a.blocks0 ? (blocks - a.blocks0) / a.g[1].tiles : 0;   // batch entries per group
     for (int g = 0; g < 2; ++g) {
         const HBGroup &G = a.g[g];
@@ -520,16 +541,19 @@ void launch_coarse(const HBArgs &a, const char *knf0, const char *knf1, const in
     static const bool stamps_on = getenv("DVM_K1_STAMPS") != nullptr;
     if (stamps_on) {   // diagnostic: synchronous, allocates — never taken in production
         unsigned long long *dbuf = nullptr;
-        const size_t n = (size_t)nblocks * HC_WAVES * 8;
+        const size_t n = (size_t)nblocks * W * 8;
         if (hipMalloc(&dbuf, n * sizeof(unsigned long long)) != hipSuccess) return;
         (void)hipMemset(dbuf, 0, n * sizeof(unsigned long long));
         c.stamps = dbuf;
-        if (qb == 1) launch_form<1, true>(c, nblocks, s); else launch_form<2, true>(c, nblocks, s);
+        if (form == 3) launch_form<1, true, false, 16>(c, nblocks, s);
+        else if (form == 2) launch_form<1, true, false, 8>(c, nblocks, s);
+        else if (form == 1) launch_form<2, true, false, 8>(c, nblocks, s);
+        else launch_form<2, true, true, 8>(c, nblocks, s);
         (void)hipStreamSynchronize(s);
         unsigned long long *hbuf = (unsigned long long *)malloc(n * sizeof(unsigned long long));
         (void)hipMemcpy(hbuf, dbuf, n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         double tot[8] = {0, 0, 0, 0, 0, 0, 0, 0}, redo = 0, nw = 0;
-        for (size_t w = 0; w < (size_t)nblocks * HC_WAVES; ++w) {
+        for (size_t w = 0; w < (size_t)nblocks * W; ++w) {
             if (hbuf[w * 8 + 6] == 0) continue;   // (workgroup routed elsewhere)
             nw += 1;
             for (int i = 0; i < 7; ++i) tot[i] += (double)hbuf[w * 8 + i];
@@ -538,15 +562,18 @@ void launch_coarse(const HBArgs &a, const char *knf0, const char *knf1, const in
         }
         if (nw > 0) {
             const double st = tot[7] / nw * qb;   // 32 x 32 blocks per wave
-            fprintf(stderr, "K1 stamps (coarse, %d blocks per wave, %d workgroups): %.2f re-done records per wave; cycles per wave and 32 x 32 block: "
+            fprintf(stderr, "K1 stamps (coarse, %d waves x %d blocks, %d workgroups): %.2f re-done records per wave; cycles per wave and 32 x 32 block: "
                             "dma %.0f  chain %.0f  epilogue %.0f  redo %.0f  barrier %.0f  | whole kernel %.0f per block (%.0f blocks per wave)\n",
-                    qb, nblocks, redo / nw, tot[0] / nw / st, tot[1] / nw / st, tot[2] / nw / st, tot[3] / nw / st, tot[5] / nw / st, tot[6] / nw / st, st);
+                    W, qb, nblocks, redo / nw, tot[0] / nw / st, tot[1] / nw / st, tot[2] / nw / st, tot[3] / nw / st, tot[5] / nw / st, tot[6] / nw / st, st);
         }
         free(hbuf);
         (void)hipFree(dbuf);
         return;
     }
-    if (qb == 1) launch_form<1, false>(c, nblocks, s); else launch_form<2, false>(c, nblocks, s);
+    if (form == 3) launch_form<1, false, false, 16>(c, nblocks, s);
+    else if (form == 2) launch_form<1, false, false, 8>(c, nblocks, s);
+    else if (form == 1) launch_form<2, false, false, 8>(c, nblocks, s);
+    else launch_form<2, false, true, 8>(c, nblocks, s);
 }
 
 }  // namespace k1

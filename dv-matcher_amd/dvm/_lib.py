@@ -68,6 +68,7 @@ SIGNATURES = {
     "dvm_linear_wgrad_workspace_bytes": (c_size_t, [ctypes.c_long, c_int, c_int]),
     "dvm_linear_wgrad_ws_f32": (c_int, [_P, _P, ctypes.c_long, c_int, c_int, _P, _P, c_size_t, _P]),
     "dvm_set_deterministic": (c_int, [c_int]),
+    "dvm_get_deterministic": (c_int, []),
     "dvm_pair_destroy": (c_int, []),
     "dvm_argmin_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "dvm_argmin_exact_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),

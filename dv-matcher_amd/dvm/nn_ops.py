@@ -201,7 +201,13 @@ class _Uni3FCTrain(torch.autograd.Function):
         return feat, tmp
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, g_feat, g_tmp):
+        if ctx.arena is None:
+            # the activations live in a caller-side arena that the first backward releases (1.1 GB at 8 x 2048), and in the fused
+            # mode the gradients were ADDED into the parameters' buffers: a second pass through this node cannot be replayed
+            raise RuntimeError("dvm Uni3FC training node: backward ran already (its activation arena is released after the first pass; "
+                               "retain_graph / a second backward through the network is not supported — set DVM_NATIVE_TRAIN=0 for that)")
         table, where, k = ctx.meta[:3]
         feat, tmp = ctx.saved_tensors
         trainable = ctx.trainable

@@ -146,24 +146,16 @@ def linear(x, w, bias=None, res=None, bn=None, slope=1.0, channel_major=False, o
     return out
 
 
-_deterministic = [None]
-
-
 def set_deterministic(on=True):
     """Fixed summation order in LG-Net's backward (dvm_set_deterministic: ordered weight-gradient partials, SA backward without its
     split, sorted in-edge lists): parameter gradients are bit-reproducible from run to run.  Returns the previous setting."""
-    prev = bool(_lib.load().dvm_set_deterministic(1 if on else 0))
-    _deterministic[0] = bool(on)
-    return prev
+    return bool(_lib.load().dvm_set_deterministic(1 if on else 0))
 
 
 def is_deterministic():
-    if _deterministic[0] is None:   # the library's own default (DVM_DETERMINISTIC)
-        lib = _lib.load()
-        prev = lib.dvm_set_deterministic(0)
-        lib.dvm_set_deterministic(prev)
-        _deterministic[0] = bool(prev)
-    return _deterministic[0]
+    """The library's current setting (dvm_get_deterministic: the flag lives in the library — DVM_DETERMINISTIC, dvm_set_deterministic
+    from any caller — and is only READ here)."""
+    return bool(_lib.load().dvm_get_deterministic())
 
 
 def linear_wgrad(gy, x, out=None):
@@ -180,11 +172,7 @@ def linear_wgrad(gy, x, out=None):
         if dW.dtype != torch.float32 or not dW.is_contiguous() or dW.numel() != Co * K:
             raise ValueError("linear_wgrad: out must be a contiguous float32 tensor of %d x %d elements" % (Co, K))
     lib = _lib.load()
-    if _deterministic[0] is None:   # the library's own default (DVM_DETERMINISTIC)
-        prev = lib.dvm_set_deterministic(0)
-        lib.dvm_set_deterministic(prev)
-        _deterministic[0] = bool(prev)
-    if _deterministic[0]:   # per-chunk partial tiles added in chunk order (needs scratch)
+    if lib.dvm_get_deterministic():   # per-chunk partial tiles added in chunk order (needs scratch)
         nb = lib.dvm_linear_wgrad_workspace_bytes(R, Co, K)
         ws = workspace(nb, gy.device, "wgrad")
         check(lib.dvm_linear_wgrad_ws_f32(_p(gy), _p(x), R, Co, K, _p(dW), _p(ws), nb, _stream()), "dvm_linear_wgrad_ws_f32")

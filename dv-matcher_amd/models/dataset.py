@@ -300,6 +300,7 @@ class PartialDataset(Dataset):
     one of twelve precomputed view index files `index_partial/index_<shape>_view_<v>.txt` with more than
     `n_partial` points is drawn, re-ordered by FPS and cut to `n_partial` (2200)."""
     n_partial = 2200
+    resamples_coordinates = True   # a target's coordinates are a fresh random view on every access: never key a cache by its name
 
     def __getitem__(self, idx):
         idx1, idx2 = self.combinations[idx]

@@ -125,6 +125,7 @@ class GraphDeformLoss_Neural(nn.Module):
         # opt-in per-shape graph cache: a dict filled by geometry(..., shape_ids=...); the reference rebuilds
         # every graph on every call (models/loss.py:1325-1337).  Entries are keyed by (shape id, FPS start, point count)
         self.graph_cache = graph_cache
+        self.graph_cache_max = 4096     # entries kept when graph_cache is an OrderedDict (~60 KB each at N = 2048)
         self.device = 'cuda:0'
         self.w_dist, self.w_map, self.w_deform, self.w_self_rec = w_dist, w_map, w_deform, w_self_rec
         self.w_cd, self.w_arap, self.w_rank, self.w_img = w_cd, w_arap, w_rank, w_img
@@ -247,6 +248,11 @@ class GraphDeformLoss_Neural(nn.Module):
                 ent["_idx"] = idx[j].clone()
                 self.graph_cache[keys[b]] = ent
         ents = [self.graph_cache[k] for k in keys]
+        if hasattr(self.graph_cache, "move_to_end"):   # an OrderedDict is kept least-recently-used first and bounded
+            for k in keys:
+                self.graph_cache.move_to_end(k)
+            while len(self.graph_cache) > max(self.graph_cache_max, B):
+                self.graph_cache.popitem(last=False)
         g = {name: torch.stack([e[name] for e in ents]) for name in ents[0] if name != "_idx"}
         return g, torch.stack([e["_idx"] for e in ents])
 

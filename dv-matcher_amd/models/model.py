@@ -458,38 +458,56 @@ class Uni3FC(nn.Module, _VisualProjection):
         sas = (self.sa1, self.sa2, self.sa3, self.sa4)
         n2ps = (self.n2p_attention1, self.n2p_attention2, self.n2p_attention3, self.n2p_attention4, self.n2p_attention5,
                 self.n2p_attention6, self.n2p_attention7)
-        ts, bns = [], []
+        slots, bns = [], []   # (module, attribute) of every table entry, in table order
 
         def bn(m):
             bns.append(m)
-            return [m.weight, m.bias, m.running_mean, m.running_var]
+            return [(m, "weight"), (m, "bias"), (m, "running_mean"), (m, "running_var")]
         for seq in convs:
-            ts += [seq[0].weight] + bn(seq[1])
+            slots += [(seq[0], "weight")] + bn(seq[1])
         for sa in sas:
-            ts += [sa.k_conv.weight, sa.v_conv.weight, sa.v_conv.bias, sa.trans_conv.weight, sa.trans_conv.bias] + bn(sa.after_norm)
+            slots += [(sa.k_conv, "weight"), (sa.v_conv, "weight"), (sa.v_conv, "bias"), (sa.trans_conv, "weight"), (sa.trans_conv, "bias")] + bn(sa.after_norm)
         for m in n2ps:
-            ts += [m.q_conv.weight, m.k_conv.weight, m.v_conv.weight] + bn(m.bn1) + [m.ff[0].weight, m.ff[2].weight] + bn(m.bn2)
+            slots += [(m.q_conv, "weight"), (m.k_conv, "weight"), (m.v_conv, "weight")] + bn(m.bn1) + [(m.ff[0], "weight"), (m.ff[2], "weight")] + bn(m.bn2)
+        ts = [getattr(m, a) for m, a in slots]
         where = [i for i, t in enumerate(ts) if isinstance(t, nn.Parameter)]
+        self.__dict__["_tt_slots"] = slots
         return ts, where, [ts[i] for i in where], bns
 
     def _train_state(self):
         """_train_table() once per parameter set, not three times per step: (tensors, positions of the trainable ones, the
         trainable ones, BatchNorm modules, detached aliases for the pointer table, parameters fit the native path).  The 167
         attribute walks, `detach()`s and layout checks cost the host ~1 ms per step.  The entry is dropped whenever the module
-        is converted (`_apply`: .to / .cuda / .float), its mode changes or a state_dict is loaded, and it is re-validated on every
-        use against the first and last parameter objects and the first one's address; code that REPLACES a parameter object in
-        between (`net.conv6[0].weight = nn.Parameter(...)`) must call `invalidate_train_state()`."""
-        first, last = self.conv[0].weight, self.n2p_attention7.bn2.bias
+        is converted (`_apply`: .to / .cuda / .float), its mode changes or a state_dict is loaded, and it is re-validated on EVERY
+        use over ALL 167 entries: the owning module still holds the very tensor object that was cached (a replaced Parameter or
+        buffer, weight tying, parametrizations) and that tensor still lives at the cached address (`p.data = ...`) — two dictionary
+        look-ups and a data_ptr() per entry, ~40 us per step.  A mismatch rebuilds the table; nothing reads stale storage."""
         c = self.__dict__.get("_tt_cache")
-        if c is not None and c[0] is first and c[1] is last and c[2] == first.data_ptr():
-            return c[3]
+        if c is not None:
+            slots, ts, ptrs = c[0], c[2][0], c[1]
+            for (m, a), t, ptr in zip(slots, ts, ptrs):
+                cur = m._parameters.get(a)
+                if cur is None:
+                    cur = m._buffers.get(a)
+                if cur is not t or t.data_ptr() != ptr:
+                    c = None
+                    break
+            if c is not None:
+                return c[2]
         ts, where, trainable, bns = self._train_table()
         ok = (not any(t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda for t in ts)
               and len({(m.eps, m.momentum) for m in bns}) == 1 and bns[0].momentum is not None
               and all(m.track_running_stats for m in bns))
         state = (ts, where, trainable, bns, [t.detach() for t in ts], ok)
-        self.__dict__["_tt_cache"] = (first, last, first.data_ptr(), state)
+        self.__dict__["_tt_cache"] = (self.__dict__.pop("_tt_slots"), [t.data_ptr() for t in ts], state)
         return state
+
+    def __getstate__(self):
+        """(pickling / torch.save(net): without the cached pointer table — it holds a second reference to every tensor)"""
+        d = dict(super().__getstate__()) if hasattr(super(), "__getstate__") else dict(self.__dict__)
+        d.pop("_tt_cache", None)
+        d.pop("_tt_slots", None)
+        return d
 
     def invalidate_train_state(self):
         self.__dict__.pop("_tt_cache", None)

@@ -120,6 +120,7 @@ class SyntheticPairs:
 
     def batch(self, idx):
         i = torch.as_tensor(idx, device=self.v1.device)
+        self.last_names = (["syn-s%d" % int(j) for j in idx], ["syn-t%d" % int(j) for j in idx])   # identities of the shapes (--graph-cache)
         return self.v1[i], self.v2[i], self.d1[i], self.d2[i], self.dist1[i], self.dist2[i]
 
 
@@ -133,6 +134,10 @@ class DatasetPairs:
 
     def batch(self, idx):
         items = [self.data[i] for i in idx]
+        # identities of the batch's shapes for --graph-cache: the dataset's shape names — or None where an item's coordinates are
+        # drawn anew on every access (PartialDataset's random views): such shapes must not be cached
+        self.last_names = None if getattr(self.data, "resamples_coordinates", False) else \
+            ([str(it["shape1"]["name"]) for it in items], [str(it["shape2"]["name"]) for it in items])
         out = []
         for s, cap in (("shape1", self.N), ("shape2", self.M)):
             n = min(min(it[s]["xyz"].shape[0] for it in items), cap)
@@ -246,6 +251,11 @@ def main(argv=None):
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:
+            # a port of its own only for the single-rank case (DVM_DIST_ALWAYS): with more ranks every rank would pick a DIFFERENT
+            # free port and the rendezvous would hang until the store timeout — the launcher has to export one
+            if world > 1:
+                raise SystemExit("train_driver: WORLD_SIZE = %d but MASTER_PORT is not set (start the ranks with "
+                                 "`python -m torch.distributed.run --master-addr 127.0.0.1 --master-port P ...` or export it)" % world)
             import socket
             with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
                 sk.bind(("127.0.0.1", 0))
@@ -295,7 +305,8 @@ def main(argv=None):
         val_set = train_set if timing else SyntheticPairs(args.val_pairs or Bg, N, M, 2000, dev)
     crit = build_criterion(cfg, partial, min(N, M))
     if args.graph_cache:
-        crit.graph_cache = {}
+        import collections
+        crit.graph_cache = collections.OrderedDict()   # least-recently-used shapes are dropped beyond crit.graph_cache_max
     frac = (hi - lo) / Bg
     sync_each = os.environ.get("DVM_SYNC_EACH_STEP", "0") == "1"   # train.py logs loss.item() every iteration
 
@@ -333,13 +344,16 @@ def main(argv=None):
     # enqueued on its own stream BEFORE the network forward and joined in front of the criterion
     geo_stream = torch.cuda.Stream() if os.environ.get("DVM_PREFETCH_GEOMETRY", "1") == "1" else None
 
-    def cached_keys(idx, n1, n2):
-        """--graph-cache: (fixed FPS starts, shape ids) of the pairs `idx` — a shape's start is a hash of its id, so the same shape
-        always gets the same graph (the key of the cache is (id, start, point count))."""
-        ids1, ids2 = [("s", int(i)) for i in idx], [("t", int(i)) for i in idx]
-        s1 = torch.tensor([(int(i) * 2654435761 + 12345) % n1 for i in idx], dtype=torch.long)
-        s2 = torch.tensor([(int(i) * 2246822519 + 54321) % n2 for i in idx], dtype=torch.long)
-        return (s1, s2), (ids1, ids2)
+    def cached_keys(names, n1, n2):
+        """--graph-cache: (fixed FPS starts, shape ids) of a batch from the NAMES of its shapes (`names` = (sources, targets), as the
+        pair set recorded them for the batch; None = these coordinates are not cacheable).  A shape's start index is a hash of its
+        name, so the same shape gets the same graph in every pair and every epoch; the cache key is (name, start, point count)."""
+        if names is None:
+            return None, None
+        import zlib
+        s1 = torch.tensor([zlib.crc32(("s:" + nm).encode()) % n1 for nm in names[0]], dtype=torch.long)
+        s2 = torch.tensor([zlib.crc32(("s:" + nm).encode()) % n2 for nm in names[1]], dtype=torch.long)
+        return (s1, s2), (list(names[0]), list(names[1]))
 
     def prefetch_geometry(v1, v2, starts=None, shape_ids=None):
         if geo_stream is None:
@@ -363,7 +377,7 @@ def main(argv=None):
         v1, v2, d1, d2, dist1, dist2 = batch
         fit_criterion(crit, cfg, min(v1.shape[1], v2.shape[1]))
         t = time.perf_counter()
-        starts, shape_ids = cached_keys(pair_ids, v1.shape[1], v2.shape[1]) if (args.graph_cache and pair_ids is not None) else (None, None)
+        starts, shape_ids = cached_keys(pair_ids, v1.shape[1], v2.shape[1]) if (args.graph_cache and pair_ids is not None) else (None, None)   # pair_ids: the batch's shape names
         geo = prefetch_geometry(v1, v2, starts, shape_ids)
         f1, f2 = forward_pair(v1, d1, v2, d2)
         t = mark(0, t)
@@ -406,7 +420,10 @@ def main(argv=None):
             feed_ids = [shard(b) for b in global_batches(train_set.pairs, Bg)[:max(1, args.steps)]]
         else:   # every rank owns its own Bg/world pairs (weak-scaling shape of the forward bench)
             feed_ids = [list(range(lo, hi)) if train_set.pairs >= Bg else list(range(hi - lo))]
-        feed = [train_set.batch(ix) for ix in feed_ids]
+        feed, feed_names = [], []
+        for ix in feed_ids:
+            feed.append(train_set.batch(ix))
+            feed_names.append(train_set.last_names)
         losses = []
         if use_graph:
             # every draw the criterion makes on the host (dist-loss anchors, FPS starts) becomes a device-resident input of
@@ -443,7 +460,7 @@ def main(argv=None):
                 graph.replay()
                 return static_vals.clone()
         for i in range(args.warmup):
-            train_step(feed[i % len(feed)], alpha, feed_ids[i % len(feed)])
+            train_step(feed[i % len(feed)], alpha, feed_names[i % len(feed)])
         torch.cuda.synchronize()
         if dist_on:
             dist.barrier()
@@ -451,7 +468,7 @@ def main(argv=None):
             host_marks[:] = [0.0, 0.0, 0.0, 0.0, 0]
         t0 = time.perf_counter()
         for i in range(args.steps):
-            losses.append(train_step(feed[i % len(feed)], alpha, feed_ids[i % len(feed)]))
+            losses.append(train_step(feed[i % len(feed)], alpha, feed_names[i % len(feed)]))
         t_host = time.perf_counter() - t0          # all steps enqueued; the rest of dt is the GPU catching up
         torch.cuda.synchronize()
         if dist_on:
@@ -497,7 +514,8 @@ def main(argv=None):
         sums, iters = torch.zeros(5, device=dev), 0
         for b in global_batches(train_set.pairs, Bg, shuffle_seed=1000 * epoch, keep_tail=(world == 1)):   # the same order on every rank
             ix = shard(b) if len(b) == Bg else b
-            sums += torch.as_tensor(train_step(train_set.batch(ix), alpha, ix), device=dev)
+            batch = train_set.batch(ix)
+            sums += torch.as_tensor(train_step(batch, alpha, train_set.last_names), device=dev)
             iters += 1
             if rank == 0 and iters % int(cfg["misc"]["log_interval"]) == 0:    # per-epoch count, (i + 1) % log_interval (train.py:120-126)
                 save_ckpt(net, dfm, args.ckpt_dir, cfg["expname"], "train_best")

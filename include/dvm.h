@@ -120,6 +120,8 @@ int dvm_linear_wgrad_ws_f32(const float *gy, const float *x, long R, int Co, int
  * in-edge order of dvm_n2p_core_bwd_f32 — so that dvm_uni3fc_train_bwd_f32 returns the same bits on every run (measured:
  * LG-Net forward + backward, 2 x 8 x 2048 points, 18.5 ms instead of 14.3 ms).  Returns the previous setting; environment default DVM_DETERMINISTIC=1.  Process-wide. */
 int dvm_set_deterministic(int on);
+/* the current setting, read-only (a reader must not toggle the process-wide flag to learn it: another thread's backward could run in between) */
+int dvm_get_deterministic(void);
 
 /* knnsearch_t_grad + topk_pi (+ the argmax map)  —  models/loss.py:110-114,
  * 1339-1347, 1404-1407.   D = cdist(f1,f2) (matmul form, bit-identical squared
