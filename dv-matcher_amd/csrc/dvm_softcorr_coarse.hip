@@ -15,24 +15,28 @@
 //
 // Structure (the tile staging, the norm instruction, the exact keys and the selection network come from the three-product
 // "second form" of rounds 3 - 4, which this kernel replaced: profiles/notes_k1.md):
-//  * a wave owns QB = 2 blocks of 32 query rows (64 VGPRs of query fragments, as the two-plane form needs for one block): every
+//  * a wave owns 2 blocks of 32 query rows (64 VGPRs of query fragments, as the two-plane form needs for one block): every
 //    key fragment read from LDS feeds two matrix instructions, and a workgroup of 8 waves covers 512 query rows, so a pair's key
 //    plane is staged 4 times instead of 8;
-//  * key tiles of 64 keys x 256 B by LDS-DMA (two 1-KiB pieces per wave and tile + the norm fragments), 16-B chunks XOR-swizzled
-//    with the row number: a 256-byte row is one full bank row, the swizzle spreads the 16 rows of a ds_read_b128 lane group over
-//    the 16 chunk positions;
-//  * norms on the matrix pipe (a 9th instruction per block), exact 32-bit keys (accumulator bits + register number), the fixed
-//    selection network for the sorted three smallest of a lane's 16 keys;
+//  * key tiles of 64 keys x 256 B by LDS-DMA (buffer_load ... lds: two 1-KiB pieces per wave and tile + the norm fragments),
+//    16-B chunks XOR-swizzled with the row number: a 256-byte row is one full bank row, the swizzle spreads the 16 rows of a
+//    ds_read_b128 lane group over the 16 chunk positions; the two waves of a SIMD issue their pieces half a tile apart;
+//  * norms on the matrix pipe (a 9th instruction per block), exact 32-bit keys (accumulator bits + register number), a fixed
+//    selection network for the sorted three smallest of a lane's 16 keys: 46 three-input min / med / max instructions;
 //  * 32-bit list entries [key: 19 bits | sub-tile: 8 | half: 1 | register: 4]: a sorted insertion is ONE v_med3_u32 per slot
-//    (the packed doubles of the other forms take a v_min_f64 + v_max_f64 pair, at half rate).  19 key bits = 5 exponent bits +
-//    14 of the mantissa, rounded DOWN: 2^-14 of the accumulator, part of HC_ERR.  Lists of 12 per half-lane; the two smallest of
-//    a sub-tile go in unconditionally, the third is recorded (16 bits, one LDS slot per lane and record), and after the last
+//    (the packed doubles of the first form take a v_min_f64 + v_max_f64 pair).  19 key bits = 5 exponent bits + 14 of the
+//    mantissa, rounded DOWN: 2^-14 of the accumulator, part of HC_ERR.  Lists of 12 per half-lane; the two smallest of a
+//    sub-tile go in unconditionally, the third is recorded (16 bits, one LDS slot per lane and record), and after the last
 //    tile a record at or below the row's bound has its sub-tiles re-done from global memory;
 //  * no softmax terms, no cut, no bound updates in the sweep;
+//  * the next sub-tile's 18 matrix instructions and this sub-tile's ~190 vector instructions are interleaved BY HAND, one
+//    matrix instruction per slice of ~10 vector instructions, fenced (`fused`): what bounds the kernel is the SIMD's vector
+//    issue (4 cycles per instruction, shared by its two waves — 60 % busy over the kernel, the matrix pipe 27 %);
 //  * at the end the two half-lanes of a row merge into 16 entries; entries above lim = min of the two 12th entries (and of the
 //    larger of the two 8th) are dropped — each half-lane is complete only up to its own 12th —, so the largest entry written
 //    IS the completeness bound pass B certifies against.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "dvm_softcorr_f16.h"
 
@@ -41,7 +45,6 @@ namespace k1 {
 namespace {
 
 constexpr int HC_ROWB = 256;                   // bytes of a key row in LDS (h plane)
-constexpr int HC_KT = 64;                      // keys per LDS tile
 constexpr int HC_KL = 12;                      // list entries per half-lane
 constexpr unsigned HC_REMOVED = 0xffc00000u;   // keys / entries >= this: removed / invalid
 constexpr unsigned HC_KBASE = 129u << 23;      // bits(4.0f): bottom of the key window
@@ -49,15 +52,16 @@ constexpr float HC_FLOOR = 4.5f;               // added to every accumulator thr
 constexpr unsigned HC_EMASK = 0xffffe00fu;     // bits of a key that survive in a list entry (19 key bits + register number)
 constexpr int HC_MAX_M = 256 * 32;             // 8 bits of sub-tile number
 
-// W waves per workgroup (8: two per SIMD, software-pipelined; 16: four per SIMD, one sub-tile at a time), QB blocks of 32 query rows per wave
-template <int QB, int W> constexpr int hc_nrec() { return 512 / (QB * W); }   // third-key records per lane and block (64 KB of LDS in all)
-template <int QB, int W> constexpr int hc_lds_bytes() { return 2 * HC_KT * HC_ROWB + 2 * HC_KT * 32 + 1024 + W * QB * hc_nrec<QB, W>() * 64 * 2; }
+constexpr int HC_QB = 2;                       // blocks of 32 query rows per wave
+constexpr int HC_WAVES = 8;                    // waves per workgroup: 512 query rows
+constexpr int HC_NREC = 32;                    // third-key records per lane and block (64 KB of LDS in all)
+template <int KT> constexpr int hc_lds_bytes() { return 2 * KT * HC_ROWB + 2 * KT * 32 + 1024 + HC_WAVES * HC_QB * HC_NREC * 64 * 2; }
 
 struct HCGroup {
     const char *qp, *kp;      // planes of the query / key side [B][rows][512]: h plane = the first 256 B of a row
     const char *knf;          // key-side norm fragments [B][Mpad][32 B] (launch_norm_frags)
     const float *nq;          // |q|^2 (ATen order)
-    int N, M, Mpad, tiles;    // tiles: workgroups per batch entry (32 QB W query rows each)
+    int N, M, Mpad, tiles;    // tiles: workgroups per batch entry (512 query rows each)
     int32_t *cidx;            // [B][N][K1_KC_COARSE]
     float *cd2, *lsum;
 };
@@ -70,9 +74,24 @@ struct HCArgs {
     unsigned long long *stamps;   // diagnostic build only (DVM_K1_STAMPS): [block][wave][8] cycle totals per phase
 };
 
-__device__ __forceinline__ unsigned umin3(unsigned a, unsigned b, unsigned c) { return min(min(a, b), c); }
-__device__ __forceinline__ unsigned umax3(unsigned a, unsigned b, unsigned c) { return max(max(a, b), c); }
-__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) { return max(min(a, b), min(max(a, b), c)); }
+// three-input unsigned min / max / median as the instructions themselves: written as min / max expressions, instruction selection
+// forms them only where the inner two-input node has a single use, and the selection network shares those nodes (55 instead of
+// 46 instructions per block; the kernel is bound by its vector instructions: 4 cycles each on a SIMD, whichever wave issues)
+__device__ __forceinline__ unsigned umin3(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ unsigned umax3(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 // three fp16 pieces of a non-negative fp32 value x < 2^31:  x = p1 2^15 + p2 2^4 + p3 2^-7  (exact: 33 >= 24 bits)
 __device__ __forceinline__ void norm_pieces(float x, _Float16 &p1, _Float16 &p2, _Float16 &p3) {
@@ -123,6 +142,15 @@ __device__ __forceinline__ Top3 top3_of_16(const unsigned (&v)[16]) {
     return Top3{min(t.s0, x), umed3(t.s0, t.s1, x), umed3(t.s1, t.s2, x)};
 }
 
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
 // sorted list of K unsigned entries; insertion = one three-input median per slot
 template <int K>
 struct List32 {
@@ -146,12 +174,13 @@ __device__ __forceinline__ int entry_col(unsigned e) {
 }
 
 // STAMP: diagnostic build — every wave adds up the shader cycles (s_memtime) it spends per phase; no output depends on them.
-// Phases: 0 LDS-DMA issue, 1 matrix chain (until the accumulators are readable), 2 epilogue, 3 re-done sub-tiles, 5 barrier
+// Phases: 0 LDS-DMA issue, 1 matrix chain + epilogue (until the accumulators are readable), 3 re-done sub-tiles, 5 barrier
 // (incl. the wait for the wave's own DMA pieces), 6 whole kernel, 7 sub-tiles (re-done records counted in the high bits).
-template <int QB, bool STAMP = false, bool PACE = true, int W = 8>
-__global__ __launch_bounds__(64 * W, W / 4) void softcorr_coarse_kernel(const HCArgs args) {
-    constexpr int NREC = hc_nrec<QB, W>(), ROWS = 32 * QB * W;
-    constexpr bool PIPE = W == 8;   // two waves per SIMD: the next sub-tile's matrix chain is issued ahead of this one's epilogue
+// KT: keys per LDS tile (a multiple of 64: an even number of 32-key sub-tiles between two barriers).
+template <int KT, bool STAMP = false>
+__global__ __launch_bounds__(64 * HC_WAVES, 1) void softcorr_coarse_kernel(const HCArgs args) {
+    constexpr int QB = HC_QB, W = HC_WAVES, NREC = HC_NREC, ROWS = 32 * QB * W, SUBS = KT / 32;
+    static_assert(SUBS % 2 == 0 && KT * HC_ROWB / 1024 % W == 0 && KT * 32 / 1024 <= W, "coarse screen: tile size");
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
     unsigned long long T[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0, tstart = 0;
     if (STAMP) tstart = tlast = __builtin_amdgcn_s_memtime();
@@ -169,9 +198,9 @@ __global__ __launch_bounds__(64 * W, W / 4) void softcorr_coarse_kernel(const HC
             stamp(slot);
         }
     };
-    char *const ktile0 = smem_b;                                         // [2][HC_KT][256], 16-B chunks XOR-swizzled
-    char *const knf0 = smem_b + (size_t)2 * HC_KT * HC_ROWB;             // [2][HC_KT][32]
-    char *const dump0 = knf0 + 2 * HC_KT * 32;                           // 1 KiB nobody reads (see stage_tile)
+    char *const ktile0 = smem_b;                                         // [2][KT][256], 16-B chunks XOR-swizzled
+    char *const knf0 = smem_b + (size_t)2 * KT * HC_ROWB;                // [2][KT][32]
+    char *const dump0 = knf0 + 2 * KT * 32;                              // 1 KiB nobody reads (see stage_tile)
     unsigned short *const rec0 = (unsigned short *)(dump0 + 1024);       // [wave][block][NREC][64 lanes]
 
     int lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -218,36 +247,37 @@ __global__ __launch_bounds__(64 * W, W / 4) void softcorr_coarse_kernel(const HC
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) kb[qb].init();
 
-    const int ntiles = (M + HC_KT - 1) / HC_KT, nsub = 2 * ntiles;
+    const int ntiles = (M + KT - 1) / KT, nsub = SUBS * ntiles;
     const int rgrp = (nsub + NREC - 1) / NREC;          // sub-tiles per record
     unsigned short *const rec = rec0 + (size_t)wave * QB * NREC * 64 + lane;
     unsigned urec[QB];                                  // smallest third key of the current record's sub-tiles
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) urec[qb] = 0xffffffffu;
 
-    // Key tiles go global -> LDS by LDS-DMA, 1 KiB = 4 rows of 256 B per wave instruction, 2 per wave and tile.  Lane L of
-    // piece p delivers position L & 15 of LDS row 4 p + (L >> 4), which holds chunk (L & 15) ^ (row & 15) of the key.  The
-    // per-lane offsets are re-formed for every tile from the lane number (v_mbcnt): anything kept in a vector register across
-    // the tile for this is spilled, and a scratch reload next to the DMA issue waits, through vmcnt, for every piece in flight.
+    // Key tiles go global -> LDS by LDS-DMA (buffer_load ... lds: a scalar resource descriptor per source array, a 32-bit
+    // per-lane offset, a scalar tile offset), 1 KiB = 4 rows of 256 B per wave instruction.  Lane L of piece p delivers position
+    // L & 15 of LDS row 4 p + (L >> 4), which holds chunk (L & 15) ^ (row & 15) of the key.  The per-lane offsets are re-formed
+    // for every tile from the lane number (v_mbcnt): anything kept in a vector register across the tile for this is spilled,
+    // and a scratch reload next to the DMA issue waits, through vmcnt, for every piece in flight.
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void *)kbase, 0, M * HB_ROWB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t nrs = __builtin_amdgcn_make_buffer_rsrc((void *)nfbase, 0, G.Mpad * 32, 0x00020000);
     auto stage_tile = [&](int t, int buf, bool clamp) __attribute__((always_inline)) {
         int lane;   // (a volatile statement: otherwise the offsets are hoisted out of the loop as invariants — and spilled)
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
-        const int j0 = t * HC_KT;
-        const char *tb = kbase + (size_t)j0 * HB_ROWB;   // wave-uniform
-        char *kt = ktile0 + (size_t)buf * HC_KT * HC_ROWB;
-        constexpr int PIECES = HC_KT * HC_ROWB / 1024 / W;
+        const int j0 = t * KT;
+        char *kt = ktile0 + (size_t)buf * KT * HC_ROWB;
+        constexpr int PIECES = KT * HC_ROWB / 1024 / W, NP = KT * 32 / 1024;
 #pragma unroll
         for (int e = 0; e < PIECES; ++e) {
             const int piece = wave * PIECES + e;
             const int r = 4 * piece + (lane >> 4), rc = clamp ? min(r, M - 1 - j0) : r;
             const unsigned off = rc * HB_ROWB + (((lane & 15) ^ (r & 15)) << 4);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tb + off),
-                                             (__attribute__((address_space(3))) void *)(kt + piece * 1024), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (__attribute__((address_space(3))) void *)(kt + piece * 1024), 16, off, j0 * HB_ROWB, 0, 0);
         }
-        // 64 keys x 32 B of norm fragments = two 1-KiB pieces, brought by waves 0 and 1; the other six waves issue the same
-        // instruction into a dump area (destination chosen by a scalar select): no branch that would cut the scheduling region
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(nfbase + (size_t)j0 * 32 + (wave & 1) * 1024 + lane * 16),
-                                         (__attribute__((address_space(3))) void *)(wave < 2 ? knf0 + buf * HC_KT * 32 + wave * 1024 : dump0), 16, 0, 0);
+        // KT keys x 32 B of norm fragments = NP 1-KiB pieces, brought by the first NP waves; the others issue the same instruction
+        // into a dump area (destination chosen by a scalar select): no branch here
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(nrs, (__attribute__((address_space(3))) void *)(wave < NP ? knf0 + buf * KT * 32 + wave * 1024 : dump0), 16,
+                                                 (wave < NP ? wave : 0) * 1024 + lane * 16, j0 * 32, 0, 0);
     };
     // every wave first waits for ITS OWN pieces (vmcnt), then joins the barrier: the compiler places its own vmcnt wait only in
     // front of the wave's next LDS read, which orders nothing for the rows the OTHER waves were to deliver
@@ -276,38 +306,20 @@ __global__ __launch_bounds__(64 * W, W / 4) void softcorr_coarse_kernel(const HC
     struct Acc {
         f32x16 a[QB];
     };
-    // the matrix work of one sub-tile: per block 8 product instructions + the norm instruction, every key fragment used QB times
+    // the matrix work of one sub-tile: per block 8 product instructions + the norm instruction (last: every partial sum before it
+    // has the magnitude of q.k), every key fragment used QB times.  (Plain form: the first sub-tile and a ragged last tile.)
     auto chain = [&](int buf, int sub) __attribute__((always_inline)) -> Acc {   // buf, sub: literals after inlining
-        const int toff = buf * (HC_KT * HC_ROWB) + sub * (32 * HC_ROWB);
+        const int toff = buf * (KT * HC_ROWB) + sub * (32 * HC_ROWB);
         Acc A;
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) A.a[qb] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        // Fragments in four batches of 2 k-steps (8 VGPRs each), two batches in flight: left alone, the scheduler requests all
-        // nine reads of a sub-tile at once next to the previous sub-tile's epilogue — and what does not fit is spilled.
-        f16x8 ah[4][2];
-        auto reads = [&](int q) __attribute__((always_inline)) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) ah[q][u] = lds16(fadr[2 * q + u], toff);
-        };
-        auto products = [&](int q) __attribute__((always_inline)) {
+        for (int s = 0; s < 8; ++s) {
+            const f16x8 fr = lds16(fadr[s], toff);
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb) A.a[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q][u], qh[qb][2 * q + u], A.a[qb], 0, 0, 0);
-        };
-        reads(0);
-        reads(1);
-        const f16x8 an = lds16(nadr, buf * (HC_KT * 32) + sub * (32 * 32));
-        if (!PACE) __builtin_amdgcn_sched_barrier(0x00E);   // (vector, scalar and matrix instructions may cross, LDS reads not)
-        products(0);
-        reads(2);
-        if (!PACE) __builtin_amdgcn_sched_barrier(0x00E);
-        products(1);
-        reads(3);
-        if (!PACE) __builtin_amdgcn_sched_barrier(0x00E);
-        products(2);
-        products(3);
-        // the norms last: every partial sum before it has the magnitude of q.k
+            for (int qb = 0; qb < QB; ++qb) A.a[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr, qh[qb][s], A.a[qb], 0, 0, 0);
+        }
+        const f16x8 an = lds16(nadr, buf * (KT * 32) + sub * (32 * 32));
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) A.a[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(an, qn[qb], A.a[qb], 0, 0, 0);
         return A;
@@ -317,12 +329,12 @@ __global__ __launch_bounds__(64 * W, W / 4) void softcorr_coarse_kernel(const HC
     auto make_keys = [&](const f32x16 &acc, unsigned (&v)[16], int jb, bool mask_pads) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            v[r] = (__float_as_uint(acc[r]) << 4) + ((unsigned)r - (HC_KBASE << 4));   // one v_lshl_add_u32 (constant in an SGPR)
+            v[r] = (__float_as_uint(acc[r]) << 4) + ((unsigned)r - (HC_KBASE << 4));   // one v_lshl_add_u32
             if (mask_pads) v[r] = jb + (r & 3) + 8 * (r >> 2) < M ? v[r] : (HC_REMOVED | r);
         }
     };
     const unsigned h4 = (unsigned)h << 4;
-    // one sub-tile, straight-line: keys, sorted three smallest, the two smallest into the list, the third into the record
+    // one sub-tile: keys, sorted three smallest, the two smallest into the list, the third into the record (plain form)
     auto epilogue = [&](const Acc &A, int s, bool mask_pads) __attribute__((always_inline)) {
         const unsigned sh = ((unsigned)s << 5) | h4;
 #pragma unroll
@@ -335,74 +347,131 @@ __global__ __launch_bounds__(64 * W, W / 4) void softcorr_coarse_kernel(const HC
             // (branch-free: a record is rewritten by every sub-tile of its group with the running minimum)
             urec[qb] = (s % rgrp == 0) ? w.s2 : min(urec[qb], w.s2);
             rec[(qb * NREC + s / rgrp) * 64] = (unsigned short)(urec[qb] >> 16);
-            stamp_after(2, (int)(w.s2 ^ kb[qb].e[0]));
         }
     };
 
-    // PACE: the scheduling region that ends here holds the matrix chain of the NEXT sub-tile (9 QB instructions, 9 LDS reads) and
-    // this sub-tile's selection + insertions (~105 QB vector instructions).  A wave issues in order: a run of matrix instructions
-    // parks it at the matrix pipe (32 cycles each) while its vector instructions wait, and the two waves of a SIMD, released by
-    // the same barrier, then do the same thing at the same time.  Ask for one matrix instruction per VPM vector instructions, the
-    // first five fragment reads up front and the other two pairs behind the 2 QB-th and the 4 QB-th matrix instruction.
-    auto pace = [&]() __attribute__((always_inline)) {
-        if (PACE) {
-            constexpr int NM = 9 * QB, VPM = 11;
-            __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+    // The hot form of the same two things — the matrix chain of the NEXT sub-tile, the epilogue of this one — written out as 18
+    // groups of ONE matrix instruction + one slice of the epilogue (~10 vector instructions), fenced so that the order stands.  A
+    // wave issues in order: behind a run of matrix instructions it is parked at the matrix pipe (32 cycles each) while its vector
+    // instructions wait, and what bounds this kernel is the SIMD's vector issue — 4 cycles per instruction whichever of its two
+    // waves issues it (measured: a wave's 18 + ~190 instructions of a sub-tile take ~1 800 cycles beside its partner's, ~900 being
+    // its own issue time).  Fragment reads are requested three k-steps ahead of their use.  Block qb's epilogue rides on the
+    // matrix instructions of the groups [9 qb, 9 qb + 9).
+    struct Epi {
+        unsigned v[16];
+        Top3 A, B, C, D, E, AB, CD, CDE, T, w;
+        unsigned m00, e0, e1;
+    };
+    auto epi_slice = [&](auto sc, Epi &S, const f32x16 &acc, int qb, int s) __attribute__((always_inline)) {
+        constexpr int SL = decltype(sc)::value;
+        auto key = [&](int r) __attribute__((always_inline)) { return (__float_as_uint(acc[r]) << 4) + ((unsigned)r - (HC_KBASE << 4)); };
+        if constexpr (SL == 0) {
 #pragma unroll
-            for (int i = 0; i < NM; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (i == 2 * QB - 1 || i == 4 * QB - 1) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
-            }
+            for (int r = 0; r < 11; ++r) S.v[r] = key(r);
+        } else if constexpr (SL == 1) {
+#pragma unroll
+            for (int r = 11; r < 16; ++r) S.v[r] = key(r);
+            S.A = sort3(S.v[0], S.v[1], S.v[2]);
+            S.B = sort3(S.v[3], S.v[4], S.v[5]);
+        } else if constexpr (SL == 2) {
+            S.C = sort3(S.v[6], S.v[7], S.v[8]);
+            S.D = sort3(S.v[9], S.v[10], S.v[11]);
+            S.E = sort3(S.v[12], S.v[13], S.v[14]);
+        } else if constexpr (SL == 3) {
+            S.AB = merge3(S.A, S.B);
+            S.m00 = max(S.C.s0, S.D.s0);
+            S.CD.s0 = min(S.C.s0, S.D.s0);
+            S.CD.s1 = umin3(S.m00, S.C.s1, S.D.s1);
+        } else if constexpr (SL == 4) {
+            S.CD.s2 = min(umin3(S.C.s2, S.D.s2, max(S.C.s1, S.D.s0)), max(S.C.s0, S.D.s1));
+            S.CDE = merge3(S.CD, S.E);
+        } else if constexpr (SL == 5) {
+            S.T = merge3(S.AB, S.CDE);
+            const unsigned x = S.v[15];
+            S.w = Top3{(unsigned)min(S.T.s0, x), umed3(S.T.s0, S.T.s1, x), umed3(S.T.s1, S.T.s2, x)};
+            const unsigned sh = ((unsigned)s << 5) | h4;
+            S.e0 = make_entry(S.w.s0, sh);
+            S.e1 = make_entry(S.w.s1, sh);
+        } else if constexpr (SL == 6) {
+            kb[qb].insert(S.e0);
+        } else if constexpr (SL == 7) {
+            kb[qb].insert(S.e1);
+        } else {
+            urec[qb] = (s % rgrp == 0) ? S.w.s2 : min(urec[qb], S.w.s2);
+            rec[(qb * NREC + s / rgrp) * 64] = (unsigned short)(urec[qb] >> 16);
         }
     };
-    const bool ragged = (M & (HC_KT - 1)) != 0;   // the last tile holds padding keys
+    // -> accumulators of sub-tile (buf, sub); `cur`: accumulators of sub-tile s (complete), whose epilogue runs meanwhile
+    auto fused = [&](int buf, int sub, const Acc &cur, int s) __attribute__((always_inline)) -> Acc {   // buf, sub: literals after inlining
+        const int toff = buf * (KT * HC_ROWB) + sub * (32 * HC_ROWB);
+        Acc A;
+        f16x8 fr[8], an;
+        Epi S[QB];
+        fr[0] = lds16(fadr[0], toff);
+        fr[1] = lds16(fadr[1], toff);
+        fr[2] = lds16(fadr[2], toff);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 9 * QB>([&](auto gc) __attribute__((always_inline)) {
+            constexpr int g = decltype(gc)::value, ks = g / QB, qb = g % QB;   // matrix instruction: k-step ks (8 = the norms) of block qb
+            constexpr int eb = g / 9, sl = g % 9;                             // epilogue slice sl of block eb
+            if constexpr (qb == 0 && ks + 3 < 8) fr[ks + 3] = lds16(fadr[ks + 3], toff);
+            if constexpr (qb == 0 && ks == 5) an = lds16(nadr, buf * (KT * 32) + sub * (32 * 32));
+            if constexpr (ks == 0) A.a[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[0], qh[qb][0], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            else if constexpr (ks < 8) A.a[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[ks], qh[qb][ks], A.a[qb], 0, 0, 0);
+            else A.a[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(an, qn[qb], A.a[qb], 0, 0, 0);
+            epi_slice(std::integral_constant<int, sl>{}, S[eb], cur.a[eb], eb, s);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        return A;
+    };
+
+    const bool ragged = M % KT != 0;   // the last tile holds padding keys
     auto stage = [&](int t, int buf) __attribute__((always_inline)) {
         if (t < ntiles) {
             if (ragged && t + 1 == ntiles) stage_tile(t, buf, true); else stage_tile(t, buf, false);
         }
     };
+    // Tile t + 1 is requested at the top of tile t, into the buffer whose last reads lie before the previous barrier — by the
+    // first half of the waves.  The second half (their SIMD partners) brings ITS pieces half a tile earlier: tile t + 2 behind the
+    // barrier of tile t, into the buffer whose last reads lie in front of that barrier — so that the two waves of a SIMD do not
+    // both stand at the LDS-DMA issue at the same time.
+    const bool late = wave >= W / 2;
     stage(0, 0);
+    if (late) stage(1, 1);
     dma_barrier();
-    if (!PIPE) {
-        // four waves per SIMD: a wave does one sub-tile at a time (chain, then epilogue); what overlaps its vector work with
-        // matrix work is the other three waves
-        auto tile = [&](int t, int buf) __attribute__((always_inline)) {   // buf: literal after inlining
-            stage(t + 1, buf ^ 1);   // (last read before the previous barrier)
-            stamp(0);
-            const bool pads = ragged && t + 1 == ntiles;
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-                const Acc a = chain(buf, sub);
-                stamp_after(1, __float_as_int(a.a[QB - 1][0]));
-                if (pads) epilogue(a, 2 * t + sub, true); else epilogue(a, 2 * t + sub, false);
-            }
-            dma_barrier();
-            stamp(5);
-            T[7] += 2;
-        };
-        for (int t = 0; t < ntiles; t += 2) {
-            tile(t, 0);
-            if (t + 1 < ntiles) tile(t + 1, 1);
-        }
-    } else {
-        // software pipeline: the matrix chain of the next sub-tile is issued ahead of the epilogue of the current one
-        Acc a0 = chain(0, 0);
+    {
+        // software pipeline across the sub-tiles of the whole sweep: accumulator sets alternate (even sub-tiles a[0], odd a[1])
+        Acc a[2];
+        a[0] = chain(0, 0);
         auto tile = [&](int t, int buf, bool last) __attribute__((always_inline)) {   // buf, last: literals after inlining
-            if (!last) stage(t + 1, buf ^ 1);   // (last read — second sub-tile of tile t - 1 — before the previous barrier)
+            if (!last && !late) stage(t + 1, buf ^ 1);
             stamp(0);
-            const Acc a1 = chain(buf, 1);
-            stamp_after(1, __float_as_int(a1.a[QB - 1][0]));
-            if (last && ragged) epilogue(a0, 2 * t, true); else { epilogue(a0, 2 * t, false); pace(); }
+            const bool plain = last && ragged;
+#pragma unroll
+            for (int sub = 1; sub < SUBS; ++sub) {
+                if (!plain) {
+                    a[sub & 1] = fused(buf, sub, a[(sub & 1) ^ 1], t * SUBS + sub - 1);
+                } else {
+                    a[sub & 1] = chain(buf, sub);
+                    epilogue(a[(sub & 1) ^ 1], t * SUBS + sub - 1, true);
+                }
+                stamp_after(1, __float_as_int(a[sub & 1].a[QB - 1][0]));
+            }
             dma_barrier();
             stamp(5);
-            if (!last) {
-                a0 = chain(buf ^ 1, 0);
-                stamp_after(1, __float_as_int(a0.a[QB - 1][0]));
+            if (late && !last) {
+                stage(t + 2, buf);
+                stamp(0);
             }
-            if (last && ragged) epilogue(a1, 2 * t + 1, true); else { epilogue(a1, 2 * t + 1, false); if (!last) pace(); }
-            T[7] += 2;
+            if (!last) {
+                a[0] = fused(buf ^ 1, 0, a[1], t * SUBS + SUBS - 1);
+                stamp_after(1, __float_as_int(a[0].a[QB - 1][0]));
+            } else if (plain) {
+                epilogue(a[1], t * SUBS + SUBS - 1, true);
+            } else {
+                epilogue(a[1], t * SUBS + SUBS - 1, false);
+            }
+            T[7] += SUBS;
         };
         // (the last tile is peeled off so that inside the loop the next chain is unconditional)
         int t = 0;
@@ -450,7 +519,7 @@ __global__ __launch_bounds__(64 * W, W / 4) void softcorr_coarse_kernel(const HC
             for (int s = g * rgrp; s < (g + 1) * rgrp && s < nsub; ++s) {
                 const int j = s * 32 + r32, jc = j < M ? j : M - 1;
                 const char *arow = kbase + (size_t)jc * HB_ROWB + 16 * h;
-                const f16x8 an = *(const f16x8 *)(nfbase + (size_t)j * 32 + 16 * h);
+                const f16x8 an = *(const f16x8 *)(nfbase + (size_t)jc * 32 + 16 * h);   // (padding keys: masked below)
                 f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8 *)(arow + 32 * u), qh[qb][u], acc, 0, 0, 0);
@@ -500,15 +569,15 @@ __global__ __launch_bounds__(64 * W, W / 4) void softcorr_coarse_kernel(const HC
     if (STAMP) {
         T[6] = __builtin_amdgcn_s_memtime() - tstart;
         if (lane == 0 && args.stamps)
-            for (int i = 0; i < 8; ++i) args.stamps[((size_t)blockIdx.x * W + wave) * 8 + i] = T[i];
+            for (int i = 0; i < 8; ++i) args.stamps[((size_t)blockIdx.x * HC_WAVES + wave) * 8 + i] = T[i];
     }
 }
 
-template <int QB, bool STAMP, bool PACE, int W>
+template <int KT, bool STAMP>
 static void launch_form(const HCArgs &a, int blocks, hipStream_t s) {
-    const int lds = hc_lds_bytes<QB, W>();
-    ensure_dyn_lds((const void *)softcorr_coarse_kernel<QB, STAMP, PACE, W>, lds);
-    hipLaunchKernelGGL((softcorr_coarse_kernel<QB, STAMP, PACE, W>), dim3(blocks), dim3(64 * W), lds, s, a);
+    const int lds = hc_lds_bytes<KT>();
+    ensure_dyn_lds((const void *)softcorr_coarse_kernel<KT, STAMP>, lds);
+    hipLaunchKernelGGL((softcorr_coarse_kernel<KT, STAMP>), dim3(blocks), dim3(64 * HC_WAVES), lds, s, a);
 }
 
 }  // namespace
@@ -522,11 +591,9 @@ void launch_norm_frags(const float *nrm, int B, int M, int Mpad, const int *amax
 // pass A for the groups in `a`, coarse screen; knf = key-side norm fragments of either group (launch_norm_frags).  `a` is laid
 // out for the 256-row workgroups of the other forms; this form re-derives its own tiling.
 void launch_coarse(const HBArgs &a, const char *knf0, const char *knf1, const int *amaxc, int blocks, hipStream_t s) {
-    // (A/B measurements, temporary) DVM_K1_COARSE_FORM: 0 = 8 waves x 2 blocks, paced (default); 1 = unpaced; 2 = 8 waves x 1 block; 3 = 16 waves x 1 block
-    static const int form = [] { const char *e = getenv("DVM_K1_COARSE_FORM"); return e ? atoi(e) : 0; }();
-    const int qb = form >= 2 ? 1 : 2, W = form == 3 ? 16 : 8;
+    constexpr int kt = 64;   // keys per LDS tile (128 — half the barriers, 137 KB of LDS — measured 5 % slower: profiles/notes_k1.md)
     HCArgs c;
-    const int rows = 32 * qb * W;
+    const int rows = 32 * HC_QB * HC_WAVES;
     const int e0 = a.blocks0 / a.g[0].tiles, e1 = blocks > a.blocks0 ? (blocks - a.blocks0) / a.g[1].tiles : 0;   // batch entries per group
     for (int g = 0; g < 2; ++g) {
         const HBGroup &G = a.g[g];
@@ -541,19 +608,16 @@ void launch_coarse(const HBArgs &a, const char *knf0, const char *knf1, const in
     static const bool stamps_on = getenv("DVM_K1_STAMPS") != nullptr;
     if (stamps_on) {   // diagnostic: synchronous, allocates — never taken in production
         unsigned long long *dbuf = nullptr;
-        const size_t n = (size_t)nblocks * W * 8;
+        const size_t n = (size_t)nblocks * HC_WAVES * 8;
         if (hipMalloc(&dbuf, n * sizeof(unsigned long long)) != hipSuccess) return;
         (void)hipMemset(dbuf, 0, n * sizeof(unsigned long long));
         c.stamps = dbuf;
-        if (form == 3) launch_form<1, true, false, 16>(c, nblocks, s);
-        else if (form == 2) launch_form<1, true, false, 8>(c, nblocks, s);
-        else if (form == 1) launch_form<2, true, false, 8>(c, nblocks, s);
-        else launch_form<2, true, true, 8>(c, nblocks, s);
+        launch_form<kt, true>(c, nblocks, s);
         (void)hipStreamSynchronize(s);
         unsigned long long *hbuf = (unsigned long long *)malloc(n * sizeof(unsigned long long));
         (void)hipMemcpy(hbuf, dbuf, n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         double tot[8] = {0, 0, 0, 0, 0, 0, 0, 0}, redo = 0, nw = 0;
-        for (size_t w = 0; w < (size_t)nblocks * W; ++w) {
+        for (size_t w = 0; w < (size_t)nblocks * HC_WAVES; ++w) {
             if (hbuf[w * 8 + 6] == 0) continue;   // (workgroup routed elsewhere)
             nw += 1;
             for (int i = 0; i < 7; ++i) tot[i] += (double)hbuf[w * 8 + i];
@@ -561,19 +625,16 @@ void launch_coarse(const HBArgs &a, const char *knf0, const char *knf1, const in
             tot[7] += (double)(hbuf[w * 8 + 7] & 0xfffff);
         }
         if (nw > 0) {
-            const double st = tot[7] / nw * qb;   // 32 x 32 blocks per wave
-            fprintf(stderr, "K1 stamps (coarse, %d waves x %d blocks, %d workgroups): %.2f re-done records per wave; cycles per wave and 32 x 32 block: "
-                            "dma %.0f  chain %.0f  epilogue %.0f  redo %.0f  barrier %.0f  | whole kernel %.0f per block (%.0f blocks per wave)\n",
-                    W, qb, nblocks, redo / nw, tot[0] / nw / st, tot[1] / nw / st, tot[2] / nw / st, tot[3] / nw / st, tot[5] / nw / st, tot[6] / nw / st, st);
+            const double st = tot[7] / nw * HC_QB;   // 32 x 32 blocks per wave
+            fprintf(stderr, "K1 stamps (coarse screen, %d keys per tile, %d workgroups): %.2f re-done records per wave; cycles per wave and 32 x 32 block: "
+                            "dma %.0f  chain + epilogue %.0f  redo %.0f  barrier %.0f  | whole kernel %.0f per block (%.0f blocks per wave)\n",
+                    kt, nblocks, redo / nw, tot[0] / nw / st, tot[1] / nw / st, tot[3] / nw / st, tot[5] / nw / st, tot[6] / nw / st, st);
         }
         free(hbuf);
         (void)hipFree(dbuf);
         return;
     }
-    if (form == 3) launch_form<1, false, false, 16>(c, nblocks, s);
-    else if (form == 2) launch_form<1, false, false, 8>(c, nblocks, s);
-    else if (form == 1) launch_form<2, false, false, 8>(c, nblocks, s);
-    else launch_form<2, false, true, 8>(c, nblocks, s);
+    launch_form<kt, false>(c, nblocks, s);
 }
 
 }  // namespace k1

@@ -615,19 +615,16 @@ static inline long hr_quads(const HRArgs &r) { return (r.rows0 + 3) / 4 + (r.row
 // entry that can rank among the first `need` OR lie within the softmax cut is evaluated exactly, the others owe no term, and the
 // row is certified only if no column outside the evaluated ones can do either.
 // GATED: the second pass behind k1_gate_kernel — only the directions it sent back to the first form (route == K1_ROUTE_LEAN).
-template <int KC, bool COARSE, int HR4W, bool GATED = false>
-__global__ __launch_bounds__(256) void softcorr_refine_kernel(const HRArgs args) {
+template <int KC, bool COARSE, int HR4W, bool GATED>
+__device__ __forceinline__ void refine_quad(const HRArgs &args, long quad, char *hr_lds) {
     constexpr int SLOTS = 4 * KC, NL = SLOTS / 16;     // candidate rows of a wave; loads per lane and 64-byte piece
-    __shared__ __attribute__((aligned(16))) char hr_lds[4 * 2 * SLOTS * 64];
     const int lane = threadIdx.x & 63, l16 = lane & 15, base = lane & 48;
     const float neg_alpha = args.neg_alpha;
     const int topk = args.topk;
     const bool cand = l16 < KC;
     // A quad (the 4 rows of a wave) never straddles the two groups, so the group - and with it every pointer of HRGroup - is
     // wave-uniform and lives in scalar registers (per-lane groups cost ~20 VGPRs, which is a wave per SIMD).
-    const long nq0 = (args.rows0 + 3) / 4, nquads = nq0 + (args.rows_total - args.rows0 + 3) / 4;
-    const long quad = ((long)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x) >> 6;   // one quad per wave
-    if (quad >= nquads) return;
+    const long nq0 = (args.rows0 + 3) / 4;
     HRRow p;
     {
         const int qd = __builtin_amdgcn_readfirstlane((int)quad);
@@ -809,6 +806,25 @@ __global__ __launch_bounds__(256) void softcorr_refine_kernel(const HRArgs args)
             if (G.sum) G.sum[row] = lsm;
         }
     }
+}
+// one quad per wave (XCD-aware numbering: a pair's key rows in one L2)
+template <int KC, bool COARSE, int HR4W>
+__global__ __launch_bounds__(256) void softcorr_refine_kernel(const HRArgs args) {
+    __shared__ __attribute__((aligned(16))) char hr_lds[4 * 2 * 4 * KC * 64];
+    const long nquads = (args.rows0 + 3) / 4 + (args.rows_total - args.rows0 + 3) / 4;
+    const long quad = ((long)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x) >> 6;
+    if (quad < nquads) refine_quad<KC, COARSE, HR4W, false>(args, quad, hr_lds);
+}
+// the gate's second pass: a small grid whose waves walk the quads — it returns at once (every wave, after one scalar load per
+// direction) in the usual case that the gate sent nothing back
+template <int KC, int HR4W>
+__global__ __launch_bounds__(256) void softcorr_refine_gated_kernel(const HRArgs args) {
+    __shared__ __attribute__((aligned(16))) char hr_lds[4 * 2 * 4 * KC * 64];
+    const long nq0 = (args.rows0 + 3) / 4, nquads = nq0 + (args.rows_total - args.rows0 + 3) / 4;
+    const bool on0 = args.route[0] == K1_ROUTE_LEAN, on1 = nquads > nq0 && args.route[args.nb] == K1_ROUTE_LEAN;
+    if (!on0 && !on1) return;
+    const long nw = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long quad = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; quad < nquads; quad += nw) refine_quad<KC, false, HR4W, true>(args, quad, hr_lds);
 }
 
 // The coarse screen serves a direction well only while few of its rows fail pass B's certification: a flagged row costs the
@@ -1293,7 +1309,7 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
             a.route = route2, r.route = route2;
             ensure_dyn_lds((const void *)softcorr_sweep_f16_kernel<true>, (int)HB_LDS_BYTES);
             hipLaunchKernelGGL(softcorr_sweep_f16_kernel<true>, dim3(blocks), dim3(HB_THREADS), HB_LDS_BYTES, s, a);
-            hipLaunchKernelGGL((softcorr_refine_kernel<HB_KC, false, 3, true>), grid, dim3(256), 0, s, r);
+            hipLaunchKernelGGL((softcorr_refine_gated_kernel<HB_KC, 3>), dim3(4096), dim3(256), 0, s, r);
         }
     }
     prof_end(s, DVM_PROF_K1_REFINE);
