@@ -1,5 +1,4 @@
-# the whole -m gpu suite + smoke
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/full
-python -m pytest tests -m gpu -q --timeout 900 > gpurun_out/full/gpu_tests.log 2>&1; echo "rc=$?" >> gpurun_out/full/gpu_tests.log
-tail -6 gpurun_out/full/gpu_tests.log
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu | tail -2
+# the whole GPU suite + the bench line (what the driver runs at round end)
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/full
+timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee gpurun_out/full/tests.txt
+timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/full/bench.json 2> gpurun_out/full/bench.err; tail -c 300 gpurun_out/full/bench.err; cut -c1-900 gpurun_out/full/bench.json
