@@ -29,10 +29,21 @@ DVM_EXPORT int dvm_device_count(void) {
 #include <atomic>
 #include <stdlib.h>
 namespace dvm {
-static std::atomic<int> g_deterministic{[] {
-    const char *e = getenv("DVM_DETERMINISTIC");
-    return (e && atoi(e) != 0) ? 1 : 0;
-}()};
+// ---------------------------------------------------------------- environment options: ONE place, read once (table: include/dvm.h)
+const Options &options() {
+    static const Options o = [] {
+        Options r{0, -1, 0.0014f, 0.02f, -1, 1, 0};
+        if (const char *e = getenv("DVM_DETERMINISTIC")) r.deterministic = atoi(e) != 0;
+        if (const char *e = getenv("DVM_K1_ROUTE")) r.k1_route = atoi(e);
+        if (const char *e = getenv("DVM_K1_ROUTE_P")) (void)sscanf(e, "%f,%f", &r.k1_p_coarse, &r.k1_p_lean);
+        if (const char *e = getenv("DVM_LINEAR_CFG")) r.linear_cfg = atoi(e);
+        if (const char *e = getenv("DVM_PAIR_OVERLAP")) r.pair_overlap = atoi(e) != 0;
+        if (const char *e = getenv("DVM_DEBUG")) r.debug = atoi(e);
+        return r;
+    }();
+    return o;
+}
+static std::atomic<int> g_deterministic{options().deterministic};
 bool deterministic() { return g_deterministic.load(std::memory_order_relaxed) != 0; }
 }  // namespace dvm
 DVM_EXPORT int dvm_set_deterministic(int on) { return dvm::g_deterministic.exchange(on ? 1 : 0); }

@@ -1154,21 +1154,12 @@ int launch_knn_neg(const float *a, const float *bq, int B, int N, int M, int C, 
     const int kchunk = ((ktiles + nz - 1) / nz) * KS_KT;
     nz = (M + kchunk - 1) / kchunk;
     // measured at 8 x 2048 / 1 x 4995 points, scores + top-k per call: C = 128: 187 -> 171 us / 184 -> 163 us with the DMA form;
-    // C = 64: 130 -> 137 us (half the bytes per key: the register path already hides them) — so C = 128 only by default
-    // (DVM_KNN_SCORES_DMA = 0: never, 2: both widths)
-    static const int dma_mode = [] { const char *e = getenv("DVM_KNN_SCORES_DMA"); return e ? atoi(e) : 1; }();
-    const bool dma = dma_mode == 2 || (dma_mode == 1 && C == 128);
-    if (C == 128 && dma) {
+    // C = 64: 130 -> 137 us (half the bytes per key: the register path already hides them) — so C = 128 only
+    if (C == 128) {
         constexpr int lds = 2 * KS_KT * 128 * 4 + 2 * KS_KT * 4;
         ensure_dyn_lds((const void *)knn_scores_dma_kernel<128>, lds);
         hipLaunchKernelGGL(knn_scores_dma_kernel<128>, dim3(qtiles, B, nz), dim3(KS_THREADS), lds, s, a, bq, na, nb, N, M, kchunk, S);
-    } else if (C == 64 && dma) {
-        constexpr int lds = 2 * KS_KT * 64 * 4 + 2 * KS_KT * 4;
-        ensure_dyn_lds((const void *)knn_scores_dma_kernel<64>, lds);
-        hipLaunchKernelGGL(knn_scores_dma_kernel<64>, dim3(qtiles, B, nz), dim3(KS_THREADS), lds, s, a, bq, na, nb, N, M, kchunk, S);
-    } else if (C == 128)
-        hipLaunchKernelGGL(knn_scores_mfma_kernel<128>, dim3(qtiles, B, nz), dim3(KS_THREADS), 0, s, a, bq, na, nb, N, M, kchunk, S);
-    else if (C == 64)
+    } else if (C == 64)
         hipLaunchKernelGGL(knn_scores_mfma_kernel<64>, dim3(qtiles, B, nz), dim3(KS_THREADS), 0, s, a, bq, na, nb, N, M, kchunk, S);
     else
         hipLaunchKernelGGL(knn_scores_scalar_kernel, dim3((N + 127) / 128, B), dim3(128), 0, s, a, bq, na, nb, N, M, C, S);
@@ -1271,14 +1262,6 @@ void launch_sa_rowstats_f16(const _Float16 *pp, int B, int N, int kchunk, int Z,
 void launch_sa_apply_f16(const _Float16 *pp, const _Float16 *vp, const float *stats, int B, int N, int kchunk, int Z, float *xr,
                          float *cinv, hipStream_t s);
 
-static bool sa_use_f16() {  // env DVM_SA_VARIANT=f32 keeps both contractions on the fp32 matrix instruction
-    static const bool v = [] {
-        const char *e = getenv("DVM_SA_VARIANT");
-        return !(e && e[0] == 'f' && e[1] == '3');
-    }();
-    return v;
-}
-
 // stats [B][N][2] and xr [B][N][64] (and cinv [B][N] when given) from p, v; `part` holds sa_partial_floats(B, N) floats,
 // `f16ws` sa_f16_ws_bytes(B, N) bytes
 static void launch_sa_forward(const float *p, const float *v, int B, int N, float *xr, float *stats, float *cinv, float *part,
@@ -1289,7 +1272,7 @@ static void launch_sa_forward(const float *p, const float *v, int B, int N, floa
     dim3 grid((N + 31) / 32, B, Z);
     const long rows = (long)B * N;
     float *pstats = part, *po = Z > 1 ? pstats + (size_t)Z * rows * 2 : nullptr, *pc = Z > 1 ? po + (size_t)Z * rows * SA_C : nullptr;
-    const bool f16 = sa_use_f16() && f16ws != nullptr;
+    const bool f16 = f16ws != nullptr;   // (a caller without the split planes' workspace — the training forward — keeps both contractions on the fp32 matrix instruction)
     _Float16 *pp = nullptr, *vp = nullptr;
     if (f16) {
         sa_f16_carve(f16ws, B, N, pp, vp);

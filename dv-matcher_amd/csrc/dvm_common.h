@@ -22,6 +22,17 @@ void prof_note(int id, const char *name);   // which kernel(s) the slot's bracke
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (current device, kernel) — dvm_api.cpp
 void ensure_dyn_lds(const void *kernel, int bytes);
 int device_cu_count();   // compute units of the current device (cached)
+// The library's environment options, read ONCE at load (dvm_api.cpp; the table is documented in include/dvm.h).
+struct Options {
+    int deterministic;        // DVM_DETERMINISTIC: initial value of the dvm_set_deterministic flag
+    int k1_route;             // DVM_K1_ROUTE: -1 = the probe decides (default), else force K1_ROUTE_* for every launch at alpha >= 32
+    float k1_p_coarse, k1_p_lean;   // DVM_K1_ROUTE_P="p_coarse,p_lean": the probe's thresholds
+    int linear_cfg;           // DVM_LINEAR_CFG: tile configuration of dvm_linear_f32 (-1 = chosen per shape)
+    int pair_overlap;         // DVM_PAIR_OVERLAP: initial value of dvm_pair_set_overlap (default 1)
+    int debug;                // DVM_DEBUG: bit mask of synchronous diagnostics on stderr (DVM_DEBUG_*)
+};
+constexpr int DVM_DEBUG_K1_ROUTES = 1, DVM_DEBUG_K1_FLAGGED = 2, DVM_DEBUG_CHAMFER_STATS = 4, DVM_DEBUG_K1_STAMPS = 8, DVM_DEBUG_MLP_STAMPS = 16;
+const Options &options();
 // helper streams / events of dvm_pair_fwd_f32 for one (device, caller stream), made by dvm_pair_init — dvm_api.cpp
 struct PairCtx {
     int device = 0;

@@ -509,20 +509,9 @@ void launch_mlp_rows_bf16(const float *z, int rows, const float *W0, const float
                           const float *W2, const float *b2, const float *W3, const float *b3, void *scratch, float *out,
                           hipStream_t s, const int *gate);
 size_t mlp_f16_pack_bytes();
-int *launch_mlp_rows_f16(const float *z, int rows, const float *W0, const float *b0, const float *W1, const float *b1,
-                         const float *W2, const float *b2, const float *W3, const float *b3, void *scratch, float *out,
-                         hipStream_t s);
 void launch_split_rows(const float *z, int rows, int stride, void *zp, hipStream_t s);
 int *launch_mlp_planes_f16(const void *zp, int rows, const float *W0, const float *b0, const float *W1, const float *b1, const float *W2,
                            const float *b2, const float *W3, const float *b3, void *scratch, float *out, hipStream_t s);
-// the persistent form of the fp16x2 kernel is the default (DVM_MLP_PERSIST=0: the one-workgroup-per-block kernel it replaced)
-bool mlp_persistent() {
-    static const bool on = [] {
-        const char *e = getenv("DVM_MLP_PERSIST");
-        return !(e && e[0] == '0');
-    }();
-    return on;
-}
 // variant 0 on rows that are in the plane form already; returns the range flag for launch_mlp_fallback
 const int *launch_mlp_planes(const void *zp, int rows, const float *W0, const float *b0, const float *W1, const float *b1, const float *W2,
                              const float *b2, const float *W3, const float *b3, float *wp, float *out, hipStream_t s) {
@@ -543,17 +532,13 @@ size_t mlp_pack_floats() {
 //            gated on its out-of-range flag; 3: bf16x3-split kernel (dvm_mlp_bf16.hip); 2: fp32-MFMA kernel
 void launch_mlp_rows(const float *z, int rows, const float *W0, const float *b0, const float *W1, const float *b1, const float *W2,
                      const float *b2, const float *W3, const float *b3, float *wp, float *out, hipStream_t s, int variant, void *zp) {
-    if (variant == 0 && zp && mlp_persistent()) {
+    if (variant == 0 && zp) {
         launch_split_rows(z, rows, DF_ZS, zp, s);
         const int *flag = launch_mlp_planes_f16(zp, rows, W0, b0, W1, b1, W2, b2, W3, b3, wp, out, s);
         launch_mlp_rows_bf16(z, rows, W0, b0, W1, b1, W2, b2, W3, b3, (char *)wp + mlp_f16_pack_bytes(), out, s, flag);
         return;
     }
-    if (variant == 0) {
-        const int *flag = launch_mlp_rows_f16(z, rows, W0, b0, W1, b1, W2, b2, W3, b3, wp, out, s);
-        launch_mlp_rows_bf16(z, rows, W0, b0, W1, b1, W2, b2, W3, b3, (char *)wp + mlp_f16_pack_bytes(), out, s, flag);
-        return;
-    }
+    if (variant == 0) variant = 3;   // (no plane buffer: the range-safe bf16x3 kernel)
     if (variant == 3) {
         launch_mlp_rows_bf16(z, rows, W0, b0, W1, b1, W2, b2, W3, b3, wp, out, s, nullptr);
         return;

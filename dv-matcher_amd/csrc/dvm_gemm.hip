@@ -497,10 +497,8 @@ struct TileCfg {
 // staging registers and their ds_write instructions (102 -> 61 VGPRs at 64x64), and the K-block totals' round trips through the
 // output buffer (they live in a second accumulator set).  Default: DMA 64x64, DMA 64x128 from K = 768 on.
 static int pick_cfg(int n, long rows_out_narrow, int K = 0) {
-    if (const char *force = getenv("DVM_LINEAR_CFG")) {
-        const int c = atoi(force);
-        if (c >= 0 && c < n) return c;
-    }
+    const int c = options().linear_cfg;   // DVM_LINEAR_CFG: every configuration gives the same bits (tests/test_gpu_linear.py runs them all)
+    if (c >= 0 && c < n) return c;
     if (rows_out_narrow <= 32) return 0;
     return n > 4 ? (K >= 768 ? 6 : 4) : 1;
 }

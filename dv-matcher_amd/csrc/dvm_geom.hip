@@ -1077,9 +1077,8 @@ int launch_map_term_nbr(const float *verts12, const float *nbr2, const int32_t *
 // -> false if a target cloud does not fit LDS (the caller then uses apply_kernel + take_col0)
 bool launch_apply3_pair(const float *val12, const int32_t *idx12, const float *verts2, float *verts12, int32_t *T12, const float *val21,
                         const int32_t *idx21, const float *verts1, float *verts21, int32_t *T21, int B, int N, int M, hipStream_t s) {
-    static const int on = [] { const char *e = getenv("DVM_APPLY_LDS"); return e ? atoi(e) : 1; }();
     const size_t lds = (size_t)(N > M ? N : M) * 3 * sizeof(float);
-    if (!on || lds > 150 * 1024) return false;
+    if (lds > 150 * 1024) return false;
     Apply3Pair a;
     a.val[0] = val12, a.idx[0] = idx12, a.V[0] = verts2, a.out[0] = verts12, a.T[0] = T12, a.N[0] = N, a.M[0] = M;
     a.val[1] = val21, a.idx[1] = idx21, a.V[1] = verts1, a.out[1] = verts21, a.T[1] = T21, a.N[1] = M, a.M[1] = N;
@@ -1088,14 +1087,12 @@ bool launch_apply3_pair(const float *val12, const int32_t *idx12, const float *v
     return true;
 }
 bool map_term_lds_applies(int M, int k) {
-    static const int on = [] { const char *e = getenv("DVM_MAP_LDS"); return e ? atoi(e) : 1; }();
-    return on && (((size_t)M * 3 * sizeof(float) + 15) / 16) * 16 + (size_t)M * k * sizeof(int32_t) <= 150 * 1024;
+    return (((size_t)M * 3 * sizeof(float) + 15) / 16) * 16 + (size_t)M * k * sizeof(int32_t) <= 150 * 1024;
 }
 bool launch_map_term_lds(const float *verts12, const float *verts2, const int32_t *idx11, const int32_t *idx22, const float *pi_val,
                          const int32_t *pi_idx, int B, int N, int M, int k, int topk, double *partial, hipStream_t s) {
-    static const int on = [] { const char *e = getenv("DVM_MAP_LDS"); return e ? atoi(e) : 1; }();
     const size_t lds = (((size_t)M * 3 * sizeof(float) + 15) / 16) * 16 + (size_t)M * k * sizeof(int32_t);
-    if (!on || topk != 10 || lds > 150 * 1024) return false;
+    if (topk != 10 || lds > 150 * 1024) return false;
     ensure_dyn_lds((const void *)map_term_lds_kernel<10>, (int)lds);
     hipLaunchKernelGGL(map_term_lds_kernel<10>, dim3(B), dim3(1024), lds, s, verts12, verts2, idx11, idx22, pi_val, pi_idx, N, M, k,
                        map_term_blocks(N, k), partial);

@@ -360,14 +360,10 @@ static void launch_fps_t(const float *xyz, int B, int N, int npoint, const int32
 
 // Each step is a dependent chain (distance update -> arg-max -> next centre), so its latency is what counts: the
 // per-thread part shrinks with more threads per cloud (and with PPT matched to N instead of rounded up to a power of
-// two), the cross-wave part grows with the wave count.  env DVM_FPS_THREADS overrides the choice (256 / 512 / 1024).
+// two), the cross-wave part grows with the wave count.
 int launch_fps(const float *xyz, int B, int N, int npoint, const int32_t *start, int32_t *out, hipStream_t s) {
-    static const int forced = [] {
-        const char *e = getenv("DVM_FPS_THREADS");
-        return e ? atoi(e) : 0;
-    }();
     // measured (us/step at 256 / 512 / 1024 threads): N = 2048: 0.65 / 0.71 / 1.18; 4995: 0.93 / 0.89 / 1.31; 12000: 1.63 / 1.22 / 1.63
-    int T = forced ? forced : (N <= 4096 ? 256 : 512);
+    int T = N <= 4096 ? 256 : 512;
     if (N > 48 * T) T = N > 48 * 512 ? 1024 : 512;
     const int ppt = (N + T - 1) / T;
 #define DVM_FPS_CASE(P)                                                                          \
@@ -484,9 +480,8 @@ int launch_dg_warp(const float *xyz, int B, int N, const int32_t *nodes_idx, con
                    const float *weights, const float *def9, float *R, float *T, float *warped, float *arap, int arap_stride,
                    float *sr, hipStream_t s) {
     const int Nn = N / 2;
-    static const int fused_on = [] { const char *e = getenv("DVM_WARP_FUSED"); return e ? atoi(e) : 1; }();
     const size_t lds = (size_t)Nn * 15 * sizeof(float);
-    if (fused_on && !sr && lds <= 150 * 1024) {   // (sr — the unused smooth-rotation term — only through the separate kernels)
+    if (!sr && lds <= 150 * 1024) {   // (sr — the unused smooth-rotation term — only through the separate kernels)
         ensure_dyn_lds((const void *)dg_warp_arap_fused_kernel, (int)lds);
         hipLaunchKernelGGL(dg_warp_arap_fused_kernel, dim3(B), dim3(256), lds, s, xyz, N, Nn, nodes_idx, ring, infl_idx, weights, def9, R, T,
                            warped, arap, arap_stride);

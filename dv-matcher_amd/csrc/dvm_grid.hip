@@ -28,11 +28,6 @@ struct GridView {          // one shape's grid (device pointers already offset t
 // GridBuf (dvm_common.h): batched storage — pts [B][P], ids [B][P], start [B][G^3+1], params [B][8]
 
 static int grid_dim_for(int P) {
-    static const int forced = [] {
-        const char *e = getenv("DVM_GRID_DIM");
-        return e ? atoi(e) : 0;
-    }();
-    if (forced >= 2 && forced <= 16) return forced;
     // ~1.2 points per cell (measured on uniform clouds at P = 2048: G = 12 beats 8 by 4 % end to end, 16 loses again);
     // results do not depend on G (exact search)
     int g = 2;
@@ -454,13 +449,10 @@ struct ChGridGroup {
 struct ChGridArgs {
     ChGridGroup g[8];
     int scan_min;   // uncertified lanes in a wave from which the whole target is scanned instead of walked
-    int ablate;     // (timing experiments, WRONG results: 1 = no tile loop, 2 = no exact evaluation of the two tiles, 4 = retry waves scan nothing)
-    int defer;      // 1: queries the radius-1 cube does not certify are marked (CH_OPEN in dout) for grid_chamfer_retry_kernel
-    unsigned long long *stats;   // diagnostic (DVM_CHAMFER_STATS): per group [8]: queries, radius-1 candidates, certified at radius 1,
+    unsigned long long *stats;   // diagnostic (DVM_DEBUG & 4): per group [8]: queries, radius-1 candidates, certified at radius 1,
                                  // walked, certified by the walk, waves that scanned, lanes served by a scan, exact fallback lanes
 };
 typedef float f32x16_g __attribute__((ext_vector_type(16)));
-constexpr unsigned CH_OPEN = 0xBF800000u;   // -1.0f in dout: "not certified by the radius-1 cube" (distances are >= 0)
 
 // the target's points [s_begin, s_end) in storage order with the reference's arithmetic (difference form, lower original index on
 // exact ties)
@@ -485,8 +477,8 @@ __device__ __forceinline__ void chamfer_exact_scan(const GridView &g, const Metr
 // One WAVE of queries against the WHOLE target, screened on the matrix cores (described in grid_chamfer_kernel); lanes with `done`
 // take part in the matrix instructions and write nothing.
 __device__ __forceinline__ void chamfer_scan_wave(const ChGridGroup &G, const GridView &g, int b, int Na, bool done, const float4 qp, int i,
-                                                  const MetricDiff &met, float margin, unsigned long long *stats, int grp, int ablate = 0) {
-    const int P = (ablate & 1) ? 32 : G.gb.P;
+                                                  const MetricDiff &met, float margin, unsigned long long *stats, int grp) {
+    const int P = G.gb.P;
     const int lane = threadIdx.x & 63, j32 = lane & 31, hh = lane >> 5;
     if (stats) {
         if (lane == 0) atomicAdd(stats + grp * 8 + 5, 1ull);
@@ -561,7 +553,7 @@ __device__ __forceinline__ void chamfer_scan_wave(const ChGridGroup &G, const Gr
     float best = INFINITY;
     int bs = 0;
     bool cert = false;
-    if (!done && !(ablate & 2)) {
+    if (!done) {
         chamfer_exact_scan(g, met, stile, stile + 32 < P ? stile + 32 : P, best, bs);
         if (ssec < INFINITY) chamfer_exact_scan(g, met, stile2, stile2 + 32 < P ? stile2 + 32 : P, best, bs);
         cert = sother - sbest > 2.f * margin;
@@ -719,19 +711,12 @@ __global__ __launch_bounds__(THREADS) void grid_chamfer_kernel(const ChGridArgs 
             if (args.stats) atomicAdd(args.stats + blockIdx.z * 8 + 2, 1ull);
         }
     }
-    // not certified within the radius-1 cube.  (Deferring these queries to a compacted second launch made the first one
-    // 2.5x faster but the incoherent retry launch cost more than it saved — queries far outside the target's box, as the
-    // bench's untrained warps produce, need most of the grid either way.)
+    // not certified within the radius-1 cube.  (Deferring these queries to a compacted second launch — marked here, gathered into
+    // full waves and scanned by a second kernel — made this one 2.5x faster, 0.81 ms, and the second launch cost 0.79 ms: 1.60 vs
+    // 1.51 ms.  The scans are bound by their own arithmetic, 2.5 G pair distances per launch, not by how full the scanning waves
+    // are; queries far outside the target's box, as the bench's untrained warps produce, need most of the grid either way.)
     const int nfall = __popcll(__ballot(!done));   // (wave-uniform)
     if (nfall == 0) return;
-    if (args.defer) {
-        // Round 3, late (DVM_CHAMFER_DEFER=1): the open queries are marked and a second kernel gathers them into FULL waves per
-        // (group, cloud) and scans the target for them on the matrix cores - nearly every wave of the bench's groups 1, 3, 5, 7
-        // holds a few open lanes (6 - 50 %), and all 64 lanes wait for their walk or scan.  This kernel then takes 0.81 ms - and
-        // the retry kernel 0.79 ms: see launch_grid_chamfer.
-        if (!done) *(unsigned *)&G.dout[(size_t)b * Na + i] = CH_OPEN;
-        return;
-    }
     // When many lanes of the wave are in that position — a query cloud far from, or much larger than, the target: a COLLAPSED
     // correspondence image (flat soft-max rows at small alpha) makes every query of the other cloud such a one — the wave goes
     // through the WHOLE target instead of walking cells.  Round 3: that scan is screened on the matrix cores.  Per 32 target
@@ -764,64 +749,6 @@ __global__ __launch_bounds__(THREADS) void grid_chamfer_kernel(const ChGridArgs 
         if (!scan) return;
     }
     chamfer_scan_wave(G, g, b, Na, done, qp, i, met, margin, args.stats, blockIdx.z);
-}
-
-// The open queries of one (group, cloud), gathered into full waves: every wave of the block streams its quarter of the query
-// cloud (in cell order), queues the marked ones in LDS and scans the target for 64 of them at a time.
-__global__ __launch_bounds__(256) void grid_chamfer_retry_kernel(const ChGridArgs args) {
-    __shared__ int queue_all[4][128];
-    const ChGridGroup &G = args.g[blockIdx.y];
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int *queue = queue_all[wave];
-    const int Na = G.gq.P;
-    GridView g = grid_view(G.gb, b);
-    GridView q = grid_view(G.gq, b);
-    const int q_end = Na;   // (slice 4 k + w of 64 queries goes to wave w: open queries cluster in space, quarters would not balance)
-    int qn = 0;
-    auto process = [&](int n) __attribute__((always_inline)) {   // the first n <= 64 entries of the queue
-        const bool active = lane < n;
-        const int tq = queue[active ? lane : n - 1];
-        const float4 qp = q.pts[tq];
-        const int i = q.ids[tq];
-        MetricDiff met;
-        met.set(qp.x, qp.y, qp.z);
-        const float margin = 64.f * 1.1920929e-7f * (g.scale2 + sumsq3(qp.x, qp.y, qp.z)) + 1e-30f;
-        if (!(args.ablate & 4)) chamfer_scan_wave(G, g, b, Na, !active, qp, i, met, margin, args.stats, blockIdx.y, args.ablate);
-    };
-    for (int s0 = 0; s0 < q_end; s0 += 1024) {   // four slices of 64 queries per round trip
-        int tqs[4];
-        unsigned marks[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            tqs[u] = s0 + 64 * (4 * u + wave) + lane;
-            const int tc = tqs[u] < q_end ? tqs[u] : q_end - 1;
-            marks[u] = (unsigned)q.ids[tc];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) marks[u] = *(const unsigned *)&G.dout[(size_t)b * Na + marks[u]];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const bool open = tqs[u] < q_end && marks[u] == CH_OPEN;
-            const unsigned long long m = __ballot(open);
-            if (m == 0) continue;
-            if (open) queue[qn + __popcll(m & ((1ull << lane) - 1ull))] = tqs[u];
-            qn += __popcll(m);
-            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the queue is written (one wave: no barrier)
-            __builtin_amdgcn_wave_barrier();
-            if (qn >= 64) {
-                process(64);
-                const int rest = qn - 64;
-                const int keep = lane < rest ? queue[64 + lane] : 0;
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_wave_barrier();
-                if (lane < rest) queue[lane] = keep;
-                qn = rest;
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-    }
-    if (qn > 0) process(qn);
 }
 
 // ---------------------------------------------------------------- host side
@@ -861,32 +788,14 @@ void launch_grid_build(const float *xyz, int B, int Nsrc, const int32_t *sel, co
     hipLaunchKernelGGL(grid_build_kernel, dim3(B), dim3(GRID_T), lds, s, xyz, Nsrc, sel, gb);
 }
 
-// LDS-resident grids for the searches (round 4): DVM_GRID_LDS=0 off, 1 (default) on where the grid fits 64 KB; threads per
-// workgroup of the LDS forms: DVM_GRID_LDS_T (256 / 512 / 1024)
-static int grid_lds_mode() {
-    static const int m = [] { const char *e = getenv("DVM_GRID_LDS"); return e ? atoi(e) : 1; }();
-    return m;
-}
-static int grid_lds_threads() {
-    static const int t = [] { const char *e = getenv("DVM_GRID_LDS_T"); return e ? atoi(e) : 512; }();
-    return t;
-}
-
+// LDS-resident grids for the searches (round 4) where the grid fits 64 KB, 512 threads per workgroup (256 / 1024 measured no
+// faster); larger clouds take the global-memory form with 128 threads
 template <int K>
 static void launch_knn_self_k(const GridBuf &gb, int B, int k, int32_t *idx, hipStream_t s) {
     const size_t lds = grid_lds_bytes(gb);
-    const int T = grid_lds_threads();
-    if (grid_lds_mode() && lds <= 64 * 1024) {
-        if (T >= 1024) {
-            ensure_dyn_lds((const void *)grid_knn_self_kernel<K, 1024, true>, (int)lds);
-            hipLaunchKernelGGL((grid_knn_self_kernel<K, 1024, true>), dim3((gb.P + 1023) / 1024, B), dim3(1024), lds, s, gb, k, idx);
-        } else if (T >= 512) {
-            ensure_dyn_lds((const void *)grid_knn_self_kernel<K, 512, true>, (int)lds);
-            hipLaunchKernelGGL((grid_knn_self_kernel<K, 512, true>), dim3((gb.P + 511) / 512, B), dim3(512), lds, s, gb, k, idx);
-        } else {
-            ensure_dyn_lds((const void *)grid_knn_self_kernel<K, 256, true>, (int)lds);
-            hipLaunchKernelGGL((grid_knn_self_kernel<K, 256, true>), dim3((gb.P + 255) / 256, B), dim3(256), lds, s, gb, k, idx);
-        }
+    if (lds <= 64 * 1024) {
+        ensure_dyn_lds((const void *)grid_knn_self_kernel<K, 512, true>, (int)lds);
+        hipLaunchKernelGGL((grid_knn_self_kernel<K, 512, true>), dim3((gb.P + 511) / 512, B), dim3(512), lds, s, gb, k, idx);
     } else {
         hipLaunchKernelGGL((grid_knn_self_kernel<K, 128, false>), dim3((gb.P + 127) / 128, B), dim3(128), 0, s, gb, k, idx);
     }
@@ -905,42 +814,21 @@ void launch_grid_knn_self(const GridBuf &gb, int B, int k, int32_t *idx, hipStre
 
 void launch_grid_ring(const GridBuf &gnodes, int B, int32_t *ring, hipStream_t s) {
     const size_t lds = grid_lds_bytes(gnodes);
-    const int T = grid_lds_threads();
-    if (grid_lds_mode() && lds <= 64 * 1024) {
-        if (T >= 512) {
-            ensure_dyn_lds((const void *)grid_ring_kernel<512, true>, (int)lds);
-            hipLaunchKernelGGL((grid_ring_kernel<512, true>), dim3((gnodes.P + 511) / 512, B), dim3(512), lds, s, gnodes, ring);
-        } else {
-            ensure_dyn_lds((const void *)grid_ring_kernel<256, true>, (int)lds);
-            hipLaunchKernelGGL((grid_ring_kernel<256, true>), dim3((gnodes.P + 255) / 256, B), dim3(256), lds, s, gnodes, ring);
-        }
+    if (lds <= 64 * 1024) {
+        ensure_dyn_lds((const void *)grid_ring_kernel<512, true>, (int)lds);
+        hipLaunchKernelGGL((grid_ring_kernel<512, true>), dim3((gnodes.P + 511) / 512, B), dim3(512), lds, s, gnodes, ring);
     } else {
         hipLaunchKernelGGL((grid_ring_kernel<128, false>), dim3((gnodes.P + 127) / 128, B), dim3(128), 0, s, gnodes, ring);
     }
 }
 
-template <int T, int MODE>
-static void launch_infl_t(const float *xyz, int B, int N, const GridBuf &gnodes, const GridBuf &gverts, int32_t *infl, float *dists, double *nnd,
-                          size_t lds, hipStream_t s) {
-    ensure_dyn_lds((const void *)grid_infl_kernel<T, MODE>, (int)lds);
-    hipLaunchKernelGGL((grid_infl_kernel<T, MODE>), dim3((N + T - 1) / T, B), dim3(T), lds, s, xyz, N, gnodes, gverts, infl, dists, nnd);
-}
 void launch_grid_infl(const float *xyz, int B, int N, const GridBuf &gnodes, const GridBuf &gverts, int32_t *infl, float *dists,
                       double *nnd, hipStream_t s) {
-    static const int mode = [] { const char *e = getenv("DVM_INFL_LDS"); return e ? atoi(e) : 1; }();   // 0 none, 1 node grid, 2 vertex grid, 3 both
-    const size_t lds = ((mode & 1) ? grid_lds_bytes(gnodes) : 0) + ((mode & 2) ? grid_lds_bytes(gverts) : 0);
-    const int T = grid_lds_threads();
-    if (grid_lds_mode() && mode >= 1 && mode <= 3 && lds <= 64 * 1024) {
-        if (mode == 1) {
-            if (T >= 512) launch_infl_t<512, 1>(xyz, B, N, gnodes, gverts, infl, dists, nnd, lds, s);
-            else launch_infl_t<256, 1>(xyz, B, N, gnodes, gverts, infl, dists, nnd, lds, s);
-        } else if (mode == 2) {
-            if (T >= 512) launch_infl_t<512, 2>(xyz, B, N, gnodes, gverts, infl, dists, nnd, lds, s);
-            else launch_infl_t<256, 2>(xyz, B, N, gnodes, gverts, infl, dists, nnd, lds, s);
-        } else {
-            if (T >= 512) launch_infl_t<512, 3>(xyz, B, N, gnodes, gverts, infl, dists, nnd, lds, s);
-            else launch_infl_t<256, 3>(xyz, B, N, gnodes, gverts, infl, dists, nnd, lds, s);
-        }
+    // the NODE grid in LDS (with the vertex grid staged as well the kernel was slower: 0.59 vs 0.41 ms)
+    const size_t lds = grid_lds_bytes(gnodes);
+    if (lds <= 64 * 1024) {
+        ensure_dyn_lds((const void *)grid_infl_kernel<512, 1>, (int)lds);
+        hipLaunchKernelGGL((grid_infl_kernel<512, 1>), dim3((N + 511) / 512, B), dim3(512), lds, s, xyz, N, gnodes, gverts, infl, dists, nnd);
     } else {
         hipLaunchKernelGGL((grid_infl_kernel<128, 0>), dim3((N + 127) / 128, B), dim3(128), 0, s, xyz, N, gnodes, gverts, infl, dists, nnd);
     }
@@ -955,31 +843,11 @@ void launch_grid_chamfer(const GridBuf *gq, const GridBuf *gb, float *const *dou
         args.g[q] = ChGridGroup{gq[r], gb[r], dout[r], iout ? iout[r] : nullptr};
         if (q < ngroups && gq[r].P > maxN) maxN = gq[r].P;
     }
-    static const int scan_min = [] {
-        const char *e = getenv("DVM_CHAMFER_SCAN_MIN");   // tuning knob; 65 = never
-        return e ? atoi(e) : 24;   // (round 3, matrix-core scan + seeded walk, bench regime: 8 / 16 / 24 / 32 / never = 2.75 / 2.32 / 2.22 / 2.30 / 2.81 ms)
-    }();
-    args.scan_min = scan_min;
+    args.scan_min = 24;   // (round 3, matrix-core scan + seeded walk, bench regime: 8 / 16 / 24 / 32 / never = 2.75 / 2.32 / 2.22 / 2.30 / 2.81 ms)
     args.stats = nullptr;
-    static const bool stats_on = getenv("DVM_CHAMFER_STATS") != nullptr;   // diagnostic: synchronous, allocates
-    if (stats_on && hipMalloc(&args.stats, 64 * sizeof(unsigned long long)) == hipSuccess)
+    if ((options().debug & DVM_DEBUG_CHAMFER_STATS) && hipMalloc(&args.stats, 64 * sizeof(unsigned long long)) == hipSuccess)   // diagnostic: synchronous, allocates
         (void)hipMemsetAsync(args.stats, 0, 64 * sizeof(unsigned long long), s);
-    // (deferred form, measured: 0.81 + 0.79 ms against 1.51 ms for the one-kernel form: the scans are bound by their own arithmetic -
-    // 2.5 G pair distances per launch - not by how full the scanning waves are.  Opt-in.)
-    static const int defer = [] { const char *e = getenv("DVM_CHAMFER_DEFER"); return e ? atoi(e) : 0; }();
-    args.defer = defer;
-    args.ablate = 0;
-#ifdef DVM_ABLATE   // `make ABLATE=1` only: WRONG results, timing experiments
-    static const int ablate = [] {
-        const char *e = getenv("DVM_CHAMFER_ABLATE");
-        const int v = e ? atoi(e) : 0;
-        if (v) fprintf(stderr, "libdvm_hip: DVM_CHAMFER_ABLATE=%d: Chamfer returns WRONG results (timing experiment)\n", v);
-        return v;
-    }();
-    args.ablate = ablate;
-#endif
-    // LDS-resident target (DVM_CHAMFER_LDS=0: off; =128 / 256 / 512: threads per workgroup): every group's target must fit
-    static const int lds_threads = [] { const char *e = getenv("DVM_CHAMFER_LDS"); return e ? atoi(e) : 512; }();
+    // LDS-resident target, 512 threads per workgroup: every group's target must fit
     size_t lds_bytes = 0;
     for (int q = 0; q < ngroups; ++q) {
         const size_t nb = (size_t)gb[q].P * sizeof(float4) + ((size_t)gb[q].G * gb[q].G * gb[q].G + 1) * sizeof(int32_t);
@@ -987,23 +855,11 @@ void launch_grid_chamfer(const GridBuf *gq, const GridBuf *gb, float *const *dou
     }
     lds_bytes = (lds_bytes + 15) / 16 * 16;
     prof_begin(s, DVM_PROF_CHAMFER);
-    if (lds_threads >= 128 && lds_bytes <= 64 * 1024 && !defer) {
-        if (lds_threads >= 1024) {
-            ensure_dyn_lds((const void *)grid_chamfer_kernel<1024, true>, (int)lds_bytes);
-            hipLaunchKernelGGL((grid_chamfer_kernel<1024, true>), dim3((maxN + 1023) / 1024, B, ngroups), dim3(1024), lds_bytes, s, args);
-        } else if (lds_threads >= 512) {
-            ensure_dyn_lds((const void *)grid_chamfer_kernel<512, true>, (int)lds_bytes);
-            hipLaunchKernelGGL((grid_chamfer_kernel<512, true>), dim3((maxN + 511) / 512, B, ngroups), dim3(512), lds_bytes, s, args);
-        } else if (lds_threads >= 256) {
-            ensure_dyn_lds((const void *)grid_chamfer_kernel<256, true>, (int)lds_bytes);
-            hipLaunchKernelGGL((grid_chamfer_kernel<256, true>), dim3((maxN + 255) / 256, B, ngroups), dim3(256), lds_bytes, s, args);
-        } else {
-            ensure_dyn_lds((const void *)grid_chamfer_kernel<128, true>, (int)lds_bytes);
-            hipLaunchKernelGGL((grid_chamfer_kernel<128, true>), dim3((maxN + 127) / 128, B, ngroups), dim3(128), lds_bytes, s, args);
-        }
+    if (lds_bytes <= 64 * 1024) {
+        ensure_dyn_lds((const void *)grid_chamfer_kernel<512, true>, (int)lds_bytes);
+        hipLaunchKernelGGL((grid_chamfer_kernel<512, true>), dim3((maxN + 511) / 512, B, ngroups), dim3(512), lds_bytes, s, args);
     } else
         hipLaunchKernelGGL((grid_chamfer_kernel<128, false>), dim3((maxN + 127) / 128, B, ngroups), dim3(128), 0, s, args);
-    if (defer) hipLaunchKernelGGL(grid_chamfer_retry_kernel, dim3(B, ngroups), dim3(256), 0, s, args);
     prof_end(s, DVM_PROF_CHAMFER);
     if (args.stats) {
         unsigned long long h[64];

@@ -28,7 +28,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 namespace {
 
 constexpr int MH_WAVES = 8, MH_THREADS = 64 * MH_WAVES;    // (MH_NODES, MH_K0, MH_SZ, the scales: dvm_mlp_f16.h)
-constexpr int MH_ZS = 264;                                     // z row stride in HBM (floats)
 constexpr int MH_K1 = 512, MH_K2 = 256, MH_K3 = 128;  // K padded to multiples of 16 (MH_K0 = 272)
 constexpr int MH_SH = 2 * 256 * 2 + 16;     // 1040 B: one half of h0 (2 x 256) and later h2 (2 x 128) / h1 (persistent form)
 constexpr size_t MH_LDS_BYTES = (size_t)MH_NODES * (MH_SZ + MH_SH);
@@ -196,163 +195,9 @@ __device__ __forceinline__ void store_act(const f32x16 &acc, const Bias16 &bv, i
     }
 }
 
-// STAMP: diagnostic build (DVM_MLP_STAMPS) — every wave adds up the shader cycles (s_memtime) it spends per phase; no output
-// depends on them.  Slots: 0 z staging + barrier, 1 / 4 layer-0 halves (matrix loop), 2 / 5 their activation stores + barrier,
-// 3 / 6 layer-1 K-halves + barrier, 7 h1 stores + barrier, 8 layer 2, 9 its stores + barrier, 10 layer 3 + output, 11 whole kernel.
-template <int AHEAD, int ABL = 0, bool STAMP = false>
-__global__ __launch_bounds__(MH_THREADS) void mlp_f16x2_kernel(const float *__restrict__ z, int rows,
-                                                               const _Float16 *__restrict__ Wp0, const float *__restrict__ b0,
-                                                               const _Float16 *__restrict__ Wp1, const float *__restrict__ b1,
-                                                               const _Float16 *__restrict__ Wp2, const float *__restrict__ b2,
-                                                               const _Float16 *__restrict__ Wp3, const float *__restrict__ b3,
-                                                               float *__restrict__ out, int *__restrict__ flag,
-                                                               unsigned long long *__restrict__ stamps) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned long long T[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0, tstart = 0, rstart = 0;
-    if (STAMP) tstart = tlast = __builtin_amdgcn_s_memtime(), rstart = __builtin_amdgcn_s_memrealtime();
-    auto stamp = [&](int slot) __attribute__((always_inline)) {
-        if (STAMP) {
-            const unsigned long long now = __builtin_amdgcn_s_memtime();
-            T[slot] += now - tlast;
-            tlast = now;
-        }
-    };
-    auto stamp_acc = [&](int slot, const f32x16 &a) __attribute__((always_inline)) {   // after the accumulator is readable
-        if (STAMP) {
-            const int x = __builtin_amdgcn_readfirstlane(__float_as_int(a[0]));
-            asm volatile("" ::"s"(x));
-            stamp(slot);
-        }
-    };
-    char *bufZ = smem;                       // [64][MH_SZ]
-    char *bufH = smem + MH_NODES * MH_SZ;    // [64][MH_SH]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r32 = lane & 31, hh = lane >> 5;
-    const int row0 = blockIdx.x * MH_NODES;
-    float amax = 0.f;   // largest |activation| of this lane (scaled): beyond fp16's range -> the flag (inf included; a NaN is a NaN in the result either way)
-    // this wave's five biases and the first weight fragments of layer 0: requested before anything else, in flight while the z
-    // rows are staged (each bias load used to sit between a phase's last matrix instruction and its activation stores)
-    // (the biases of a phase — 16 per lane — are requested at the head of the phase: they land under its matrix instructions)
-    WFrag<AHEAD> wfirst;
-    wfirst.request(Wp0 + (size_t)wave * (MH_K0 / 16) * 1024 + lane * 8, MH_K0 / 16);
+// (The one-workgroup-per-block kernel of round 3, mlp_f16x2_kernel — the same arithmetic, z rows staged through registers, 1.87 ms
+// against 1.76 ms — and its timing ablations were removed in round 5: profiles/notes_r4.md.)
 
-    // stage z: scale, split into the two planes (columns 262..271 are zero)
-    // (all of a thread's 9 loads are requested before the first is used: row and column are clamped and the value selected —
-    // a predicated load is a branch around a load with a full wait in front of it, nine dependent round trips per workgroup)
-    constexpr int ZIT = (MH_NODES * (MH_K0 / 4) + MH_THREADS - 1) / MH_THREADS;
-    f32x4 zv[ZIT];
-#pragma unroll
-    for (int it = 0; it < ZIT; ++it) {
-        const int e = tid + it * MH_THREADS, ec = e < MH_NODES * (MH_K0 / 4) ? e : 0;
-        const int r = ec / (MH_K0 / 4), c = ec % (MH_K0 / 4);
-        const int rr = row0 + r < rows ? row0 + r : rows - 1, cc = 4 * c < MH_ZS ? 4 * c : MH_ZS - 4;
-        zv[it] = *(const f32x4 *)(z + (size_t)rr * MH_ZS + cc);
-    }
-#pragma unroll
-    for (int it = 0; it < ZIT; ++it) {
-        const int e = tid + it * MH_THREADS;
-        if (e >= MH_NODES * (MH_K0 / 4)) break;
-        const int r = e / (MH_K0 / 4), c = e % (MH_K0 / 4);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row0 + r < rows && 4 * c < MH_ZS) v = zv[it];
-        char *p = bufZ + r * MH_SZ + 8 * c;
-        float a[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            a[q] = (4 * c + q < 262 ? v[q] : 0.f) * MH_SA;
-            amax = fmaxf(amax, fabsf(a[q]));
-        }
-        unsigned h0, m0, h1, m1;
-        split2x2(a[0], a[1], h0, m0);
-        split2x2(a[2], a[3], h1, m1);
-        const u32x2 h = {h0, h1}, m = {m0, m1};
-        *(u32x2 *)(p) = h;
-        *(u32x2 *)(p + 2 * MH_K0) = m;
-    }
-    __syncthreads();
-    stamp(0);
-
-    // layer 0 in two halves of 256 outputs; layer 1 consumes each half at once (split-K, accumulators in registers)
-    const _Float16 *const w0p[2] = {Wp0 + (size_t)wave * (MH_K0 / 16) * 1024 + lane * 8, Wp0 + (size_t)(8 + wave) * (MH_K0 / 16) * 1024 + lane * 8};
-    const _Float16 *const w1p[2] = {Wp1 + ((size_t)wave * (MH_K1 / 16)) * 1024 + lane * 8, Wp1 + ((size_t)wave * (MH_K1 / 16) + 16) * 1024 + lane * 8};
-    const _Float16 *const w2p = Wp2 + (size_t)(wave & 3) * (MH_K2 / 16) * 1024 + lane * 8;
-    const _Float16 *const w3p = Wp3 + lane * 8;
-    f32x16 acc1[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[t][r] = 0.f;
-    WFrag<AHEAD> wa = wfirst, wb;   // (wfirst: layer 0, first half — requested before the z rows were staged)
-    Bias16 bias1;
-    for (int hlf = 0; hlf < 2; ++hlf) {
-        {
-            const int ot = 8 * hlf + wave;  // of 16 output tiles
-            f32x16 acc0[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc0[t][r] = 0.f;
-            Bias16 bv;
-            bv.request(b0, ot * 32 + 4 * hh);
-            mma_tiles<2, AHEAD, MH_K0 / 16, ABL>(bufZ + r32 * MH_SZ + 16 * hh, MH_SZ, 2 * MH_K0, w0p[hlf], acc0, wa);
-            stamp_acc(hlf ? 4 : 1, acc0[1]);
-            wb.request(w1p[hlf], 16);   // layer 1's first fragments travel while this half's activations are stored
-#pragma unroll
-            for (int t = 0; t < 2; ++t) store_act(acc0[t], bv, wave * 32 + 4 * hh, bufH + (t * 32 + r32) * MH_SH, 2 * 256, amax);
-        }
-        __syncthreads();
-        stamp(hlf ? 5 : 2);
-        // layer 1, K-half hlf: out tile = wave (8 tiles = 256 outputs), k-steps 16*hlf .. 16*hlf+15
-        if (hlf == 1) bias1.request(b1, wave * 32 + 4 * hh);
-        mma_tiles<2, AHEAD, 16, ABL>(bufH + r32 * MH_SH + 16 * hh, MH_SH, 2 * 256, w1p[hlf], acc1, wb);
-        if (hlf == 0) wa.request(w0p[1], MH_K0 / 16); else wa.request(w2p, MH_K2 / 16);   // the next phase's, across the barrier
-        stamp_acc(12, acc1[1]);
-        __syncthreads();
-        stamp(hlf ? 6 : 3);
-    }
-    {   // h1 -> bufZ (z is dead)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) store_act(acc1[t], bias1, wave * 32 + 4 * hh, bufZ + (t * 32 + r32) * MH_SZ, 2 * MH_K2, amax);
-    }
-    __syncthreads();
-    stamp(7);
-    // layer 2: 256 -> 128 : 4 output tiles x 2 node tiles, one pair per wave
-    {
-        const int ot = wave & 3, nt = wave >> 2;
-        f32x16 acc2[1];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[0][r] = 0.f;
-        Bias16 bias2;
-        bias2.request(b2, ot * 32 + 4 * hh);
-        mma_tiles<1, AHEAD, MH_K2 / 16, ABL>(bufZ + (nt * 32 + r32) * MH_SZ + 16 * hh, MH_SZ, 2 * MH_K2, w2p, acc2, wa);
-        stamp_acc(8, acc2[0]);
-        if (wave < 2) wb.request(w3p, MH_K3 / 16);
-        store_act(acc2[0], bias2, ot * 32 + 4 * hh, bufH + (nt * 32 + r32) * MH_SH, 2 * MH_K3, amax);
-    }
-    __syncthreads();
-    stamp(9);
-    // layer 3: 128 -> 9 : one output tile per node tile, straight to HBM
-    if (wave < 2) {
-        f32x16 acc3[1];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc3[0][r] = 0.f;
-        mma_tiles<1, AHEAD, MH_K3 / 16, ABL>(bufH + (wave * 32 + r32) * MH_SH + 16 * hh, MH_SH, 2 * MH_K3, w3p, acc3, wb);
-        const int node = wave * 32 + r32;   // (transposed tile: the lane's node, outputs (r & 3) + 8 (r >> 2) + 4 hh — r < 5 reaches 0..8)
-#pragma unroll
-        for (int r = 0; r < 5; ++r) {
-            const int o = (r & 3) + 8 * (r >> 2) + 4 * hh;
-            if (o < 9 && row0 + node < rows) out[(size_t)(row0 + node) * 9 + o] = acc3[0][r] * MH_INV + b3[o];
-        }
-    }
-    if (__any(!(amax <= MH_LIMIT)) && lane == 0) atomicOr(flag, 1);
-    if (STAMP) {
-        stamp(10);
-        T[11] = __builtin_amdgcn_s_memtime() - tstart;
-        T[13] = __builtin_amdgcn_s_memrealtime() - rstart;   // the constant 100 MHz counter: T[11] / T[13] = the shader clock in units of 100 MHz
-        if (lane == 0 && stamps)
-            for (int i = 0; i < 14; ++i) stamps[((size_t)blockIdx.x * MH_WAVES + wave) * 14 + i] = T[i];
-    }
-}
 
 // ---------------------------------------------------------------- the persistent form (round 4)
 // Cycle stamps of the kernel above (DVM_MLP_STAMPS, profiles/r4_mlp_stamps.txt): its matrix loops run AT the pipe's floor for two
@@ -630,18 +475,14 @@ int *launch_mlp_planes_f16(const void *zp, int rows, const float *W0, const floa
     const int nblocks = (rows + MH_NODES - 1) / MH_NODES;
     // blocks per workgroup: the next block's planes travel under the current block, so the more the better for THIS kernel — but a
     // workgroup holds its compute unit (146 KB of LDS) until it is through, and whatever else is queued on the device (the next
-    // call's coordinate chain on its helper stream) gets a compute unit only when one retires.  DVM_MLP_BPW = A/B; 0: one
-    // workgroup per compute unit walks its whole share.
-    static const int bpw_env = [] {
-        const char *e = getenv("DVM_MLP_BPW");
-        return e ? atoi(e) : 4;
-    }();
+    // call's coordinate chain on its helper stream) gets a compute unit only when one retires: 4 is the measured optimum (one
+    // workgroup per compute unit walking its whole share: fewest cycles, slowest step — 12.0 vs 11.7 ms)
+    constexpr int bpw_env = 4;
     const int cus = device_cu_count();
     int bpw = bpw_env > 0 ? bpw_env : (nblocks + cus - 1) / cus;
     if (bpw < 1) bpw = 1;
     const dim3 grid((nblocks + bpw - 1) / bpw), block(MH_THREADS);
-    static const bool stamps_on = getenv("DVM_MLP_STAMPS") != nullptr;
-    if (stamps_on) {   // diagnostic: synchronous, allocates — never taken in production
+    if (options().debug & DVM_DEBUG_MLP_STAMPS) {   // diagnostic: synchronous, allocates — never taken in production
         unsigned long long *dbuf = nullptr;
         const size_t n = (size_t)grid.x * MH_WAVES * 14;
         if (hipMalloc(&dbuf, n * sizeof(unsigned long long)) != hipSuccess) return flag;
@@ -668,89 +509,6 @@ int *launch_mlp_planes_f16(const void *zp, int rows, const float *W0, const floa
     ensure_dyn_lds((const void *)mlp_f16x2p_kernel<4>, (int)MP_LDS_BYTES);
     hipLaunchKernelGGL((mlp_f16x2p_kernel<4>), grid, block, MP_LDS_BYTES, s, (const char *)zp, rows, nblocks, bpw, Wp0, b0, Wp1, b1, Wp2, b2, W3x, b3, out, flag,
                        (unsigned long long *)nullptr);
-    prof_end(s, DVM_PROF_MLP);
-    return flag;
-}
-
-// z [rows][264] fp32 -> out [rows][9]; scratch = mlp_f16_pack_bytes() bytes.  Returns the device flag that is non-zero
-// when a value left fp16's range (the results are then invalid and the bf16x3 kernel must overwrite them).
-int *launch_mlp_rows_f16(const float *z, int rows, const float *W0, const float *b0, const float *W1, const float *b1,
-                         const float *W2, const float *b2, const float *W3, const float *b3, void *scratch, float *out,
-                         hipStream_t s) {
-    _Float16 *Wp0 = (_Float16 *)scratch;
-    _Float16 *Wp1 = Wp0 + (size_t)16 * (MH_K0 / 16) * 1024;
-    _Float16 *Wp2 = Wp1 + (size_t)8 * (MH_K1 / 16) * 1024;
-    _Float16 *Wp3 = Wp2 + (size_t)4 * (MH_K2 / 16) * 1024;
-    int *flag = (int *)((char *)scratch + mlp_f16_pack_bytes() - align_up(sizeof(int)));
-    (void)hipMemsetAsync(flag, 0, sizeof(int), s);
-    {
-        PackLayersF16 a;
-        a.plane_form = 0;
-        long maxth = 0;
-        auto layer = [&](int q, const float *W, int O, int I, int otiles, int steps, _Float16 *Wp) {
-            a.W[q] = W, a.O[q] = O, a.I[q] = I, a.otiles[q] = otiles, a.steps[q] = steps, a.Wp[q] = Wp;
-            const long th = (long)otiles * steps * 512;
-            maxth = th > maxth ? th : maxth;
-        };
-        layer(0, W0, 512, 262, 16, MH_K0 / 16, Wp0);
-        layer(1, W1, 256, 512, 8, MH_K1 / 16, Wp1);
-        layer(2, W2, 128, 256, 4, MH_K2 / 16, Wp2);
-        layer(3, W3, 9, 128, 1, MH_K3 / 16, Wp3);
-        hipLaunchKernelGGL(pack_layers_f16_kernel, dim3((unsigned)((maxth + 255) / 256), 4), dim3(256), 0, s, a, flag);
-    }
-    // weight k-steps requested ahead of their matrix instructions: 2 / 4 / 8 measured alike (2.74 / 2.83 / 2.82 ms per launch
-    // at 512 pairs) — the waves' 59 % parked cycles (SQ_WAIT_ANY) are not the L2 latency of the weights (DVM_MLP_AHEAD = A/B)
-    static const int ahead = [] {
-        const char *e = getenv("DVM_MLP_AHEAD");
-        return e ? atoi(e) : 4;
-    }();
-    const dim3 grid((rows + MH_NODES - 1) / MH_NODES), block(MH_THREADS);
-    static const bool stamps_on = getenv("DVM_MLP_STAMPS") != nullptr;
-    if (stamps_on) {   // diagnostic: synchronous, allocates — never taken in production
-        unsigned long long *dbuf = nullptr;
-        const size_t n = (size_t)grid.x * MH_WAVES * 14;
-        if (hipMalloc(&dbuf, n * sizeof(unsigned long long)) != hipSuccess) return flag;
-        ensure_dyn_lds((const void *)mlp_f16x2_kernel<4, 0, true>, (int)MH_LDS_BYTES);
-        hipLaunchKernelGGL((mlp_f16x2_kernel<4, 0, true>), grid, block, MH_LDS_BYTES, s, z, rows, Wp0, b0, Wp1, b1, Wp2, b2, Wp3, b3, out, flag, dbuf);
-        (void)hipStreamSynchronize(s);
-        unsigned long long *hbuf = (unsigned long long *)malloc(n * sizeof(unsigned long long));
-        (void)hipMemcpy(hbuf, dbuf, n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-        double tot[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (size_t w = 0; w < (size_t)grid.x * MH_WAVES; ++w)
-            for (int i = 0; i < 14; ++i) tot[i] += (double)hbuf[w * 14 + i];
-        const double nw = (double)grid.x * MH_WAVES;
-        fprintf(stderr, "MLP stamps (%u workgroups), cycles per wave: z %.0f | L0a mfma %.0f store+bar %.0f | L1a mfma %.0f bar %.0f | L0b mfma %.0f store+bar %.0f | "
-                        "L1 mfma (both halves) %.0f bar %.0f | h1 store+bar %.0f | L2 mfma %.0f store+bar %.0f | L3 %.0f | whole %.0f | shader clock %.0f MHz\n", grid.x, tot[0] / nw, tot[1] / nw,
-                tot[2] / nw, 0.0, tot[3] / nw, tot[4] / nw, tot[5] / nw, tot[12] / nw, tot[6] / nw, tot[7] / nw, tot[8] / nw, tot[9] / nw, tot[10] / nw, tot[11] / nw, 100.0 * tot[11] / tot[13]);
-        free(hbuf);
-        (void)hipFree(dbuf);
-        return flag;
-    }
-    prof_note(DVM_PROF_MLP, "mlp_f16x2_kernel");
-    prof_begin(s, DVM_PROF_MLP);
-    // (ablation, WRONG results: 1 = the weight fragments are not re-loaded in the k-loops, 2 = the activation fragments are read
-    // from one LDS address, 3 = both: what is left is the matrix instructions, the activation stores and the barriers)
-    // compiled in only with `make ABLATE=1` (-DDVM_ABLATE): a stray environment variable must not be able to corrupt a production run
-#ifdef DVM_ABLATE
-    static const int abl = [] { const char *e = getenv("DVM_MLP_ABLATE"); return e ? atoi(e) : 0; }();
-    if (abl == 1 || abl == 2 || abl == 3) {
-        static bool warned = false;
-        if (!warned) warned = true, fprintf(stderr, "libdvm_hip: DVM_MLP_ABLATE=%d: the Deformer MLP returns WRONG results (timing experiment)\n", abl);
-        auto k = abl == 1 ? mlp_f16x2_kernel<2, 1> : abl == 2 ? mlp_f16x2_kernel<2, 2> : mlp_f16x2_kernel<2, 3>;
-        ensure_dyn_lds((const void *)k, (int)MH_LDS_BYTES);
-        hipLaunchKernelGGL(k, grid, block, MH_LDS_BYTES, s, z, rows, Wp0, b0, Wp1, b1, Wp2, b2, Wp3, b3, out, flag, nullptr);
-    } else
-#endif
-    if (ahead <= 2) {
-        ensure_dyn_lds((const void *)mlp_f16x2_kernel<2>, (int)MH_LDS_BYTES);
-        hipLaunchKernelGGL(mlp_f16x2_kernel<2>, grid, block, MH_LDS_BYTES, s, z, rows, Wp0, b0, Wp1, b1, Wp2, b2, Wp3, b3, out, flag, nullptr);
-    } else if (ahead <= 4) {
-        ensure_dyn_lds((const void *)mlp_f16x2_kernel<4>, (int)MH_LDS_BYTES);
-        hipLaunchKernelGGL(mlp_f16x2_kernel<4>, grid, block, MH_LDS_BYTES, s, z, rows, Wp0, b0, Wp1, b1, Wp2, b2, Wp3, b3, out, flag, nullptr);
-    } else {
-        ensure_dyn_lds((const void *)mlp_f16x2_kernel<8>, (int)MH_LDS_BYTES);
-        hipLaunchKernelGGL(mlp_f16x2_kernel<8>, grid, block, MH_LDS_BYTES, s, z, rows, Wp0, b0, Wp1, b1, Wp2, b2, Wp3, b3, out, flag, nullptr);
-    }
     prof_end(s, DVM_PROF_MLP);
     return flag;
 }

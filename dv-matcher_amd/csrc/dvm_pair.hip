@@ -181,7 +181,6 @@ void launch_assemble_pooled_planes(const float *vsrc, const float *vcorr, const 
 size_t mlp_pack_floats();
 size_t mlp_zplane_bytes(int rows);
 size_t mlp_zplane_row_bytes();
-bool mlp_persistent();
 void launch_mlp_rows(const float *z, int rows, const float *W0, const float *b0, const float *W1, const float *b1, const float *W2,
                      const float *b2, const float *W3, const float *b3, float *wp, float *out, hipStream_t s, int variant, void *zp);
 const int *launch_mlp_planes(const void *zp, int rows, const float *W0, const float *b0, const float *W1, const float *b1, const float *W2,
@@ -270,10 +269,7 @@ DVM_EXPORT size_t dvm_pair_workspace_bytes(int B, int N, int M) {
 }
 
 // 1 (default): the geometry chain runs on a helper stream next to the soft-correspondence chain; 0: one stream
-static int g_pair_overlap = [] {
-    const char *e = getenv("DVM_PAIR_OVERLAP");
-    return (e && atoi(e) == 0) ? 0 : 1;
-}();
+static int g_pair_overlap = options().pair_overlap;
 
 DVM_EXPORT int dvm_pair_set_overlap(int on) {
     const int prev = g_pair_overlap;
@@ -386,9 +382,9 @@ static int pair_fwd_impl(const float *feat1, const float *feat2, const float *ve
     const int Nn1 = N / 2, Nn2 = M / 2;
     float *z21 = w.z + (size_t)B * Nn1 * 264;
     const int rows = B * (Nn1 + Nn2);
-    if (mlp_persistent()) {
-        // the rows straight in the plane form the persistent MLP kernel stages by LDS-DMA; the fp32 rows are written (and the
-        // bf16x3 kernel runs) only if that kernel's range flag comes up: three gated launches that return at once otherwise
+    {
+        // the rows straight in the plane form the MLP kernel stages by LDS-DMA; the fp32 rows are written (and the bf16x3 kernel
+        // runs) only if that kernel's range flag comes up: three gated launches that return at once otherwise
         char *zp21 = w.zp + (size_t)B * Nn1 * mlp_zplane_row_bytes();
         launch_assemble_pooled_planes(verts1, verts12, w.gall[0], w.gall[1], w.pval[0], w.pidx[0], w.nodes[0], B, N, M, Nn1, w.zp, s);
         launch_assemble_pooled_planes(verts2, verts21, w.gall[1], w.gall[0], w.pval[1], w.pidx[1], w.nodes[1], B, M, N, Nn2, zp21, s);
@@ -396,10 +392,6 @@ static int pair_fwd_impl(const float *feat1, const float *feat2, const float *ve
         launch_assemble_pooled(verts1, verts12, w.gall[0], w.gall[1], w.pval[0], w.pidx[0], w.nodes[0], B, N, M, Nn1, w.z, s, flag);
         launch_assemble_pooled(verts2, verts21, w.gall[1], w.gall[0], w.pval[1], w.pidx[1], w.nodes[1], B, M, N, Nn2, z21, s, flag);
         launch_mlp_fallback(w.z, rows, W0, b0, W1, b1, W2, b2, W3, b3, w.wp, w.def9, s, flag);
-    } else {
-        launch_assemble_pooled(verts1, verts12, w.gall[0], w.gall[1], w.pval[0], w.pidx[0], w.nodes[0], B, N, M, Nn1, w.z, s);
-        launch_assemble_pooled(verts2, verts21, w.gall[1], w.gall[0], w.pval[1], w.pidx[1], w.nodes[1], B, M, N, Nn2, z21, s);
-        launch_mlp_rows(w.z, rows, W0, b0, W1, b1, W2, b2, W3, b3, w.wp, w.def9, s, 0, nullptr);
     }
     // ---- ED warp + ARAP (losses[:,2])
     float *def21 = w.def9 + (size_t)B * Nn1 * 9, *R21 = w.R + (size_t)B * Nn1 * 9, *T21v = w.T + (size_t)B * Nn1 * 3;

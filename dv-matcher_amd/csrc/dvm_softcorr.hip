@@ -622,15 +622,6 @@ void launch_rownorm2(const float *x, int rows, int K, float *out, hipStream_t s)
 size_t softcorr_pair_ws_bytes(int B, int N, int M) { return align_up(514 * sizeof(int)) + softcorr_f16_ws_bytes(B, N, M, true); }
 int launch_softcorr_pair(const float *f1, const float *f2, float *n1, float *n2, int B, int N, int M, float neg_alpha, float *val12,
                          int32_t *idx12, float *val21, int32_t *idx21, void *ws, size_t ws_bytes, hipStream_t s) {
-    static const int forced = [] {
-        const char *e = getenv("DVM_SOFTCORR_VARIANT");
-        return e ? atoi(e) : 3;
-    }();
-    if (forced == 2) {
-        launch_rownorm2(f1, B * N, 128, n1, s);
-        launch_rownorm2(f2, B * M, 128, n2, s);
-        return launch_softcorr_both(f1, f2, n1, n2, B, N, M, neg_alpha, val12, idx12, val21, idx21, s);
-    }
     Arena ar(ws, ws_bytes);
     int *slots = ar.take<int>(2 * 256 + 2);
     int *amax = slots + 512;
@@ -688,13 +679,7 @@ DVM_EXPORT int dvm_softcorr_fwd_f32(const float *f1, const float *f2, int B, int
         return DVM_ENOSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
-    if (variant == 0 && d == MF_D && topk <= 10) {  // auto: the fp16-split sweep unless DVM_SOFTCORR_VARIANT (debug, A/B) says otherwise
-        static const int forced = [] {
-            const char *e = getenv("DVM_SOFTCORR_VARIANT");
-            return e ? atoi(e) : 3;
-        }();
-        variant = forced >= 1 && forced <= 3 ? forced : 3;
-    }
+    if (variant == 0 && d == MF_D && topk <= 10) variant = 3;   // auto: the fp16-split sweep (variants 1 / 2: the `variant` argument)
     if (variant == 3) {
         int *slots = ar.take<int>(2 * 256 + 2);
         int *amax = slots + 512;

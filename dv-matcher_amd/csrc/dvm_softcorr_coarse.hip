@@ -605,8 +605,7 @@ void launch_coarse(const HBArgs &a, const char *knf0, const char *knf1, const in
     c.route = a.route;
     c.nb = a.nb;
     c.stamps = nullptr;
-    static const bool stamps_on = getenv("DVM_K1_STAMPS") != nullptr;
-    if (stamps_on) {   // diagnostic: synchronous, allocates — never taken in production
+    if (options().debug & DVM_DEBUG_K1_STAMPS) {   // diagnostic: synchronous, allocates — never taken in production
         unsigned long long *dbuf = nullptr;
         const size_t n = (size_t)nblocks * HC_WAVES * 8;
         if (hipMalloc(&dbuf, n * sizeof(unsigned long long)) != hipSuccess) return;

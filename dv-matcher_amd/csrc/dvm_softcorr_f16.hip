@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void sample_absmax_kernel(const float *__restr
 // instructions per row pair.  (The same order on the 8-columns-per-lane layout costs 48 DPP additions per row and lane: built
 // first, 355 us per launch.)
 constexpr int RS_LROW = 160;          // floats between rows in LDS
-template <int RS_ROWS>   // rows per 16-lane group and trip (all requested before the first is used): DVM_PREP_ROWS = 1 | 2 | 4
+template <int RS_ROWS>   // rows per 16-lane group and trip (all requested before the first is used); 2 ships
 __global__ __launch_bounds__(256) void rownorm_split_kernel(const float *__restrict__ x, long rows, float *__restrict__ nrm,
                                                             int *__restrict__ absmax_slots, const int *__restrict__ spec,
                                                             char *__restrict__ planes) {
@@ -1108,22 +1108,8 @@ __global__ __launch_bounds__(256) void argmin_exact_rows_kernel(const AMArgs arg
 
 }  // namespace
 
-// routing thresholds of the probe (fractions of a row within the cut), env DVM_K1_ROUTE_P="p_coarse,p_lean"; DVM_K1_ROUTE
-// forces one route (K1_ROUTE_*: 0 full, 1 lean, 3 coarse), DVM_K1_ROUTE_DEBUG prints the routes of every launch (synchronous)
-struct RoutePolicy {
-    int forced;
-    float p_coarse, p_lean;
-    bool debug;
-};
-static const RoutePolicy &route_policy() {
-    static const RoutePolicy pol = [] {
-        RoutePolicy r{-1, 0.0014f, 0.02f, getenv("DVM_K1_ROUTE_DEBUG") != nullptr};
-        if (const char *e = getenv("DVM_K1_ROUTE")) r.forced = atoi(e);
-        if (const char *e = getenv("DVM_K1_ROUTE_P")) (void)sscanf(e, "%f,%f", &r.p_coarse, &r.p_lean);
-        return r;
-    }();
-    return pol;
-}
+// routing: Options::k1_route forces one route (K1_ROUTE_*: 0 full, 1 lean, 3 coarse; -1 = the probe decides), k1_p_coarse / k1_p_lean
+// are the probe's thresholds (fractions of a row within the cut), DVM_DEBUG & 1 prints the routes of every launch (synchronous)
 static void report_routes(const int *route, const float *frac, int n, hipStream_t s) {   // diagnostic
     std::vector<int> r(n);
     std::vector<float> p(n);
@@ -1192,17 +1178,12 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
     }
     const long r1 = (long)B * N, r2 = (long)B * M;
     (void)hipMemsetAsync(nmax1, 0, 2 * align_up((size_t)B * sizeof(float)) + 2 * sizeof(int), s);
-    static const bool fuse_ok = [] { const char *e = getenv("DVM_K1_FUSED_PREP"); return !(e && atoi(e) == 0); }();
-    if (fuse_slots && fuse_ok) {
+    if (fuse_slots) {
         (void)hipMemsetAsync(fuse_slots, 0, 512 * sizeof(int), s);
         (void)hipMemsetAsync(spec, 0, 2 * sizeof(int), s);
         hipLaunchKernelGGL(sample_absmax_kernel, dim3(256), dim3(256), 0, s, f1, r1, f2, r2, spec);
-        static const int prep_rows = [] { const char *e = getenv("DVM_PREP_ROWS"); const int v = e ? atoi(e) : 2; return v == 1 || v == 4 ? v : 2; }();
-        auto prep = [&](const float *f, long r, float *nn, int *slots, char *pp) {
-            const auto grid = [&](int rr) { return dim3((unsigned)((r + 16 * rr - 1) / (16 * rr))); };
-            if (prep_rows == 1) hipLaunchKernelGGL(rownorm_split_kernel<1>, grid(1), dim3(256), 0, s, f, r, nn, slots, spec, pp);
-            else if (prep_rows == 4) hipLaunchKernelGGL(rownorm_split_kernel<4>, grid(4), dim3(256), 0, s, f, r, nn, slots, spec, pp);
-            else hipLaunchKernelGGL(rownorm_split_kernel<2>, grid(2), dim3(256), 0, s, f, r, nn, slots, spec, pp);
+        auto prep = [&](const float *f, long r, float *nn, int *slots, char *pp) {   // 2 rows per 16-lane group and trip (1: 315 us, 2: 296, 4: 365)
+            hipLaunchKernelGGL(rownorm_split_kernel<2>, dim3((unsigned)((r + 31) / 32)), dim3(256), 0, s, f, r, nn, slots, spec, pp);
         };
         prep(f1, r1, (float *)n1, fuse_slots, p1);
         prep(f2, r2, (float *)n2, fuse_slots + 256, p2);
@@ -1210,12 +1191,6 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
         hipLaunchKernelGGL(split_planes_gated_kernel, dim3(2048), dim3(256), 0, s, f1, r1, amax, spec, p1);
         hipLaunchKernelGGL(split_planes_gated_kernel, dim3(2048), dim3(256), 0, s, f2, r2, amax + 1, spec, p2);
     } else {
-        if (fuse_slots) {   // (DVM_K1_FUSED_PREP=0: the two-pass preparation, for A/B)
-            (void)hipMemsetAsync(fuse_slots, 0, 512 * sizeof(int), s);
-            launch_rownorm2_absmax(f1, (int)r1, (float *)n1, fuse_slots, s);
-            launch_rownorm2_absmax(f2, (int)r2, (float *)n2, fuse_slots + 256, s);
-            launch_absmax_finalize(fuse_slots, 2, (int *)amax_in, s);
-        }
         if (!amax_in) {
             hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, s, f1, r1 * 32, amax_own);
             hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, s, f2, r2 * 32, amax_own + 1);
@@ -1231,22 +1206,22 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
     // probe; DVM_K1_ROUTE = 0 / 1 / 2 forces one kernel for all of them (A/B measurements), DVM_K1_SWEEP=0 takes the second
     // form out of the choice.
     const bool lean = -neg_alpha >= 32.f;
-    const RoutePolicy &pol = route_policy();
+    const Options &pol = options();
     const bool havec = coarse_supports(N, M);
-    const bool routed = lean && pol.forced < 0;
-    const int fixed = !lean ? K1_ROUTE_FULL : pol.forced < 0 ? -1
-                     : (pol.forced == K1_ROUTE_COARSE && havec) ? K1_ROUTE_COARSE : pol.forced == K1_ROUTE_FULL ? K1_ROUTE_FULL : K1_ROUTE_LEAN;
+    const bool routed = lean && pol.k1_route < 0;
+    const int fixed = !lean ? K1_ROUTE_FULL : pol.k1_route < 0 ? -1
+                     : (pol.k1_route == K1_ROUTE_COARSE && havec) ? K1_ROUTE_COARSE : pol.k1_route == K1_ROUTE_FULL ? K1_ROUTE_FULL : K1_ROUTE_LEAN;
     if (routed) {
         K1ProbeArgs pa;
         pa.f[0] = f1, pa.f[1] = f2, pa.n[0] = n1, pa.n[1] = n2;
         pa.rows[0] = N, pa.rows[1] = M;
         pa.cutw = 20.f / -neg_alpha;
-        pa.p_coarse = pol.p_coarse, pa.p_lean = pol.p_lean;
+        pa.p_coarse = pol.k1_p_coarse, pa.p_lean = pol.k1_p_lean;
         pa.have_coarse = havec;
         pa.route = route, pa.frac = pfrac;
         hipLaunchKernelGGL(k1_probe_kernel, dim3(B, both ? 2 : 1), dim3(256), 0, s, pa);
         hipLaunchKernelGGL(k1_route_kernel, dim3(both ? 2 : 1), dim3(256), 0, s, pa, B);
-        if (pol.debug) report_routes(route, pfrac, B * (both ? 2 : 1), s);
+        if (pol.debug & DVM_DEBUG_K1_ROUTES) report_routes(route, pfrac, B * (both ? 2 : 1), s);
     }
     if (routed ? havec : fixed == K1_ROUTE_COARSE) {
         launch_norm_frags(n2, B, M, Mp, amax, nf2, s);
@@ -1320,8 +1295,7 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
                   : HXGroup{nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     x.neg_alpha = neg_alpha;
     x.topk = topk;
-    static const bool flag_debug = getenv("DVM_K1_FLAG_DEBUG") != nullptr;   // diagnostic (synchronous): rows pass B could not certify
-    if (flag_debug) {
+    if (options().debug & DVM_DEBUG_K1_FLAGGED) {   // diagnostic (synchronous): rows pass B could not certify
         int n[2] = {0, 0};
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(&n[0], flag[0], sizeof(int), hipMemcpyDeviceToHost);

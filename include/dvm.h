@@ -41,6 +41,21 @@ extern "C" {
 #define DVM_ELAUNCH (-2)   /* HIP launch / runtime error */
 #define DVM_ENOSPACE (-3)  /* workspace too small */
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Environment options of the library: SIX variables, read once when the library is loaded (csrc/dvm_api.cpp::options()).
+ * Nothing else in the library reads the environment; every option selects among HIP paths (there is no CPU path).
+ *
+ *   DVM_DETERMINISTIC=1        initial value of the dvm_set_deterministic flag (fixed summation order in LG-Net's backward)
+ *   DVM_K1_ROUTE=0|1|3         force pass A of the soft correspondence at alpha >= 32: 0 full first form, 1 lean first form,
+ *                              3 coarse screen; default: a probe picks per launch and direction, and a device-side gate sends a
+ *                              direction the coarse screen serves badly through the lean form (results never depend on the route)
+ *   DVM_K1_ROUTE_P="pc,pl"     the probe's thresholds (fractions of a row within the softmax cut; default 0.0014,0.02)
+ *   DVM_LINEAR_CFG=0..7        tile configuration of dvm_linear_f32 (default: chosen per shape; all give the same bits)
+ *   DVM_PAIR_OVERLAP=0         initial value of dvm_pair_set_overlap (helper-stream overlap of the pair forward)
+ *   DVM_DEBUG=<bits>           synchronous diagnostics on stderr: 1 K1 routes per launch, 2 rows sent to the exact-rows kernel,
+ *                              4 grid-Chamfer query statistics, 8 K1 coarse-screen cycle stamps, 16 Deformer-MLP cycle stamps
+ * --------------------------------------------------------------------------------------------------------------------- */
+
 int dvm_abi_version(void);
 const char *dvm_last_error(void);
 /* number of visible HIP devices (<=0: none) — lets callers fail loudly. */

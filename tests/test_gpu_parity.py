@@ -111,7 +111,7 @@ def test_softcorr_routed_sweeps_vs_oracle(ops, alpha):
 
 
 def test_softcorr_probe_routes():
-    """The probe's choice on the two synthetic feature sets of SURVEY 8d, read from the DVM_K1_ROUTE_DEBUG report of a child
+    """The probe's choice on the two synthetic feature sets of SURVEY 8d, read from the DVM_DEBUG=1 report of a child
     process (the policy is read once per process): random features -> lean first form at alpha 33 (seven columns of a row within
     the cut: more than the coarse screen's list certifies for every row), the coarse screen at 100 and 150; trained-like features
     -> full first form at alpha 33, lean first form at 100 and 150."""
@@ -126,7 +126,7 @@ def test_softcorr_probe_routes():
         "    for alpha in (33.0, 100.0, 150.0):\n"
         "        ops.softcorr(f1, f2, alpha, topk=10, variant=3)\n"
         "torch.cuda.synchronize()\n" % ROOT)
-    env = dict(os.environ, DVM_K1_ROUTE_DEBUG="1")
+    env = dict(os.environ, DVM_DEBUG="1")
     env.pop("DVM_K1_ROUTE", None), env.pop("DVM_K1_ROUTE_P", None)
     res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr[-2000:]
@@ -137,40 +137,31 @@ def test_softcorr_probe_routes():
         assert w in ln, (ln, w)
 
 
-def test_pair_forward_fused_preparation_equals_two_pass(tmp_path):
+@pytest.mark.parametrize("mode", ["sq", "spike", "ragged", "zero"])
+def test_pair_forward_fused_preparation_equals_two_pass(ops, golden, mode):
     """The pair path makes the row norms, the absmax and the fp16 planes of the features in ONE pass (rownorm_split_kernel,
     dvm_softcorr_f16.hip) with a provisional scale from a 1/64 sample of the rows, and re-makes the planes only when the true
-    absmax has another exponent.  Every output must be the two-pass path's (DVM_K1_FUSED_PREP=0), bit for bit: on random
-    features (the sample is right), with one large value in a row the sample does not see (the planes are re-made), at a
-    shape whose row counts are no multiples of anything, and for all-zero features."""
-    code = (
-        "import os, sys, numpy as np, torch\n"
-        "sys.path.insert(0, os.path.join(%r, 'dv-matcher_amd'))\n"
-        "from dvm import ops\n"
-        "wl = ops.deformer_weight_list(dict(np.load(os.path.join(%r, 'tests', 'golden', 'deformer_scape_r_weights.npz'))), 'cuda')\n"
-        "g = torch.Generator().manual_seed(21)\n"
-        "out = {}\n"
-        "for name, (B, N, M, mode) in {'sq': (3, 2048, 2048, 0), 'spike': (3, 2048, 2048, 1), 'ragged': (2, 1021, 777, 0), 'zero': (1, 256, 256, 2)}.items():\n"
-        "    f1, f2 = torch.randn(B, N, 128, generator=g), torch.randn(B, M, 128, generator=g)\n"
-        "    if mode == 1: f2[1, 33, 7] = 300.0\n"
-        "    if mode == 2: f1, f2 = f1 * 0, f2 * 0\n"
-        "    v1, v2 = torch.rand(B, N, 3, generator=g), torch.rand(B, M, 3, generator=g)\n"
-        "    s1 = torch.zeros(B, dtype=torch.int32)\n"
-        "    o = ops.pair_forward(wl, f1.cuda(), f2.cuda(), v1.cuda(), v2.cuda(), 100.0, s1.cuda(), s1.cuda())\n"
-        "    for d, od in enumerate(o):\n"
-        "        for k, t in od.items(): out['%%s_%%d_%%s' %% (name, d, k)] = t.cpu().numpy()\n"
-        "torch.cuda.synchronize()\n"
-        "np.savez(sys.argv[1], **out)\n" % (ROOT, ROOT))
-    res = {}
-    for mode in ("1", "0"):
-        path = str(tmp_path / ("prep%s.npz" % mode))
-        r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, DVM_K1_FUSED_PREP=mode), capture_output=True, text=True,
-                           timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        res[mode] = dict(np.load(path))
-    assert res["1"].keys() == res["0"].keys() and len(res["1"]) == 32
-    for k in res["1"]:
-        assert np.array_equal(res["1"][k], res["0"][k], equal_nan=True), k
+    absmax has another exponent.  The one-direction entry prepares in two passes (norms + absmax, then the planes): every output of
+    the fused call must be that path's, bit for bit — on random features (the sample is right), with one large value in a row the
+    sample does not see (the planes are re-made), at a shape whose row counts are no multiples of anything, and for all-zero
+    features.  (The planes themselves against a host computation: tools/check_planes.py.)"""
+    B, N, M = {"sq": (3, 2048, 2048), "spike": (3, 2048, 2048), "ragged": (2, 1021, 777), "zero": (1, 256, 256)}[mode]
+    wl = ops.deformer_weight_list(golden("deformer_scape_r_weights"), "cuda")
+    g = torch.Generator().manual_seed(21)
+    f1, f2 = torch.randn(B, N, 128, generator=g), torch.randn(B, M, 128, generator=g)
+    if mode == "spike":
+        f2[1, 33, 7] = 300.0
+    if mode == "zero":
+        f1, f2 = f1 * 0, f2 * 0
+    v1, v2 = torch.rand(B, N, 3, generator=g), torch.rand(B, M, 3, generator=g)
+    s = torch.zeros(B, dtype=torch.int32).cuda()
+    d = [t.cuda() for t in (f1, f2, v1, v2)]
+    o12, o21 = ops.pair_forward(wl, *d, 100.0, s, s)
+    r12 = ops.pair_direction(wl, d[0], d[1], d[2], d[3], 100.0, s)
+    r21 = ops.pair_direction(wl, d[1], d[0], d[3], d[2], 100.0, s)
+    for k in r12:
+        assert torch.equal(o12[k], r12[k]) or (torch.isnan(o12[k]) == torch.isnan(r12[k])).all() and torch.equal(torch.nan_to_num(o12[k]), torch.nan_to_num(r12[k])), ("12", k)
+        assert torch.equal(o21[k], r21[k]) or (torch.isnan(o21[k]) == torch.isnan(r21[k])).all() and torch.equal(torch.nan_to_num(o21[k]), torch.nan_to_num(r21[k])), ("21", k)
 
 
 def test_softcorr_duplicate_rows(ops):

@@ -24,14 +24,6 @@ def test_grid_searches_on_degenerate_clouds():
     assert len(re.findall(r"chamfer True  knn True  graph True", text)) == 8, text
 
 
-def test_grid_chamfer_deferred_form_on_degenerate_clouds():
-    """DVM_CHAMFER_DEFER=1: the queries the radius-1 cube does not certify are marked and gathered into full waves by a second
-    kernel (grid_chamfer_retry_kernel) instead of being walked / scanned by the wave that found them — same answers."""
-    text = _run("stress_geometry.py", DVM_CHAMFER_DEFER="1")
-    assert "mismatches: 0" in text, text
-    assert len(re.findall(r"chamfer True  knn True  graph True", text)) == 8, text
-
-
 def test_attention_cores_far_from_unit_scale():
     text = _run("stress_scales.py")
     lines = [ln for ln in text.splitlines() if ln.startswith(("SA ", "SAev", "N2P"))]
