@@ -1231,6 +1231,36 @@ DVM_EXPORT int dvm_pos_encoding_f32(const float *x, int B, int N, float *out, vo
     return DVM_OK;
 }
 
+namespace dvm {
+__global__ void minmax_final_kernel(const float *__restrict__ part, int nparts, float *__restrict__ out2) {
+    float mn = INFINITY, mx = -INFINITY;
+    for (int q = 0; q < nparts; ++q) mn = fminf(mn, part[2 * q]), mx = fmaxf(mx, part[2 * q + 1]);
+    out2[0] = mn, out2[1] = mx;
+}
+}  // namespace dvm
+// The same encoding with the range taken over ALL ranks' tensors (models/model.py:548 normalises with the min / max of the whole
+// batch: under data parallelism that is the global batch): this rank's min / max go to minmax2 (two floats of caller-owned device
+// memory), the caller's collective combines them (MIN on the first, MAX on the second, enqueued on `stream`), then the encoding.
+DVM_EXPORT int dvm_pos_encoding_sync_f32(const float *x, int B, int N, float *out, void *ws, size_t ws_bytes, const dvm_collective *coll,
+                                         float *minmax2, void *stream) {
+    DVM_REQUIRE(x && out && B >= 1 && N >= 1 && coll && coll->allreduce && minmax2, "dvm_pos_encoding_sync_f32: bad arguments");
+    Arena ar(ws, ws_bytes);
+    float *part = ar.take<float>(2 * 256);
+    if (!ar.ok()) {
+        set_error("dvm_pos_encoding_sync_f32: workspace too small");
+        return DVM_ENOSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    long n = (long)B * 3 * N;
+    int nparts = (int)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256);
+    hipLaunchKernelGGL(minmax_partial_kernel, dim3(nparts), dim3(256), 0, s, x, n, part);
+    hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(1), 0, s, part, nparts, minmax2);
+    int rc = coll->allreduce(coll->user, minmax2, 1, 0, 1, stream);
+    if (rc == 0) rc = coll->allreduce(coll->user, minmax2 + 1, 1, 0, 2, stream);
+    DVM_REQUIRE(rc == 0, "dvm_pos_encoding_sync_f32: the caller's all-reduce failed (%d)", rc);
+    return dvm_pos_encoding_minmax_f32(x, minmax2, B, N, out, stream);
+}
+
 DVM_EXPORT int dvm_pos_encoding_minmax_f32(const float *x, const float *minmax, int B, int N, float *out, void *stream) {
     DVM_REQUIRE(x && minmax && out && B >= 1 && N >= 1, "dvm_pos_encoding_minmax_f32: bad arguments");
     hipStream_t s = (hipStream_t)stream;

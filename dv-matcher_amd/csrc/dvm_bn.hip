@@ -264,19 +264,28 @@ __global__ __launch_bounds__(256) void bn_pm_finalize_fwd_kernel(const double *_
                                                                  const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
                                                                  float momentum, float *__restrict__ fin, float *__restrict__ mean_out,
                                                                  float *__restrict__ invstd_out, float *__restrict__ running_mean,
-                                                                 float *__restrict__ running_var, float *__restrict__ unb_out, int groups) {
+                                                                 float *__restrict__ running_var, float *__restrict__ unb_out, int groups,
+                                                                 const double *__restrict__ glob) {
+    // glob (cross-rank statistics): [groups][C][2] totals + [groups] row counts, summed over the ranks — then `partial` is not read
     const int cl = threadIdx.x & (PM_CG - 1), sl = threadIdx.x / PM_CG, c = blockIdx.x * PM_CG + cl;
     for (int g = 0; g < groups; ++g) {   // group after group: the running statistics take the groups' updates in order
         double ta, tq;
-        const bool lead = pm_sum_partials(partial + (size_t)g * S * C * 2, S, C, c, cl, sl, ta, tq);
+        bool lead;
+        double Rd = (double)R;
+        if (glob) {
+            lead = sl == 0 && c < C;
+            if (lead) ta = glob[((size_t)g * C + c) * 2], tq = glob[((size_t)g * C + c) * 2 + 1], Rd = glob[(size_t)groups * C * 2 + g];
+        } else {
+            lead = pm_sum_partials(partial + (size_t)g * S * C * 2, S, C, c, cl, sl, ta, tq);
+        }
         if (lead) {
-            const double mean = ta / (double)R;
-            double var = tq / (double)R - mean * mean;
+            const double mean = ta / Rd;
+            double var = tq / Rd - mean * mean;
             var = var > 0.0 ? var : 0.0;
             const float invstd = (float)(1.0 / sqrt(var + (double)eps)), mf = (float)mean;
             mean_out[(size_t)g * C + c] = mf;
             invstd_out[(size_t)g * C + c] = invstd;
-            const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
+            const double unb = Rd > 1.0 ? var * Rd / (Rd - 1.0) : var;
             if (unb_out) unb_out[(size_t)g * C + c] = (float)unb;   // for a deferred running-statistics update: the same float
             if (running_mean) {
                 running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mf;
@@ -288,14 +297,33 @@ __global__ __launch_bounds__(256) void bn_pm_finalize_fwd_kernel(const double *_
             f[2] = (gamma ? gamma[c] : 1.f) * invstd;
             f[3] = beta ? beta[c] : 0.f;
         }
-        __syncthreads();   // (pm_sum_partials' shared arrays are reused by the next group)
+        if (!glob) __syncthreads();   // (pm_sum_partials' shared arrays are reused by the next group)
+    }
+}
+
+// partials -> per-(group, channel) totals in pm_sum_partials' order + the groups' row counts: what the ranks of a data-parallel
+// step combine (tot [groups][C][2] + [groups], doubles)
+__global__ __launch_bounds__(256) void bn_pm_totals_kernel(const double *__restrict__ partial, int S, long R, int C, int groups,
+                                                           double *__restrict__ tot) {
+    const int cl = threadIdx.x & (PM_CG - 1), sl = threadIdx.x / PM_CG, c = blockIdx.x * PM_CG + cl;
+    for (int g = 0; g < groups; ++g) {
+        double ta, tq;
+        if (pm_sum_partials(partial + (size_t)g * S * C * 2, S, C, c, cl, sl, ta, tq)) {
+            tot[((size_t)g * C + c) * 2] = ta;
+            tot[((size_t)g * C + c) * 2 + 1] = tq;
+            if (c == 0) tot[(size_t)groups * C * 2 + g] = (double)R;
+        }
+        __syncthreads();
     }
 }
 
 __global__ __launch_bounds__(256) void bn_pm_finalize_bwd_kernel(const double *__restrict__ partial, int S, long R, int C,
                                                                  const float *__restrict__ gamma, const float *__restrict__ mean,
                                                                  const float *__restrict__ invstd, float *__restrict__ fin,
-                                                                 float *__restrict__ dgamma, float *__restrict__ dbeta, int accumulate, int groups) {
+                                                                 float *__restrict__ dgamma, float *__restrict__ dbeta, int accumulate, int groups,
+                                                                 const double *__restrict__ glob) {
+    // glob (cross-rank statistics, as in the forward): the means of dz and dz xhat are taken over ALL ranks' rows; the parameter
+    // gradients stay this rank's own sums (the gradient all-reduce adds the ranks')
     const int cl = threadIdx.x & (PM_CG - 1), sl = threadIdx.x / PM_CG, c = blockIdx.x * PM_CG + cl;
     float sg = 0.f, sb = 0.f;   // the groups' parameter gradients, added in group order
     bool any = false;
@@ -306,8 +334,10 @@ __global__ __launch_bounds__(256) void bn_pm_finalize_bwd_kernel(const double *_
             any = true;
             sg += (float)tq, sb += (float)ta;
             float *f = fin + ((size_t)g * C + c) * 4;
-            f[0] = (float)(ta / (double)R);
-            f[1] = (float)(tq / (double)R);
+            double Rd = (double)R;
+            if (glob) ta = glob[((size_t)g * C + c) * 2], tq = glob[((size_t)g * C + c) * 2 + 1], Rd = glob[(size_t)groups * C * 2 + g];
+            f[0] = (float)(ta / Rd);
+            f[1] = (float)(tq / Rd);
             f[2] = (gamma ? gamma[c] : 1.f) * invstd[(size_t)g * C + c];
             f[3] = 0.f;
         }
@@ -454,10 +484,21 @@ DVM_EXPORT size_t dvm_bn_pm_groups_workspace_bytes(long R, int C, int groups) {
     return align_up((size_t)groups * C * pm_splits_for(R, C) * 2 * sizeof(double)) + align_up((size_t)groups * C * 4 * sizeof(float));
 }
 
+DVM_EXPORT size_t dvm_bn_pm_sync_bytes(int C, int groups) { return align_up(((size_t)groups * C * 2 + groups) * sizeof(double)); }
+
 DVM_EXPORT int dvm_bn_act_train_fwd_pm_var_f32(const float *x, const float *res, const float *gamma, const float *beta, long R, int C, int groups,
                                                float eps, float slope, float momentum, float *y, float *save_mean, float *save_invstd,
                                                float *save_var_unbiased, float *running_mean, float *running_var, void *ws, size_t ws_bytes,
                                                void *stream) {
+    return dvm_bn_act_train_fwd_pm_sync_f32(x, res, gamma, beta, R, C, groups, eps, slope, momentum, y, save_mean, save_invstd, save_var_unbiased,
+                                            running_mean, running_var, ws, ws_bytes, nullptr, nullptr, stream);
+}
+
+DVM_EXPORT int dvm_bn_act_train_fwd_pm_sync_f32(const float *x, const float *res, const float *gamma, const float *beta, long R, int C, int groups,
+                                                float eps, float slope, float momentum, float *y, float *save_mean, float *save_invstd,
+                                                float *save_var_unbiased, float *running_mean, float *running_var, void *ws, size_t ws_bytes,
+                                                const dvm_collective *coll, void *sync_buf, void *stream) {
+    DVM_REQUIRE(!coll || (coll->allreduce && sync_buf), "dvm_bn_act_train_fwd_pm_sync_f32: a collective needs its function and the statistics buffer");
     DVM_REQUIRE(groups >= 1 && groups <= 64, "dvm_bn_act_train_fwd_pm_var_f32: bad group count %d", groups);
     DVM_REQUIRE(x && y && save_mean && save_invstd, "dvm_bn_act_train_fwd_pm_f32: null pointer");
     DVM_REQUIRE(R >= 1 && C >= 4 && C % 4 == 0 && C <= 1024, "dvm_bn_act_train_fwd_pm_f32: need R >= 1 and C a multiple of 4, at most 1024 (R=%ld C=%d)", R, C);
@@ -475,8 +516,16 @@ DVM_EXPORT int dvm_bn_act_train_fwd_pm_var_f32(const float *x, const float *res,
     const long Rall = R * groups;   // R: rows PER GROUP
     hipLaunchKernelGGL(bn_pm_reduce_kernel<false>, dim3(S, C / CG, groups), dim3(256), 0, s, x, res, nullptr, nullptr, nullptr, nullptr, R, C, CG,
                        pm_chunk_for(R, C), slope, partial);
+    const double *glob = nullptr;
+    if (coll) {   // per-(group, channel) totals + row counts -> summed over the ranks by the caller's collective, on this stream
+        double *tot = (double *)sync_buf;
+        hipLaunchKernelGGL(bn_pm_totals_kernel, dim3((C + PM_CG - 1) / PM_CG), dim3(256), 0, s, partial, S, R, C, groups, tot);
+        const int rc = coll->allreduce(coll->user, tot, (size_t)groups * C * 2 + groups, 1, 0, stream);
+        DVM_REQUIRE(rc == 0, "dvm_bn_act_train_fwd_pm_sync_f32: the caller's all-reduce failed (%d)", rc);
+        glob = tot;
+    }
     hipLaunchKernelGGL(bn_pm_finalize_fwd_kernel, dim3((C + PM_CG - 1) / PM_CG), dim3(256), 0, s, partial, S, R, C, gamma, beta, eps, momentum, fin,
-                       save_mean, save_invstd, running_mean, running_var, save_var_unbiased, groups);
+                       save_mean, save_invstd, running_mean, running_var, save_var_unbiased, groups, glob);
     hipLaunchKernelGGL(bn_pm_apply_kernel<false>, dim3((unsigned)((Rall * C / 4 + 255) / 256)), dim3(256), 0, s, x, res, nullptr, nullptr, fin,
                        nullptr, nullptr, Rall, C, slope, y, R);
     DVM_CHECK_LAUNCH("bn_act_train_fwd_pm");
@@ -493,6 +542,15 @@ DVM_EXPORT int dvm_bn_act_train_bwd_pm_f32(const float *dy, const float *y, cons
 DVM_EXPORT int dvm_bn_act_train_bwd_pm_groups_f32(const float *dy, const float *y, const float *x, const float *res, const float *gamma,
                                                   const float *save_mean, const float *save_invstd, long R, int C, int groups, float slope,
                                                   float *dx, float *dgamma, float *dbeta, int accumulate, void *ws, size_t ws_bytes, void *stream) {
+    return dvm_bn_act_train_bwd_pm_sync_f32(dy, y, x, res, gamma, save_mean, save_invstd, R, C, groups, slope, dx, dgamma, dbeta, accumulate, ws, ws_bytes,
+                                            nullptr, nullptr, stream);
+}
+
+DVM_EXPORT int dvm_bn_act_train_bwd_pm_sync_f32(const float *dy, const float *y, const float *x, const float *res, const float *gamma,
+                                                const float *save_mean, const float *save_invstd, long R, int C, int groups, float slope,
+                                                float *dx, float *dgamma, float *dbeta, int accumulate, void *ws, size_t ws_bytes,
+                                                const dvm_collective *coll, void *sync_buf, void *stream) {
+    DVM_REQUIRE(!coll || (coll->allreduce && sync_buf), "dvm_bn_act_train_bwd_pm_sync_f32: a collective needs its function and the statistics buffer");
     DVM_REQUIRE(dy && y && x && save_mean && save_invstd && dx, "dvm_bn_act_train_bwd_pm_f32: null pointer");
     DVM_REQUIRE(groups >= 1 && groups <= 64, "dvm_bn_act_train_bwd_pm_groups_f32: bad group count %d", groups);
     DVM_REQUIRE(R >= 1 && C >= 4 && C % 4 == 0 && C <= 1024, "dvm_bn_act_train_bwd_pm_f32: need R >= 1 and C a multiple of 4, at most 1024 (R=%ld C=%d)", R, C);
@@ -509,8 +567,16 @@ DVM_EXPORT int dvm_bn_act_train_bwd_pm_groups_f32(const float *dy, const float *
     const long Rall = R * groups;   // R: rows PER GROUP
     hipLaunchKernelGGL(bn_pm_reduce_kernel<true>, dim3(S, C / CG, groups), dim3(256), 0, s, x, res, dy, y, save_mean, save_invstd, R, C, CG,
                        pm_chunk_for(R, C), slope, partial);
+    const double *glob = nullptr;
+    if (coll) {
+        double *tot = (double *)sync_buf;
+        hipLaunchKernelGGL(bn_pm_totals_kernel, dim3((C + PM_CG - 1) / PM_CG), dim3(256), 0, s, partial, S, R, C, groups, tot);
+        const int rc = coll->allreduce(coll->user, tot, (size_t)groups * C * 2 + groups, 1, 0, stream);
+        DVM_REQUIRE(rc == 0, "dvm_bn_act_train_bwd_pm_sync_f32: the caller's all-reduce failed (%d)", rc);
+        glob = tot;
+    }
     hipLaunchKernelGGL(bn_pm_finalize_bwd_kernel, dim3((C + PM_CG - 1) / PM_CG), dim3(256), 0, s, partial, S, R, C, gamma, save_mean, save_invstd, fin,
-                       dgamma, dbeta, accumulate, groups);
+                       dgamma, dbeta, accumulate, groups, glob);
     hipLaunchKernelGGL(bn_pm_apply_kernel<true>, dim3((unsigned)((Rall * C / 4 + 255) / 256)), dim3(256), 0, s, x, res, dy, y, fin, save_mean,
                        save_invstd, Rall, C, slope, dx, R);
     DVM_CHECK_LAUNCH("bn_act_train_bwd_pm");

@@ -552,15 +552,25 @@ __global__ __launch_bounds__(64 * HC_WAVES, 1) void softcorr_coarse_kernel(const
         for (int t = 0; t < HC_KL; ++t) out.insert((unsigned)__shfl_xor((int)kb[qb].e[t], 32, 64));
         if (h == 0 && qrow[qb] < N) {
             const size_t row = (size_t)b * N + qrow[qb];
+            // (16-byte stores: a row's 16 columns / distances are 64 contiguous bytes — as 4-byte stores, one per lane and entry at a
+            // 64-byte stride, the launch wrote 554 MB for 285 MB of lists)
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-            for (int t = 0; t < K1_KC_COARSE; ++t) {
-                const unsigned e = out.e[t];
-                const bool live = e < HC_REMOVED && e <= lim[qb];
-                // the entry's accumulator, rounded down to the 19 key bits it kept -> squared distance (a lower bound of the
-                // coarse value within 2^-14 of the accumulator: part of HC_ERR)
-                const float d2 = fmaxf(__uint_as_float(((e & 0xffffe000u) >> 4) + HC_KBASE) - rowc[qb], 0.f) * cf;
-                G.cidx[row * K1_KC_COARSE + t] = live ? entry_col(e) : 0x7fffffff;
-                G.cd2[row * K1_KC_COARSE + t] = live ? d2 : INFINITY;
+            for (int q = 0; q < K1_KC_COARSE / 4; ++q) {
+                i32x4 ci;
+                f32x4 cd;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned e = out.e[4 * q + u];
+                    const bool live = e < HC_REMOVED && e <= lim[qb];
+                    // the entry's accumulator, rounded down to the 19 key bits it kept -> squared distance (a lower bound of the
+                    // coarse value within 2^-14 of the accumulator: part of HC_ERR)
+                    const float d2 = fmaxf(__uint_as_float(((e & 0xffffe000u) >> 4) + HC_KBASE) - rowc[qb], 0.f) * cf;
+                    ci[u] = live ? entry_col(e) : 0x7fffffff;
+                    cd[u] = live ? d2 : INFINITY;
+                }
+                *(i32x4 *)(G.cidx + row * K1_KC_COARSE + 4 * q) = ci;
+                *(f32x4 *)(G.cd2 + row * K1_KC_COARSE + 4 * q) = cd;
             }
             G.lsum[row * 2] = 0.f;            // no softmax terms from this screen: pass B certifies that none is owed
             G.lsum[row * 2 + 1] = -INFINITY;

@@ -63,6 +63,7 @@ struct SaSave {
 struct ChainScratch {   // per stream: library workspaces + gradient ping-pong buffers of the backward
     void *bnws, *knnws, *saws, *sabws, *npbws, *wgws;
     size_t bn_bytes, knn_bytes, sa_bytes, sab_bytes, npb_bytes, wg_bytes;
+    void *syncbuf;         // cross-rank BatchNorm totals of one layer (dvm_bn_pm_sync_bytes(512, MAXG)): the caller's collective works in place
     float *colpart;        // colsum_accum partials
     unsigned *counter;
     float *g768, *g512a, *g512b, *g256a, *g256b, *ga, *gb, *gc, *gd, *ge, *dqkv, *dh, *dp;   // gradient scratch (backward)
@@ -70,7 +71,7 @@ struct ChainScratch {   // per stream: library workspaces + gradient ping-pong b
 };
 struct TrainWs {
     // saved by the forward
-    float *pe, *pews, *fpe;
+    float *pe, *pews, *fpe, *pesync;
     ConvSave cv[8];     // cv[1].y is the caller's `tmp`, cv[7].y the caller's `feat`
     NpSave np[7];
     SaSave sa[4];
@@ -92,6 +93,7 @@ void carve_chain(Arena &ar, int B, int N, int K, ChainScratch &c, bool local) {
             c.bn_bytes = b > c.bn_bytes ? b : c.bn_bytes;
         }
     c.bnws = ar.take<char>(c.bn_bytes);
+    c.syncbuf = ar.take<char>(dvm_bn_pm_sync_bytes(512, MAXG));
     c.knn_bytes = local ? dvm_knn_neg_workspace_bytes(B, N, N, 128, K) : 0;
     c.knnws = local ? (void *)ar.take<char>(c.knn_bytes) : nullptr;
     c.sa_bytes = local ? 0 : dvm_sa_attention_train_fwd_workspace_bytes(B, N);
@@ -132,6 +134,7 @@ void carve(Arena &ar, int B, int N, int K, TrainWs &w) {
     const size_t R = (size_t)B * N;
     w.pe = ar.take<float>(R * 384);
     w.pews = ar.take<float>(dvm_pos_encoding_workspace_bytes() / sizeof(float));
+    w.pesync = ar.take<float>(2 * MAXG);
     w.fpe = ar.take<float>(R * 384);
     for (int i = 0; i < 8; ++i) {
         w.cv[i].z = ar.take<float>(R * CONV_CO[i]);
@@ -201,6 +204,7 @@ struct Net {
     long R, Rg;
     float eps, momentum;
     bool defer_stats = false;   // leave the running statistics alone (dvm_uni3fc_train_running_stats_f32 applies the updates later)
+    const dvm_collective *coll = nullptr;   // data-parallel step: BatchNorm statistics and the position-encoding range over ALL ranks
     TrainWs w;
 };
 
@@ -208,8 +212,8 @@ struct Net {
 int bn_fwd(const Net &n, const float *x, const float *res, const float *g, const float *b, float *rm, float *rv, int C, float slope, float *y,
            const BnSave &sv, const ChainScratch &c, hipStream_t s) {
     // per group its own batch statistics (one launch set for all groups); the running statistics take the groups' updates in order
-    return dvm_bn_act_train_fwd_pm_var_f32(x, res, g, b, n.Rg, C, n.G, n.eps, slope, n.momentum, y, sv.mean, sv.invstd, sv.var,
-                                           n.defer_stats ? nullptr : rm, n.defer_stats ? nullptr : rv, c.bnws, c.bn_bytes, s);
+    return dvm_bn_act_train_fwd_pm_sync_f32(x, res, g, b, n.Rg, C, n.G, n.eps, slope, n.momentum, y, sv.mean, sv.invstd, sv.var,
+                                            n.defer_stats ? nullptr : rm, n.defer_stats ? nullptr : rv, c.bnws, c.bn_bytes, n.coll, c.syncbuf, s);
 }
 
 // conv block i: y = leaky_0.2(bn(x W^T))
@@ -272,7 +276,7 @@ void max_prefix(const Net &n, const float *wide, const float *x, unsigned long l
 // ---------------------------------------------------------------- backward pieces
 int bn_bwd(const Net &n, const float *dy, const float *y, const float *x, const float *res, const float *g, const BnSave &sv, int C, float slope,
            float *dx, float *dg, float *db, const ChainScratch &c, hipStream_t s) {
-    return dvm_bn_act_train_bwd_pm_groups_f32(dy, y, x, res, g, sv.mean, sv.invstd, n.Rg, C, n.G, slope, dx, dg, db, 1, c.bnws, c.bn_bytes, s);
+    return dvm_bn_act_train_bwd_pm_sync_f32(dy, y, x, res, g, sv.mean, sv.invstd, n.Rg, C, n.G, slope, dx, dg, db, 1, c.bnws, c.bn_bytes, n.coll, c.syncbuf, s);
 }
 // dX [R][K] = dY [R][Co] W [Co][K]  (+ res): dvm_linear_f32 with the operands' roles swapped
 int dgrad(const Net &n, const float *dy, const float *W, int Co, int K, const float *res, float *dx, hipStream_t s) {
@@ -405,12 +409,22 @@ DVM_EXPORT size_t dvm_uni3fc_train_workspace_bytes(int B, int N, int k) {
 DVM_EXPORT int dvm_uni3fc_train_fwd_f32(const float *xyz, const float *dino, int B, int N, const float *const *params, int nparams, int k, float eps,
                                         float momentum, int groups, int defer_running_stats, const int32_t *const *knn_forced,
                                         int32_t *const *knn_log, float *feat, float *tmp, void *arena, size_t arena_bytes, void *stream) {
+    return dvm_uni3fc_train_fwd_sync_f32(xyz, dino, B, N, params, nparams, k, eps, momentum, groups, defer_running_stats, knn_forced, knn_log, feat, tmp,
+                                         arena, arena_bytes, nullptr, stream);
+}
+
+DVM_EXPORT int dvm_uni3fc_train_fwd_sync_f32(const float *xyz, const float *dino, int B, int N, const float *const *params, int nparams, int k, float eps,
+                                             float momentum, int groups, int defer_running_stats, const int32_t *const *knn_forced,
+                                             int32_t *const *knn_log, float *feat, float *tmp, void *arena, size_t arena_bytes,
+                                             const dvm_collective *coll, void *stream) {
     DVM_REQUIRE(xyz && dino && params && feat && tmp, "dvm_uni3fc_train_fwd_f32: null pointer");
+    DVM_REQUIRE(!coll || coll->allreduce, "dvm_uni3fc_train_fwd_sync_f32: a collective without its function");
     T_TRY(check_args("dvm_uni3fc_train_fwd_f32", B, N, k, nparams, (const void *const *)params, false));
     Net n;
     T_TRY(check_groups("dvm_uni3fc_train_fwd_f32", B, groups));
     n.P = params, n.GR = nullptr, n.B = B, n.N = N, n.K = k, n.R = (long)B * N, n.eps = eps, n.momentum = momentum;
     n.G = groups, n.Rg = n.R / groups;
+    n.coll = coll;
     n.knn_forced = knn_forced, n.knn_log = knn_log;
     n.defer_stats = defer_running_stats != 0;
     Arena ar(arena, arena_bytes);
@@ -442,8 +456,12 @@ DVM_EXPORT int dvm_uni3fc_train_fwd_f32(const float *xyz, const float *dino, int
     // f = blk(conv, dino); tmp = blk(conv0, f + pos_encoding(x)^T)
     T_TRY(conv_fwd(n, 0, dino, w.cv[0].y, c0, s));
     for (int q = 0; q < n.G; ++q)   // the encoding normalises with the min / max over ONE call's tensor (models/model.py:548)
-        T_TRY(dvm_pos_encoding_f32(xyz + (size_t)q * (B / n.G) * 3 * N, B / n.G, N, w.pe + (size_t)q * n.Rg * 384, w.pews,
-                                   dvm_pos_encoding_workspace_bytes(), s));
+        if (n.coll)
+            T_TRY(dvm_pos_encoding_sync_f32(xyz + (size_t)q * (B / n.G) * 3 * N, B / n.G, N, w.pe + (size_t)q * n.Rg * 384, w.pews,
+                                            dvm_pos_encoding_workspace_bytes(), n.coll, w.pesync + 2 * q, s));
+        else
+            T_TRY(dvm_pos_encoding_f32(xyz + (size_t)q * (B / n.G) * 3 * N, B / n.G, N, w.pe + (size_t)q * n.Rg * 384, w.pews,
+                                       dvm_pos_encoding_workspace_bytes(), s));
     (void)hipMemcpyAsync(w.fpe, w.cv[0].y, (size_t)R * 384 * sizeof(float), hipMemcpyDeviceToDevice, s);
     hipLaunchKernelGGL(add_transposed_kernel, dim3((N + 31) / 32, 384 / 32, B), dim3(256), 0, s, w.fpe, w.pe, N, 384);
     T_TRY(conv_fwd(n, 1, w.fpe, tmp, c0, s));
@@ -497,13 +515,21 @@ DVM_EXPORT int dvm_uni3fc_train_fwd_f32(const float *xyz, const float *dino, int
 DVM_EXPORT int dvm_uni3fc_train_bwd_f32(const float *g_feat, const float *g_tmp, const float *dino, const float *feat, const float *tmp, int B, int N,
                                         const float *const *params, float *const *grads, int nparams, int k, int groups, void *arena,
                                         size_t arena_bytes, void *stream) {
+    return dvm_uni3fc_train_bwd_sync_f32(g_feat, g_tmp, dino, feat, tmp, B, N, params, grads, nparams, k, groups, arena, arena_bytes, nullptr, stream);
+}
+
+DVM_EXPORT int dvm_uni3fc_train_bwd_sync_f32(const float *g_feat, const float *g_tmp, const float *dino, const float *feat, const float *tmp, int B, int N,
+                                             const float *const *params, float *const *grads, int nparams, int k, int groups, void *arena,
+                                             size_t arena_bytes, const dvm_collective *coll, void *stream) {
     DVM_REQUIRE(g_feat && dino && feat && tmp && params && grads, "dvm_uni3fc_train_bwd_f32: null pointer");
+    DVM_REQUIRE(!coll || coll->allreduce, "dvm_uni3fc_train_bwd_sync_f32: a collective without its function");
     T_TRY(check_args("dvm_uni3fc_train_bwd_f32", B, N, k, nparams, (const void *const *)params, false));
     T_TRY(check_args("dvm_uni3fc_train_bwd_f32 (gradients)", B, N, k, nparams, (const void *const *)grads, true));
     Net n;
     T_TRY(check_groups("dvm_uni3fc_train_bwd_f32", B, groups));
     n.P = params, n.GR = grads, n.B = B, n.N = N, n.K = k, n.R = (long)B * N, n.eps = 0.f, n.momentum = 0.f;
     n.G = groups, n.Rg = n.R / groups;
+    n.coll = coll;
     Arena ar(arena, arena_bytes);
     carve(ar, B, N, k, n.w);
     if (!ar.ok()) {

@@ -65,6 +65,13 @@ SIGNATURES = {
     "dvm_bn_pm_groups_workspace_bytes": (c_size_t, [ctypes.c_long, c_int, c_int]),
     "dvm_bn_act_train_bwd_pm_groups_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, ctypes.c_long, c_int, c_int, c_float, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "dvm_uni3fc_train_bwd_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
+    # the same calls with the caller's collective for cross-rank statistics (dvm_collective *: passed as a pointer)
+    "dvm_uni3fc_train_fwd_sync_f32": (c_int, [_P, _P, c_int, c_int, _P, c_int, c_int, c_float, c_float, c_int, c_int, _P, _P, _P, _P, _P, c_size_t, _P, _P]),
+    "dvm_uni3fc_train_bwd_sync_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P, _P]),
+    "dvm_bn_pm_sync_bytes": (c_size_t, [c_int, c_int]),
+    "dvm_bn_act_train_fwd_pm_sync_f32": (c_int, [_P, _P, _P, _P, ctypes.c_long, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P, _P, _P]),
+    "dvm_bn_act_train_bwd_pm_sync_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, ctypes.c_long, c_int, c_int, c_float, _P, _P, _P, c_int, _P, c_size_t, _P, _P, _P]),
+    "dvm_pos_encoding_sync_f32": (c_int, [_P, c_int, c_int, _P, _P, c_size_t, _P, _P, _P]),
     "dvm_linear_wgrad_workspace_bytes": (c_size_t, [ctypes.c_long, c_int, c_int]),
     "dvm_linear_wgrad_ws_f32": (c_int, [_P, _P, ctypes.c_long, c_int, c_int, _P, _P, c_size_t, _P]),
     "dvm_set_deterministic": (c_int, [c_int]),

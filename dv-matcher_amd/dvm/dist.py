@@ -4,6 +4,8 @@ Pairs are independent units: the forward benchmark shards them with no collectiv
 has exactly one exchange step, the sum of the flat fp32 gradient (2.12 M floats, 8.5 MB) — one
 bucket, one all-reduce (RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests).
 """
+import ctypes
+
 import torch
 import torch.distributed as dist
 
@@ -90,3 +92,46 @@ def global_minmax(x, group=None):
         dist.all_reduce(mn, op=dist.ReduceOp.MIN, group=group)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
     return mn, mx
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The caller's collective of the library's *_sync_f32 entry points (include/dvm.h: dvm_collective), on torch.distributed.
+_ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p)
+
+
+class _CollectiveStruct(ctypes.Structure):
+    _fields_ = [("allreduce", _ALLREDUCE_FN), ("user", ctypes.c_void_p)]
+
+
+class TorchCollective:
+    """Cross-rank statistics for the native training node (dvm_uni3fc_train_{fwd,bwd}_sync_f32): the library calls `allreduce`
+    on the host while it enqueues its launches; the statistics buffers lie inside the node's arena, so the call is an in-place
+    torch.distributed.all_reduce of a VIEW of that arena tensor, issued under the HIP stream the library names (RCCL with the
+    "nccl" backend; gloo copies through the host — the two-ranks-on-one-GPU tests).  `calls` counts the collectives."""
+
+    def __init__(self, group=None):
+        self.group, self.arena, self.calls, self.error = group, None, 0, None
+        self._fn = _ALLREDUCE_FN(self._allreduce)            # (kept alive with the object: the library holds a raw pointer)
+        self.struct = _CollectiveStruct(self._fn, None)
+
+    def bind(self, arena):
+        """The uint8 tensor the next native call works in (the buffers handed to `allreduce` are slices of it)."""
+        self.arena = arena
+        return ctypes.cast(ctypes.pointer(self.struct), ctypes.c_void_p)
+
+    def _allreduce(self, user, buf, count, dtype, op, stream):
+        try:
+            a = self.arena
+            off, size = int(buf) - a.data_ptr(), 8 if dtype == 1 else 4
+            if off < 0 or off + count * size > a.numel():
+                raise RuntimeError("collective buffer outside the bound arena")
+            t = a[off:off + count * size].view(torch.float64 if dtype == 1 else torch.float32)
+            rop = (dist.ReduceOp.SUM, dist.ReduceOp.MIN, dist.ReduceOp.MAX)[op]
+            st = torch.cuda.ExternalStream(int(stream), device=a.device) if stream else torch.cuda.default_stream(a.device)
+            with torch.cuda.stream(st):
+                dist.all_reduce(t, op=rop, group=self.group)
+            self.calls += 1
+            return 0
+        except Exception as e:  # noqa: BLE001  (no exception may cross the C boundary: reported by the caller of the native call)
+            self.error = e
+            return -1

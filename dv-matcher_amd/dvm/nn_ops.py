@@ -191,7 +191,8 @@ class _Uni3FCTrain(torch.autograd.Function):
         table, where, k, eps, momentum = meta[:5]
         defer = len(meta) > 5 and meta[5] is not None     # meta[5]: a list that receives the arena (deferred running statistics)
         groups = meta[6] if len(meta) > 6 else 1          # meta[6]: network calls merged into this one
-        feat, tmp, arena = ops.uni3fc_train_forward(table, x, dino, k, eps, momentum, defer_stats=defer, groups=groups)
+        coll = meta[7] if len(meta) > 7 else None         # meta[7]: dvm.dist.TorchCollective — batch statistics over all ranks
+        feat, tmp, arena = ops.uni3fc_train_forward(table, x, dino, k, eps, momentum, defer_stats=defer, groups=groups, coll=coll)
         if defer:
             meta[5].append(arena)
         ctx.set_materialize_grads(False)
@@ -230,7 +231,7 @@ class _Uni3FCTrain(torch.autograd.Function):
                 off += n
             out = [g if need else None for g, need in zip(out, ctx.needs_input_grad[3:])]
         ops.uni3fc_train_backward(table, grads, ctx.dino, feat, tmp, ctx.arena, g_feat.contiguous(), None if g_tmp is None else g_tmp.contiguous(), k,
-                                  groups=ctx.meta[6] if len(ctx.meta) > 6 else 1)
+                                  groups=ctx.meta[6] if len(ctx.meta) > 6 else 1, coll=ctx.meta[7] if len(ctx.meta) > 7 else None)
         ctx.arena = None
         return (None, None, None) + tuple(out)
 
@@ -245,7 +246,8 @@ def uni3fc_train_merged(meta, x1, dino1, x2, dino2, trainable):
     call, in call order — the results of two separate calls (bit-identical forward) for half the launches.
     -> ((feat1, tmp1), (feat2, tmp2))."""
     B = x1.shape[0]
-    feat, tmp = _Uni3FCTrain.apply(tuple(meta) + (None, 2), torch.cat([x1, x2], 0), torch.cat([dino1, dino2], 0), *trainable)
+    meta = tuple(meta)
+    feat, tmp = _Uni3FCTrain.apply(meta[:5] + (None, 2) + meta[7:8], torch.cat([x1, x2], 0), torch.cat([dino1, dino2], 0), *trainable)
     return (feat[:B], tmp[:B]), (feat[B:], tmp[B:])
 
 

@@ -908,7 +908,14 @@ def knn_tap():
     return None if inspect.isfunction(fn) else (fn if hasattr(fn, "log") and hasattr(fn, "forced") else None)
 
 
-def uni3fc_train_forward(params, x, dino, k, eps, momentum, defer_stats=False, groups=1):
+def _coll_check(coll, rc, what):
+    if coll is not None and coll.error is not None:
+        err, coll.error = coll.error, None
+        raise DvmError("%s: the collective failed: %r" % (what, err))
+    check(rc, what)
+
+
+def uni3fc_train_forward(params, x, dino, k, eps, momentum, defer_stats=False, groups=1, coll=None):
     """LG-Net's training-mode forward in ONE native call (dvm_uni3fc_train_fwd_f32).  params: the U3_TRAIN_NPARAMS tensors of
     include/dvm.h's table (raw parameters + BatchNorm running statistics, updated in place); x (B,3,N), dino (B,N,1152)
     -> feat (B,N,128), tmp (B,N,64), arena (uint8 tensor holding what dvm_uni3fc_train_bwd_f32 needs)."""
@@ -936,9 +943,10 @@ def uni3fc_train_forward(params, x, dino, k, eps, momentum, defer_stats=False, g
             if any(tuple(f.shape) != (B, N, int(k)) for f in forced):
                 raise DvmError("uni3fc_train_forward: forced neighbour sets must be (B, N, k)")
             ftab = ctypes.cast(_ptr_table(forced, 7), ctypes.c_void_p)
-    check(lib.dvm_uni3fc_train_fwd_f32(_p(x), _p(dino), B, N, ctypes.cast(table, ctypes.c_void_p), U3_TRAIN_NPARAMS, int(k), float(eps),
-                                       float(momentum), int(groups), 1 if defer_stats else 0, ftab, ltab, _p(feat), _p(tmp), _p(arena), nb, _stream()),
-          "dvm_uni3fc_train_fwd_f32")
+    # coll (dvm.dist.TorchCollective): BatchNorm statistics and the position-encoding range over ALL ranks of a data-parallel step
+    _coll_check(coll, lib.dvm_uni3fc_train_fwd_sync_f32(_p(x), _p(dino), B, N, ctypes.cast(table, ctypes.c_void_p), U3_TRAIN_NPARAMS, int(k), float(eps),
+                                                        float(momentum), int(groups), 1 if defer_stats else 0, ftab, ltab, _p(feat), _p(tmp), _p(arena), nb,
+                                                        coll.bind(arena) if coll is not None else None, _stream()), "dvm_uni3fc_train_fwd_f32")
     if tap is not None:
         tap.log.extend(logs)
         if forced is not None:
@@ -955,7 +963,7 @@ def uni3fc_train_running_stats(params, arena, B, N, k, momentum, groups=1):
                                                  _p(arena), arena.numel(), _stream()), "dvm_uni3fc_train_running_stats_f32")
 
 
-def uni3fc_train_backward(params, grads, dino, feat, tmp, arena, g_feat, g_tmp, k, groups=1):
+def uni3fc_train_backward(params, grads, dino, feat, tmp, arena, g_feat, g_tmp, k, groups=1, coll=None):
     """dvm_uni3fc_train_bwd_f32: ADDS the parameter gradients into `grads` (tensors aligned with `params`; None for the
     running statistics)."""
     _need_gpu(g_feat, dino)
@@ -965,9 +973,9 @@ def uni3fc_train_backward(params, grads, dino, feat, tmp, arena, g_feat, g_tmp, 
     g_feat = _f(g_feat)
     g_tmp = None if g_tmp is None else _f(g_tmp)
     ptab, gtab = _ptr_table(params, U3_TRAIN_NPARAMS), _ptr_table(grads, U3_TRAIN_NPARAMS)
-    check(lib.dvm_uni3fc_train_bwd_f32(_p(g_feat), _p(g_tmp), _p(dino), _p(feat), _p(tmp), B, N, ctypes.cast(ptab, ctypes.c_void_p),
-                                       ctypes.cast(gtab, ctypes.c_void_p), U3_TRAIN_NPARAMS, int(k), int(groups), _p(arena), arena.numel(), _stream()),
-          "dvm_uni3fc_train_bwd_f32")
+    _coll_check(coll, lib.dvm_uni3fc_train_bwd_sync_f32(_p(g_feat), _p(g_tmp), _p(dino), _p(feat), _p(tmp), B, N, ctypes.cast(ptab, ctypes.c_void_p),
+                                                        ctypes.cast(gtab, ctypes.c_void_p), U3_TRAIN_NPARAMS, int(k), int(groups), _p(arena), arena.numel(),
+                                                        coll.bind(arena) if coll is not None else None, _stream()), "dvm_uni3fc_train_bwd_f32")
 
 
 class GeometryCache:

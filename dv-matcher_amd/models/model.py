@@ -527,7 +527,7 @@ class Uni3FC(nn.Module, _VisualProjection):
     def _native_train_ok(self, x, dino_feat):
         """The native training path takes plain data tensors (no gradient w.r.t. x / dino_feat), fp32 contiguous parameters and
         one (eps, momentum) for all BatchNorms; anything else goes through the autograd path below."""
-        if os.environ.get("DVM_NATIVE_TRAIN", "1") != "1" or not x.is_cuda or getattr(self, "sync_minmax", False):
+        if os.environ.get("DVM_NATIVE_TRAIN", "1") != "1" or not x.is_cuda:
             return False
         if x.requires_grad or dino_feat.requires_grad or x.dtype != torch.float32 or dino_feat.dtype != torch.float32:
             return False
@@ -539,8 +539,16 @@ class Uni3FC(nn.Module, _VisualProjection):
         ts, where, trainable, bns, det, _ = self._train_state()
         with torch.no_grad():
             torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
-        meta = (det, where, self.k, bns[0].eps, bns[0].momentum)
+        meta = (det, where, self.k, bns[0].eps, bns[0].momentum) + self._sync_meta()
+        self.__dict__["native_train_calls"] = self.__dict__.get("native_train_calls", 0) + 1
         return nn_ops.uni3fc_train(meta, x.contiguous(), dino_feat.contiguous(), trainable)
+
+    def _sync_meta(self):
+        """Data-parallel training with batch statistics over ALL ranks (train_driver.py --sync-stats): `self.sync_stats` holds the
+        collective (dvm.dist.TorchCollective) the native node hands its BatchNorm totals and position-encoding range to — the
+        node's meta then carries it behind (deferred-statistics list, groups)."""
+        coll = getattr(self, "sync_stats", None)
+        return () if coll is None else (None, 1, coll)
 
     def forward_pair(self, x1, dino1, x2, dino2, upsampler=None):
         """The two network calls of a training step (train.py:100-101: `Uni3FC(verts1^T, dino1)`, `Uni3FC(verts2^T, dino2)`) — same
@@ -555,6 +563,8 @@ class Uni3FC(nn.Module, _VisualProjection):
         mode = os.environ.get("DVM_PAIR_CALLS", "merged")
         if mode == "merged" and (dino1 is None or dino2 is None or tuple(x1.shape) != tuple(x2.shape)):
             mode = "0"
+        if mode == "1" and getattr(self, "sync_stats", None) is not None:
+            mode = "0"   # (cross-rank statistics: every rank must issue its collectives in ONE order)
         native = (self.training and x1.is_cuda and dino1 is not None and dino2 is not None and mode in ("1", "merged")
                   and os.environ.get("DVM_TRAIN_LAYOUT", "pm") == "pm" and torch.is_grad_enabled()
                   and all(type(m) is nn.BatchNorm1d for m in self.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm))
@@ -567,8 +577,9 @@ class Uni3FC(nn.Module, _VisualProjection):
         with torch.no_grad():
             torch._foreach_add_([m.num_batches_tracked for m in bns], 2)
         meta = (det, where, self.k, bns[0].eps, bns[0].momentum)
+        self.__dict__["native_train_calls"] = self.__dict__.get("native_train_calls", 0) + 1
         if mode == "merged":
-            return nn_ops.uni3fc_train_merged(meta, x1, dino1, x2, dino2, trainable)
+            return nn_ops.uni3fc_train_merged(meta + self._sync_meta(), x1, dino1, x2, dino2, trainable)
         return nn_ops.uni3fc_train_pair(meta, x1.contiguous(), dino1.contiguous(), x2.contiguous(), dino2.contiguous(), trainable)
 
     def _forward_train_pm(self, x, dino_feat):
@@ -623,6 +634,12 @@ class Uni3FC(nn.Module, _VisualProjection):
                 all(type(m) is nn.BatchNorm1d for m in self.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)):
             if self._native_train_ok(x, dino_feat):
                 return self._forward_train_native(x, dino_feat)
+            if getattr(self, "sync_stats", None) is not None:
+                # plain BatchNorm modules + a collective: only the native node combines the statistics over the ranks — the
+                # autograd path would silently normalise per shard
+                raise RuntimeError("Uni3FC.sync_stats is set but this call cannot take the native training node (DVM_NATIVE_TRAIN=0, "
+                                   "inputs that require grad, non-fp32 / non-contiguous parameters): convert the BatchNorms with "
+                                   "torch.nn.SyncBatchNorm.convert_sync_batchnorm and set sync_minmax instead")
             return self._forward_train_pm(x, dino_feat.contiguous())
         # channel-major fallback (eval-mode fine-tuning, SyncBatchNorm): the reference's own layout.
         # conv -> BatchNorm -> LeakyReLU blocks: the GEMM, then ONE fused statistics + normalise + activation pass

@@ -270,9 +270,16 @@ def main(argv=None):
     seed_data, seed_py, seed_torch = rank_seeds(rank)
     torch.manual_seed(0)  # identical initial weights on every rank
     net, dfm = Uni3FC(k=40).to(dev), Deformer(k=cfg["loss"]["k_deform"]).to(dev)
-    if args.sync_stats and world > 1:
-        net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)
-        net.sync_minmax = True
+    if args.sync_stats and dist_on:
+        # batch-global BatchNorm statistics and position-encoding range, as in the reference's single-process batch
+        # (models/model.py:496-503, 548).  The native training node takes a collective for them (dvm_uni3fc_train_*_sync_f32: the
+        # per-channel totals and the min / max are all-reduced between its launches); the autograd paths need converted modules.
+        if os.environ.get("DVM_NATIVE_TRAIN", "1") == "1" and os.environ.get("DVM_TRAIN_LAYOUT", "pm") == "pm":
+            from dvm.dist import TorchCollective
+            net.sync_stats = TorchCollective()
+        else:
+            net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)
+        net.sync_minmax = True      # (the eval / autograd paths' position encoding)
     params = list(net.parameters()) + list(dfm.parameters())
     use_graph = bool(args.graph) and world == 1 and args.epochs <= 0
     # one fused multi-tensor Adam launch per step (same update as the reference's torch.optim.Adam, train.py:44-45; the default
@@ -493,7 +500,11 @@ def main(argv=None):
                                            "note": "algorithmic matrix flops of the whole step per GPU over the step time; the step is "
                                                    "~900 small launches, bound by the latency of its kernel chain (network forward -> criterion -> backward), not by the matrix pipe"},
                               "points": N, "points_target": M, "criterion": type(crit).__name__, "alpha": float(alpha),
-                              "hip_graph": use_graph, "graph_cache": bool(args.graph_cache), "process_group": (dist.get_backend() if dist_on else None),
+                              "hip_graph": use_graph, "graph_cache": bool(args.graph_cache),
+                              "sync_stats": (None if not (args.sync_stats and dist_on) else
+                                             {"native_node": getattr(net, "sync_stats", None) is not None,
+                                              "native_calls": net.__dict__.get("native_train_calls", 0),
+                                              "collectives": getattr(getattr(net, "sync_stats", None), "calls", None)}), "process_group": (dist.get_backend() if dist_on else None),
                               "grad_bucket_floats": bucket.numel, "first_losses": losses[0], "last_losses": losses[-1]}))
         if dist_on:
             dist.destroy_process_group()

@@ -41,6 +41,17 @@ extern "C" {
 #define DVM_ELAUNCH (-2)   /* HIP launch / runtime error */
 #define DVM_ENOSPACE (-3)  /* workspace too small */
 
+/* The caller's collective for data-parallel statistics (the *_sync_f32 entry points): `allreduce` is called on the HOST while
+ * the library enqueues its launches and must enqueue, ordered on `stream`, an IN-PLACE all-reduce over all ranks of `count`
+ * elements at the device pointer `buf` (inside memory the caller handed to that entry point); dtype: 0 = float32, 1 = float64;
+ * op: 0 = SUM, 1 = MIN, 2 = MAX.  Returns 0 on success.  (RCCL: ncclAllReduce(buf, buf, count, type, op, comm, stream);
+ * torch.distributed: all_reduce of a view of the caller's tensor under torch.cuda.stream(ExternalStream(stream)).) */
+typedef int (*dvm_allreduce_fn)(void *user, void *buf, size_t count, int dtype, int op, void *stream);
+typedef struct dvm_collective {
+    dvm_allreduce_fn allreduce;
+    void *user;
+} dvm_collective;
+
 /* ---------------------------------------------------------------------------------------------------------------------
  * Environment options of the library: SIX variables, read once when the library is loaded (csrc/dvm_api.cpp::options()).
  * Nothing else in the library reads the environment; every option selects among HIP paths (there is no CPU path).
@@ -293,6 +304,10 @@ int dvm_pos_encoding_f32(const float *x, int B, int N, float *out, void *ws, siz
  * pair batch sharded over ranks the reference's whole-tensor min/max (models/model.py:548) is the min/max over
  * ALL ranks' shards; the host reduces the two numbers (MIN / MAX all-reduce) and passes them here. */
 int dvm_pos_encoding_minmax_f32(const float *x, const float *minmax, int B, int N, float *out, void *stream);
+/* ... with the range over all ranks: this rank's (min, max) -> minmax2 (two floats of caller-owned device memory), the caller's
+ * collective (MIN on the first, MAX on the second), then the encoding */
+int dvm_pos_encoding_sync_f32(const float *x, int B, int N, float *out, void *ws, size_t ws_bytes, const dvm_collective *coll,
+                              float *minmax2, void *stream);
 
 /* Training-mode nn.BatchNorm1d over [B,C,N] fused with the residual add in front of it and the (Leaky)ReLU behind it
  * (models/model.py:97-123 SA_Layer, 325-395 N2PAttention, 506-529 conv blocks):
@@ -320,6 +335,20 @@ int dvm_bn_act_train_fwd_pm_var_f32(const float *x, const float *res, const floa
  * [groups][C]; the running statistics take the groups' updates one after the other; dgamma / dbeta sum over the groups.
  * Workspace: dvm_bn_pm_groups_workspace_bytes(R, C, groups). */
 size_t dvm_bn_pm_groups_workspace_bytes(long R, int C, int groups);
+/* Cross-rank statistics for a data-parallel step (train.py under DDP: the reference's single-process batch normalises over ALL
+ * pairs, models/model.py:496-503).  With a collective, the per-(group, channel) totals (sum x, sum x^2 — backward: sum dz,
+ * sum dz xhat) and the groups' row counts are written to `sync_buf` (dvm_bn_pm_sync_bytes(C, groups) bytes of caller-owned device
+ * memory), handed to the caller's all-reduce (float64, SUM, in place, enqueued on `stream`), and the normalisation uses the global
+ * totals; dgamma / dbeta stay this rank's sums (the gradient all-reduce adds the ranks').  coll == NULL: the plain calls above. */
+size_t dvm_bn_pm_sync_bytes(int C, int groups);
+int dvm_bn_act_train_fwd_pm_sync_f32(const float *x, const float *res, const float *gamma, const float *beta, long R, int C, int groups,
+                                     float eps, float slope, float momentum, float *y, float *save_mean, float *save_invstd,
+                                     float *save_var_unbiased, float *running_mean, float *running_var, void *ws, size_t ws_bytes,
+                                     const dvm_collective *coll, void *sync_buf, void *stream);
+int dvm_bn_act_train_bwd_pm_sync_f32(const float *dy, const float *y, const float *x, const float *res, const float *gamma,
+                                     const float *save_mean, const float *save_invstd, long R, int C, int groups, float slope,
+                                     float *dx, float *dgamma, float *dbeta, int accumulate, void *ws, size_t ws_bytes,
+                                     const dvm_collective *coll, void *sync_buf, void *stream);
 int dvm_bn_act_train_bwd_pm_groups_f32(const float *dy, const float *y, const float *x, const float *res, const float *gamma,
                                        const float *save_mean, const float *save_invstd, long R, int C, int groups, float slope,
                                        float *dx, float *dgamma, float *dbeta, int accumulate, void *ws, size_t ws_bytes, void *stream);
@@ -540,6 +569,18 @@ int dvm_uni3fc_train_running_stats_f32(const float *const *params, int nparams, 
 int dvm_uni3fc_train_bwd_f32(const float *g_feat, const float *g_tmp, const float *dino, const float *feat, const float *tmp,
                              int B, int N, const float *const *params, float *const *grads, int nparams, int k, int groups,
                              void *arena, size_t arena_bytes, void *stream);
+/* The same two calls inside a DATA-PARALLEL step (train.py:30-33 picks one device; the 8-GPU run shards the pair batch): with
+ * `coll` every batch statistic the reference takes over its whole batch is combined over the ranks by the caller's collective —
+ * the 26 BatchNorms' totals in both passes (dvm_bn_act_train_*_pm_sync_f32) and the position encoding's min / max
+ * (dvm_pos_encoding_sync_f32, models/model.py:548) — so the sharded step reproduces the single-process one on THIS native node.
+ * The buffers handed to the collective lie inside `arena`.  coll == NULL: identical to the calls above. */
+int dvm_uni3fc_train_fwd_sync_f32(const float *xyz, const float *dino, int B, int N, const float *const *params, int nparams, int k,
+                                  float eps, float momentum, int groups, int defer_running_stats, const int32_t *const *knn_forced,
+                                  int32_t *const *knn_log, float *feat, float *tmp, void *arena, size_t arena_bytes,
+                                  const dvm_collective *coll, void *stream);
+int dvm_uni3fc_train_bwd_sync_f32(const float *g_feat, const float *g_tmp, const float *dino, const float *feat, const float *tmp,
+                                  int B, int N, const float *const *params, float *const *grads, int nparams, int k, int groups,
+                                  void *arena, size_t arena_bytes, const dvm_collective *coll, void *stream);
 
 /* dvm_pair_fwd_f32 can run its coordinate-only chain (FPS, graph, xyz kNN: latency-bound) on helper streams, forked
  * from and joined back into `stream` by events, next to the feature-only soft-correspondence chain.  The helper streams

@@ -1,6 +1,7 @@
 """SURVEY §8e on one GPU: two processes (gloo over device tensors, both on cuda:0) each take half of a pair batch.
-With batch-global statistics (SyncBatchNorm + the global min/max of the positional encoding) and the flat-bucket
-gradient mean, features and gradients equal the single-process run on the whole batch."""
+With batch-global statistics — on the NATIVE training node through its collective hook (dvm_uni3fc_train_*_sync_f32: BatchNorm
+totals and the positional encoding's min / max all-reduced between the node's launches), or on the autograd path through
+SyncBatchNorm modules — and the flat-bucket gradient mean, features and gradients equal the single-process run on the whole batch."""
 import os
 import sys
 
@@ -37,7 +38,11 @@ def _worker(rank, world, port, ret, sync):
         dev = torch.device("cuda", 0)
         torch.manual_seed(0)
         net = Uni3FC(k=20).to(dev)
-        if sync:
+        if sync == "native":       # plain BatchNorm modules: the native node combines the statistics through the collective
+            from dvm.dist import TorchCollective
+            net.sync_stats = TorchCollective()
+            net.sync_minmax = True
+        elif sync:
             net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)
             net.sync_minmax = True
         x, dino = _inputs()
@@ -45,19 +50,21 @@ def _worker(rank, world, port, ret, sync):
         bucket = FlatGradBucket(list(net.parameters()), attach=True)
         feat = _run(net, x[lo:hi].to(dev), dino[lo:hi].to(dev), 1.0)   # local mean over 1 pair == its share of the global mean * world
         bucket.all_reduce_mean()
+        if sync == "native":       # ... and it WAS the native node: one call, 26 BatchNorms x 2 passes + 2 range collectives
+            assert net.__dict__.get("native_train_calls", 0) == 1 and net.sync_stats.calls == 26 * 2 + 2, (net.__dict__.get("native_train_calls"), net.sync_stats.calls)
         ret[rank] = (feat.cpu(), bucket.flat.cpu(), net.bn0.running_mean.cpu())
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("sync", [True, False])
+@pytest.mark.parametrize("sync", ["native", True, False], ids=["sync", "syncbn", "unsynced"])
 def test_sharded_step_equals_single_process(sync):
     sys.path.insert(0, os.path.join(ROOT, "dv-matcher_amd"))
     from dvm.dist import FlatGradBucket
     from models.model import Uni3FC
     world = 2
     ret = mp.Manager().dict()
-    mp.spawn(_worker, args=(world, 29700 + os.getpid() % 2000 + (7 if sync else 0), ret, sync), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, 29700 + os.getpid() % 2000 + (13 if sync == "native" else 7 if sync else 0), ret, sync), nprocs=world, join=True)
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     net = Uni3FC(k=20).to(dev)
@@ -301,6 +308,10 @@ def test_rccl_branch_runs_at_world_size_one():
         ([os.path.join(ROOT, "bench.py"), "--workload", "train", "--steps", "2", "--warmup", "1", "--backend", "nccl"], 2122644),
         ([os.path.join(ROOT, "dv-matcher_amd", "train_driver.py"), "--steps", "2", "--warmup", "1", "--batch", "2", "--points", "256",
           "--backend", "nccl"], 2122644),
+        # ... and with --sync-stats: the native training node's collective hook over RCCL (the BatchNorm totals and the position
+        # encoding's range all-reduced between its launches: 2 x 26 + 2 collectives per merged network call and step)
+        ([os.path.join(ROOT, "dv-matcher_amd", "train_driver.py"), "--steps", "2", "--warmup", "1", "--batch", "2", "--points", "256",
+          "--backend", "nccl", "--sync-stats"], 2122644),
     ]
     for cmd, bucket in runs:
         out = subprocess.run([sys.executable] + cmd, capture_output=True, text=True, timeout=900, env=env)
@@ -312,6 +323,9 @@ def test_rccl_branch_runs_at_world_size_one():
         if bucket and "grad_bucket_floats" in res:
             assert res["grad_bucket_floats"] == bucket
             assert all(v == v and abs(v) < 1e9 for v in res["first_losses"] + res["last_losses"])
+        if "--sync-stats" in cmd:
+            ss = res["sync_stats"]
+            assert ss["native_node"] and ss["native_calls"] == 3 and ss["collectives"] == 3 * (2 * 26 + 2 * 2), ss   # (3 steps: warm-up + 2; two groups: two ranges)
 
 
 def test_training_driver_graph_cache_flag():
