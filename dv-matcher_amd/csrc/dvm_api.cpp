@@ -100,7 +100,7 @@ PairCtx *pair_ctx_find(hipStream_t caller) {
 static void pair_ctx_free(PairCtx *c) {
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->side2) (void)hipStreamDestroy(c->side2);
-    for (hipEvent_t e : {c->ev_fork, c->ev_join, c->ev_join2})
+    for (hipEvent_t e : {c->ev_fork, c->ev_join, c->ev_join2, c->ev_aux})
         if (e) (void)hipEventDestroy(e);
     delete c;
 }
@@ -121,7 +121,8 @@ DVM_EXPORT int dvm_pair_init(void *stream) {
         hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_aux, hipEventDisableTiming) != hipSuccess) {
         dvm::pair_ctx_free(c);
         dvm::set_error("dvm_pair_init: cannot create the helper streams / events on device %d", dev);
         return DVM_ELAUNCH;

@@ -37,7 +37,7 @@ const Options &options();
 struct PairCtx {
     int device = 0;
     hipStream_t side = nullptr, side2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_aux = nullptr;
 };
 PairCtx *pair_ctx_find(hipStream_t caller);
 

@@ -383,12 +383,15 @@ int launch_fps(const float *xyz, int B, int N, int npoint, const int32_t *start,
 // the caller), gnodes = grid over the FPS nodes
 int launch_dg_build(const float *xyz, int B, int N, const int32_t *start, int32_t *nodes_idx, int32_t *ring,
                     int32_t *infl_idx, float *dists, float *weights, double *sigma, double *nnd, const GridBuf &gverts,
-                    const GridBuf &gnodes, bool build_gverts, hipStream_t s) {
+                    const GridBuf &gnodes, bool build_gverts, hipStream_t s, hipEvent_t gverts_ready) {
+    // gverts_ready: the vertex grid is built by another stream (which records this event behind it); waited for in front of the
+    // influence search, the first kernel here that reads it
     const int Nn = N / 2;
     launch_fps(xyz, B, N, Nn, start, nodes_idx, s);
     if (build_gverts) launch_grid_build(xyz, B, N, nullptr, gverts, s);
     launch_grid_build(xyz, B, N, nodes_idx, gnodes, s);
     launch_grid_ring(gnodes, B, ring, s);
+    if (gverts_ready) (void)hipStreamWaitEvent(s, gverts_ready, 0);
     launch_grid_infl(xyz, B, N, gnodes, gverts, infl_idx, dists, nnd, s);
     hipLaunchKernelGGL(dg_weights_kernel, dim3(B), dim3(256), 0, s, nnd, dists, N, weights, sigma);
     return DVM_OK;
@@ -526,7 +529,7 @@ DVM_EXPORT int dvm_dg_build_f32(const float *xyz, int B, int N, const int32_t *s
         set_error("dvm_dg_build_f32: workspace too small (%zu < %zu)", ws_bytes, ar.off);
         return DVM_ENOSPACE;
     }
-    launch_dg_build(xyz, B, N, start, nodes_idx, ring, infl_idx, dists, weights, sigma, nnd, gv, gn, true, (hipStream_t)stream);
+    launch_dg_build(xyz, B, N, start, nodes_idx, ring, infl_idx, dists, weights, sigma, nnd, gv, gn, true, (hipStream_t)stream, nullptr);
     DVM_CHECK_LAUNCH("dg_build");
     return DVM_OK;
 }

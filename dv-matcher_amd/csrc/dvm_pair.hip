@@ -24,7 +24,7 @@ bool launch_apply3_pair(const float *val12, const int32_t *idx12, const float *v
                         const int32_t *idx21, const float *verts1, float *verts21, int32_t *T21, int B, int N, int M, hipStream_t s);
 int launch_dg_build(const float *xyz, int B, int N, const int32_t *start, int32_t *nodes_idx, int32_t *ring, int32_t *infl_idx,
                     float *dists, float *weights, double *sigma, double *nnd, const GridBuf &gverts, const GridBuf &gnodes,
-                    bool build_gverts, hipStream_t s);
+                    bool build_gverts, hipStream_t s, hipEvent_t gverts_ready = nullptr);
 int launch_dg_warp(const float *xyz, int B, int N, const int32_t *nodes_idx, const int32_t *ring, const int32_t *infl_idx,
                    const float *weights, const float *def9, float *R, float *T, float *warped, float *arap, int arap_stride,
                    float *sr, hipStream_t s);
@@ -320,6 +320,7 @@ static int pair_fwd_impl(const float *feat1, const float *feat2, const float *ve
         (void)hipStreamWaitEvent(cx->side, cx->ev_fork, 0);
         s = cx->side;
     }
+    bool pooled = false;   // the pooled features were made on the second helper stream (below)
     if (reuse_geometry) {
         // graphs, grids and xyz kNN of both clouds are in the workspace already
     } else if (both) {
@@ -327,9 +328,28 @@ static int pair_fwd_impl(const float *feat1, const float *feat2, const float *ve
         (void)hipMemcpyAsync(w.vcat + (size_t)B * N * 3, verts2, (size_t)B * N * 3 * sizeof(float), hipMemcpyDeviceToDevice, s);
         (void)hipMemcpyAsync(w.startcat, start1, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
         (void)hipMemcpyAsync(w.startcat + B, start2, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
-        launch_dg_build(w.vcat, 2 * B, N, w.startcat, w.nodes[0], w.ring[0], w.infl[0], w.dists[0], w.weights[0], nullptr,
-                        w.nnd[0], w.gvcat, w.gncat, true, s);
-        launch_grid_knn_self(w.gvcat, 2 * B, 10, w.idxk[0], s);
+        if (overlap) {
+            // FPS is N / 2 dependent steps on one workgroup per cloud (0.7 ms whatever the batch) and everything behind it on this
+            // stream waits for it — but the vertex grid, the xyz kNN and the pooled features need the coordinates / features only:
+            // they go on the SECOND helper stream, beside FPS (at 64 pairs per GPU — one rank's share of an 8-GPU strong-scaling
+            // run — FPS fills half the compute units and the step is this chain: 1.96 -> 1.7 ms; profiles/r5_scaling_proxy.txt)
+            (void)hipEventRecord(cx->ev_aux, s);                      // the concatenated coordinates are in place
+            (void)hipStreamWaitEvent(cx->side2, cx->ev_aux, 0);
+            launch_grid_build(w.vcat, 2 * B, N, nullptr, w.gvcat, cx->side2);
+            (void)hipEventRecord(cx->ev_aux, cx->side2);              // (re-used: the vertex grid is built)
+            launch_grid_knn_self(w.gvcat, 2 * B, 10, w.idxk[0], cx->side2);
+            launch_pool_all(feat1, w.idxk[0], B, N, 10, conv_w, conv_b, w.gall[0], cx->side2, w.gv[0].ids);
+            launch_pool_all(feat2, w.idxk[1], B, M, 10, conv_w, conv_b, w.gall[1], cx->side2, w.gv[1].ids);
+            (void)hipEventRecord(cx->ev_join2, cx->side2);
+            pooled = true;
+            launch_dg_build(w.vcat, 2 * B, N, w.startcat, w.nodes[0], w.ring[0], w.infl[0], w.dists[0], w.weights[0], nullptr,
+                            w.nnd[0], w.gvcat, w.gncat, false, s, cx->ev_aux);
+            (void)hipStreamWaitEvent(s, cx->ev_join2, 0);             // ev_join (below) then covers both helper streams
+        } else {
+            launch_dg_build(w.vcat, 2 * B, N, w.startcat, w.nodes[0], w.ring[0], w.infl[0], w.dists[0], w.weights[0], nullptr,
+                            w.nnd[0], w.gvcat, w.gncat, true, s);
+            launch_grid_knn_self(w.gvcat, 2 * B, 10, w.idxk[0], s);
+        }
     } else {
         // N != M (or sizes that do not tile the arena): one chain per cloud set.  FPS is a one-workgroup-per-cloud
         // sequential kernel, so the two chains go on two helper streams and overlap each other as well.
@@ -348,8 +368,10 @@ static int pair_fwd_impl(const float *feat1, const float *feat2, const float *ve
     // still on the geometry side: what depends on the xyz kNN and the input features only — the Deformer's pooled features
     // (once per cloud, points in grid-cell order) and the neighbours' coordinates of the map term — so that the L2-bound
     // gathers run next to the ALU-bound sweep instead of after it
-    launch_pool_all(feat1, w.idxk[0], B, N, 10, conv_w, conv_b, w.gall[0], s, w.gv[0].ids);
-    launch_pool_all(feat2, w.idxk[1], B, M, 10, conv_w, conv_b, w.gall[1], s, w.gv[1].ids);
+    if (!pooled) {
+        launch_pool_all(feat1, w.idxk[0], B, N, 10, conv_w, conv_b, w.gall[0], s, w.gv[0].ids);
+        launch_pool_all(feat2, w.idxk[1], B, M, 10, conv_w, conv_b, w.gall[1], s, w.gv[1].ids);
+    }
     const bool map_lds = map_term_lds_applies(N, 10) && map_term_lds_applies(M, 10);   // (the target side in LDS: no neighbour tables)
     if (with_map && !reuse_geometry && !map_lds) {
         launch_gather_nbr_xyz(verts2, w.idxk[1], B, M, 10, w.nbrxyz[1], s);
