@@ -40,7 +40,7 @@ struct LinArgs {
     int I, J, K;                             // rows of P, columns of Q, reduction length
     long q_bs, y_bs;                         // batch strides (channel-major); 0 otherwise
     int ldy;
-    float slope;                             // 1: no activation; 0: ReLU; else LeakyReLU(slope)
+    float slope;                             // 1: no activation; 0: ReLU; < 0: ELU (alpha = 1); else LeakyReLU(slope)
     const float *post_res;                   // NULL, or laid out like Y: y = post_res + post_scale * (what the epilogue made)
     float post_scale;
     int tiles_i, tiles_j;
@@ -452,7 +452,8 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a) {
                     if (a.bias) t = t + cb[e];
                     if (R) t = t + rr[e];
                     if (a.alpha) t = fmaf(t, ca[e], ct[e]);
-                    if (slope != 1.f) t = t > 0.f ? t : (slope == 0.f ? 0.f : t * slope);
+                    if (slope != 1.f)   // (ELU as torch evaluates it on fp32: exp(x) - 1, see dvm_deformer.hip::elu1)
+                        t = t > 0.f ? t : (slope == 0.f ? 0.f : slope < 0.f ? __builtin_amdgcn_exp2f(t * 1.4426950408889634f) - 1.f : t * slope);
                     if (R2) t = __fadd_rn(__fmul_rn(t, a.post_scale), r2[e]);   // two roundings, like `conv(x) * s + r` in torch
                     v[e] = t;
                 }

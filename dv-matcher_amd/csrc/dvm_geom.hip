@@ -555,7 +555,8 @@ template <int TOPK>
 __global__ __launch_bounds__(256) void map_term_kernel(const float *__restrict__ verts12, const float *__restrict__ verts2,
                                                        const int32_t *__restrict__ idx11, const int32_t *__restrict__ idx22,
                                                        const float *__restrict__ pi_val, const int32_t *__restrict__ pi_idx,
-                                                       int N, int M, int k, int topk, double *__restrict__ partial) {
+                                                       int N, int M, int k, int topk, double *__restrict__ partial,
+                                                       float *__restrict__ resid /* nullptr, or [B][N][k][3]: e_c kept for the backward */) {
     const int b = blockIdx.y;
     const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
     float e2 = 0.f;
@@ -597,6 +598,10 @@ __global__ __launch_bounds__(256) void map_term_kernel(const float *__restrict__
         const float *p12 = verts12 + ((size_t)b * N + idx11[row * k + s]) * 3;
         float e0 = p12[0] - acc[0], e1 = p12[1] - acc[1], e2c = p12[2] - acc[2];
         e2 = (e0 * e0 + e1 * e1) + e2c * e2c;
+        if (resid) {
+            float *r = resid + ((size_t)b * N * k + g) * 3;
+            r[0] = e0, r[1] = e1, r[2] = e2c;
+        }
     }
     // block reduction in double, fixed order
     __shared__ double red[256 / 64];
@@ -907,6 +912,29 @@ DVM_EXPORT int dvm_softcorr_apply_f32(const float *pi_val, const int32_t *pi_idx
     return DVM_OK;
 }
 
+namespace dvm {
+// The pieces of dvm_softcorr_apply_bwd_f32's gather form, for callers that keep the reversed lists (dvm_criterion_train.hip):
+// idx [B][E] (entries with a target in [0, M)) -> offs [B][M+1], edges [B][E] (entry numbers grouped by target); cursor [B][M] scratch
+void launch_rev_csr(const int32_t *idx, int B, long E, int M, int32_t *offs, int32_t *cursor, int32_t *edges, hipStream_t s) {
+    dim3 egrid((unsigned)((E + 255) / 256), B);
+    (void)hipMemsetAsync(offs, 0, (size_t)B * (M + 1) * sizeof(int32_t), s);
+    hipLaunchKernelGGL(rev_count_kernel, egrid, dim3(256), 0, s, idx, E, M, offs);
+    hipLaunchKernelGGL(rev_scan_kernel, dim3(B), dim3(1024), 0, s, offs, M, cursor);
+    hipLaunchKernelGGL(rev_fill_kernel, egrid, dim3(256), 0, s, idx, E, M, cursor, edges);
+}
+void launch_apply_bwd_dval(const float *pi_val, const int32_t *pi_idx, const float *V, const float *g_out, int B, int N, int M, int topk, int C,
+                           float *d_val, hipStream_t s) {
+    int gp2 = 1;
+    while (gp2 < (C + 3) / 4) gp2 <<= 1;
+    dim3 grid((unsigned)(((long)N * gp2 + 255) / 256), B);
+    hipLaunchKernelGGL(apply_bwd_kernel, grid, dim3(256), 0, s, pi_val, pi_idx, V, g_out, N, M, topk, C, gp2, d_val, (float *)nullptr);
+}
+void launch_apply_bwd_gather(const float *pi_val, const float *g_out, const int32_t *offs, const int32_t *edges, int B, int N, int M, int topk, int C,
+                             float *d_V, hipStream_t s) {
+    hipLaunchKernelGGL(apply_bwd_gather_kernel, dim3((M + 3) / 4, B), dim3(256), 0, s, pi_val, g_out, offs, edges, N, M, topk, C, d_V);
+}
+}  // namespace dvm
+
 DVM_EXPORT size_t dvm_softcorr_apply_bwd_workspace_bytes(int B, int N, int M, int topk) {
     return align_up((size_t)B * (M + 1) * sizeof(int32_t)) + align_up((size_t)B * M * sizeof(int32_t)) +
            align_up((size_t)B * N * topk * sizeof(int32_t));
@@ -933,15 +961,9 @@ DVM_EXPORT int dvm_softcorr_apply_bwd_f32(const float *pi_val, const int32_t *pi
             set_error("dvm_softcorr_apply_bwd_f32: workspace too small (%zu < %zu)", ws_bytes, ar.off);
             return DVM_ENOSPACE;
         }
-        const long E = (long)N * topk;
-        dim3 egrid((unsigned)((E + 255) / 256), B);
-        (void)hipMemsetAsync(offs, 0, (size_t)B * (M + 1) * sizeof(int32_t), s);
-        hipLaunchKernelGGL(rev_count_kernel, egrid, dim3(256), 0, s, pi_idx, E, M, offs);
-        hipLaunchKernelGGL(rev_scan_kernel, dim3(B), dim3(1024), 0, s, offs, M, cursor);
-        hipLaunchKernelGGL(rev_fill_kernel, egrid, dim3(256), 0, s, pi_idx, E, M, cursor, edges);
-        hipLaunchKernelGGL(apply_bwd_kernel, grid, block, 0, s, pi_val, pi_idx, V, g_out, N, M, topk, C, gp2, d_val, (float *)nullptr);
-        hipLaunchKernelGGL(apply_bwd_gather_kernel, dim3((M + 3) / 4, B), dim3(256), 0, s, pi_val, g_out, offs, edges, N, M, topk, C,
-                           d_V);
+        launch_rev_csr(pi_idx, B, (long)N * topk, M, offs, cursor, edges, s);
+        launch_apply_bwd_dval(pi_val, pi_idx, V, g_out, B, N, M, topk, C, d_val, s);
+        launch_apply_bwd_gather(pi_val, g_out, offs, edges, B, N, M, topk, C, d_V, s);
         DVM_CHECK_LAUNCH("softcorr_apply_bwd(gather)");
         return DVM_OK;
     }
@@ -1020,10 +1042,10 @@ DVM_EXPORT int dvm_map_term_f32(const float *verts12, const float *verts2, const
     hipStream_t s = (hipStream_t)stream;
     if (topk <= 10)
         hipLaunchKernelGGL(map_term_kernel<10>, dim3(nblk, B), dim3(256), 0, s, verts12, verts2, idx11, idx22, pi_val, pi_idx,
-                           N, M, k, topk, partial);
+                           N, M, k, topk, partial, (float *)nullptr);
     else
         hipLaunchKernelGGL(map_term_kernel<16>, dim3(nblk, B), dim3(256), 0, s, verts12, verts2, idx11, idx22, pi_val, pi_idx,
-                           N, M, k, topk, partial);
+                           N, M, k, topk, partial, (float *)nullptr);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(B), dim3(256), 0, s, partial, nblk, 1.0f, out, 1, 0);
     DVM_CHECK_LAUNCH("map_term");
     return DVM_OK;
@@ -1100,10 +1122,10 @@ bool launch_map_term_lds(const float *verts12, const float *verts2, const int32_
 }
 int launch_map_term(const float *verts12, const float *verts2, const int32_t *idx11, const int32_t *idx22,
                     const float *pi_val, const int32_t *pi_idx, int B, int N, int M, int k, int topk, double *partial,
-                    hipStream_t s) {
+                    hipStream_t s, float *resid) {
     int nblk = map_term_blocks(N, k);
     hipLaunchKernelGGL(map_term_kernel<10>, dim3(nblk, B), dim3(256), 0, s, verts12, verts2, idx11, idx22, pi_val, pi_idx, N,
-                       M, k, topk, partial);
+                       M, k, topk, partial, resid);
     return DVM_OK;
 }
 }  // namespace dvm

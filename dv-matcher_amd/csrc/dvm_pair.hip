@@ -16,7 +16,7 @@ void launch_gather_nbr_xyz(const float *verts, const int32_t *idx, int B, int M,
 int launch_map_term_nbr(const float *verts12, const float *nbr2, const int32_t *idx11, const float *pi_val, const int32_t *pi_idx,
                         int B, int N, int M, int k, int topk, double *partial, hipStream_t s);
 int launch_map_term(const float *verts12, const float *verts2, const int32_t *idx11, const int32_t *idx22, const float *pi_val,
-                    const int32_t *pi_idx, int B, int N, int M, int k, int topk, double *partial, hipStream_t s);
+                    const int32_t *pi_idx, int B, int N, int M, int k, int topk, double *partial, hipStream_t s, float *resid = nullptr);
 bool launch_map_term_lds(const float *verts12, const float *verts2, const int32_t *idx11, const int32_t *idx22, const float *pi_val,
                          const int32_t *pi_idx, int B, int N, int M, int k, int topk, double *partial, hipStream_t s);
 bool map_term_lds_applies(int M, int k);

@@ -954,6 +954,44 @@ def uni3fc_train_forward(params, x, dino, k, eps, momentum, defer_stats=False, g
     return feat, tmp, arena
 
 
+CRIT_TRAIN_NPARAMS = 10
+
+
+def criterion_train_forward(params, feat, verts, g, knn_idx, alpha, topk=10, with_map=True):
+    """The deformation part of the training criterion for B pairs as ONE native call (dvm_criterion_train_fwd_f32).  feat (2B,N,128),
+    verts (2B,N,3): the B first shapes followed by the B second shapes; g = their batched graph dict (dg_build), knn_idx (2B,N,k)
+    their xyz-kNN; params: the Deformer's 10 tensors (conv weight, bias, then the decoder's weight / bias pairs).
+    -> terms (2B,6) [map numerator, Chamfer side means of warped (2) and verts12 (2), ARAP], arena (uint8 tensor for the backward)."""
+    _need_gpu(feat, verts)
+    feat, verts = _f(feat), _f(verts)
+    P, N, C = feat.shape
+    k = knn_idx.shape[-1]
+    lib = _lib.load()
+    terms = torch.empty(P, 6, dtype=torch.float32, device=feat.device)
+    nb = lib.dvm_criterion_train_workspace_bytes(P // 2, N, k, topk)
+    arena = torch.empty(nb, dtype=torch.uint8, device=feat.device)
+    table = _ptr_table(params, CRIT_TRAIN_NPARAMS)
+    check(lib.dvm_criterion_train_fwd_f32(_p(feat), _p(verts), _p(g["nodes_idx"]), _p(g["one_ring"]), _p(g["infl_idx"]), _p(g["weights"]), _p(knn_idx),
+                                          P // 2, N, C, k, topk, neg_alpha_f32(alpha), ctypes.cast(table, ctypes.c_void_p), CRIT_TRAIN_NPARAMS,
+                                          1 if with_map else 0, _p(terms), _p(arena), nb, _stream()), "dvm_criterion_train_fwd_f32")
+    return terms, arena
+
+
+def criterion_train_backward(params, grads, g_terms, feat, verts, g, knn_idx, alpha, arena, topk=10, with_map=True):
+    """dvm_criterion_train_bwd_f32: -> d_feat (2B,N,128); the Deformer's parameter gradients are ADDED into `grads`."""
+    _need_gpu(feat, g_terms)
+    P, N, C = feat.shape
+    k = knn_idx.shape[-1]
+    lib = _lib.load()
+    d_feat = torch.empty_like(feat)
+    ptab, gtab = _ptr_table(params, CRIT_TRAIN_NPARAMS), _ptr_table(grads, CRIT_TRAIN_NPARAMS)
+    check(lib.dvm_criterion_train_bwd_f32(_p(_f(g_terms)), _p(feat), _p(verts), _p(g["nodes_idx"]), _p(g["one_ring"]), _p(g["infl_idx"]), _p(g["weights"]),
+                                          _p(knn_idx), P // 2, N, C, k, topk, neg_alpha_f32(alpha), ctypes.cast(ptab, ctypes.c_void_p),
+                                          ctypes.cast(gtab, ctypes.c_void_p), CRIT_TRAIN_NPARAMS, 1 if with_map else 0, _p(d_feat), _p(arena),
+                                          arena.numel(), _stream()), "dvm_criterion_train_bwd_f32")
+    return d_feat
+
+
 def uni3fc_train_running_stats(params, arena, B, N, k, momentum, groups=1):
     """The 26 running-statistics updates of a forward that ran with defer_stats=True (dvm_uni3fc_train_running_stats_f32), on the
     current stream."""

@@ -83,6 +83,17 @@ def _crit_streams(device, cur):
     return _crit_side[key]
 
 
+def _joint(u, v):
+    """cat([u, v], 0) — without the copy when u and v are the two halves of one contiguous tensor (LG-Net's merged training call and
+    the batched graph build return such views); autograd then flows straight into that tensor."""
+    base = u._base
+    if (base is not None and base is v._base and base.is_contiguous() and base.shape[0] == 2 * u.shape[0] and base.shape[1:] == u.shape[1:]
+            and u.shape == v.shape and u.is_contiguous() and v.is_contiguous() and u.data_ptr() == base.data_ptr()
+            and v.data_ptr() == base.data_ptr() + u.numel() * u.element_size()):
+        return base
+    return torch.cat([u, v], 0)
+
+
 class SparsePi:
     """Top-k rows of the soft correspondence: val/idx (B,N,k); stands in for the dense (B,N,M) Pi."""
 
@@ -135,6 +146,9 @@ class GraphDeformLoss_Neural(nn.Module):
         self.frob_loss = FrobeniusLoss()
         self.save_name = save_name
         self.dump = dump  # the reference writes 4 OFF files + a print per deform() call; opt-in here
+        # training, equal point counts: the deformation part as ONE native autograd node (nn_ops.criterion_train); False = the
+        # autograd path over the per-op nodes (the two agree to fp32 rounding, tests/test_gpu_train.py)
+        self.native_train = True
 
     def _identity6(self, device):
         """[1,0,0,0,1,0]: the identity rotation in the 6D parametrisation (models/loss.py:1258-1262), made once per device."""
@@ -222,6 +236,26 @@ class GraphDeformLoss_Neural(nn.Module):
             map_sum = ((lhs - rhs) ** 2).sum(dim=(1, 2, 3))
         return map_sum, cd_warp, (arap if per_pair else arap.sum()), cd_self, dict(warped=warped, verts12=verts12, pval=pval, pidx=pidx)
 
+    def _term_weights(self, B, N, device):
+        """(2B*6, 6) matrix taking the native node's table [map, cd_warp (2), cd_self (2), arap] x 2B directional pairs to
+        [deform_loss, map_loss, self_rec_loss, sum-type share, mean-type share, total] (models/loss.py:1413-1432; data_parallel_loss)."""
+        key = (B, N, str(device), self.w_cd, self.w_arap, self.w_deform, self.w_map, self.w_self_rec)
+        cache = self.__dict__.setdefault("_term_w", {})
+        if key not in cache:
+            half = N * self.w_deform / 2        # (non-partial criterion: scale = N)
+            row = torch.zeros(6, 6, dtype=torch.float64)
+            row[1, 0] = row[2, 0] = self.w_cd * half / B            # Chamfer: mean over the B pairs of each direction
+            row[5, 0] = self.w_arap * half                          # ARAP: sum over the pairs
+            row[5, 3] = self.w_arap * half
+            row[1, 4] = row[2, 4] = self.w_cd * half / B
+            if self.w_map > 0:
+                row[0, 1] = row[0, 4] = self.w_map / (3 * B) / 2    # FrobeniusLoss: sum over (N,k), mean over (B,3)
+            if self.w_self_rec > 0:
+                row[3, 2] = row[4, 2] = row[3, 4] = row[4, 4] = N * self.w_self_rec / 2 / B
+            row[:, 5] = row[:, 0] + row[:, 1] + row[:, 2]
+            cache[key] = row.repeat(2 * B, 1).float().to(device)
+        return cache[key]
+
     def _dump(self, ex, verts1, verts2, n, cd, arap):
         print("Rand:%s, Deform_Result: cd_loss:%s, arap_loss:%s" % (n, cd, arap))
         path = 'visual_result/' + str(self.save_name)
@@ -302,6 +336,7 @@ class GraphDeformLoss_Neural(nn.Module):
         self.geometry(verts1, verts2, fps_starts) returned, when the caller made it ahead of time; shape_ids = (ids of the B
         source shapes, ids of the B target shapes) lets a criterion built with graph_cache={} reuse per-shape graphs."""
         loss = 0
+        native = False
         self._sum_part = self._mean_part = 0
         B, N, _ = verts1.shape
         M = verts2.shape[1]
@@ -343,7 +378,22 @@ class GraphDeformLoss_Neural(nn.Module):
             merged = (train and N == M and not self.dump and not self.partial_variant and self.w_rank <= 0
                       and os.environ.get("DVM_CRIT_MERGE", "1") == "1"
                       and all(torch.is_tensor(g1[k]) for k in g1))
-            if merged:
+            native = (merged and self.native_train and feat1.is_cuda and feat1.dtype == torch.float32 and feat1.shape[-1] == 128 and N % 4 == 0
+                      and 64 <= N <= 8192 and self.k_deform <= 16 and idx11.shape[-1] == self.k_deform
+                      and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in deformer.parameters()))
+            if native:
+                # Both directions of deform() for the B pairs = 2B directional pairs [(1 -> 2) x B | (2 -> 1) x B] through ONE native
+                # autograd node; its table of per-pair terms is weighted by one small matrix product (the reductions of
+                # models/loss.py:1413-1432 are linear in the table: sums over the pairs for ARAP, batch means for the rest)
+                from dvm.ops import DEFORMER_KEYS
+                named = dict(deformer.named_parameters())
+                gj = {k: _joint(g1[k], g2[k]) for k in ("nodes_idx", "one_ring", "infl_idx", "weights")}
+                meta = (_joint(verts1, verts2), gj, _joint(idx11, idx22), alpha_i, 10, bool(self.w_map > 0))
+                terms = nn_ops.criterion_train(meta, _joint(feat1, feat2), [named[k] for k in DEFORMER_KEYS])
+                parts = terms.reshape(-1) @ self._term_weights(B, N, terms.device)
+                n12 = str(random.randint(0, 10))
+                n21 = str(random.randint(0, 10))
+            elif merged:
                 # Both directions are the SAME function of (source, target): with equal point counts they run as ONE batch of 2B
                 # pairs — [(1 -> 2) x B | (2 -> 1) x B] — through every kernel of deform() and its backward: half the launches of two
                 # calls (which at 8 pairs fill a fraction of the chip each).  Chamfer / self-reconstruction are means over the batch
@@ -370,7 +420,17 @@ class GraphDeformLoss_Neural(nn.Module):
             self.dist_loss = joined(0, dterm)
             loss = loss + self.dist_loss
             self._sum_part = self._sum_part + self.dist_loss
-        if self.w_deform > 0 or not self.partial_variant:
+        if (self.w_deform > 0 or not self.partial_variant) and native:
+            # parts = [deform, map, self_rec, the sum-type share, the mean-type share, deform + map + self_rec]
+            self.deform_loss = parts[0]
+            if self.w_map > 0:
+                self.map_loss = parts[1]
+            if self.w_self_rec > 0:
+                self.self_rec_loss = parts[2]
+            loss = loss + parts[5]
+            self._sum_part = self._sum_part + parts[3]
+            self._mean_part = self._mean_part + parts[4]
+        elif self.w_deform > 0 or not self.partial_variant:
             cross12 = c12 * self.w_cd + a12 * self.w_arap
             cross21 = c21 * self.w_cd + a21 * self.w_arap
             if self.dump:

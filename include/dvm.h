@@ -108,7 +108,8 @@ int dvm_rownorm2_f32(const float *x, int rows, int K, float *out, void *stream);
  * than 768 remain, then one block or two halves): bit-identical to the reference evaluated by one CPU thread,
  * independent of B, N and of the tile configuration.  Then, in this order:
  *   y += bias[co];  y += res;  y = fma(y, bn_alpha[co], bn_beta[co]);  y = y > 0 ? y : y * slope
- * (each step skipped when its pointer is NULL / slope == 1; slope 0 = ReLU).
+ * (each step skipped when its pointer is NULL / slope == 1; slope 0 = ReLU; slope < 0 = ELU with alpha 1: y > 0 ? y : exp(y) - 1,
+ * the Deformer's decoder MLP, models/model.py:433-452).
  *   channel_major == 0: x [B*N, K], y / res [B*N, Co]          (inference, activations point-major)
  *   channel_major == 1: x [B, K, N], y / res [B, Co, N]        (the reference's Conv1d layout, training forward)
  * w [Co, K]; K <= 8448 (16-byte aligned rows, K % 4 == 0, take the vector-load path). */
@@ -581,6 +582,33 @@ int dvm_uni3fc_train_fwd_sync_f32(const float *xyz, const float *dino, int B, in
 int dvm_uni3fc_train_bwd_sync_f32(const float *g_feat, const float *g_tmp, const float *dino, const float *feat, const float *tmp,
                                   int B, int N, const float *const *params, float *const *grads, int nparams, int k, int groups,
                                   void *arena, size_t arena_bytes, const dvm_collective *coll, void *stream);
+
+/* The deformation part of GraphDeformLoss_Neural.forward in TRAINING, natively — models/loss.py:1228-1296 (deform(), both
+ * directions), the Deformer models/model.py:454-478 and its MLP 433-452; the weighting 1413-1432 stays with the caller.
+ * The B pairs of a step are handled as ONE batch of P = 2B directional pairs [(1 -> 2) x B | (2 -> 1) x B]:
+ *   feat [P][N][C=128], verts [P][N][3]  : the B first shapes followed by the B second shapes (LG-Net's merged training call
+ *                                          and the batched graph build lay them out like this); pair p maps shape p onto
+ *                                          shape (p + B) mod P
+ *   nodes_idx [P][N/2], ring [P][N/2][9], infl_idx [P][N][3], weights [P][N][3] : dvm_dg_build_f32 of verts
+ *   knn_idx [P][N][k]                    : dvm_knn_cdist_f32(verts, verts, k)
+ *   params: DVM_CRIT_TRAIN_NPARAMS device pointers — Deformer.conv_layer.weight [k], .bias [1], then the decoder's
+ *           (weight, bias) x 4: [512][262], [512], [256][512], [256], [128][256], [128], [9][128], [9]
+ * fwd -> terms [P][6] = [map numerator (0 when with_map == 0) | mean d(warped -> target), mean d(target -> warped) |
+ *        mean d(verts12 -> target), mean d(target -> verts12) | ARAP]; everything the backward needs stays in `arena`
+ *        (dvm_criterion_train_workspace_bytes bytes, caller-owned, untouched until the matching bwd).
+ * bwd: g_terms [P][6] = dL / d terms -> d_feat [P][N][C] (overwritten; the coordinates carry no gradient), the parameter
+ *      gradients ADDED into grads[i] (fp32 atomics; same indexing as params).
+ * N a multiple of 4 in 64..8192, k <= 16, topk <= 10, neg_alpha < 0 as in dvm_softcorr_fwd_f32. */
+#define DVM_CRIT_TRAIN_NPARAMS 10
+size_t dvm_criterion_train_workspace_bytes(int B, int N, int k, int topk);
+int dvm_criterion_train_fwd_f32(const float *feat, const float *verts, const int32_t *nodes_idx, const int32_t *ring,
+                                const int32_t *infl_idx, const float *weights, const int32_t *knn_idx, int B, int N, int C, int k,
+                                int topk, float neg_alpha, const float *const *params, int nparams, int with_map, float *terms,
+                                void *arena, size_t arena_bytes, void *stream);
+int dvm_criterion_train_bwd_f32(const float *g_terms, const float *feat, const float *verts, const int32_t *nodes_idx,
+                                const int32_t *ring, const int32_t *infl_idx, const float *weights, const int32_t *knn_idx, int B,
+                                int N, int C, int k, int topk, float neg_alpha, const float *const *params, float *const *grads,
+                                int nparams, int with_map, float *d_feat, void *arena, size_t arena_bytes, void *stream);
 
 /* dvm_pair_fwd_f32 can run its coordinate-only chain (FPS, graph, xyz kNN: latency-bound) on helper streams, forked
  * from and joined back into `stream` by events, next to the feature-only soft-correspondence chain.  The helper streams

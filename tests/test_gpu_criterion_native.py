@@ -1,0 +1,109 @@
+"""-m gpu: the training criterion's native autograd node (dvm_criterion_train_{fwd,bwd}_f32, csrc/dvm_criterion_train.hip) against the
+per-op autograd path it replaces (GraphDeformLoss_Neural._direction_train, itself pinned to the reference's training step by
+tests/test_gpu_network.py::test_training_step_matches_reference — which now runs THROUGH the native node).  Same kernels for the
+soft correspondence, Chamfer, warp / ARAP and the map term; the decoder MLP runs on the library's fp32 chain instead of the
+vendor GEMM and the reductions are weighted by one matrix product: losses and gradients agree to fp32 rounding.
+Reference: models/loss.py:1228-1296 (deform), 1398-1437 (forward), models/model.py:454-478 (Deformer)."""
+import copy
+import random
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(B, N, seed, w_map=0.005, w_self_rec=0.5):
+    import models.loss as ml
+    import models.model as mm
+    g = torch.Generator().manual_seed(seed)
+    v1 = (torch.rand(B, N, 3, generator=g) - 0.5).cuda()
+    v2 = (v1.cpu() + 0.05 * torch.randn(B, N, 3, generator=g)).cuda()
+    # features with the scale of a trained LG-Net's (non-negative, a few tenths), joint (2B,N,128) like the merged network call returns
+    featj = (0.3 * torch.relu(torch.randn(2 * B, N, 128, generator=g))).cuda().requires_grad_(True)
+    torch.manual_seed(seed + 1)
+    d = mm.Deformer(10).cuda().train()
+    crit = ml.GraphDeformLoss_Neural(k_deform=10, w_dist=0.02, w_map=w_map, k_dist=min(50, N // 2), N_dist=min(40, N // 2), partial=False,
+                                     w_deform=0.5, w_img=0, w_rank=0, w_self_rec=w_self_rec, w_cd=0.1, w_arap=0.01, save_name="t")
+    starts = (torch.randint(0, N, (B,), generator=g), torch.randint(0, N, (B,), generator=g))
+    anchors = (random.Random(seed).sample(range(N), crit.N_dist), random.Random(seed + 1).sample(range(N), crit.N_dist))
+    return crit, d, featj, v1, v2, starts, anchors
+
+
+def _step(crit, d, featj, v1, v2, starts, anchors, native, alpha=60.0):
+    B = v1.shape[0]
+    crit.native_train = native
+    d.zero_grad(set_to_none=True)
+    featj.grad = None
+    f1, f2 = featj[:B], featj[B:]
+    random.seed(5)
+    out = crit(f1, f2, torch.cdist(v1, v1), torch.cdist(v2, v2), v1, v2, alpha, d, fps_starts=starts, anchors=anchors)
+    crit.data_parallel_loss(0.5).backward()
+    return ([float(o) for o in out], featj.grad.clone(), {k: p.grad.clone() for k, p in d.named_parameters()},
+            float(crit._sum_part), float(crit._mean_part))
+
+
+def _rel(a, b):
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("B,N,w_map,w_self", [(2, 256, 0.005, 0.5), (1, 64, 0.005, 0.5), (3, 516, 0.0, 0.5), (2, 1024, 0.01, 0.0)])
+def test_native_criterion_equals_autograd_path(B, N, w_map, w_self):
+    crit, d, featj, v1, v2, starts, anchors = _setup(B, N, 100 + N, w_map, w_self)
+    ln, gfn, gdn, sn, mn = _step(crit, d, featj, v1, v2, starts, anchors, True)
+    la, gfa, gda, sa, ma = _step(crit, d, featj, v1, v2, starts, anchors, False)
+    for x, y in zip(ln, la):
+        assert abs(x - y) <= 2e-5 * max(abs(y), 1e-3), (ln, la)
+    assert abs(sn - sa) <= 2e-5 * abs(sa) and abs(mn - ma) <= 2e-5 * abs(ma)
+    assert torch.isfinite(gfn).all()
+    assert _rel(gfn, gfa) <= 2e-3, _rel(gfn, gfa)
+    for k in gda:
+        assert _rel(gdn[k], gda[k]) <= 2e-3, (k, _rel(gdn[k], gda[k]))
+
+
+def test_native_criterion_full_size_runs_on_the_native_node_and_frozen_deformer():
+    """B = 8, N = 2048 (BASELINE configs[2]): finite, equal to the autograd path, one call of each native entry per step (counted through
+    the wrappers); with the Deformer frozen only the feature gradient is produced."""
+    from dvm import ops
+    B, N = 8, 2048
+    crit, d, featj, v1, v2, starts, anchors = _setup(B, N, 7)
+    calls = {"f": 0, "b": 0}
+    fwd, bwd = ops.criterion_train_forward, ops.criterion_train_backward
+
+    def cf(*a, **k):
+        calls["f"] += 1
+        return fwd(*a, **k)
+
+    def cb(*a, **k):
+        calls["b"] += 1
+        return bwd(*a, **k)
+
+    ops.criterion_train_forward, ops.criterion_train_backward = cf, cb
+    try:
+        ln, gfn, gdn, _, _ = _step(crit, d, featj, v1, v2, starts, anchors, True, alpha=120.0)
+    finally:
+        ops.criterion_train_forward, ops.criterion_train_backward = fwd, bwd
+    assert calls == {"f": 1, "b": 1}
+    la, gfa, gda, _, _ = _step(crit, d, featj, v1, v2, starts, anchors, False, alpha=120.0)
+    for x, y in zip(ln, la):
+        assert abs(x - y) <= 5e-5 * max(abs(y), 1e-3), (ln, la)
+    assert _rel(gfn, gfa) <= 3e-3
+    for k in gda:
+        assert _rel(gdn[k], gda[k]) <= 3e-3, k
+    d2 = copy.deepcopy(d)
+    for p in d2.parameters():
+        p.requires_grad_(False)
+    crit.native_train = True
+    featj.grad = None
+    out = crit(featj[:B], featj[B:], torch.cdist(v1, v1), torch.cdist(v2, v2), v1, v2, 120.0, d2, fps_starts=starts, anchors=anchors)
+    out[0].backward()
+    assert all(p.grad is None for p in d2.parameters()) and torch.isfinite(featj.grad).all()
+
+
+def test_native_criterion_second_backward_is_refused():
+    crit, d, featj, v1, v2, starts, anchors = _setup(1, 128, 3)
+    crit.native_train = True
+    out = crit(featj[:1], featj[1:], torch.cdist(v1, v1), torch.cdist(v2, v2), v1, v2, 50.0, d, fps_starts=starts, anchors=anchors)
+    out[0].backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="backward ran already"):
+        out[0].backward()
