@@ -1068,7 +1068,8 @@ __device__ __forceinline__ void dist_rows128(const float *__restrict__ featb, co
 
 __global__ __launch_bounds__(256) void dist_loss_kernel(const float *__restrict__ feat, const float *__restrict__ dist,
                                                         const int32_t *__restrict__ anchors, const int32_t *__restrict__ idx,
-                                                        int N, int nA, int k, double *__restrict__ partial) {
+                                                        int N, int nA, int k, double *__restrict__ partial,
+                                                        float *__restrict__ xsave /* nullptr, or [B][nA][k] x 2: x_j, y_j kept for the backward */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = blockIdx.x * (blockDim.x >> 6) + wave;
     const int b = blockIdx.y;
@@ -1077,6 +1078,12 @@ __global__ __launch_bounds__(256) void dist_loss_kernel(const float *__restrict_
     if (n < nA) {
         float xs[8], ys[8];
         dist_rows128(feat + (size_t)b * N * 128, dist + (size_t)b * N * N, N, anchors[n], idx + ((size_t)b * nA + n) * k, k, lane, xs, ys);
+        if (xsave) {
+            float *xr = xsave + ((size_t)b * nA + n) * k * 2;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (lane + 64 * u < k) xr[lane + 64 * u] = xs[u], xr[k + lane + 64 * u] = ys[u];
+        }
         float sxy = 0.f, sxx = 0.f, syy = 0.f;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -1127,6 +1134,50 @@ __global__ __launch_bounds__(256) void dist_loss_bwd_weights_kernel(const float 
         const int j = lane + 64 * u;
         if (j < k && xs[u] > 0.f) Wr[ix[j]] = g * (ys[u] * inv - cx * xs[u]) / xs[u];
     }
+}
+
+// the same weights from the x_j, y_j the forward kept (dist_loss_kernel's xsave): no second pass over the feature rows; also the row
+// sums rs [B][nA] = sum_v W[b, n, v] (in lane order + a wave reduction).  gterm read at gterm[b * gstride].
+__global__ __launch_bounds__(256) void dist_loss_bwd_weights_saved_kernel(const float *__restrict__ xsave, const int32_t *__restrict__ idx,
+                                                                          const float *__restrict__ gterm, int gstride, int N, int nA, int k,
+                                                                          float *__restrict__ W, float *__restrict__ rs) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * (blockDim.x >> 6) + wave;
+    const int b = blockIdx.y;
+    if (n >= nA) return;
+    const int32_t *ix = idx + ((size_t)b * nA + n) * k;
+    const float *xr = xsave + ((size_t)b * nA + n) * k * 2;
+    float xs[8], ys[8];
+    float sxy = 0.f, sxx = 0.f, syy = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int j = lane + 64 * u;
+        xs[u] = j < k ? xr[j] : 0.f, ys[u] = j < k ? xr[k + j] : 0.f;
+        sxy = fmaf(xs[u], ys[u], sxy);
+        sxx = fmaf(xs[u], xs[u], sxx);
+        syy = fmaf(ys[u], ys[u], syy);
+    }
+    sxy = wave_sum(sxy);
+    sxx = wave_sum(sxx);
+    syy = wave_sum(syy);
+    const float nx = fmaxf(sqrt_rn(sxx), 1e-8f), ny = fmaxf(sqrt_rn(syy), 1e-8f);
+    const float cosv = sxy / (nx * ny);
+    const float sg = cosv > 0.f ? -1.f : (cosv < 0.f ? 1.f : 0.f);
+    const float g = gterm[(size_t)b * gstride] * sg;
+    const float inv = 1.f / (nx * ny), cx = cosv / (nx * nx);
+    float *Wr = W + ((size_t)b * nA + n) * N;
+    float acc = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int j = lane + 64 * u;
+        if (j < k && xs[u] > 0.f) {
+            const float wv = g * (ys[u] * inv - cx * xs[u]) / xs[u];
+            Wr[ix[j]] = wv;
+            acc += wv;
+        }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) rs[(size_t)b * nA + n] = acc;
 }
 
 __global__ void gather_rows_kernel(const float *__restrict__ src, const int32_t *__restrict__ rows, int N, int C, int nR,
@@ -1398,11 +1449,11 @@ DVM_EXPORT size_t dvm_dist_loss_workspace_bytes(int B, int N, int C, int nA, int
            align_up((size_t)B * ((nA + 3) / 4) * sizeof(double)) + dvm_knn_neg_workspace_bytes(B, nA, N, C, k);
 }
 
-DVM_EXPORT int dvm_dist_loss_fwd_f32(const float *feat, const float *dist, const int32_t *anchors, int B, int N, int C, int nA,
-                                     int k, float *out, int32_t *idx_out, void *ws, size_t ws_bytes, void *stream) {
-    DVM_REQUIRE(feat && dist && anchors && out, "dvm_dist_loss_fwd_f32: null pointer");
-    DVM_REQUIRE(B >= 1 && N >= 1 && nA >= 1 && C % 4 == 0, "dvm_dist_loss_fwd_f32: bad sizes");
-    DVM_REQUIRE(k >= 1 && k <= 512 && k <= N, "dvm_dist_loss_fwd_f32: k=%d unsupported", k);
+namespace dvm {
+// dvm_dist_loss_fwd_f32 with the sum written at out[b * out_stride + out_off], the selected neighbours at idx_out (NULL: scratch) and, for
+// a backward that does not read the feature rows again (C == 128), x_j / y_j at xsave [B][nA][k] x 2; fa_out [B][nA][C] = the anchors' rows
+int launch_dist_loss_fwd(const float *feat, const float *dist, const int32_t *anchors, int B, int N, int C, int nA, int k, float *out, int out_stride,
+                         int out_off, int32_t *idx_out, float *xsave, float *fa_out, void *ws, size_t ws_bytes, hipStream_t s) {
     Arena ar(ws, ws_bytes);
     float *fa = ar.take<float>((size_t)B * nA * C);
     int32_t *idx = ar.take<int32_t>((size_t)B * nA * k);
@@ -1416,15 +1467,32 @@ DVM_EXPORT int dvm_dist_loss_fwd_f32(const float *feat, const float *dist, const
         return DVM_ENOSPACE;
     }
     if (idx_out) idx = idx_out;
-    hipStream_t s = (hipStream_t)stream;
+    if (fa_out) fa = fa_out;
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)(((long)nA * C + 255) / 256), B), dim3(256), 0, s, feat, anchors, N, C, nA,
                        fa);
     launch_knn_neg(fa, feat, B, nA, N, C, k, idx, na, nb, S, s);
     if (C == 128 && k <= 512)
-        hipLaunchKernelGGL(dist_loss_kernel, dim3(nblk, B), dim3(256), 0, s, feat, dist, anchors, idx, N, nA, k, partial);
+        hipLaunchKernelGGL(dist_loss_kernel, dim3(nblk, B), dim3(256), 0, s, feat, dist, anchors, idx, N, nA, k, partial, xsave);
     else
         hipLaunchKernelGGL(dist_loss_generic_kernel, dim3(nblk, B), dim3(256), 0, s, feat, dist, anchors, idx, N, C, nA, k, partial);
-    launch_reduce_partials(partial, B, nblk, 1.f, out, 1, 0, s);
+    launch_reduce_partials(partial, B, nblk, 1.f, out, out_stride, out_off, s);
+    return DVM_OK;
+}
+// W [B][nA][N] (zeroed here) and its row sums from the forward's xsave; gterm read at gterm[b * gstride]
+void launch_dist_loss_bwd_weights_saved(const float *xsave, const int32_t *idx, const float *gterm, int gstride, int B, int N, int nA, int k, float *W,
+                                        float *rs, hipStream_t s) {
+    (void)hipMemsetAsync(W, 0, (size_t)B * nA * N * sizeof(float), s);
+    hipLaunchKernelGGL(dist_loss_bwd_weights_saved_kernel, dim3((nA + 3) / 4, B), dim3(256), 0, s, xsave, idx, gterm, gstride, N, nA, k, W, rs);
+}
+}  // namespace dvm
+
+DVM_EXPORT int dvm_dist_loss_fwd_f32(const float *feat, const float *dist, const int32_t *anchors, int B, int N, int C, int nA,
+                                     int k, float *out, int32_t *idx_out, void *ws, size_t ws_bytes, void *stream) {
+    DVM_REQUIRE(feat && dist && anchors && out, "dvm_dist_loss_fwd_f32: null pointer");
+    DVM_REQUIRE(B >= 1 && N >= 1 && nA >= 1 && C % 4 == 0, "dvm_dist_loss_fwd_f32: bad sizes");
+    DVM_REQUIRE(k >= 1 && k <= 512 && k <= N, "dvm_dist_loss_fwd_f32: k=%d unsupported", k);
+    const int rc = launch_dist_loss_fwd(feat, dist, anchors, B, N, C, nA, k, out, 1, 0, idx_out, nullptr, nullptr, ws, ws_bytes, (hipStream_t)stream);
+    if (rc != DVM_OK) return rc;
     DVM_CHECK_LAUNCH("dist_loss");
     return DVM_OK;
 }

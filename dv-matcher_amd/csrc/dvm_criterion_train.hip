@@ -6,8 +6,9 @@
 // training call and the batched geometry() produce anyway (features / coordinates / graphs / xyz-kNN of the B first shapes followed by
 // those of the B second shapes); the TARGET of pair p is shape (p + B) mod P.  Every step is one of the library's launches or a small
 // kernel of this file, enqueued without Python in between (the autograd path enqueued ~300 launches through ~40 autograd nodes per
-// step).  Forward keeps what the backward needs in a caller-provided arena; the output is the table terms [P][6] =
-// [map numerator, cd(warped -> target) side means (2), cd(verts12 -> target) side means (2), ARAP]; the caller's weighting of the table
+// step).  Forward keeps what the backward needs in a caller-provided arena; the output is the table terms [P][7] =
+// [map numerator, cd(warped -> target) side means (2), cd(verts12 -> target) side means (2), ARAP, dist term of shape p (models/loss.py:
+// 1351-1396; optional, on a helper stream beside the deformation part)]; the caller's weighting of the table
 // (sums / batch means, models/loss.py:1413-1432) stays with autograd: one small matrix product.  Backward takes d terms and writes
 // d feat [P][N][C] and ADDS the Deformer's parameter gradients into caller-provided buffers.
 //
@@ -19,6 +20,8 @@
 //   def9 = MLP(z)   (dvm_linear_f32, ELU in the epilogue)           dvm_linear_wgrad_f32 / dvm_linear_f32 with the roles swapped
 //   warped, ARAP = warp(def9)            (one workgroup per shape)  dvm_dg_warp_arap_bwd + rot6d backward
 //   cd = Chamfer side means; map = sum |lhs - rhs|^2                source-side Chamfer gradient; map residuals kept in the arena
+//   dist[p] = sum_n 1 - |cos(x_n, y_n)| (x_j, y_j kept)             weights W from the kept x, y; d feat = diag(colsum W) feat - W^T fa,
+//                                                                   d feat[a_n] += rowsum(W)_n fa_n - (W feat)_n on the library's GEMM kernels
 #include "dvm_common.h"
 
 namespace dvm {
@@ -50,13 +53,20 @@ void launch_chamfer_bwd_src2(const float *a0, const float *a1, const float *b0, 
                              const int32_t *i1b, const int32_t *i2b, const float *gt, int gstride, int off0, int off1, int B, int N, int M,
                              float *da0, float *da1, hipStream_t s);
 
+ int launch_dist_loss_fwd(const float *feat, const float *dist, const int32_t *anchors, int B, int N, int C, int nA, int k, float *out, int out_stride,
+                         int out_off, int32_t *idx_out, float *xsave, float *fa_out, void *ws, size_t ws_bytes, hipStream_t s);
+void launch_dist_loss_bwd_weights_saved(const float *xsave, const int32_t *idx, const float *gterm, int gstride, int B, int N, int nA, int k, float *W,
+                                        float *rs, hipStream_t s);
+void launch_wgrad_batched(const float *gy, const float *x, int nb, long R, int Co, int K, float *dW, hipStream_t s);
+void launch_linear_bmm(const float *x, const float *w, int B, int N, int K, int Co, float *y, hipStream_t s);
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CT_C = 128;                // feature width (the Deformer's pooled features, models/model.py:459)
 constexpr int CT_Z = 2 * CT_C + 6;       // 262: the decoder's input row
-constexpr int CT_TERMS = 6;
+constexpr int CT_TERMS = 7;
 constexpr int CT_H[3] = {512, 256, 128};
 enum { PW_CONV_W = 0, PW_CONV_B, PW_W0, PW_B0, PW_W1, PW_B1, PW_W2, PW_B2, PW_W3, PW_B3, PW_N };
 static_assert(PW_N == DVM_CRIT_TRAIN_NPARAMS, "parameter table layout and include/dvm.h disagree");
@@ -270,11 +280,48 @@ __global__ __launch_bounds__(256) void gval_nodes_kernel(const float *__restrict
     float *o = gval + ((size_t)p * N + nodes[(size_t)p * Nn + a]) * topk + t;
     *o = *o + dval_n[(size_t)p * Nn * topk + g];
 }
-// dfeat[q] = df1[q] + df2[(q + B) mod 2B] + dpool[q]
+// dfeat[q] = df1[q] + df2[(q + B) mod 2B] + dpool[q] (+ ddist[q])
 __global__ __launch_bounds__(256) void combine_feat_kernel(const f32x4 *__restrict__ df1, const f32x4 *__restrict__ df2, const f32x4 *__restrict__ dpool,
-                                                           long half, f32x4 *__restrict__ out) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * half; i += (long)gridDim.x * blockDim.x)
-        out[i] = (df1[i] + df2[i < half ? i + half : i - half]) + dpool[i];
+                                                           const f32x4 *__restrict__ ddist, long half, f32x4 *__restrict__ out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * half; i += (long)gridDim.x * blockDim.x) {
+        f32x4 v = (df1[i] + df2[i < half ? i + half : i - half]) + dpool[i];
+        if (ddist) v = v + ddist[i];
+        out[i] = v;
+    }
+}
+// dist term backward: cs[b][v] = sum_n W[b][n][v] (anchors in order)
+__global__ __launch_bounds__(256) void dist_colsum_kernel(const float *__restrict__ W, int N, int nA, float *__restrict__ cs) {
+    const int b = blockIdx.y, v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= N) return;
+    const float *w = W + (size_t)b * nA * N + v;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int n = 0;
+    for (; n + 3 < nA; n += 4) a0 += w[(size_t)n * N], a1 += w[(size_t)(n + 1) * N], a2 += w[(size_t)(n + 2) * N], a3 += w[(size_t)(n + 3) * N];
+    for (; n < nA; ++n) a0 += w[(size_t)n * N];
+    cs[(size_t)b * N + v] = (a0 + a1) + (a2 + a3);
+}
+// ddist[b][v] = cs[b][v] feat[b][v] - C1[b][v]
+__global__ __launch_bounds__(256) void dist_combine_rows_kernel(const float *__restrict__ cs, const f32x4 *__restrict__ feat, const f32x4 *__restrict__ c1,
+                                                                long rows, f32x4 *__restrict__ out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < rows * (CT_C / 4); i += (long)gridDim.x * blockDim.x) {
+        const float c = cs[i / (CT_C / 4)];
+        const f32x4 f = feat[i], g = c1[i];
+        out[i] = f32x4{c * f.x - g.x, c * f.y - g.y, c * f.z - g.z, c * f.w - g.w};
+    }
+}
+// ddist[b][a_n] += rs[b][n] fa[b][n] - C2[b][n]   (the anchors of a shape are distinct points)
+__global__ __launch_bounds__(256) void dist_combine_anchors_kernel(const float *__restrict__ rs, const f32x4 *__restrict__ fa, const f32x4 *__restrict__ c2,
+                                                                   const int32_t *__restrict__ anchors, int N, int nA, f32x4 *__restrict__ out) {
+    const int b = blockIdx.y;
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (long)nA * (CT_C / 4)) return;
+    const int n = (int)(g / (CT_C / 4)), c4 = (int)(g % (CT_C / 4));
+    const size_t src = ((size_t)b * nA + n) * (CT_C / 4) + c4, dst = ((size_t)b * N + anchors[n]) * (CT_C / 4) + c4;
+    const float r = rs[(size_t)b * nA + n];
+    const f32x4 f = fa[src], q = c2[src];
+    f32x4 o = out[dst];
+    o.x += r * f.x - q.x, o.y += r * f.y - q.y, o.z += r * f.z - q.z, o.w += r * f.w - q.w;
+    out[dst] = o;
 }
 
 // ---------------------------------------------------------------- arena
@@ -299,10 +346,15 @@ struct CritWs {
     int32_t *offsA, *curA, *edgesA, *offsB, *curB, *edgesB;
     void *sbws, *wgws;
     size_t sb_bytes, wg_bytes;
+    // dist term (nA > 0)
+    int32_t *didx;
+    float *xsave, *fa, *W, *rs, *cs, *c1, *c2, *ddist;
+    void *dws;
+    size_t d_bytes;
 };
 constexpr int COLSUM_CHUNKS = 128, SUM_BLOCKS = 256;
 
-void carve(Arena &ar, int P, int N, int k, int topk, CritWs &w) {
+void carve(Arena &ar, int P, int N, int k, int topk, int nA, int kd, CritWs &w) {
     const size_t Nn = (size_t)N / 2, R = (size_t)P * Nn, PN = (size_t)P * N;
     w.featT = ar.take<float>(PN * CT_C), w.vertsT = ar.take<float>(PN * 3), w.idxT = ar.take<int32_t>(PN * k);
     w.pval = ar.take<float>(PN * topk), w.pidx = ar.take<int32_t>(PN * topk), w.smax = ar.take<float>(PN), w.ssum = ar.take<float>(PN);
@@ -328,6 +380,13 @@ void carve(Arena &ar, int P, int N, int k, int topk, CritWs &w) {
     w.offsB = ar.take<int32_t>((size_t)P * (N + 1)), w.curB = ar.take<int32_t>(PN), w.edgesB = ar.take<int32_t>(PN * k);
     w.sb_bytes = dvm_softcorr_bwd_workspace_bytes(P, N, N, CT_C), w.sbws = ar.take<char>(w.sb_bytes);
     w.wg_bytes = dvm_linear_wgrad_workspace_bytes((long)R, 512, CT_Z), w.wgws = ar.take<char>(w.wg_bytes);
+    if (nA > 0) {
+        const size_t B = (size_t)P / 2;
+        w.didx = ar.take<int32_t>((size_t)P * nA * kd), w.xsave = ar.take<float>((size_t)P * nA * kd * 2), w.fa = ar.take<float>((size_t)P * nA * CT_C);
+        w.d_bytes = dvm_dist_loss_workspace_bytes((int)B, N, CT_C, nA, kd), w.dws = ar.take<char>(w.d_bytes);
+        w.W = ar.take<float>(B * nA * N), w.rs = ar.take<float>(B * nA), w.cs = ar.take<float>(B * N);
+        w.c1 = ar.take<float>(B * N * CT_C), w.c2 = ar.take<float>(B * nA * CT_C), w.ddist = ar.take<float>(PN * CT_C);
+    }
 }
 
 void swap_halves(const void *const *src, void *const *dst, const long *half_bytes, int count, hipStream_t s) {
@@ -351,6 +410,13 @@ void colsum_add(const float *g, long R, int C, float *out, const CritWs &w, hipS
     hipLaunchKernelGGL(colsum_any_final_kernel, dim3(slabs), dim3(64), 0, s, w.colpart, (int)chunks, C, out);
 }
 
+int check_dist(const char *who, int N, const void *d1, const void *d2, const void *a1, const void *a2, int nA, int kd) {
+    if (nA == 0) return DVM_OK;
+    DVM_REQUIRE(d1 && d2 && a1 && a2, "%s: the dist term needs both distance matrices and both anchor lists", who);
+    DVM_REQUIRE(nA >= 1 && nA <= N && kd >= 1 && kd <= 512 && kd <= N, "%s: dist term sizes out of range (anchors %d, neighbours %d)", who, nA, kd);
+    return DVM_OK;
+}
+
 int check_common(const char *who, int B, int N, int C, int k, int topk, const void *const *params, int nparams) {
     DVM_REQUIRE(B >= 1 && N >= 64 && N % 4 == 0 && N <= 8192, "%s: bad sizes (B=%d N=%d; N a multiple of 4 in 64..8192)", who, B, N);
     DVM_REQUIRE(C == CT_C, "%s: C=%d (the Deformer pools 128-wide features)", who, C);
@@ -365,31 +431,49 @@ int check_common(const char *who, int B, int N, int C, int k, int topk, const vo
 
 using namespace dvm;
 
-DVM_EXPORT size_t dvm_criterion_train_workspace_bytes(int B, int N, int k, int topk) {
-    if (B < 1 || N < 2 || k < 1 || topk < 1) return 0;
+DVM_EXPORT size_t dvm_criterion_train_workspace_bytes(int B, int N, int k, int topk, int n_anchors, int k_dist) {
+    if (B < 1 || N < 2 || k < 1 || topk < 1 || n_anchors < 0 || (n_anchors > 0 && k_dist < 1)) return 0;
     Arena ar(nullptr, 0);
     CritWs w;
-    carve(ar, 2 * B, N, k, topk, w);
+    carve(ar, 2 * B, N, k, topk, n_anchors, k_dist, w);
     return ar.off;
 }
 
 DVM_EXPORT int dvm_criterion_train_fwd_f32(const float *feat, const float *verts, const int32_t *nodes_idx, const int32_t *ring,
                                            const int32_t *infl_idx, const float *weights, const int32_t *knn_idx, int B, int N, int C, int k,
-                                           int topk, float neg_alpha, const float *const *params, int nparams, int with_map, float *terms,
-                                           void *arena, size_t arena_bytes, void *stream) {
+                                           int topk, float neg_alpha, const float *const *params, int nparams, int with_map, const float *dist1,
+                                           const float *dist2, const int32_t *anchors1, const int32_t *anchors2, int n_anchors, int k_dist,
+                                           float *terms, void *arena, size_t arena_bytes, void *stream) {
     DVM_REQUIRE(feat && verts && nodes_idx && ring && infl_idx && weights && knn_idx && terms, "dvm_criterion_train_fwd_f32: null pointer");
     CT_TRY(check_common("dvm_criterion_train_fwd_f32", B, N, C, k, topk, (const void *const *)params, nparams));
+    CT_TRY(check_dist("dvm_criterion_train_fwd_f32", N, dist1, dist2, anchors1, anchors2, n_anchors, k_dist));
     DVM_REQUIRE(neg_alpha < 0.f, "dvm_criterion_train_fwd_f32: neg_alpha must be negative");
     const int P = 2 * B, Nn = N / 2;
     const long R = (long)P * Nn, PN = (long)P * N;
     Arena ar(arena, arena_bytes);
     CritWs w;
-    carve(ar, P, N, k, topk, w);
+    carve(ar, P, N, k, topk, n_anchors, k_dist, w);
     if (!ar.ok()) {
         set_error("dvm_criterion_train_fwd_f32: arena too small (%zu < %zu)", arena_bytes, ar.off);
         return DVM_ENOSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
+    // the dist term of the 2B shapes: independent of the deformation part, on the helper stream of the caller's context (dvm_pair_init)
+    PairCtx *cx = n_anchors > 0 ? pair_ctx_find(s) : nullptr;
+    if (n_anchors > 0) {
+        hipStream_t ds = cx ? cx->side : s;
+        if (cx) (void)hipEventRecord(cx->ev_fork, s), (void)hipStreamWaitEvent(ds, cx->ev_fork, 0);
+        for (int side = 0; side < 2; ++side) {
+            const size_t so = (size_t)side * B;
+            CT_TRY(launch_dist_loss_fwd(feat + so * N * CT_C, side ? dist2 : dist1, side ? anchors2 : anchors1, B, N, CT_C, n_anchors, k_dist,
+                                        terms + so * CT_TERMS, CT_TERMS, 6, w.didx + so * n_anchors * k_dist, w.xsave + so * n_anchors * k_dist * 2,
+                                        w.fa + so * n_anchors * CT_C, w.dws, w.d_bytes, ds));
+        }
+        if (cx) (void)hipEventRecord(cx->ev_join, ds);
+    } else {
+        (void)hipMemsetAsync(w.partial, 0, (size_t)P * sizeof(double), s);
+        launch_reduce_partials(w.partial, P, 1, 1.f, terms, CT_TERMS, 6, s);
+    }
     {   // the target side of every directional pair
         const void *src[3] = {feat, verts, knn_idx};
         void *dst[3] = {w.featT, w.vertsT, w.idxT};
@@ -429,6 +513,7 @@ DVM_EXPORT int dvm_criterion_train_fwd_f32(const float *feat, const float *verts
         (void)hipMemsetAsync(w.partial, 0, (size_t)P * sizeof(double), s);
         launch_reduce_partials(w.partial, P, 1, 1.f, terms, CT_TERMS, 0, s);
     }
+    if (cx) (void)hipStreamWaitEvent(s, cx->ev_join, 0);
     (void)R, (void)PN;
     DVM_CHECK_LAUNCH("criterion_train_fwd");
     return DVM_OK;
@@ -437,22 +522,49 @@ DVM_EXPORT int dvm_criterion_train_fwd_f32(const float *feat, const float *verts
 DVM_EXPORT int dvm_criterion_train_bwd_f32(const float *g_terms, const float *feat, const float *verts, const int32_t *nodes_idx,
                                            const int32_t *ring, const int32_t *infl_idx, const float *weights, const int32_t *knn_idx, int B,
                                            int N, int C, int k, int topk, float neg_alpha, const float *const *params, float *const *grads,
-                                           int nparams, int with_map, float *d_feat, void *arena, size_t arena_bytes, void *stream) {
+                                           int nparams, int with_map, const int32_t *anchors1, const int32_t *anchors2, int n_anchors, int k_dist,
+                                           float *d_feat, void *arena, size_t arena_bytes, void *stream) {
     DVM_REQUIRE(g_terms && feat && verts && nodes_idx && ring && infl_idx && weights && knn_idx && d_feat && grads,
                 "dvm_criterion_train_bwd_f32: null pointer");
     CT_TRY(check_common("dvm_criterion_train_bwd_f32", B, N, C, k, topk, (const void *const *)params, nparams));
+    DVM_REQUIRE(n_anchors == 0 || (anchors1 && anchors2 && n_anchors <= N && k_dist >= 1 && k_dist <= 512),
+                "dvm_criterion_train_bwd_f32: the dist term needs both anchor lists (anchors %d, neighbours %d)", n_anchors, k_dist);
     for (int i = 0; i < PW_N; ++i) DVM_REQUIRE(grads[i] != nullptr, "dvm_criterion_train_bwd_f32: gradient buffer %d is null", i);
     const int P = 2 * B, Nn = N / 2;
     const long R = (long)P * Nn, PN = (long)P * N;
     Arena ar(arena, arena_bytes);
     CritWs w;
-    carve(ar, P, N, k, topk, w);
+    carve(ar, P, N, k, topk, n_anchors, k_dist, w);
     if (!ar.ok()) {
         set_error("dvm_criterion_train_bwd_f32: arena too small (%zu < %zu)", arena_bytes, ar.off);
         return DVM_ENOSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
     const dim3 node_grid((unsigned)(((long)Nn * 32 + 255) / 256), P);
+    // the dist term's feature gradient (helper stream): W from the kept x, y, then the two products on the library's GEMM kernels
+    PairCtx *cx = n_anchors > 0 ? pair_ctx_find(s) : nullptr;
+    if (n_anchors > 0) {
+        hipStream_t ds = cx ? cx->side : s;
+        if (cx) (void)hipEventRecord(cx->ev_fork, s), (void)hipStreamWaitEvent(ds, cx->ev_fork, 0);
+        const int nA = n_anchors;
+        for (int side = 0; side < 2; ++side) {
+            const size_t so = (size_t)side * B;
+            const float *fs = feat + so * N * CT_C, *fa = w.fa + so * nA * CT_C;
+            const int32_t *an = side ? anchors2 : anchors1;
+            float *dd = w.ddist + so * N * CT_C;
+            launch_dist_loss_bwd_weights_saved(w.xsave + so * nA * k_dist * 2, w.didx + so * nA * k_dist, g_terms + so * CT_TERMS + 6, CT_TERMS, B, N, nA,
+                                               k_dist, w.W, w.rs, ds);
+            (void)hipMemsetAsync(w.c1, 0, (size_t)B * N * CT_C * sizeof(float), ds);
+            launch_wgrad_batched(w.W, fa, B, nA, N, CT_C, w.c1, ds);                 // C1[b] = W[b]^T fa[b]      [N][C]
+            launch_linear_bmm(fs, w.W, B, CT_C, N, nA, w.c2, ds);                    // C2[b] = W[b] feat[b]      [nA][C]
+            hipLaunchKernelGGL(dist_colsum_kernel, dim3((N + 255) / 256, B), dim3(256), 0, ds, w.W, N, nA, w.cs);
+            hipLaunchKernelGGL(dist_combine_rows_kernel, dim3(blocks_for((long)B * N * (CT_C / 4))), dim3(256), 0, ds, w.cs, (const f32x4 *)fs,
+                               (const f32x4 *)w.c1, (long)B * N, (f32x4 *)dd);
+            hipLaunchKernelGGL(dist_combine_anchors_kernel, dim3((unsigned)(((long)nA * (CT_C / 4) + 255) / 256), B), dim3(256), 0, ds, w.rs,
+                               (const f32x4 *)fa, (const f32x4 *)w.c2, an, N, nA, (f32x4 *)dd);
+        }
+        if (cx) (void)hipEventRecord(cx->ev_join, ds);
+    }
     // Chamfer side means -> d warped, d verts12 (source side only: the targets are inputs)
     launch_chamfer_bwd_src2(w.warped, w.verts12, w.vertsT, w.vertsT, w.i1w, w.i2w, w.i1s, w.i2s, g_terms, CT_TERMS, 1, 3, P, N, N, w.dwarped, w.dv12, s);
     // warp + ARAP -> (dR, dT) -> d def9
@@ -500,8 +612,10 @@ DVM_EXPORT int dvm_criterion_train_bwd_f32(const float *g_terms, const float *fe
     hipLaunchKernelGGL(gval_nodes_kernel, dim3((unsigned)(((long)Nn * topk + 255) / 256), P), dim3(256), 0, s, w.dval_n, nodes_idx, N, Nn, topk, w.gval);
     CT_TRY(dvm_softcorr_bwd_f32(feat, w.featT, P, N, N, CT_C, neg_alpha, topk, w.pval, w.pidx, w.smax, w.ssum, w.gval, w.df1, w.df2, 0, w.sbws,
                                 w.sb_bytes, s));
+    if (cx) (void)hipStreamWaitEvent(s, cx->ev_join, 0);
     hipLaunchKernelGGL(combine_feat_kernel, dim3(blocks_for(PN * CT_C / 4)), dim3(256), 0, s, (const f32x4 *)w.df1, (const f32x4 *)w.df2,
-                       (const f32x4 *)w.dpool, (long)B * N * CT_C / 4, (f32x4 *)d_feat);
+                       (const f32x4 *)w.dpool, n_anchors > 0 ? (const f32x4 *)w.ddist : (const f32x4 *)nullptr, (long)B * N * CT_C / 4,
+                       (f32x4 *)d_feat);
     DVM_CHECK_LAUNCH("criterion_train_bwd");
     return DVM_OK;
 }

@@ -39,6 +39,7 @@ struct LinArgs {
     const float *bias, *res, *alpha, *beta;  // per output channel (bias, alpha, beta); res laid out like Y
     int I, J, K;                             // rows of P, columns of Q, reduction length
     long q_bs, y_bs;                         // batch strides (channel-major); 0 otherwise
+    long p_bs;                               // channel-major: batch stride of P (0: one weight matrix for every batch element)
     int ldy;
     float slope;                             // 1: no activation; 0: ReLU; < 0: ELU (alpha = 1); else LeakyReLU(slope)
     const float *post_res;                   // NULL, or laid out like Y: y = post_res + post_scale * (what the epilogue made)
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a) {
     if ((total & 7) == 0) t = (t & 7) * (total >> 3) + (t >> 3);
     const int ti = t / a.tiles_j, tj = t % a.tiles_j;
     const int i0 = ti * BM, j0 = tj * BN, b = blockIdx.y;
-    const float *__restrict__ P = a.P;
+    const float *__restrict__ P = a.P + (size_t)b * a.p_bs;
     const float *__restrict__ Q = a.Q + (size_t)b * a.q_bs;
     const int K = a.K, I = a.I, J = a.J;
 
@@ -504,10 +505,11 @@ static int pick_cfg(int n, long rows_out_narrow, int K = 0) {
     return n > 4 ? (K >= 768 ? 6 : 4) : 1;
 }
 
-void launch_linear(const float *x, const float *w, int B, int N, int K, int Co, int channel_major, const float *bias,
-                   const float *res, const float *alpha, const float *beta, float slope, float *y, hipStream_t s,
-                   const float *xg = nullptr, int Cg = 0, const float *post_res = nullptr, float post_scale = 1.f) {
+static void launch_linear_impl(const float *x, const float *w, int B, int N, int K, int Co, int channel_major, const float *bias,
+                               const float *res, const float *alpha, const float *beta, float slope, float *y, hipStream_t s,
+                               const float *xg, int Cg, const float *post_res, float post_scale, long w_bs) {
     LinArgs a;
+    a.p_bs = channel_major ? w_bs : 0;   // w_bs: a weight matrix PER batch element (channel-major only): y[b] = w[b] x[b]
     a.G = xg, a.Cg = xg ? Cg : 0, a.Nrow = N, a.ldp = K - a.Cg;
     a.post_res = post_res, a.post_scale = post_scale;
     a.bias = bias, a.res = res, a.alpha = alpha, a.beta = beta, a.slope = slope, a.K = K, a.Y = y;
@@ -545,6 +547,17 @@ void launch_linear(const float *x, const float *w, int B, int N, int K, int Co, 
     }
 }
 
+void launch_linear(const float *x, const float *w, int B, int N, int K, int Co, int channel_major, const float *bias,
+                   const float *res, const float *alpha, const float *beta, float slope, float *y, hipStream_t s,
+                   const float *xg = nullptr, int Cg = 0, const float *post_res = nullptr, float post_scale = 1.f) {
+    launch_linear_impl(x, w, B, N, K, Co, channel_major, bias, res, alpha, beta, slope, y, s, xg, Cg, post_res, post_scale, 0);
+}
+// y[b] [Co][N] = w[b] [Co][K] x[b] [K][N]: the channel-major form with a weight matrix per batch element (a batched matrix product with
+// both operands K-major / N-major as they lie; the k-chain order of dvm_linear_f32)
+void launch_linear_bmm(const float *x, const float *w, int B, int N, int K, int Co, float *y, hipStream_t s) {
+    launch_linear_impl(x, w, B, N, K, Co, 1, nullptr, nullptr, nullptr, nullptr, 1.f, y, s, nullptr, 0, nullptr, 1.f, (long)Co * K);
+}
+
 // ---------------------------------------------------------------- weight gradient of a point-major linear layer
 // dW[co][k] = sum_r gy[r][co] * x[r][k]  (r over the B*N rows): a "TN" product whose reduction runs over the ROWS, so both
 // operands are read exactly as they lie in memory — the A fragment of v_mfma_f32_32x32x2_f32 wants, per k-step, 32
@@ -564,6 +577,9 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(const float *__res
     const int tiles_k = (K + 63) / 64;
     const int co0 = (blockIdx.x / tiles_k) * 64, k0 = (blockIdx.x % tiles_k) * 64;
     const long rbeg = (long)blockIdx.y * rchunk, rend = rbeg + rchunk < R ? rbeg + rchunk : R;
+    if (!DET) {   // blockIdx.z: independent products of the same shape, operands and results back to back (launch_wgrad_batched)
+        gy += (size_t)blockIdx.z * R * Co, x += (size_t)blockIdx.z * R * K, dW += (size_t)blockIdx.z * Co * K;
+    }
     // staging: 32 rows x 64 floats per operand = 512 float4: 2 per thread
     f32x4 pg[2], px[2];
     auto fetch = [&](long r0) {
@@ -707,6 +723,20 @@ static long wgrad_chunks(long R, int Co, int K, long &rchunk) {
     rchunk = (R + chunks - 1) / chunks;
     rchunk = (rchunk + WG_ROWS - 1) / WG_ROWS * WG_ROWS;
     return (R + rchunk - 1) / rchunk;
+}
+}  // namespace dvm
+
+namespace dvm {
+// dW[b] [Co][K] += gy[b]^T x[b] for nb products of one shape, operands and results back to back; row chunks combined with fp32 atomics
+// (dW zeroed by the caller)
+void launch_wgrad_batched(const float *gy, const float *x, int nb, long R, int Co, int K, float *dW, hipStream_t s) {
+    const int tiles = ((Co + 63) / 64) * ((K + 63) / 64);
+    long chunks = 1;
+    while ((long)tiles * chunks * nb < 1024 && R / (chunks * 2) >= 256) chunks *= 2;
+    long rchunk = (R + chunks - 1) / chunks;
+    rchunk = (rchunk + WG_ROWS - 1) / WG_ROWS * WG_ROWS;
+    chunks = (R + rchunk - 1) / rchunk;
+    hipLaunchKernelGGL(linear_wgrad_kernel<false>, dim3((unsigned)tiles, (unsigned)chunks, (unsigned)nb), dim3(256), 0, s, gy, x, R, Co, K, rchunk, dW);
 }
 }  // namespace dvm
 

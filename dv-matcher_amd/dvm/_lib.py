@@ -72,10 +72,11 @@ SIGNATURES = {
     "dvm_bn_act_train_fwd_pm_sync_f32": (c_int, [_P, _P, _P, _P, ctypes.c_long, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P, _P, _P]),
     "dvm_bn_act_train_bwd_pm_sync_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, ctypes.c_long, c_int, c_int, c_float, _P, _P, _P, c_int, _P, c_size_t, _P, _P, _P]),
     "dvm_pos_encoding_sync_f32": (c_int, [_P, c_int, c_int, _P, _P, c_size_t, _P, _P, _P]),
-    "dvm_criterion_train_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
-    "dvm_criterion_train_fwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P, c_int, c_int, _P, _P, c_size_t, _P]),
-    "dvm_criterion_train_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, c_int, c_int, _P, _P,
-                                            c_size_t, _P]),
+    "dvm_criterion_train_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "dvm_criterion_train_fwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P, c_int, c_int, _P, _P, _P, _P, c_int,
+                                            c_int, _P, _P, c_size_t, _P]),
+    "dvm_criterion_train_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, c_int, c_int, _P, _P, c_int,
+                                            c_int, _P, _P, c_size_t, _P]),
     "dvm_linear_wgrad_workspace_bytes": (c_size_t, [ctypes.c_long, c_int, c_int]),
     "dvm_linear_wgrad_ws_f32": (c_int, [_P, _P, ctypes.c_long, c_int, c_int, _P, _P, c_size_t, _P]),
     "dvm_set_deterministic": (c_int, [c_int]),

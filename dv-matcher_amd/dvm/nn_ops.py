@@ -240,12 +240,13 @@ class _CriterionTrain(torch.autograd.Function):
     """The deformation part of the training criterion — both directions of deform() for the B pairs of a step, as 2B directional
     pairs — as ONE autograd node over two native calls (dvm_criterion_train_{fwd,bwd}_f32): the ~300 launches the autograd path
     enqueued through ~40 nodes, without Python in between.  meta = (verts (2B,N,3), graph dict, knn_idx (2B,N,k), alpha, topk,
-    with_map); inputs: feat (2B,N,128) and the Deformer's 10 tensors in ops.DEFORMER_KEYS order.  -> terms (2B,6)."""
+    with_map, dist) with dist = None or (dist1, dist2, anchors1, anchors2, k_dist) for the dist term; inputs: feat (2B,N,128) and the
+    Deformer's 10 tensors in ops.DEFORMER_KEYS order.  -> terms (2B,7)."""
 
     @staticmethod
     def forward(ctx, meta, feat, *trainable):
-        verts, g, knn_idx, alpha, topk, with_map = meta
-        terms, arena = ops.criterion_train_forward([p.detach() for p in trainable], feat, verts, g, knn_idx, alpha, topk, with_map)
+        verts, g, knn_idx, alpha, topk, with_map, dist = meta
+        terms, arena = ops.criterion_train_forward([p.detach() for p in trainable], feat, verts, g, knn_idx, alpha, topk, with_map, dist)
         ctx.meta, ctx.arena, ctx.trainable = meta, arena, trainable
         ctx.save_for_backward(feat)
         return terms
@@ -255,7 +256,7 @@ class _CriterionTrain(torch.autograd.Function):
     def backward(ctx, g_terms):
         if ctx.arena is None:
             raise RuntimeError("dvm criterion training node: backward ran already (its arena is released after the first pass)")
-        verts, g, knn_idx, alpha, topk, with_map = ctx.meta
+        verts, g, knn_idx, alpha, topk, with_map, dist = ctx.meta
         (feat,) = ctx.saved_tensors
         trainable = ctx.trainable
         need = ctx.needs_input_grad[2:]
@@ -271,7 +272,7 @@ class _CriterionTrain(torch.autograd.Function):
                 off += n
             out = [gr.view_as(p) if nd else None for gr, p, nd in zip(grads, trainable, need)]
         d_feat = ops.criterion_train_backward([p.detach() for p in trainable], grads, g_terms.contiguous(), feat, verts, g, knn_idx, alpha,
-                                              ctx.arena, topk, with_map)
+                                              ctx.arena, topk, with_map, dist)
         ctx.arena = None
         return (None, d_feat if ctx.needs_input_grad[1] else None) + tuple(out)
 

@@ -957,38 +957,52 @@ def uni3fc_train_forward(params, x, dino, k, eps, momentum, defer_stats=False, g
 CRIT_TRAIN_NPARAMS = 10
 
 
-def criterion_train_forward(params, feat, verts, g, knn_idx, alpha, topk=10, with_map=True):
-    """The deformation part of the training criterion for B pairs as ONE native call (dvm_criterion_train_fwd_f32).  feat (2B,N,128),
-    verts (2B,N,3): the B first shapes followed by the B second shapes; g = their batched graph dict (dg_build), knn_idx (2B,N,k)
-    their xyz-kNN; params: the Deformer's 10 tensors (conv weight, bias, then the decoder's weight / bias pairs).
-    -> terms (2B,6) [map numerator, Chamfer side means of warped (2) and verts12 (2), ARAP], arena (uint8 tensor for the backward)."""
+def criterion_train_forward(params, feat, verts, g, knn_idx, alpha, topk=10, with_map=True, dist=None):
+    """The training criterion for B pairs as ONE native call (dvm_criterion_train_fwd_f32).  feat (2B,N,128), verts (2B,N,3): the B first
+    shapes followed by the B second shapes; g = their batched graph dict (dg_build), knn_idx (2B,N,k) their xyz-kNN; params: the
+    Deformer's 10 tensors (conv weight, bias, then the decoder's weight / bias pairs); dist = None or (dist1 (B,N,N), dist2 (B,N,N),
+    anchors1 (nA,) int32, anchors2 (nA,) int32, k_dist): the dist term of all 2B shapes.
+    -> terms (2B,7) [map numerator, Chamfer side means of warped (2) and verts12 (2), ARAP, dist term], arena (uint8 tensor for the backward)."""
     _need_gpu(feat, verts)
     feat, verts = _f(feat), _f(verts)
     P, N, C = feat.shape
     k = knn_idx.shape[-1]
     lib = _lib.load()
-    terms = torch.empty(P, 6, dtype=torch.float32, device=feat.device)
-    nb = lib.dvm_criterion_train_workspace_bytes(P // 2, N, k, topk)
+    terms = torch.empty(P, 7, dtype=torch.float32, device=feat.device)
+    d1, d2, a1, a2, kd = dist if dist is not None else (None, None, None, None, 0)
+    nA = 0 if dist is None else int(a1.numel())
+    if dist is not None and not (d1.dtype is torch.float32 and d1.is_contiguous() and d2.dtype is torch.float32 and d2.is_contiguous()
+                                 and a1.dtype is torch.int32 and a2.dtype is torch.int32 and tuple(d1.shape) == (P // 2, N, N)
+                                 and tuple(d2.shape) == (P // 2, N, N) and a2.numel() == nA):
+        raise DvmError("criterion_train_forward: dist term inputs must be contiguous fp32 (B,N,N) matrices and int32 anchor lists of one length")
+    nb = lib.dvm_criterion_train_workspace_bytes(P // 2, N, k, topk, nA, int(kd))
     arena = torch.empty(nb, dtype=torch.uint8, device=feat.device)
+    if nA:
+        _ensure_pair_ctx(feat.device)
     table = _ptr_table(params, CRIT_TRAIN_NPARAMS)
     check(lib.dvm_criterion_train_fwd_f32(_p(feat), _p(verts), _p(g["nodes_idx"]), _p(g["one_ring"]), _p(g["infl_idx"]), _p(g["weights"]), _p(knn_idx),
                                           P // 2, N, C, k, topk, neg_alpha_f32(alpha), ctypes.cast(table, ctypes.c_void_p), CRIT_TRAIN_NPARAMS,
-                                          1 if with_map else 0, _p(terms), _p(arena), nb, _stream()), "dvm_criterion_train_fwd_f32")
+                                          1 if with_map else 0, _p(d1), _p(d2), _p(a1), _p(a2), nA, int(kd), _p(terms), _p(arena), nb, _stream()),
+          "dvm_criterion_train_fwd_f32")
     return terms, arena
 
 
-def criterion_train_backward(params, grads, g_terms, feat, verts, g, knn_idx, alpha, arena, topk=10, with_map=True):
+def criterion_train_backward(params, grads, g_terms, feat, verts, g, knn_idx, alpha, arena, topk=10, with_map=True, dist=None):
     """dvm_criterion_train_bwd_f32: -> d_feat (2B,N,128); the Deformer's parameter gradients are ADDED into `grads`."""
     _need_gpu(feat, g_terms)
     P, N, C = feat.shape
     k = knn_idx.shape[-1]
     lib = _lib.load()
     d_feat = torch.empty_like(feat)
+    _, _, a1, a2, kd = dist if dist is not None else (None, None, None, None, 0)
+    nA = 0 if dist is None else int(a1.numel())
+    if nA:
+        _ensure_pair_ctx(feat.device)
     ptab, gtab = _ptr_table(params, CRIT_TRAIN_NPARAMS), _ptr_table(grads, CRIT_TRAIN_NPARAMS)
     check(lib.dvm_criterion_train_bwd_f32(_p(_f(g_terms)), _p(feat), _p(verts), _p(g["nodes_idx"]), _p(g["one_ring"]), _p(g["infl_idx"]), _p(g["weights"]),
                                           _p(knn_idx), P // 2, N, C, k, topk, neg_alpha_f32(alpha), ctypes.cast(ptab, ctypes.c_void_p),
-                                          ctypes.cast(gtab, ctypes.c_void_p), CRIT_TRAIN_NPARAMS, 1 if with_map else 0, _p(d_feat), _p(arena),
-                                          arena.numel(), _stream()), "dvm_criterion_train_bwd_f32")
+                                          ctypes.cast(gtab, ctypes.c_void_p), CRIT_TRAIN_NPARAMS, 1 if with_map else 0, _p(a1), _p(a2), nA, int(kd),
+                                          _p(d_feat), _p(arena), arena.numel(), _stream()), "dvm_criterion_train_bwd_f32")
     return d_feat
 
 

@@ -236,14 +236,15 @@ class GraphDeformLoss_Neural(nn.Module):
             map_sum = ((lhs - rhs) ** 2).sum(dim=(1, 2, 3))
         return map_sum, cd_warp, (arap if per_pair else arap.sum()), cd_self, dict(warped=warped, verts12=verts12, pval=pval, pidx=pidx)
 
-    def _term_weights(self, B, N, device):
-        """(2B*6, 6) matrix taking the native node's table [map, cd_warp (2), cd_self (2), arap] x 2B directional pairs to
-        [deform_loss, map_loss, self_rec_loss, sum-type share, mean-type share, total] (models/loss.py:1413-1432; data_parallel_loss)."""
-        key = (B, N, str(device), self.w_cd, self.w_arap, self.w_deform, self.w_map, self.w_self_rec)
+    def _term_weights(self, B, N, device, with_dist=False):
+        """(2B*7, 7) matrix taking the native node's table [map, cd_warp (2), cd_self (2), arap, dist] x 2B (directional pairs / shapes) to
+        [deform_loss, map_loss, self_rec_loss, sum-type share, mean-type share, total, dist_loss] (models/loss.py:1398-1437;
+        data_parallel_loss)."""
+        key = (B, N, str(device), self.w_cd, self.w_arap, self.w_deform, self.w_map, self.w_self_rec, self.w_dist if with_dist else 0)
         cache = self.__dict__.setdefault("_term_w", {})
         if key not in cache:
             half = N * self.w_deform / 2        # (non-partial criterion: scale = N)
-            row = torch.zeros(6, 6, dtype=torch.float64)
+            row = torch.zeros(7, 7, dtype=torch.float64)
             row[1, 0] = row[2, 0] = self.w_cd * half / B            # Chamfer: mean over the B pairs of each direction
             row[5, 0] = self.w_arap * half                          # ARAP: sum over the pairs
             row[5, 3] = self.w_arap * half
@@ -252,7 +253,9 @@ class GraphDeformLoss_Neural(nn.Module):
                 row[0, 1] = row[0, 4] = self.w_map / (3 * B) / 2    # FrobeniusLoss: sum over (N,k), mean over (B,3)
             if self.w_self_rec > 0:
                 row[3, 2] = row[4, 2] = row[3, 4] = row[4, 4] = N * self.w_self_rec / 2 / B
-            row[:, 5] = row[:, 0] + row[:, 1] + row[:, 2]
+            if with_dist:
+                row[6, 6] = row[6, 3] = self.w_dist                 # dist term: sum over all 2B shapes
+            row[:, 5] = row[:, 0] + row[:, 1] + row[:, 2] + row[:, 6]
             cache[key] = row.repeat(2 * B, 1).float().to(device)
         return cache[key]
 
@@ -372,7 +375,7 @@ class GraphDeformLoss_Neural(nn.Module):
                 anchors = (random.sample(range(dist1.shape[1]), self.N_dist), random.sample(range(dist2.shape[1]), self.N_dist))
             # (device tensors pass through untouched: no host-to-device copy inside a captured step)
             a1, a2 = _host_draw_to_device(anchors[0], feat1.device), _host_draw_to_device(anchors[1], feat2.device)
-            dterm = on(0, lambda: (dist_term(feat1, dist1, a1) + dist_term(feat2, dist2, a2)) * self.w_dist)
+        native_dist = False
         if self.w_deform > 0 or not self.partial_variant:
             g1, g2, idx11, idx22 = geometry if geometry is not None else self.geometry(verts1, verts2, fps_starts, shape_ids)
             merged = (train and N == M and not self.dump and not self.partial_variant and self.w_rank <= 0
@@ -381,6 +384,12 @@ class GraphDeformLoss_Neural(nn.Module):
             native = (merged and self.native_train and feat1.is_cuda and feat1.dtype == torch.float32 and feat1.shape[-1] == 128 and N % 4 == 0
                       and 64 <= N <= 8192 and self.k_deform <= 16 and idx11.shape[-1] == self.k_deform
                       and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in deformer.parameters()))
+            # ... and the dist term of all 2B shapes inside the same node (on its helper stream)
+            native_dist = (native and self.w_dist > 0 and self.k_dist <= 512 and a1.numel() == a2.numel() and a1.numel() <= N
+                           and all(d.is_cuda and d.dtype == torch.float32 and d.is_contiguous() and tuple(d.shape) == (B, N, N) for d in (dist1, dist2)))
+        if self.w_dist > 0 and not native_dist:
+            dterm = on(0, lambda: (dist_term(feat1, dist1, a1) + dist_term(feat2, dist2, a2)) * self.w_dist)
+        if self.w_deform > 0 or not self.partial_variant:
             if native:
                 # Both directions of deform() for the B pairs = 2B directional pairs [(1 -> 2) x B | (2 -> 1) x B] through ONE native
                 # autograd node; its table of per-pair terms is weighted by one small matrix product (the reductions of
@@ -388,9 +397,10 @@ class GraphDeformLoss_Neural(nn.Module):
                 from dvm.ops import DEFORMER_KEYS
                 named = dict(deformer.named_parameters())
                 gj = {k: _joint(g1[k], g2[k]) for k in ("nodes_idx", "one_ring", "infl_idx", "weights")}
-                meta = (_joint(verts1, verts2), gj, _joint(idx11, idx22), alpha_i, 10, bool(self.w_map > 0))
+                dmeta = (dist1, dist2, ops._i(a1), ops._i(a2), self.k_dist) if native_dist else None
+                meta = (_joint(verts1, verts2), gj, _joint(idx11, idx22), alpha_i, 10, bool(self.w_map > 0), dmeta)
                 terms = nn_ops.criterion_train(meta, _joint(feat1, feat2), [named[k] for k in DEFORMER_KEYS])
-                parts = terms.reshape(-1) @ self._term_weights(B, N, terms.device)
+                parts = terms.reshape(-1) @ self._term_weights(B, N, terms.device, native_dist)
                 n12 = str(random.randint(0, 10))
                 n21 = str(random.randint(0, 10))
             elif merged:
@@ -416,12 +426,15 @@ class GraphDeformLoss_Neural(nn.Module):
                 n12 = str(random.randint(0, 10))
                 m21, c21, a21, s21, ex21 = joined(1, r21)
                 n21 = str(random.randint(0, 10))
-        if self.w_dist > 0:
+        if self.w_dist > 0 and not native_dist:
             self.dist_loss = joined(0, dterm)
             loss = loss + self.dist_loss
             self._sum_part = self._sum_part + self.dist_loss
         if (self.w_deform > 0 or not self.partial_variant) and native:
-            # parts = [deform, map, self_rec, the sum-type share, the mean-type share, deform + map + self_rec]
+            # parts = [deform, map, self_rec, the sum-type share, the mean-type share, their total, dist] (the last three with the dist term
+            # when the node computed it)
+            if native_dist:
+                self.dist_loss = parts[6]
             self.deform_loss = parts[0]
             if self.w_map > 0:
                 self.map_loss = parts[1]

@@ -593,22 +593,27 @@ int dvm_uni3fc_train_bwd_sync_f32(const float *g_feat, const float *g_tmp, const
  *   knn_idx [P][N][k]                    : dvm_knn_cdist_f32(verts, verts, k)
  *   params: DVM_CRIT_TRAIN_NPARAMS device pointers — Deformer.conv_layer.weight [k], .bias [1], then the decoder's
  *           (weight, bias) x 4: [512][262], [512], [256][512], [256], [128][256], [128], [9][128], [9]
- * fwd -> terms [P][6] = [map numerator (0 when with_map == 0) | mean d(warped -> target), mean d(target -> warped) |
- *        mean d(verts12 -> target), mean d(target -> verts12) | ARAP]; everything the backward needs stays in `arena`
- *        (dvm_criterion_train_workspace_bytes bytes, caller-owned, untouched until the matching bwd).
- * bwd: g_terms [P][6] = dL / d terms -> d_feat [P][N][C] (overwritten; the coordinates carry no gradient), the parameter
+ *   dist term (models/loss.py:1351-1396), n_anchors > 0: dist1 / dist2 [B][N][N] the geodesic matrices of the first / second shapes,
+ *           anchors1 / anchors2 [n_anchors] the anchor draws, k_dist <= 512 neighbours — what dvm_dist_loss_fwd_f32 takes, for all 2B
+ *           shapes; runs on the helper stream of the caller's dvm_pair_init context beside the deformation part.  n_anchors == 0: off.
+ * fwd -> terms [P][7] = [map numerator (0 when with_map == 0) | mean d(warped -> target), mean d(target -> warped) |
+ *        mean d(verts12 -> target), mean d(target -> verts12) | ARAP | dist term of SHAPE p (0 when off)]; everything the backward
+ *        needs stays in `arena` (dvm_criterion_train_workspace_bytes bytes, caller-owned, untouched until the matching bwd).
+ * bwd: g_terms [P][7] = dL / d terms -> d_feat [P][N][C] (overwritten; the coordinates carry no gradient), the parameter
  *      gradients ADDED into grads[i] (fp32 atomics; same indexing as params).
  * N a multiple of 4 in 64..8192, k <= 16, topk <= 10, neg_alpha < 0 as in dvm_softcorr_fwd_f32. */
 #define DVM_CRIT_TRAIN_NPARAMS 10
-size_t dvm_criterion_train_workspace_bytes(int B, int N, int k, int topk);
+size_t dvm_criterion_train_workspace_bytes(int B, int N, int k, int topk, int n_anchors, int k_dist);
 int dvm_criterion_train_fwd_f32(const float *feat, const float *verts, const int32_t *nodes_idx, const int32_t *ring,
                                 const int32_t *infl_idx, const float *weights, const int32_t *knn_idx, int B, int N, int C, int k,
-                                int topk, float neg_alpha, const float *const *params, int nparams, int with_map, float *terms,
-                                void *arena, size_t arena_bytes, void *stream);
+                                int topk, float neg_alpha, const float *const *params, int nparams, int with_map, const float *dist1,
+                                const float *dist2, const int32_t *anchors1, const int32_t *anchors2, int n_anchors, int k_dist,
+                                float *terms, void *arena, size_t arena_bytes, void *stream);
 int dvm_criterion_train_bwd_f32(const float *g_terms, const float *feat, const float *verts, const int32_t *nodes_idx,
                                 const int32_t *ring, const int32_t *infl_idx, const float *weights, const int32_t *knn_idx, int B,
                                 int N, int C, int k, int topk, float neg_alpha, const float *const *params, float *const *grads,
-                                int nparams, int with_map, float *d_feat, void *arena, size_t arena_bytes, void *stream);
+                                int nparams, int with_map, const int32_t *anchors1, const int32_t *anchors2, int n_anchors, int k_dist,
+                                float *d_feat, void *arena, size_t arena_bytes, void *stream);
 
 /* dvm_pair_fwd_f32 can run its coordinate-only chain (FPS, graph, xyz kNN: latency-bound) on helper streams, forked
  * from and joined back into `stream` by events, next to the feature-only soft-correspondence chain.  The helper streams
