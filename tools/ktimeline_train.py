@@ -1,14 +1,19 @@
 """One TRAINING step from a rocprofv3 kernel trace: where the wall time of the step goes — the union of the kernels' intervals (GPU busy),
 the idle gaps between them (nothing on any queue: launch latency, host, dependencies), the busy time per queue, and the step in 0.5-ms slices
 (kernels running, dominant kernel).  A step = the kernels between two optimizer launches (multi_tensor_apply).
-usage: ktimeline_train.py <dir-or-csv> [step-index]"""
+usage: ktimeline_train.py <dir-or-csv> [step-index] [first-kernel-substring]   (with a substring: a step BEGINS at that kernel — the pair bench)"""
 import collections, csv, glob, os, sys
 p = sys.argv[1]; which = int(sys.argv[2]) if len(sys.argv) > 2 else -2
 f = p if p.endswith(".csv") else sorted(glob.glob(os.path.join(p, "**", "*kernel_trace.csv"), recursive=True))[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-adam = [i for i, r in enumerate(rows) if "multi_tensor_apply" in r["Kernel_Name"]]
-ends = [i for j, i in enumerate(adam) if j + 1 == len(adam) or adam[j + 1] - i > 20]      # the last optimizer launch of every step
-a, b = ends[which - 1] + 1, ends[which] + 1
+if len(sys.argv) > 3:
+    st = [i for i, r in enumerate(rows) if sys.argv[3].lower() in r["Kernel_Name"].lower()]
+    st = [i for j, i in enumerate(st) if j == 0 or i - st[j - 1] > 20]
+    a, b = st[which - 1], st[which]
+else:
+    adam = [i for i, r in enumerate(rows) if "multi_tensor_apply" in r["Kernel_Name"]]
+    ends = [i for j, i in enumerate(adam) if j + 1 == len(adam) or adam[j + 1] - i > 20]      # the last optimizer launch of every step
+    a, b = ends[which - 1] + 1, ends[which] + 1
 ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], r["Kernel_Name"]) for r in rows[a:b]]
 t0, t1 = ks[0][0], max(k[1] for k in ks)
 print("step of %d kernels, span %.3f ms, sum of kernel times %.3f ms" % (len(ks), (t1 - t0) / 1e6, sum(k[1] - k[0] for k in ks) / 1e6))
