@@ -20,6 +20,12 @@ import json,sys
 d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1])
 print('train batch %d: %7.1f pairs/s  %7.2f ms/step  host enqueue %.2f ms' % ($b, d['value'], d['ms_per_step'], d['host_enqueue_ms_per_step']))"
 done >> $O/scaling_proxy.txt 2>&1
+for b in 1 2 8; do   # the same step captured into one HIP graph and replayed (train_driver --graph): no host work per step
+  python dv-matcher_amd/train_driver.py --steps 10 --warmup 3 --batch $b --points 2048 --graph 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1])
+print('train batch %d, captured step: %7.1f pairs/s  %7.2f ms/step' % ($b, d['value'], d['ms_per_step']))"
+done >> $O/scaling_proxy.txt 2>&1
 cd /tmp
 rocprofv3 --kernel-trace --stats -d /tmp/p_bench -o x --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-check > /tmp/p_bench.log 2>&1
 cp $(find /tmp/p_bench -name "*kernel_stats.csv" | head -1) $O/kernel_stats_bench_steps3_pairs512.csv
