@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void swap_halves_kernel(const SwapArgs a) {
 __global__ __launch_bounds__(256) void assemble_train_kernel(const float *__restrict__ verts, const float *__restrict__ verts12,
                                                              const float *__restrict__ gp, const float *__restrict__ gpT,
                                                              const float *__restrict__ pval, const int32_t *__restrict__ pidx,
-                                                             const int32_t *__restrict__ nodes, int N, int Nn, int topk, float *__restrict__ z,
+                                                             const int32_t *__restrict__ nodes, int N, int M, int Nn, int topk, float *__restrict__ z,
                                                              float *__restrict__ pval_n, int32_t *__restrict__ pidx_n) {
     const int p = blockIdx.y;
     const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void assemble_train_kernel(const float *__rest
     const int a = (int)(g >> 5), c4 = (int)(g & 31);
     const int v = nodes[(size_t)p * Nn + a];
     const size_t row = (size_t)p * N + v, nrow = (size_t)p * Nn + a;
-    const float *gt = gpT + (size_t)p * N * CT_C;
+    const float *gt = gpT + (size_t)p * M * CT_C;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < topk; ++t) {
         const float w = pval[row * topk + t];
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void map_bwd_gather_kernel(const float *__rest
 // part only with the map term)
 __global__ __launch_bounds__(256) void gval_total_kernel(const float *__restrict__ dv12, const float *__restrict__ vertsT,
                                                          const int32_t *__restrict__ idxT, const int32_t *__restrict__ pidx,
-                                                         const float *__restrict__ resid, const float *__restrict__ gt, int N, int k, int topk,
+                                                         const float *__restrict__ resid, const float *__restrict__ gt, int N, int M, int k, int topk,
                                                          float *__restrict__ gval) {
     const int p = blockIdx.y;
     const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -255,11 +255,11 @@ __global__ __launch_bounds__(256) void gval_total_kernel(const float *__restrict
     const int i = (int)(g / topk);
     const size_t row = (size_t)p * N + i;
     const int col = pidx[(size_t)p * N * topk + g];
-    const float *vt = vertsT + (size_t)p * N * 3;
+    const float *vt = vertsT + (size_t)p * M * 3;
     const float *d = dv12 + row * 3, *q = vt + (size_t)col * 3;
     float acc = (d[0] * q[0] + d[1] * q[1]) + d[2] * q[2];
     if (resid) {
-        const int32_t *nb = idxT + ((size_t)p * N + col) * k;
+        const int32_t *nb = idxT + ((size_t)p * M + col) * k;
         const float *r = resid + row * k * 3;
         float m = 0.f;
         for (int s = 0; s < k; ++s) {
@@ -288,6 +288,10 @@ __global__ __launch_bounds__(256) void combine_feat_kernel(const f32x4 *__restri
         if (ddist) v = v + ddist[i];
         out[i] = v;
     }
+}
+// out = a + b
+__global__ __launch_bounds__(256) void add2_kernel(const f32x4 *__restrict__ a, const f32x4 *__restrict__ b, long n4, f32x4 *__restrict__ out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) out[i] = a[i] + b[i];
 }
 // dist term backward: cs[b][v] = sum_n W[b][n][v] (anchors in order)
 __global__ __launch_bounds__(256) void dist_colsum_kernel(const float *__restrict__ W, int N, int nA, float *__restrict__ cs) {
@@ -325,6 +329,12 @@ __global__ __launch_bounds__(256) void dist_combine_anchors_kernel(const float *
 }
 
 // ---------------------------------------------------------------- arena
+// One batch of P directional pairs: sources with N points, targets with M.  `swapped`: the targets ARE the sources of the other half
+// (N == M, P = 2B: target of pair p = source of pair (p + B) mod P) — their copies are made here; otherwise the caller hands them in.
+struct Dims {
+    int P, N, M, k, topk, nA, kd;
+    bool swapped;
+};
 struct CritWs {
     // kept from the forward
     float *featT, *vertsT;
@@ -341,12 +351,12 @@ struct CritWs {
     void *scws, *chws;
     size_t sc_bytes, ch_bytes;
     // backward scratch
-    float *dwarped, *dv12, *dR, *dT, *ddef9, *dh[3], *dz, *colpart, *g2t_c, *dval_n, *dgpT, *dgp, *wexp, *dvalw, *dpool, *gval, *df1, *df2;
+    float *dwarped, *dv12, *dR, *dT, *ddef9, *dh[3], *dz, *colpart, *g2t_c, *dval_n, *dgpT, *dgp, *wexp, *dvalw, *dpool, *dpoolT, *gval, *df1, *df2;
     double *sumpart;
-    int32_t *offsA, *curA, *edgesA, *offsB, *curB, *edgesB;
+    int32_t *offsA, *curA, *edgesA, *offsB, *curB, *edgesB, *offsC, *curC, *edgesC;
     void *sbws, *wgws;
     size_t sb_bytes, wg_bytes;
-    // dist term (nA > 0)
+    // dist term (nA > 0; swapped form only)
     int32_t *didx;
     float *xsave, *fa, *W, *rs, *cs, *c1, *c2, *ddist;
     void *dws;
@@ -354,34 +364,40 @@ struct CritWs {
 };
 constexpr int COLSUM_CHUNKS = 128, SUM_BLOCKS = 256;
 
-void carve(Arena &ar, int P, int N, int k, int topk, int nA, int kd, CritWs &w) {
-    const size_t Nn = (size_t)N / 2, R = (size_t)P * Nn, PN = (size_t)P * N;
-    w.featT = ar.take<float>(PN * CT_C), w.vertsT = ar.take<float>(PN * 3), w.idxT = ar.take<int32_t>(PN * k);
+void carve(Arena &ar, const Dims &d, CritWs &w) {
+    const int P = d.P, N = d.N, M = d.M, k = d.k, topk = d.topk;
+    const size_t Nn = (size_t)N / 2, R = (size_t)P * Nn, PN = (size_t)P * N, PM = (size_t)P * M, PX = PN > PM ? PN : PM;
+    w.featT = w.vertsT = nullptr, w.idxT = nullptr;
+    if (d.swapped) w.featT = ar.take<float>(PM * CT_C), w.vertsT = ar.take<float>(PM * 3), w.idxT = ar.take<int32_t>(PM * k);
     w.pval = ar.take<float>(PN * topk), w.pidx = ar.take<int32_t>(PN * topk), w.smax = ar.take<float>(PN), w.ssum = ar.take<float>(PN);
-    w.verts12 = ar.take<float>(PN * 3), w.warped = ar.take<float>(PN * 3), w.gp = ar.take<float>(PN * CT_C), w.gpT = ar.take<float>(PN * CT_C);
+    w.verts12 = ar.take<float>(PN * 3), w.warped = ar.take<float>(PN * 3), w.gp = ar.take<float>(PN * CT_C), w.gpT = ar.take<float>(PM * CT_C);
     w.z = ar.take<float>(R * CT_Z), w.pval_n = ar.take<float>(R * topk), w.pidx_n = ar.take<int32_t>(R * topk);
     for (int l = 0; l < 3; ++l) w.h[l] = ar.take<float>(R * CT_H[l]);
     w.def9 = ar.take<float>(R * 9), w.Rm = ar.take<float>(R * 9), w.T = ar.take<float>(R * 3);
-    w.d1w = ar.take<float>(PN), w.d2w = ar.take<float>(PN), w.d1s = ar.take<float>(PN), w.d2s = ar.take<float>(PN);
-    w.i1w = ar.take<int32_t>(PN), w.i2w = ar.take<int32_t>(PN), w.i1s = ar.take<int32_t>(PN), w.i2s = ar.take<int32_t>(PN);
+    w.d1w = ar.take<float>(PN), w.d2w = ar.take<float>(PM), w.d1s = ar.take<float>(PN), w.d2s = ar.take<float>(PM);
+    w.i1w = ar.take<int32_t>(PN), w.i2w = ar.take<int32_t>(PM), w.i1s = ar.take<int32_t>(PN), w.i2s = ar.take<int32_t>(PM);
     w.resid = ar.take<float>(PN * k * 3);
     w.partial = ar.take<double>((size_t)P * map_term_blocks(N, k));
-    w.sc_bytes = dvm_softcorr_workspace_bytes(P, N, N, CT_C), w.scws = ar.take<char>(w.sc_bytes);
-    w.ch_bytes = dvm_chamfer_workspace_bytes(P, N, N), w.chws = ar.take<char>(w.ch_bytes);
+    w.sc_bytes = dvm_softcorr_workspace_bytes(P, N, M, CT_C), w.scws = ar.take<char>(w.sc_bytes);
+    w.ch_bytes = dvm_chamfer_workspace_bytes(P, N, M), w.chws = ar.take<char>(w.ch_bytes);
     // backward
     w.dwarped = ar.take<float>(PN * 3), w.dv12 = ar.take<float>(PN * 3), w.dR = ar.take<float>(R * 9), w.dT = ar.take<float>(R * 3);
     w.ddef9 = ar.take<float>(R * 9);
     for (int l = 0; l < 3; ++l) w.dh[l] = ar.take<float>(R * CT_H[l]);
     w.dz = ar.take<float>(R * CT_Z), w.colpart = ar.take<float>((size_t)COLSUM_CHUNKS * 512), w.sumpart = ar.take<double>(SUM_BLOCKS);
-    w.g2t_c = ar.take<float>(R * CT_C), w.dval_n = ar.take<float>(R * topk), w.dgpT = ar.take<float>(PN * CT_C), w.dgp = ar.take<float>(PN * CT_C);
-    w.wexp = ar.take<float>(PN * k), w.dvalw = ar.take<float>(PN * k), w.dpool = ar.take<float>(PN * CT_C), w.gval = ar.take<float>(PN * topk);
-    w.df1 = ar.take<float>(PN * CT_C), w.df2 = ar.take<float>(PN * CT_C);
-    w.offsA = ar.take<int32_t>((size_t)P * (N + 1)), w.curA = ar.take<int32_t>(PN), w.edgesA = ar.take<int32_t>(R * topk);
+    w.g2t_c = ar.take<float>(R * CT_C), w.dval_n = ar.take<float>(R * topk), w.dgpT = ar.take<float>(PM * CT_C), w.dgp = ar.take<float>(PN * CT_C);
+    w.wexp = ar.take<float>(PX * k), w.dvalw = ar.take<float>(PX * k), w.dpool = ar.take<float>(PN * CT_C), w.gval = ar.take<float>(PN * topk);
+    w.dpoolT = d.swapped ? nullptr : ar.take<float>(PM * CT_C);
+    w.df1 = ar.take<float>(PN * CT_C), w.df2 = ar.take<float>(PM * CT_C);
+    w.offsA = ar.take<int32_t>((size_t)P * (M + 1)), w.curA = ar.take<int32_t>(PM), w.edgesA = ar.take<int32_t>(R * topk);
     w.offsB = ar.take<int32_t>((size_t)P * (N + 1)), w.curB = ar.take<int32_t>(PN), w.edgesB = ar.take<int32_t>(PN * k);
-    w.sb_bytes = dvm_softcorr_bwd_workspace_bytes(P, N, N, CT_C), w.sbws = ar.take<char>(w.sb_bytes);
+    w.offsC = w.curC = w.edgesC = nullptr;
+    if (!d.swapped) w.offsC = ar.take<int32_t>((size_t)P * (M + 1)), w.curC = ar.take<int32_t>(PM), w.edgesC = ar.take<int32_t>(PM * k);
+    w.sb_bytes = dvm_softcorr_bwd_workspace_bytes(P, N, M, CT_C), w.sbws = ar.take<char>(w.sb_bytes);
     w.wg_bytes = dvm_linear_wgrad_workspace_bytes((long)R, 512, CT_Z), w.wgws = ar.take<char>(w.wg_bytes);
-    if (nA > 0) {
+    if (d.nA > 0) {
         const size_t B = (size_t)P / 2;
+        const int nA = d.nA, kd = d.kd;
         w.didx = ar.take<int32_t>((size_t)P * nA * kd), w.xsave = ar.take<float>((size_t)P * nA * kd * 2), w.fa = ar.take<float>((size_t)P * nA * CT_C);
         w.d_bytes = dvm_dist_loss_workspace_bytes((int)B, N, CT_C, nA, kd), w.dws = ar.take<char>(w.d_bytes);
         w.W = ar.take<float>(B * nA * N), w.rs = ar.take<float>(B * nA), w.cs = ar.take<float>(B * N);
@@ -417,8 +433,9 @@ int check_dist(const char *who, int N, const void *d1, const void *d2, const voi
     return DVM_OK;
 }
 
-int check_common(const char *who, int B, int N, int C, int k, int topk, const void *const *params, int nparams) {
-    DVM_REQUIRE(B >= 1 && N >= 64 && N % 4 == 0 && N <= 8192, "%s: bad sizes (B=%d N=%d; N a multiple of 4 in 64..8192)", who, B, N);
+int check_common(const char *who, int P, int N, int M, bool swapped, int C, int k, int topk, const void *const *params, int nparams) {
+    DVM_REQUIRE(P >= 1 && N >= 64 && N <= 8192 && M >= 64 && M <= 8192, "%s: bad sizes (pairs %d, N=%d, M=%d; point counts in 64..8192)", who, P, N, M);
+    DVM_REQUIRE(!swapped || (N == M && N % 4 == 0), "%s: N=%d must be a multiple of 4", who, N);
     DVM_REQUIRE(C == CT_C, "%s: C=%d (the Deformer pools 128-wide features)", who, C);
     DVM_REQUIRE(k >= 1 && k <= 16 && topk >= 1 && topk <= 10, "%s: k=%d / topk=%d out of range (k <= 16, topk <= 10)", who, k, topk);
     DVM_REQUIRE(params && nparams == PW_N, "%s: the parameter table has %d entries, expected %d", who, nparams, (int)PW_N);
@@ -426,134 +443,119 @@ int check_common(const char *who, int B, int N, int C, int k, int topk, const vo
     return DVM_OK;
 }
 
-}  // namespace
-}  // namespace dvm
+// what a pass reads of its sources and targets
+struct Sides {
+    const float *feat_s, *verts_s;
+    const int32_t *nodes, *ring, *infl;
+    const float *weights;
+    const int32_t *knn_s;
+    const float *feat_t, *verts_t;   // swapped form: filled from the arena's copies
+    const int32_t *knn_t;
+};
+struct DistIn {
+    const float *dist1, *dist2;
+    const int32_t *anchors1, *anchors2;
+};
 
-using namespace dvm;
-
-DVM_EXPORT size_t dvm_criterion_train_workspace_bytes(int B, int N, int k, int topk, int n_anchors, int k_dist) {
-    if (B < 1 || N < 2 || k < 1 || topk < 1 || n_anchors < 0 || (n_anchors > 0 && k_dist < 1)) return 0;
-    Arena ar(nullptr, 0);
-    CritWs w;
-    carve(ar, 2 * B, N, k, topk, n_anchors, k_dist, w);
-    return ar.off;
-}
-
-DVM_EXPORT int dvm_criterion_train_fwd_f32(const float *feat, const float *verts, const int32_t *nodes_idx, const int32_t *ring,
-                                           const int32_t *infl_idx, const float *weights, const int32_t *knn_idx, int B, int N, int C, int k,
-                                           int topk, float neg_alpha, const float *const *params, int nparams, int with_map, const float *dist1,
-                                           const float *dist2, const int32_t *anchors1, const int32_t *anchors2, int n_anchors, int k_dist,
-                                           float *terms, void *arena, size_t arena_bytes, void *stream) {
-    DVM_REQUIRE(feat && verts && nodes_idx && ring && infl_idx && weights && knn_idx && terms, "dvm_criterion_train_fwd_f32: null pointer");
-    CT_TRY(check_common("dvm_criterion_train_fwd_f32", B, N, C, k, topk, (const void *const *)params, nparams));
-    CT_TRY(check_dist("dvm_criterion_train_fwd_f32", N, dist1, dist2, anchors1, anchors2, n_anchors, k_dist));
-    DVM_REQUIRE(neg_alpha < 0.f, "dvm_criterion_train_fwd_f32: neg_alpha must be negative");
-    const int P = 2 * B, Nn = N / 2;
-    const long R = (long)P * Nn, PN = (long)P * N;
+int crit_fwd(const char *who, const Dims &d, Sides io, const DistIn &di, float neg_alpha, const float *const *params, int with_map, float *terms,
+             void *arena, size_t arena_bytes, hipStream_t s) {
+    const int P = d.P, N = d.N, M = d.M, k = d.k, topk = d.topk, Nn = N / 2, B = P / 2;
     Arena ar(arena, arena_bytes);
     CritWs w;
-    carve(ar, P, N, k, topk, n_anchors, k_dist, w);
+    carve(ar, d, w);
     if (!ar.ok()) {
-        set_error("dvm_criterion_train_fwd_f32: arena too small (%zu < %zu)", arena_bytes, ar.off);
+        set_error("%s: arena too small (%zu < %zu)", who, arena_bytes, ar.off);
         return DVM_ENOSPACE;
     }
-    hipStream_t s = (hipStream_t)stream;
     // the dist term of the 2B shapes: independent of the deformation part, on the helper stream of the caller's context (dvm_pair_init)
-    PairCtx *cx = n_anchors > 0 ? pair_ctx_find(s) : nullptr;
-    if (n_anchors > 0) {
+    PairCtx *cx = d.nA > 0 ? pair_ctx_find(s) : nullptr;
+    if (d.nA > 0) {
         hipStream_t ds = cx ? cx->side : s;
         if (cx) (void)hipEventRecord(cx->ev_fork, s), (void)hipStreamWaitEvent(ds, cx->ev_fork, 0);
         for (int side = 0; side < 2; ++side) {
             const size_t so = (size_t)side * B;
-            CT_TRY(launch_dist_loss_fwd(feat + so * N * CT_C, side ? dist2 : dist1, side ? anchors2 : anchors1, B, N, CT_C, n_anchors, k_dist,
-                                        terms + so * CT_TERMS, CT_TERMS, 6, w.didx + so * n_anchors * k_dist, w.xsave + so * n_anchors * k_dist * 2,
-                                        w.fa + so * n_anchors * CT_C, w.dws, w.d_bytes, ds));
+            CT_TRY(launch_dist_loss_fwd(io.feat_s + so * N * CT_C, side ? di.dist2 : di.dist1, side ? di.anchors2 : di.anchors1, B, N, CT_C, d.nA, d.kd,
+                                        terms + so * CT_TERMS, CT_TERMS, 6, w.didx + so * d.nA * d.kd, w.xsave + so * d.nA * d.kd * 2,
+                                        w.fa + so * d.nA * CT_C, w.dws, w.d_bytes, ds));
         }
         if (cx) (void)hipEventRecord(cx->ev_join, ds);
     } else {
         (void)hipMemsetAsync(w.partial, 0, (size_t)P * sizeof(double), s);
         launch_reduce_partials(w.partial, P, 1, 1.f, terms, CT_TERMS, 6, s);
     }
-    {   // the target side of every directional pair
-        const void *src[3] = {feat, verts, knn_idx};
+    if (d.swapped) {   // the target side of every directional pair = the other half's sources
+        const void *src[3] = {io.feat_s, io.verts_s, io.knn_s};
         void *dst[3] = {w.featT, w.vertsT, w.idxT};
         const long half[3] = {(long)B * N * CT_C * 4, (long)B * N * 3 * 4, (long)B * N * k * 4};
         swap_halves(src, dst, half, 3, s);
+        io.feat_t = w.featT, io.verts_t = w.vertsT, io.knn_t = w.idxT;
     }
-    CT_TRY(dvm_softcorr_fwd_f32(feat, w.featT, P, N, N, CT_C, neg_alpha, topk, w.pval, w.pidx, w.smax, w.ssum, 0, w.scws, w.sc_bytes, s));
-    CT_TRY(dvm_softcorr_apply_f32(w.pval, w.pidx, w.vertsT, P, N, N, topk, 3, w.verts12, s));
-    launch_pool_all(feat, knn_idx, P, N, k, params[PW_CONV_W], params[PW_CONV_B], w.gp, s, nullptr);
-    {
+    CT_TRY(dvm_softcorr_fwd_f32(io.feat_s, io.feat_t, P, N, M, CT_C, neg_alpha, topk, w.pval, w.pidx, w.smax, w.ssum, 0, w.scws, w.sc_bytes, s));
+    CT_TRY(dvm_softcorr_apply_f32(w.pval, w.pidx, io.verts_t, P, N, M, topk, 3, w.verts12, s));
+    launch_pool_all(io.feat_s, io.knn_s, P, N, k, params[PW_CONV_W], params[PW_CONV_B], w.gp, s, nullptr);
+    if (d.swapped) {
         const void *src[1] = {w.gp};
         void *dst[1] = {w.gpT};
         const long half[1] = {(long)B * N * CT_C * 4};
         swap_halves(src, dst, half, 1, s);
+    } else {
+        launch_pool_all(io.feat_t, io.knn_t, P, M, k, params[PW_CONV_W], params[PW_CONV_B], w.gpT, s, nullptr);
     }
-    hipLaunchKernelGGL(assemble_train_kernel, dim3((unsigned)(((long)Nn * 32 + 255) / 256), P), dim3(256), 0, s, verts, w.verts12, w.gp, w.gpT, w.pval,
-                       w.pidx, nodes_idx, N, Nn, topk, w.z, w.pval_n, w.pidx_n);
+    hipLaunchKernelGGL(assemble_train_kernel, dim3((unsigned)(((long)Nn * 32 + 255) / 256), P), dim3(256), 0, s, io.verts_s, w.verts12, w.gp, w.gpT,
+                       w.pval, w.pidx, io.nodes, N, M, Nn, topk, w.z, w.pval_n, w.pidx_n);
     // the decoder MLP 262 -> 512 -> 256 -> 128 -> 9, ELU between the layers (models/model.py:433-452)
     launch_linear(w.z, params[PW_W0], P, Nn, CT_Z, 512, 0, params[PW_B0], nullptr, nullptr, nullptr, -1.f, w.h[0], s, nullptr, 0, nullptr, 1.f);
     launch_linear(w.h[0], params[PW_W1], P, Nn, 512, 256, 0, params[PW_B1], nullptr, nullptr, nullptr, -1.f, w.h[1], s, nullptr, 0, nullptr, 1.f);
     launch_linear(w.h[1], params[PW_W2], P, Nn, 256, 128, 0, params[PW_B2], nullptr, nullptr, nullptr, -1.f, w.h[2], s, nullptr, 0, nullptr, 1.f);
     launch_linear(w.h[2], params[PW_W3], P, Nn, 128, 9, 0, params[PW_B3], nullptr, nullptr, nullptr, 1.f, w.def9, s, nullptr, 0, nullptr, 1.f);
     // rot6d (+ identity) -> embedded-deformation warp -> ARAP (lib/deformation_graph_point.py:233-261); ARAP lands in terms[:, 5]
-    launch_dg_warp(verts, P, N, nodes_idx, ring, infl_idx, weights, w.def9, w.Rm, w.T, w.warped, terms + 5, CT_TERMS, nullptr, s);
-    CT_TRY(dvm_chamfer_fwd_f32(w.warped, w.vertsT, P, N, N, w.d1w, w.d2w, w.i1w, w.i2w, w.chws, w.ch_bytes, s));
-    CT_TRY(dvm_chamfer_fwd_f32(w.verts12, w.vertsT, P, N, N, w.d1s, w.d2s, w.i1s, w.i2s, w.chws, w.ch_bytes, s));
+    launch_dg_warp(io.verts_s, P, N, io.nodes, io.ring, io.infl, io.weights, w.def9, w.Rm, w.T, w.warped, terms + 5, CT_TERMS, nullptr, s);
+    CT_TRY(dvm_chamfer_fwd_f32(w.warped, io.verts_t, P, N, M, w.d1w, w.d2w, w.i1w, w.i2w, w.chws, w.ch_bytes, s));
+    CT_TRY(dvm_chamfer_fwd_f32(w.verts12, io.verts_t, P, N, M, w.d1s, w.d2s, w.i1s, w.i2s, w.chws, w.ch_bytes, s));
     {
         const float *in[4] = {w.d1w, w.d2w, w.d1s, w.d2s};
-        const int n[4] = {N, N, N, N}, off[4] = {1, 2, 3, 4};
+        const int n[4] = {N, M, N, M}, off[4] = {1, 2, 3, 4};
         float *out[4] = {terms, terms, terms, terms};
         launch_mean_grouped(in, n, out, off, 4, P, 1.f, CT_TERMS, s);
     }
     if (with_map) {
-        launch_map_term(w.verts12, w.vertsT, knn_idx, w.idxT, w.pval, w.pidx, P, N, N, k, topk, w.partial, s, w.resid);
+        launch_map_term(w.verts12, io.verts_t, io.knn_s, io.knn_t, w.pval, w.pidx, P, N, M, k, topk, w.partial, s, w.resid);
         launch_reduce_partials(w.partial, P, map_term_blocks(N, k), 1.f, terms, CT_TERMS, 0, s);
     } else {
         (void)hipMemsetAsync(w.partial, 0, (size_t)P * sizeof(double), s);
         launch_reduce_partials(w.partial, P, 1, 1.f, terms, CT_TERMS, 0, s);
     }
     if (cx) (void)hipStreamWaitEvent(s, cx->ev_join, 0);
-    (void)R, (void)PN;
-    DVM_CHECK_LAUNCH("criterion_train_fwd");
     return DVM_OK;
 }
 
-DVM_EXPORT int dvm_criterion_train_bwd_f32(const float *g_terms, const float *feat, const float *verts, const int32_t *nodes_idx,
-                                           const int32_t *ring, const int32_t *infl_idx, const float *weights, const int32_t *knn_idx, int B,
-                                           int N, int C, int k, int topk, float neg_alpha, const float *const *params, float *const *grads,
-                                           int nparams, int with_map, const int32_t *anchors1, const int32_t *anchors2, int n_anchors, int k_dist,
-                                           float *d_feat, void *arena, size_t arena_bytes, void *stream) {
-    DVM_REQUIRE(g_terms && feat && verts && nodes_idx && ring && infl_idx && weights && knn_idx && d_feat && grads,
-                "dvm_criterion_train_bwd_f32: null pointer");
-    CT_TRY(check_common("dvm_criterion_train_bwd_f32", B, N, C, k, topk, (const void *const *)params, nparams));
-    DVM_REQUIRE(n_anchors == 0 || (anchors1 && anchors2 && n_anchors <= N && k_dist >= 1 && k_dist <= 512),
-                "dvm_criterion_train_bwd_f32: the dist term needs both anchor lists (anchors %d, neighbours %d)", n_anchors, k_dist);
-    for (int i = 0; i < PW_N; ++i) DVM_REQUIRE(grads[i] != nullptr, "dvm_criterion_train_bwd_f32: gradient buffer %d is null", i);
-    const int P = 2 * B, Nn = N / 2;
-    const long R = (long)P * Nn, PN = (long)P * N;
+// d_feat_s [P][N][C] (and, directional form, d_feat_t [P][M][C]) overwritten; parameter gradients added into grads
+int crit_bwd(const char *who, const Dims &d, Sides io, const DistIn &di, const float *g_terms, float neg_alpha, const float *const *params,
+             float *const *grads, int with_map, float *d_feat_s, float *d_feat_t, void *arena, size_t arena_bytes, hipStream_t s) {
+    const int P = d.P, N = d.N, M = d.M, k = d.k, topk = d.topk, Nn = N / 2, B = P / 2;
+    const long R = (long)P * Nn, PN = (long)P * N, PM = (long)P * M;
     Arena ar(arena, arena_bytes);
     CritWs w;
-    carve(ar, P, N, k, topk, n_anchors, k_dist, w);
+    carve(ar, d, w);
     if (!ar.ok()) {
-        set_error("dvm_criterion_train_bwd_f32: arena too small (%zu < %zu)", arena_bytes, ar.off);
+        set_error("%s: arena too small (%zu < %zu)", who, arena_bytes, ar.off);
         return DVM_ENOSPACE;
     }
-    hipStream_t s = (hipStream_t)stream;
+    if (d.swapped) io.feat_t = w.featT, io.verts_t = w.vertsT, io.knn_t = w.idxT;
     const dim3 node_grid((unsigned)(((long)Nn * 32 + 255) / 256), P);
     // the dist term's feature gradient (helper stream): W from the kept x, y, then the two products on the library's GEMM kernels
-    PairCtx *cx = n_anchors > 0 ? pair_ctx_find(s) : nullptr;
-    if (n_anchors > 0) {
+    PairCtx *cx = d.nA > 0 ? pair_ctx_find(s) : nullptr;
+    if (d.nA > 0) {
         hipStream_t ds = cx ? cx->side : s;
         if (cx) (void)hipEventRecord(cx->ev_fork, s), (void)hipStreamWaitEvent(ds, cx->ev_fork, 0);
-        const int nA = n_anchors;
+        const int nA = d.nA;
         for (int side = 0; side < 2; ++side) {
             const size_t so = (size_t)side * B;
-            const float *fs = feat + so * N * CT_C, *fa = w.fa + so * nA * CT_C;
-            const int32_t *an = side ? anchors2 : anchors1;
+            const float *fs = io.feat_s + so * N * CT_C, *fa = w.fa + so * nA * CT_C;
+            const int32_t *an = side ? di.anchors2 : di.anchors1;
             float *dd = w.ddist + so * N * CT_C;
-            launch_dist_loss_bwd_weights_saved(w.xsave + so * nA * k_dist * 2, w.didx + so * nA * k_dist, g_terms + so * CT_TERMS + 6, CT_TERMS, B, N, nA,
-                                               k_dist, w.W, w.rs, ds);
+            launch_dist_loss_bwd_weights_saved(w.xsave + so * nA * d.kd * 2, w.didx + so * nA * d.kd, g_terms + so * CT_TERMS + 6, CT_TERMS, B, N, nA, d.kd,
+                                               w.W, w.rs, ds);
             (void)hipMemsetAsync(w.c1, 0, (size_t)B * N * CT_C * sizeof(float), ds);
             launch_wgrad_batched(w.W, fa, B, nA, N, CT_C, w.c1, ds);                 // C1[b] = W[b]^T fa[b]      [N][C]
             launch_linear_bmm(fs, w.W, B, CT_C, N, nA, w.c2, ds);                    // C2[b] = W[b] feat[b]      [nA][C]
@@ -566,9 +568,9 @@ DVM_EXPORT int dvm_criterion_train_bwd_f32(const float *g_terms, const float *fe
         if (cx) (void)hipEventRecord(cx->ev_join, ds);
     }
     // Chamfer side means -> d warped, d verts12 (source side only: the targets are inputs)
-    launch_chamfer_bwd_src2(w.warped, w.verts12, w.vertsT, w.vertsT, w.i1w, w.i2w, w.i1s, w.i2s, g_terms, CT_TERMS, 1, 3, P, N, N, w.dwarped, w.dv12, s);
+    launch_chamfer_bwd_src2(w.warped, w.verts12, io.verts_t, io.verts_t, w.i1w, w.i2w, w.i1s, w.i2s, g_terms, CT_TERMS, 1, 3, P, N, M, w.dwarped, w.dv12, s);
     // warp + ARAP -> (dR, dT) -> d def9
-    launch_dg_warp_arap_bwd(verts, P, N, nodes_idx, ring, infl_idx, weights, w.Rm, w.T, w.dwarped, g_terms + 5, CT_TERMS, w.dR, w.dT, s);
+    launch_dg_warp_arap_bwd(io.verts_s, P, N, io.nodes, io.ring, io.infl, io.weights, w.Rm, w.T, w.dwarped, g_terms + 5, CT_TERMS, w.dR, w.dT, s);
     launch_def9_bwd(w.def9, w.dR, w.dT, (int)R, w.ddef9, s);
     // the decoder MLP, last layer first: bias gradient (column sums), weight gradient, input gradient x ELU'
     {
@@ -585,37 +587,144 @@ DVM_EXPORT int dvm_criterion_train_bwd_f32(const float *g_terms, const float *fe
         }
     }
     // z rows back to their sources
-    hipLaunchKernelGGL(z_bwd_split_kernel, node_grid, dim3(256), 0, s, w.dz, nodes_idx, N, Nn, w.dv12, w.g2t_c);
-    launch_rev_csr(w.pidx_n, P, (long)Nn * topk, N, w.offsA, w.curA, w.edgesA, s);
-    launch_apply_bwd_dval(w.pval_n, w.pidx_n, w.gpT, w.g2t_c, P, Nn, N, topk, CT_C, w.dval_n, s);
-    launch_apply_bwd_gather(w.pval_n, w.g2t_c, w.offsA, w.edgesA, P, Nn, N, topk, CT_C, w.dgpT, s);
-    {   // d gp[q] = d gpT[(q + B) mod P] (+ the node rows of dz)
+    hipLaunchKernelGGL(z_bwd_split_kernel, node_grid, dim3(256), 0, s, w.dz, io.nodes, N, Nn, w.dv12, w.g2t_c);
+    launch_rev_csr(w.pidx_n, P, (long)Nn * topk, M, w.offsA, w.curA, w.edgesA, s);
+    launch_apply_bwd_dval(w.pval_n, w.pidx_n, w.gpT, w.g2t_c, P, Nn, M, topk, CT_C, w.dval_n, s);
+    launch_apply_bwd_gather(w.pval_n, w.g2t_c, w.offsA, w.edgesA, P, Nn, M, topk, CT_C, w.dgpT, s);
+    if (d.swapped) {   // d gp[q] = d gpT[(q + B) mod P] (+ the node rows of dz)
         const void *src[1] = {w.dgpT};
         void *dst[1] = {w.dgp};
         const long half[1] = {(long)B * N * CT_C * 4};
         swap_halves(src, dst, half, 1, s);
+    } else {
+        (void)hipMemsetAsync(w.dgp, 0, (size_t)PN * CT_C * sizeof(float), s);
     }
-    hipLaunchKernelGGL(z_bwd_pool_kernel, node_grid, dim3(256), 0, s, w.dz, nodes_idx, N, Nn, w.dgp);
+    hipLaunchKernelGGL(z_bwd_pool_kernel, node_grid, dim3(256), 0, s, w.dz, io.nodes, N, Nn, w.dgp);
     // the pooling conv backward through the reversed xyz-kNN lists (also the map term's left-hand side)
-    launch_rev_csr(knn_idx, P, (long)N * k, N, w.offsB, w.curB, w.edgesB, s);
+    launch_rev_csr(io.knn_s, P, (long)N * k, N, w.offsB, w.curB, w.edgesB, s);
     hipLaunchKernelGGL(expand_w_kernel, dim3(blocks_for(PN * k)), dim3(256), 0, s, params[PW_CONV_W], k, PN * k, w.wexp);
-    launch_apply_bwd_dval(w.wexp, knn_idx, feat, w.dgp, P, N, N, k, CT_C, w.dvalw, s);
+    launch_apply_bwd_dval(w.wexp, io.knn_s, io.feat_s, w.dgp, P, N, N, k, CT_C, w.dvalw, s);
     launch_apply_bwd_gather(w.wexp, w.dgp, w.offsB, w.edgesB, P, N, N, k, CT_C, w.dpool, s);
     colsum_add(w.dvalw, PN, k, grads[PW_CONV_W], w, s);
     hipLaunchKernelGGL(sum_all_partial_kernel, dim3(SUM_BLOCKS), dim3(256), 0, s, (const f32x4 *)w.dgp, PN * CT_C / 4, w.sumpart);
     hipLaunchKernelGGL(sum_all_final_kernel, dim3(1), dim3(256), 0, s, w.sumpart, SUM_BLOCKS, grads[PW_CONV_B]);
+    if (!d.swapped) {   // ... and of the targets' own pooling (the swapped form pooled them as the other half's sources)
+        launch_rev_csr(io.knn_t, P, (long)M * k, M, w.offsC, w.curC, w.edgesC, s);
+        hipLaunchKernelGGL(expand_w_kernel, dim3(blocks_for(PM * k)), dim3(256), 0, s, params[PW_CONV_W], k, PM * k, w.wexp);
+        launch_apply_bwd_dval(w.wexp, io.knn_t, io.feat_t, w.dgpT, P, M, M, k, CT_C, w.dvalw, s);
+        launch_apply_bwd_gather(w.wexp, w.dgpT, w.offsC, w.edgesC, P, M, M, k, CT_C, w.dpoolT, s);
+        colsum_add(w.dvalw, PM, k, grads[PW_CONV_W], w, s);
+        hipLaunchKernelGGL(sum_all_partial_kernel, dim3(SUM_BLOCKS), dim3(256), 0, s, (const f32x4 *)w.dgpT, PM * CT_C / 4, w.sumpart);
+        hipLaunchKernelGGL(sum_all_final_kernel, dim3(1), dim3(256), 0, s, w.sumpart, SUM_BLOCKS, grads[PW_CONV_B]);
+    }
     if (with_map)
         hipLaunchKernelGGL(map_bwd_gather_kernel, dim3((N + 255) / 256, P), dim3(256), 0, s, w.resid, w.offsB, w.edgesB, g_terms, N, k, w.dv12);
     // everything that reaches the correspondence values, then the soft correspondence itself
-    hipLaunchKernelGGL(gval_total_kernel, dim3((unsigned)(((long)N * topk + 255) / 256), P), dim3(256), 0, s, w.dv12, w.vertsT, w.idxT, w.pidx,
-                       with_map ? w.resid : (const float *)nullptr, g_terms, N, k, topk, w.gval);
-    hipLaunchKernelGGL(gval_nodes_kernel, dim3((unsigned)(((long)Nn * topk + 255) / 256), P), dim3(256), 0, s, w.dval_n, nodes_idx, N, Nn, topk, w.gval);
-    CT_TRY(dvm_softcorr_bwd_f32(feat, w.featT, P, N, N, CT_C, neg_alpha, topk, w.pval, w.pidx, w.smax, w.ssum, w.gval, w.df1, w.df2, 0, w.sbws,
+    hipLaunchKernelGGL(gval_total_kernel, dim3((unsigned)(((long)N * topk + 255) / 256), P), dim3(256), 0, s, w.dv12, io.verts_t, io.knn_t, w.pidx,
+                       with_map ? w.resid : (const float *)nullptr, g_terms, N, M, k, topk, w.gval);
+    hipLaunchKernelGGL(gval_nodes_kernel, dim3((unsigned)(((long)Nn * topk + 255) / 256), P), dim3(256), 0, s, w.dval_n, io.nodes, N, Nn, topk, w.gval);
+    CT_TRY(dvm_softcorr_bwd_f32(io.feat_s, io.feat_t, P, N, M, CT_C, neg_alpha, topk, w.pval, w.pidx, w.smax, w.ssum, w.gval, w.df1, w.df2, 0, w.sbws,
                                 w.sb_bytes, s));
     if (cx) (void)hipStreamWaitEvent(s, cx->ev_join, 0);
-    hipLaunchKernelGGL(combine_feat_kernel, dim3(blocks_for(PN * CT_C / 4)), dim3(256), 0, s, (const f32x4 *)w.df1, (const f32x4 *)w.df2,
-                       (const f32x4 *)w.dpool, n_anchors > 0 ? (const f32x4 *)w.ddist : (const f32x4 *)nullptr, (long)B * N * CT_C / 4,
-                       (f32x4 *)d_feat);
+    if (d.swapped) {
+        hipLaunchKernelGGL(combine_feat_kernel, dim3(blocks_for(PN * CT_C / 4)), dim3(256), 0, s, (const f32x4 *)w.df1, (const f32x4 *)w.df2,
+                           (const f32x4 *)w.dpool, d.nA > 0 ? (const f32x4 *)w.ddist : (const f32x4 *)nullptr, (long)B * N * CT_C / 4, (f32x4 *)d_feat_s);
+    } else {
+        hipLaunchKernelGGL(add2_kernel, dim3(blocks_for(PN * CT_C / 4)), dim3(256), 0, s, (const f32x4 *)w.df1, (const f32x4 *)w.dpool, PN * CT_C / 4,
+                           (f32x4 *)d_feat_s);
+        hipLaunchKernelGGL(add2_kernel, dim3(blocks_for(PM * CT_C / 4)), dim3(256), 0, s, (const f32x4 *)w.df2, (const f32x4 *)w.dpoolT, PM * CT_C / 4,
+                           (f32x4 *)d_feat_t);
+    }
+    return DVM_OK;
+}
+
+}  // namespace
+}  // namespace dvm
+
+using namespace dvm;
+
+DVM_EXPORT size_t dvm_criterion_train_workspace_bytes(int B, int N, int k, int topk, int n_anchors, int k_dist) {
+    if (B < 1 || N < 2 || k < 1 || topk < 1 || n_anchors < 0 || (n_anchors > 0 && k_dist < 1)) return 0;
+    Arena ar(nullptr, 0);
+    CritWs w;
+    carve(ar, Dims{2 * B, N, N, k, topk, n_anchors, k_dist, true}, w);
+    return ar.off;
+}
+
+DVM_EXPORT int dvm_criterion_train_fwd_f32(const float *feat, const float *verts, const int32_t *nodes_idx, const int32_t *ring,
+                                           const int32_t *infl_idx, const float *weights, const int32_t *knn_idx, int B, int N, int C, int k,
+                                           int topk, float neg_alpha, const float *const *params, int nparams, int with_map, const float *dist1,
+                                           const float *dist2, const int32_t *anchors1, const int32_t *anchors2, int n_anchors, int k_dist,
+                                           float *terms, void *arena, size_t arena_bytes, void *stream) {
+    const char *who = "dvm_criterion_train_fwd_f32";
+    DVM_REQUIRE(feat && verts && nodes_idx && ring && infl_idx && weights && knn_idx && terms, "%s: null pointer", who);
+    CT_TRY(check_common(who, 2 * B, N, N, true, C, k, topk, (const void *const *)params, nparams));
+    CT_TRY(check_dist(who, N, dist1, dist2, anchors1, anchors2, n_anchors, k_dist));
+    DVM_REQUIRE(neg_alpha < 0.f, "%s: neg_alpha must be negative", who);
+    const Sides io{feat, verts, nodes_idx, ring, infl_idx, weights, knn_idx, nullptr, nullptr, nullptr};
+    CT_TRY(crit_fwd(who, Dims{2 * B, N, N, k, topk, n_anchors, k_dist, true}, io, DistIn{dist1, dist2, anchors1, anchors2}, neg_alpha, params, with_map,
+                    terms, arena, arena_bytes, (hipStream_t)stream));
+    DVM_CHECK_LAUNCH("criterion_train_fwd");
+    return DVM_OK;
+}
+
+DVM_EXPORT int dvm_criterion_train_bwd_f32(const float *g_terms, const float *feat, const float *verts, const int32_t *nodes_idx,
+                                           const int32_t *ring, const int32_t *infl_idx, const float *weights, const int32_t *knn_idx, int B,
+                                           int N, int C, int k, int topk, float neg_alpha, const float *const *params, float *const *grads,
+                                           int nparams, int with_map, const int32_t *anchors1, const int32_t *anchors2, int n_anchors, int k_dist,
+                                           float *d_feat, void *arena, size_t arena_bytes, void *stream) {
+    const char *who = "dvm_criterion_train_bwd_f32";
+    DVM_REQUIRE(g_terms && feat && verts && nodes_idx && ring && infl_idx && weights && knn_idx && d_feat && grads, "%s: null pointer", who);
+    CT_TRY(check_common(who, 2 * B, N, N, true, C, k, topk, (const void *const *)params, nparams));
+    DVM_REQUIRE(n_anchors == 0 || (anchors1 && anchors2 && n_anchors <= N && k_dist >= 1 && k_dist <= 512),
+                "%s: the dist term needs both anchor lists (anchors %d, neighbours %d)", who, n_anchors, k_dist);
+    for (int i = 0; i < PW_N; ++i) DVM_REQUIRE(grads[i] != nullptr, "%s: gradient buffer %d is null", who, i);
+    const Sides io{feat, verts, nodes_idx, ring, infl_idx, weights, knn_idx, nullptr, nullptr, nullptr};
+    CT_TRY(crit_bwd(who, Dims{2 * B, N, N, k, topk, n_anchors, k_dist, true}, io, DistIn{nullptr, nullptr, anchors1, anchors2}, g_terms, neg_alpha, params,
+                    grads, with_map, d_feat, nullptr, arena, arena_bytes, (hipStream_t)stream));
     DVM_CHECK_LAUNCH("criterion_train_bwd");
+    return DVM_OK;
+}
+
+// ONE direction of deform() for P pairs with sources of N and targets of M points (the partial-shape configs: models/loss.py:986-1073,
+// train_partial.py:93-112): the same passes with the targets handed in by the caller and their own pooling / reversed lists.
+DVM_EXPORT size_t dvm_criterion_dir_train_workspace_bytes(int P, int N, int M, int k, int topk) {
+    if (P < 1 || N < 2 || M < 2 || k < 1 || topk < 1) return 0;
+    Arena ar(nullptr, 0);
+    CritWs w;
+    carve(ar, Dims{P, N, M, k, topk, 0, 0, false}, w);
+    return ar.off;
+}
+
+DVM_EXPORT int dvm_criterion_dir_train_fwd_f32(const float *feat_s, const float *feat_t, const float *verts_s, const float *verts_t,
+                                               const int32_t *nodes_idx, const int32_t *ring, const int32_t *infl_idx, const float *weights,
+                                               const int32_t *knn_s, const int32_t *knn_t, int P, int N, int M, int C, int k, int topk,
+                                               float neg_alpha, const float *const *params, int nparams, int with_map, float *terms, void *arena,
+                                               size_t arena_bytes, void *stream) {
+    const char *who = "dvm_criterion_dir_train_fwd_f32";
+    DVM_REQUIRE(feat_s && feat_t && verts_s && verts_t && nodes_idx && ring && infl_idx && weights && knn_s && knn_t && terms, "%s: null pointer", who);
+    CT_TRY(check_common(who, P, N, M, false, C, k, topk, (const void *const *)params, nparams));
+    DVM_REQUIRE(neg_alpha < 0.f, "%s: neg_alpha must be negative", who);
+    const Sides io{feat_s, verts_s, nodes_idx, ring, infl_idx, weights, knn_s, feat_t, verts_t, knn_t};
+    CT_TRY(crit_fwd(who, Dims{P, N, M, k, topk, 0, 0, false}, io, DistIn{nullptr, nullptr, nullptr, nullptr}, neg_alpha, params, with_map, terms, arena,
+                    arena_bytes, (hipStream_t)stream));
+    DVM_CHECK_LAUNCH("criterion_dir_train_fwd");
+    return DVM_OK;
+}
+
+DVM_EXPORT int dvm_criterion_dir_train_bwd_f32(const float *g_terms, const float *feat_s, const float *feat_t, const float *verts_s,
+                                               const float *verts_t, const int32_t *nodes_idx, const int32_t *ring, const int32_t *infl_idx,
+                                               const float *weights, const int32_t *knn_s, const int32_t *knn_t, int P, int N, int M, int C, int k,
+                                               int topk, float neg_alpha, const float *const *params, float *const *grads, int nparams, int with_map,
+                                               float *d_feat_s, float *d_feat_t, void *arena, size_t arena_bytes, void *stream) {
+    const char *who = "dvm_criterion_dir_train_bwd_f32";
+    DVM_REQUIRE(g_terms && feat_s && feat_t && verts_s && verts_t && nodes_idx && ring && infl_idx && weights && knn_s && knn_t && d_feat_s && d_feat_t && grads,
+                "%s: null pointer", who);
+    CT_TRY(check_common(who, P, N, M, false, C, k, topk, (const void *const *)params, nparams));
+    for (int i = 0; i < PW_N; ++i) DVM_REQUIRE(grads[i] != nullptr, "%s: gradient buffer %d is null", who, i);
+    const Sides io{feat_s, verts_s, nodes_idx, ring, infl_idx, weights, knn_s, feat_t, verts_t, knn_t};
+    CT_TRY(crit_bwd(who, Dims{P, N, M, k, topk, 0, 0, false}, io, DistIn{nullptr, nullptr, nullptr, nullptr}, g_terms, neg_alpha, params, grads, with_map,
+                    d_feat_s, d_feat_t, arena, arena_bytes, (hipStream_t)stream));
+    DVM_CHECK_LAUNCH("criterion_dir_train_bwd");
     return DVM_OK;
 }

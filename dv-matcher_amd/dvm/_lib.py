@@ -77,6 +77,11 @@ SIGNATURES = {
                                             c_int, _P, _P, c_size_t, _P]),
     "dvm_criterion_train_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, c_int, c_int, _P, _P, c_int,
                                             c_int, _P, _P, c_size_t, _P]),
+    "dvm_criterion_dir_train_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "dvm_criterion_dir_train_fwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, c_int, c_int, _P,
+                                                _P, c_size_t, _P]),
+    "dvm_criterion_dir_train_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, c_int,
+                                                c_int, _P, _P, _P, c_size_t, _P]),
     "dvm_linear_wgrad_workspace_bytes": (c_size_t, [ctypes.c_long, c_int, c_int]),
     "dvm_linear_wgrad_ws_f32": (c_int, [_P, _P, ctypes.c_long, c_int, c_int, _P, _P, c_size_t, _P]),
     "dvm_set_deterministic": (c_int, [c_int]),

@@ -259,18 +259,7 @@ class _CriterionTrain(torch.autograd.Function):
         verts, g, knn_idx, alpha, topk, with_map, dist = ctx.meta
         (feat,) = ctx.saved_tensors
         trainable = ctx.trainable
-        need = ctx.needs_input_grad[2:]
-        bufs = [_grad_buffer(p) if n else None for p, n in zip(trainable, need)]
-        if all(need) and all(b is not None for b in bufs):   # the kernels add into the parameters' existing .grad buffers
-            grads, out = bufs, [None] * len(trainable)
-        else:                                                # one zeroed flat buffer; autograd accumulates its views into .grad
-            sizes = [p.numel() for p in trainable]
-            flat = torch.zeros(sum(sizes), dtype=torch.float32, device=feat.device)
-            grads, off = [], 0
-            for p, n in zip(trainable, sizes):
-                grads.append(flat[off:off + n])
-                off += n
-            out = [gr.view_as(p) if nd else None for gr, p, nd in zip(grads, trainable, need)]
+        grads, out = _param_grad_targets(trainable, ctx.needs_input_grad[2:], feat.device)
         d_feat = ops.criterion_train_backward([p.detach() for p in trainable], grads, g_terms.contiguous(), feat, verts, g, knn_idx, alpha,
                                               ctx.arena, topk, with_map, dist)
         ctx.arena = None
@@ -279,6 +268,53 @@ class _CriterionTrain(torch.autograd.Function):
 
 def criterion_train(meta, feat, trainable):
     return _CriterionTrain.apply(meta, feat, *trainable)
+
+
+def _param_grad_targets(trainable, need, device):
+    """Where a native node adds its parameter gradients: the parameters' existing .grad buffers (-> autograd gets None), else views of one
+    zeroed flat buffer (-> autograd accumulates them).  -> (buffers for the node, what backward returns)."""
+    bufs = [_grad_buffer(p) if n else None for p, n in zip(trainable, need)]
+    if all(need) and all(b is not None for b in bufs):
+        return bufs, [None] * len(trainable)
+    sizes = [p.numel() for p in trainable]
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=device)
+    grads, off = [], 0
+    for n in sizes:
+        grads.append(flat[off:off + n])
+        off += n
+    return grads, [gr.view_as(p) if nd else None for gr, p, nd in zip(grads, trainable, need)]
+
+
+class _CriterionDirTrain(torch.autograd.Function):
+    """ONE direction of deform() for P pairs with N source and M target points as one native node (dvm_criterion_dir_train_{fwd,bwd}_f32):
+    the partial-shape configs, whose two directions have different shapes.  meta = (verts_s, verts_t, source graph dict, knn_s, knn_t,
+    alpha, topk, with_map); inputs feat_s (P,N,128), feat_t (P,M,128), the Deformer's 10 tensors.  -> terms (P,7)."""
+
+    @staticmethod
+    def forward(ctx, meta, feat_s, feat_t, *trainable):
+        verts_s, verts_t, g, knn_s, knn_t, alpha, topk, with_map = meta
+        terms, arena = ops.criterion_dir_train_forward([p.detach() for p in trainable], feat_s, feat_t, verts_s, verts_t, g, knn_s, knn_t, alpha, topk,
+                                                       with_map)
+        ctx.meta, ctx.arena, ctx.trainable = meta, arena, trainable
+        ctx.save_for_backward(feat_s, feat_t)
+        return terms
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_terms):
+        if ctx.arena is None:
+            raise RuntimeError("dvm criterion training node: backward ran already (its arena is released after the first pass)")
+        verts_s, verts_t, g, knn_s, knn_t, alpha, topk, with_map = ctx.meta
+        feat_s, feat_t = ctx.saved_tensors
+        grads, out = _param_grad_targets(ctx.trainable, ctx.needs_input_grad[3:], feat_s.device)
+        d_s, d_t = ops.criterion_dir_train_backward([p.detach() for p in ctx.trainable], grads, g_terms.contiguous(), feat_s.contiguous(),
+                                                    feat_t.contiguous(), verts_s, verts_t, g, knn_s, knn_t, alpha, ctx.arena, topk, with_map)
+        ctx.arena = None
+        return (None, d_s if ctx.needs_input_grad[1] else None, d_t if ctx.needs_input_grad[2] else None) + tuple(out)
+
+
+def criterion_dir_train(meta, feat_s, feat_t, trainable):
+    return _CriterionDirTrain.apply(meta, feat_s, feat_t, *trainable)
 
 
 def uni3fc_train(meta, x, dino, trainable):

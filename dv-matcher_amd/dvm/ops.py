@@ -1006,6 +1006,42 @@ def criterion_train_backward(params, grads, g_terms, feat, verts, g, knn_idx, al
     return d_feat
 
 
+def criterion_dir_train_forward(params, feat_s, feat_t, verts_s, verts_t, g, knn_s, knn_t, alpha, topk=10, with_map=False):
+    """ONE direction of the training criterion's deformation part for P pairs with N source and M target points
+    (dvm_criterion_dir_train_fwd_f32): g = the SOURCES' graph dict, knn_s (P,N,k) / knn_t (P,M,k) the xyz-kNN of both sides.
+    -> terms (P,7), arena."""
+    _need_gpu(feat_s, feat_t)
+    feat_s, feat_t, verts_s, verts_t = _f(feat_s), _f(feat_t), _f(verts_s), _f(verts_t)
+    P, N, C = feat_s.shape
+    M, k = feat_t.shape[1], knn_s.shape[-1]
+    lib = _lib.load()
+    terms = torch.empty(P, 7, dtype=torch.float32, device=feat_s.device)
+    nb = lib.dvm_criterion_dir_train_workspace_bytes(P, N, M, k, topk)
+    arena = torch.empty(nb, dtype=torch.uint8, device=feat_s.device)
+    table = _ptr_table(params, CRIT_TRAIN_NPARAMS)
+    check(lib.dvm_criterion_dir_train_fwd_f32(_p(feat_s), _p(feat_t), _p(verts_s), _p(verts_t), _p(g["nodes_idx"]), _p(g["one_ring"]), _p(g["infl_idx"]),
+                                              _p(g["weights"]), _p(knn_s), _p(knn_t), P, N, M, C, k, topk, neg_alpha_f32(alpha),
+                                              ctypes.cast(table, ctypes.c_void_p), CRIT_TRAIN_NPARAMS, 1 if with_map else 0, _p(terms), _p(arena), nb,
+                                              _stream()), "dvm_criterion_dir_train_fwd_f32")
+    return terms, arena
+
+
+def criterion_dir_train_backward(params, grads, g_terms, feat_s, feat_t, verts_s, verts_t, g, knn_s, knn_t, alpha, arena, topk=10, with_map=False):
+    """dvm_criterion_dir_train_bwd_f32: -> (d_feat_s (P,N,128), d_feat_t (P,M,128)); parameter gradients ADDED into `grads`."""
+    _need_gpu(feat_s, g_terms)
+    P, N, C = feat_s.shape
+    M, k = feat_t.shape[1], knn_s.shape[-1]
+    lib = _lib.load()
+    d_s, d_t = torch.empty_like(feat_s), torch.empty_like(feat_t)
+    ptab, gtab = _ptr_table(params, CRIT_TRAIN_NPARAMS), _ptr_table(grads, CRIT_TRAIN_NPARAMS)
+    check(lib.dvm_criterion_dir_train_bwd_f32(_p(_f(g_terms)), _p(feat_s), _p(feat_t), _p(verts_s), _p(verts_t), _p(g["nodes_idx"]), _p(g["one_ring"]),
+                                              _p(g["infl_idx"]), _p(g["weights"]), _p(knn_s), _p(knn_t), P, N, M, C, k, topk, neg_alpha_f32(alpha),
+                                              ctypes.cast(ptab, ctypes.c_void_p), ctypes.cast(gtab, ctypes.c_void_p), CRIT_TRAIN_NPARAMS,
+                                              1 if with_map else 0, _p(d_s), _p(d_t), _p(arena), arena.numel(), _stream()),
+          "dvm_criterion_dir_train_bwd_f32")
+    return d_s, d_t
+
+
 def uni3fc_train_running_stats(params, arena, B, N, k, momentum, groups=1):
     """The 26 running-statistics updates of a forward that ran with defer_stats=True (dvm_uni3fc_train_running_stats_f32), on the
     current stream."""

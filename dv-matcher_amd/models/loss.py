@@ -211,6 +211,24 @@ class GraphDeformLoss_Neural(nn.Module):
         """deform() with autograd (models/loss.py:1228-1296).  per_pair: Chamfer terms as (B,2) per-pair side means and ARAP as (B,)
         instead of batch scalars (for a caller that has merged several calls into one batch)."""
         B, N, _ = verts1.shape
+        M = verts2.shape[1]
+        if (self.native_train and not per_pair and not self.dump and self.w_rank <= 0 and feat1.is_cuda and feat1.dtype == torch.float32
+                and feat2.dtype == torch.float32 and feat1.shape[-1] == 128 and 64 <= N <= 8192 and 64 <= M <= 8192 and self.k_deform <= 16
+                and idx11.shape[-1] == self.k_deform and all(torch.is_tensor(g1[k]) for k in ("nodes_idx", "one_ring", "infl_idx", "weights"))
+                and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in deformer.parameters())):
+            # this direction as ONE native autograd node (sources of N, targets of M points: the partial-shape configs, whose directions
+            # cannot be merged); the reductions below are those of the per-op path, on the node's table of per-pair terms
+            from dvm.ops import DEFORMER_KEYS
+            named = dict(deformer.named_parameters())
+            with_map = self.w_map > 0 and not self.partial_variant
+            meta = (verts1, verts2, {k: g1[k] for k in ("nodes_idx", "one_ring", "infl_idx", "weights")}, idx11, idx22, alpha, 10, with_map)
+            terms = nn_ops.criterion_dir_train(meta, feat1, feat2, [named[k] for k in DEFORMER_KEYS])
+            tm = terms.mean(0)
+            if self.partial_variant:   # one-sided Chamfer: the smaller cloud's side (models/loss.py:875-880)
+                cd_warp, cd_self = (tm[1], tm[3]) if N <= M else (tm[2], tm[4])
+            else:
+                cd_warp, cd_self = tm[1] + tm[2], tm[3] + tm[4]
+            return (terms[:, 0] if with_map else None), cd_warp, terms[:, 5].sum(), cd_self, None
         pval, pidx = nn_ops.softcorr_topk(feat1, feat2, alpha, 10)
         verts12 = nn_ops.sparse_apply(pval, pidx, verts2)
         g1p = nn_ops.pool_rows(feat1, idx11, deformer.conv_layer.weight, deformer.conv_layer.bias)

@@ -615,6 +615,23 @@ int dvm_criterion_train_bwd_f32(const float *g_terms, const float *feat, const f
                                 int nparams, int with_map, const int32_t *anchors1, const int32_t *anchors2, int n_anchors, int k_dist,
                                 float *d_feat, void *arena, size_t arena_bytes, void *stream);
 
+/* The same node for ONE direction of deform() with sources of N and targets of M points (the partial-shape configs:
+ * GraphDeformLoss_Neural_Partial, models/loss.py:986-1073; train_partial.py:93-112): P pairs, feat_s [P][N][128] / verts_s [P][N][3] /
+ * knn_s [P][N][k] and the graph of the SOURCES, feat_t [P][M][128] / verts_t [P][M][3] / knn_t [P][M][k] of the targets.
+ * -> terms [P][7] as above (column 6 = 0: the dist term stays with the caller); bwd -> d_feat_s [P][N][128], d_feat_t [P][M][128]
+ * (overwritten), parameter gradients ADDED.  N, M in 64..8192 (any parity). */
+size_t dvm_criterion_dir_train_workspace_bytes(int P, int N, int M, int k, int topk);
+int dvm_criterion_dir_train_fwd_f32(const float *feat_s, const float *feat_t, const float *verts_s, const float *verts_t,
+                                    const int32_t *nodes_idx, const int32_t *ring, const int32_t *infl_idx, const float *weights,
+                                    const int32_t *knn_s, const int32_t *knn_t, int P, int N, int M, int C, int k, int topk,
+                                    float neg_alpha, const float *const *params, int nparams, int with_map, float *terms, void *arena,
+                                    size_t arena_bytes, void *stream);
+int dvm_criterion_dir_train_bwd_f32(const float *g_terms, const float *feat_s, const float *feat_t, const float *verts_s,
+                                    const float *verts_t, const int32_t *nodes_idx, const int32_t *ring, const int32_t *infl_idx,
+                                    const float *weights, const int32_t *knn_s, const int32_t *knn_t, int P, int N, int M, int C, int k,
+                                    int topk, float neg_alpha, const float *const *params, float *const *grads, int nparams, int with_map,
+                                    float *d_feat_s, float *d_feat_t, void *arena, size_t arena_bytes, void *stream);
+
 /* dvm_pair_fwd_f32 can run its coordinate-only chain (FPS, graph, xyz kNN: latency-bound) on helper streams, forked
  * from and joined back into `stream` by events, next to the feature-only soft-correspondence chain.  The helper streams
  * and events are NOT created by the compute call: dvm_pair_init(stream) makes them for (current device, `stream`) —

@@ -100,6 +100,44 @@ def test_native_criterion_full_size_runs_on_the_native_node_and_frozen_deformer(
     assert all(p.grad is None for p in d2.parameters()) and torch.isfinite(featj.grad).all()
 
 
+@pytest.mark.parametrize("partial", [True, False], ids=["partial", "full"])
+@pytest.mark.parametrize("N,M", [(301, 212), (128, 515)])
+def test_directional_node_equals_autograd_path(partial, N, M):
+    """N != M (the partial-shape configs, train_partial.py:93-112): each direction is its own native node
+    (dvm_criterion_dir_train_{fwd,bwd}_f32) with the targets' own pooling and reversed lists; losses and gradients of both feature
+    tensors and of the Deformer against the per-op autograd path."""
+    import models.loss as ml
+    import models.model as mm
+    B = 2
+    g = torch.Generator().manual_seed(N * 7 + M)
+    v1 = (torch.rand(B, N, 3, generator=g) - 0.5).cuda()
+    v2 = (torch.rand(B, M, 3, generator=g) - 0.5).cuda()
+    f1 = (0.3 * torch.relu(torch.randn(B, N, 128, generator=g))).cuda().requires_grad_(True)
+    f2 = (0.3 * torch.relu(torch.randn(B, M, 128, generator=g))).cuda().requires_grad_(True)
+    torch.manual_seed(11)
+    d = mm.Deformer(10).cuda().train()
+    cls = ml.GraphDeformLoss_Neural_Partial if partial else ml.GraphDeformLoss_Neural
+    crit = cls(k_deform=10, w_dist=0.02, w_map=0.005, k_dist=40, N_dist=30, partial=partial, w_deform=0.5, w_img=0, w_rank=0, w_self_rec=0.5, w_cd=0.1,
+               w_arap=0.01, save_name="t")
+    starts = (torch.randint(0, N, (B,), generator=g), torch.randint(0, M, (B,), generator=g))
+    anchors = (random.Random(1).sample(range(N), 30), random.Random(2).sample(range(M), 30))
+    res = []
+    for native in (True, False):
+        crit.native_train = native
+        d.zero_grad(set_to_none=True)
+        f1.grad = f2.grad = None
+        random.seed(5)
+        out = crit(f1, f2, torch.cdist(v1, v1), torch.cdist(v2, v2), v1, v2, 45.0, d, fps_starts=starts, anchors=anchors)
+        out[0].backward()
+        res.append(([float(o) for o in out], f1.grad.clone(), f2.grad.clone(), {k: p.grad.clone() for k, p in d.named_parameters()}))
+    (ln, g1n, g2n, gdn), (la, g1a, g2a, gda) = res
+    for x, y in zip(ln, la):
+        assert abs(x - y) <= 2e-5 * max(abs(y), 1e-3), (ln, la)
+    assert _rel(g1n, g1a) <= 2e-3 and _rel(g2n, g2a) <= 2e-3, (_rel(g1n, g1a), _rel(g2n, g2a))
+    for k in gda:
+        assert _rel(gdn[k], gda[k]) <= 2e-3, (k, _rel(gdn[k], gda[k]))
+
+
 def test_native_criterion_second_backward_is_refused():
     crit, d, featj, v1, v2, starts, anchors = _setup(1, 128, 3)
     crit.native_train = True
