@@ -45,19 +45,10 @@ for p in (ROOT, os.path.join(ROOT, "dv-matcher_amd")):
         sys.path.insert(0, p)
 
 N_PTS, M_PTS, DIM, ALPHA = 2048, 2048, 128, 100.0
-PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense f16 / bf16 matrix peak (same guide)
 PEAK_HBM_GBS = 8000.0          # HBM3E peak (same guide; 6.3 TB/s achievable)
 CHECK_PAIRS = 4
-TRAFFIC_FILE = "r5_k1_traffic.json"   # PMC passes of this round's dominant kernel (tools/k1_traffic.py)
-
-
-def k1_products(kernel_name):
-    """fp16 products of the N x M contraction that pass A PERFORMS per direction: the coarse screen runs the hh product alone, the
-    first form the three products hh + hm + mh of the exact 2-way split.  A routed launch prices the kernel the probe sends the
-    bench's inputs to (random features at alpha 100: the coarse screen — checked by tests/test_gpu_parity.py::test_softcorr_probe_routes);
-    the others return at once."""
-    return 1 if "softcorr_coarse_kernel" in kernel_name else 3
+TRAFFIC_FILE = "r6_k1_traffic.json"   # PMC passes of this round's dominant kernel (tools/k1_traffic.py)
 
 
 def parse_args(argv=None):
@@ -71,11 +62,16 @@ def parse_args(argv=None):
                     help="pair: configs[1] (default); train: configs[2] training step B=8/GPU N=2048; partial: configs[3] "
                          "training step B=2/GPU 4995 x 2200")
     ap.add_argument("--cpu-sample", type=int, default=48, help="pairs timed for cpu_baseline (0 = skip; rank 0 at N = 1 only)")
-    ap.add_argument("--no-check", action="store_true", help="skip the oracle check of 4 pairs of the timed batch")
+    ap.add_argument("--no-check", action="store_true", help="skip the oracle check of 4 pairs of the timed batches")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="time the one-call form (dvm_pair_fwd_f32 on ONE resident batch, rounds 1-5) instead of the two-stage "
+                         "pipeline over two alternating batches")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo for the "
                     "two-ranks-on-one-GPU test of this script)")
+    ap.add_argument("--dist-always", action="store_true", help="initialise the process group at world size 1 too (runs the RCCL "
+                    "branch on a 1-GPU box; tests/test_gpu_ddp.py)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
-                    help="per-launch HBM bytes of the dominant kernel from the PMC passes (default: profiles/r5_k1_traffic.json, "
+                    help="per-launch HBM bytes of the dominant kernel from the PMC passes (default: profiles/r6_k1_traffic.json, "
                          "used only if it was taken on this kernel source, for the kernel the timed launches ran, at this --pairs)")
     return ap.parse_args(argv)
 
@@ -173,34 +169,36 @@ def checked_pair_ids(P, n, seed=20260):
     return sorted(random.Random(seed + P).sample(range(P), min(n, P)))
 
 
-def oracle_legs(batch, out12, out21, sample_pairs, check_pairs):
-    """The CPU oracle (oracle/dvm_oracle.c, test infrastructure) on pairs of the batch that was timed: `check_pairs`
-    seeded-random pairs are compared with the GPU outputs; the cpu_baseline is timed on those plus the first pairs of the
+def oracle_legs(timed, sample_pairs, check_pairs):
+    """The CPU oracle (oracle/dvm_oracle.c, test infrastructure) on pairs of the batches that were timed.  `timed` = [(batch, out12,
+    out21), ...] (two entries for the pipelined form): `check_pairs` seeded-random pairs, dealt round-robin over the batches, are
+    compared with the GPU outputs of the timed region; the cpu_baseline is timed on those plus the first pairs of the first
     batch up to `sample_pairs` in all."""
     import numpy as np
     from oracle import oracle as O
     O.lib()
     w = load_weights()
-    P = batch[0].shape[0]
-    ids = checked_pair_ids(P, check_pairs) if check_pairs > 0 else []
-    ids += [p for p in range(P) if p not in ids][:max(0, sample_pairs - len(ids))]
-    host = {p: [t[p].cpu().numpy() for t in batch] for p in ids}
+    P = timed[0][0][0].shape[0]
+    ids = [(n % len(timed), p) for n, p in enumerate(checked_pair_ids(P, check_pairs))] if check_pairs > 0 else []
+    ids += [(0, p) for p in range(P) if (0, p) not in ids][:max(0, sample_pairs - len(ids))]
+    host = {bp: [t[bp[1]].cpu().numpy() for t in timed[bp[0]][0]] for bp in ids}
     f1, f2, v1, v2, _, _ = host[ids[0]]
     O.pair_direction(w, f1[:256], f2[:256], v1[:256], v2[:256], ALPHA, 0)  # warm the thread pool
-    check = {"T_exact": True, "max_abs_warped": 0.0, "max_abs_verts12": 0.0, "max_rel_losses": 0.0, "pairs": ids[:check_pairs]}
+    check = {"T_exact": True, "max_abs_warped": 0.0, "max_abs_verts12": 0.0, "max_rel_losses": 0.0,
+             "pairs": [{"batch": b, "pair": p} for b, p in ids[:check_pairs]]}
     kept = []
     dt = None
     t0 = time.perf_counter()
-    for n, p in enumerate(ids):
-        f1, f2, v1, v2, s1, s2 = host[p]
+    for n, bp in enumerate(ids):
+        f1, f2, v1, v2, s1, s2 = host[bp]
         o12 = O.pair_direction(w, f1, f2, v1, v2, ALPHA, int(s1))
         o21 = O.pair_direction(w, f2, f1, v2, v1, ALPHA, int(s2))
         if n == sample_pairs - 1:
             dt = time.perf_counter() - t0
         if n < check_pairs:
-            kept.append((p, o12, o21))
-    for p, o12, o21 in kept:
-        for o, g in ((o12, out12), (o21, out21)):
+            kept.append((bp, o12, o21))
+    for (b, p), o12, o21 in kept:
+        for o, g in ((o12, timed[b][1]), (o21, timed[b][2])):
             check["T_exact"] = check["T_exact"] and bool(np.array_equal(g["T12"][p].cpu().numpy(), o["T12"]))
             check["max_abs_warped"] = max(check["max_abs_warped"], float(np.abs(g["warped"][p].cpu().numpy() - o["warped"]).max()))
             check["max_abs_verts12"] = max(check["max_abs_verts12"], float(np.abs(g["verts12"][p].cpu().numpy() - o["verts12"]).max()))
@@ -213,9 +211,9 @@ def oracle_legs(batch, out12, out21, sample_pairs, check_pairs):
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         omp = int(os.environ.get("OMP_NUM_THREADS", cores))
         cpu = {"value": sample_pairs / dt, "unit": "pairs/s", "cores": min(cores, omp), "kind": "port",
-               "sample": "%d pairs of the timed batch (the %d checked ones + the first %d; N=M=%d, d=%d, both directions), C oracle "
-                         "with OpenMP (%.1f s)" % (sample_pairs, min(check_pairs, sample_pairs), max(0, sample_pairs - check_pairs),
-                                                   N_PTS, DIM, dt)}
+               "sample": "%d pairs of the timed batches (the %d checked ones + the first %d; N=M=%d, d=%d, both directions), C oracle "
+                         "with OpenMP: a scalar k-ordered fmaf chain per distance, the arithmetic the parity tests pin (%.1f s)"
+                         % (sample_pairs, min(check_pairs, sample_pairs), max(0, sample_pairs - check_pairs), N_PTS, DIM, dt)}
     return check, cpu
 
 
@@ -232,7 +230,7 @@ def k1_sources_sha16():
 
 
 def load_traffic(P, kernel_name):
-    """(bytes per launch or None, provenance dict) from profiles/r5_k1_traffic.json."""
+    """(bytes per launch or None, provenance dict) from profiles/r6_k1_traffic.json."""
     tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
     if not os.path.exists(tpath):
         return None, {"file": None, "why_null": "no traffic file for this round"}
@@ -248,6 +246,18 @@ def load_traffic(P, kernel_name):
     else:
         return tj.get("bytes_per_launch"), prov
     return None, prov
+
+
+def load_pmc(P, kernel_name):
+    """The SQ / TCC figures of the dominant kernel from profiles/r6_k1_traffic.json (tools/k1_traffic.py), under the same
+    provenance rule as `traffic`: {} unless measured on this kernel source, for this kernel, at this --pairs."""
+    tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
+    if not os.path.exists(tpath):
+        return {}
+    tj = json.load(open(tpath))
+    if tj.get("pairs") != P or tj.get("kernel_slot_name") != kernel_name or tj.get("source_sha16") != k1_sources_sha16():
+        return {}
+    return {k: tj.get(k) for k in ("mfma_busy", "valu_per_mfma", "l2_hit_rate", "algorithmic_bytes_per_launch")}
 
 
 def kernel_models(P):
@@ -286,9 +296,9 @@ def run_pair(args):
     local = local % torch.cuda.device_count()  # (more ranks than devices only happens in the gloo test)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    # DVM_DIST_ALWAYS=1: initialise the process group (and run the barriers / the MAX all-reduce) even at world size 1, so
+    # --dist-always: initialise the process group (and run the barriers / the MAX all-reduce) even at world size 1, so
     # that the RCCL branch of this script executes on a 1-GPU box (tests/test_gpu_ddp.py) and not first on the 8-GPU node
-    dist_on = world > 1 or os.environ.get("DVM_DIST_ALWAYS", "0") == "1"
+    dist_on = world > 1 or args.dist_always
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:
@@ -319,13 +329,38 @@ def run_pair(args):
         outs = ops.pair_forward(wl, f1, f2, v1, v2, ALPHA, s1, s2, with_map=True, out=outs)
         out12, out21 = outs
 
+    # The timed form: a two-stage pipeline over TWO alternating resident batches (ops.PairPipeline).  Step t enqueues the
+    # coordinate-only geometry of batch t + 1 (dvm_pair_geometry_f32: FPS -> node grid -> ring -> influence, vertex grid, xyz kNN)
+    # on its own stream and runs the feature-dependent half of batch t (dvm_pair_fwd_cached_f32, reuse_geometry = 1) on the main
+    # stream.  Every step builds the graphs of one batch and consumes the graphs of one batch — nothing is cached (the two batches
+    # have different coordinates, and each workspace is rewritten every other step); K timed steps contain K geometry builds and
+    # K feature halves.  `--no-pipeline` times the one-call form of rounds 1-5 on one batch instead; it is also reported below.
+    pipelined = not args.no_pipeline
+    batches = [batch]
+    pouts = [None, None]
+    if pipelined:
+        batches.append(make_batch(P, 5000 + rank, dev))
+        pipe = ops.PairPipeline(wl, P, N_PTS, M_PTS, with_map=True)
+        ticket = pipe.prefetch(*batches[0][2:])
+        tstep = 0
+
+    def pstep():
+        nonlocal ticket, tstep
+        cur, nxt = batches[tstep % 2], batches[(tstep + 1) % 2]
+        nxt_ticket = pipe.prefetch(*nxt[2:])
+        pouts[tstep % 2] = pipe.forward(ticket, cur[0], cur[1], ALPHA, out=pouts[tstep % 2])
+        ticket = nxt_ticket
+        tstep += 1
+
+    timed_step = pstep if pipelined else step
+
     def read_slot(slot):
         ms, nl = ctypes.c_double(), ctypes.c_int()
         ops.check(lib.dvm_profile_read_kernel(slot, ctypes.byref(ms), ctypes.byref(nl)), "dvm_profile_read_kernel")
         return ms.value, nl.value
 
     for _ in range(args.warmup):
-        step()
+        timed_step()
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
@@ -337,13 +372,17 @@ def run_pair(args):
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
-        step()
+        timed_step()
         marks[i + 1].record()
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # which pass-A kernel the last timed launch's (direction, pair) entries went to (the probe and the gate decide on the device)
+    routes = (ctypes.c_int * 5)()
+    ops.check(lib.dvm_k1_last_routes(routes), "dvm_k1_last_routes")
+    routes = dict(zip(("full", "lean", "coarse", "reswept_lean", "entries"), list(routes)))
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     k1_total_ms, k1_launches = read_slot(0)
@@ -369,6 +408,23 @@ def run_pair(args):
     alone_ms, alone_n = read_slot(0)
     lib.dvm_profile_disable()
     lib.dvm_pair_set_overlap(1)
+    # the one-call form of rounds 1-5 (dvm_pair_fwd_f32 on ONE resident batch: geometry and features of the same batch inside one
+    # call, the geometry chain on the call's helper streams), timed over the same number of steps
+    single = None
+    if pipelined:
+        for _ in range(max(1, args.warmup)):
+            step()
+        torch.cuda.synchronize()
+        ts0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        single = time.perf_counter() - ts0
+        if dist_on:
+            t = torch.tensor([single], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            single = float(t.item())
+        pipe_same = all(torch.equal(pouts[0][sd][k], outs[sd][k]) for sd in (0, 1) for k in outs[sd])   # batch 0: both forms, same bits
     # "graph build reported with and without caching".  The timed region above rebuilds both clouds' deformation graphs
     # every step, as the reference does (models/loss.py:1325-1337); here the same steps reuse the graphs / grids / xyz kNN of a
     # first call through the opt-in per-shape cache (dvm_pair_fwd_cached_f32: bit-identical outputs, checked below)
@@ -407,7 +463,12 @@ def run_pair(args):
         k1_alone = alone_ms / max(alone_n, 1)
         flops_launch = P * (2.0 * N_PTS * M_PTS * DIM)   # the distance tile counted once per pair
         tf = lambda ms_: flops_launch / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0  # noqa: E731
-        nprod = k1_products(k1_name)
+        # fp16 products of the N x M contraction pass A PERFORMED per direction, from the routes the library reports for the last
+        # timed launch: coarse screen 1 (hh), first forms 3 (hh + hm + mh); None when the launch was mixed or partly swept twice
+        nprod = (1 if routes["coarse"] == routes["entries"] and routes["reswept_lean"] == 0
+                 else 3 if routes["coarse"] == 0 else None)
+        perf = (lambda ms_: 2.0 * nprod * tf(ms_)) if nprod else (lambda ms_: None)  # noqa: E731
+        frac16 = lambda x: None if x is None else x / PEAK_F16_MFMA_TFLOPS  # noqa: E731
         kernels = []
         for k, (ms_tot, n) in sorted(slots.items()):
             if n == 0:
@@ -423,6 +484,7 @@ def run_pair(args):
             kernels.append({"kernel": lib.dvm_profile_kernel_name(k).decode(), "bound": m["bound"], "achieved": ach, "peak": peak,
                             "unit": unit, "frac": ach / peak, "launch_ms": per_launch, "launches_per_step": n / 3.0,
                             "ms_per_step": per_step, "algorithmic_per_launch": work, "note": m["note"]})
+        pmc = load_pmc(P, k1_name)
         res = {
             "metric": "point-cloud pairs/sec (N=2048, d=128)", "value": value, "unit": "pairs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "median_ms_per_step": median_ms,
@@ -431,47 +493,54 @@ def run_pair(args):
             "config": {"workload": "BASELINE configs[1]: synthetic random pairs N=M=2048 d=128, correspondence+deform "
                                    "forward, both directions", "pairs_per_gpu_per_step": P, "pairs_per_step": pairs_per_step,
                        "alpha": ALPHA, "deformer_weights": "reference ckpt/dvmatcher_scape_r (fixture)", "fps_start": 0,
-                       "parallelism": "pairs sharded over %d GPU(s), no collective" % world},
+                       "parallelism": "pairs sharded over %d GPU(s), no collective" % world,
+                       "schedule": ("two-stage pipeline over 2 alternating resident batches: step t builds the graphs / grids / xyz kNN "
+                                    "of batch t+1 (dvm_pair_geometry_f32, own stream) while it runs the feature-dependent half of batch t "
+                                    "(dvm_pair_fwd_cached_f32); every step builds one batch's graphs and consumes one batch's graphs, "
+                                    "nothing is cached" if pipelined else
+                                    "one call per step on one resident batch (dvm_pair_fwd_f32)")},
             "per_gpu": {"pairs_per_s": value / world, "rank0_ms_per_step": local_dt / args.steps * 1e3},
+            # the one-call form (geometry and features of the SAME batch inside one call; rounds 1-5 timed this)
+            "single_call": (None if single is None else
+                            {"value": pairs_per_step * args.steps / single, "unit": "pairs/s", "ms_per_step": single / args.steps * 1e3,
+                             "bit_identical_to_pipelined": bool(pipe_same)}),
             # the same steps with the per-shape graph cache on (opt-in; NOT `value`: the reference rebuilds the graphs per call)
             "graph_cached": {"value": pairs_per_step * args.steps / dtc, "unit": "pairs/s", "ms_per_step": dtc / args.steps * 1e3,
                              "hits": args.steps, "bit_identical_to_uncached": bool(cached_same),
                              "what": "graphs (FPS nodes, rings, skinning), uniform grids and xyz kNN of both clouds reused from a first "
                                      "call (dvm_pair_fwd_cached_f32); everything feature-dependent recomputed"},
             "process_group": (dist.get_backend() if dist_on else None),
-            # The dominant kernel runs the N x M contraction on the 16-bit matrix pipe.  `achieved` / `peak` / `frac` price the
-            # flops it PERFORMS — `products` fp16 products per direction (coarse screen: hh alone; first form: hh + hm + mh of the
-            # exact 2-way split) x 2 directions of one distance tile, the norm instruction not counted — against the pipe it
-            # runs on (dense f16 peak): the utilisation figure.  `algorithmic` is SURVEY §8d's accounting: 2*N*M*d per pair, the
-            # distance tile counted once, over the same launch time, against the fp32 matrix peak §8d prescribes (a
-            # formulation-independent number: it exceeds what an fp32-MFMA kernel could ever reach).
+            # The dominant kernel runs the N x M contraction on the 16-bit matrix pipe.  ONE denominator: the dense f16 matrix peak.
+            #   achieved / frac      = flops the kernel PERFORMS (`products_per_direction` fp16 products x 2 directions x B*2NMd; the norm
+            #                          instruction not counted) / launch time            -> the pipe's utilisation
+            #   algorithmic_frac_f16 = SURVEY §8d's formulation-independent count (B*2NMd: the distance tile once per pair) / launch time,
+            #                          against the same peak
+            #   mfma_busy, valu_per_mfma, l2_hit_rate, traffic = PMC passes of this kernel (profiles/r6_k1_traffic.json; null unless
+            #                          taken on this kernel source, for this kernel, at this --pairs): why the pipe is not busier
             "roofline": {"bound": "mfma", "kernel": k1_name + " (K1 pass A: the N x M sweep on the f16 matrix pipe; named by the library "
                                                              "from what the timed launches ran)",
-                         "products_per_direction": nprod,
-                         "achieved": 2.0 * nprod * tf(k1_ms), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": 2.0 * nprod * tf(k1_ms) / PEAK_F16_MFMA_TFLOPS, "pipe": "f16 matrix (v_mfma_f32_32x32x16_f16)",
+                         "routes_last_timed_launch": routes, "products_per_direction": nprod,
+                         "achieved": perf(k1_ms), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": frac16(perf(k1_ms)), "pipe": "f16 matrix (v_mfma_f32_32x32x16_f16)",
+                         "algorithmic_flops_per_launch": flops_launch, "algorithmic_frac_f16": frac16(tf(k1_ms)),
                          "traffic": traffic, "traffic_source": traffic_src, "launch_ms": k1_ms, "launches_timed": k1_launches,
-                         "flops_per_launch": 2.0 * nprod * flops_launch,
-                         "algorithmic": {"flops_per_launch": flops_launch, "achieved": tf(k1_ms), "peak": PEAK_F32_MFMA_TFLOPS,
-                                         "frac": tf(k1_ms) / PEAK_F32_MFMA_TFLOPS, "peak_name": "fp32 matrix"},
+                         "flops_per_launch": (2.0 * nprod * flops_launch) if nprod else None,
+                         "mfma_busy": pmc.get("mfma_busy"), "valu_per_mfma": pmc.get("valu_per_mfma"), "l2_hit_rate": pmc.get("l2_hit_rate"),
+                         "algorithmic_bytes_per_launch": pmc.get("algorithmic_bytes_per_launch"),
                          "share_of_step": (k1_total_ms * 1e-3) / local_dt if local_dt > 0 else None,
-                         # in the timed region the sweep shares the CUs with the geometry chain on the helper stream
-                         # (FPS / graph / kNN / pooling), which stretches its launch; alone (overlap off, 3 launches after
-                         # the timed region) it takes `launch_ms` below
-                         "standalone": {"launch_ms": k1_alone, "achieved": 2.0 * nprod * tf(k1_alone),
-                                        "frac": 2.0 * nprod * tf(k1_alone) / PEAK_F16_MFMA_TFLOPS,
-                                        "algorithmic_frac": tf(k1_alone) / PEAK_F32_MFMA_TFLOPS},
-                         "kernels": kernels,
-                         # SURVEY §8d's whole-path count: 2.5 GFLOP of matrix work per pair (both directions' distance tiles,
-                         # Deformer MLP) over the step time, per GPU, against the fp32 matrix peak
-                         "whole_path": {"gflop_per_pair": 2.5, "achieved": 2.5e9 * value / world / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
-                                        "unit": "TFLOP/s", "frac": 2.5e9 * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS}},
+                         # in the timed region the sweep shares the CUs with the geometry chain of the NEXT batch (FPS / graph / kNN)
+                         # and this batch's pooling on the helper streams, which stretches its launch; alone (one-call form, helper
+                         # streams off, 3 launches after the timed region) it takes `launch_ms` below
+                         "standalone": {"launch_ms": k1_alone, "achieved": perf(k1_alone), "frac": frac16(perf(k1_alone)),
+                                        "algorithmic_frac_f16": frac16(tf(k1_alone))},
+                         "kernels": kernels},
         }
         if args.no_check and not (world == 1 and args.cpu_sample > 0):
             res["checked_pairs"], res["check"], res["cpu_baseline"] = 0, None, None
         else:
             ncheck = 0 if args.no_check else min(CHECK_PAIRS, P)
-            check, cpu = oracle_legs(batch, out12, out21, args.cpu_sample if world == 1 else 0, ncheck)
+            timed = [(batches[i], pouts[i][0], pouts[i][1]) for i in range(2)] if pipelined else [(batch, out12, out21)]
+            check, cpu = oracle_legs(timed, args.cpu_sample if world == 1 else 0, ncheck)
             res["checked_pairs"], res["check"], res["cpu_baseline"] = ncheck, (check if ncheck else None), cpu
         print(json.dumps(res))
         if res["check"] is not None and not res["check"]["ok"]:
@@ -495,6 +564,7 @@ def run_train(args):
     per_gpu = 2 if partial else 8
     batch = args.pairs_total if args.pairs_total is not None else per_gpu * world
     argv = ["--steps", str(args.steps), "--warmup", str(args.warmup), "--batch", str(batch), "--backend", args.backend]
+    argv += ["--dist-always"] if args.dist_always else []
     argv += ["--partial", "--points", "4995", "--points-target", "2200"] if partial else ["--points", "2048"]
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):

@@ -77,6 +77,29 @@ static_assert(PW_N == DVM_CRIT_TRAIN_NPARAMS, "parameter table layout and includ
         if (rc_ != DVM_OK) return rc_; \
     } while (0)
 
+// Work forked onto the context's helper stream writes into the caller's arena: the caller's stream must wait for it on EVERY exit path,
+// error returns included (the caller may free or reuse the arena as soon as the call returns).  Armed at the fork, disarmed by the
+// regular join; an early return records a fresh join point behind whatever was enqueued on the helper stream and waits for it.
+struct HelperJoin {
+    PairCtx *cx;
+    hipStream_t s;
+    bool pending = false;
+    HelperJoin(PairCtx *c, hipStream_t st) : cx(c), s(st) {}
+    void fork() {
+        if (!cx) return;
+        (void)hipEventRecord(cx->ev_fork, s);
+        (void)hipStreamWaitEvent(cx->side, cx->ev_fork, 0);
+        pending = true;
+    }
+    void join() {
+        if (!pending) return;
+        (void)hipEventRecord(cx->ev_join, cx->side);
+        (void)hipStreamWaitEvent(s, cx->ev_join, 0);
+        pending = false;
+    }
+    ~HelperJoin() { join(); }
+};
+
 inline unsigned blocks_for(long n, int cap = 8192) { return (unsigned)((n + 255) / 256 < cap ? (n + 255) / 256 : cap); }
 
 // ---------------------------------------------------------------- small kernels
@@ -313,7 +336,9 @@ __global__ __launch_bounds__(256) void dist_combine_rows_kernel(const float *__r
         out[i] = f32x4{c * f.x - g.x, c * f.y - g.y, c * f.z - g.z, c * f.w - g.w};
     }
 }
-// ddist[b][a_n] += rs[b][n] fa[b][n] - C2[b][n]   (the anchors of a shape are distinct points)
+// ddist[b][a_n] += rs[b][n] fa[b][n] - C2[b][n].  The reference draws a shape's anchors with random.sample (distinct points), but
+// the criterion's `anchors=` argument is public: atomic adds, so that a repeated anchor accumulates instead of losing an update
+// (with distinct anchors each location receives exactly one add: same bits as a plain store)
 __global__ __launch_bounds__(256) void dist_combine_anchors_kernel(const float *__restrict__ rs, const f32x4 *__restrict__ fa, const f32x4 *__restrict__ c2,
                                                                    const int32_t *__restrict__ anchors, int N, int nA, f32x4 *__restrict__ out) {
     const int b = blockIdx.y;
@@ -323,9 +348,11 @@ __global__ __launch_bounds__(256) void dist_combine_anchors_kernel(const float *
     const size_t src = ((size_t)b * nA + n) * (CT_C / 4) + c4, dst = ((size_t)b * N + anchors[n]) * (CT_C / 4) + c4;
     const float r = rs[(size_t)b * nA + n];
     const f32x4 f = fa[src], q = c2[src];
-    f32x4 o = out[dst];
-    o.x += r * f.x - q.x, o.y += r * f.y - q.y, o.z += r * f.z - q.z, o.w += r * f.w - q.w;
-    out[dst] = o;
+    float *o = (float *)(out + dst);
+    unsafeAtomicAdd(o + 0, r * f.x - q.x);
+    unsafeAtomicAdd(o + 1, r * f.y - q.y);
+    unsafeAtomicAdd(o + 2, r * f.z - q.z);
+    unsafeAtomicAdd(o + 3, r * f.w - q.w);
 }
 
 // ---------------------------------------------------------------- arena
@@ -469,16 +496,16 @@ int crit_fwd(const char *who, const Dims &d, Sides io, const DistIn &di, float n
     }
     // the dist term of the 2B shapes: independent of the deformation part, on the helper stream of the caller's context (dvm_pair_init)
     PairCtx *cx = d.nA > 0 ? pair_ctx_find(s) : nullptr;
+    HelperJoin hj(cx, s);
     if (d.nA > 0) {
         hipStream_t ds = cx ? cx->side : s;
-        if (cx) (void)hipEventRecord(cx->ev_fork, s), (void)hipStreamWaitEvent(ds, cx->ev_fork, 0);
+        hj.fork();
         for (int side = 0; side < 2; ++side) {
             const size_t so = (size_t)side * B;
             CT_TRY(launch_dist_loss_fwd(io.feat_s + so * N * CT_C, side ? di.dist2 : di.dist1, side ? di.anchors2 : di.anchors1, B, N, CT_C, d.nA, d.kd,
                                         terms + so * CT_TERMS, CT_TERMS, 6, w.didx + so * d.nA * d.kd, w.xsave + so * d.nA * d.kd * 2,
                                         w.fa + so * d.nA * CT_C, w.dws, w.d_bytes, ds));
         }
-        if (cx) (void)hipEventRecord(cx->ev_join, ds);
     } else {
         (void)hipMemsetAsync(w.partial, 0, (size_t)P * sizeof(double), s);
         launch_reduce_partials(w.partial, P, 1, 1.f, terms, CT_TERMS, 6, s);
@@ -525,7 +552,7 @@ int crit_fwd(const char *who, const Dims &d, Sides io, const DistIn &di, float n
         (void)hipMemsetAsync(w.partial, 0, (size_t)P * sizeof(double), s);
         launch_reduce_partials(w.partial, P, 1, 1.f, terms, CT_TERMS, 0, s);
     }
-    if (cx) (void)hipStreamWaitEvent(s, cx->ev_join, 0);
+    hj.join();
     return DVM_OK;
 }
 
@@ -545,9 +572,10 @@ int crit_bwd(const char *who, const Dims &d, Sides io, const DistIn &di, const f
     const dim3 node_grid((unsigned)(((long)Nn * 32 + 255) / 256), P);
     // the dist term's feature gradient (helper stream): W from the kept x, y, then the two products on the library's GEMM kernels
     PairCtx *cx = d.nA > 0 ? pair_ctx_find(s) : nullptr;
+    HelperJoin hj(cx, s);
     if (d.nA > 0) {
         hipStream_t ds = cx ? cx->side : s;
-        if (cx) (void)hipEventRecord(cx->ev_fork, s), (void)hipStreamWaitEvent(ds, cx->ev_fork, 0);
+        hj.fork();
         const int nA = d.nA;
         for (int side = 0; side < 2; ++side) {
             const size_t so = (size_t)side * B;
@@ -565,7 +593,6 @@ int crit_bwd(const char *who, const Dims &d, Sides io, const DistIn &di, const f
             hipLaunchKernelGGL(dist_combine_anchors_kernel, dim3((unsigned)(((long)nA * (CT_C / 4) + 255) / 256), B), dim3(256), 0, ds, w.rs,
                                (const f32x4 *)fa, (const f32x4 *)w.c2, an, N, nA, (f32x4 *)dd);
         }
-        if (cx) (void)hipEventRecord(cx->ev_join, ds);
     }
     // Chamfer side means -> d warped, d verts12 (source side only: the targets are inputs)
     launch_chamfer_bwd_src2(w.warped, w.verts12, io.verts_t, io.verts_t, w.i1w, w.i2w, w.i1s, w.i2s, g_terms, CT_TERMS, 1, 3, P, N, M, w.dwarped, w.dv12, s);
@@ -625,7 +652,7 @@ int crit_bwd(const char *who, const Dims &d, Sides io, const DistIn &di, const f
     hipLaunchKernelGGL(gval_nodes_kernel, dim3((unsigned)(((long)Nn * topk + 255) / 256), P), dim3(256), 0, s, w.dval_n, io.nodes, N, Nn, topk, w.gval);
     CT_TRY(dvm_softcorr_bwd_f32(io.feat_s, io.feat_t, P, N, M, CT_C, neg_alpha, topk, w.pval, w.pidx, w.smax, w.ssum, w.gval, w.df1, w.df2, 0, w.sbws,
                                 w.sb_bytes, s));
-    if (cx) (void)hipStreamWaitEvent(s, cx->ev_join, 0);
+    hj.join();
     if (d.swapped) {
         hipLaunchKernelGGL(combine_feat_kernel, dim3(blocks_for(PN * CT_C / 4)), dim3(256), 0, s, (const f32x4 *)w.df1, (const f32x4 *)w.df2,
                            (const f32x4 *)w.dpool, d.nA > 0 ? (const f32x4 *)w.ddist : (const f32x4 *)nullptr, (long)B * N * CT_C / 4, (f32x4 *)d_feat_s);

@@ -620,13 +620,29 @@ __global__ __launch_bounds__(256) void map_term_kernel(const float *__restrict__
 // of a (point, slot) thread is two LDS reads instead of L2 round trips; no [M][k][3] neighbour table is built (gather_nbr_xyz_kernel
 // and its 250 MB per launch disappear).  The workgroup walks the 256-thread blocks of map_term_kernel four at a time and writes
 // the SAME partial sums in the same slots (a wave's sum, then the block's four waves in order): bit-identical to both older forms.
+// (round 6: blockIdx.y = direction, so that both directions of the pair path are ONE launch — one workgroup per cloud is 64 - 128
+// workgroups on 256 compute units at the small resident batches of a strong-scaling rank)
+struct MapTermSide {
+    const float *verts12, *verts2;
+    const int32_t *idx11, *idx22;
+    const float *pi_val;
+    const int32_t *pi_idx;
+    int N, M, nblk;
+    double *partial;
+};
+struct MapTermArgs {
+    MapTermSide d[2];
+    int k;
+};
 template <int TOPK>
-__global__ __launch_bounds__(1024) void map_term_lds_kernel(const float *__restrict__ verts12, const float *__restrict__ verts2,
-                                                            const int32_t *__restrict__ idx11, const int32_t *__restrict__ idx22,
-                                                            const float *__restrict__ pi_val, const int32_t *__restrict__ pi_idx, int N, int M,
-                                                            int k, int nblk, double *__restrict__ partial) {
+__global__ __launch_bounds__(1024) void map_term_lds_kernel(const MapTermArgs args) {
     extern __shared__ __attribute__((aligned(16))) char mt_lds[];
     __shared__ double red[16];
+    const MapTermSide &A = args.d[blockIdx.y];
+    const float *__restrict__ verts12 = A.verts12, *__restrict__ verts2 = A.verts2, *__restrict__ pi_val = A.pi_val;
+    const int32_t *__restrict__ idx11 = A.idx11, *__restrict__ idx22 = A.idx22, *__restrict__ pi_idx = A.pi_idx;
+    double *__restrict__ partial = A.partial;
+    const int N = A.N, M = A.M, nblk = A.nblk, k = args.k;
     float *v2 = (float *)mt_lds;                                   // [M][3]
     int32_t *i22 = (int32_t *)(mt_lds + (((size_t)M * 3 * sizeof(float) + 15) / 16) * 16);   // [M][k]
     const int b = blockIdx.x;
@@ -1116,8 +1132,25 @@ bool launch_map_term_lds(const float *verts12, const float *verts2, const int32_
     const size_t lds = (((size_t)M * 3 * sizeof(float) + 15) / 16) * 16 + (size_t)M * k * sizeof(int32_t);
     if (topk != 10 || lds > 150 * 1024) return false;
     ensure_dyn_lds((const void *)map_term_lds_kernel<10>, (int)lds);
-    hipLaunchKernelGGL(map_term_lds_kernel<10>, dim3(B), dim3(1024), lds, s, verts12, verts2, idx11, idx22, pi_val, pi_idx, N, M, k,
-                       map_term_blocks(N, k), partial);
+    MapTermArgs a;
+    a.d[0] = a.d[1] = MapTermSide{verts12, verts2, idx11, idx22, pi_val, pi_idx, N, M, map_term_blocks(N, k), partial};
+    a.k = k;
+    hipLaunchKernelGGL(map_term_lds_kernel<10>, dim3(B, 1), dim3(1024), lds, s, a);
+    return true;
+}
+// both directions of B pairs in one launch (direction 0: N sources against M targets; direction 1: the reverse); same partial sums
+bool launch_map_term_lds_pair(const float *verts12, const float *verts21, const float *verts1, const float *verts2, const int32_t *idx11,
+                              const int32_t *idx22, const float *val12, const int32_t *pidx12, const float *val21, const int32_t *pidx21, int B,
+                              int N, int M, int k, int topk, double *partial12, double *partial21, hipStream_t s) {
+    auto need = [&](int m) { return (((size_t)m * 3 * sizeof(float) + 15) / 16) * 16 + (size_t)m * k * sizeof(int32_t); };
+    const size_t lds = need(N) > need(M) ? need(N) : need(M);
+    if (topk != 10 || lds > 150 * 1024) return false;
+    ensure_dyn_lds((const void *)map_term_lds_kernel<10>, (int)lds);
+    MapTermArgs a;
+    a.d[0] = MapTermSide{verts12, verts2, idx11, idx22, val12, pidx12, N, M, map_term_blocks(N, k), partial12};
+    a.d[1] = MapTermSide{verts21, verts1, idx22, idx11, val21, pidx21, M, N, map_term_blocks(M, k), partial21};
+    a.k = k;
+    hipLaunchKernelGGL(map_term_lds_kernel<10>, dim3(B, 2), dim3(1024), lds, s, a);
     return true;
 }
 int launch_map_term(const float *verts12, const float *verts2, const int32_t *idx11, const int32_t *idx22,

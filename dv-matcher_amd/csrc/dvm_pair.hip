@@ -20,6 +20,9 @@ int launch_map_term(const float *verts12, const float *verts2, const int32_t *id
 bool launch_map_term_lds(const float *verts12, const float *verts2, const int32_t *idx11, const int32_t *idx22, const float *pi_val,
                          const int32_t *pi_idx, int B, int N, int M, int k, int topk, double *partial, hipStream_t s);
 bool map_term_lds_applies(int M, int k);
+bool launch_map_term_lds_pair(const float *verts12, const float *verts21, const float *verts1, const float *verts2, const int32_t *idx11,
+                              const int32_t *idx22, const float *val12, const int32_t *pidx12, const float *val21, const int32_t *pidx21, int B,
+                              int N, int M, int k, int topk, double *partial12, double *partial21, hipStream_t s);
 bool launch_apply3_pair(const float *val12, const int32_t *idx12, const float *verts2, float *verts12, int32_t *T12, const float *val21,
                         const int32_t *idx21, const float *verts1, float *verts21, int32_t *T21, int B, int N, int M, hipStream_t s);
 int launch_dg_build(const float *xyz, int B, int N, const int32_t *start, int32_t *nodes_idx, int32_t *ring, int32_t *infl_idx,
@@ -277,10 +280,77 @@ DVM_EXPORT int dvm_pair_set_overlap(int on) {
     return prev;
 }
 
+// The coordinate-only part of the pair path — both clouds' deformation graphs (FPS nodes, rings, skinning), their uniform grids, the
+// xyz kNN and (without the LDS map term) the neighbours' coordinates — written into the workspace `w`.  `s` carries the FPS chain;
+// with a context `cx` the vertex grid and the xyz kNN, which need no FPS, run beside it on cx->side2 (joined into `s` before this
+// returns).  `pool` (feature pointers given): the Deformer's pooled features are made right behind the xyz kNN on that stream.
+// Reference: lib/deformation_graph_point.py:18-33, 177-201; models/loss.py:1325-1337 (graphs), :97-101 (xyz kNN).
+namespace dvm {
+static bool pair_geometry(PairCtx *cx, hipStream_t s, const Pair2Ws &w, const float *verts1, const float *verts2, int B, int N, int M,
+                          const int32_t *start1, const int32_t *start2, bool both, bool gather_nbr, const float *pool_feat1,
+                          const float *pool_feat2, const float *conv_w, const float *conv_b) {
+    const int P[2] = {N, M};
+    const float *verts[2] = {verts1, verts2};
+    const int32_t *start[2] = {start1, start2};
+    bool pooled = false;
+    if (both) {
+        (void)hipMemcpyAsync(w.vcat, verts1, (size_t)B * N * 3 * sizeof(float), hipMemcpyDeviceToDevice, s);
+        (void)hipMemcpyAsync(w.vcat + (size_t)B * N * 3, verts2, (size_t)B * N * 3 * sizeof(float), hipMemcpyDeviceToDevice, s);
+        (void)hipMemcpyAsync(w.startcat, start1, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
+        (void)hipMemcpyAsync(w.startcat + B, start2, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
+        if (cx) {
+            // FPS is N / 2 dependent steps on one workgroup per cloud (0.7 ms whatever the batch) and everything behind it on this
+            // stream waits for it — but the vertex grid, the xyz kNN and the pooled features need the coordinates / features only:
+            // they go on the SECOND helper stream, beside FPS
+            (void)hipEventRecord(cx->ev_aux, s);                      // the concatenated coordinates are in place
+            (void)hipStreamWaitEvent(cx->side2, cx->ev_aux, 0);
+            launch_grid_build(w.vcat, 2 * B, N, nullptr, w.gvcat, cx->side2);
+            (void)hipEventRecord(cx->ev_aux, cx->side2);              // (re-used: the vertex grid is built)
+            launch_grid_knn_self(w.gvcat, 2 * B, 10, w.idxk[0], cx->side2);
+            if (pool_feat1) {
+                launch_pool_all(pool_feat1, w.idxk[0], B, N, 10, conv_w, conv_b, w.gall[0], cx->side2, w.gv[0].ids);
+                launch_pool_all(pool_feat2, w.idxk[1], B, M, 10, conv_w, conv_b, w.gall[1], cx->side2, w.gv[1].ids);
+                pooled = true;
+            }
+            (void)hipEventRecord(cx->ev_join2, cx->side2);
+            launch_dg_build(w.vcat, 2 * B, N, w.startcat, w.nodes[0], w.ring[0], w.infl[0], w.dists[0], w.weights[0], nullptr,
+                            w.nnd[0], w.gvcat, w.gncat, false, s, cx->ev_aux);
+            (void)hipStreamWaitEvent(s, cx->ev_join2, 0);
+        } else {
+            launch_dg_build(w.vcat, 2 * B, N, w.startcat, w.nodes[0], w.ring[0], w.infl[0], w.dists[0], w.weights[0], nullptr,
+                            w.nnd[0], w.gvcat, w.gncat, true, s);
+            launch_grid_knn_self(w.gvcat, 2 * B, 10, w.idxk[0], s);
+        }
+    } else {
+        // N != M (or sizes that do not tile the arena): one chain per cloud set.  FPS is a one-workgroup-per-cloud
+        // sequential kernel, so the two chains go on two streams and overlap each other as well.
+        if (cx) {
+            (void)hipEventRecord(cx->ev_aux, s);
+            (void)hipStreamWaitEvent(cx->side2, cx->ev_aux, 0);
+        }
+        for (int sd = 0; sd < 2; ++sd) {
+            const hipStream_t cs = (cx && sd == 1) ? cx->side2 : s;
+            launch_dg_build(verts[sd], B, P[sd], start[sd], w.nodes[sd], w.ring[sd], w.infl[sd], w.dists[sd], w.weights[sd],
+                            nullptr, w.nnd[sd], w.gv[sd], w.gn[sd], true, cs);
+            launch_grid_knn_self(w.gv[sd], B, 10, w.idxk[sd], cs);
+        }
+        if (cx) {
+            (void)hipEventRecord(cx->ev_join2, cx->side2);
+            (void)hipStreamWaitEvent(s, cx->ev_join2, 0);
+        }
+    }
+    if (gather_nbr) {
+        launch_gather_nbr_xyz(verts2, w.idxk[1], B, M, 10, w.nbrxyz[1], s);
+        launch_gather_nbr_xyz(verts1, w.idxk[0], B, N, 10, w.nbrxyz[0], s);
+    }
+    return pooled;
+}
+}  // namespace dvm
+
 // reuse_geometry != 0: the coordinate-only products of an earlier call on the SAME workspace with the SAME coordinates and FPS
-// starts — both clouds' deformation graphs (nodes, rings, skinning), their uniform grids, the xyz kNN and the neighbours'
-// coordinates of the map term — are still in `ws` and are used as they are (the per-shape graph cache of SURVEY 8f-2 / 8d;
-// the reference rebuilds them on every call, models/loss.py:1325-1337); everything that depends on the features runs as always
+// starts — dvm_pair_geometry_f32, or a dvm_pair_fwd[_cached]_f32 call — are still in `ws` and are used as they are (the per-shape
+// graph cache of SURVEY 8f-2 / 8d and the geometry prefetch of a pipelined caller; the reference rebuilds them on every call,
+// models/loss.py:1325-1337); everything that depends on the features runs as always
 static int pair_fwd_impl(const float *feat1, const float *feat2, const float *verts1, const float *verts2, int B, int N, int M,
                          float neg_alpha, const int32_t *start1, const int32_t *start2, const float *conv_w, const float *conv_b,
                          const float *W0, const float *b0, const float *W1, const float *b1, const float *W2, const float *b2,
@@ -301,9 +371,6 @@ static int pair_fwd_impl(const float *feat1, const float *feat2, const float *ve
         return DVM_ENOSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
-    const int P[2] = {N, M};
-    const float *verts[2] = {verts1, verts2};
-    const int32_t *start[2] = {start1, start2};
     int rc;
     const bool both = (N == M) && contiguous_sides(B, N);
     // ---- per-cloud geometry: graph + xyz kNN.  It depends on the coordinates only and is latency-bound (FPS: N/2
@@ -320,62 +387,15 @@ static int pair_fwd_impl(const float *feat1, const float *feat2, const float *ve
         (void)hipStreamWaitEvent(cx->side, cx->ev_fork, 0);
         s = cx->side;
     }
-    bool pooled = false;   // the pooled features were made on the second helper stream (below)
-    if (reuse_geometry) {
-        // graphs, grids and xyz kNN of both clouds are in the workspace already
-    } else if (both) {
-        (void)hipMemcpyAsync(w.vcat, verts1, (size_t)B * N * 3 * sizeof(float), hipMemcpyDeviceToDevice, s);
-        (void)hipMemcpyAsync(w.vcat + (size_t)B * N * 3, verts2, (size_t)B * N * 3 * sizeof(float), hipMemcpyDeviceToDevice, s);
-        (void)hipMemcpyAsync(w.startcat, start1, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
-        (void)hipMemcpyAsync(w.startcat + B, start2, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
-        if (overlap) {
-            // FPS is N / 2 dependent steps on one workgroup per cloud (0.7 ms whatever the batch) and everything behind it on this
-            // stream waits for it — but the vertex grid, the xyz kNN and the pooled features need the coordinates / features only:
-            // they go on the SECOND helper stream, beside FPS (at 64 pairs per GPU — one rank's share of an 8-GPU strong-scaling
-            // run — FPS fills half the compute units and the step is this chain: 1.96 -> 1.7 ms; profiles/r5_scaling_proxy.txt)
-            (void)hipEventRecord(cx->ev_aux, s);                      // the concatenated coordinates are in place
-            (void)hipStreamWaitEvent(cx->side2, cx->ev_aux, 0);
-            launch_grid_build(w.vcat, 2 * B, N, nullptr, w.gvcat, cx->side2);
-            (void)hipEventRecord(cx->ev_aux, cx->side2);              // (re-used: the vertex grid is built)
-            launch_grid_knn_self(w.gvcat, 2 * B, 10, w.idxk[0], cx->side2);
-            launch_pool_all(feat1, w.idxk[0], B, N, 10, conv_w, conv_b, w.gall[0], cx->side2, w.gv[0].ids);
-            launch_pool_all(feat2, w.idxk[1], B, M, 10, conv_w, conv_b, w.gall[1], cx->side2, w.gv[1].ids);
-            (void)hipEventRecord(cx->ev_join2, cx->side2);
-            pooled = true;
-            launch_dg_build(w.vcat, 2 * B, N, w.startcat, w.nodes[0], w.ring[0], w.infl[0], w.dists[0], w.weights[0], nullptr,
-                            w.nnd[0], w.gvcat, w.gncat, false, s, cx->ev_aux);
-            (void)hipStreamWaitEvent(s, cx->ev_join2, 0);             // ev_join (below) then covers both helper streams
-        } else {
-            launch_dg_build(w.vcat, 2 * B, N, w.startcat, w.nodes[0], w.ring[0], w.infl[0], w.dists[0], w.weights[0], nullptr,
-                            w.nnd[0], w.gvcat, w.gncat, true, s);
-            launch_grid_knn_self(w.gvcat, 2 * B, 10, w.idxk[0], s);
-        }
-    } else {
-        // N != M (or sizes that do not tile the arena): one chain per cloud set.  FPS is a one-workgroup-per-cloud
-        // sequential kernel, so the two chains go on two helper streams and overlap each other as well.
-        if (overlap) (void)hipStreamWaitEvent(cx->side2, cx->ev_fork, 0);
-        for (int sd = 0; sd < 2; ++sd) {
-            const hipStream_t cs = (overlap && sd == 1) ? cx->side2 : s;
-            launch_dg_build(verts[sd], B, P[sd], start[sd], w.nodes[sd], w.ring[sd], w.infl[sd], w.dists[sd], w.weights[sd],
-                            nullptr, w.nnd[sd], w.gv[sd], w.gn[sd], true, cs);
-            launch_grid_knn_self(w.gv[sd], B, 10, w.idxk[sd], cs);
-        }
-        if (overlap) {
-            (void)hipEventRecord(cx->ev_join2, cx->side2);
-            (void)hipStreamWaitEvent(cx->side, cx->ev_join2, 0);  // ev_join (below) then covers both chains
-        }
-    }
+    const bool map_lds = map_term_lds_applies(N, 10) && map_term_lds_applies(M, 10);   // (the target side in LDS: no neighbour tables)
+    bool pooled = false;   // the pooled features were made on the second helper stream
+    if (!reuse_geometry)
+        pooled = pair_geometry(cx, s, w, verts1, verts2, B, N, M, start1, start2, both, with_map && !map_lds, feat1, feat2, conv_w, conv_b);
     // still on the geometry side: what depends on the xyz kNN and the input features only — the Deformer's pooled features
-    // (once per cloud, points in grid-cell order) and the neighbours' coordinates of the map term — so that the L2-bound
-    // gathers run next to the ALU-bound sweep instead of after it
+    // (once per cloud, points in grid-cell order) — so that the L2-bound gathers run next to the ALU-bound sweep instead of after it
     if (!pooled) {
         launch_pool_all(feat1, w.idxk[0], B, N, 10, conv_w, conv_b, w.gall[0], s, w.gv[0].ids);
         launch_pool_all(feat2, w.idxk[1], B, M, 10, conv_w, conv_b, w.gall[1], s, w.gv[1].ids);
-    }
-    const bool map_lds = map_term_lds_applies(N, 10) && map_term_lds_applies(M, 10);   // (the target side in LDS: no neighbour tables)
-    if (with_map && !reuse_geometry && !map_lds) {
-        launch_gather_nbr_xyz(verts2, w.idxk[1], B, M, 10, w.nbrxyz[1], s);
-        launch_gather_nbr_xyz(verts1, w.idxk[0], B, N, 10, w.nbrxyz[0], s);
     }
     if (overlap) {
         (void)hipEventRecord(cx->ev_join, cx->side);
@@ -400,6 +420,42 @@ static int pair_fwd_impl(const float *feat1, const float *feat2, const float *ve
         if (rc != DVM_OK) return fail(rc);
     }
     if (overlap) (void)hipStreamWaitEvent(caller, cx->ev_join, 0);  // join: everything below needs the graphs / kNN
+    // ---- second fork (round 6): what needs the soft correspondence but NOT the Deformer — the Chamfer terms of the Pi-mapped clouds
+    // (verts12 / verts21 against the targets) and the map terms — runs on the helper stream beside assemble -> MLP -> warp -> the warped
+    // clouds' Chamfer terms.  At a strong-scaling rank's batch (32 - 64 pairs) none of these kernels fills the chip and the step is
+    // the LENGTH of this chain; at 512 pairs it is neutral.  Same kernels, same arguments per group: same bits as the one-stream order.
+    hipStream_t s2 = s;
+    if (overlap) {
+        (void)hipEventRecord(cx->ev_fork, caller);
+        (void)hipStreamWaitEvent(cx->side, cx->ev_fork, 0);
+        s2 = cx->side;
+    }
+    {
+        const float *const gx[2] = {verts12, verts21};
+        const int gn[2] = {N, M};
+        const GridBuf gg[2] = {w.gc[0], w.gc[1]};
+        launch_grid_build_sets(gx, gn, gg, 2, B, s2);
+        const GridBuf qg[4] = {w.gc[0], w.gv[1], w.gc[1], w.gv[0]};
+        const GridBuf tg[4] = {w.gv[1], w.gc[0], w.gv[0], w.gc[1]};
+        float *const cd[4] = {w.cd[2], w.cd[3], w.cd[6], w.cd[7]};
+        launch_grid_chamfer(qg, tg, cd, nullptr, 4, B, s2);
+    }
+    // ---- map terms (losses[:,5])
+    if (with_map) {
+        if (map_lds) {
+            launch_map_term_lds_pair(verts12, verts21, verts1, verts2, w.idxk[0], w.idxk[1], w.pval[0], w.pidx[0], w.pval[1], w.pidx[1], B, N, M, 10,
+                                     10, w.partial[0], w.partial[1], s2);
+        } else {
+            launch_map_term_nbr(verts12, w.nbrxyz[1], w.idxk[0], w.pval[0], w.pidx[0], B, N, M, 10, 10, w.partial[0], s2);
+            launch_map_term_nbr(verts21, w.nbrxyz[0], w.idxk[1], w.pval[1], w.pidx[1], B, M, N, 10, 10, w.partial[1], s2);
+        }
+        launch_reduce_partials(w.partial[0], B, map_term_blocks(N, 10), 1.f, losses12, 6, 5, s2);
+        launch_reduce_partials(w.partial[1], B, map_term_blocks(M, 10), 1.f, losses21, 6, 5, s2);
+    } else {
+        launch_mean(w.cd[0], B, 1, 0.f, losses12, 6, 5, 0, s2);
+        launch_mean(w.cd[0], B, 1, 0.f, losses21, 6, 5, 0, s2);
+    }
+    if (overlap) (void)hipEventRecord(cx->ev_join2, cx->side);
     // ---- Deformer: z for both directions from the pooled features (made above), one MLP launch
     const int Nn1 = N / 2, Nn2 = M / 2;
     float *z21 = w.z + (size_t)B * Nn1 * 264;
@@ -421,36 +477,21 @@ static int pair_fwd_impl(const float *feat1, const float *feat2, const float *ve
                    nullptr, s);
     launch_dg_warp(verts2, B, M, w.nodes[1], w.ring[1], w.infl[1], w.weights[1], def21, R21, T21v, warped21, losses21 + 2, 6,
                    nullptr, s);
-    // ---- the four Chamfer terms, both sides each, in one grouped launch
+    // ---- the warped clouds' Chamfer terms, then the means of all eight
     {
-        {   // the grids of the four Chamfer clouds in one launch
-            const float *const gx[4] = {warped12, verts12, warped21, verts21};
-            const int gn[4] = {N, N, M, M};
-            const GridBuf gg[4] = {w.gw[0], w.gc[0], w.gw[1], w.gc[1]};
-            launch_grid_build_sets(gx, gn, gg, 4, B, s);
-        }
-        const GridBuf qg[8] = {w.gw[0], w.gv[1], w.gc[0], w.gv[1], w.gw[1], w.gv[0], w.gc[1], w.gv[0]};
-        const GridBuf tg[8] = {w.gv[1], w.gw[0], w.gv[1], w.gc[0], w.gv[0], w.gw[1], w.gv[0], w.gc[1]};
+        const float *const gx[2] = {warped12, warped21};
+        const int gn[2] = {N, M};
+        const GridBuf gg[2] = {w.gw[0], w.gw[1]};
+        launch_grid_build_sets(gx, gn, gg, 2, B, s);
+        const GridBuf qg[4] = {w.gw[0], w.gv[1], w.gw[1], w.gv[0]};
+        const GridBuf tg[4] = {w.gv[1], w.gw[0], w.gv[0], w.gw[1]};
+        float *const cd[4] = {w.cd[0], w.cd[1], w.cd[4], w.cd[5]};
+        launch_grid_chamfer(qg, tg, cd, nullptr, 4, B, s);
+        if (overlap) (void)hipStreamWaitEvent(caller, cx->ev_join2, 0);   // the helper stream's Chamfer and map terms
         const int Na[8] = {N, M, N, M, M, N, M, N};
-        launch_grid_chamfer(qg, tg, w.cd, nullptr, 8, B, s);
         float *const L[8] = {losses12, losses12, losses12, losses12, losses21, losses21, losses21, losses21};
         const int off[8] = {0, 1, 3, 4, 0, 1, 3, 4};
         launch_mean_grouped(w.cd, Na, L, off, 8, B, 1.f, 6, s);   // (one launch for the eight means)
-    }
-    // ---- map terms (losses[:,5])
-    if (with_map) {
-        if (map_lds) {
-            launch_map_term_lds(verts12, verts2, w.idxk[0], w.idxk[1], w.pval[0], w.pidx[0], B, N, M, 10, 10, w.partial[0], s);
-            launch_map_term_lds(verts21, verts1, w.idxk[1], w.idxk[0], w.pval[1], w.pidx[1], B, M, N, 10, 10, w.partial[1], s);
-        } else {
-            launch_map_term_nbr(verts12, w.nbrxyz[1], w.idxk[0], w.pval[0], w.pidx[0], B, N, M, 10, 10, w.partial[0], s);
-            launch_map_term_nbr(verts21, w.nbrxyz[0], w.idxk[1], w.pval[1], w.pidx[1], B, M, N, 10, 10, w.partial[1], s);
-        }
-        launch_reduce_partials(w.partial[0], B, map_term_blocks(N, 10), 1.f, losses12, 6, 5, s);
-        launch_reduce_partials(w.partial[1], B, map_term_blocks(M, 10), 1.f, losses21, 6, 5, s);
-    } else {
-        launch_mean(w.cd[0], B, 1, 0.f, losses12, 6, 5, 0, s);
-        launch_mean(w.cd[0], B, 1, 0.f, losses21, 6, 5, 0, s);
     }
     DVM_CHECK_LAUNCH("pair_fwd");
     return DVM_OK;
@@ -476,4 +517,30 @@ DVM_EXPORT int dvm_pair_fwd_cached_f32(const float *feat1, const float *feat2, c
     return pair_fwd_impl(feat1, feat2, verts1, verts2, B, N, M, neg_alpha, start1, start2, conv_w, conv_b, W0, b0, W1, b1, W2, b2, W3, b3,
                          with_map, warped12, verts12, T12, losses12, warped21, verts21, T21, losses21, ws, ws_bytes, stream,
                          reuse_geometry ? 1 : 0);
+}
+
+// The coordinate-only half of dvm_pair_fwd_f32 as a call of its own: a pipelined caller enqueues the geometry of batch t + 1 on
+// another stream while batch t's feature-dependent half (soft correspondence -> Deformer -> warp -> Chamfer) runs, and then calls
+// dvm_pair_fwd_cached_f32(..., reuse_geometry = 1) on the SAME workspace.  Nothing is cached: every batch's graphs are still built
+// once per step, only earlier (the reference builds them inside the criterion call, models/loss.py:1325-1337, from coordinates that
+// are known as soon as the batch is loaded).  With a dvm_pair_init context for `stream` the vertex grid + xyz kNN run beside the FPS
+// chain on the context's second helper stream; both are joined into `stream` before this returns.
+DVM_EXPORT int dvm_pair_geometry_f32(const float *verts1, const float *verts2, int B, int N, int M, const int32_t *start1,
+                                     const int32_t *start2, int with_map, void *ws, size_t ws_bytes, void *stream) {
+    DVM_REQUIRE(verts1 && verts2 && start1 && start2, "dvm_pair_geometry_f32: null input pointer");
+    DVM_REQUIRE(B >= 1 && N >= 20 && M >= 20, "dvm_pair_geometry_f32: bad sizes (B=%d N=%d M=%d)", B, N, M);
+    Arena ar(ws, ws_bytes);
+    Pair2Ws w;
+    carve_pair2(ar, B, N, M, w);
+    if (!ar.ok()) {
+        set_error("dvm_pair_geometry_f32: workspace too small (%zu < %zu)", ws_bytes, ar.off);
+        return DVM_ENOSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    PairCtx *cx = g_pair_overlap != 0 ? pair_ctx_find(s) : nullptr;
+    const bool both = (N == M) && contiguous_sides(B, N);
+    const bool map_lds = map_term_lds_applies(N, 10) && map_term_lds_applies(M, 10);
+    pair_geometry(cx, s, w, verts1, verts2, B, N, M, start1, start2, both, with_map && !map_lds, nullptr, nullptr, nullptr, nullptr);
+    DVM_CHECK_LAUNCH("pair_geometry");
+    return DVM_OK;
 }

@@ -874,13 +874,15 @@ __global__ __launch_bounds__(256) void softcorr_exact_rows_kernel(const HXArgs a
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float neg_alpha = args.neg_alpha;
     const int topk = args.topk;
-    for (int grp = 0; grp < 2; ++grp) {
-        const HXGroup &G = args.g[grp];
-        if (!G.flagged) continue;
-        const int cnt = *G.nflagged;
-        const int N = G.N, M = G.M;
-        for (int f = blockIdx.x; f < cnt; f += gridDim.x) {  // one workgroup per row: the sweep is latency-bound
-            const long row = G.flagged[f];
+    // the flagged rows of BOTH directions as one list: workgroups [0, cnt0) take direction 0's, [cnt0, cnt0 + cnt1) direction 1's — a
+    // launch lasts as long as ONE row's dependent chain (round 6; the directions used to follow each other inside a workgroup: two
+    // chains, 105 - 125 us per launch whatever the batch)
+    const int cnt0 = args.g[0].flagged ? *args.g[0].nflagged : 0, cnt1 = args.g[1].flagged ? *args.g[1].nflagged : 0;
+    {
+        for (int v = blockIdx.x; v < cnt0 + cnt1; v += gridDim.x) {  // one workgroup per row: the sweep is latency-bound
+            const HXGroup &G = args.g[v < cnt0 ? 0 : 1];
+            const int N = G.N, M = G.M;
+            const long row = G.flagged[v < cnt0 ? v : v - cnt0];
             const int b = (int)(row / N);
             const float *q = G.q + (size_t)row * HB_D;
             const float na = G.nq[row];
@@ -1128,6 +1130,15 @@ static void report_routes(const int *route, const float *frac, int n, hipStream_
             cnt[3], 100 * ps / n, 100 * pmin, 100 * pmax);
 }
 
+// what the most recent launch_softcorr_f16 of this host thread did with its (direction, pair) entries: device pointers into the
+// caller's workspace (valid until it is rewritten), read back by dvm_k1_last_routes
+struct K1LastLaunch {
+    const int *route = nullptr, *route2 = nullptr;   // first-pass routes (nullptr: `fixed` for every entry), the gate's second pass
+    int n = 0, fixed = -1;
+    hipStream_t s = nullptr;
+};
+static thread_local K1LastLaunch g_k1_last;
+
 // workspace of the fp16 path for (B, N, M): planes of both sides, candidates of both directions, flags
 size_t softcorr_f16_ws_bytes(int B, int N, int M, bool both) {
     const size_t Np = (size_t)(N + HB_KT - 1) / HB_KT * HB_KT, Mp = (size_t)(M + HB_KT - 1) / HB_KT * HB_KT;
@@ -1203,8 +1214,8 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
     hipLaunchKernelGGL(norm_max_kernel, dim3((M + 255) / 256, B), dim3(256), 0, s, n2, M, nmax2);
     for (int d = 0; d < (both ? 2 : 1); ++d) (void)hipMemsetAsync(flag[d], 0, sizeof(int32_t), s);
     // alpha < 32: every softmax term counts, the first form in full.  From 32 on each (direction, pair) is routed by the
-    // probe; DVM_K1_ROUTE = 0 / 1 / 2 forces one kernel for all of them (A/B measurements), DVM_K1_SWEEP=0 takes the second
-    // form out of the choice.
+    // probe; DVM_K1_ROUTE = 0 / 1 / 3 (K1_ROUTE_FULL / LEAN / COARSE) forces one kernel for all of them (A/B measurements,
+    // tests/test_gpu_k1_routes.py).
     const bool lean = -neg_alpha >= 32.f;
     const Options &pol = options();
     const bool havec = coarse_supports(N, M);
@@ -1288,6 +1299,7 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
         }
     }
     prof_end(s, DVM_PROF_K1_REFINE);
+    g_k1_last = K1LastLaunch{routed ? route : nullptr, (routed ? havec : fixed == K1_ROUTE_COARSE) ? route2 : nullptr, B * (both ? 2 : 1), fixed, s};
 
     HXArgs x;
     x.g[0] = HXGroup{f1, f2, n1, n2, N, M, val12, idx12, smax12, sum12, flag[0] + 1, flag[0]};
@@ -1393,3 +1405,27 @@ int launch_argmin_f16(const float *f1, const float *f2, int B, int N, int M, int
 }
 
 }  // namespace dvm
+
+// Diagnostic, SYNCHRONOUS (it waits for the launch's stream and copies a few hundred bytes to the host): which pass-A kernel the
+// most recent soft-correspondence launch of this host thread sent its (direction, pair) entries to.  counts[0] = full first form,
+// [1] = lean first form, [2] = coarse screen, [3] = entries the gate swept AGAIN with the lean form behind the coarse screen,
+// [4] = entries in all.  Valid only while the launch's workspace has not been rewritten (call it right after the launch).
+DVM_EXPORT int dvm_k1_last_routes(int *counts) {
+    DVM_REQUIRE(counts, "dvm_k1_last_routes: null pointer");
+    const dvm::K1LastLaunch &L = dvm::g_k1_last;
+    for (int i = 0; i < 5; ++i) counts[i] = 0;
+    DVM_REQUIRE(L.n > 0, "dvm_k1_last_routes: no soft-correspondence launch on this thread yet");
+    counts[4] = L.n;
+    if (hipStreamSynchronize(L.s) != hipSuccess) {
+        dvm::set_error("dvm_k1_last_routes: stream synchronisation failed");
+        return DVM_ELAUNCH;
+    }
+    std::vector<int> r(L.n, L.fixed), r2(L.n, -1);
+    if (L.route && hipMemcpy(r.data(), L.route, L.n * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return DVM_ELAUNCH;
+    if (L.route2 && hipMemcpy(r2.data(), L.route2, L.n * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return DVM_ELAUNCH;
+    for (int i = 0; i < L.n; ++i) {
+        counts[r[i] == dvm::k1::K1_ROUTE_COARSE ? 2 : r[i] == dvm::k1::K1_ROUTE_LEAN ? 1 : 0] += 1;
+        if (r2[i] == dvm::k1::K1_ROUTE_LEAN) counts[3] += 1;
+    }
+    return DVM_OK;
+}

@@ -56,6 +56,8 @@ int main() {
                             nullptr, nullptr, nullptr, nullptr, nullptr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                             nullptr, 0, nullptr) == DVM_EINVAL);
     EXPECT(dvm_rot6d_f32(nullptr, 4, nullptr, nullptr) == DVM_EINVAL);
+    EXPECT(dvm_pair_geometry_f32(nullptr, nullptr, 1, 64, 64, nullptr, nullptr, 1, nullptr, 0, nullptr) == DVM_EINVAL);
+    EXPECT(dvm_pair_geometry_f32(dummy, dummy, 1, 64, 64, idummy, idummy, 1, nullptr, 0, nullptr) == DVM_ENOSPACE);
     EXPECT(dvm_graph_geodesics_f64(nullptr, nullptr, 10, 4, nullptr, nullptr) == DVM_EINVAL);
     EXPECT(dvm_profile_read(nullptr, nullptr) == DVM_EINVAL);
     EXPECT(dvm_profile_enable(0) == DVM_EINVAL);

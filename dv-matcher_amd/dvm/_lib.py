@@ -86,6 +86,7 @@ SIGNATURES = {
     "dvm_linear_wgrad_ws_f32": (c_int, [_P, _P, ctypes.c_long, c_int, c_int, _P, _P, c_size_t, _P]),
     "dvm_set_deterministic": (c_int, [c_int]),
     "dvm_get_deterministic": (c_int, []),
+    "dvm_k1_last_routes": (c_int, [_P]),
     "dvm_pair_destroy": (c_int, []),
     "dvm_argmin_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "dvm_argmin_exact_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
@@ -138,6 +139,7 @@ SIGNATURES = {
                          [_P, c_size_t, _P]),
     "dvm_pair_fwd_cached_f32": (c_int, [_P] * 4 + [c_int] * 3 + [c_float, _P, _P] + [_P] * 10 + [c_int] + [_P] * 8 +
                                 [_P, c_size_t, c_int, _P]),
+    "dvm_pair_geometry_f32": (c_int, [_P, _P] + [c_int] * 3 + [_P, _P, c_int, _P, c_size_t, _P]),
 }
 
 

@@ -208,7 +208,7 @@ class _Uni3FCTrain(torch.autograd.Function):
             # the activations live in a caller-side arena that the first backward releases (1.1 GB at 8 x 2048), and in the fused
             # mode the gradients were ADDED into the parameters' buffers: a second pass through this node cannot be replayed
             raise RuntimeError("dvm Uni3FC training node: backward ran already (its activation arena is released after the first pass; "
-                               "retain_graph / a second backward through the network is not supported — set DVM_NATIVE_TRAIN=0 for that)")
+                               "retain_graph / a second backward through the network is not supported — set Uni3FC.native_train = False for that)")
         table, where, k = ctx.meta[:3]
         feat, tmp = ctx.saved_tensors
         trainable = ctx.trainable
@@ -330,54 +330,6 @@ def uni3fc_train_merged(meta, x1, dino1, x2, dino2, trainable):
     meta = tuple(meta)
     feat, tmp = _Uni3FCTrain.apply(meta[:5] + (None, 2) + meta[7:8], torch.cat([x1, x2], 0), torch.cat([dino1, dino2], 0), *trainable)
     return (feat[:B], tmp[:B]), (feat[B:], tmp[B:])
-
-
-_pair_streams = {}
-
-
-def uni3fc_train_pair(meta, x1, dino1, x2, dino2, trainable):
-    """The criterion's two network calls (train.py:100-101) SIDE BY SIDE: each native node on its own stream (with its own helper
-    stream for the global chain), joined into the caller's stream; autograd replays each node's backward on its stream, so
-    the two backward passes overlap too.  The calls share every BatchNorm: their running-statistics updates are deferred and
-    applied afterwards on the caller's stream, call 1 then call 2 — the reference's order, the fused kernel's expression.
-    -> ((feat1, tmp1), (feat2, tmp2))."""
-    dev = x1.device
-    cur = torch.cuda.current_stream(dev)
-    key = (dev, cur.cuda_stream)
-    if key not in _pair_streams:
-        _pair_streams[key] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
-    outs, arenas = [], []
-    for st, x, d in zip(_pair_streams[key], (x1, x2), (dino1, dino2)):
-        st.wait_stream(cur)
-        box = []
-        with torch.cuda.stream(st):
-            x.record_stream(st), d.record_stream(st)
-            outs.append(_Uni3FCTrain.apply(tuple(meta) + (box,), x, d, *trainable))
-        arenas.append(box)
-    # the deferred running-statistics updates, each on ITS call's stream (the arena never leaves the stream it was allocated on: a
-    # record_stream on a 1 GB block defers its reuse and makes the next step allocate afresh), call 2's ordered behind call 1's
-    table, _, k, _, momentum = meta[:5]
-    s1, s2 = _pair_streams[key]
-    with torch.cuda.stream(s1):
-        ops.uni3fc_train_running_stats(table, arenas[0][0], x1.shape[0], x1.shape[2], k, momentum)
-    s2.wait_stream(s1)
-    with torch.cuda.stream(s2):
-        ops.uni3fc_train_running_stats(table, arenas[1][0], x2.shape[0], x2.shape[2], k, momentum)
-    for st, out in zip((s1, s2), outs):
-        cur.wait_stream(st)
-        for t in out:
-            t.record_stream(cur)
-    return outs[0], outs[1]
-
-
-def join_pair_streams(device=None):
-    """The caller's stream waits for the two network-call streams of uni3fc_train_pair (their backward passes write parameter
-    gradients straight into the flat bucket): call after backward(), before the gradients are read."""
-    cur = torch.cuda.current_stream(device)
-    for (dev, _), sts in _pair_streams.items():
-        if dev == cur.device:
-            for st in sts:
-                cur.wait_stream(st)
 
 
 def sa_attention_pm(xt, w_qk, w_v, b_v):

@@ -957,14 +957,20 @@ def uni3fc_train_forward(params, x, dino, k, eps, momentum, defer_stats=False, g
 CRIT_TRAIN_NPARAMS = 10
 
 
+def _graph_c(g):
+    """The batched graph dict as the C ABI wants it: int32 / fp32, contiguous (the same tensors when they already are — dg_build's
+    always are; a caller-supplied `geometry=` with int64 or strided indices is converted instead of being reinterpreted)."""
+    return {"nodes_idx": _i(g["nodes_idx"]), "one_ring": _i(g["one_ring"]), "infl_idx": _i(g["infl_idx"]), "weights": _f(g["weights"])}
+
+
 def criterion_train_forward(params, feat, verts, g, knn_idx, alpha, topk=10, with_map=True, dist=None):
     """The training criterion for B pairs as ONE native call (dvm_criterion_train_fwd_f32).  feat (2B,N,128), verts (2B,N,3): the B first
     shapes followed by the B second shapes; g = their batched graph dict (dg_build), knn_idx (2B,N,k) their xyz-kNN; params: the
     Deformer's 10 tensors (conv weight, bias, then the decoder's weight / bias pairs); dist = None or (dist1 (B,N,N), dist2 (B,N,N),
     anchors1 (nA,) int32, anchors2 (nA,) int32, k_dist): the dist term of all 2B shapes.
     -> terms (2B,7) [map numerator, Chamfer side means of warped (2) and verts12 (2), ARAP, dist term], arena (uint8 tensor for the backward)."""
-    _need_gpu(feat, verts)
-    feat, verts = _f(feat), _f(verts)
+    _need_gpu(feat, verts, knn_idx, *[g[k_] for k_ in ("nodes_idx", "one_ring", "infl_idx", "weights")])
+    feat, verts, knn_idx, g = _f(feat), _f(verts), _i(knn_idx), _graph_c(g)
     P, N, C = feat.shape
     k = knn_idx.shape[-1]
     lib = _lib.load()
@@ -989,7 +995,8 @@ def criterion_train_forward(params, feat, verts, g, knn_idx, alpha, topk=10, wit
 
 def criterion_train_backward(params, grads, g_terms, feat, verts, g, knn_idx, alpha, arena, topk=10, with_map=True, dist=None):
     """dvm_criterion_train_bwd_f32: -> d_feat (2B,N,128); the Deformer's parameter gradients are ADDED into `grads`."""
-    _need_gpu(feat, g_terms)
+    _need_gpu(feat, g_terms, knn_idx)
+    feat, verts, knn_idx, g = _f(feat), _f(verts), _i(knn_idx), _graph_c(g)
     P, N, C = feat.shape
     k = knn_idx.shape[-1]
     lib = _lib.load()
@@ -1010,8 +1017,9 @@ def criterion_dir_train_forward(params, feat_s, feat_t, verts_s, verts_t, g, knn
     """ONE direction of the training criterion's deformation part for P pairs with N source and M target points
     (dvm_criterion_dir_train_fwd_f32): g = the SOURCES' graph dict, knn_s (P,N,k) / knn_t (P,M,k) the xyz-kNN of both sides.
     -> terms (P,7), arena."""
-    _need_gpu(feat_s, feat_t)
+    _need_gpu(feat_s, feat_t, verts_s, verts_t, knn_s, knn_t)
     feat_s, feat_t, verts_s, verts_t = _f(feat_s), _f(feat_t), _f(verts_s), _f(verts_t)
+    knn_s, knn_t, g = _i(knn_s), _i(knn_t), _graph_c(g)
     P, N, C = feat_s.shape
     M, k = feat_t.shape[1], knn_s.shape[-1]
     lib = _lib.load()
@@ -1028,7 +1036,9 @@ def criterion_dir_train_forward(params, feat_s, feat_t, verts_s, verts_t, g, knn
 
 def criterion_dir_train_backward(params, grads, g_terms, feat_s, feat_t, verts_s, verts_t, g, knn_s, knn_t, alpha, arena, topk=10, with_map=False):
     """dvm_criterion_dir_train_bwd_f32: -> (d_feat_s (P,N,128), d_feat_t (P,M,128)); parameter gradients ADDED into `grads`."""
-    _need_gpu(feat_s, g_terms)
+    _need_gpu(feat_s, g_terms, knn_s, knn_t)
+    feat_s, feat_t, verts_s, verts_t = _f(feat_s), _f(feat_t), _f(verts_s), _f(verts_t)
+    knn_s, knn_t, g = _i(knn_s), _i(knn_t), _graph_c(g)
     P, N, C = feat_s.shape
     M, k = feat_t.shape[1], knn_s.shape[-1]
     lib = _lib.load()
@@ -1134,3 +1144,79 @@ def pair_forward(wl, feat1, feat2, verts1, verts2, alpha, start1, start2, with_m
                                _p(o12["T12"]), _p(o12["losses"]), _p(o21["warped"]), _p(o21["verts12"]), _p(o21["T12"]),
                                _p(o21["losses"]), _p(ws), nb, _stream()), "dvm_pair_fwd_f32")
     return o12, o21
+
+
+class PairPipeline:
+    """The pair forward as a two-stage software pipeline over a stream of batches: stage 1 = the coordinate-only geometry of a
+    batch (dvm_pair_geometry_f32: FPS -> node grid -> ring -> influence -> skinning, vertex grid, xyz kNN) on a stream of its own,
+    stage 2 = everything that needs the features (dvm_pair_fwd_cached_f32 with reuse_geometry = 1) on torch's current stream.
+    While stage 2 of batch t runs, stage 1 of batch t + 1 does: the N / 2 dependent FPS steps (0.65 us each, a latency chain that
+    no batch size hides) leave the critical path.  NOTHING is cached — every batch's graphs are built exactly once, as in the
+    reference (models/loss.py:1325-1337), only one stage earlier; outputs are bit-identical to pair_forward.
+
+        pipe = PairPipeline(wl, B, N, M)
+        tk = pipe.prefetch(v1, v2, s1, s2)                    # batch 0
+        for each batch:  nxt = pipe.prefetch(<next batch's coordinates>);  o12, o21 = pipe.forward(tk, f1, f2, alpha);  tk = nxt
+
+    `depth` workspaces (default 2) rotate; a ticket must be consumed by forward() before `depth` further prefetches."""
+
+    def __init__(self, wl, B, N, M, with_map=True, depth=2, device=None):
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        self.wl, self.B, self.N, self.M, self.with_map, self.dev = wl, int(B), int(N), int(M), bool(with_map), dev
+        lib = _lib.load()
+        self.nb = lib.dvm_pair_workspace_bytes(self.B, self.N, self.M)
+        self.ws = [torch.empty(max(int(self.nb), 256), dtype=torch.uint8, device=dev) for _ in range(depth)]
+        self.free = [None] * depth           # event: the stage-2 call that last used the workspace has finished
+        self.geo = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(self.geo):
+            check(lib.dvm_pair_init(_stream()), "dvm_pair_init")      # the geometry stream's own helper stream / events
+        self.n = 0
+
+    def prefetch(self, verts1, verts2, start1, start2):
+        """Enqueue stage 1 for a batch; -> ticket for forward()."""
+        _need_gpu(verts1, verts2, start1, start2)
+        verts1, verts2, start1, start2 = _f(verts1), _f(verts2), _i(start1), _i(start2)
+        if tuple(verts1.shape) != (self.B, self.N, 3) or tuple(verts2.shape) != (self.B, self.M, 3):
+            raise DvmError("PairPipeline.prefetch: coordinates %s / %s, built for B=%d N=%d M=%d"
+                           % (tuple(verts1.shape), tuple(verts2.shape), self.B, self.N, self.M))
+        slot = self.n % len(self.ws)
+        self.n += 1
+        cur = torch.cuda.current_stream(self.dev)
+        self.geo.wait_stream(cur)                       # the coordinates were produced on the caller's stream
+        if self.free[slot] is not None:
+            self.geo.wait_event(self.free[slot])        # the workspace's previous consumer is done
+        with torch.cuda.stream(self.geo):
+            check(_lib.load().dvm_pair_geometry_f32(_p(verts1), _p(verts2), self.B, self.N, self.M, _p(start1), _p(start2),
+                                                    int(self.with_map), _p(self.ws[slot]), self.nb, _stream()), "dvm_pair_geometry_f32")
+            ready = torch.cuda.Event()
+            ready.record()
+        return dict(slot=slot, ready=ready, verts1=verts1, verts2=verts2, start1=start1, start2=start2)
+
+    def forward(self, ticket, feat1, feat2, alpha, out=None):
+        """Stage 2 of the ticket's batch on the current stream -> (out12, out21) as pair_forward."""
+        _need_gpu(feat1, feat2, *self.wl)
+        feat1, feat2 = _f(feat1), _f(feat2)
+        B, N, M, dev = self.B, self.N, self.M, self.dev
+        if tuple(feat1.shape) != (B, N, 128) or tuple(feat2.shape) != (B, M, 128):
+            raise DvmError("PairPipeline.forward: features %s / %s, built for B=%d N=%d M=%d" % (tuple(feat1.shape), tuple(feat2.shape), B, N, M))
+        lib = _lib.load()
+
+        def alloc(n):
+            return dict(warped=torch.empty(B, n, 3, dtype=torch.float32, device=dev),
+                        verts12=torch.empty(B, n, 3, dtype=torch.float32, device=dev),
+                        T12=torch.empty(B, n, dtype=torch.int32, device=dev),
+                        losses=torch.empty(B, 6, dtype=torch.float32, device=dev))
+        o12, o21 = out if out is not None else (alloc(N), alloc(M))
+        _ensure_pair_ctx(dev)
+        cur = torch.cuda.current_stream(dev)
+        cur.wait_event(ticket["ready"])
+        slot = ticket["slot"]
+        check(lib.dvm_pair_fwd_cached_f32(_p(feat1), _p(feat2), _p(ticket["verts1"]), _p(ticket["verts2"]), B, N, M, neg_alpha_f32(alpha),
+                                          _p(ticket["start1"]), _p(ticket["start2"]), *[_p(w) for w in self.wl], int(self.with_map),
+                                          _p(o12["warped"]), _p(o12["verts12"]), _p(o12["T12"]), _p(o12["losses"]), _p(o21["warped"]),
+                                          _p(o21["verts12"]), _p(o21["T12"]), _p(o21["losses"]), _p(self.ws[slot]), self.nb, 1, _stream()),
+              "dvm_pair_fwd_cached_f32")
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self.free[slot] = ev
+        return o12, o21

@@ -147,7 +147,7 @@ class GraphDeformLoss_Neural(nn.Module):
         self.save_name = save_name
         self.dump = dump  # the reference writes 4 OFF files + a print per deform() call; opt-in here
         # training, equal point counts: the deformation part as ONE native autograd node (nn_ops.criterion_train); False = the
-        # autograd path over the per-op nodes (the two agree to fp32 rounding, tests/test_gpu_train.py)
+        # autograd path over the per-op nodes (the two agree to fp32 rounding, tests/test_gpu_criterion_native.py)
         self.native_train = True
 
     def _identity6(self, device):
@@ -367,8 +367,8 @@ class GraphDeformLoss_Neural(nn.Module):
         direction = self._direction_train if train else self._direction
         # The dist term and the two directions of the deformation part are independent of each other: on a GPU they run on
         # three streams (forked from / joined into the caller's stream; autograd replays each branch's backward on the stream its
-        # forward ran on).  At 8 pairs their kernels fill a fraction of the chip each.  DVM_CRIT_STREAMS=0: one stream.
-        par = feat1.is_cuda and os.environ.get("DVM_CRIT_STREAMS", "1") == "1" and not self.dump
+        # forward ran on).  At 8 pairs their kernels fill a fraction of the chip each.
+        par = feat1.is_cuda and not self.dump
         cur = torch.cuda.current_stream(feat1.device) if par else None
         side = _crit_streams(feat1.device, cur) if par else None
 
@@ -397,7 +397,6 @@ class GraphDeformLoss_Neural(nn.Module):
         if self.w_deform > 0 or not self.partial_variant:
             g1, g2, idx11, idx22 = geometry if geometry is not None else self.geometry(verts1, verts2, fps_starts, shape_ids)
             merged = (train and N == M and not self.dump and not self.partial_variant and self.w_rank <= 0
-                      and os.environ.get("DVM_CRIT_MERGE", "1") == "1"
                       and all(torch.is_tensor(g1[k]) for k in g1))
             native = (merged and self.native_train and feat1.is_cuda and feat1.dtype == torch.float32 and feat1.shape[-1] == 128 and N % 4 == 0
                       and 64 <= N <= 8192 and self.k_deform <= 16 and idx11.shape[-1] == self.k_deform

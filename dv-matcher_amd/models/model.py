@@ -8,7 +8,6 @@ test.py / deform.py call sequence runs unchanged and its checkpoints load with
 1x1 convolutions / BatchNorm stay on PyTorch-ROCm as BASELINE.json's north_star prescribes.
 """
 import math
-import os
 
 import numpy as np
 import torch
@@ -315,8 +314,8 @@ def _two_branches(x, main, side):
     """LG-Net's local (kNN attention) and global (self-attention) chains share only their input `x`: `main()` runs on the
     current stream, `side()` concurrently on a per-device helper stream, joined before returning (main(), side()).  Neither
     chain fills 256 CUs on its own (their kernels are one workgroup per CU or fewer at 8 x 2048 points); autograd replays
-    each chain's backward on the stream its forward ran on.  DVM_BRANCH_STREAMS=0 runs them back to back."""
-    if not x.is_cuda or os.environ.get("DVM_BRANCH_STREAMS", "1") != "1":
+    each chain's backward on the stream its forward ran on."""
+    if not x.is_cuda:
         return main(), side()
     cur = torch.cuda.current_stream(x.device)
     helper = _side_streams.get((x.device, cur.cuda_stream))
@@ -333,7 +332,6 @@ def _two_branches(x, main, side):
 
 
 def join_side_streams(device=None):
-    nn_ops.join_pair_streams(device)
     _join_branch_streams(device)
 
 
@@ -350,6 +348,14 @@ def _join_branch_streams(device=None):
 
 
 class Uni3FC(nn.Module, _VisualProjection):
+    # Which of this module's equivalent execution paths a call takes (class defaults; an instance attribute overrides).  They are
+    # not tuning switches: the per-layer paths are what a call falls back to when the native nodes do not apply (inputs that
+    # require grad, SyncBatchNorm, non-fp32 parameters, a kNN tap), and the tests that pin a native node against them set these.
+    native_forward = True      # eval forward as ONE dvm_uni3fc_fwd_f32 call (tests/test_gpu_network.py::test_native_forward_is_the_python_path)
+    native_train = True        # training forward + backward as ONE autograd node (tests/test_gpu_train_native.py)
+    merge_pair_calls = True    # forward_pair: the step's two network calls as one native call with two groups (same file)
+    point_major_train = True   # training in the point-major layout; False: the reference's (B,C,N) layout, per layer (tests/test_gpu_train_pm.py)
+
     def __init__(self, k=40):
         super().__init__()
         self.device = 'cuda:0'
@@ -398,7 +404,7 @@ class Uni3FC(nn.Module, _VisualProjection):
         neighbour rows are contiguous for the gather kernels, nothing is transposed between layers.  (Training keeps the
         reference's (B,C,N) layout: there MIOpen's BatchNorm kernels want it and the step is GEMM/launch-bound.)"""
         B, _, N = x.shape
-        if os.environ.get("DVM_NATIVE_FWD", "1") == "1" and x.is_cuda and not getattr(self, "sync_minmax", False):
+        if self.native_forward and x.is_cuda and not getattr(self, "sync_minmax", False):
             # the same launches, enqueued by ONE native call (dvm_uni3fc_fwd_f32): no Python between the ~250 kernels
             with torch.no_grad():
                 return ops.uni3fc_forward(self._native_table(), x, dino_feat.contiguous(), self.k)
@@ -527,7 +533,7 @@ class Uni3FC(nn.Module, _VisualProjection):
     def _native_train_ok(self, x, dino_feat):
         """The native training path takes plain data tensors (no gradient w.r.t. x / dino_feat), fp32 contiguous parameters and
         one (eps, momentum) for all BatchNorms; anything else goes through the autograd path below."""
-        if os.environ.get("DVM_NATIVE_TRAIN", "1") != "1" or not x.is_cuda:
+        if not self.native_train or not x.is_cuda:
             return False
         if x.requires_grad or dino_feat.requires_grad or x.dtype != torch.float32 or dino_feat.dtype != torch.float32:
             return False
@@ -552,25 +558,14 @@ class Uni3FC(nn.Module, _VisualProjection):
 
     def forward_pair(self, x1, dino1, x2, dino2, upsampler=None):
         """The two network calls of a training step (train.py:100-101: `Uni3FC(verts1^T, dino1)`, `Uni3FC(verts2^T, dino2)`) — same
-        results as calling forward twice.  In train mode on the native path the two calls run SIDE BY SIDE on two streams (forward
-        and, through autograd, backward), with the shared BatchNorms' running statistics updated afterwards in the reference's
-        call order; otherwise simply two calls.  -> ((feat1, cfeats1), (feat2, cfeats2)).
-        The side-by-side form is OPT-IN (DVM_PAIR_CALLS=1): measured on one MI355X it takes LG-Net's forward + backward alone from
-        14.2 to 13.1 ms at 2 x 8 x 2048 points, but the whole training step from 21.3 to 23.2 ms (with the criterion's three streams
-        and the geometry stream the process then drives ~10 streams through the runtime's 4 hardware queues)."""
-        # DVM_PAIR_CALLS: "merged" (default where both shapes have the same point count) = ONE native call with two groups;
-        # "1" = two calls side by side on two streams (opt-in, below); "0" = two calls one after the other
-        mode = os.environ.get("DVM_PAIR_CALLS", "merged")
-        if mode == "merged" and (dino1 is None or dino2 is None or tuple(x1.shape) != tuple(x2.shape)):
-            mode = "0"
-        if mode == "1" and getattr(self, "sync_stats", None) is not None:
-            mode = "0"   # (cross-rank statistics: every rank must issue its collectives in ONE order)
-        native = (self.training and x1.is_cuda and dino1 is not None and dino2 is not None and mode in ("1", "merged")
-                  and os.environ.get("DVM_TRAIN_LAYOUT", "pm") == "pm" and torch.is_grad_enabled()
+        results as calling forward twice.  In train mode on the native path, with equal point counts, the two calls are ONE native
+        call with two groups (BatchNorm statistics, position-encoding range and running-statistics updates per call, in call order:
+        bit-identical forward, half the launches); otherwise simply two calls.  -> ((feat1, cfeats1), (feat2, cfeats2)).
+        (Two native nodes side by side on two streams were measured slower for the whole step — 21.3 -> 23.2 ms — and removed.)"""
+        native = (self.merge_pair_calls and self.training and x1.is_cuda and dino1 is not None and dino2 is not None
+                  and tuple(x1.shape) == tuple(x2.shape) and self.point_major_train and torch.is_grad_enabled()
                   and all(type(m) is nn.BatchNorm1d for m in self.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm))
-                  and self._native_train_ok(x1, dino1) and self._native_train_ok(x2, dino2) and ops.knn_tap() is None
-                  and (mode == "merged" or (not ops.is_deterministic()    # (deterministic mode adds the ordered weight-gradient partials non-atomically)
-                                            and not torch.cuda.is_current_stream_capturing())))
+                  and self._native_train_ok(x1, dino1) and self._native_train_ok(x2, dino2) and ops.knn_tap() is None)
         if not native:
             return self.forward(x1, dino1, upsampler), self.forward(x2, dino2, upsampler)
         ts, where, trainable, bns, det, _ = self._train_state()
@@ -578,9 +573,7 @@ class Uni3FC(nn.Module, _VisualProjection):
             torch._foreach_add_([m.num_batches_tracked for m in bns], 2)
         meta = (det, where, self.k, bns[0].eps, bns[0].momentum)
         self.__dict__["native_train_calls"] = self.__dict__.get("native_train_calls", 0) + 1
-        if mode == "merged":
-            return nn_ops.uni3fc_train_merged(meta + self._sync_meta(), x1, dino1, x2, dino2, trainable)
-        return nn_ops.uni3fc_train_pair(meta, x1.contiguous(), dino1.contiguous(), x2.contiguous(), dino2.contiguous(), trainable)
+        return nn_ops.uni3fc_train_merged(meta + self._sync_meta(), x1, dino1, x2, dino2, trainable)
 
     def _forward_train_pm(self, x, dino_feat):
         """Autograd forward with activations kept point-major (B,N,C), the layout dino_feat arrives in and the kNN /
@@ -630,14 +623,14 @@ class Uni3FC(nn.Module, _VisualProjection):
                                                   any(p.requires_grad for p in self.parameters()))
         if not self.training and not wants_grad:
             return self._forward_infer(x, dino_feat)
-        if self.training and os.environ.get("DVM_TRAIN_LAYOUT", "pm") == "pm" and \
+        if self.training and self.point_major_train and \
                 all(type(m) is nn.BatchNorm1d for m in self.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)):
             if self._native_train_ok(x, dino_feat):
                 return self._forward_train_native(x, dino_feat)
             if getattr(self, "sync_stats", None) is not None:
                 # plain BatchNorm modules + a collective: only the native node combines the statistics over the ranks — the
                 # autograd path would silently normalise per shard
-                raise RuntimeError("Uni3FC.sync_stats is set but this call cannot take the native training node (DVM_NATIVE_TRAIN=0, "
+                raise RuntimeError("Uni3FC.sync_stats is set but this call cannot take the native training node (native_train = False, "
                                    "inputs that require grad, non-fp32 / non-contiguous parameters): convert the BatchNorms with "
                                    "torch.nn.SyncBatchNorm.convert_sync_batchnorm and set sync_minmax instead")
             return self._forward_train_pm(x, dino_feat.contiguous())

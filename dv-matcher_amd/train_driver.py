@@ -227,6 +227,10 @@ def main(argv=None):
                     "fixed FPS start index (from its id) instead of the reference's fresh random start per call (models/loss.py:1325-1337), and its "
                     "graph / xyz kNN are built once and reused whenever the shape comes up again")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--dist-always", action="store_true", help="initialise the process group, the flat-bucket all-reduce and the barriers "
+                    "at world size 1 too (the RCCL branch then runs on a 1-GPU box: tests/test_gpu_ddp.py)")
+    ap.add_argument("--sync-each-step", action="store_true", help="read the loss values back every step (train.py logs loss.item() every iteration)")
+    ap.add_argument("--step-breakdown", action="store_true", help="timing mode: host seconds per phase of the step on stderr")
     ap.add_argument("--data-root", default=None, help="dataset directory (shapes_train/, shapes_test/, feat/, cache_*.pt); default: synthetic")
     ap.add_argument("--data-name", default=None)
     ap.add_argument("--random-feat", action="store_true", help="with --data-root: random visual features instead of feat/*.mat")
@@ -245,13 +249,13 @@ def main(argv=None):
     local = pick_device(local, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    # DVM_DIST_ALWAYS=1: the process group, the flat-bucket all-reduce and the barriers also at world size 1 — the RCCL branch
+    # --dist-always: the process group, the flat-bucket all-reduce and the barriers also at world size 1 — the RCCL branch
     # of this driver then runs on a 1-GPU box (tests/test_gpu_ddp.py) instead of first on the 8-GPU node
-    dist_on = world > 1 or os.environ.get("DVM_DIST_ALWAYS", "0") == "1"
+    dist_on = world > 1 or args.dist_always
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:
-            # a port of its own only for the single-rank case (DVM_DIST_ALWAYS): with more ranks every rank would pick a DIFFERENT
+            # a port of its own only for the single-rank case (--dist-always): with more ranks every rank would pick a DIFFERENT
             # free port and the rendezvous would hang until the store timeout — the launcher has to export one
             if world > 1:
                 raise SystemExit("train_driver: WORLD_SIZE = %d but MASTER_PORT is not set (start the ranks with "
@@ -274,7 +278,7 @@ def main(argv=None):
         # batch-global BatchNorm statistics and position-encoding range, as in the reference's single-process batch
         # (models/model.py:496-503, 548).  The native training node takes a collective for them (dvm_uni3fc_train_*_sync_f32: the
         # per-channel totals and the min / max are all-reduced between its launches); the autograd paths need converted modules.
-        if os.environ.get("DVM_NATIVE_TRAIN", "1") == "1" and os.environ.get("DVM_TRAIN_LAYOUT", "pm") == "pm":
+        if net.native_train and net.point_major_train:
             from dvm.dist import TorchCollective
             net.sync_stats = TorchCollective()
         else:
@@ -283,15 +287,14 @@ def main(argv=None):
     params = list(net.parameters()) + list(dfm.parameters())
     use_graph = bool(args.graph) and world == 1 and args.epochs <= 0
     # one fused multi-tensor Adam launch per step (same update as the reference's torch.optim.Adam, train.py:44-45; the default
-    # foreach form costs the host ~1.5 ms per step in ~10 launches over 151 tensors); DVM_FUSED_ADAM=0 = the foreach form
-    fused_adam = os.environ.get("DVM_FUSED_ADAM", "1") == "1" and not use_graph
+    # foreach form costs the host ~1.5 ms per step in ~10 launches over 151 tensors; a captured step needs the capturable form)
+    fused_adam = not use_graph
     opt = torch.optim.Adam(params, lr=float(cfg["optimizer"]["lr"]), betas=(cfg["optimizer"]["b1"], cfg["optimizer"]["b2"]),
                            **({"fused": True} if fused_adam else {"capturable": use_graph}))
     # world > 1: every p.grad is a view into one flat buffer (one all-reduce, no pack/unpack); a single rank has nothing to
     # exchange and lets autograd hand Adam its gradient tensors directly — unless the step is captured into a graph, whose
-    # gradient tensors must keep their addresses.  (DVM_FLAT_GRADS=1 forces the flat buffer on a single rank: the fused
-    # gradient accumulation then covers the first network call of a step as well; measured neutral, 27.7 vs 27.9 ms.)
-    attach = dist_on or use_graph or os.environ.get("DVM_FLAT_GRADS", "0") == "1"
+    # gradient tensors must keep their addresses.
+    attach = dist_on or use_graph
     bucket = FlatGradBucket(params, attach=attach)
     random.seed(seed_py)
     torch.manual_seed(seed_torch)
@@ -315,10 +318,10 @@ def main(argv=None):
         import collections
         crit.graph_cache = collections.OrderedDict()   # least-recently-used shapes are dropped beyond crit.graph_cache_max
     frac = (hi - lo) / Bg
-    sync_each = os.environ.get("DVM_SYNC_EACH_STEP", "0") == "1"   # train.py logs loss.item() every iteration
+    sync_each = args.sync_each_step   # train.py logs loss.item() every iteration
 
     from dvm import nn_ops
-    nn_ops.fuse_grad_accumulation(os.environ.get("DVM_FUSE_GRAD_ACC", "1") == "1")   # .backward() only below, never autograd.grad()
+    nn_ops.fuse_grad_accumulation(True)   # .backward() only below, never autograd.grad()
 
     # with_dino = False on a dataset without stored features: the reference passes dino_feat = None and Uni3FC renders the
     # shapes, runs the image backbone and back-projects (train_partial.py:98-104, models/model.py:683-710).  Built only then.
@@ -340,7 +343,7 @@ def main(argv=None):
             return f1, f2
         return net(v1.permute(0, 2, 1), d1, upsampler)[0], net(v2.permute(0, 2, 1), d2, upsampler)[0]
 
-    host_marks = [0.0, 0.0, 0.0, 0.0, 0] if os.environ.get("DVM_STEP_BREAKDOWN", "0") == "1" else None   # host seconds per phase
+    host_marks = [0.0, 0.0, 0.0, 0.0, 0] if args.step_breakdown else None   # host seconds per phase
 
     def mark(i, t0):
         if host_marks is not None:
@@ -349,7 +352,7 @@ def main(argv=None):
 
     # the criterion's geometry (graphs: FPS is a 0.65 ms chain of dependent steps; xyz kNN) needs the coordinates only: it is
     # enqueued on its own stream BEFORE the network forward and joined in front of the criterion
-    geo_stream = torch.cuda.Stream() if os.environ.get("DVM_PREFETCH_GEOMETRY", "1") == "1" else None
+    geo_stream = torch.cuda.Stream()
 
     def cached_keys(names, n1, n2):
         """--graph-cache: (fixed FPS starts, shape ids) of a batch from the NAMES of its shapes (`names` = (sources, targets), as the

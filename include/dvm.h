@@ -55,6 +55,8 @@ typedef struct dvm_collective {
 /* ---------------------------------------------------------------------------------------------------------------------
  * Environment options of the library: SIX variables, read once when the library is loaded (csrc/dvm_api.cpp::options()).
  * Nothing else in the library reads the environment; every option selects among HIP paths (there is no CPU path).
+ * (The Python host side, dv-matcher_amd/, reads one variable of its own — DVM_RANK_CPUS, the host cores of a rank, set by
+ * `bench.py --gpus N` — and no execution-path switches: those are module attributes and driver flags, listed in README.md.)
  *
  *   DVM_DETERMINISTIC=1        initial value of the dvm_set_deterministic flag (fixed summation order in LG-Net's backward)
  *   DVM_K1_ROUTE=0|1|3         force pass A of the soft correspondence at alpha >= 32: 0 full first form, 1 lean first form,
@@ -149,6 +151,13 @@ int dvm_linear_wgrad_ws_f32(const float *gy, const float *x, long R, int Co, int
 int dvm_set_deterministic(int on);
 /* the current setting, read-only (a reader must not toggle the process-wide flag to learn it: another thread's backward could run in between) */
 int dvm_get_deterministic(void);
+
+/* Diagnostic, SYNCHRONOUS: which pass-A kernel of knnsearch_t_grad + topk_pi (models/loss.py:110-114, 1339-1347) the most recent
+ * soft-correspondence launch of the calling host thread sent its (direction, pair) entries to — the probe and the gate decide on
+ * the device, nothing else reads them back.  counts[0] full first form (3 fp16 products), [1] lean first form (3), [2] coarse
+ * screen (1), [3] entries swept again by the lean form behind the coarse screen, [4] entries in all.  bench.py prices the
+ * roofline line from it.  Waits for that launch's stream; valid only until its workspace is rewritten. */
+int dvm_k1_last_routes(int *counts);
 
 /* knnsearch_t_grad + topk_pi (+ the argmax map)  —  models/loss.py:110-114,
  * 1339-1347, 1404-1407.   D = cdist(f1,f2) (matmul form, bit-identical squared
@@ -507,6 +516,18 @@ int dvm_pair_fwd_cached_f32(const float *feat1, const float *feat2, const float 
                             const float *W2, const float *b2, const float *W3, const float *b3, int with_map, float *warped12,
                             float *verts12, int32_t *T12, float *losses12, float *warped21, float *verts21, int32_t *T21,
                             float *losses21, void *ws, size_t ws_bytes, int reuse_geometry, void *stream);
+
+/* The coordinate-only half of dvm_pair_fwd_f32 as its own call, for a pipelined caller: both clouds' deformation graphs (FPS nodes,
+ * node rings, skinning weights: lib/deformation_graph_point.py:18-33, 177-201 via models/loss.py:1325-1337), their uniform grids,
+ * the xyz kNN (models/loss.py:97-101) and, when the map term needs them, the neighbour coordinates are written into `ws`
+ * (dvm_pair_workspace_bytes(B, N, M)); a later dvm_pair_fwd_cached_f32(..., reuse_geometry = 1) on the SAME workspace, B, N, M,
+ * coordinates, starts and with_map consumes them.  Typical use: the geometry of batch t + 1 on a second stream while batch t's
+ * feature-dependent half runs (dv-matcher_amd/dvm/ops.py::PairPipeline; the caller orders the two calls with its own events and
+ * keeps one workspace per batch in flight).  Nothing is cached: each batch's graphs are built once, only earlier; outputs are
+ * bit-identical to dvm_pair_fwd_f32.  With a dvm_pair_init context for `stream`, vertex grid + xyz kNN run on the context's second
+ * helper stream beside the FPS chain and are joined into `stream` before the call returns. */
+int dvm_pair_geometry_f32(const float *verts1, const float *verts2, int B, int N, int M, const int32_t *start1,
+                          const int32_t *start2, int with_map, void *ws, size_t ws_bytes, void *stream);
 
 /* ---- LG-Net, the whole eval-mode forward in one call (reference models/model.py:680-761 `Uni3FC.forward` with
  * torch.no_grad() / model.eval(); layers 506-529, N2P blocks 325-395, SA_Layer 97-123).  xyz [B][3][N] coordinates, dino

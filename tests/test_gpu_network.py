@@ -78,7 +78,7 @@ def test_uni3fc_teacher_forced(golden, monkeypatch, name, mode):
     net = _net(g, mode)
     tap = KnnTap(ops, forced=g["knn_idx"])
     monkeypatch.setattr(ops, "knn_neg", tap)
-    monkeypatch.setenv("DVM_NATIVE_FWD", "0")   # the tap sits on the Python-level op: take the layer-by-layer path (== the native call, bit for bit: test_native_forward_is_the_python_path)
+    monkeypatch.setattr(type(net), "native_forward", False)   # the tap sits on the Python-level op: take the layer-by-layer path (== the native call, bit for bit: test_native_forward_is_the_python_path)
     B, _, N = g["xyz"].shape
     with torch.no_grad():
         feat, cf = net(dev(g["xyz"]), dino_from_seed(int(g["dino_seed"]), B, N).cuda(), None)
@@ -110,7 +110,7 @@ def test_uni3fc_free_running_stable_regime(golden, monkeypatch):
     net = _net(g, "eval")
     tap = KnnTap(ops)
     monkeypatch.setattr(ops, "knn_neg", tap)
-    monkeypatch.setenv("DVM_NATIVE_FWD", "0")   # the tap sits on the Python-level op: take the layer-by-layer path (== the native call, bit for bit: test_native_forward_is_the_python_path)
+    monkeypatch.setattr(type(net), "native_forward", False)   # the tap sits on the Python-level op: take the layer-by-layer path (== the native call, bit for bit: test_native_forward_is_the_python_path)
     B, _, N = g["xyz"].shape
     with torch.no_grad():
         feat, cf = net(dev(g["xyz"]), dino_from_seed(int(g["dino_seed"]), B, N).cuda(), None)
@@ -193,7 +193,7 @@ def _train_step(golden, name, monkeypatch, forced):
                                      partial=False, w_deform=0.5, w_img=0, w_rank=0, w_self_rec=0.5, w_cd=0.1, w_arap=0.01, save_name="t")
     tap = KnnTap(ops, forced=g["knn_idx"] if forced else None)
     monkeypatch.setattr(ops, "knn_neg", tap)
-    monkeypatch.setenv("DVM_NATIVE_FWD", "0")   # the tap sits on the Python-level op: take the layer-by-layer path (== the native call, bit for bit: test_native_forward_is_the_python_path)
+    monkeypatch.setattr(type(net), "native_forward", False)   # the tap sits on the Python-level op: take the layer-by-layer path (== the native call, bit for bit: test_native_forward_is_the_python_path)
     v1, v2 = dev(g["verts1"]), dev(g["verts2"])
     B, N, _ = v1.shape
     random.seed(9001)
@@ -403,7 +403,7 @@ def test_uni3fc_full_size_against_the_oracle(monkeypatch, B, N):
         return idx
 
     monkeypatch.setattr(ops, "knn_neg", tap)
-    monkeypatch.setenv("DVM_NATIVE_FWD", "0")   # the tap sits on the Python-level op: take the layer-by-layer path (== the native call, bit for bit: test_native_forward_is_the_python_path)
+    monkeypatch.setattr(type(net), "native_forward", False)   # the tap sits on the Python-level op: take the layer-by-layer path (== the native call, bit for bit: test_native_forward_is_the_python_path)
     with torch.no_grad():
         feat, cf = net(x.cuda(), dino.cuda(), None)
     assert len(acts) == 7
@@ -434,10 +434,10 @@ def test_native_forward_is_the_python_path(monkeypatch, B, N):
             if isinstance(m, torch.nn.BatchNorm1d):
                 m.running_mean.normal_(0, 0.3), m.running_var.uniform_(0.5, 1.5), m.weight.uniform_(0.7, 1.3), m.bias.normal_(0, 0.2)
     x, dino = torch.rand(B, 3, N).cuda(), torch.randn(B, N, 1152).cuda()
-    monkeypatch.setenv("DVM_NATIVE_FWD", "0")
+    net.native_forward = False
     with torch.no_grad():
         ref, rtmp = net(x, dino, None)
-    monkeypatch.setenv("DVM_NATIVE_FWD", "1")
+    net.native_forward = True
     with torch.no_grad():
         out, otmp = net(x, dino, None)
         assert torch.equal(otmp, rtmp) and torch.equal(out, ref)
@@ -445,7 +445,7 @@ def test_native_forward_is_the_python_path(monkeypatch, B, N):
         net.conv6[0].weight.mul_(0.5)
         net.bn6.running_var.mul_(1.7)
         out2, _ = net(x, dino, None)
-        monkeypatch.setenv("DVM_NATIVE_FWD", "0")
+        net.native_forward = False
         ref2, _ = net(x, dino, None)
     assert torch.equal(out2, ref2) and not torch.equal(out2, out)
 

@@ -397,6 +397,49 @@ def test_pair_forward_equals_two_directions(ops, golden, shape):
         assert torch.equal(o21[k], r21[k]), ("21", k)
 
 
+@pytest.mark.parametrize("shape", [(3, 512, 512), (2, 300, 170), (2, 330, 330), (2, 2048, 2048)])
+@pytest.mark.parametrize("with_map", [True, False])
+def test_pair_pipeline_equals_pair_forward(ops, golden, shape, with_map):
+    """The two-call form (dvm_pair_geometry_f32 on its own stream for batch t + 1 while dvm_pair_fwd_cached_f32 consumes batch t's)
+    over a stream of FIVE different batches through TWO rotating workspaces: every output of every batch bit-identical to the
+    one-call dvm_pair_fwd_f32 — a prefetch is never a cache hit (each batch has its own coordinates and FPS starts), and a
+    workspace is rewritten while the other is being consumed."""
+    B, N, M = shape
+    w = golden("deformer_scape_r_weights")
+    wl = ops.deformer_weight_list(w, "cuda")
+    batches = []
+    for t in range(5):
+        f1, f2, v1, v2, s1 = _pair_inputs(B, N, M, 900 + 7 * t + N)
+        s2 = (torch.arange(B, dtype=torch.int32) * (t + 3)) % M
+        batches.append([x.cuda() for x in (f1, f2, v1, v2, s1, s2)])
+    ref = []
+    for f1, f2, v1, v2, s1, s2 in batches:
+        o12, o21 = ops.pair_forward(wl, f1, f2, v1, v2, 50.0, s1, s2, with_map=with_map)
+        ref.append(({k: v.clone() for k, v in o12.items()}, {k: v.clone() for k, v in o21.items()}))
+    torch.cuda.synchronize()
+    pipe = ops.PairPipeline(wl, B, N, M, with_map=with_map)
+    tk = pipe.prefetch(*batches[0][2:])
+    got = []
+    for t in range(5):
+        nxt = pipe.prefetch(*batches[t + 1][2:]) if t + 1 < 5 else None
+        got.append(pipe.forward(tk, batches[t][0], batches[t][1], 50.0))
+        tk = nxt
+    torch.cuda.synchronize()
+    for t in range(5):
+        for side in (0, 1):
+            for k in ref[t][side]:
+                assert torch.equal(got[t][side][k], ref[t][side][k]), (t, side, k)
+
+
+def test_pair_pipeline_rejects_other_shapes(ops, golden):
+    from dvm._lib import DvmError
+    wl = ops.deformer_weight_list(golden("deformer_scape_r_weights"), "cuda")
+    pipe = ops.PairPipeline(wl, 2, 256, 256)
+    f1, f2, v1, v2, s1 = _pair_inputs(2, 256, 200, 3)
+    with pytest.raises(DvmError):
+        pipe.prefetch(v1.cuda(), v2.cuda(), s1.cuda(), s1.cuda())
+
+
 def test_pair_forward_full_size_vs_oracle(ops, golden):
     """The very call bench.py times — ops.pair_forward at N = M = 2048, d = 128, randn features, alpha = 100, helper-stream
     overlap ON — against the oracle for EVERY pair and both directions: arg-max maps bit-exact, coordinates <= 1e-4,

@@ -42,13 +42,10 @@ def _inputs(B, N, seed):
 
 
 def _run(net, x, dino, native, with_tmp, gf, gt):
-    os.environ["DVM_NATIVE_TRAIN"] = "1" if native else "0"
-    try:
-        feat, tmp = net(x, dino, None)
-        loss = (feat * gf).sum() + ((tmp * gt).sum() if with_tmp else 0.0)
-        loss.backward()
-    finally:
-        os.environ.pop("DVM_NATIVE_TRAIN", None)
+    net.native_train = bool(native)
+    feat, tmp = net(x, dino, None)
+    loss = (feat * gf).sum() + ((tmp * gt).sum() if with_tmp else 0.0)
+    loss.backward()
     return feat.detach(), tmp.detach()
 
 
@@ -103,7 +100,7 @@ def test_native_training_fused_accumulation_over_two_calls():
     ba = FlatGradBucket(list(a.parameters()), attach=True)
     prev = nn_ops.fuse_grad_accumulation(True)
     try:
-        os.environ["DVM_NATIVE_TRAIN"] = "1"
+        a.native_train = True
         f1, _ = a(x1, d1, None)
         f2, _ = a(x2, d2, None)
         ((f1 * gf).sum() + (f2 * gf).sum()).backward()
@@ -111,15 +108,11 @@ def test_native_training_fused_accumulation_over_two_calls():
         mm.join_side_streams(torch.device("cuda", 0))
     finally:
         nn_ops.fuse_grad_accumulation(prev)
-        os.environ.pop("DVM_NATIVE_TRAIN", None)
     assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(ba.params, ba.views))     # still the bucket's views
-    os.environ["DVM_NATIVE_TRAIN"] = "0"
-    try:
-        g1, _ = b(x1, d1, None)
-        g2, _ = b(x2, d2, None)
-        ((g1 * gf).sum() + (g2 * gf).sum()).backward()
-    finally:
-        os.environ.pop("DVM_NATIVE_TRAIN", None)
+    b.native_train = False
+    g1, _ = b(x1, d1, None)
+    g2, _ = b(x2, d2, None)
+    ((g1 * gf).sum() + (g2 * gf).sum()).backward()
     assert torch.equal(f1, g1) and torch.equal(f2, g2)
     _compare(a, b, 2e-4)
 
@@ -184,16 +177,16 @@ def test_deterministic_switch_gives_bit_reproducible_gradients(native):
     assert worst < 1e-3, worst
 
 
-@pytest.mark.parametrize("mode", ["merged", "1"])
-def test_forward_pair_equals_two_calls(mode):
-    """Uni3FC.forward_pair — the step's two network calls as ONE native call with two groups ("merged": BatchNorm statistics,
-    position-encoding range and running-statistics updates per call, in call order), or side by side on two streams with the
-    running statistics deferred ("1") — against two sequential forward() calls on an identical copy: features, second outputs,
-    running statistics and batch counters bit-identical; parameter gradients to summation-order noise."""
+def test_forward_pair_equals_two_calls():
+    """Uni3FC.forward_pair — the step's two network calls as ONE native call with two groups (BatchNorm statistics,
+    position-encoding range and running-statistics updates per call, in call order) — against two sequential forward() calls on
+    an identical copy (merge_pair_calls = False): features, second outputs, running statistics and batch counters bit-identical;
+    parameter gradients to summation-order noise."""
     from dvm import nn_ops
     from dvm.dist import FlatGradBucket
     import models.model as mm
     a, b = _nets(40, seed=7, gain=0.5)
+    b.merge_pair_calls = False
     x1, d1 = _inputs(4, 1024, 31)
     x2, d2 = _inputs(4, 1024, 32)
     g = torch.Generator().manual_seed(9)
@@ -201,24 +194,17 @@ def test_forward_pair_equals_two_calls(mode):
     ba, bb = FlatGradBucket(list(a.parameters()), attach=True), FlatGradBucket(list(b.parameters()), attach=True)
     prev = nn_ops.fuse_grad_accumulation(True)
     try:
-        for _ in range(2):   # twice: the second round reuses the pair streams and the caching allocator's blocks
+        for _ in range(2):   # twice: the second round reuses the helper streams and the caching allocator's blocks
             ba.zero(), bb.zero()
-            os.environ["DVM_PAIR_CALLS"] = mode
-            try:
-                (f1, t1), (f2, t2) = a.forward_pair(x1, d1, x2, d2)
-            finally:
-                os.environ.pop("DVM_PAIR_CALLS", None)
-            node = f1.grad_fn if mode == "1" else f1.grad_fn.next_functions[0][0]      # (merged: the outputs are row slices of ONE node's)
+            (f1, t1), (f2, t2) = a.forward_pair(x1, d1, x2, d2)
+            node = f1.grad_fn.next_functions[0][0]      # (the outputs are row slices of ONE node's)
             assert type(node).__name__ == "_Uni3FCTrainBackward"
             ((f1 * gf1).sum() + (f2 * gf2).sum() + t1.sum()).backward()
             mm.join_side_streams(torch.device("cuda", 0))
-            os.environ["DVM_PAIR_CALLS"] = "0"
-            try:
-                (g1, u1), (g2, u2) = b.forward_pair(x1, d1, x2, d2)
-                ((g1 * gf1).sum() + (g2 * gf2).sum() + u1.sum()).backward()
-                mm.join_side_streams(torch.device("cuda", 0))
-            finally:
-                os.environ.pop("DVM_PAIR_CALLS", None)
+            (g1, u1), (g2, u2) = b.forward_pair(x1, d1, x2, d2)
+            assert g1.grad_fn is not f1.grad_fn and type(g1.grad_fn).__name__ == "_Uni3FCTrainBackward"   # two nodes, one per call
+            ((g1 * gf1).sum() + (g2 * gf2).sum() + u1.sum()).backward()
+            mm.join_side_streams(torch.device("cuda", 0))
             torch.cuda.synchronize()
             assert torch.equal(f1, g1) and torch.equal(f2, g2) and torch.equal(t1, u1) and torch.equal(t2, u2)
             _compare(a, b, 2e-4)

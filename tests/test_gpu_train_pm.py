@@ -108,7 +108,7 @@ def test_train_layouts_agree(monkeypatch):
     d = torch.randn(2, 1024, 1152, generator=g).to(_dev())
     outs = []
     for m, layout in ((net, "pm"), (net2, "cm")):
-        monkeypatch.setenv("DVM_TRAIN_LAYOUT", layout)
+        m.point_major_train = layout == "pm"
         m.train()
         feat, cf = m(x, d)
         (feat.square().mean() + cf.square().mean()).backward()

@@ -1,4 +1,4 @@
-"""profiles/r5_k1_traffic.json from the PMC passes of tools/gpu/profiles_r5.sh: per-launch HBM bytes (and the SQ rows) of pass A of
+"""profiles/r6_k1_traffic.json from the PMC passes of tools/gpu/profiles_r6.sh: per-launch HBM bytes (and the SQ rows) of pass A of
 K1 as bench.py launches it, with the provenance bench.py checks before it reports `roofline.traffic`: the kernel name the library
 reports for the timed launches (dvm_profile_kernel_name(0), taken from the bench line measured in the same script) and the sha256
 of the kernel's source files.  FETCH_SIZE is doubled as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (128-byte
@@ -31,10 +31,18 @@ res = {
     # direction 16 candidate (column, distance) pairs, the two partial softmax sums and the norm fragments (2 x 2048 x 168 B)
     "algorithmic_bytes_per_launch": P * (2 * 2048 * (256 if "softcorr_coarse_kernel" in line["roofline"]["kernel"] else 512) + 2 * 2048 * 168),
     "l2_hit_rate": (per["TCC_HIT_sum"] / (per["TCC_HIT_sum"] + per["TCC_MISS_sum"])) if "TCC_HIT_sum" in per and "TCC_MISS_sum" in per else None,
+    # share of the chip's SIMD time the matrix pipe is busy: SQ_VALU_MFMA_BUSY_CYCLES (summed over the SIMDs) / (the launches' GPU
+    # cycles x 256 CUs x 4 SIMDs); vector instructions issued per matrix instruction
+    "mfma_busy": (per["SQ_VALU_MFMA_BUSY_CYCLES"] / (per["GRBM_GUI_ACTIVE"] * 1024.0)) if "SQ_VALU_MFMA_BUSY_CYCLES" in per and per.get("GRBM_GUI_ACTIVE") else None,
+    "valu_per_mfma": (per["SQ_INSTS_VALU"] / per["SQ_INSTS_MFMA"]) if per.get("SQ_INSTS_MFMA") else None,
+    "gpu_cycles_per_launch": per.get("GRBM_GUI_ACTIVE"),
+    "aggregation": "every counter = sum over the kernels of the slot-0 bracket of (mean over that kernel's launches of the value rocprofv3 "
+                   "reports per dispatch, itself the sum over all XCDs / SEs); one launch = BOTH directions of `pairs` pairs (4x the rows of "
+                   "a 256-pair one-direction run such as tools/gpu/r5_pmc_coarse.sh)",
     "SQ": {k: v for k, v in sorted(per.items()) if k.startswith("SQ_")},
     "kernels_in_bracket": sorted({k for ks in acc.values() for k in ks}),
     "how": "rocprofv3 --kernel-trace --pmc <one group per pass> -- python3 bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-check "
-           "(tools/gpu/profiles_r5.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md; Infinity-Cache hits are counted in FETCH_SIZE",
+           "(tools/gpu/profiles_r6.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md; Infinity-Cache hits are counted in FETCH_SIZE",
 }
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps({k: res[k] for k in ("kernel_slot_name", "source_sha16", "pairs", "bytes_per_launch", "algorithmic_bytes_per_launch", "l2_hit_rate")}))
