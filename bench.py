@@ -341,15 +341,15 @@ def run_pair(args):
     if pipelined:
         batches.append(make_batch(P, 5000 + rank, dev))
         pipe = ops.PairPipeline(wl, P, N_PTS, M_PTS, with_map=True)
-        ticket = pipe.prefetch(*batches[0][2:])
+        resident = torch.cuda.Event()
+        resident.record()                       # both batches are in HBM behind this point
+        ticket = pipe.prefetch(*batches[0][2:], ready=resident)
         tstep = 0
 
     def pstep():
         nonlocal ticket, tstep
         cur, nxt = batches[tstep % 2], batches[(tstep + 1) % 2]
-        nxt_ticket = pipe.prefetch(*nxt[2:])
-        pouts[tstep % 2] = pipe.forward(ticket, cur[0], cur[1], ALPHA, out=pouts[tstep % 2])
-        ticket = nxt_ticket
+        pouts[tstep % 2], ticket = pipe.step(ticket, cur[0], cur[1], ALPHA, next_coords=nxt[2:], ready=resident, out=pouts[tstep % 2])
         tstep += 1
 
     timed_step = pstep if pipelined else step

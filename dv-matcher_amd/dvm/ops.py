@@ -1146,6 +1146,11 @@ def pair_forward(wl, feat1, feat2, verts1, verts2, alpha, start1, start2, with_m
     return o12, o21
 
 
+def check_cus():
+    """Compute units of the current device."""
+    return torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+
+
 class PairPipeline:
     """The pair forward as a two-stage software pipeline over a stream of batches: stage 1 = the coordinate-only geometry of a
     batch (dvm_pair_geometry_f32: FPS -> node grid -> ring -> influence -> skinning, vertex grid, xyz kNN) on a stream of its own,
@@ -1155,10 +1160,14 @@ class PairPipeline:
     reference (models/loss.py:1325-1337), only one stage earlier; outputs are bit-identical to pair_forward.
 
         pipe = PairPipeline(wl, B, N, M)
-        tk = pipe.prefetch(v1, v2, s1, s2)                    # batch 0
-        for each batch:  nxt = pipe.prefetch(<next batch's coordinates>);  o12, o21 = pipe.forward(tk, f1, f2, alpha);  tk = nxt
+        tk = pipe.prefetch(v1, v2, s1, s2, ready=ev)          # batch 0
+        for each batch:  (o12, o21), tk = pipe.step(tk, f1, f2, alpha, next_coords=(v1', v2', s1', s2'), ready=ev')
 
-    `depth` workspaces (default 2) rotate; a ticket must be consumed by forward() before `depth` further prefetches."""
+    step() enqueues the two stages in the order (`schedule`) that measured faster for the batch size (bench.py --pairs 32 ... 512,
+    profiles/r6_pipeline_order.txt): "geometry first" while its FPS workgroups (one per cloud) fit the compute units once — the
+    dependent FPS chain is then the long pole and must start at once —, "features first" beyond (the chip is throughput-bound and
+    the sweep, enqueued first, is disturbed less).  `depth` workspaces (default 2) rotate; a ticket must be consumed by forward()
+    before `depth` further prefetches."""
 
     def __init__(self, wl, B, N, M, with_map=True, depth=2, device=None):
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
@@ -1171,9 +1180,12 @@ class PairPipeline:
         with torch.cuda.stream(self.geo):
             check(lib.dvm_pair_init(_stream()), "dvm_pair_init")      # the geometry stream's own helper stream / events
         self.n = 0
+        self.schedule = "geometry first" if 2 * self.B <= check_cus() else "features first"
 
-    def prefetch(self, verts1, verts2, start1, start2):
-        """Enqueue stage 1 for a batch; -> ticket for forward()."""
+    def prefetch(self, verts1, verts2, start1, start2, ready=None):
+        """Enqueue stage 1 for a batch; -> ticket for forward().  ready: a torch.cuda.Event behind which the coordinates and starts are
+        valid (e.g. recorded when the batch was loaded); None = behind everything enqueued on the current stream so far — which, called
+        after a forward(), is the END of that forward: no overlap with it (pass `ready` to pipeline)."""
         _need_gpu(verts1, verts2, start1, start2)
         verts1, verts2, start1, start2 = _f(verts1), _f(verts2), _i(start1), _i(start2)
         if tuple(verts1.shape) != (self.B, self.N, 3) or tuple(verts2.shape) != (self.B, self.M, 3):
@@ -1182,7 +1194,10 @@ class PairPipeline:
         slot = self.n % len(self.ws)
         self.n += 1
         cur = torch.cuda.current_stream(self.dev)
-        self.geo.wait_stream(cur)                       # the coordinates were produced on the caller's stream
+        if ready is None:
+            self.geo.wait_stream(cur)                   # the coordinates were produced on the caller's stream
+        else:
+            self.geo.wait_event(ready)
         if self.free[slot] is not None:
             self.geo.wait_event(self.free[slot])        # the workspace's previous consumer is done
         with torch.cuda.stream(self.geo):
@@ -1220,3 +1235,14 @@ class PairPipeline:
         ev.record(cur)
         self.free[slot] = ev
         return o12, o21
+
+    def step(self, ticket, feat1, feat2, alpha, next_coords=None, ready=None, out=None):
+        """forward(ticket, ...) and prefetch(*next_coords, ready=ready) in the order that suits the batch size
+        -> ((out12, out21), next ticket or None)."""
+        if next_coords is None:
+            return self.forward(ticket, feat1, feat2, alpha, out=out), None
+        if self.schedule == "geometry first":
+            nxt = self.prefetch(*next_coords, ready=ready)
+            return self.forward(ticket, feat1, feat2, alpha, out=out), nxt
+        outs = self.forward(ticket, feat1, feat2, alpha, out=out)
+        return outs, self.prefetch(*next_coords, ready=ready)

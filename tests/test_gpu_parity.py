@@ -417,18 +417,24 @@ def test_pair_pipeline_equals_pair_forward(ops, golden, shape, with_map):
         o12, o21 = ops.pair_forward(wl, f1, f2, v1, v2, 50.0, s1, s2, with_map=with_map)
         ref.append(({k: v.clone() for k, v in o12.items()}, {k: v.clone() for k, v in o21.items()}))
     torch.cuda.synchronize()
-    pipe = ops.PairPipeline(wl, B, N, M, with_map=with_map)
-    tk = pipe.prefetch(*batches[0][2:])
-    got = []
-    for t in range(5):
-        nxt = pipe.prefetch(*batches[t + 1][2:]) if t + 1 < 5 else None
-        got.append(pipe.forward(tk, batches[t][0], batches[t][1], 50.0))
-        tk = nxt
-    torch.cuda.synchronize()
-    for t in range(5):
-        for side in (0, 1):
-            for k in ref[t][side]:
-                assert torch.equal(got[t][side][k], ref[t][side][k]), (t, side, k)
+    loaded = torch.cuda.Event()
+    loaded.record()
+    for order in ("step", "geometry first", "features first", "no ready event"):
+        pipe = ops.PairPipeline(wl, B, N, M, with_map=with_map)
+        ready = None if order == "no ready event" else loaded
+        if order in ("geometry first", "features first"):
+            pipe.schedule = order
+        tk = pipe.prefetch(*batches[0][2:], ready=ready)
+        got = []
+        for t in range(5):
+            outs, tk = pipe.step(tk, batches[t][0], batches[t][1], 50.0, next_coords=batches[t + 1][2:] if t + 1 < 5 else None, ready=ready)
+            got.append(outs)
+        assert tk is None
+        torch.cuda.synchronize()
+        for t in range(5):
+            for side in (0, 1):
+                for k in ref[t][side]:
+                    assert torch.equal(got[t][side][k], ref[t][side][k]), (order, t, side, k)
 
 
 def test_pair_pipeline_rejects_other_shapes(ops, golden):
