@@ -6,7 +6,9 @@ Default workload (BASELINE.json configs[1]): synthetic random pairs, N = M = 204
   graph(verts) -> soft correspondence (top-10) -> Pi@verts -> xyz kNN -> Deformer -> ED warp +
   ARAP -> 2x Chamfer (+ map term),
 i.e. GraphDeformLoss_Neural.deform() x2 without the dumps (reference models/loss.py:1401-1411).
-A "step" is one pass over a resident batch of pairs; inputs are in HBM before the timed region.
+A "step" is one pass over a resident batch of pairs; inputs are in HBM before the timed region.  The timed form is a
+two-stage pipeline over two alternating resident batches (ops.PairPipeline: the graphs of batch t + 1 are built while
+the feature half of batch t runs; nothing is cached); `single_call` reports the one-call form beside it.
 
   python bench.py [--gpus N --steps K --warmup W --pairs P | --pairs-total T] [--workload pair|train|partial]
 
@@ -23,12 +25,13 @@ timing mode: forward + criterion + backward + all-reduce + Adam), one JSON line 
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the soft-correspondence sweep, pass A
 of K1), its launch time measured with HIP events on the launch stream inside the timed region; `frac` =
-flops performed on the f16 matrix pipe / its dense peak, `algorithmic` = SURVEY §8d's flops against the fp32
-matrix peak; `roofline.kernels` = the other kernels of the step, event-timed the same way over 3 extra steps
+flops performed on the f16 matrix pipe / its dense peak, `algorithmic_frac_f16` = SURVEY §8d's flops against the
+same peak; `roofline.kernels` = the other kernels of the step, event-timed the same way over 3 extra steps
 after the timed region.  `checked_pairs`: after the timed region 4 seeded-random pairs of the very batch that was
 timed are recomputed by the CPU oracle and compared (arg-max maps bit-exact, coordinates <= 1e-4, losses rtol
 1e-3); `cpu_baseline` is the same oracle ("port": a C/OpenMP restatement of the reference's algorithm)
-timed on a bounded sample of pairs of that same batch.
+timed on a bounded sample of pairs of that same batch, with a second figure `cpu_baseline.aten`: the same pairs in the
+reference's dense ATen / MKL formulation on all host threads.
 """
 import argparse
 import ctypes
@@ -214,6 +217,28 @@ def oracle_legs(timed, sample_pairs, check_pairs):
                "sample": "%d pairs of the timed batches (the %d checked ones + the first %d; N=M=%d, d=%d, both directions), C oracle "
                          "with OpenMP: a scalar k-ordered fmaf chain per distance, the arithmetic the parity tests pin (%.1f s)"
                          % (sample_pairs, min(check_pairs, sample_pairs), max(0, sample_pairs - check_pairs), N_PTS, DIM, dt)}
+    if cpu is not None:
+        # second figure: the same pairs in the reference's dense ATen / MKL formulation on every host thread (cdist, softmax, topk,
+        # matmul: what the reference's CPU run executes; oracle/torch_ref.py::pair_direction_aten, pinned to the C oracle by
+        # tests/test_modules_cpu.py) — bounded to a few pairs
+        import torch
+        from oracle import torch_ref as TR
+        n_aten = min(8, sample_pairs)
+        f1, f2, v1, v2, s1, s2 = host[ids[0]]
+        TR.pair_direction_aten(w, f1[:256], f2[:256], v1[:256], v2[:256], ALPHA, 0)   # warm up
+        ta = time.perf_counter()
+        agree = True
+        for n, bp in enumerate(ids[:n_aten]):
+            f1, f2, v1, v2, s1, s2 = host[bp]
+            a12 = TR.pair_direction_aten(w, f1, f2, v1, v2, ALPHA, int(s1))
+            TR.pair_direction_aten(w, f2, f1, v2, v1, ALPHA, int(s2))
+            if n < len(kept):
+                agree = agree and float(np.abs(a12["losses"] - kept[n][1]["losses"]).max() / np.abs(kept[n][1]["losses"]).max()) < 1e-3
+        dta = time.perf_counter() - ta
+        cpu["aten"] = {"value": n_aten / dta, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+                       "losses_agree_with_c_oracle": bool(agree),
+                       "sample": "%d of those pairs, both directions, dense N x M tensors on ATen / MKL as the reference's CPU run computes "
+                                 "them (graphs from the C oracle: the reference's Python FPS loop + KDTree is not charged) (%.1f s)" % (n_aten, dta)}
     return check, cpu
 
 

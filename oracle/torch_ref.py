@@ -244,3 +244,75 @@ def dg_warp_arap(verts, g, R, T):
     rest_offset = nodes.unsqueeze(2) - ring_rest
     residual = (nodes + T).unsqueeze(2) - (ring_rest + ring_shift) - torch.einsum("bnij,bnqj->bnqi", R, rest_offset)
     return warped, residual.square().sum(dim=(1, 2, 3)) / Nn
+
+
+def deform_terms_dense(feat_s, feat_t, verts_s, verts_t, alpha, g, knn_s, knn_t, dparams, with_map=True, topk=10, cols_out=None):
+    """One direction of GraphDeformLoss_Neural.deform() for P pairs in the reference's DENSE formulation, differentiable, in the dtype
+    of its inputs (run it in float64 as the checker of dvm_criterion_[dir_]train_{fwd,bwd}_f32): models/loss.py:110-114 + 1339-1347
+    (Pi = topk10(softmax(-alpha cdist))), :1408-1409 (Pi @ verts), models/model.py:454-478 (Deformer: Conv2d(k->1) pooling of the xyz
+    neighbours' features, Pi @ pooled targets, node rows [v, g, verts12, Pi g], MLP with ELU), models/loss.py:1258-1264 + 39-45 (rot6d
+    + identity), lib/deformation_graph_point.py:233-261 (warp, ARAP), models/loss.py:1216-1226 (Chamfer), :1237 (map term).
+    feat_s (P,N,C), feat_t (P,M,C), verts_* (P,*,3); g = the SOURCES' batched graph (nodes_idx, one_ring, infl_idx, weights: constants);
+    knn_s (P,N,k) / knn_t (P,M,k) xyz-kNN (constants); dparams = [conv_w (k,), conv_b (1,), W0, b0, W1, b1, W2, b2, W3, b3].
+    -> terms (P,6): [map numerator, mean d(warped->t), mean d(t->warped), mean d(verts12->t), mean d(t->verts12), ARAP]
+    (the first six columns of the native node's table).  One pair at a time: the N x M matrices of a 4995 x 2200 pair are 88 MB each."""
+    P, N, C = feat_s.shape
+    M = feat_t.shape[1]
+    conv_w, conv_b, W0, b0, W1, b1, W2, b2, W3, b3 = dparams
+    rows = []
+    iden = torch.tensor([1, 0, 0, 0, 1, 0], dtype=feat_s.dtype, device=feat_s.device)
+    for p in range(P):
+        f1, f2, v1, v2 = feat_s[p], feat_t[p], verts_s[p], verts_t[p]
+        pi = torch.softmax(-alpha * torch.cdist(f1[None], f2[None])[0], dim=-1)
+        val, col = torch.topk(pi, topk, dim=-1)                                   # (N,10): kept values, no renormalisation
+        if cols_out is not None:
+            cols_out.append(col)                                                   # (column 0 = the arg-max map)
+        v12 = (val.unsqueeze(-1) * v2[col]).sum(1)                                 # Pi @ verts2
+        i11, i22 = knn_s[p].long(), knn_t[p].long()
+        g1 = (f1[i11] * conv_w.view(1, -1, 1)).sum(1) + conv_b                     # Conv2d(k -> 1, 1x1) over the neighbours
+        g2 = (f2[i22] * conv_w.view(1, -1, 1)).sum(1) + conv_b
+        nodes = g["nodes_idx"][p].long()
+        g12n = (val[nodes].unsqueeze(-1) * g2[col[nodes]]).sum(1)                  # (Pi @ g2) at the nodes
+        z = torch.cat([v1[nodes], g1[nodes], v12[nodes], g12n], dim=-1)
+        h = F.elu(F.linear(z, W0, b0))
+        h = F.elu(F.linear(h, W1, b1))
+        h = F.elu(F.linear(h, W2, b2))
+        d9 = F.linear(h, W3, b3)
+        gp = {k: g[k][p:p + 1] for k in ("nodes_idx", "one_ring", "infl_idx", "weights")}
+        warped, arap = dg_warp_arap(v1[None], gp, rot6d(d9[None, :, 3:] + iden), d9[None, :, :3])
+        cd = []
+        for a in (warped[0], v12):
+            D = (a.unsqueeze(1) - v2.unsqueeze(0)).square().sum(-1)               # squared distances (chamfer_3DDist semantics)
+            cd += [D.min(1)[0].mean(), D.min(0)[0].mean()]
+        if with_map:
+            # einsum('bij,bjkm->bikm', Pi, verts2[idx22]) against verts12[idx11]   (models/loss.py:1237, 1410)
+            rhs = (val.view(N, topk, 1, 1) * v2[i22[col]]).sum(1)                  # (N,k,3)
+            mp = (v12[i11] - rhs).square().sum()
+        else:
+            mp = v12.sum() * 0
+        rows.append(torch.stack([mp, cd[0], cd[1], cd[2], cd[3], arap[0]]))
+    return torch.stack(rows)
+
+
+def pair_direction_aten(weights, feat1, feat2, verts1, verts2, alpha, fps_start, with_map=True):
+    """One direction of the pair path (BASELINE configs[1]) the way the REFERENCE'S CPU RUN executes it: dense N x M tensors on ATen /
+    MKL with every host thread (cdist, softmax, topk, matmul — deform_terms_dense above), the xyz kNN as cdist + topk
+    (models/loss.py:97-101).  The deformation graph comes from the C oracle (oracle.dg_build: the reference's Python FPS loop + scipy
+    KDTree takes 0.14 - 0.40 s per shape, SURVEY §8a-13 — this leg does not charge it).  bench.py times it as the second, BLAS-backed
+    cpu_baseline figure beside the scalar-chain C oracle; tests/test_modules_cpu.py pins its outputs to that oracle's.
+    numpy in (one pair: feat (N,128) / (M,128), verts (N,3) / (M,3)) -> dict(T12, losses[6]) with the C oracle's layout:
+    [mean d(warped->t), mean d(t->warped), ARAP, mean d(verts12->t), mean d(t->verts12), map numerator]."""
+    import numpy as np
+    from . import oracle as O
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))  # noqa: E731
+    f1, f2, v1, v2 = t(feat1), t(feat2), t(verts1), t(verts2)
+    with torch.no_grad():
+        g = O.dg_build(verts1, fps_start)
+        gt = {k: torch.from_numpy(np.ascontiguousarray(g[k]))[None] for k in ("nodes_idx", "one_ring", "infl_idx", "weights")}
+        knn_s = torch.cdist(v1[None], v1[None])[0].topk(10, dim=-1, largest=False)[1][None]
+        knn_t = torch.cdist(v2[None], v2[None])[0].topk(10, dim=-1, largest=False)[1][None]
+        cw, cb, mats = O._mlp_args(weights)
+        dparams = [torch.from_numpy(cw), torch.tensor([cb])] + [torch.from_numpy(m) for m in mats]
+        cols = []
+        terms = deform_terms_dense(f1[None], f2[None], v1[None], v2[None], float(alpha), gt, knn_s, knn_t, dparams, with_map, cols_out=cols)[0]
+    return dict(T12=cols[0][:, 0].numpy().astype(np.int32), losses=terms[[1, 2, 5, 3, 4, 0]].numpy())

@@ -145,3 +145,104 @@ def test_native_criterion_second_backward_is_refused():
     out[0].backward(retain_graph=True)
     with pytest.raises(RuntimeError, match="backward ran already"):
         out[0].backward()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Contract-size gradient parity against something OTHER than the repo's own per-op path (VERDICT r5 "weak 1"): the node's table
+# of per-pair terms and its gradients w.r.t. the features and the Deformer against a float64 autograd run of the reference's DENSE
+# formulation (oracle/torch_ref.py::deform_terms_dense + dist_loss_term; test infrastructure), contracted with a fixed random
+# positive weight per term.  Bar: the same dense formulation run in float32 (what the reference itself computes, on ATen) against
+# float64 — the node must be within 3x that noise (floor 2e-3 of the gradient's norm: discrete top-10 / nearest-neighbour flips).
+def _dense_reference(dtype, feat_s, feat_t, verts_s, verts_t, alpha, g, knn_s, knn_t, params, with_map, G, dist=None):
+    from oracle import torch_ref as TR
+    fs = feat_s.detach().to(dtype).requires_grad_(True)
+    ft = fs if feat_t is None else feat_t.detach().to(dtype).requires_grad_(True)
+    ps = [p.detach().to(dtype).requires_grad_(True) for p in params]
+    gg = {k: (v.to(dtype) if v.dtype.is_floating_point else v) for k, v in g.items()}
+    conv_w = ps[0].reshape(-1)
+    if feat_t is None:      # the full node: targets = the other half's sources
+        B = fs.shape[0] // 2
+        swap = lambda t: torch.cat([t[B:], t[:B]], 0)  # noqa: E731
+        terms = TR.deform_terms_dense(fs, swap(fs), verts_s.to(dtype), swap(verts_s).to(dtype), alpha, gg, knn_s, swap(knn_s),
+                                      [conv_w, ps[1].reshape(-1)] + ps[2:], with_map)
+    else:
+        terms = TR.deform_terms_dense(fs, ft, verts_s.to(dtype), verts_t.to(dtype), alpha, gg, knn_s, knn_t, [conv_w, ps[1].reshape(-1)] + ps[2:], with_map)
+    if dist is not None:
+        d1, d2, a1, a2, kd = dist
+        B = fs.shape[0] // 2
+        dt = torch.cat([TR.dist_loss_term(fs[:B], d1.to(dtype), a1.long(), kd), TR.dist_loss_term(fs[B:], d2.to(dtype), a2.long(), kd)])
+        terms = torch.cat([terms, dt.unsqueeze(1)], 1)
+    (terms * G[:, :terms.shape[1]].to(dtype)).sum().backward()
+    grads = [fs.grad] + ([] if feat_t is None else [ft.grad]) + [p.grad for p in ps]
+    return terms.detach(), grads
+
+
+def _check_against_dense(name, got_terms, got_grads, ref64, ref32):
+    t64, g64 = ref64
+    t32, g32 = ref32
+    ncol = t64.shape[1]
+    tn = float((t32.double() - t64).abs().max() / t64.abs().max())
+    te = float((got_terms[:, :ncol].double() - t64).abs().max() / t64.abs().max())
+    assert te <= max(3 * tn, 1e-4), (name, "terms", te, tn)
+    worst = []
+    for i, (a, r64, r32) in enumerate(zip(got_grads, g64, g32)):
+        noise = float((r32.double() - r64).norm() / r64.norm())
+        err = float((a.double().reshape(r64.shape) - r64).norm() / r64.norm())
+        worst.append((i, err, noise))
+        assert err <= max(3 * noise, 2e-3), (name, "gradient %d" % i, err, noise)
+    print("%s: terms %.2e (fp32 dense reference: %.2e); gradients (index, node vs fp64, fp32 dense vs fp64): %s"
+          % (name, te, tn, ", ".join("(%d, %.1e, %.1e)" % w for w in worst)))
+
+
+def test_native_criterion_gradients_vs_float64_dense_reference_full_size():
+    """8 x 2048 (BASELINE configs[2]): dvm_criterion_train_{fwd,bwd}_f32 incl. the dist term (N_dist 1000, k_dist 500: config/scape_r.yaml)."""
+    from dvm import nn_ops, ops
+    from dvm.ops import DEFORMER_KEYS
+    import models.model as mm
+    B, N = 8, 2048
+    g = torch.Generator().manual_seed(4242)
+    v = (torch.rand(2 * B, N, 3, generator=g) - 0.5).cuda()
+    feat = (0.3 * torch.relu(torch.randn(2 * B, N, 128, generator=g))).cuda().requires_grad_(True)
+    torch.manual_seed(5)
+    d = mm.Deformer(10).cuda().train()
+    named = dict(d.named_parameters())
+    params = [named[k] for k in DEFORMER_KEYS]
+    graph = ops.dg_build(v, torch.randint(0, N, (2 * B,), generator=g).int().cuda())
+    gj = {k: graph[k] for k in ("nodes_idx", "one_ring", "infl_idx", "weights")}
+    knn = ops.knn_cdist(v, v, 10)
+    dist1, dist2 = torch.cdist(v[:B], v[:B]).contiguous(), torch.cdist(v[B:], v[B:]).contiguous()
+    a1 = torch.tensor(random.Random(1).sample(range(N), 1000), dtype=torch.int32).cuda()
+    a2 = torch.tensor(random.Random(2).sample(range(N), 1000), dtype=torch.int32).cuda()
+    G = (0.5 + torch.rand(2 * B, 7, generator=g)).cuda() * torch.tensor([1e-3, 1.0, 1.0, 1.0, 1.0, 1e-2, 1e-2]).cuda()
+    alpha = 80.0
+    terms = nn_ops.criterion_train((v, gj, knn, alpha, 10, True, (dist1, dist2, a1, a2, 500)), feat, params)
+    (terms * G).sum().backward()
+    got = [feat.grad] + [p.grad for p in params]
+    args = (feat, None, v, None, alpha, gj, knn, None, params, True, G, (dist1, dist2, a1, a2, 500))
+    _check_against_dense("criterion node 8 x 2048", terms.detach(), got, _dense_reference(torch.float64, *args), _dense_reference(torch.float32, *args))
+
+
+def test_directional_node_gradients_vs_float64_dense_reference_contract_size():
+    """1 x 4995 x 2200 (BASELINE configs[3], one direction of GraphDeformLoss_Neural_Partial): dvm_criterion_dir_train_{fwd,bwd}_f32."""
+    from dvm import nn_ops, ops
+    from dvm.ops import DEFORMER_KEYS
+    import models.model as mm
+    N, M = 4995, 2200
+    g = torch.Generator().manual_seed(99)
+    vs, vt = (torch.rand(1, N, 3, generator=g) - 0.5).cuda(), (torch.rand(1, M, 3, generator=g) - 0.5).cuda()
+    fs = (0.3 * torch.relu(torch.randn(1, N, 128, generator=g))).cuda().requires_grad_(True)
+    ft = (0.3 * torch.relu(torch.randn(1, M, 128, generator=g))).cuda().requires_grad_(True)
+    torch.manual_seed(6)
+    d = mm.Deformer(10).cuda().train()
+    named = dict(d.named_parameters())
+    params = [named[k] for k in DEFORMER_KEYS]
+    graph = ops.dg_build(vs, torch.tensor([17], dtype=torch.int32).cuda())
+    gj = {k: graph[k] for k in ("nodes_idx", "one_ring", "infl_idx", "weights")}
+    ks, kt = ops.knn_cdist(vs, vs, 10), ops.knn_cdist(vt, vt, 10)
+    G = (0.5 + torch.rand(1, 7, generator=g)).cuda() * torch.tensor([0.0, 1.0, 1.0, 1.0, 1.0, 1e-2, 0.0]).cuda()
+    alpha = 60.0
+    terms = nn_ops.criterion_dir_train((vs, vt, gj, ks, kt, alpha, 10, False), fs, ft, params)
+    (terms * G).sum().backward()
+    got = [fs.grad, ft.grad] + [p.grad for p in params]
+    args = (fs, ft, vs, vt, alpha, gj, ks, kt, params, False, G)
+    _check_against_dense("directional node 4995 x 2200", terms.detach(), got, _dense_reference(torch.float64, *args), _dense_reference(torch.float32, *args))

@@ -204,3 +204,19 @@ def test_train_pointer_table_cache_follows_the_parameters():
     st4 = net._train_state()
     net.invalidate_train_state()
     assert net._train_state() is not st4
+
+
+def test_aten_cpu_leg_matches_the_c_oracle(golden):
+    """bench.py's second cpu_baseline figure (oracle/torch_ref.py::pair_direction_aten: the pair path in the reference's dense ATen
+    formulation) computes what the C oracle computes: arg-max map equal up to fp32 ties of the two cdist forms, losses to 1e-4."""
+    from oracle import oracle as O
+    w = golden("deformer_scape_r_weights")
+    g = torch.Generator().manual_seed(31)
+    N, M = 384, 300
+    f1, f2 = torch.randn(N, 128, generator=g).numpy(), torch.randn(M, 128, generator=g).numpy()
+    v1, v2 = torch.rand(N, 3, generator=g).numpy(), torch.rand(M, 3, generator=g).numpy()
+    for with_map in (True, False):
+        a = TR.pair_direction_aten(w, f1, f2, v1, v2, 100.0, 5, with_map=with_map)
+        o = O.pair_direction(w, f1, f2, v1, v2, 100.0, 5, with_map=with_map)
+        assert (a["T12"] != o["T12"]).mean() < 5e-3
+        np.testing.assert_allclose(a["losses"], o["losses"], rtol=2e-4, atol=1e-7)
