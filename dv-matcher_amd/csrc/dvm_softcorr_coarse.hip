@@ -16,11 +16,11 @@
 // Structure (the tile staging, the norm instruction, the exact keys and the selection network come from the three-product
 // "second form" of rounds 3 - 4, which this kernel replaced: profiles/notes_k1.md):
 //  * a wave owns 2 blocks of 32 query rows (64 VGPRs of query fragments, as the two-plane form needs for one block): every
-//    key fragment read from LDS feeds two matrix instructions, and a workgroup of 8 waves covers 512 query rows, so a pair's key
-//    plane is staged 4 times instead of 8;
+//    key fragment read from LDS feeds two matrix instructions, and a workgroup of 4 waves covers 256 query rows (a pair's key plane is
+//    staged 8 times; two such workgroups share a compute unit — HC_WAVES below);
 //  * key tiles of 64 keys x 256 B by LDS-DMA (buffer_load ... lds: two 1-KiB pieces per wave and tile + the norm fragments),
 //    16-B chunks XOR-swizzled with the row number: a 256-byte row is one full bank row, the swizzle spreads the 16 rows of a
-//    ds_read_b128 lane group over the 16 chunk positions; the two waves of a SIMD issue their pieces half a tile apart;
+//    ds_read_b128 lane group over the 16 chunk positions; the two halves of a workgroup's waves issue their pieces half a tile apart;
 //  * norms on the matrix pipe (a 9th instruction per block), exact 32-bit keys (accumulator bits + register number), a fixed
 //    selection network for the sorted three smallest of a lane's 16 keys: 46 three-input min / med / max instructions;
 //  * 32-bit list entries [key: 19 bits | sub-tile: 8 | half: 1 | register: 4]: a sorted insertion is ONE v_med3_u32 per slot
@@ -53,9 +53,14 @@ constexpr unsigned HC_EMASK = 0xffffe00fu;     // bits of a key that survive in 
 constexpr int HC_MAX_M = 256 * 32;             // 8 bits of sub-tile number
 
 constexpr int HC_QB = 2;                       // blocks of 32 query rows per wave
-constexpr int HC_WAVES = 8;                    // waves per workgroup: 512 query rows
-constexpr int HC_NREC = 32;                    // third-key records per lane and block (64 KB of LDS in all)
-template <int KT> constexpr int hc_lds_bytes() { return 2 * KT * HC_ROWB + 2 * KT * 32 + 1024 + HC_WAVES * HC_QB * HC_NREC * 64 * 2; }
+constexpr int HC_NREC = 32;                    // third-key records per lane and block (8 KB of LDS per wave)
+// Waves per workgroup: 4, i.e. 256 query rows and 71 KB of LDS — TWO independent workgroups per compute unit, one wave of each per SIMD
+// (round 6).  With one 8-wave workgroup (512 rows, 103 KB; rounds 4 - 5) both waves of a SIMD stand at the same barrier and the same
+// LDS-DMA issue; two workgroups in different phases fill each other's dead time: 1.74 -> 1.63 ms per launch of 512 pairs alone,
+// 2.30 -> 2.20 ms inside the step — for twice the L2 -> LDS staging of the key plane (8 instead of 4 times per pair: L2 hits).
+constexpr int HC_WAVES = 4;
+// W = waves per workgroup: 64 W query rows
+template <int KT, int W> constexpr int hc_lds_bytes() { return 2 * KT * HC_ROWB + 2 * KT * 32 + 1024 + W * HC_QB * HC_NREC * 64 * 2; }
 
 struct HCGroup {
     const char *qp, *kp;      // planes of the query / key side [B][rows][512]: h plane = the first 256 B of a row
@@ -177,9 +182,9 @@ __device__ __forceinline__ int entry_col(unsigned e) {
 // Phases: 0 LDS-DMA issue, 1 matrix chain + epilogue (until the accumulators are readable), 3 re-done sub-tiles, 5 barrier
 // (incl. the wait for the wave's own DMA pieces), 6 whole kernel, 7 sub-tiles (re-done records counted in the high bits).
 // KT: keys per LDS tile (a multiple of 64: an even number of 32-key sub-tiles between two barriers).
-template <int KT, bool STAMP = false>
-__global__ __launch_bounds__(64 * HC_WAVES, 1) void softcorr_coarse_kernel(const HCArgs args) {
-    constexpr int QB = HC_QB, W = HC_WAVES, NREC = HC_NREC, ROWS = 32 * QB * W, SUBS = KT / 32;
+template <int KT, int W, bool STAMP = false>
+__global__ __launch_bounds__(64 * W, 8 / W) void softcorr_coarse_kernel(const HCArgs args) {
+    constexpr int QB = HC_QB, NREC = HC_NREC, ROWS = 32 * QB * W, SUBS = KT / 32;
     static_assert(SUBS % 2 == 0 && KT * HC_ROWB / 1024 % W == 0 && KT * 32 / 1024 <= W, "coarse screen: tile size");
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
     unsigned long long T[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0, tstart = 0;
@@ -552,8 +557,10 @@ __global__ __launch_bounds__(64 * HC_WAVES, 1) void softcorr_coarse_kernel(const
         for (int t = 0; t < HC_KL; ++t) out.insert((unsigned)__shfl_xor((int)kb[qb].e[t], 32, 64));
         if (h == 0 && qrow[qb] < N) {
             const size_t row = (size_t)b * N + qrow[qb];
-            // (16-byte stores: a row's 16 columns / distances are 64 contiguous bytes — as 4-byte stores, one per lane and entry at a
-            // 64-byte stride, the launch wrote 554 MB for 285 MB of lists)
+            // (16-byte stores: a row's 16 columns / distances are 64 contiguous bytes.  Round 6: transposing the block's 32 rows through LDS so
+            // that every store instruction covers 1 KiB of consecutive addresses changed neither the launch time nor WRITE_SIZE
+            // (0.55 -> 0.59 GB for 0.27 GB of lists) and was removed: the excess is the kernel's scratch — 36 spilled registers,
+            // 148 B per lane, written once per wave = 0.31 GB per launch — not partial lines)
             typedef int i32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
             for (int q = 0; q < K1_KC_COARSE / 4; ++q) {
@@ -579,15 +586,15 @@ __global__ __launch_bounds__(64 * HC_WAVES, 1) void softcorr_coarse_kernel(const
     if (STAMP) {
         T[6] = __builtin_amdgcn_s_memtime() - tstart;
         if (lane == 0 && args.stamps)
-            for (int i = 0; i < 8; ++i) args.stamps[((size_t)blockIdx.x * HC_WAVES + wave) * 8 + i] = T[i];
+            for (int i = 0; i < 8; ++i) args.stamps[((size_t)blockIdx.x * W + wave) * 8 + i] = T[i];
     }
 }
 
-template <int KT, bool STAMP>
+template <int KT, int W, bool STAMP>
 static void launch_form(const HCArgs &a, int blocks, hipStream_t s) {
-    const int lds = hc_lds_bytes<KT>();
-    ensure_dyn_lds((const void *)softcorr_coarse_kernel<KT, STAMP>, lds);
-    hipLaunchKernelGGL((softcorr_coarse_kernel<KT, STAMP>), dim3(blocks), dim3(64 * HC_WAVES), lds, s, a);
+    const int lds = hc_lds_bytes<KT, W>();
+    ensure_dyn_lds((const void *)softcorr_coarse_kernel<KT, W, STAMP>, lds);
+    hipLaunchKernelGGL((softcorr_coarse_kernel<KT, W, STAMP>), dim3(blocks), dim3(64 * W), lds, s, a);
 }
 
 }  // namespace
@@ -621,7 +628,7 @@ void launch_coarse(const HBArgs &a, const char *knf0, const char *knf1, const in
         if (hipMalloc(&dbuf, n * sizeof(unsigned long long)) != hipSuccess) return;
         (void)hipMemset(dbuf, 0, n * sizeof(unsigned long long));
         c.stamps = dbuf;
-        launch_form<kt, true>(c, nblocks, s);
+        launch_form<kt, HC_WAVES, true>(c, nblocks, s);
         (void)hipStreamSynchronize(s);
         unsigned long long *hbuf = (unsigned long long *)malloc(n * sizeof(unsigned long long));
         (void)hipMemcpy(hbuf, dbuf, n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
@@ -643,7 +650,7 @@ void launch_coarse(const HBArgs &a, const char *knf0, const char *knf1, const in
         (void)hipFree(dbuf);
         return;
     }
-    launch_form<kt, false>(c, nblocks, s);
+    launch_form<kt, HC_WAVES, false>(c, nblocks, s);
 }
 
 }  // namespace k1

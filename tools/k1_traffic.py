@@ -32,10 +32,14 @@ res = {
     "algorithmic_bytes_per_launch": P * (2 * 2048 * (256 if "softcorr_coarse_kernel" in line["roofline"]["kernel"] else 512) + 2 * 2048 * 168),
     "l2_hit_rate": (per["TCC_HIT_sum"] / (per["TCC_HIT_sum"] + per["TCC_MISS_sum"])) if "TCC_HIT_sum" in per and "TCC_MISS_sum" in per else None,
     # share of the chip's SIMD time the matrix pipe is busy: SQ_VALU_MFMA_BUSY_CYCLES (summed over the SIMDs) / (the launches' GPU
-    # cycles x 256 CUs x 4 SIMDs); vector instructions issued per matrix instruction
-    "mfma_busy": (per["SQ_VALU_MFMA_BUSY_CYCLES"] / (per["GRBM_GUI_ACTIVE"] * 1024.0)) if "SQ_VALU_MFMA_BUSY_CYCLES" in per and per.get("GRBM_GUI_ACTIVE") else None,
+    # cycles x 256 CUs x 4 SIMDs), the cycles of the launch AS PROFILED (counter passes run the kernels one at a time: the launch
+    # alone); vector instructions issued per matrix instruction
+    # (rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs: cycles = GRBM / 8, SIMD-cycles = cycles x 1024 = GRBM x 128)
+    "mfma_busy": (per["SQ_VALU_MFMA_BUSY_CYCLES"] / (per["GRBM_GUI_ACTIVE"] * 128.0)) if "SQ_VALU_MFMA_BUSY_CYCLES" in per and per.get("GRBM_GUI_ACTIVE") else None,
     "valu_per_mfma": (per["SQ_INSTS_VALU"] / per["SQ_INSTS_MFMA"]) if per.get("SQ_INSTS_MFMA") else None,
-    "gpu_cycles_per_launch": per.get("GRBM_GUI_ACTIVE"),
+    "gpu_cycles_per_launch": (per["GRBM_GUI_ACTIVE"] / 8.0) if per.get("GRBM_GUI_ACTIVE") else None,
+    "scratch_bytes_per_launch_estimate": "148 B per lane (36 spilled VGPRs) x 64 lanes x 4 waves x 8192 workgroups = 0.31 GB written once and re-read: the "
+                                         "larger part of WRITE_SIZE - list bytes (0.27 GB)",
     "aggregation": "every counter = sum over the kernels of the slot-0 bracket of (mean over that kernel's launches of the value rocprofv3 "
                    "reports per dispatch, itself the sum over all XCDs / SEs); one launch = BOTH directions of `pairs` pairs (4x the rows of "
                    "a 256-pair one-direction run such as tools/gpu/r5_pmc_coarse.sh)",
