@@ -868,9 +868,15 @@ struct HXArgs {
     int topk;
 };
 
+// The keys go through LDS, 256 at a time, in whole coalesced rows (a wave's load instruction covers two 512-byte rows) and every thread
+// runs ONE chain over ITS key's LDS row (stride 132 floats: a 16-lane group of a ds_read_b128 covers the 64 banks once).  (Rounds 2 - 5:
+// every lane loaded its own key rows from global memory, 64 different cache lines per load instruction, four chains per lane in flight:
+// 60 -> 50 us per launch at 64 pairs, 197 -> 119 us at 512 — round 6, same chains, same order of columns per thread: bit-identical.)
+constexpr int HX_LD = 132;   // floats per staged key row
 __global__ __launch_bounds__(256) void softcorr_exact_rows_kernel(const HXArgs args) {
     __shared__ float sk[4][10], sm[4], sl[4];
     __shared__ int sj[4][10];
+    extern __shared__ __attribute__((aligned(16))) float hx_keys[];   // [256][HX_LD]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float neg_alpha = args.neg_alpha;
     const int topk = args.topk;
@@ -889,36 +895,35 @@ __global__ __launch_bounds__(256) void softcorr_exact_rows_kernel(const HXArgs a
             KBest<10, float> kb;
             kb.init(INFINITY);
             float m = -INFINITY, l = 0.f;
-            // (Round 3: the same distances as 16 systolic streams — the form of softcorr_refine_kernel<2>: whole 512-byte key rows per
-            // load, finished chains parked one per lane and processed 16 at a time — was built and is bit-identical, and the kernel
-            // took the same 150 us per launch: with ~420 flagged rows of 2 M (DVM_K1_FLAG_DEBUG prints the count) every workgroup has
-            // at most one row per direction, and the launch lasts as long as one row's dependent chain, whichever way it is fed.)
-            for (int j0 = wave * 64 + lane; j0 < M; j0 += 1024) {  // four independent chains per lane in flight
-                float acc[4] = {0.f, 0.f, 0.f, 0.f};
-                const float *kr[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) kr[u] = G.k + ((size_t)b * M + (j0 + 256 * u < M ? j0 + 256 * u : j0)) * HB_D;
+            {
+                const float *kb0 = G.k + (size_t)b * M * HB_D;
+                for (int t0 = 0; t0 < M; t0 += 256) {
+                    __syncthreads();   // (the previous tile's chains are done)
 #pragma unroll 8
-                for (int c = 0; c < HB_D; c += 4) {
-                    const f32x4 qv = *(const f32x4 *)(q + c);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const f32x4 kv = *(const f32x4 *)(kr[u] + c);
-                        acc[u] = fmaf(-2.f * qv.x, kv.x, acc[u]);
-                        acc[u] = fmaf(-2.f * qv.y, kv.y, acc[u]);
-                        acc[u] = fmaf(-2.f * qv.z, kv.z, acc[u]);
-                        acc[u] = fmaf(-2.f * qv.w, kv.w, acc[u]);
+                    for (int i = 0; i < 32; ++i) {
+                        const int r = (threadIdx.x >> 5) + 8 * i, c = threadIdx.x & 31;
+                        const int j = t0 + r < M ? t0 + r : M - 1;
+                        *(f32x4 *)(hx_keys + r * HX_LD + 4 * c) = *(const f32x4 *)(kb0 + (size_t)j * HB_D + 4 * c);
                     }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int j = j0 + 256 * u;
+                    __syncthreads();
+                    const float *kr = hx_keys + threadIdx.x * HX_LD;
+                    float acc = 0.f;
+#pragma unroll 8
+                    for (int c = 0; c < HB_D; c += 4) {
+                        const f32x4 qv = *(const f32x4 *)(q + c);
+                        const f32x4 kv = *(const f32x4 *)(kr + c);
+                        acc = fmaf(-2.f * qv.x, kv.x, acc);
+                        acc = fmaf(-2.f * qv.y, kv.y, acc);
+                        acc = fmaf(-2.f * qv.z, kv.z, acc);
+                        acc = fmaf(-2.f * qv.w, kv.w, acc);
+                    }
+                    const int j = t0 + (int)threadIdx.x;
                     if (j < M) {
-                        const float d2 = (acc[u] + na) + G.nk[(size_t)b * M + j];
+                        const float d2 = (acc + na) + G.nk[(size_t)b * M + j];
                         const float de = sqrt_rn(d2 > 0.f ? d2 : 0.f);
                         const float s = de * neg_alpha;
                         const float mn = fmaxf(m, s);
-                        l = l * exp2f((m - mn) * LOG2E) + exp2f((s - mn) * LOG2E);  // m = -inf, l = 0 -> 0 * 0
+                        l = l * exp2f((m - mn) * LOG2E) + exp2f((s - mn) * LOG2E);
                         m = mn;
                         kb.insert(de, j);
                     }
@@ -1314,7 +1319,8 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
         if (both) (void)hipMemcpy(&n[1], flag[1], sizeof(int), hipMemcpyDeviceToHost);
         fprintf(stderr, "K1 pass B: %d + %d of %ld rows go through the exact-rows kernel\n", n[0], n[1], r.rows_total);
     }
-    hipLaunchKernelGGL(softcorr_exact_rows_kernel, dim3(512), dim3(256), 0, s, x);
+    ensure_dyn_lds((const void *)softcorr_exact_rows_kernel, 256 * HX_LD * (int)sizeof(float));
+    hipLaunchKernelGGL(softcorr_exact_rows_kernel, dim3(512), dim3(256), 256 * HX_LD * sizeof(float), s, x);
     return DVM_OK;
 }
 
