@@ -64,7 +64,7 @@ template <int KT, int W> constexpr int hc_lds_bytes() { return 2 * KT * HC_ROWB 
 
 struct HCGroup {
     const char *qp, *kp;      // planes of the query / key side [B][rows][512]: h plane = the first 256 B of a row
-    const char *knf;          // key-side norm fragments [B][Mpad][32 B] (launch_norm_frags)
+    const char *knf;          // key-side norm fragments [B][Mpad][32 B] (launch_norm_prep)
     const float *nq;          // |q|^2 (ATen order)
     int N, M, Mpad, tiles;    // tiles: workgroups per batch entry (512 query rows each)
     int32_t *cidx;            // [B][N][K1_KC_COARSE]
@@ -110,22 +110,8 @@ __device__ __forceinline__ void norm_pieces(float x, _Float16 &p1, _Float16 &p2,
 __device__ __forceinline__ float norm_scaled(float n, int se) { return (n * pow2i(se)) * pow2i(se - 1); }
 
 // key-side norm fragments, padded to whole key tiles (padding keys: zero norm; their entries are masked by column in the
-// sweep): out [B][Mpad][16 fp16] = {a1, a2, a3, 2^15, 2^4, 2^-7, 0, 0 | 0 x 8} — the A operand of the norm instruction
-__global__ void norm_frags_kernel(const float *__restrict__ nrm, int M, int Mpad, const int *__restrict__ amax, char *__restrict__ out) {
-    const int b = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Mpad) return;
-    f16x8 lo = {0, 0, 0, (_Float16)0x1p+15f, (_Float16)0x1p+4f, (_Float16)0x1p-7f, 0, 0};
-    const f16x8 hi = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (i < M) {
-        _Float16 p1, p2, p3;
-        norm_pieces(norm_scaled(nrm[(size_t)b * M + i], scale_exp(*amax)), p1, p2, p3);
-        lo[0] = p1, lo[1] = p2, lo[2] = p3;
-    }
-    char *p = out + ((size_t)b * Mpad + i) * 32;
-    *(f16x8 *)p = lo;
-    *(f16x8 *)(p + 16) = hi;
-}
+// sweep): [B][Mpad][16 fp16] = {a1, a2, a3, 2^15, 2^4, 2^-7, 0, 0 | 0 x 8} — the A operand of the norm instruction; written by
+// norm_prep_kernel below
 
 // sorted (s0 <= s1 <= s2) three smallest of 16 distinct keys: 46 three-input unsigned min / med / max instructions
 struct Top3 {
@@ -601,11 +587,42 @@ static void launch_form(const HCArgs &a, int blocks, hipStream_t s) {
 
 bool coarse_supports(int N, int M) { return M <= HC_MAX_M && N <= HC_MAX_M; }
 
-void launch_norm_frags(const float *nrm, int B, int M, int Mpad, const int *amax, char *out, hipStream_t s) {
-    hipLaunchKernelGGL(norm_frags_kernel, dim3((Mpad + 255) / 256, B), dim3(256), 0, s, nrm, M, Mpad, amax, out);
+// Everything pass A and pass B want of the row norms of both sides in ONE launch (round 6; six launches before: norm_max x 2,
+// pad_norms x 2, norm_frags x 2 — at a strong-scaling rank's batch the prologue of the sweep is a chain of ~20 launches of a few
+// microseconds each): per side the maximum per batch element (atomic: positive floats order like their bit patterns), the norms padded
+// to whole key tiles with +inf, the coarse screen's norm fragments; block (0, 0, 0) also zeroes the flagged-row counters.
+__global__ __launch_bounds__(256) void norm_prep_kernel(const NormPrep a) {
+    const int sd = blockIdx.z, b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int M = a.rows[sd], Mp = a.pad[sd];
+    if (blockIdx.x == 0 && b == 0 && sd == 0 && threadIdx.x < 2 && a.zero[threadIdx.x]) *a.zero[threadIdx.x] = 0;
+    if (blockIdx.x * blockDim.x >= Mp) return;
+    const float nv = i < M ? a.nrm[sd][(size_t)b * M + i] : 0.f;
+    float v = nv;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    if ((threadIdx.x & 63) == 0 && blockIdx.x * blockDim.x + (threadIdx.x & ~63) < M) atomicMax((int *)a.nmax[sd] + b, __float_as_int(v));
+    if (i >= Mp) return;
+    if (a.npad[sd]) a.npad[sd][(size_t)b * Mp + i] = i < M ? nv : INFINITY;
+    if (a.nfrag[sd]) {
+        f16x8 lo = {0, 0, 0, (_Float16)0x1p+15f, (_Float16)0x1p+4f, (_Float16)0x1p-7f, 0, 0};
+        const f16x8 hi = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (i < M) {
+            _Float16 p1, p2, p3;
+            norm_pieces(norm_scaled(nv, scale_exp(*a.amax)), p1, p2, p3);
+            lo[0] = p1, lo[1] = p2, lo[2] = p3;
+        }
+        char *p = a.nfrag[sd] + ((size_t)b * Mp + i) * 32;
+        *(f16x8 *)p = lo;
+        *(f16x8 *)(p + 16) = hi;
+    }
+}
+void launch_norm_prep(const NormPrep &a, int B, hipStream_t s) {
+    const int mp = a.pad[0] > a.pad[1] ? a.pad[0] : a.pad[1];
+    hipLaunchKernelGGL(norm_prep_kernel, dim3((mp + 255) / 256, B, 2), dim3(256), 0, s, a);
 }
 
-// pass A for the groups in `a`, coarse screen; knf = key-side norm fragments of either group (launch_norm_frags).  `a` is laid
+// pass A for the groups in `a`, coarse screen; knf = key-side norm fragments of either group (launch_norm_prep).  `a` is laid
 // out for the 256-row workgroups of the other forms; this form re-derives its own tiling.
 void launch_coarse(const HBArgs &a, const char *knf0, const char *knf1, const int *amaxc, int blocks, hipStream_t s) {
     constexpr int kt = 64;   // keys per LDS tile (128 — half the barriers, 137 KB of LDS — measured 5 % slower: profiles/notes_k1.md)

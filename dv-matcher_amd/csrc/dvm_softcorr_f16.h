@@ -113,7 +113,17 @@ void launch_coarse(const HBArgs &a, const char *knf0, const char *knf1, const in
 
 
 // key-side norm fragments of the coarse screen [B][Mpad][32 B] (dvm_softcorr_coarse.hip)
-void launch_norm_frags(const float *nrm, int B, int M, int Mpad, const int *amax, char *out, hipStream_t s);
+// one launch for the norms of both sides (dvm_softcorr_coarse.hip::norm_prep_kernel): side sd has rows[sd] norms per batch element,
+// padded to pad[sd]; nmax [B] (zeroed by the caller) always; npad [B][pad] / nfrag [B][pad][32 B] where not NULL; zero[]: counters to clear
+struct NormPrep {
+    const float *nrm[2];
+    int rows[2], pad[2];
+    float *nmax[2], *npad[2];
+    char *nfrag[2];
+    const int *amax;
+    int32_t *zero[2];
+};
+void launch_norm_prep(const NormPrep &a, int B, hipStream_t s);
 
 }  // namespace k1
 }  // namespace dvm

@@ -198,23 +198,6 @@ __global__ __launch_bounds__(256) void split_planes_gated_kernel(const float *__
     }
 }
 
-// norms padded to whole key tiles with +inf: out [B][Mpad]
-__global__ void pad_norms_kernel(const float *__restrict__ nrm, int M, int Mpad, float *__restrict__ out) {
-    const int b = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < Mpad) out[(size_t)b * Mpad + i] = i < M ? nrm[(size_t)b * M + i] : INFINITY;
-}
-
-// max of the row norms of every batch element (positive floats order like their bit patterns)
-__global__ void norm_max_kernel(const float *__restrict__ nrm, int rows_per_batch, float *__restrict__ out) {
-    const int b = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    float v = i < rows_per_batch ? nrm[(size_t)b * rows_per_batch + i] : 0.f;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax((int *)out + b, __float_as_int(v));
-}
-
 // ---------------------------------------------------------------- pass A
 template <bool LEAN>
 __global__ __launch_bounds__(HB_THREADS, 2) void softcorr_sweep_f16_kernel(const HBArgs args) {
@@ -1193,10 +1176,10 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
         return DVM_ENOSPACE;
     }
     const long r1 = (long)B * N, r2 = (long)B * M;
-    (void)hipMemsetAsync(nmax1, 0, 2 * align_up((size_t)B * sizeof(float)) + 2 * sizeof(int), s);
+    // nmax1, nmax2, amax_own and spec lie back to back in the arena (256-byte slots): one fill
+    (void)hipMemsetAsync(nmax1, 0, (size_t)((char *)spec - (char *)nmax1) + 2 * sizeof(int), s);
     if (fuse_slots) {
         (void)hipMemsetAsync(fuse_slots, 0, 512 * sizeof(int), s);
-        (void)hipMemsetAsync(spec, 0, 2 * sizeof(int), s);
         hipLaunchKernelGGL(sample_absmax_kernel, dim3(256), dim3(256), 0, s, f1, r1, f2, r2, spec);
         auto prep = [&](const float *f, long r, float *nn, int *slots, char *pp) {   // 2 rows per 16-lane group and trip (1: 315 us, 2: 296, 4: 365)
             hipLaunchKernelGGL(rownorm_split_kernel<2>, dim3((unsigned)((r + 31) / 32)), dim3(256), 0, s, f, r, nn, slots, spec, pp);
@@ -1215,9 +1198,6 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
         hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((r1 * 16 + 255) / 256)), dim3(256), 0, s, f1, r1, amax, p1);
         hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((r2 * 16 + 255) / 256)), dim3(256), 0, s, f2, r2, amax + 1, p2);
     }
-    hipLaunchKernelGGL(norm_max_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, n1, N, nmax1);
-    hipLaunchKernelGGL(norm_max_kernel, dim3((M + 255) / 256, B), dim3(256), 0, s, n2, M, nmax2);
-    for (int d = 0; d < (both ? 2 : 1); ++d) (void)hipMemsetAsync(flag[d], 0, sizeof(int32_t), s);
     // alpha < 32: every softmax term counts, the first form in full.  From 32 on each (direction, pair) is routed by the
     // probe; DVM_K1_ROUTE = 0 / 1 / 3 (K1_ROUTE_FULL / LEAN / COARSE) forces one kernel for all of them (A/B measurements,
     // tests/test_gpu_k1_routes.py).
@@ -1239,13 +1219,12 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
         hipLaunchKernelGGL(k1_route_kernel, dim3(both ? 2 : 1), dim3(256), 0, s, pa, B);
         if (pol.debug & DVM_DEBUG_K1_ROUTES) report_routes(route, pfrac, B * (both ? 2 : 1), s);
     }
-    if (routed ? havec : fixed == K1_ROUTE_COARSE) {
-        launch_norm_frags(n2, B, M, Mp, amax, nf2, s);
-        if (both) launch_norm_frags(n1, B, N, Np, amax, nf1, s);
-    }
-    {   // (the first form's padded norms: also behind the coarse screen, for the gate's second pass)
-        hipLaunchKernelGGL(pad_norms_kernel, dim3((Mp + 255) / 256, B), dim3(256), 0, s, n2, M, Mp, n2p);
-        if (both) hipLaunchKernelGGL(pad_norms_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, s, n1, N, Np, n1p);
+    {   // the norms' maxima, the first form's padded norms (also behind the coarse screen, for the gate's second pass), the coarse
+        // screen's norm fragments and the flagged-row counters: one launch
+        const bool frags = routed ? havec : fixed == K1_ROUTE_COARSE;
+        NormPrep np{{n1, n2}, {N, M}, {Np, Mp}, {nmax1, nmax2}, {both ? n1p : nullptr, n2p}, {frags && both ? nf1 : nullptr, frags ? nf2 : nullptr},
+                    amax, {flag[0], both ? flag[1] : nullptr}};
+        launch_norm_prep(np, B, s);
     }
 
     HBArgs a;
@@ -1362,9 +1341,6 @@ int launch_argmin_f16(const float *f1, const float *f2, int B, int N, int M, int
     hipLaunchKernelGGL(common_absmax_kernel, dim3(1), dim3(1), 0, s, amax, amax);
     hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((r1 * 16 + 255) / 256)), dim3(256), 0, s, f1, r1, amax, p1);
     hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((r2 * 16 + 255) / 256)), dim3(256), 0, s, f2, r2, amax + 1, p2);
-    hipLaunchKernelGGL(norm_max_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, n1, N, nmax1);
-    hipLaunchKernelGGL(norm_max_kernel, dim3((M + 255) / 256, B), dim3(256), 0, s, n2, M, nmax2);
-    for (int d = 0; d < (both ? 2 : 1); ++d) (void)hipMemsetAsync(flag[d], 0, sizeof(int32_t), s);
     // coarse screen first (lists of 16), the first form behind the device-side gate for directions it serves badly
     const bool havec = coarse_supports(N, M);
     int *route = ar.take<int>(2 * (size_t)B);
@@ -1372,12 +1348,11 @@ int launch_argmin_f16(const float *f1, const float *f2, int B, int N, int M, int
         set_error("argmin (fp16 sweep): workspace too small (%zu < %zu)", ws_bytes, ar.off);
         return DVM_ENOSPACE;
     }
-    if (havec) {
-        launch_norm_frags(n2, B, M, Mp, amax, nf2, s);
-        if (both) launch_norm_frags(n1, B, N, Np, amax, nf1, s);
+    {
+        NormPrep np{{n1, n2}, {N, M}, {Np, Mp}, {nmax1, nmax2}, {both ? n1p : nullptr, n2p}, {havec && both ? nf1 : nullptr, havec ? nf2 : nullptr},
+                    amax, {flag[0], both ? flag[1] : nullptr}};
+        launch_norm_prep(np, B, s);
     }
-    hipLaunchKernelGGL(pad_norms_kernel, dim3((Mp + 255) / 256, B), dim3(256), 0, s, n2, M, Mp, n2p);
-    if (both) hipLaunchKernelGGL(pad_norms_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, s, n1, N, Np, n1p);
     HBArgs a;
     a.g[0] = HBGroup{p1, p2, amax, amax + 1, n1, n2p, N, M, Mp, (N + HB_QB - 1) / HB_QB, cidx[0], cd2[0], lsum[0]};
     a.g[1] = both ? HBGroup{p2, p1, amax + 1, amax, n2, n1p, M, N, Np, (M + HB_QB - 1) / HB_QB, cidx[1], cd2[1], lsum[1]} : a.g[0];
