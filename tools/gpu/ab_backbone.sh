@@ -1,4 +1,5 @@
 # A/B of two builds on the eval forward (kernel times by launch shape): csrc/libdvm_old.so vs libdvm_hip.so
+: ${GRAFT_REPO_ROOT:?}   # (the recipes rm -rf / write under it)
 cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
 cp $R/dv-matcher_amd/csrc/libdvm_hip.so $R/dv-matcher_amd/csrc/libdvm_new.so
 for v in old new; do

@@ -1,4 +1,5 @@
 # SQ counters of dvm_linear_f32 at LG-Net's layer shapes (separate --pmc passes, kernel-trace only)
+: ${GRAFT_REPO_ROOT:?}   # (the recipes rm -rf / write under it)
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_gemm
 rm -rf $OUT; mkdir -p $OUT

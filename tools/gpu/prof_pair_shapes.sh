@@ -1,4 +1,5 @@
 # the fused pair forward at the shapes of the configs, with the kernel trace of the asymmetric case
+: ${GRAFT_REPO_ROOT:?}   # (the recipes rm -rf / write under it)
 cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
 python3 $R/tools/bench_pair.py 2>&1 | grep pair_forward
 cat > /tmp/pshape.py <<'PY'

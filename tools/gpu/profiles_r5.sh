@@ -1,6 +1,7 @@
 # round-5 evidence under gpurun_out/r5p/ (copied into profiles/r5_* by hand): bench lines of the three workloads, kernel stats of the
 # bench and of the training step, PMC passes (separate runs, kernel-trace only) for the K1 screen (HBM bytes + SQ rows at --pairs 512),
 # pass B, the MLP, pooling; the strong-scaling proxy (small resident batches on one GPU).
+: ${GRAFT_REPO_ROOT:?}   # (the recipes rm -rf / write under it)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r5p; rm -rf $O; mkdir -p $O
 cd $R

@@ -1,4 +1,5 @@
 # the directional (N != M) criterion node: its tests, the partial-shape training bench before / after (criterion.native_train is the switch)
+: ${GRAFT_REPO_ROOT:?}   # (the recipes rm -rf / write under it)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r5s
 timeout 1500 python -m pytest tests/test_gpu_criterion_native.py -m gpu -x -q 2>&1 | tail -6
 timeout 1500 python -m pytest tests/test_gpu_ddp.py tests/test_gpu_network.py -m gpu -x -q -k "partial or sharded or training_step" 2>&1 | tail -4

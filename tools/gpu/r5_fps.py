@@ -1,4 +1,4 @@
-"""FPS kernel forms: per-launch time and identical indices.  usage: python tools/gpu/r5_fps.py  (DVM_DEBUG=32 selects the multi-wave form)"""
+"""FPS kernel forms: per-launch time and identical indices.  usage: python tools/gpu/r5_fps.py  (the multi-wave form it was written for was measured slower and removed: profiles/notes_train.md)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "dv-matcher_amd"))

@@ -1,4 +1,5 @@
 # round 5: kernel stats of the bench (rocprofv3 kernel trace)
+: ${GRAFT_REPO_ROOT:?}   # (the recipes rm -rf / write under it)
 cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out/r5
 rm -rf /tmp/p_bench
 rocprofv3 --kernel-trace --stats -d /tmp/p_bench -o x --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-check > /tmp/p_bench.log 2>&1

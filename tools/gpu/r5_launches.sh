@@ -1,4 +1,5 @@
 # launches PER STEP of the training bench, without the one-time launches (model upload, optimizer state): two kernel-stat runs of 4 and 12 steps, differenced
+: ${GRAFT_REPO_ROOT:?}   # (the recipes rm -rf / write under it)
 cd /tmp && export TMPDIR=/tmp; O=$GRAFT_REPO_ROOT/gpurun_out/r5s; mkdir -p $O
 for K in 4 12; do
   rm -rf /tmp/pl$K

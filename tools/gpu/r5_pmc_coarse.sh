@@ -1,4 +1,5 @@
 # round 5: SQ counters of the coarse screen alone (K1 only, 256 pairs one direction; separate --pmc passes, kernel trace only)
+: ${GRAFT_REPO_ROOT:?}   # (the recipes rm -rf / write under it)
 cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r5/pmc_coarse; rm -rf $O; mkdir -p $O
 export DVM_K1_ROUTE=3
 B="python3 $R/tools/run_softcorr.py 256 4 3 100"

@@ -1,4 +1,5 @@
 # the training step after a change of its native nodes: the tests that pin them, the train bench, launch counts, the callers of what is left of ATen
+: ${GRAFT_REPO_ROOT:?}   # (the recipes rm -rf / write under it)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r5s
 timeout 2400 python -m pytest tests/test_gpu_criterion_native.py tests/test_gpu_train_native.py tests/test_gpu_train_pm.py tests/test_gpu_ddp.py tests/test_gpu_backward.py -m gpu -x -q 2>&1 | tail -8
 timeout 1500 python -m pytest tests/test_gpu_network.py -m gpu -x -q -k "training_step or backbone_backward" 2>&1 | tail -5

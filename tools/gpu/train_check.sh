@@ -1,4 +1,5 @@
 # training-path tests + step timing (B = 8 x 2048, B = 2 x 1024 eager and graph)
+: ${GRAFT_REPO_ROOT:?}   # (the recipes rm -rf / write under it)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 timeout 1200 python -m pytest tests/test_gpu_backward.py tests/test_gpu_train_pm.py tests/test_gpu_network.py tests/test_gpu_ddp.py -q -x 2>&1 | tail -3
 cd dv-matcher_amd

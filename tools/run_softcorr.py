@@ -22,4 +22,4 @@ if variant == 3:
     print("  idx equal:", bool((ref[1] == out[1]).all()), " smax equal:", bool((ref[2] == out[2]).all()),
           " max rel val diff: %.2e" % float(((ref[0] - out[0]).abs() / ref[0].clamp_min(1e-30)).max()),
           " max rel sum diff: %.2e" % float(((ref[3] - out[3]).abs() / ref[3]).max()))
-# (rows that failed pass B's certification: run with DVM_K1_FLAG_DEBUG=1, printed per call on stderr)
+# (rows that failed pass B's certification: run with DVM_DEBUG=2, printed per call on stderr)
