@@ -856,7 +856,8 @@ struct HXArgs {
 // every lane loaded its own key rows from global memory, 64 different cache lines per load instruction, four chains per lane in flight:
 // 60 -> 50 us per launch at 64 pairs, 197 -> 119 us at 512 — round 6, same chains, same order of columns per thread: bit-identical.)
 constexpr int HX_LD = 132;   // floats per staged key row
-__global__ __launch_bounds__(256) void softcorr_exact_rows_kernel(const HXArgs args) {
+constexpr int HX_T = 1024;   // threads: all of them stage (8 loads each per tile: the staging is what a row waits for), the first 256 run the chains
+__global__ __launch_bounds__(HX_T) void softcorr_exact_rows_kernel(const HXArgs args) {
     __shared__ float sk[4][10], sm[4], sl[4];
     __shared__ int sj[4][10];
     extern __shared__ __attribute__((aligned(16))) float hx_keys[];   // [256][HX_LD]
@@ -882,13 +883,14 @@ __global__ __launch_bounds__(256) void softcorr_exact_rows_kernel(const HXArgs a
                 const float *kb0 = G.k + (size_t)b * M * HB_D;
                 for (int t0 = 0; t0 < M; t0 += 256) {
                     __syncthreads();   // (the previous tile's chains are done)
-#pragma unroll 8
-                    for (int i = 0; i < 32; ++i) {
-                        const int r = (threadIdx.x >> 5) + 8 * i, c = threadIdx.x & 31;
+#pragma unroll
+                    for (int i = 0; i < 256 * 32 / HX_T; ++i) {
+                        const int r = (threadIdx.x >> 5) + (HX_T / 32) * i, c = threadIdx.x & 31;
                         const int j = t0 + r < M ? t0 + r : M - 1;
                         *(f32x4 *)(hx_keys + r * HX_LD + 4 * c) = *(const f32x4 *)(kb0 + (size_t)j * HB_D + 4 * c);
                     }
                     __syncthreads();
+                    if (threadIdx.x >= 256) continue;   // (wave-uniform; the barriers above are reached by every thread on the next trip)
                     const float *kr = hx_keys + threadIdx.x * HX_LD;
                     float acc = 0.f;
 #pragma unroll 8
@@ -912,30 +914,32 @@ __global__ __launch_bounds__(256) void softcorr_exact_rows_kernel(const HXArgs a
                     }
                 }
             }
-            float mm = m;
+            if (wave < 4) {   // (the staging-only waves hold no chains)
+                float mm = m;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o, 64));
-            float lt = (m == -INFINITY) ? 0.f : l * exp2f((m - mm) * LOG2E);
+                for (int o = 32; o > 0; o >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o, 64));
+                float lt = (m == -INFINITY) ? 0.f : l * exp2f((m - mm) * LOG2E);
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) lt += __shfl_xor(lt, o, 64);
-            // the wave's 10 best: pop the minimum of the 64 list heads ten times
-            for (int t = 0; t < 10; ++t) {
-                float bd = kb.key[0];
-                int bj = kb.idx[0];
+                for (int o = 32; o > 0; o >>= 1) lt += __shfl_xor(lt, o, 64);
+                // the wave's 10 best: pop the minimum of the 64 list heads ten times
+                for (int t = 0; t < 10; ++t) {
+                    float bd = kb.key[0];
+                    int bj = kb.idx[0];
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const float od = __shfl_xor(bd, o, 64);
-                    const int oj = __shfl_xor(bj, o, 64);
-                    if (od < bd || (od == bd && oj < bj)) bd = od, bj = oj;
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const float od = __shfl_xor(bd, o, 64);
+                        const int oj = __shfl_xor(bj, o, 64);
+                        if (od < bd || (od == bd && oj < bj)) bd = od, bj = oj;
+                    }
+                    if (kb.idx[0] == bj && kb.key[0] == bd) {  // the owner pops its head
+#pragma unroll
+                        for (int p = 0; p < 9; ++p) kb.key[p] = kb.key[p + 1], kb.idx[p] = kb.idx[p + 1];
+                        kb.key[9] = INFINITY, kb.idx[9] = 0x7fffffff;
+                    }
+                    if (lane == 0) sk[wave][t] = bd, sj[wave][t] = bj;
                 }
-                if (kb.idx[0] == bj && kb.key[0] == bd) {  // the owner pops its head
-#pragma unroll
-                    for (int p = 0; p < 9; ++p) kb.key[p] = kb.key[p + 1], kb.idx[p] = kb.idx[p + 1];
-                    kb.key[9] = INFINITY, kb.idx[9] = 0x7fffffff;
-                }
-                if (lane == 0) sk[wave][t] = bd, sj[wave][t] = bj;
+                if (lane == 0) sm[wave] = mm, sl[wave] = lt;
             }
-            if (lane == 0) sm[wave] = mm, sl[wave] = lt;
             __syncthreads();
             if (wave == 0) {  // merge the four waves: rank the 40 entries by (distance, column)
                 const float gm = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));  // = max_j s_j exactly (s monotone in de)
@@ -1299,7 +1303,7 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
         fprintf(stderr, "K1 pass B: %d + %d of %ld rows go through the exact-rows kernel\n", n[0], n[1], r.rows_total);
     }
     ensure_dyn_lds((const void *)softcorr_exact_rows_kernel, 256 * HX_LD * (int)sizeof(float));
-    hipLaunchKernelGGL(softcorr_exact_rows_kernel, dim3(512), dim3(256), 256 * HX_LD * sizeof(float), s, x);
+    hipLaunchKernelGGL(softcorr_exact_rows_kernel, dim3(512), dim3(HX_T), 256 * HX_LD * sizeof(float), s, x);
     return DVM_OK;
 }
 

@@ -397,7 +397,7 @@ def test_pair_forward_equals_two_directions(ops, golden, shape):
         assert torch.equal(o21[k], r21[k]), ("21", k)
 
 
-@pytest.mark.parametrize("shape", [(3, 512, 512), (2, 300, 170), (2, 330, 330), (2, 2048, 2048)])
+@pytest.mark.parametrize("shape", [(3, 512, 512), (2, 300, 170), (2, 330, 330), (2, 2048, 2048), (1, 4995, 2200)])
 @pytest.mark.parametrize("with_map", [True, False])
 def test_pair_pipeline_equals_pair_forward(ops, golden, shape, with_map):
     """The two-call form (dvm_pair_geometry_f32 on its own stream for batch t + 1 while dvm_pair_fwd_cached_f32 consumes batch t's)
