@@ -854,7 +854,8 @@ struct HXArgs {
 // The keys go through LDS, 256 at a time, in whole coalesced rows (a wave's load instruction covers two 512-byte rows) and every thread
 // runs ONE chain over ITS key's LDS row (stride 132 floats: a 16-lane group of a ds_read_b128 covers the 64 banks once).  (Rounds 2 - 5:
 // every lane loaded its own key rows from global memory, 64 different cache lines per load instruction, four chains per lane in flight:
-// 60 -> 50 us per launch at 64 pairs, 197 -> 119 us at 512 — round 6, same chains, same order of columns per thread: bit-identical.)
+// 60 -> 50 us per launch at 64 pairs, 197 -> 119 us at 512 — round 6, same chains, same order of columns per thread: bit-identical;
+// with 1 024 threads staging — 8 loads each per tile instead of 32 — and the first 256 running the chains: 42 / 109 us.)
 constexpr int HX_LD = 132;   // floats per staged key row
 constexpr int HX_T = 1024;   // threads: all of them stage (8 loads each per tile: the staging is what a row waits for), the first 256 run the chains
 __global__ __launch_bounds__(HX_T) void softcorr_exact_rows_kernel(const HXArgs args) {
