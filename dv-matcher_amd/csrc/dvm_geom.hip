@@ -634,62 +634,119 @@ struct MapTermArgs {
     MapTermSide d[2];
     int k;
 };
+// Round 6: ONE THREAD PER POINT (all k slots), verts12 staged as well: 0.66 -> 0.58 ms per launch of 1 024 clouds x 2 directions (what is
+// left is the LDS pipe: 5.2 M LDS instructions per launch, 60 % of their cycles bank conflicts of the random 16-byte coordinate reads, 41 %
+// of the wave cycles waiting on them; neither 8-byte loads of the three 40-byte global rows nor the batched staging moved it further).  As one thread per (point, slot) the 10 threads of a point each
+// loaded the point's whole Pi row (20 global loads per thread and trip, then a dependent gather of verts12) and the workgroup — 16 waves
+// on the compute unit, 104 KB of LDS — waited out those round trips 20 times per cloud: 0.66 ms per launch of 1 024 clouds x 2 directions.
+// Here a thread loads its Pi row and its xyz-neighbour row once (120 B), and every other lookup is an LDS read — vector reads: the
+// coordinates are staged as float4, a correspondence's 10 neighbour indices are five 8-byte reads (430 scalar LDS reads per point as
+// first written: bank-conflict-bound at 0.63 ms; 160 vector reads: see below).  Partial sums: per point
+// the k squared residuals in slot order (fp32 -> double), a wave's 64 points by wave_sum, one partial per wave, the rest of the `nblk`
+// slots zero (reduce_partials_kernel adds them all): same value to rounding of the double sums (the oracle's bar is rtol 1e-4).
 template <int TOPK>
 __global__ __launch_bounds__(1024) void map_term_lds_kernel(const MapTermArgs args) {
     extern __shared__ __attribute__((aligned(16))) char mt_lds[];
-    __shared__ double red[16];
     const MapTermSide &A = args.d[blockIdx.y];
     const float *__restrict__ verts12 = A.verts12, *__restrict__ verts2 = A.verts2, *__restrict__ pi_val = A.pi_val;
     const int32_t *__restrict__ idx11 = A.idx11, *__restrict__ idx22 = A.idx22, *__restrict__ pi_idx = A.pi_idx;
     double *__restrict__ partial = A.partial;
-    const int N = A.N, M = A.M, nblk = A.nblk, k = args.k;
-    float *v2 = (float *)mt_lds;                                   // [M][3]
-    int32_t *i22 = (int32_t *)(mt_lds + (((size_t)M * 3 * sizeof(float) + 15) / 16) * 16);   // [M][k]
+    const int N = A.N, M = A.M, nblk = A.nblk;
+    constexpr int K = 10;                                          // xyz neighbours per point (checked by the launcher)
+    float4 *v2 = (float4 *)mt_lds;                                 // [M] (x, y, z, -)
+    float4 *v12 = v2 + M;                                          // [N]
+    int32_t *i22 = (int32_t *)(v12 + N);                           // [M][K]: rows of 40 B, 8-byte aligned
     const int b = blockIdx.x;
     {
-        const float *gv = verts2 + (size_t)b * M * 3;
-        const int32_t *gi = idx22 + (size_t)b * M * k;
-        for (int e = threadIdx.x; e < M * 3; e += 1024) v2[e] = gv[e];
-        for (int e = threadIdx.x; e < M * k; e += 1024) i22[e] = gi[e];
+        const float *gv = verts2 + (size_t)b * M * 3, *gw = verts12 + (size_t)b * N * 3;
+        const int32_t *gi = idx22 + (size_t)b * M * K;
+        for (int e = threadIdx.x; e < M; e += 1024) v2[e] = float4{gv[3 * e], gv[3 * e + 1], gv[3 * e + 2], 0.f};
+        for (int e = threadIdx.x; e < N; e += 1024) v12[e] = float4{gw[3 * e], gw[3 * e + 1], gw[3 * e + 2], 0.f};
+        // (the table is 80 KB at 2048 points: 16-byte loads, all of a thread's requested before its first LDS store — as a loop of
+        // 4-byte load / store pairs the staging was 20 dependent round trips)
+        const int n4 = (M * K) / 4;
+        if (((size_t)gi & 15) == 0) {
+            typedef int i32x4_t __attribute__((ext_vector_type(4)));
+            for (int e0 = 0; e0 < n4; e0 += 8 * 1024) {
+                i32x4_t t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + u * 1024 + (int)threadIdx.x;
+                    t[u] = e < n4 ? *(const i32x4_t *)(gi + 4 * e) : i32x4_t{0, 0, 0, 0};
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + u * 1024 + (int)threadIdx.x;
+                    if (e < n4) *(i32x4_t *)(i22 + 4 * e) = t[u];
+                }
+            }
+            for (int e = 4 * n4 + threadIdx.x; e < M * K; e += 1024) i22[e] = gi[e];
+        } else {
+            for (int e = threadIdx.x; e < M * K; e += 1024) i22[e] = gi[e];
+        }
     }
     __syncthreads();
-    const int sub = threadIdx.x >> 8, tl = threadIdx.x & 255;      // four virtual 256-thread blocks at a time
-    for (int vb0 = 0; vb0 < nblk; vb0 += 4) {
-        const int vb = vb0 + sub;
-        const long g = (long)vb * 256 + tl;
-        float e2 = 0.f;
-        if (vb < nblk && g < (long)N * k) {
-            const int i = (int)(g / k), s = (int)(g % k);
+    const int wave = threadIdx.x >> 6, npass = (N + 1023) / 1024;
+    for (int p = 0; p < npass; ++p) {
+        const int i = p * 1024 + (int)threadIdx.x;
+        double e2 = 0.0;
+        if (i < N) {
             const size_t row = (size_t)b * N + i;
-            int col[TOPK];
+            int col[TOPK], n11[K];
             float w[TOPK];
+            // (the three 40-byte rows as 8-byte loads: rows are 8-byte aligned, and a wave's load instruction touches the same ~20 cache
+            // lines whatever its width — five instructions per row instead of ten)
+            static_assert(TOPK % 2 == 0 && K % 2 == 0, "8-byte row loads");
+            {
+                const int2 *ri = (const int2 *)(pi_idx + row * TOPK), *rn = (const int2 *)(idx11 + row * K);
+                const float2 *rw = (const float2 *)(pi_val + row * TOPK);
 #pragma unroll
-            for (int t = 0; t < TOPK; ++t) col[t] = pi_idx[row * TOPK + t], w[t] = pi_val[row * TOPK + t];
-            int nb[TOPK];
+                for (int u = 0; u < TOPK / 2; ++u) {
+                    const int2 ci = ri[u];
+                    const float2 cw = rw[u];
+                    col[2 * u] = ci.x, col[2 * u + 1] = ci.y, w[2 * u] = cw.x, w[2 * u + 1] = cw.y;
+                }
 #pragma unroll
-            for (int t = 0; t < TOPK; ++t) nb[t] = i22[col[t] * k + s];
-            float acc[3] = {0.f, 0.f, 0.f};
+                for (int u = 0; u < K / 2; ++u) {
+                    const int2 cn = rn[u];
+                    n11[2 * u] = cn.x, n11[2 * u + 1] = cn.y;
+                }
+            }
+            // Pi-weighted sums of the targets' neighbour coordinates: slot s of correspondence t is neighbour s of column col[t]; a
+            // correspondence's K neighbour indices are one 40-byte LDS row (five 8-byte reads), a coordinate one 16-byte read; the
+            // sum over t runs in t order for every slot (the order of the (point, slot) form)
+            float acc[K][3];
+#pragma unroll
+            for (int s = 0; s < K; ++s) acc[s][0] = acc[s][1] = acc[s][2] = 0.f;
 #pragma unroll
             for (int t = 0; t < TOPK; ++t) {
-                const float *p = v2 + 3 * nb[t];
-                acc[0] = fmaf(w[t], p[0], acc[0]);
-                acc[1] = fmaf(w[t], p[1], acc[1]);
-                acc[2] = fmaf(w[t], p[2], acc[2]);
+                int nb[K];
+                const int2 *r = (const int2 *)(i22 + col[t] * K);
+#pragma unroll
+                for (int u = 0; u < K / 2; ++u) {
+                    const int2 v = r[u];
+                    nb[2 * u] = v.x, nb[2 * u + 1] = v.y;
+                }
+#pragma unroll
+                for (int s = 0; s < K; ++s) {
+                    const float4 q = v2[nb[s]];
+                    acc[s][0] = fmaf(w[t], q.x, acc[s][0]);
+                    acc[s][1] = fmaf(w[t], q.y, acc[s][1]);
+                    acc[s][2] = fmaf(w[t], q.z, acc[s][2]);
+                }
             }
-            const float *p12 = verts12 + ((size_t)b * N + idx11[row * k + s]) * 3;
-            const float e0 = p12[0] - acc[0], e1 = p12[1] - acc[1], e2c = p12[2] - acc[2];
-            e2 = (e0 * e0 + e1 * e1) + e2c * e2c;
+#pragma unroll
+            for (int s = 0; s < K; ++s) {
+                const float4 p12 = v12[n11[s]];
+                const float e0 = p12.x - acc[s][0], e1 = p12.y - acc[s][1], e2c = p12.z - acc[s][2];
+                e2 += (double)((e0 * e0 + e1 * e1) + e2c * e2c);
+            }
         }
-        const double ws = wave_sum((double)e2);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ws;
-        __syncthreads();
-        if (tl == 0 && vb < nblk) {
-            double t = 0.0;
-            for (int q = 0; q < 4; ++q) t += red[sub * 4 + q];
-            partial[(size_t)b * nblk + vb] = t;
-        }
-        __syncthreads();
+        const double ws = wave_sum(e2);
+        const int slot = p * 16 + wave;
+        if ((threadIdx.x & 63) == 0 && slot < nblk) partial[(size_t)b * nblk + slot] = ws;
     }
+    for (int q = npass * 16 + (int)threadIdx.x; q < nblk; q += 1024) partial[(size_t)b * nblk + q] = 0.0;
 }
 
 // Two-level gathers flattened (fused pair path): nbr[b][j][s][3] = verts[b][idx[b][j][s]] once per cloud, then the map
@@ -1124,13 +1181,13 @@ bool launch_apply3_pair(const float *val12, const int32_t *idx12, const float *v
     hipLaunchKernelGGL(apply3_pair_kernel, dim3(B, 2), dim3(256), lds, s, a);
     return true;
 }
-bool map_term_lds_applies(int M, int k) {
-    return (((size_t)M * 3 * sizeof(float) + 15) / 16) * 16 + (size_t)M * k * sizeof(int32_t) <= 150 * 1024;
-}
+// LDS of a workgroup: the target's coordinates and xyz-kNN table + the mapped cloud's coordinates (up to 2 x M points of it)
+static size_t map_term_lds_bytes(int N, int M, int k) { return (size_t)(M + N) * sizeof(float4) + (size_t)M * k * sizeof(int32_t); }
+bool map_term_lds_applies(int N, int M, int k) { return k == 10 && map_term_lds_bytes(N, M, k) <= 150 * 1024; }
 bool launch_map_term_lds(const float *verts12, const float *verts2, const int32_t *idx11, const int32_t *idx22, const float *pi_val,
                          const int32_t *pi_idx, int B, int N, int M, int k, int topk, double *partial, hipStream_t s) {
-    const size_t lds = (((size_t)M * 3 * sizeof(float) + 15) / 16) * 16 + (size_t)M * k * sizeof(int32_t);
-    if (topk != 10 || lds > 150 * 1024) return false;
+    const size_t lds = map_term_lds_bytes(N, M, k);
+    if (topk != 10 || k != 10 || lds > 150 * 1024) return false;
     ensure_dyn_lds((const void *)map_term_lds_kernel<10>, (int)lds);
     MapTermArgs a;
     a.d[0] = a.d[1] = MapTermSide{verts12, verts2, idx11, idx22, pi_val, pi_idx, N, M, map_term_blocks(N, k), partial};
@@ -1142,9 +1199,8 @@ bool launch_map_term_lds(const float *verts12, const float *verts2, const int32_
 bool launch_map_term_lds_pair(const float *verts12, const float *verts21, const float *verts1, const float *verts2, const int32_t *idx11,
                               const int32_t *idx22, const float *val12, const int32_t *pidx12, const float *val21, const int32_t *pidx21, int B,
                               int N, int M, int k, int topk, double *partial12, double *partial21, hipStream_t s) {
-    auto need = [&](int m) { return (((size_t)m * 3 * sizeof(float) + 15) / 16) * 16 + (size_t)m * k * sizeof(int32_t); };
-    const size_t lds = need(N) > need(M) ? need(N) : need(M);
-    if (topk != 10 || lds > 150 * 1024) return false;
+    const size_t l0 = map_term_lds_bytes(N, M, k), l1 = map_term_lds_bytes(M, N, k), lds = l0 > l1 ? l0 : l1;
+    if (topk != 10 || k != 10 || lds > 150 * 1024) return false;
     ensure_dyn_lds((const void *)map_term_lds_kernel<10>, (int)lds);
     MapTermArgs a;
     a.d[0] = MapTermSide{verts12, verts2, idx11, idx22, val12, pidx12, N, M, map_term_blocks(N, k), partial12};

@@ -19,7 +19,7 @@ int launch_map_term(const float *verts12, const float *verts2, const int32_t *id
                     const int32_t *pi_idx, int B, int N, int M, int k, int topk, double *partial, hipStream_t s, float *resid = nullptr);
 bool launch_map_term_lds(const float *verts12, const float *verts2, const int32_t *idx11, const int32_t *idx22, const float *pi_val,
                          const int32_t *pi_idx, int B, int N, int M, int k, int topk, double *partial, hipStream_t s);
-bool map_term_lds_applies(int M, int k);
+bool map_term_lds_applies(int N, int M, int k);
 bool launch_map_term_lds_pair(const float *verts12, const float *verts21, const float *verts1, const float *verts2, const int32_t *idx11,
                               const int32_t *idx22, const float *val12, const int32_t *pidx12, const float *val21, const int32_t *pidx21, int B,
                               int N, int M, int k, int topk, double *partial12, double *partial21, hipStream_t s);
@@ -387,7 +387,7 @@ static int pair_fwd_impl(const float *feat1, const float *feat2, const float *ve
         (void)hipStreamWaitEvent(cx->side, cx->ev_fork, 0);
         s = cx->side;
     }
-    const bool map_lds = map_term_lds_applies(N, 10) && map_term_lds_applies(M, 10);   // (the target side in LDS: no neighbour tables)
+    const bool map_lds = map_term_lds_applies(N, M, 10) && map_term_lds_applies(M, N, 10);   // (the target side in LDS: no neighbour tables)
     bool pooled = false;   // the pooled features were made on the second helper stream
     if (!reuse_geometry)
         pooled = pair_geometry(cx, s, w, verts1, verts2, B, N, M, start1, start2, both, with_map && !map_lds, feat1, feat2, conv_w, conv_b);
@@ -539,7 +539,7 @@ DVM_EXPORT int dvm_pair_geometry_f32(const float *verts1, const float *verts2, i
     hipStream_t s = (hipStream_t)stream;
     PairCtx *cx = g_pair_overlap != 0 ? pair_ctx_find(s) : nullptr;
     const bool both = (N == M) && contiguous_sides(B, N);
-    const bool map_lds = map_term_lds_applies(N, 10) && map_term_lds_applies(M, 10);
+    const bool map_lds = map_term_lds_applies(N, M, 10) && map_term_lds_applies(M, N, 10);
     pair_geometry(cx, s, w, verts1, verts2, B, N, M, start1, start2, both, with_map && !map_lds, nullptr, nullptr, nullptr, nullptr);
     DVM_CHECK_LAUNCH("pair_geometry");
     return DVM_OK;
