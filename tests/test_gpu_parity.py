@@ -437,6 +437,47 @@ def test_pair_pipeline_equals_pair_forward(ops, golden, shape, with_map):
                     assert torch.equal(got[t][side][k], ref[t][side][k]), (order, t, side, k)
 
 
+def test_pair_geometry_call_without_helper_streams(ops, golden):
+    """dvm_pair_geometry_f32 + dvm_pair_fwd_cached_f32(reuse_geometry = 1) straight through the C ABI on a stream that has NO
+    dvm_pair_init context (everything on the caller's stream), and with the helper-stream overlap switched off: same bits as the
+    one-call form; a workspace that is too small is refused before any launch."""
+    import ctypes
+    from dvm import _lib
+    lib = _lib.load()
+    B, N, M = 2, 384, 384
+    w = golden("deformer_scape_r_weights")
+    wl = ops.deformer_weight_list(w, "cuda")
+    f1, f2, v1, v2, s1 = _pair_inputs(B, N, M, 4711)
+    f1, f2, v1, v2, s1 = (x.cuda() for x in (f1, f2, v1, v2, s1))
+    s2 = torch.tensor([3, 300], dtype=torch.int32).cuda()
+    ref12, ref21 = ops.pair_forward(wl, f1, f2, v1, v2, 70.0, s1, s2)
+    torch.cuda.synchronize()
+    nb = lib.dvm_pair_workspace_bytes(B, N, M)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    assert lib.dvm_pair_geometry_f32(P(v1), P(v2), B, N, M, P(s1), P(s2), 1, None, 0, None) == -3      # DVM_ENOSPACE
+    for overlap in (1, 0):
+        prev = lib.dvm_pair_set_overlap(overlap)
+        try:
+            st = torch.cuda.Stream()          # (never passed to dvm_pair_init)
+            ws = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+            out = [dict(warped=torch.empty(B, n, 3, device="cuda"), verts12=torch.empty(B, n, 3, device="cuda"),
+                        T12=torch.empty(B, n, dtype=torch.int32, device="cuda"), losses=torch.empty(B, 6, device="cuda")) for n in (N, M)]
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                raw = ctypes.c_void_p(st.cuda_stream)
+                ops.check(lib.dvm_pair_geometry_f32(P(v1), P(v2), B, N, M, P(s1), P(s2), 1, P(ws), nb, raw), "dvm_pair_geometry_f32")
+                ops.check(lib.dvm_pair_fwd_cached_f32(P(f1), P(f2), P(v1), P(v2), B, N, M, ops.neg_alpha_f32(70.0), P(s1), P(s2), *[P(x) for x in wl], 1,
+                                                      P(out[0]["warped"]), P(out[0]["verts12"]), P(out[0]["T12"]), P(out[0]["losses"]),
+                                                      P(out[1]["warped"]), P(out[1]["verts12"]), P(out[1]["T12"]), P(out[1]["losses"]), P(ws), nb, 1, raw),
+                          "dvm_pair_fwd_cached_f32")
+            st.synchronize()
+        finally:
+            lib.dvm_pair_set_overlap(prev)
+        for o, r in zip(out, (ref12, ref21)):
+            for k in r:
+                assert torch.equal(o[k], r[k]), (overlap, k)
+
+
 def test_pair_pipeline_rejects_other_shapes(ops, golden):
     from dvm._lib import DvmError
     wl = ops.deformer_weight_list(golden("deformer_scape_r_weights"), "cuda")
