@@ -1182,6 +1182,19 @@ class PairPipeline:
         self.n = 0
         self.schedule = "geometry first" if 2 * self.B <= check_cus() else "features first"
 
+    def close(self):
+        """The current stream waits for whatever the geometry stream still has in flight (a prefetch that no forward() consumed writes
+        into a workspace this object owns: its memory must not return to the allocator before that)."""
+        if getattr(self, "geo", None) is not None:
+            torch.cuda.current_stream(self.dev).wait_stream(self.geo)
+            self.geo = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
     def prefetch(self, verts1, verts2, start1, start2, ready=None):
         """Enqueue stage 1 for a batch; -> ticket for forward().  ready: a torch.cuda.Event behind which the coordinates and starts are
         valid (e.g. recorded when the batch was loaded); None = behind everything enqueued on the current stream so far — which, called
