@@ -153,6 +153,8 @@ def test_bench_single_gpu_line_and_check():
     res = _bench_line([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--pairs", "8", "--cpu-sample", "4"])
     assert res["n_gpus"] == 1 and res["checked_pairs"] == 4 and res["check"]["ok"]
     assert res["cpu_baseline"]["kind"] == "port" and res["cpu_baseline"]["value"] > 0 and "timed batch" in res["cpu_baseline"]["sample"]
+    aten = res["cpu_baseline"]["aten"]      # the same pairs in the reference's dense ATen / MKL formulation
+    assert aten["value"] > 0 and aten["losses_agree_with_c_oracle"] and aten["cores"] >= 1
     names = [k["kernel"] for k in res["roofline"]["kernels"]]
     assert "softcorr_refine_kernel" in names and "grid_chamfer_kernel" in names
     assert "mlp_f16x2p_kernel" in names or "mlp_f16x2_kernel" in names      # (the MLP slot reports the kernel the launch ran)
