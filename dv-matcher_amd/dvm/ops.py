@@ -1146,7 +1146,7 @@ def pair_forward(wl, feat1, feat2, verts1, verts2, alpha, start1, start2, with_m
     return o12, o21
 
 
-def check_cus():
+def _cu_count():
     """Compute units of the current device."""
     return torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
 
@@ -1180,7 +1180,8 @@ class PairPipeline:
         with torch.cuda.stream(self.geo):
             check(lib.dvm_pair_init(_stream()), "dvm_pair_init")      # the geometry stream's own helper stream / events
         self.n = 0
-        self.schedule = "geometry first" if 2 * self.B <= check_cus() else "features first"
+        self.slot_gen = [0] * depth          # which prefetch last wrote the workspace (a ticket is valid while it is the one)
+        self.schedule = "geometry first" if 2 * self.B <= _cu_count() else "features first"
 
     def close(self):
         """The current stream waits for whatever the geometry stream still has in flight (a prefetch that no forward() consumed writes
@@ -1204,8 +1205,11 @@ class PairPipeline:
         if tuple(verts1.shape) != (self.B, self.N, 3) or tuple(verts2.shape) != (self.B, self.M, 3):
             raise DvmError("PairPipeline.prefetch: coordinates %s / %s, built for B=%d N=%d M=%d"
                            % (tuple(verts1.shape), tuple(verts2.shape), self.B, self.N, self.M))
+        if self.geo is None:
+            raise DvmError("PairPipeline.prefetch: the pipeline was closed")
         slot = self.n % len(self.ws)
         self.n += 1
+        self.slot_gen[slot] = self.n
         cur = torch.cuda.current_stream(self.dev)
         if ready is None:
             self.geo.wait_stream(cur)                   # the coordinates were produced on the caller's stream
@@ -1218,7 +1222,7 @@ class PairPipeline:
                                                     int(self.with_map), _p(self.ws[slot]), self.nb, _stream()), "dvm_pair_geometry_f32")
             ready = torch.cuda.Event()
             ready.record()
-        return dict(slot=slot, ready=ready, verts1=verts1, verts2=verts2, start1=start1, start2=start2)
+        return dict(slot=slot, gen=self.n, ready=ready, verts1=verts1, verts2=verts2, start1=start1, start2=start2)
 
     def forward(self, ticket, feat1, feat2, alpha, out=None):
         """Stage 2 of the ticket's batch on the current stream -> (out12, out21) as pair_forward."""
@@ -1234,11 +1238,14 @@ class PairPipeline:
                         verts12=torch.empty(B, n, 3, dtype=torch.float32, device=dev),
                         T12=torch.empty(B, n, dtype=torch.int32, device=dev),
                         losses=torch.empty(B, 6, dtype=torch.float32, device=dev))
+        slot = ticket["slot"]
+        if self.slot_gen[slot] != ticket["gen"]:
+            raise DvmError("PairPipeline.forward: this ticket's workspace has been rewritten by a later prefetch (%d workspaces rotate: "
+                           "consume a ticket before %d further prefetches)" % (len(self.ws), len(self.ws)))
         o12, o21 = out if out is not None else (alloc(N), alloc(M))
         _ensure_pair_ctx(dev)
         cur = torch.cuda.current_stream(dev)
         cur.wait_event(ticket["ready"])
-        slot = ticket["slot"]
         check(lib.dvm_pair_fwd_cached_f32(_p(feat1), _p(feat2), _p(ticket["verts1"]), _p(ticket["verts2"]), B, N, M, neg_alpha_f32(alpha),
                                           _p(ticket["start1"]), _p(ticket["start2"]), *[_p(w) for w in self.wl], int(self.with_map),
                                           _p(o12["warped"]), _p(o12["verts12"]), _p(o12["T12"]), _p(o12["losses"]), _p(o21["warped"]),

@@ -485,6 +485,17 @@ def test_pair_pipeline_rejects_other_shapes(ops, golden):
     f1, f2, v1, v2, s1 = _pair_inputs(2, 256, 200, 3)
     with pytest.raises(DvmError):
         pipe.prefetch(v1.cuda(), v2.cuda(), s1.cuda(), s1.cuda())
+    # a ticket whose workspace a later prefetch has rewritten (two workspaces rotate) is refused, not silently consumed
+    f1, f2, v1, v2, s1 = (x.cuda() for x in _pair_inputs(2, 256, 256, 4))
+    stale = pipe.prefetch(v1, v2, s1, s1)
+    pipe.prefetch(v1, v2, s1, s1)
+    live = pipe.prefetch(v1, v2, s1, s1)
+    with pytest.raises(DvmError):
+        pipe.forward(stale, f1, f2, 50.0)
+    pipe.forward(live, f1, f2, 50.0)
+    pipe.close()
+    with pytest.raises(DvmError):
+        pipe.prefetch(v1, v2, s1, s1)
 
 
 def test_pair_forward_full_size_vs_oracle(ops, golden):
