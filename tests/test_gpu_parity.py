@@ -640,7 +640,7 @@ def test_rownorm2_bit_exact(ops, rows, K):
     assert np.array_equal(got, O.rownorm2(x.numpy())), (rows, K)
 
 
-@pytest.mark.parametrize("kind", ["collapsed_target", "far_queries", "duplicates"])
+@pytest.mark.parametrize("kind", ["collapsed_target", "far_queries", "duplicates", "holes"])
 def test_chamfer_grid_scan_path_equals_brute_force(ops, kind):
     """The uniform-grid Chamfer at a batch large enough to take it (B * (N + M) > 65536), on the configurations where most
     lanes of a wave fail the radius-1 certification and the kernel scans the whole target instead of walking the grid — a
@@ -654,6 +654,16 @@ def test_chamfer_grid_scan_path_equals_brute_force(ops, kind):
         b = 0.5 + 1e-3 * torch.rand(B, M, 3, generator=g)
     elif kind == "far_queries":
         a = a + torch.tensor([3.0, -2.0, 5.0])
+    elif kind == "holes":
+        # the WALK path (round 6: the radius-3 cube searched by the whole wave): a few queries per wave whose radius-1 cube holds no
+        # certifiable neighbour — the target has empty balls of ~1.5 cells radius — with the displaced points stacked onto others
+        # (exact ties on the rim: lowest index wins)
+        centres = torch.rand(B, 12, 3, generator=g)
+        inside = (torch.cdist(b, centres) < 0.12).any(-1)                     # (B, M)
+        donors = torch.randint(0, M, (B, M), generator=g)
+        b = torch.where(inside.unsqueeze(-1), torch.gather(b, 1, donors.unsqueeze(-1).expand(-1, -1, 3)), b)
+        inside2 = (torch.cdist(b, centres) < 0.12).any(-1)                    # (a donor may itself lie in a ball: push those out)
+        b = torch.where(inside2.unsqueeze(-1), b[:, :1].expand(-1, M, -1), b)
     else:
         b[:, M // 2:] = b[:, :M // 2]
     d1, d2, i1, i2 = ops.chamfer(a.cuda(), b.cuda(), want_idx=True)
