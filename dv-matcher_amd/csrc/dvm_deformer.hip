@@ -158,13 +158,28 @@ __global__ __launch_bounds__(256) void assemble_kernel(const float *__restrict__
 // PLANES: the row goes out in the plane form the persistent MLP kernel stages by LDS-DMA (dvm_mlp_f16.h: scaled by 32, split into
 // two fp16 planes, the two 128-wide blocks first) instead of as 264 floats; gate (fp32 form only): the launch does nothing unless
 // *gate != 0 — the fp32 rows are needed only by the range fallback of that kernel.
+// (round 6: blockIdx.z = direction — the pair path's two directions are one launch)
+struct AssembleSide {
+    const float *vsrc, *vcorr, *gsrc, *gtgt, *pi_val;
+    const int32_t *pi_idx, *fps;
+    int N, M, Nn;
+    float *z;
+};
+struct AssembleArgs {
+    AssembleSide d[2];
+    int topk;
+    const int *gate;
+};
 template <int TOPK, bool PLANES = false>
-__global__ __launch_bounds__(256) void assemble_pooled_kernel(const float *__restrict__ vsrc, const float *__restrict__ vcorr,
-                                                              const float *__restrict__ gsrc, const float *__restrict__ gtgt,
-                                                              const float *__restrict__ pi_val, const int32_t *__restrict__ pi_idx,
-                                                              const int32_t *__restrict__ fps, int N, int M, int Nn, int topk,
-                                                              float *__restrict__ z, const int *__restrict__ gate) {
+__global__ __launch_bounds__(256) void assemble_pooled_kernel(const AssembleArgs args) {
+    const int *__restrict__ gate = args.gate;
     if (gate && *gate == 0) return;
+    const AssembleSide &A = args.d[blockIdx.z];
+    const float *__restrict__ vsrc = A.vsrc, *__restrict__ vcorr = A.vcorr, *__restrict__ gsrc = A.gsrc, *__restrict__ gtgt = A.gtgt;
+    const float *__restrict__ pi_val = A.pi_val;
+    const int32_t *__restrict__ pi_idx = A.pi_idx, *__restrict__ fps = A.fps;
+    const int N = A.N, M = A.M, Nn = A.Nn, topk = args.topk;
+    float *__restrict__ z = A.z;
     const int b = blockIdx.y;
     const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= (long)Nn * (DF_C / 4)) return;
@@ -491,18 +506,39 @@ void launch_pool_all(const float *feat, const int32_t *idx, int B, int P, int k,
 }
 void launch_assemble_pooled(const float *vsrc, const float *vcorr, const float *gsrc, const float *gtgt, const float *pi_val,
                             const int32_t *pi_idx, const int32_t *fps, int B, int N, int M, int Nn, float *z, hipStream_t s, const int *gate) {
+    AssembleArgs a;
+    a.d[0] = a.d[1] = AssembleSide{vsrc, vcorr, gsrc, gtgt, pi_val, pi_idx, fps, N, M, Nn, z};
+    a.topk = 10, a.gate = gate;
     if (!gate) prof_begin(s, DVM_PROF_ASSEMBLE);
-    hipLaunchKernelGGL(assemble_pooled_kernel<10>, dim3((unsigned)(((long)Nn * 32 + 255) / 256), B), dim3(256), 0, s, vsrc, vcorr,
-                       gsrc, gtgt, pi_val, pi_idx, fps, N, M, Nn, 10, z, gate);
+    hipLaunchKernelGGL(assemble_pooled_kernel<10>, dim3((unsigned)(((long)Nn * 32 + 255) / 256), B, 1), dim3(256), 0, s, a);
     if (!gate) prof_end(s, DVM_PROF_ASSEMBLE);
 }
 // the rows in the plane form (zp: row (b, n) at ((b Nn + n) MH_SZ) bytes)
 void launch_assemble_pooled_planes(const float *vsrc, const float *vcorr, const float *gsrc, const float *gtgt, const float *pi_val,
                                    const int32_t *pi_idx, const int32_t *fps, int B, int N, int M, int Nn, void *zp, hipStream_t s) {
+    AssembleArgs a;
+    a.d[0] = a.d[1] = AssembleSide{vsrc, vcorr, gsrc, gtgt, pi_val, pi_idx, fps, N, M, Nn, (float *)zp};
+    a.topk = 10, a.gate = nullptr;
     prof_begin(s, DVM_PROF_ASSEMBLE);
-    hipLaunchKernelGGL((assemble_pooled_kernel<10, true>), dim3((unsigned)(((long)Nn * 32 + 255) / 256), B), dim3(256), 0, s, vsrc, vcorr,
-                       gsrc, gtgt, pi_val, pi_idx, fps, N, M, Nn, 10, (float *)zp, (const int *)nullptr);
+    hipLaunchKernelGGL((assemble_pooled_kernel<10, true>), dim3((unsigned)(((long)Nn * 32 + 255) / 256), B, 1), dim3(256), 0, s, a);
     prof_end(s, DVM_PROF_ASSEMBLE);
+}
+// both directions of the pair path in one launch: side 0 = (clouds 1 -> 2), side 1 = (2 -> 1); planes: the plane form (zp*), else the
+// fp32 rows behind `gate`
+void launch_assemble_pooled_pair(const float *verts1, const float *verts2, const float *verts12, const float *verts21, const float *g1,
+                                 const float *g2, const float *val12, const int32_t *idx12, const float *val21, const int32_t *idx21,
+                                 const int32_t *nodes1, const int32_t *nodes2, int B, int N, int M, void *z12, void *z21, bool planes,
+                                 const int *gate, hipStream_t s) {
+    AssembleArgs a;
+    a.d[0] = AssembleSide{verts1, verts12, g1, g2, val12, idx12, nodes1, N, M, N / 2, (float *)z12};
+    a.d[1] = AssembleSide{verts2, verts21, g2, g1, val21, idx21, nodes2, M, N, M / 2, (float *)z21};
+    a.topk = 10, a.gate = gate;
+    const int nn = N / 2 > M / 2 ? N / 2 : M / 2;
+    const dim3 grid((unsigned)(((long)nn * 32 + 255) / 256), B, 2);
+    if (!gate) prof_begin(s, DVM_PROF_ASSEMBLE);
+    if (planes) hipLaunchKernelGGL((assemble_pooled_kernel<10, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(assemble_pooled_kernel<10>, grid, dim3(256), 0, s, a);
+    if (!gate) prof_end(s, DVM_PROF_ASSEMBLE);
 }
 size_t mlp_bf16_pack_bytes();
 void launch_mlp_rows_bf16(const float *z, int rows, const float *W0, const float *b0, const float *W1, const float *b1,

@@ -402,13 +402,26 @@ int launch_dg_build(const float *xyz, int B, int N, const int32_t *start, int32_
 // for every (vertex, influence node) and (node, ring neighbour) pair (62 + 105 us per launch of 1024 clouds, latency-bound: 256
 // threads per cloud in the ARAP kernel); here every such lookup is an LDS read.  Same expressions in the same order; the ARAP sum
 // keeps the 256-thread accumulation and reduction tree of dg_arap_kernel (thread t: nodes t, t + 256, ...), hence the same bits.
-__global__ __launch_bounds__(256) void dg_warp_arap_fused_kernel(const float *__restrict__ xyz, int N, int Nn, const int32_t *__restrict__ nodes_idx,
-                                                                 const int32_t *__restrict__ ring, const int32_t *__restrict__ infl,
-                                                                 const float *__restrict__ weights, const float *__restrict__ def9,
-                                                                 float *__restrict__ R, float *__restrict__ T, float *__restrict__ warped,
-                                                                 float *__restrict__ arap, int arap_stride) {
+// (round 6: blockIdx.y = direction — both warps of the pair path in one launch of 2 B workgroups)
+struct WarpSide {
+    const float *xyz;
+    int N, Nn;
+    const int32_t *nodes_idx, *ring, *infl;
+    const float *weights, *def9;
+    float *R, *T, *warped, *arap;
+};
+struct WarpArgs {
+    WarpSide d[2];
+    int arap_stride;
+};
+__global__ __launch_bounds__(256) void dg_warp_arap_fused_kernel(const WarpArgs args) {
     extern __shared__ __attribute__((aligned(16))) float wa_lds[];   // gpos [Nn][3] | R [Nn][9] | T [Nn][3]
     __shared__ double red[256];
+    const WarpSide &A = args.d[blockIdx.y];
+    const float *__restrict__ xyz = A.xyz, *__restrict__ weights = A.weights, *__restrict__ def9 = A.def9;
+    const int32_t *__restrict__ nodes_idx = A.nodes_idx, *__restrict__ ring = A.ring, *__restrict__ infl = A.infl;
+    float *__restrict__ R = A.R, *__restrict__ T = A.T, *__restrict__ warped = A.warped, *__restrict__ arap = A.arap;
+    const int N = A.N, Nn = A.Nn, arap_stride = args.arap_stride;
     float *gp = wa_lds, *lr = wa_lds + (size_t)Nn * 3, *lt = lr + (size_t)Nn * 9;
     const int b = blockIdx.x;
     const float *p = xyz + (size_t)b * N * 3;
@@ -486,8 +499,10 @@ int launch_dg_warp(const float *xyz, int B, int N, const int32_t *nodes_idx, con
     const size_t lds = (size_t)Nn * 15 * sizeof(float);
     if (!sr && lds <= 150 * 1024) {   // (sr — the unused smooth-rotation term — only through the separate kernels)
         ensure_dyn_lds((const void *)dg_warp_arap_fused_kernel, (int)lds);
-        hipLaunchKernelGGL(dg_warp_arap_fused_kernel, dim3(B), dim3(256), lds, s, xyz, N, Nn, nodes_idx, ring, infl_idx, weights, def9, R, T,
-                           warped, arap, arap_stride);
+        WarpArgs a;
+        a.d[0] = a.d[1] = WarpSide{xyz, N, Nn, nodes_idx, ring, infl_idx, weights, def9, R, T, warped, arap};
+        a.arap_stride = arap_stride;
+        hipLaunchKernelGGL(dg_warp_arap_fused_kernel, dim3(B, 1), dim3(256), lds, s, a);
         return DVM_OK;
     }
     hipLaunchKernelGGL(rot6d_kernel, dim3((B * Nn + 255) / 256), dim3(256), 0, s, def9, B * Nn, R, T);
@@ -495,6 +510,23 @@ int launch_dg_warp(const float *xyz, int B, int N, const int32_t *nodes_idx, con
                        warped);
     hipLaunchKernelGGL(dg_arap_kernel, dim3(B), dim3(256), 0, s, xyz, N, Nn, nodes_idx, ring, R, T, arap, arap_stride, sr, 9);
     return DVM_OK;
+}
+
+// both directions' rot6d + warp + ARAP in one launch (the fused form only; false: the caller launches the directions one by one)
+bool launch_dg_warp_pair(const float *xyz1, const float *xyz2, int B, int N, int M, const int32_t *const nodes[2], const int32_t *const ring[2],
+                         const int32_t *const infl[2], const float *const weights[2], const float *def9_12, const float *def9_21, float *R12,
+                         float *R21, float *T12, float *T21, float *warped12, float *warped21, float *arap12, float *arap21, int arap_stride,
+                         hipStream_t s) {
+    const int nn = N / 2 > M / 2 ? N / 2 : M / 2;
+    const size_t lds = (size_t)nn * 15 * sizeof(float);
+    if (lds > 150 * 1024) return false;
+    ensure_dyn_lds((const void *)dg_warp_arap_fused_kernel, (int)lds);
+    WarpArgs a;
+    a.d[0] = WarpSide{xyz1, N, N / 2, nodes[0], ring[0], infl[0], weights[0], def9_12, R12, T12, warped12, arap12};
+    a.d[1] = WarpSide{xyz2, M, M / 2, nodes[1], ring[1], infl[1], weights[1], def9_21, R21, T21, warped21, arap21};
+    a.arap_stride = arap_stride;
+    hipLaunchKernelGGL(dg_warp_arap_fused_kernel, dim3(B, 2), dim3(256), lds, s, a);
+    return true;
 }
 
 }  // namespace dvm

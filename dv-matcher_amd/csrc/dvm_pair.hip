@@ -31,6 +31,10 @@ int launch_dg_build(const float *xyz, int B, int N, const int32_t *start, int32_
 int launch_dg_warp(const float *xyz, int B, int N, const int32_t *nodes_idx, const int32_t *ring, const int32_t *infl_idx,
                    const float *weights, const float *def9, float *R, float *T, float *warped, float *arap, int arap_stride,
                    float *sr, hipStream_t s);
+bool launch_dg_warp_pair(const float *xyz1, const float *xyz2, int B, int N, int M, const int32_t *const nodes[2], const int32_t *const ring[2],
+                         const int32_t *const infl[2], const float *const weights[2], const float *def9_12, const float *def9_21, float *R12,
+                         float *R21, float *T12, float *T21, float *warped12, float *warped21, float *arap12, float *arap21, int arap_stride,
+                         hipStream_t s);
 int launch_deformer(const float *feat1, const float *feat2, const float *verts1, const float *verts12, const int32_t *idx11,
                     const int32_t *idx22, const float *pi_val, const int32_t *pi_idx, const int32_t *fps1, int B, int N, int M,
                     int Nn, int k, int topk, const float *conv_w, const float *conv_b, const float *W0, const float *b0,
@@ -181,6 +185,10 @@ void launch_assemble_pooled(const float *vsrc, const float *vcorr, const float *
                             const int32_t *pi_idx, const int32_t *fps, int B, int N, int M, int Nn, float *z, hipStream_t s, const int *gate = nullptr);
 void launch_assemble_pooled_planes(const float *vsrc, const float *vcorr, const float *gsrc, const float *gtgt, const float *pi_val,
                                    const int32_t *pi_idx, const int32_t *fps, int B, int N, int M, int Nn, void *zp, hipStream_t s);
+void launch_assemble_pooled_pair(const float *verts1, const float *verts2, const float *verts12, const float *verts21, const float *g1,
+                                 const float *g2, const float *val12, const int32_t *idx12, const float *val21, const int32_t *idx21,
+                                 const int32_t *nodes1, const int32_t *nodes2, int B, int N, int M, void *z12, void *z21, bool planes,
+                                 const int *gate, hipStream_t s);
 size_t mlp_pack_floats();
 size_t mlp_zplane_bytes(int rows);
 size_t mlp_zplane_row_bytes();
@@ -464,19 +472,23 @@ static int pair_fwd_impl(const float *feat1, const float *feat2, const float *ve
         // the rows straight in the plane form the MLP kernel stages by LDS-DMA; the fp32 rows are written (and the bf16x3 kernel
         // runs) only if that kernel's range flag comes up: three gated launches that return at once otherwise
         char *zp21 = w.zp + (size_t)B * Nn1 * mlp_zplane_row_bytes();
-        launch_assemble_pooled_planes(verts1, verts12, w.gall[0], w.gall[1], w.pval[0], w.pidx[0], w.nodes[0], B, N, M, Nn1, w.zp, s);
-        launch_assemble_pooled_planes(verts2, verts21, w.gall[1], w.gall[0], w.pval[1], w.pidx[1], w.nodes[1], B, M, N, Nn2, zp21, s);
+        // (both directions per launch: the plane rows, and — gated — the fp32 rows)
+        launch_assemble_pooled_pair(verts1, verts2, verts12, verts21, w.gall[0], w.gall[1], w.pval[0], w.pidx[0], w.pval[1], w.pidx[1], w.nodes[0],
+                                    w.nodes[1], B, N, M, w.zp, zp21, true, nullptr, s);
         const int *flag = launch_mlp_planes(w.zp, rows, W0, b0, W1, b1, W2, b2, W3, b3, w.wp, w.def9, s);
-        launch_assemble_pooled(verts1, verts12, w.gall[0], w.gall[1], w.pval[0], w.pidx[0], w.nodes[0], B, N, M, Nn1, w.z, s, flag);
-        launch_assemble_pooled(verts2, verts21, w.gall[1], w.gall[0], w.pval[1], w.pidx[1], w.nodes[1], B, M, N, Nn2, z21, s, flag);
+        launch_assemble_pooled_pair(verts1, verts2, verts12, verts21, w.gall[0], w.gall[1], w.pval[0], w.pidx[0], w.pval[1], w.pidx[1], w.nodes[0],
+                                    w.nodes[1], B, N, M, w.z, z21, false, flag, s);
         launch_mlp_fallback(w.z, rows, W0, b0, W1, b1, W2, b2, W3, b3, w.wp, w.def9, s, flag);
     }
     // ---- ED warp + ARAP (losses[:,2])
     float *def21 = w.def9 + (size_t)B * Nn1 * 9, *R21 = w.R + (size_t)B * Nn1 * 9, *T21v = w.T + (size_t)B * Nn1 * 3;
-    launch_dg_warp(verts1, B, N, w.nodes[0], w.ring[0], w.infl[0], w.weights[0], w.def9, w.R, w.T, warped12, losses12 + 2, 6,
-                   nullptr, s);
-    launch_dg_warp(verts2, B, M, w.nodes[1], w.ring[1], w.infl[1], w.weights[1], def21, R21, T21v, warped21, losses21 + 2, 6,
-                   nullptr, s);
+    if (!launch_dg_warp_pair(verts1, verts2, B, N, M, w.nodes, w.ring, w.infl, w.weights, w.def9, def21, w.R, R21, w.T, T21v, warped12, warped21,
+                             losses12 + 2, losses21 + 2, 6, s)) {
+        launch_dg_warp(verts1, B, N, w.nodes[0], w.ring[0], w.infl[0], w.weights[0], w.def9, w.R, w.T, warped12, losses12 + 2, 6,
+                       nullptr, s);
+        launch_dg_warp(verts2, B, M, w.nodes[1], w.ring[1], w.infl[1], w.weights[1], def21, R21, T21v, warped21, losses21 + 2, 6,
+                       nullptr, s);
+    }
     // ---- the warped clouds' Chamfer terms, then the means of all eight
     {
         const float *const gx[2] = {warped12, warped21};

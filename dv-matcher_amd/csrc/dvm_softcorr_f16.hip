@@ -186,10 +186,18 @@ __global__ void spec_finalize_kernel(const int *__restrict__ slots, int *__restr
         spec[1] = scale_exp(spec[0]) != scale_exp(c) ? 1 : 0;
     }
 }
-__global__ __launch_bounds__(256) void split_planes_gated_kernel(const float *__restrict__ x, long rows, const int *__restrict__ maxbits,
-                                                                 const int *__restrict__ spec, char *__restrict__ planes) {
+// (blockIdx.y = side: both feature sets in one launch)
+struct SplitGated {
+    const float *x[2];
+    long rows[2];
+    char *planes[2];
+};
+__global__ __launch_bounds__(256) void split_planes_gated_kernel(const SplitGated a, const int *__restrict__ maxbits2, const int *__restrict__ spec) {
     if (spec[1] == 0) return;   // (the usual case: the provisional scale was the right one)
-    const float sc = pow2i(scale_exp(*maxbits));
+    const float *__restrict__ x = a.x[blockIdx.y];
+    const long rows = a.rows[blockIdx.y];
+    char *__restrict__ planes = a.planes[blockIdx.y];
+    const float sc = pow2i(scale_exp(maxbits2[blockIdx.y]));
     for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < rows * (HB_D / 8); g += (long)gridDim.x * blockDim.x) {
         const long row = g / (HB_D / 8);
         const int c = (int)(g % (HB_D / 8));
@@ -798,6 +806,19 @@ __global__ __launch_bounds__(256) void softcorr_refine_kernel(const HRArgs args)
     const long quad = ((long)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x) >> 6;
     if (quad < nquads) refine_quad<KC, COARSE, HR4W, false>(args, quad, hr_lds);
 }
+// Routed launch with the coarse screen among the candidates: ONE kernel for both list lengths — a wave takes the form of its direction's
+// route (one route per direction: wave-uniform).  As two launches, the form that did not apply still cost its whole grid of returning
+// waves IN the feature half's dependent chain: 14 us at 64 pairs, 62 us at 512 (round 6).
+template <int HR4W>
+__global__ __launch_bounds__(256) void softcorr_refine_routed_kernel(const HRArgs args) {
+    __shared__ __attribute__((aligned(16))) char hr_lds[4 * 2 * 4 * K1_KC_COARSE * 64];
+    const long nq0 = (args.rows0 + 3) / 4, nquads = nq0 + (args.rows_total - args.rows0 + 3) / 4;
+    const long quad = ((long)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x) >> 6;
+    if (quad >= nquads) return;
+    const int grp = __builtin_amdgcn_readfirstlane(quad >= nq0 ? 1 : 0);
+    if (args.route[grp * args.nb] == K1_ROUTE_COARSE) refine_quad<K1_KC_COARSE, true, HR4W, false>(args, quad, hr_lds);
+    else refine_quad<HB_KC, false, HR4W, false>(args, quad, hr_lds);
+}
 // the gate's second pass: a small grid whose waves walk the quads — it returns at once (every wave, after one scalar load per
 // direction) in the usual case that the gate sent nothing back
 template <int KC, int HR4W>
@@ -1192,8 +1213,7 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
         prep(f1, r1, (float *)n1, fuse_slots, p1);
         prep(f2, r2, (float *)n2, fuse_slots + 256, p2);
         hipLaunchKernelGGL(spec_finalize_kernel, dim3(1), dim3(128), 0, s, fuse_slots, (int *)amax_in, amax_own, spec);
-        hipLaunchKernelGGL(split_planes_gated_kernel, dim3(2048), dim3(256), 0, s, f1, r1, amax, spec, p1);
-        hipLaunchKernelGGL(split_planes_gated_kernel, dim3(2048), dim3(256), 0, s, f2, r2, amax + 1, spec, p2);
+        hipLaunchKernelGGL(split_planes_gated_kernel, dim3(1024, 2), dim3(256), 0, s, SplitGated{{f1, f2}, {r1, r2}, {p1, p2}}, amax, spec);
     } else {
         if (!amax_in) {
             hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, s, f1, r1 * 32, amax_own);
@@ -1276,8 +1296,12 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
         const dim3 grid((unsigned)((hr_quads(r) * 64 + 255) / 256));
         const bool coarse = routed ? havec : fixed == K1_ROUTE_COARSE;
         // (window 3: 112 VGPRs, 4 waves per SIMD, 1.11 ms per launch of the bench; window 2: 96, 5 waves, 1.17 ms)
-        if (coarse) hipLaunchKernelGGL((softcorr_refine_kernel<K1_KC_COARSE, true, 3>), grid, dim3(256), 0, s, r);
-        if (routed || fixed != K1_ROUTE_COARSE) hipLaunchKernelGGL((softcorr_refine_kernel<HB_KC, false, 3>), grid, dim3(256), 0, s, r);
+        if (routed && coarse) {
+            hipLaunchKernelGGL((softcorr_refine_routed_kernel<3>), grid, dim3(256), 0, s, r);
+        } else {
+            if (coarse) hipLaunchKernelGGL((softcorr_refine_kernel<K1_KC_COARSE, true, 3>), grid, dim3(256), 0, s, r);
+            if (routed || fixed != K1_ROUTE_COARSE) hipLaunchKernelGGL((softcorr_refine_kernel<HB_KC, false, 3>), grid, dim3(256), 0, s, r);
+        }
         if (coarse) {   // the gate and its second pass (k1_gate_kernel)
             K1GateArgs ga{routed ? route : nullptr, route2, {flag[0], both ? flag[1] : flag[0]}, {r1, r2}, both ? 2 : 1, B};
             hipLaunchKernelGGL(k1_gate_kernel, dim3(1), dim3(256), 0, s, ga);
