@@ -104,10 +104,21 @@ __global__ __launch_bounds__(256) void sample_absmax_kernel(const float *__restr
 // instructions per row pair.  (The same order on the 8-columns-per-lane layout costs 48 DPP additions per row and lane: built
 // first, 355 us per launch.)
 constexpr int RS_LROW = 160;          // floats between rows in LDS
+struct RownormSplit {   // blockIdx.y = side (both feature sets in one launch: round 6)
+    const float *x[2];
+    long rows[2];
+    float *nrm[2];
+    int *slots[2];
+    char *planes[2];
+};
 template <int RS_ROWS>   // rows per 16-lane group and trip (all requested before the first is used); 2 ships
-__global__ __launch_bounds__(256) void rownorm_split_kernel(const float *__restrict__ x, long rows, float *__restrict__ nrm,
-                                                            int *__restrict__ absmax_slots, const int *__restrict__ spec,
-                                                            char *__restrict__ planes) {
+__global__ __launch_bounds__(256) void rownorm_split_kernel(const RownormSplit a, const int *__restrict__ spec) {
+    const float *__restrict__ x = a.x[blockIdx.y];
+    const long rows = a.rows[blockIdx.y];
+    if ((long)blockIdx.x * (16 * RS_ROWS) >= rows) return;   // (the grid spans the larger side)
+    float *__restrict__ nrm = a.nrm[blockIdx.y];
+    int *__restrict__ absmax_slots = a.slots[blockIdx.y];
+    char *__restrict__ planes = a.planes[blockIdx.y];
     __shared__ __attribute__((aligned(16))) float xs_all[4][4 * RS_ROWS * RS_LROW];
     const int lane = threadIdx.x & 63, l16 = lane & 15, g4 = lane >> 4;
     float *xs = xs_all[threadIdx.x >> 6];
@@ -207,20 +218,21 @@ __global__ __launch_bounds__(256) void split_planes_gated_kernel(const SplitGate
 }
 
 // ---------------------------------------------------------------- pass A
-template <bool LEAN>
-__global__ __launch_bounds__(HB_THREADS, 2) void softcorr_sweep_f16_kernel(const HBArgs args) {
-    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+// One workgroup's share of the sweep: logical block `block` of `nblocks` (the kernels below pass their hardware block number, or walk
+// several blocks).  CHECK_ROUTE: return at once unless the block's (direction, pair) is routed to this form.
+template <bool LEAN, bool CHECK_ROUTE = true>
+__device__ __forceinline__ void sweep_f16_block(const HBArgs &args, int block, int nblocks, char *smem_b) {
     char *const ktile0 = smem_b;                                             // [2][HB_KT][512], 16-B chunks XOR-swizzled
     float *const knorm0 = (float *)(smem_b + (size_t)2 * HB_KT * HB_ROWB);   // [2][HB_KT]
     float *const stage = knorm0 + 2 * HB_KT + (threadIdx.x >> 6) * HB_STAGE + (threadIdx.x & 63);
 
-    int lid = xcd_remap(blockIdx.x, gridDim.x);
+    int lid = xcd_remap(block, nblocks);
     const int grp = lid >= args.blocks0 ? 1 : 0;
     lid -= grp ? args.blocks0 : 0;
     const HBGroup &G = args.g[grp];
     const int N = G.N, M = G.M;
     const int b = lid / G.tiles, qt = lid % G.tiles;
-    if (args.route && args.route[grp * args.nb + b] != (LEAN ? K1_ROUTE_LEAN : K1_ROUTE_FULL)) return;   // another kernel's pair
+    if (CHECK_ROUTE && args.route && args.route[grp * args.nb + b] != (LEAN ? K1_ROUTE_LEAN : K1_ROUTE_FULL)) return;   // another kernel's pair
     const float neg_alpha = args.neg_alpha;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r32 = lane & 31, h = lane >> 5;
@@ -415,6 +427,34 @@ __global__ __launch_bounds__(HB_THREADS, 2) void softcorr_sweep_f16_kernel(const
         }
         G.lsum[row * 2] = l;
         G.lsum[row * 2 + 1] = cref;
+    }
+}
+template <bool LEAN>
+__global__ __launch_bounds__(HB_THREADS, 2) void softcorr_sweep_f16_kernel(const HBArgs args) {
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+    sweep_f16_block<LEAN>(args, blockIdx.x, gridDim.x, smem_b);
+}
+// Routed first pass (round 6): ONE launch for the lean and the full first form — a workgroup takes the form its (direction, pair) is
+// routed to, and returns at once if that is the coarse screen's.  (As two launches, each form cost its whole grid of returning
+// workgroups — two per compute unit at a time, they need the form's LDS — in the feature half's dependent chain.)
+__global__ __launch_bounds__(HB_THREADS, 2) void softcorr_sweep_f16_routed_kernel(const HBArgs args) {
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+    int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int grp = lid >= args.blocks0 ? 1 : 0;
+    lid -= grp ? args.blocks0 : 0;
+    const int route = args.route[grp * args.nb + lid / args.g[grp].tiles];
+    if (route == K1_ROUTE_LEAN) sweep_f16_block<true, false>(args, blockIdx.x, gridDim.x, smem_b);
+    else if (route == K1_ROUTE_FULL) sweep_f16_block<false, false>(args, blockIdx.x, gridDim.x, smem_b);
+}
+// The gate's second pass (lean form): a SMALL grid whose workgroups walk the logical blocks — in the usual case that the gate sent
+// nothing back every workgroup returns after two scalar loads (the full grid cost 15 us at 64 pairs, 40 us at 512, for nothing).
+__global__ __launch_bounds__(HB_THREADS, 2) void softcorr_sweep_f16_gated_kernel(const HBArgs args, int nblocks) {
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+    const bool on0 = args.route[0] == K1_ROUTE_LEAN, on1 = nblocks > args.blocks0 && args.route[args.nb] == K1_ROUTE_LEAN;
+    if (!on0 && !on1) return;
+    for (int vb = blockIdx.x; vb < nblocks; vb += gridDim.x) {
+        sweep_f16_block<true>(args, vb, nblocks, smem_b);
+        __syncthreads();   // (the next block re-stages the LDS tiles)
     }
 }
 
@@ -1178,10 +1218,11 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
     // in the same pass that writes the fp16 planes (rownorm_split_kernel); fuse_slots = 512 ints of scratch
     const bool both = val21 != nullptr;
     Arena ar(ws, ws_bytes);
-    char *p1 = ar.take<char>((size_t)B * N * HB_ROWB), *p2 = ar.take<char>((size_t)B * M * HB_ROWB);
+    // (the small zero-initialised slots first: in the pair path they follow the caller's absmax slots directly — one fill for all)
     float *nmax1 = ar.take<float>(B), *nmax2 = ar.take<float>(B);
     int *amax_own = ar.take<int>(2);  // bit patterns of max|f1|, max|f2| when the caller did not fuse them into the norms
     int *spec = ar.take<int>(2);      // fused preparation: [0] absmax of the sampled rows (provisional scale), [1] planes must be re-made
+    char *p1 = ar.take<char>((size_t)B * N * HB_ROWB), *p2 = ar.take<char>((size_t)B * M * HB_ROWB);
     const int *amax = amax_own;   // ONE scale for both sides (the larger absmax), see common_absmax_kernel
     const int Np = (N + HB_KT - 1) / HB_KT * HB_KT, Mp = (M + HB_KT - 1) / HB_KT * HB_KT;
     float *n1p = ar.take<float>((size_t)B * Np), *n2p = ar.take<float>((size_t)B * Mp);
@@ -1202,16 +1243,21 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
         return DVM_ENOSPACE;
     }
     const long r1 = (long)B * N, r2 = (long)B * M;
-    // nmax1, nmax2, amax_own and spec lie back to back in the arena (256-byte slots): one fill
-    (void)hipMemsetAsync(nmax1, 0, (size_t)((char *)spec - (char *)nmax1) + 2 * sizeof(int), s);
+    // nmax1, nmax2, amax_own and spec lie back to back in the arena (256-byte slots), and in the pair path right behind the caller's
+    // 514 absmax slots: one fill
+    if (fuse_slots && (char *)fuse_slots + align_up(514 * sizeof(int)) == (char *)nmax1) {
+        (void)hipMemsetAsync(fuse_slots, 0, (size_t)((char *)spec - (char *)fuse_slots) + 2 * sizeof(int), s);
+    } else {
+        (void)hipMemsetAsync(nmax1, 0, (size_t)((char *)spec - (char *)nmax1) + 2 * sizeof(int), s);
+        if (fuse_slots) (void)hipMemsetAsync(fuse_slots, 0, 512 * sizeof(int), s);
+    }
     if (fuse_slots) {
-        (void)hipMemsetAsync(fuse_slots, 0, 512 * sizeof(int), s);
         hipLaunchKernelGGL(sample_absmax_kernel, dim3(256), dim3(256), 0, s, f1, r1, f2, r2, spec);
-        auto prep = [&](const float *f, long r, float *nn, int *slots, char *pp) {   // 2 rows per 16-lane group and trip (1: 315 us, 2: 296, 4: 365)
-            hipLaunchKernelGGL(rownorm_split_kernel<2>, dim3((unsigned)((r + 31) / 32)), dim3(256), 0, s, f, r, nn, slots, spec, pp);
-        };
-        prep(f1, r1, (float *)n1, fuse_slots, p1);
-        prep(f2, r2, (float *)n2, fuse_slots + 256, p2);
+        {   // 2 rows per 16-lane group and trip (1: 315 us, 2: 296, 4: 365): a workgroup = 4 waves x 8 rows
+            const long rmax = r1 > r2 ? r1 : r2;
+            hipLaunchKernelGGL(rownorm_split_kernel<2>, dim3((unsigned)((rmax + 31) / 32), 2), dim3(256), 0, s,
+                               RownormSplit{{f1, f2}, {r1, r2}, {(float *)n1, (float *)n2}, {fuse_slots, fuse_slots + 256}, {p1, p2}}, spec);
+        }
         hipLaunchKernelGGL(spec_finalize_kernel, dim3(1), dim3(128), 0, s, fuse_slots, (int *)amax_in, amax_own, spec);
         hipLaunchKernelGGL(split_planes_gated_kernel, dim3(1024, 2), dim3(256), 0, s, SplitGated{{f1, f2}, {r1, r2}, {p1, p2}}, amax, spec);
     } else {
@@ -1269,11 +1315,13 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
     prof_begin(s);
     // (routed: all three kernels are launched and a workgroup whose pair belongs to another one returns at once)
     if (routed ? havec : fixed == K1_ROUTE_COARSE) launch_coarse(a, nf2, nf1, amax, blocks, s);
-    if (routed || fixed == K1_ROUTE_LEAN) {
+    if (routed) {
+        ensure_dyn_lds((const void *)softcorr_sweep_f16_routed_kernel, (int)HB_LDS_BYTES);
+        hipLaunchKernelGGL(softcorr_sweep_f16_routed_kernel, dim3(blocks), dim3(HB_THREADS), HB_LDS_BYTES, s, a);
+    } else if (fixed == K1_ROUTE_LEAN) {
         ensure_dyn_lds((const void *)softcorr_sweep_f16_kernel<true>, (int)HB_LDS_BYTES);
         hipLaunchKernelGGL(softcorr_sweep_f16_kernel<true>, dim3(blocks), dim3(HB_THREADS), HB_LDS_BYTES, s, a);
-    }
-    if (routed || fixed == K1_ROUTE_FULL) {
+    } else if (fixed == K1_ROUTE_FULL) {
         ensure_dyn_lds((const void *)softcorr_sweep_f16_kernel<false>, (int)HB_LDS_BYTES);
         hipLaunchKernelGGL(softcorr_sweep_f16_kernel<false>, dim3(blocks), dim3(HB_THREADS), HB_LDS_BYTES, s, a);
     }
@@ -1306,8 +1354,8 @@ int launch_softcorr_f16(const float *f1, const float *f2, const float *n1, const
             K1GateArgs ga{routed ? route : nullptr, route2, {flag[0], both ? flag[1] : flag[0]}, {r1, r2}, both ? 2 : 1, B};
             hipLaunchKernelGGL(k1_gate_kernel, dim3(1), dim3(256), 0, s, ga);
             a.route = route2, r.route = route2;
-            ensure_dyn_lds((const void *)softcorr_sweep_f16_kernel<true>, (int)HB_LDS_BYTES);
-            hipLaunchKernelGGL(softcorr_sweep_f16_kernel<true>, dim3(blocks), dim3(HB_THREADS), HB_LDS_BYTES, s, a);
+            ensure_dyn_lds((const void *)softcorr_sweep_f16_gated_kernel, (int)HB_LDS_BYTES);
+            hipLaunchKernelGGL(softcorr_sweep_f16_gated_kernel, dim3(blocks < 2048 ? blocks : 2048), dim3(HB_THREADS), HB_LDS_BYTES, s, a, blocks);
             hipLaunchKernelGGL((softcorr_refine_gated_kernel<HB_KC, 3>), dim3(4096), dim3(256), 0, s, r);
         }
     }
